@@ -1,0 +1,212 @@
+/* libladder_hip.so -- C ABI of the MI355X (gfx950) LaDDer training-path kernels.
+ *
+ * The reference (lin-shuyu/ladder-latent-data-distribution-modelling) has NO FFI / plugin
+ * registry: its hot path is a TF-1.15 graph evaluated by `sess.run(fetches, feed_dict)`
+ * (codes/base.py:587-594, 603-605, 615-622, 639).  Each export below replaces one family of
+ * TF/TFP op call sites of that graph; the call site it replaces is cited per function
+ * (paths relative to the reference checkout).  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions (all exports):
+ *   - extern "C", returns int: 0 = LADDER_OK, <0 = LADDER_E_*.  Never throws, never
+ *     allocates, never synchronises the device, keeps no global mutable state.
+ *   - every pointer is CALLER-OWNED DEVICE memory, fp32 unless stated, dense row-major,
+ *     activations NHWC, conv filters HWIO, dense weights [in,out] (the reference's
+ *     checkpoint layouts).  16-byte alignment of tensor base pointers is required.
+ *   - `stream` is the HIP stream the work is enqueued on (pass the caller's current stream).
+ *   - scratch memory is passed in explicitly (`ws`, `ws_bytes`); the matching
+ *     `*_workspace_bytes` query returns the requirement.  Reductions use a fixed order
+ *     (no float atomics) so results are bit-reproducible for a given shape.
+ */
+#ifndef LADDER_HIP_H
+#define LADDER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* ladder_stream_t; /* == hipStream_t */
+
+enum { LADDER_OK = 0, LADDER_E_SHAPE = -1, LADDER_E_ALIGN = -2, LADDER_E_WORKSPACE = -3, LADDER_E_LAUNCH = -4 };
+enum { LADDER_ACT_NONE = 0, LADDER_ACT_LEAKY = 1 /* alpha 0.2 */, LADDER_ACT_RELU = 2, LADDER_ACT_TANH = 3 };
+
+/* Build/ABI identification. */
+int ladder_abi_version(void);
+
+/* ---------------------------------------------------------------- N1: tf.layers.conv2d
+ * codes/models.py:51-71,115-148,203-229,273-315,398-460,514-585.
+ * y[n,ho,wo,co] = act(b[co] + sum_{r,s,ci} x[n, ho*stride+r-pad_t, wo*stride+s-pad_l, ci] * w[r,s,ci,co])
+ * (out-of-range taps read 0).  Explicit top/left padding expresses TF SAME (asymmetric) and VALID. */
+int ladder_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
+                      int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                      int KH, int KW, int stride, int pad_t, int pad_l, int act, ladder_stream_t stream);
+/* wT[KH-1-r][KW-1-s][co][ci] = w[r][s][ci][co]: the filter bank bwd_data consumes. */
+int ladder_filter_flip_transpose(const float* w, float* wT, int KH, int KW, int Cin, int Cout, ladder_stream_t stream);
+/* dx[n,hi,wi,ci] = sum dy[n,ho,wo,co] * w[r,s,ci,co] over {hi = ho*stride + r - pad_t, ...}; wT from above.
+ * (N,H,W,Cin) describe dx, (Ho,Wo,Cout) describe dy. */
+int ladder_conv2d_bwd_data(const float* dy, const float* wT, float* dx,
+                           int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                           int KH, int KW, int stride, int pad_t, int pad_l, ladder_stream_t stream);
+size_t ladder_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW);
+/* dw[r,s,ci,co] = sum_{n,ho,wo} x[...] * dy[n,ho,wo,co];  db[co] = sum dy (db may be NULL). */
+int ladder_conv2d_bwd_filter(const float* x, const float* dy, float* dw, float* db,
+                             int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                             int KH, int KW, int stride, int pad_t, int pad_l,
+                             void* ws, size_t ws_bytes, ladder_stream_t stream);
+
+/* ---------------------------------------------------------------- N2: tf.layers.dense
+ * codes/models.py:73-95,109,231-253,267,478-488,501-510; codes/modules.py:8; codes/base.py:145-186.
+ * y[M,N] = act(x[M,K] @ w[K,N] + b).  MFMA-f32 (v_mfma_f32_32x32x2_f32). */
+int ladder_dense_fwd(const float* x, const float* w, const float* bias, float* y,
+                     int M, int K, int N, int act, ladder_stream_t stream);
+/* dx[M,K] = dy[M,N] @ w^T, wT = ladder_filter_flip_transpose(w, 1,1,K,N) i.e. [N,K]. */
+int ladder_dense_bwd_data(const float* dy, const float* wT, float* dx, int M, int K, int N, ladder_stream_t stream);
+size_t ladder_dense_bwd_weight_workspace_bytes(int M, int K, int N);
+int ladder_dense_bwd_weight(const float* x, const float* dy, float* dw, float* db,
+                            int M, int K, int N, void* ws, size_t ws_bytes, ladder_stream_t stream);
+
+/* ---------------------------------------------------------------- N12: activations (backward)
+ * dx = dy * act'(y) evaluated from the activation OUTPUT y (leaky/relu/tanh).  In-place (dx==dy) allowed. */
+int ladder_act_bwd(const float* dy, const float* y, float* dx, size_t n, int act, ladder_stream_t stream);
+
+/* ---------------------------------------------------------------- N3: tf.layers.batch_normalization(training=True)
+ * codes/models.py:398-460 (is_training is the constant True, models.py:471).  Two-phase so that the host can
+ * all-reduce the 2C statistics between the phases (data-parallel: statistics of the GLOBAL batch).
+ * x is [rows, C] with rows = N*H*W.  eps = 1e-3 in the reference (TF default). */
+size_t ladder_bn_workspace_bytes(size_t rows, int C);
+/* sums[0:C] = sum_rows x ; sums[C:2C] = sum_rows x^2   (fixed-order two-stage, final stage in fp64) */
+int ladder_bn_fwd_stats(const float* x, float* sums /*[2C]*/, size_t rows, int C,
+                        void* ws, size_t ws_bytes, ladder_stream_t stream);
+/* mean = sums[c]/count ; var = sums[C+c]/count - mean^2 (biased) ; y = act(gamma*(x-mean)*rsqrt(var+eps)+beta).
+ * Writes mean_rstd[0:C]=mean, [C:2C]=rstd.  `count` = GLOBAL row count (after the all-reduce). */
+int ladder_bn_fwd_apply(const float* x, const float* sums, double count,
+                        const float* gamma, const float* beta, float* y, float* mean_rstd,
+                        size_t rows, int C, float eps, int act, ladder_stream_t stream);
+/* dp = dy*act'(pre), pre = gamma*xhat+beta ;  dsums[0:C] = sum dp, dsums[C:2C] = sum dp*xhat. */
+int ladder_bn_bwd_stats(const float* dy, const float* x, const float* mean_rstd, const float* gamma,
+                        const float* beta, float* dsums /*[2C]*/, size_t rows, int C, int act,
+                        void* ws, size_t ws_bytes, ladder_stream_t stream);
+/* dx = gamma*rstd*(dp - dsums[c]/count - xhat*dsums[C+c]/count); dgamma = dsums[C+c]; dbeta = dsums[c].
+ * dx may be NULL (first layer), dgamma/dbeta may be NULL. */
+int ladder_bn_bwd_apply(const float* dy, const float* x, const float* mean_rstd, const float* gamma,
+                        const float* beta, const float* dsums, double count, float* dx,
+                        float* dgamma, float* dbeta, size_t rows, int C, int act, ladder_stream_t stream);
+
+/* ---------------------------------------------------------------- N4+N5+N12: instance_norm + style_mod + leaky
+ * codes/models.py:522-528,531-537,547-554,564-571; codes/modules.py:6-10.
+ * x [N,HW,C]; style [N,2C] (raw output of the StyleMod dense: [:,0:C] scale-1, [:,C:2C] shift).
+ * y = act(((x-mean)*rstd) * (style0+1) + style1), moments over HW per (n,c), biased var, eps. */
+int ladder_in_style_fwd(const float* x, const float* style, float* y, float* mean_rstd /*[N,2C]*/,
+                        int N, int HW, int C, float eps, int act, ladder_stream_t stream);
+int ladder_in_style_bwd(const float* dy, const float* x, const float* style, const float* mean_rstd,
+                        float* dx, float* dstyle /*[N,2C]*/, int N, int HW, int C, int act, ladder_stream_t stream);
+
+/* ---------------------------------------------------------------- N6: tf.image.resize_images (TF1 legacy bilinear)
+ * codes/models.py:519,538,544,555,561,572,578.  align_corners=False, half_pixel_centers=False;
+ * OH/H and OW/W must be integers (1->2, 2->8, 8->16, ... in the reference). */
+int ladder_resize_bilinear_fwd(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, ladder_stream_t stream);
+int ladder_resize_bilinear_bwd(const float* dy, float* dx, int N, int H, int W, int C, int OH, int OW, ladder_stream_t stream);
+
+/* ---------------------------------------------------------------- N7: depth_to_space (DCR) / tf.pad SYMMETRIC
+ * codes/models.py:48-50,113,122,131,140,200-202,271,...,307.  inverse!=0 gives space_to_depth (the backward). */
+int ladder_depth_to_space(const float* x, float* y, int N, int H, int W, int C, int r, int inverse, ladder_stream_t stream);
+int ladder_pad_symmetric(const float* x, float* y, int N, int H, int W, int C, int p, ladder_stream_t stream);
+
+/* ---------------------------------------------------------------- N8: reparameterised sampling
+ * codes/models.py:97-103,255-262,490-497; codes/base.py:164-167.  Philox4x32-10 + Box-Muller normals. */
+int ladder_randn(float* out, size_t n, uint64_t seed, uint64_t offset, ladder_stream_t stream);
+
+/* ---------------------------------------------------------------- N9: tfd.Mixture(...).log_prob + gradient
+ * codes/base.py:109-124, 308-313.
+ * prepare: per component Cholesky L_k of cov_k (fp32), packed[k] = { logw_k - sum log diag L_k - R/2 log 2pi,
+ *          mean_k[R], Linv_k (row-major lower-triangular, R*(R+1)/2) } ; stride = ladder_gmm_packed_stride(R). */
+int ladder_gmm_packed_stride(int R);
+int ladder_gmm_prepare(const float* weights, const float* means, const float* covs, int K, int R,
+                       float* packed, ladder_stream_t stream);
+/* R in 1..8.  t[l,b,:] = mu[b,:] + sd[b,:]*eps[l,b,:];  lp = logsumexp_k(...).  Outputs: sum_logp[0] = sum_{l,b} lp;
+ * dmu[b,:] = sum_l dlp/dt ; dsd[b,:] = sum_l dlp/dt * eps   (un-normalised; host scales by 1/(L*B_global)).
+ * One workgroup per batch row, wavefronts stride over l, lane = component; logsumexp / responsibilities
+ * reduced with wave shuffles. */
+size_t ladder_gmm_workspace_bytes(int L, int B);
+int ladder_gmm_logprob_fwd_bwd(const float* mu, const float* sd, const float* eps, const float* packed,
+                               int L, int B, int R, int K, float* sum_logp, float* dmu, float* dsd,
+                               void* ws, size_t ws_bytes, ladder_stream_t stream);
+
+/* ---------------------------------------------------------------- N10: ELBO reductions + scalar algebra
+ * codes/base.py:262-305,374-402; codes/models.py:152-159,319-326,591-597.
+ *
+ * Partial sums live in ONE device vector `partials` (floats) so the host can all-reduce it in one call:
+ *   [LADDER_P_*] fixed slots, then Z floats (sum_b sd_z[b,:]) and R floats (sum_b sd_t[b,:]).
+ * Fetched scalars + backward coefficients live in the device vector `scalars` ([LADDER_S_*]). */
+enum { LADDER_P_PIX_ABS = 0, LADDER_P_PIX_SQ = 1, LADDER_P_LOG_SDZ = 2, LADDER_P_MU2SD2_Z = 3, LADDER_P_CODE_ERR = 4,
+       LADDER_P_CODE_SQRT = 5, LADDER_P_CODE_ABS = 6, LADDER_P_LOG_SDT = 7, LADDER_P_MU2SD2_T = 8, LADDER_P_LOGP = 9,
+       LADDER_P_FIXED = 16 };
+enum { LADDER_S_SIGMA = 0, LADDER_S_MPE = 1, LADDER_S_ENTROPY_Z = 2, LADDER_S_XENT_SG = 3, LADDER_S_XENT_PRIOR = 4,
+       LADDER_S_L1 = 5, LADDER_S_L2 = 6, LADDER_S_RECON_LL = 7, LADDER_S_SIGMA_REG = 8, LADDER_S_ELBO = 9,
+       LADDER_S_LOSS_AE = 10, LADDER_S_INNER_SIGMA = 11, LADDER_S_MEAN_CODE_ERROR = 12, LADDER_S_CODE_LL = 13,
+       LADDER_S_CODE_L1 = 14, LADDER_S_REP_REG = 15, LADDER_S_ENTROPY_T = 16, LADDER_S_XENT_T = 17,
+       LADDER_S_ELBO_PRIOR = 18, LADDER_S_LOSS_PRIOR = 19,
+       /* backward coefficients, already divided by the GLOBAL batch */
+       LADDER_S_G_PIX = 20,             /* d loss_ae/d xhat = G_PIX * sign(xhat-x) (incl. the sigma=max(.,mpe) path) */
+       LADDER_S_G_SIGMA_VAR = 21,       /* d loss_ae / d sigma/Variable                                             */
+       LADDER_S_G_CODE = 22,            /* d loss / d err[b,j] = 1/(2 inner_sigma^2 B)                               */
+       LADDER_S_G_INNER_SIGMA_VAR = 23, /* d loss_prior / d inner_sigma/Variable                                     */
+       LADDER_S_INV_B = 24, LADDER_S_INV_LB = 25, LADDER_S_COUNT = 32 };
+typedef struct {
+  int B_global, D, Z, R, L;
+  int sigma_uses_mpe;    /* celeba: 1 ; mnist: TRAIN_sigma (models.py:158,325,597) */
+  int has_inner;         /* prior == "ours" */
+  int use_sg;            /* use_standard_gaussian_prior feed (base.py:318-320) */
+  int clamp_inner_sigma; /* TRAIN_inner_sigma (base.py:210-212) */
+  float inner_sigma_lb, inner_sigma_ub;
+} LadderElboCfg;
+
+/* out[0] = sum |x-xhat|, out[1] = sum (x-xhat)^2 over n elements (fp64 accumulation across workgroups). */
+size_t ladder_pixel_partials_workspace_bytes(size_t n);
+int ladder_pixel_partials(const float* x, const float* xhat, size_t n, float* out /*[2]*/,
+                          void* ws, size_t ws_bytes, ladder_stream_t stream);
+/* dxhat = coef[0] * sign(xhat - x); coef is a DEVICE scalar (&scalars[LADDER_S_G_PIX]). */
+int ladder_pixel_grad(const float* x, const float* xhat, const float* coef, float* dxhat, size_t n, ladder_stream_t stream);
+/* Latent block (models.py:95-103, base.py:162-167, 269-280, 302-305): sd = sd_raw + lvp ; z = mu + sd*eps (z may be NULL).
+ * p_log[0] = sum_bj log sd ; p_mu2sd2[0] = sum_bj (mu^2 + sd^2) ; p_sdsum[j] = sum_b sd[b,j] (may be NULL). */
+int ladder_latent_fwd(const float* mu, const float* sd_raw, const float* eps, float lvp, float* z, float* sd,
+                      float* p_log, float* p_mu2sd2, float* p_sdsum, int B, int Z, ladder_stream_t stream);
+/* base.py:286-297: err = (z-zhat)^2 (0 where use_mask && sd_z>1). out[0]=sum err, out[1]=sum sqrt(err), out[2]=sum|z-zhat|. */
+int ladder_code_partials(const float* z, const float* zhat, const float* sd_z, int use_mask,
+                         float* out /*[3]*/, int B, int Z, ladder_stream_t stream);
+/* The scalar algebra of define_loss (base.py:257-413) + the sigma / inner_sigma blocks, on device. */
+int ladder_elbo_finalize(const float* partials, const float* sigma_var, const float* inner_sigma_var,
+                         LadderElboCfg cfg, float* scalars, ladder_stream_t stream);
+/* dz_accum += 2*G_CODE*(z-zhat)*mask (dz_accum may be NULL) ; dzhat = -2*G_CODE*(z-zhat)*mask. */
+int ladder_code_grad(const float* z, const float* zhat, const float* sd_z, int use_mask, const float* scalars,
+                     float* dz_accum, float* dzhat, int B, int Z, ladder_stream_t stream);
+/* Gradient of a reparameterised latent block w.r.t. its heads:
+ *   dmu = g_sample [+ mu*INV_B if mode&2] + extra_sign*INV_LB*extra_mu
+ *   dsd = g_sample*eps [- INV_B/sd if mode&1] [+ sd*INV_B if mode&2] + extra_sign*INV_LB*extra_sd
+ *   dsd_raw = dsd * (sd_raw > 0)     (relu of the std head)
+ * mode bit0 = entropy term, bit1 = standard-Gaussian cross-entropy term; g_sample / extra_* may be NULL. */
+int ladder_latent_bwd(const float* g_sample, const float* mu, const float* sd, const float* sd_raw, const float* eps,
+                      const float* extra_mu, const float* extra_sd, float extra_sign, const float* scalars, int mode,
+                      float* dmu, float* dsd_raw, int B, int Z, ladder_stream_t stream);
+
+/* ---------------------------------------------------------------- N11: tf.train.AdamOptimizer + clip_by_value
+ * codes/base.py:457-517.  g <- clip(g,-clip,clip); m,v update; theta -= lr_t * m/(sqrt(v)+eps) with
+ * lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller (TF form).  Flat buffers: one launch per optimiser.
+ * `g` may point into the device `scalars` vector for the two 1-element sigma optimisers. */
+int ladder_adam_clip(float* theta, const float* g, float* m, float* v, size_t n,
+                     float lr_t, float beta1, float beta2, float eps, float clip, ladder_stream_t stream);
+
+/* ---------------------------------------------------------------- helpers */
+size_t ladder_colstats_workspace_bytes(size_t rows, int C);
+/* out[i] (+)= scale * in[i]. accumulate!=0 adds into out. */
+int ladder_axpy(const float* in, float* out, size_t n, float scale, int accumulate, ladder_stream_t stream);
+/* out[c] = sum_rows x[row,c] (fixed-order two-stage). */
+int ladder_colsum(const float* x, float* out, size_t rows, int C, void* ws, size_t ws_bytes, ladder_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LADDER_HIP_H */

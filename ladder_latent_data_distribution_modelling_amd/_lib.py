@@ -1,0 +1,114 @@
+"""ctypes binding of libladder_hip.so (the C ABI declared in include/ladder_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a call returns an error code the
+product path raises.  `python -m ladder_latent_data_distribution_modelling_amd.csrc.build`
+(or `__graft_entry__.build()`) produces the library with hipcc for gfx950.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libladder_hip.so")
+
+ERRORS = {-1: "LADDER_E_SHAPE", -2: "LADDER_E_ALIGN", -3: "LADDER_E_WORKSPACE", -4: "LADDER_E_LAUNCH"}
+ACT = {None: 0, "none": 0, "leaky_relu": 1, "relu": 2, "tanh": 3}
+
+# partial / scalar slot indices (mirror include/ladder_hip.h)
+P_PIX_ABS, P_PIX_SQ, P_LOG_SDZ, P_MU2SD2_Z, P_CODE_ERR, P_CODE_SQRT, P_CODE_ABS, P_LOG_SDT, P_MU2SD2_T, P_LOGP = range(10)
+P_FIXED = 16
+S_NAMES = ["sigma", "mean_pixel_error", "entropy_z", "crossEntropy_prior_sg", "crossEntropy_prior",
+           "l1_reconstruction_error", "l2_reconstruction_error", "reconstruction_likelihood", "sigma_regularisor",
+           "elbo", "loss_ae", "inner_sigma", "mean_code_error", "code_reconstruction_likelihood",
+           "code_l1_reconstruction_error", "representation_regularisor", "entropy_t",
+           "crossEntropy_representation", "elbo_prior", "loss_prior",
+           "_g_pix", "_g_sigma_var", "_g_code", "_g_inner_sigma_var", "_inv_B", "_inv_LB"]
+S_INDEX = {n: i for i, n in enumerate(S_NAMES)}
+S_COUNT = 32
+
+
+class LadderElboCfg(C.Structure):
+    _fields_ = [("B_global", C.c_int), ("D", C.c_int), ("Z", C.c_int), ("R", C.c_int), ("L", C.c_int),
+                ("sigma_uses_mpe", C.c_int), ("has_inner", C.c_int), ("use_sg", C.c_int),
+                ("clamp_inner_sigma", C.c_int), ("inner_sigma_lb", C.c_float), ("inner_sigma_ub", C.c_float)]
+
+
+_p, _i, _f, _d, _z, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_uint64
+
+# name -> (restype, argtypes); every int-returning export is error-checked by `call`.
+PROTOTYPES = {
+    "ladder_abi_version": (_i, []),
+    "ladder_conv2d_fwd": (_i, [_p, _p, _p, _p] + [_i] * 13 + [_p]),
+    "ladder_filter_flip_transpose": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "ladder_conv2d_bwd_data": (_i, [_p, _p, _p] + [_i] * 12 + [_p]),
+    "ladder_conv2d_bwd_filter_workspace_bytes": (_z, [_i] * 9),
+    "ladder_conv2d_bwd_filter": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p, _z, _p]),
+    "ladder_dense_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "ladder_dense_bwd_data": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "ladder_dense_bwd_weight_workspace_bytes": (_z, [_i, _i, _i]),
+    "ladder_dense_bwd_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "ladder_act_bwd": (_i, [_p, _p, _p, _z, _i, _p]),
+    "ladder_bn_workspace_bytes": (_z, [_z, _i]),
+    "ladder_bn_fwd_stats": (_i, [_p, _p, _z, _i, _p, _z, _p]),
+    "ladder_bn_fwd_apply": (_i, [_p, _p, _d, _p, _p, _p, _p, _z, _i, _f, _i, _p]),
+    "ladder_bn_bwd_stats": (_i, [_p, _p, _p, _p, _p, _p, _z, _i, _i, _p, _z, _p]),
+    "ladder_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _d, _p, _p, _p, _z, _i, _i, _p]),
+    "ladder_in_style_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _p]),
+    "ladder_in_style_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "ladder_resize_bilinear_fwd": (_i, [_p, _p] + [_i] * 6 + [_p]),
+    "ladder_resize_bilinear_bwd": (_i, [_p, _p] + [_i] * 6 + [_p]),
+    "ladder_depth_to_space": (_i, [_p, _p] + [_i] * 6 + [_p]),
+    "ladder_pad_symmetric": (_i, [_p, _p] + [_i] * 5 + [_p]),
+    "ladder_randn": (_i, [_p, _z, _u64, _u64, _p]),
+    "ladder_gmm_packed_stride": (_i, [_i]),
+    "ladder_gmm_prepare": (_i, [_p, _p, _p, _i, _i, _p, _p]),
+    "ladder_gmm_workspace_bytes": (_z, [_i, _i]),
+    "ladder_gmm_logprob_fwd_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _z, _p]),
+    "ladder_pixel_partials_workspace_bytes": (_z, [_z]),
+    "ladder_pixel_partials": (_i, [_p, _p, _z, _p, _p, _z, _p]),
+    "ladder_pixel_grad": (_i, [_p, _p, _p, _p, _z, _p]),
+    "ladder_latent_fwd": (_i, [_p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "ladder_code_partials": (_i, [_p, _p, _p, _i, _p, _i, _i, _p]),
+    "ladder_elbo_finalize": (_i, [_p, _p, _p, LadderElboCfg, _p, _p]),
+    "ladder_code_grad": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _p]),
+    "ladder_latent_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _i, _p, _p, _i, _i, _p]),
+    "ladder_adam_clip": (_i, [_p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _p]),
+    "ladder_axpy": (_i, [_p, _p, _z, _f, _i, _p]),
+    "ladder_colstats_workspace_bytes": (_z, [_z, _i]),
+    "ladder_colsum": (_i, [_p, _p, _z, _i, _p, _z, _p]),
+}
+
+_lib = None
+
+
+class LadderHipError(RuntimeError):
+    pass
+
+
+def load(path=None):
+    """Load (once) and return the ctypes handle; raises LadderHipError if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or os.environ.get("LADDER_HIP_LIB", LIB_PATH)
+    if not os.path.exists(path):
+        raise LadderHipError(
+            "libladder_hip.so not found at %s: build it with `python -m "
+            "ladder_latent_data_distribution_modelling_amd.csrc.build` (there is no CPU fallback)" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)      # AttributeError here == header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an int-returning export and raise on a non-zero status."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise LadderHipError("%s failed: %s (%d)" % (name, ERRORS.get(rc, "?"), rc))
+
+
+def query(name, *args):
+    return getattr(load(), name)(*args)

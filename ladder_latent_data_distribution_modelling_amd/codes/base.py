@@ -1,0 +1,244 @@
+"""Trainer base classes with the reference's step-function surface (codes/base.py:520-1010).
+
+Each step function issues the same sequence of "runs" the reference issues as `sess.run` calls; a run
+is evaluated by the HIP engine.  Plotting (matplotlib figures) is out of scope.
+"""
+import time
+
+import numpy as np
+import torch
+
+from .models import BaseModel  # noqa: F401  (re-export, reference exposes BaseModel from codes.base)
+
+
+class BaseTrain:
+    def __init__(self, sess, model, data, config):
+        self.model, self.config, self.sess, self.data = model, config, sess, data
+        self.engine = model.engine
+        self.cur_epoch = 0
+        # same record lists as codes/base.py:531-570
+        for name in ("train_loss train_loss_prior val_loss val_loss_prior train_loss_ave_epoch val_loss_ave_epoch elbo_train "
+                     "elbo_val recons_error_train recons_error_val entropy_z_train entropy_z_val crossEntropy_prior_train "
+                     "crossEntropy_prior_val vampPrior_crossEntropy_prior_val vampPrior_crossEntropy_prior_train "
+                     "sigma_reguarisor_train sigma_reguarisor_val code_elbo_train code_elbo_val entropy_t_train entropy_t_val "
+                     "crossEntropy_t_train crossEntropy_t_val code_recons_error_train code_recons_error_val "
+                     "code_recons_likelihood_train code_inner_sigma_train iter_epochs_list test_batch_code_mean "
+                     "test_batch_code_std_dev test_sigma sigma_train classifier_accuracy gmm_mean gmm_cov gmm_weight").split():
+            setattr(self, name, [])
+        self.n_train_iter, self.n_val_iter = 0, 0
+        self.gm_params = None          # (weights, means, covs) currently fed as the GM hyper-prior
+        self.GM_prior_final = None
+
+    def compute_execution_time(self, cur_epoch, total_epoch):
+        self.current_time = time.time()
+        elapsed = (self.current_time - self.start_time) / 60
+        print("Already trained for {} min.".format(elapsed))
+        remain = (self.current_time - self.start_time) / (cur_epoch + 1) * total_epoch / 60 - elapsed
+        print("Remaining {} min.\n".format(remain))
+
+    # ------------------------------------------------------------------ regime / feed (base.py:862-899)
+    def compute_feeddict(self, batch_data=None, model_to_train=None):
+        """Selects the feed regime: SG pre-training (dummy N(0,I) mixture, use_standard_gaussian_prior=True)
+        vs the fitted mixture; use_mask from use_mask_start.  Returns (use_sg, use_mask)."""
+        cfg, eng = self.config, self.engine
+        if cfg["prior"] == "standard_gaussian":
+            return True, False
+        use_sg = self.cur_epoch <= int(cfg["sg_pretraining"])
+        if use_sg or self.gm_params is None:
+            if getattr(self, "_fed", None) != "sg":
+                eng.set_sg_mixture()
+                self._fed = "sg"
+        elif getattr(self, "_fed", None) is not self.gm_params:
+            eng.set_mixture(*self.gm_params)
+            self._fed = self.gm_params
+        return use_sg, self.cur_epoch >= int(cfg["use_mask_start"])
+
+    # ------------------------------------------------------------------ step functions
+    def train_step_ae(self, cur_lr, batch_data, noise=None):
+        """RUN#1 (+ RUN#2 if TRAIN_sigma): codes/base.py:583-608.  `noise` (optional) = [noise_run1, noise_run2]."""
+        eng, cfg = self.engine, self.config
+        use_sg, use_mask = self.compute_feeddict(batch_data, "VAE")
+        eng.run_ae(batch_data, cur_lr, noise[0] if noise else None, use_sg, use_mask)
+        f = eng.fetch()
+        self.recons_error_train.append(f["l1_reconstruction_error"])
+        self.entropy_z_train.append(f["entropy_z"])
+        self.crossEntropy_prior_train.append(f["crossEntropy_prior"])
+        self.sigma_reguarisor_train.append(f["sigma_regularisor"])
+        self.elbo_train.append(f["elbo"])
+        self.last_fetch_ae = f
+        if int(cfg["TRAIN_sigma"]) == 1:
+            lr_s = float(cfg["learning_rate_sigma"]) * (0.99 ** (self.cur_epoch - 1))
+            eng.run_sigma(batch_data, lr_s, noise[1] if noise else None, use_sg, use_mask)
+            self.last_fetch_sigma = eng.fetch(["sigma"])
+            self.sigma_train.append(self.last_fetch_sigma["sigma"])
+        return f["loss_ae"]
+
+    def train_step_prior(self, batch_data, noise=None):
+        """RUN#3 (+ RUN#4 if TRAIN_inner_sigma): codes/base.py:610-641."""
+        eng, cfg = self.engine, self.config
+        use_sg, use_mask = self.compute_feeddict(batch_data, "prior")
+        lr_p = float(cfg["learning_rate_prior"]) * (1.01 ** (self.cur_epoch - 1))
+        eng.run_prior(batch_data, lr_p, noise[0] if noise else None, use_sg, use_mask)
+        f = eng.fetch()
+        self.code_recons_error_train.append(f["code_l1_reconstruction_error"])
+        self.code_recons_likelihood_train.append(f["code_reconstruction_likelihood"])
+        self.entropy_t_train.append(f["entropy_t"])
+        self.crossEntropy_t_train.append(f["crossEntropy_representation"])
+        self.code_elbo_train.append(f["elbo_prior"])
+        self.code_inner_sigma_train.append(f["inner_sigma"])
+        self.last_fetch_prior = f
+        if int(cfg["TRAIN_inner_sigma"]) == 1:
+            lr_i = float(cfg["learning_rate_inner_sigma"]) * (1.01 ** (self.cur_epoch - 1))
+            eng.run_inner_sigma(batch_data, lr_i, noise[1] if noise else None, use_sg, use_mask)
+
+    def val_step(self, model_to_train, batch_data, noise=None):
+        """codes/base.py:643-679."""
+        use_sg, use_mask = self.compute_feeddict(batch_data, model_to_train)
+        self.engine.evaluate(batch_data, noise, use_sg, use_mask)
+        f = self.engine.fetch()
+        if model_to_train == "VAE":
+            self.val_loss.append(f["loss_ae"])
+            self.recons_error_val.append(f["l1_reconstruction_error"])
+            self.entropy_z_val.append(f["entropy_z"])
+            self.elbo_val.append(f["elbo"])
+            self.crossEntropy_prior_val.append(f["crossEntropy_prior"])
+            return f["loss_ae"]
+        self.val_loss_prior.append(f["loss_prior"])
+        self.code_recons_error_val.append(f["code_l1_reconstruction_error"])
+        self.entropy_t_val.append(f["entropy_t"])
+        self.code_elbo_val.append(f["elbo_prior"])
+        self.crossEntropy_t_val.append(f["crossEntropy_representation"])
+        return f["loss_prior"]
+
+    # ------------------------------------------------------------------ GM fit (base.py:681-789)
+    def _draw_t_samples(self, iterator, n_batch):
+        eng = self.engine
+        chunks = []
+        for _ in range(n_batch):
+            t = eng.sample_representation(iterator.next())
+            if eng.ctx.comm.on:   # C5: gather every rank's samples
+                parts = [torch.empty_like(t) for _ in range(eng.ctx.comm.world)]
+                eng.ctx.comm.dist.all_gather(parts, t.contiguous(), group=eng.ctx.comm.group)
+                t = torch.cat(parts, 0)
+            chunks.append(t.cpu().numpy())
+        return np.concatenate(chunks, 0).astype(np.float64)
+
+    def _share_gm(self, gm):
+        """rank 0 fits, every rank receives (weights, means, covs)."""
+        eng = self.engine
+        K, R = int(self.config["n_mixtures"]), int(self.config["representation_size"])
+        buf = torch.zeros(K + K * R + K * R * R, dtype=torch.float64, device=eng.ctx.device)
+        if eng.ctx.comm.rank == 0:
+            flat = np.concatenate([gm.weights_.ravel(), gm.means_.ravel(), gm.covariances_.ravel()])
+            buf.copy_(torch.as_tensor(flat))
+        eng.ctx.comm.broadcast_(buf, 0)
+        a = buf.cpu().numpy()
+        return a[:K].copy(), a[K:K + K * R].reshape(K, R).copy(), a[K + K * R:].reshape(K, R, R).copy()
+
+    def fit_GMM_VI(self, iterator, mode="fast", space="t"):
+        if space != "t":
+            raise NotImplementedError("prior 'GMM' (mixture on z) is a later row (SURVEY 8f4)")
+        bs_global = int(self.config["batch_size"]) * self.engine.ctx.comm.world
+        rank0 = self.engine.ctx.comm.rank == 0
+        if mode == "fast":
+            samples = self._draw_t_samples(iterator, 2000 // bs_global + 1)
+            gm = self.model.GM_prior_training
+            if rank0:
+                gm.fit(samples)
+            self.gm_params = self._share_gm(gm)
+            w = self.gm_params[0]
+        else:
+            from sklearn.mixture import BayesianGaussianMixture
+            samples = self._draw_t_samples(iterator, 20000 // bs_global + 1)
+            self.GM_prior_final = BayesianGaussianMixture(
+                n_components=int(self.config["n_mixtures"]), covariance_type="full", max_iter=2000,
+                n_init=int(self.config["GM_fit_restart"]), weight_concentration_prior_type="dirichlet_process",
+                weight_concentration_prior=0.1, warm_start=False)
+            if rank0:
+                self.GM_prior_final.fit(samples)
+            self.gm_final_params = self._share_gm(self.GM_prior_final)
+            w, m, K = self.gm_final_params
+            idx = np.flatnonzero(w >= 1e-2)
+            if rank0:
+                aw = w[idx] / np.sum(w[idx]) if len(idx) else w[idx]
+                np.savez("{}GM_prior_info.npz".format(self.config["result_dir"]), w_active=aw, m_active=m[idx],
+                         K_active=K[idx], w_full=w, m_full=m, K_full=K)          # same keys as base.py:772-777
+                print("Final fitted prior saved.")
+        print("There are {} active mixtures.".format(int(np.sum(w >= 1e-2))))
+        return samples
+
+    def save_variables_VAE(self):
+        """<result_dir>/<exp_name>-result.npz with the reference's keys (codes/base.py:791-823)."""
+        if self.engine.ctx.comm.rank != 0:
+            return
+        file_name = "{}{}-result.npz".format(self.config["result_dir"], self.config["exp_name"])
+        np.savez(file_name, iter_list_val=self.iter_epochs_list, n_train_iter=self.n_train_iter, n_val_iter=self.n_val_iter,
+                 train_loss=self.train_loss, elbo_train=self.elbo_train, val_loss=self.val_loss, elbo_val=self.elbo_val,
+                 train_loss_prior=self.train_loss_prior, val_loss_prior=self.val_loss_prior,
+                 code_elbo_train=self.code_elbo_train, code_elbo_val=self.code_elbo_val,
+                 recons_loss_train=self.recons_error_train, recons_loss_val=self.recons_error_val,
+                 recons_loss_prior_train=self.code_recons_error_train, recons_loss_prior_val=self.code_recons_error_val,
+                 entropy_z_train=self.entropy_z_train, entropy_z_val=self.entropy_z_val,
+                 entropy_t_train=self.entropy_t_train, entropy_t_val=self.entropy_t_val,
+                 crossentropy_z_train=self.crossEntropy_prior_train, crossentropy_z_val=self.crossEntropy_prior_val,
+                 crossentropy_t_train=self.crossEntropy_t_train, crossentropy_t_val=self.crossEntropy_t_val,
+                 vampPrior_crossEntropy_z_train_prior=self.vampPrior_crossEntropy_prior_train,
+                 vampPrior_crossEntropy_z_val_prior=self.vampPrior_crossEntropy_prior_val,
+                 sigma_regularisor_train=self.sigma_reguarisor_train, sigma_regularisor_val=self.sigma_reguarisor_val,
+                 num_para_VAE=self.model.num_para_list, sigma=self.test_sigma)
+
+
+class BaseTrain_joint(BaseTrain):
+    def train(self):
+        """codes/base.py:848-860."""
+        self.start_time = time.time()
+        for _ in range(int(self.config["num_epochs"])):
+            self.train_epoch()
+            self.model.save(self.sess, model="joint" if self.config["prior"] in ("ours", "hierarchical", "vampPrior") else "VAE")
+            self.compute_execution_time(self.cur_epoch - 1, self.config["num_epochs"])
+
+    def test_step(self, batch_data, print_result=False, noise=None):
+        """codes/base.py:944-986."""
+        use_sg, use_mask = self.compute_feeddict(batch_data)
+        eng = self.engine
+        eng.evaluate(batch_data, noise, use_sg, use_mask)
+        f = eng.fetch()
+        self.output_test = np.squeeze(eng.xhat.cpu().numpy())
+        if print_result:
+            print("test loss: elbo: {:.4f}, recons_loss_l1: {:.4f}, entropy z: {:.4f}, cross entropy z: {:.4f}, "
+                  "sigma_regularisor: {:.4f}".format(f["elbo"], f["l1_reconstruction_error"], f["entropy_z"],
+                                                     f["crossEntropy_prior"], f["sigma_regularisor"]))
+        self.test_sigma.append(f["sigma"])
+        print("current sigma: mean: {:.7f}; pixel mean error: {:.7f}".format(f["sigma"], f["mean_pixel_error"]))
+        if print_result:
+            print("current z std: {}".format(eng.std_dev_code()))
+            if eng.has_inner:
+                print("current t std: {}".format(eng.std_dev_representation()))
+                print("current inner VAE sigma: {}".format(f["inner_sigma"]))
+                print("current code prediction error per channel: {}".format(f["mean_code_error"]))
+        return f
+
+    def fit_GM(self, iterator):
+        """codes/base.py:988-999 (prior 'ours')."""
+        if self.config["prior"] == "ours":
+            self.fit_GMM_VI(iterator=iterator, mode="fast", space="t")
+            if self.cur_epoch % int(self.config["accurate_fit"]) == 0 or self.cur_epoch == int(self.config["num_epochs"]):
+                self.fit_GMM_VI(iterator=iterator, mode="accurate", space="t")
+
+    def generate_samples_from_prior(self, n_sample=10):
+        """Latent samples -> decoded images (codes/base.py:1064-1168, figure writing omitted)."""
+        eng, cfg = self.engine, self.config
+        n = n_sample ** 2
+        rng = np.random.default_rng(self.cur_epoch)
+        if cfg["prior"] == "ours" and self.cur_epoch > int(cfg["sg_pretraining"]) and self.gm_params is not None:
+            accurate = (self.cur_epoch % int(cfg["accurate_fit"]) == 0 or self.cur_epoch == int(cfg["num_epochs"]))
+            w, m, K = self.gm_final_params if (accurate and self.GM_prior_final is not None) else self.gm_params
+            w = np.clip(w, 0, None)
+            comp = rng.choice(len(w), size=n, p=w / w.sum())
+            Lc = np.linalg.cholesky(K)
+            t = m[comp] + np.einsum("nij,nj->ni", Lc[comp], rng.standard_normal((n, m.shape[1])))
+            code = eng.decode_representation(t)
+        else:
+            code = rng.standard_normal((n, int(cfg["code_size"])))
+        self.generated_samples = eng.decode(code).cpu().numpy()
+        return self.generated_samples

@@ -1,0 +1,90 @@
+"""Model classes with the reference's names and constructor signature (codes/models.py:10,163,330;
+codes/base.py:32-124).  A model owns a LadderEngine (HIP kernels + parameters + optimiser slots) and the
+sklearn mixture object that produces the hyper-prior feed (base.py:93-106).
+"""
+import os
+
+import numpy as np
+
+from ..engine import LadderEngine
+from .. import arch
+
+
+class BaseModel:
+    exp_name = None
+
+    def __init__(self, config, device=None, values=None, seed=1, comm=None):
+        if self.exp_name is not None and config["exp_name"] != self.exp_name:
+            raise ValueError("%s expects exp_name=%r, got %r" % (type(self).__name__, self.exp_name, config["exp_name"]))
+        self.config = config
+        if device is None:
+            device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+        self.engine = LadderEngine(config, device, values, seed, comm)
+        self.define_GM_prior()
+        ps = self.engine.ps
+        self.num_encoder, self.num_decoder = ps.num_params("encoder/"), ps.num_params("decoder/")
+        self.num_sigma = ps.num_params("sigma/")
+        self.num_prior_ae, self.num_prior_sigma = ps.num_params("prior/"), ps.num_params("inner_sigma/")
+        self.num_para_list = [self.num_encoder, self.num_decoder, self.num_sigma, self.num_prior_ae, self.num_prior_sigma]
+        print("Total number of trainable parameters in VAE network is:\n{}k\n".format(np.around(sum(self.num_para_list) / 1000, 2)))
+        self.init_saver()
+
+    # codes/base.py:88-106 -- the producer of (prior_weight, prior_mean, prior_cov)
+    def define_GM_prior(self):
+        self.GM_prior_training = None
+        if self.config["prior"] == "ours":
+            from sklearn.mixture import BayesianGaussianMixture
+            self.GM_prior_training = BayesianGaussianMixture(
+                n_components=int(self.config["n_mixtures"]), covariance_type="full", max_iter=1000, n_init=1,
+                weight_concentration_prior_type="dirichlet_distribution", weight_concentration_prior=0.1, warm_start=True)
+
+    # codes/base.py:37-85 -- two savers: vae-model (encoder+decoder+sigma), prior-model (prior/* + inner sigma).
+    # Adam slots / epoch counter are not saved by the reference either.  Format: npz keyed by TF variable name.
+    def init_saver(self):
+        self.saver_path_ae = os.path.join(self.config.get("checkpoint_dir", "."), "vae-model")
+        self.saver_path_prior = os.path.join(self.config.get("checkpoint_dir", "."), "prior-model")
+
+    def _save(self, path, groups):
+        if self.engine.ctx.comm.rank == 0:
+            np.savez(path + ".npz", **self.engine.ps.to_dict(groups))
+
+    def save(self, sess, model):
+        print("Saving model...")
+        if model == "VAE" or (model == "joint" and int(self.config["TRAIN_VAE"]) == 1):
+            self._save(self.saver_path_ae, ("ae", "sigma"))
+            print("Outer VAE model saved.")
+        if self.config["prior"] in ("ours", "hierarchical", "vampPrior") and (
+                model == "prior" or (model == "joint" and int(self.config["TRAIN_prior"]) == 1)):
+            self._save(self.saver_path_prior, ("prior", "inner_sigma"))
+            print("Prior model saved.")
+
+    def load(self, sess, model):
+        print("\ncheckpoint_dir to be loaded:\n{}\n".format(self.config.get("checkpoint_dir")))
+        path = (self.saver_path_ae if model == "VAE" else self.saver_path_prior) + ".npz"
+        label = "Outer VAE" if model == "VAE" else "Prior"
+        if os.path.isfile(path):
+            self.engine.ps.load_dict(dict(np.load(path)), strict=False)
+            print("%s model loaded." % label)
+        else:
+            print("No %s model found. No %s model loaded." % (label.lower(), "VAE" if model == "VAE" else "prior"))
+
+    @staticmethod
+    def ClipIfNotNone(grad):
+        """codes/base.py:514-517 (element-wise clip to [-1,1]); numpy/torch arrays."""
+        return None if grad is None else grad.clip(-1, 1)
+
+    @property
+    def variable_shapes(self):
+        return dict(arch.param_specs(self.config))
+
+
+class MNISTModel_digit(BaseModel):
+    exp_name = "mnist_digit"
+
+
+class MNISTModel_fashion(BaseModel):
+    exp_name = "mnist_fashion"
+
+
+class CelebAModel_densenet(BaseModel):
+    exp_name = "celeba"

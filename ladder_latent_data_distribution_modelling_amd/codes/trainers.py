@@ -1,0 +1,103 @@
+"""Epoch drivers with the reference's class names (codes/trainers.py:12-83, 130-209)."""
+import numpy as np
+
+from .base import BaseTrain, BaseTrain_joint  # noqa: F401
+from .data_loader import BatchIterator
+
+
+class _JointEpochMixin:
+    """The per-epoch sequence shared by both trainers (trainers.py:23-83 and 141-198)."""
+
+    def _iterators(self):
+        raise NotImplementedError
+
+    def _prior_training_on(self):
+        cfg = self.config
+        return (self.cur_epoch > int(cfg["sg_pretraining"]) - 1 and cfg["prior"] in ("ours", "hierarchical", "vampPrior")
+                and int(cfg["TRAIN_prior"]) == 1)
+
+    def train_epoch(self):
+        cfg = self.config
+        self.cur_epoch += 1
+        print("{}/{}:".format(self.cur_epoch, cfg["num_epochs"]))
+        train_it, val_it = self._iterators()
+        self.compute_cur_lr()
+        train_loss_cur_epoch = 0.0
+        for i in range(self.n_train_iter):                                  # HOT LOOP (trainers.py:33-40, 148-155)
+            batch = train_it.next()
+            if int(cfg["TRAIN_VAE"]) == 1:
+                loss = self.train_step_ae(cur_lr=self.cur_lr, batch_data=batch)
+                self.train_loss.append(loss)
+                train_loss_cur_epoch += loss
+            if self._prior_training_on():
+                self.train_step_prior(batch_data=batch)
+        if int(cfg["TRAIN_VAE"]) == 1:
+            self.train_loss_ave_epoch.append(train_loss_cur_epoch / max(self.n_train_iter, 1))
+            self.iter_epochs_list.append(len(self.train_loss) - 1)
+        if self.cur_epoch > int(cfg["sg_pretraining"]) - 1 and cfg["prior"] in ("ours", "GMM"):
+            self.fit_GM(iterator=train_it)
+        self.generate_samples_from_prior()
+        self.test_step(batch_data=self.test_batch, print_result=True)
+        val_loss_cur_epoch = 0.0
+        for i in range(self.n_val_iter):
+            vb = val_it.next()
+            val_loss_cur_epoch += self.val_step(batch_data=vb, model_to_train="VAE")
+            if self.cur_epoch > int(cfg["sg_pretraining"]) - 1 and cfg["prior"] in ("ours", "hierarchical", "vampPrior"):
+                self.val_step(batch_data=vb, model_to_train="prior")
+        self.val_loss_ave_epoch.append(val_loss_cur_epoch / max(self.n_val_iter, 1))
+        if int(cfg["TRAIN_VAE"]) == 1:
+            print("Average overall negative ELBO loss:\ntrain: {:.4f}, val: {:.4f}".format(
+                self.train_loss_ave_epoch[self.cur_epoch - 1], self.val_loss_ave_epoch[self.cur_epoch - 1]))
+        self.save_variables_VAE()
+
+
+class MNISTTrainer_joint_training(_JointEpochMixin, BaseTrain_joint):
+    def __init__(self, sess, model, data, config):
+        super().__init__(sess, model, data, config)
+        self.test_batch = self.data.test_set["image"]
+        world = self.engine.ctx.comm.world
+        self.n_train_iter = self.data.n_train // (int(config["batch_size"]) * world)
+        self.n_val_iter = self.data.n_val // (int(config["batch_size"]) * world)
+
+    def _shard(self, images):
+        c = self.engine.ctx.comm
+        return images[c.rank::c.world] if c.on else images
+
+    def _iterators(self):
+        bs = int(self.config["batch_size"])
+        return (BatchIterator(self._shard(self.data.train_set["image"]), bs, seed=self.cur_epoch),
+                BatchIterator(self._shard(self.data.val_set["image"]), bs, seed=self.cur_epoch))
+
+    def compute_cur_lr(self):
+        self.cur_lr = float(self.config["learning_rate_ae"]) * (0.99 ** (self.cur_epoch - 1))     # trainers.py:30
+
+
+class CelebATrainer_joint_training(_JointEpochMixin, BaseTrain_joint):
+    def __init__(self, sess, model, data, config):
+        super().__init__(sess, model, data, config)
+        bs = int(config["batch_size"])
+        self.test_batch = self.data.celeba_images("test")[:bs]
+        self._train, self._val = self.data.celeba_images("train"), self.data.celeba_images("val")
+        world = self.engine.ctx.comm.world
+        n_train = self.data.n_train if not self.data.synthetic else self._train.shape[0]
+        n_val = self.data.n_val if not self.data.synthetic else self._val.shape[0]
+        self.n_train_iter = n_train // (bs * world)
+        self.n_val_iter = n_val // (bs * world)
+
+    def _iterators(self):
+        c, bs = self.engine.ctx.comm, int(self.config["batch_size"])
+        tr = self._train[c.rank::c.world] if c.on else self._train
+        va = self._val[c.rank::c.world] if c.on else self._val
+        return BatchIterator(tr, bs, seed=self.cur_epoch), BatchIterator(va, bs, seed=self.cur_epoch, shuffle=False)
+
+    def compute_cur_lr(self):
+        """Piecewise schedule of codes/trainers.py:200-209."""
+        e, lr0 = self.cur_epoch, float(self.config["learning_rate_ae"])
+        if e <= 25:
+            self.cur_lr = lr0 * (0.99 ** (e - 1))
+        elif e <= 50:
+            self.cur_lr = lr0 / 2 * (0.99 ** (e - 25))
+        elif e <= 75:
+            self.cur_lr = lr0 / 5 * (0.99 ** (e - 50))
+        else:
+            self.cur_lr = lr0 / 10 * (0.99 ** (e - 75))

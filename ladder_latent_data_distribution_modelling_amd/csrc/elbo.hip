@@ -1,0 +1,581 @@
+// ELBO-side kernels of the LaDDer path for gfx950: latent blocks, pixel reductions, the Gaussian-mixture
+// hyper-prior log-prob (+ responsibilities-weighted gradient) with wavefront-shuffle logsumexp, the scalar
+// algebra of define_loss (codes/base.py:257-413) evaluated ON DEVICE so the step never syncs with the host,
+// fused clip+Adam, and a Philox normal generator.
+#include "common.h"
+
+namespace {
+
+constexpr double kLog2Pi = 1.8378770664093453;
+
+// ----------------------------------------------------------------------------- block reduction helper
+// 256 threads; returns the block total in every thread of wave 0 (others undefined). Fixed order.
+__device__ __forceinline__ double block_sum_256(double v, double* sm /*[4]*/) {
+  v = wave_sum_d(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+// ----------------------------------------------------------------------------- pixel terms
+__global__ __launch_bounds__(256) void pixel_partials_stage1(const float* __restrict__ x, const float* __restrict__ xh, size_t n,
+                                                             double* __restrict__ ws) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t n4 = n / 4;
+  float a = 0.f, q = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 u = reinterpret_cast<const float4*>(x)[i], v = reinterpret_cast<const float4*>(xh)[i];
+    const float d0 = u.x - v.x, d1 = u.y - v.y, d2 = u.z - v.z, d3 = u.w - v.w;
+    a += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
+    q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  }
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float d0 = x[i] - xh[i];
+    a += fabsf(d0);
+    q += d0 * d0;
+  }
+  __shared__ double sm[4];
+  const double ta = block_sum_256((double)a, sm);
+  const double tq = block_sum_256((double)q, sm);
+  if (threadIdx.x == 0) {
+    ws[2 * blockIdx.x] = ta;
+    ws[2 * blockIdx.x + 1] = tq;
+  }
+}
+__global__ void pixel_partials_stage2(const double* __restrict__ ws, int nblk, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double a = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+      a += ws[2 * b];
+      q += ws[2 * b + 1];
+    }
+    out[0] = (float)a;
+    out[1] = (float)q;
+  }
+}
+inline int pixel_nblk(size_t n) {
+  size_t g = (n / 4 + 255) / 256;
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+__global__ void pixel_grad_kernel(const float* __restrict__ x, const float* __restrict__ xh, const float* __restrict__ coef,
+                                  float* __restrict__ dxh, size_t n) {
+  const float g = coef[0];
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float d = xh[i] - x[i];
+    dxh[i] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+  }
+}
+
+// ----------------------------------------------------------------------------- latent blocks (single workgroup: B*Z is tiny)
+__global__ __launch_bounds__(256) void latent_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ sd_raw,
+                                                         const float* __restrict__ eps, float lvp, float* __restrict__ z,
+                                                         float* __restrict__ sd, float* __restrict__ p_log,
+                                                         float* __restrict__ p_mu2sd2, float* __restrict__ p_sdsum, int B, int Z) {
+  const int n = B * Z;
+  double slog = 0.0, ssq = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float s = sd_raw[i] + lvp, m = mu[i];
+    sd[i] = s;
+    if (z != nullptr) z[i] = m + s * eps[i];
+    slog += (double)logf(s);
+    ssq += (double)(m * m + s * s);
+  }
+  __shared__ double sm[4];
+  const double a = block_sum_256(slog, sm);
+  const double b = block_sum_256(ssq, sm);
+  if (threadIdx.x == 0) {
+    p_log[0] = (float)a;
+    p_mu2sd2[0] = (float)b;
+  }
+  if (p_sdsum != nullptr)
+    for (int j = threadIdx.x; j < Z; j += 256) {
+      double s = 0.0;
+      for (int bb = 0; bb < B; ++bb) s += (double)(sd_raw[bb * Z + j] + lvp);
+      p_sdsum[j] = (float)s;
+    }
+}
+
+__global__ __launch_bounds__(256) void code_partials_kernel(const float* __restrict__ z, const float* __restrict__ zhat,
+                                                            const float* __restrict__ sd_z, int use_mask, float* __restrict__ out, int n) {
+  double e = 0.0, q = 0.0, a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float d = z[i] - zhat[i];
+    float err = d * d;
+    if (use_mask && sd_z[i] > 1.f) err = 0.f;
+    e += (double)err;
+    q += (double)sqrtf(err);
+    a += (double)fabsf(d);
+  }
+  __shared__ double sm[4];
+  const double te = block_sum_256(e, sm), tq = block_sum_256(q, sm), ta = block_sum_256(a, sm);
+  if (threadIdx.x == 0) {
+    out[0] = (float)te;
+    out[1] = (float)tq;
+    out[2] = (float)ta;
+  }
+}
+
+__global__ void code_grad_kernel(const float* __restrict__ z, const float* __restrict__ zhat, const float* __restrict__ sd_z,
+                                 int use_mask, const float* __restrict__ scal, float* __restrict__ dz_accum,
+                                 float* __restrict__ dzhat, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float g = 2.f * scal[LADDER_S_G_CODE];
+  float d = z[i] - zhat[i];
+  if (use_mask && sd_z[i] > 1.f) d = 0.f;
+  if (dz_accum != nullptr) dz_accum[i] += g * d;
+  dzhat[i] = -g * d;
+}
+
+__global__ void latent_bwd_kernel(const float* __restrict__ g_sample, const float* __restrict__ mu, const float* __restrict__ sd,
+                                  const float* __restrict__ sd_raw, const float* __restrict__ eps, const float* __restrict__ extra_mu,
+                                  const float* __restrict__ extra_sd, float extra_sign, const float* __restrict__ scal, int mode,
+                                  float* __restrict__ dmu, float* __restrict__ dsd_raw, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float invB = scal[LADDER_S_INV_B], invLB = scal[LADDER_S_INV_LB];
+  const float g = g_sample != nullptr ? g_sample[i] : 0.f;
+  float gm = g, gs = g * eps[i];
+  if (mode & 1) gs -= invB / sd[i];
+  if (mode & 2) {
+    gm += mu[i] * invB;
+    gs += sd[i] * invB;
+  }
+  if (extra_mu != nullptr) {
+    gm += extra_sign * invLB * extra_mu[i];
+    gs += extra_sign * invLB * extra_sd[i];
+  }
+  dmu[i] = gm;
+  dsd_raw[i] = sd_raw[i] > 0.f ? gs : 0.f;
+}
+
+// ----------------------------------------------------------------------------- scalar algebra
+__global__ void elbo_finalize_kernel(const float* __restrict__ P, const float* __restrict__ sigma_var,
+                                     const float* __restrict__ inner_sigma_var, LadderElboCfg cfg, float* __restrict__ S) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double B = cfg.B_global, D = cfg.D, Z = cfg.Z, R = cfg.R, L = cfg.L;
+  const double sabs = P[LADDER_P_PIX_ABS];
+  const double mpe = sabs / (B * D);
+  const double sv = sigma_var[0];
+  const double sig0 = fabs(sv);
+  const bool branch_mpe = cfg.sigma_uses_mpe && (mpe > sig0);  // tf.maximum: gradient to the first arg on ties
+  const double sigma = branch_mpe ? mpe : sig0;
+  const double l1 = sabs / B, l2 = (double)P[LADDER_P_PIX_SQ] / B;
+  const double recon_ll = -l1 / sigma;
+  const double sigma_reg = -D * log(2.0 * sigma);
+  const double entropy_z = -0.5 * Z * kLog2Pi - 0.5 * Z - (double)P[LADDER_P_LOG_SDZ] / B;
+  const double xent_sg = -0.5 * Z * kLog2Pi - 0.5 * (double)P[LADDER_P_MU2SD2_Z] / B;
+  double xent_prior = xent_sg;
+  double g_code = 0.0, g_isv = 0.0;
+  if (cfg.has_inner) {
+    const double iv = inner_sigma_var[0];
+    const double is0 = fabs(iv);
+    double isg = is0;
+    bool pass = true;
+    if (cfg.clamp_inner_sigma) {  // tf.minimum(tf.maximum(s, lb), ub): base.py:211-212
+      const double lo = cfg.inner_sigma_lb, hi = cfg.inner_sigma_ub;
+      const double m1 = is0 >= lo ? is0 : lo;
+      pass = (is0 >= lo) && (m1 <= hi);
+      isg = m1 <= hi ? m1 : hi;
+    }
+    const double E = P[LADDER_P_CODE_ERR];
+    const double code_ll = -E / (2.0 * isg * isg * B);
+    const double rep_reg = -Z * log(isg) - 0.5 * Z * kLog2Pi;
+    const double entropy_t = -0.5 * R * kLog2Pi - 0.5 * R - (double)P[LADDER_P_LOG_SDT] / B;
+    const double xent_t = (double)P[LADDER_P_LOGP] / (L * B);
+    const double elbo_prior = code_ll + rep_reg - entropy_t + xent_t;
+    S[LADDER_S_INNER_SIGMA] = (float)isg;
+    S[LADDER_S_MEAN_CODE_ERROR] = (float)((double)P[LADDER_P_CODE_ABS] / (B * Z));
+    S[LADDER_S_CODE_LL] = (float)code_ll;
+    S[LADDER_S_CODE_L1] = (float)((double)P[LADDER_P_CODE_SQRT] / B);
+    S[LADDER_S_REP_REG] = (float)rep_reg;
+    S[LADDER_S_ENTROPY_T] = (float)entropy_t;
+    S[LADDER_S_XENT_T] = (float)xent_t;
+    S[LADDER_S_ELBO_PRIOR] = (float)elbo_prior;
+    S[LADDER_S_LOSS_PRIOR] = (float)(-elbo_prior);
+    if (!cfg.use_sg) xent_prior = elbo_prior;
+    g_code = 1.0 / (2.0 * isg * isg * B);
+    const double sgn = iv > 0 ? 1.0 : (iv < 0 ? -1.0 : 0.0);
+    g_isv = pass ? (-E / (isg * isg * isg * B) + Z / isg) * sgn : 0.0;
+  }
+  const double elbo = recon_ll + sigma_reg - entropy_z + xent_prior;
+  const double dl_dsigma = -l1 / (sigma * sigma) + D / sigma;
+  const double sgn_s = sv > 0 ? 1.0 : (sv < 0 ? -1.0 : 0.0);
+  S[LADDER_S_SIGMA] = (float)sigma;
+  S[LADDER_S_MPE] = (float)mpe;
+  S[LADDER_S_ENTROPY_Z] = (float)entropy_z;
+  S[LADDER_S_XENT_SG] = (float)xent_sg;
+  S[LADDER_S_XENT_PRIOR] = (float)xent_prior;
+  S[LADDER_S_L1] = (float)l1;
+  S[LADDER_S_L2] = (float)l2;
+  S[LADDER_S_RECON_LL] = (float)recon_ll;
+  S[LADDER_S_SIGMA_REG] = (float)sigma_reg;
+  S[LADDER_S_ELBO] = (float)elbo;
+  S[LADDER_S_LOSS_AE] = (float)(-elbo);
+  S[LADDER_S_G_PIX] = (float)(1.0 / (sigma * B) + (branch_mpe ? dl_dsigma / (B * D) : 0.0));
+  S[LADDER_S_G_SIGMA_VAR] = (float)(branch_mpe ? 0.0 : dl_dsigma * sgn_s);
+  S[LADDER_S_G_CODE] = (float)g_code;
+  S[LADDER_S_G_INNER_SIGMA_VAR] = (float)g_isv;
+  S[LADDER_S_INV_B] = (float)(1.0 / B);
+  S[LADDER_S_INV_LB] = (float)(1.0 / (L * B));
+}
+
+// ----------------------------------------------------------------------------- mixture hyper-prior
+// packed[k] = { c_k = log w_k - log sum w - sum_i log L_ii - R/2 log 2pi, mean_k[R], Linv_k (lower tri, row-major) }
+template <int R>
+__global__ void gmm_prepare_kernel(const float* __restrict__ w, const float* __restrict__ m, const float* __restrict__ cov, int K,
+                                   float* __restrict__ packed) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  constexpr int STRIDE = 1 + R + R * (R + 1) / 2;
+  float wsum = 0.f;
+  for (int j = 0; j < K; ++j) wsum += w[j];
+  float Lm[R][R], Li[R][R];
+  const float* c = cov + (size_t)k * R * R;
+  float logdet = 0.f;
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      Lm[i][j] = 0.f;
+      Li[i][j] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) {       // Cholesky-Banachiewicz, fp32 like tf.linalg.cholesky on the fp32 feed
+    float s = c[j * R + j];
+#pragma unroll
+    for (int p = 0; p < R; ++p)
+      if (p < j) s -= Lm[j][p] * Lm[j][p];
+    const float djj = sqrtf(s);
+    Lm[j][j] = djj;
+    logdet += logf(djj);
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      if (i > j) {
+        float t = c[i * R + j];
+#pragma unroll
+        for (int p = 0; p < R; ++p)
+          if (p < j) t -= Lm[i][p] * Lm[j][p];
+        Lm[i][j] = t / djj;
+      }
+    }
+  }
+#pragma unroll
+  for (int col = 0; col < R; ++col) {  // Linv by forward substitution on the identity
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      if (i >= col) {
+        float t = (i == col) ? 1.f : 0.f;
+#pragma unroll
+        for (int p = 0; p < R; ++p)
+          if (p >= col && p < i) t -= Lm[i][p] * Li[p][col];
+        Li[i][col] = t / Lm[i][i];
+      }
+    }
+  }
+  float* o = packed + (size_t)k * STRIDE;
+  o[0] = logf(w[k]) - logf(wsum) - logdet - 0.5f * (float)R * (float)kLog2Pi;
+#pragma unroll
+  for (int j = 0; j < R; ++j) o[1 + j] = m[(size_t)k * R + j];
+  int q = 1 + R;
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+      if (j <= i) o[q++] = Li[i][j];
+}
+
+// One workgroup (4 wavefronts) per batch row b; wavefront w handles MC samples l = w, w+4, ...; lane = component.
+// Per sample: lp_k in-lane, logsumexp and the R gradient components reduced with wave shuffles.
+template <int R>
+__global__ __launch_bounds__(256) void gmm_logprob_kernel(const float* __restrict__ mu, const float* __restrict__ sd,
+                                                          const float* __restrict__ eps, const float* __restrict__ packed, int L,
+                                                          int B, int K, float* __restrict__ dmu, float* __restrict__ dsd,
+                                                          double* __restrict__ ws_logp) {
+  constexpr int STRIDE = 1 + R + R * (R + 1) / 2;
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nchunk = (K + 63) / 64;
+  float m_[R], s_[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    m_[j] = mu[(size_t)b * R + j];
+    s_[j] = sd[(size_t)b * R + j];
+  }
+  double acc_lp = 0.0;
+  float acc_mu[R], acc_sd[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) acc_mu[j] = acc_sd[j] = 0.f;
+
+  for (int l = wv; l < L; l += 4) {
+    float e_[R], t_[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      e_[j] = eps[((size_t)l * B + b) * R + j];
+      t_[j] = m_[j] + s_[j] * e_[j];
+    }
+    // pass 1: log-prob per component, running max
+    float mx = -INFINITY;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const int k = ch * 64 + lane;
+      float lp = -INFINITY;
+      if (k < K) {
+        const float* prm = packed + (size_t)k * STRIDE;
+        float maha = 0.f;
+        int q = 1 + R;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          float yi = 0.f;
+#pragma unroll
+          for (int j = 0; j < R; ++j)
+            if (j <= i) yi += prm[q++] * (t_[j] - prm[1 + j]);
+          maha += yi * yi;
+        }
+        lp = prm[0] - 0.5f * maha;
+      }
+      mx = fmaxf(mx, lp);
+    }
+    mx = wave_max(mx);
+    // pass 2: sum exp, gradient numerators
+    float se = 0.f, g_[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) g_[j] = 0.f;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const int k = ch * 64 + lane;
+      if (k < K) {
+        const float* prm = packed + (size_t)k * STRIDE;
+        float y_[R];
+        float maha = 0.f;
+        int q = 1 + R;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          float yi = 0.f;
+#pragma unroll
+          for (int j = 0; j < R; ++j)
+            if (j <= i) yi += prm[q++] * (t_[j] - prm[1 + j]);
+          y_[i] = yi;
+          maha += yi * yi;
+        }
+        const float ex = __expf(prm[0] - 0.5f * maha - mx);
+        se += ex;
+        q = 1 + R;
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+          for (int j = 0; j < R; ++j)
+            if (j <= i) g_[j] -= ex * prm[q++] * y_[i];   // -exp(.) * (Linv^T y)_j
+      }
+    }
+    se = wave_sum(se);
+    acc_lp += (double)(mx + logf(se));
+    const float inv = 1.f / se;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const float G = wave_sum(g_[j]) * inv;   // d lp / d t_j = -sum_k r_k (Sigma_k^-1 (t-m_k))_j
+      acc_mu[j] += G;
+      acc_sd[j] += G * e_[j];
+    }
+  }
+  __shared__ float sm_mu[4][R], sm_sd[4][R];
+  __shared__ double sm_lp[4];
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      sm_mu[wv][j] = acc_mu[j];
+      sm_sd[wv][j] = acc_sd[j];
+    }
+    sm_lp[wv] = acc_lp;
+  }
+  __syncthreads();
+  if (threadIdx.x < R) {
+    const int j = threadIdx.x;
+    dmu[(size_t)b * R + j] = (sm_mu[0][j] + sm_mu[1][j]) + (sm_mu[2][j] + sm_mu[3][j]);
+    dsd[(size_t)b * R + j] = (sm_sd[0][j] + sm_sd[1][j]) + (sm_sd[2][j] + sm_sd[3][j]);
+  }
+  if (threadIdx.x == 0) ws_logp[b] = (sm_lp[0] + sm_lp[1]) + (sm_lp[2] + sm_lp[3]);
+}
+__global__ void gmm_sum_kernel(const double* __restrict__ ws, int B, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int b = 0; b < B; ++b) s += ws[b];
+    out[0] = (float)s;
+  }
+}
+
+// ----------------------------------------------------------------------------- clip + Adam (TF form)
+__global__ void adam_clip_kernel(float* __restrict__ theta, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                 size_t n, float lr_t, float b1, float b2, float eps, float clip) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float gi = g[i];
+    gi = fminf(fmaxf(gi, -clip), clip);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    theta[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+// ----------------------------------------------------------------------------- Philox4x32-10 normals
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__global__ void randn_kernel(float* __restrict__ out, size_t n, uint64_t seed, uint64_t offset) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // 4 normals per thread
+  if (q * 4 >= n) return;
+  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  float o[4];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const float u1 = ((float)(c[2 * p] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c[2 * p + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float rr = sqrtf(-2.f * logf(u1));
+    float sn, cs;
+    sincosf(6.28318530717958647692f * u2, &sn, &cs);
+    o[2 * p] = rr * cs;
+    o[2 * p + 1] = rr * sn;
+  }
+  for (int j = 0; j < 4; ++j)
+    if (q * 4 + j < n) out[q * 4 + j] = o[j];
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ladder_pixel_partials_workspace_bytes(size_t n) { return (size_t)pixel_nblk(n) * 2 * sizeof(double); }
+
+int ladder_pixel_partials(const float* x, const float* xhat, size_t n, float* out, void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  if (n == 0) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(x) || !ladder_aligned16(xhat)) return LADDER_E_ALIGN;
+  const int nblk = pixel_nblk(n);
+  if (ws_bytes < (size_t)nblk * 2 * sizeof(double)) return LADDER_E_WORKSPACE;
+  hipLaunchKernelGGL(pixel_partials_stage1, dim3(nblk), dim3(256), 0, stream, x, xhat, n, (double*)ws);
+  hipLaunchKernelGGL(pixel_partials_stage2, dim3(1), dim3(64), 0, stream, (const double*)ws, nblk, out);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_pixel_grad(const float* x, const float* xhat, const float* coef, float* dxhat, size_t n, ladder_stream_t stream) {
+  if (n == 0) return LADDER_E_SHAPE;
+  size_t g = (n + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(pixel_grad_kernel, dim3((unsigned)g), dim3(256), 0, stream, x, xhat, coef, dxhat, n);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_latent_fwd(const float* mu, const float* sd_raw, const float* eps, float lvp, float* z, float* sd, float* p_log,
+                      float* p_mu2sd2, float* p_sdsum, int B, int Z, ladder_stream_t stream) {
+  if (B <= 0 || Z <= 0) return LADDER_E_SHAPE;
+  hipLaunchKernelGGL(latent_fwd_kernel, dim3(1), dim3(256), 0, stream, mu, sd_raw, eps, lvp, z, sd, p_log, p_mu2sd2, p_sdsum, B, Z);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_code_partials(const float* z, const float* zhat, const float* sd_z, int use_mask, float* out, int B, int Z,
+                         ladder_stream_t stream) {
+  if (B <= 0 || Z <= 0) return LADDER_E_SHAPE;
+  hipLaunchKernelGGL(code_partials_kernel, dim3(1), dim3(256), 0, stream, z, zhat, sd_z, use_mask, out, B * Z);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_code_grad(const float* z, const float* zhat, const float* sd_z, int use_mask, const float* scalars, float* dz_accum,
+                     float* dzhat, int B, int Z, ladder_stream_t stream) {
+  if (B <= 0 || Z <= 0) return LADDER_E_SHAPE;
+  const int n = B * Z;
+  hipLaunchKernelGGL(code_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, z, zhat, sd_z, use_mask, scalars, dz_accum, dzhat, n);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_latent_bwd(const float* g_sample, const float* mu, const float* sd, const float* sd_raw, const float* eps,
+                      const float* extra_mu, const float* extra_sd, float extra_sign, const float* scalars, int mode, float* dmu,
+                      float* dsd_raw, int B, int Z, ladder_stream_t stream) {
+  if (B <= 0 || Z <= 0) return LADDER_E_SHAPE;
+  const int n = B * Z;
+  hipLaunchKernelGGL(latent_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, g_sample, mu, sd, sd_raw, eps, extra_mu, extra_sd,
+                     extra_sign, scalars, mode, dmu, dsd_raw, n);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_elbo_finalize(const float* partials, const float* sigma_var, const float* inner_sigma_var, LadderElboCfg cfg,
+                         float* scalars, ladder_stream_t stream) {
+  if (cfg.B_global <= 0 || cfg.D <= 0 || cfg.Z <= 0) return LADDER_E_SHAPE;
+  hipLaunchKernelGGL(elbo_finalize_kernel, dim3(1), dim3(64), 0, stream, partials, sigma_var, inner_sigma_var, cfg, scalars);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_gmm_packed_stride(int R) { return 1 + R + R * (R + 1) / 2; }
+
+#define LADDER_R_SWITCH(R, ...) \
+  switch (R) {                   \
+    case 1: { constexpr int RR = 1; __VA_ARGS__; } break; \
+    case 2: { constexpr int RR = 2; __VA_ARGS__; } break; \
+    case 3: { constexpr int RR = 3; __VA_ARGS__; } break; \
+    case 4: { constexpr int RR = 4; __VA_ARGS__; } break; \
+    case 5: { constexpr int RR = 5; __VA_ARGS__; } break; \
+    case 6: { constexpr int RR = 6; __VA_ARGS__; } break; \
+    case 7: { constexpr int RR = 7; __VA_ARGS__; } break; \
+    case 8: { constexpr int RR = 8; __VA_ARGS__; } break; \
+    default: return LADDER_E_SHAPE;                \
+  }
+
+int ladder_gmm_prepare(const float* weights, const float* means, const float* covs, int K, int R, float* packed, ladder_stream_t stream) {
+  if (K <= 0 || K > 1024) return LADDER_E_SHAPE;
+  LADDER_R_SWITCH(R, hipLaunchKernelGGL(gmm_prepare_kernel<RR>, dim3((K + 63) / 64), dim3(64), 0, stream, weights, means, covs, K, packed));
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+size_t ladder_gmm_workspace_bytes(int L, int B) { (void)L; return (size_t)B * sizeof(double); }
+
+int ladder_gmm_logprob_fwd_bwd(const float* mu, const float* sd, const float* eps, const float* packed, int L, int B, int R, int K,
+                               float* sum_logp, float* dmu, float* dsd, void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  if (L <= 0 || B <= 0 || K <= 0 || K > 1024) return LADDER_E_SHAPE;
+  if (ws_bytes < (size_t)B * sizeof(double)) return LADDER_E_WORKSPACE;
+  LADDER_R_SWITCH(R, hipLaunchKernelGGL(gmm_logprob_kernel<RR>, dim3(B), dim3(256), 0, stream, mu, sd, eps, packed, L, B, K, dmu, dsd, (double*)ws));
+  hipLaunchKernelGGL(gmm_sum_kernel, dim3(1), dim3(64), 0, stream, (const double*)ws, B, sum_logp);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_adam_clip(float* theta, const float* g, float* m, float* v, size_t n, float lr_t, float beta1, float beta2, float eps,
+                     float clip, ladder_stream_t stream) {
+  if (n == 0) return LADDER_OK;
+  size_t gr = (n + 255) / 256;
+  if (gr > 2048) gr = 2048;
+  hipLaunchKernelGGL(adam_clip_kernel, dim3((unsigned)gr), dim3(256), 0, stream, theta, g, m, v, n, lr_t, beta1, beta2, eps, clip);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_randn(float* out, size_t n, uint64_t seed, uint64_t offset, ladder_stream_t stream) {
+  if (n == 0) return LADDER_OK;
+  const size_t q = (n + 3) / 4;
+  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, stream, out, n, seed, offset);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+}  // extern "C"

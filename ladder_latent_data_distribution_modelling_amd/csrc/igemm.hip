@@ -1,0 +1,588 @@
+// Implicit-GEMM convolution / dense kernels for gfx950 (MI355X), fp32 in / fp32 accumulate on the
+// matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain at the fp32 vector rate).
+//
+//   fwd / bwd_data / dense :  C[M x N] = A_gather[M x K] * B[K x N]
+//        M = N_img*Ho*Wo output pixels, N = Cout, K = KH*KW*Cin ordered (r,s,ci), ci fastest.
+//        A is gathered on the fly from the NHWC input (no im2col buffer): tap (r,s) of pixel
+//        (n,ho,wo) reads x[n, (ho*S + r - pad_t)/U, (wo*S + s - pad_l)/U, :] (U = 1 for a forward
+//        conv; U = stride with S = 1 for the backward-data pass of a strided conv, where only
+//        positions divisible by U exist).  B is the HWIO filter bank viewed as a row-major
+//        [K x Cout] matrix -- exactly the reference's checkpoint layout.
+//   bwd_filter / dense bwd_weight : dW[K x N] = A_gather^T[K x M] * dY[M x N], split over M with a
+//        fixed-order second-stage reduction (bit-reproducible).
+//
+// Tiling: 256-thread workgroups (4 wavefronts of 64), BMxBN output tile, each wavefront owns a
+// (BM/WM)x(BN/WN) sub-tile built from 32x32 MFMA blocks; K is consumed in 16-deep chunks staged
+// through double-buffered LDS (global -> registers issued before the MFMA block of the current
+// chunk, registers -> LDS after it, one barrier per chunk).  NHWC keeps ci contiguous, so every
+// global load is a 16-byte, 64-byte-per-row-segment coalesced access.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct IgemmDesc {
+  int N, H, W, Cin;      // gathered tensor
+  int Ho, Wo, Cout;      // GEMM-M spatial extent and GEMM-N
+  int KH, KW, stride, ups, pad_t, pad_l;
+  int M, K;
+  int act;
+};
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int BK = 16;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// One gathered element of A: returns pointer offset or -1 when the tap falls outside / between samples.
+__device__ __forceinline__ long gather_off(const IgemmDesc& d, long img, int bh, int bw, int r, int s, int ci) {
+  int nh = bh + r, nw = bw + s;
+  if (nh < 0 || nw < 0) return -1;
+  if (d.ups > 1) {
+    if ((nh % d.ups) | (nw % d.ups)) return -1;
+    nh /= d.ups;
+    nw /= d.ups;
+  }
+  if (nh >= d.H || nw >= d.W) return -1;
+  return img + ((long)nh * d.W + nw) * d.Cin + ci;
+}
+
+template <int BM, int BN, int WM, int WN, bool VECA, bool VECB>
+__global__ __launch_bounds__(kThreads) void igemm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             const IgemmDesc d, const int tiles_n) {
+  constexpr int LDA = BK + 1;  // odd row stride: conflict-free ds_read_b32 of A fragments
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+  constexpr int A_UNITS = BM * (BK / 4), B_UNITS = BK * (BN / 4);
+  constexpr int AU = (A_UNITS + kThreads - 1) / kThreads, BU = (B_UNITS + kThreads - 1) / kThreads;
+  static_assert(WM * WN == 4, "4 wavefronts");
+  __shared__ float As[2][BM * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int HoWo = d.Ho * d.Wo;
+
+  // per-thread A rows (fixed for the whole K loop)
+  int a_row[AU], a_kq[AU], a_bh[AU], a_bw[AU];
+  long a_img[AU];
+  bool a_ok[AU];
+#pragma unroll
+  for (int i = 0; i < AU; ++i) {
+    const int u = tid + i * kThreads;
+    a_row[i] = u >> 2;
+    a_kq[i] = u & 3;
+    const int m = m0 + a_row[i];
+    a_ok[i] = (u < A_UNITS) && (m < d.M);
+    const int mm = a_ok[i] ? m : 0;
+    const int n_img = mm / HoWo, rem = mm - n_img * HoWo;
+    const int ho = rem / d.Wo, wo = rem - ho * d.Wo;
+    a_bh[i] = ho * d.stride - d.pad_t;
+    a_bw[i] = wo * d.stride - d.pad_l;
+    a_img[i] = (long)n_img * d.H * d.W * d.Cin;
+  }
+  int b_kr[BU], b_nq[BU];
+#pragma unroll
+  for (int i = 0; i < BU; ++i) {
+    const int u = tid + i * kThreads;
+    b_kr[i] = u / (BN / 4);
+    b_nq[i] = u % (BN / 4);
+  }
+
+  float4 ra[AU], rb[BU];
+  auto load_chunk = [&](int c) {
+    const int k0 = c * BK;
+    if (VECA) {  // Cin % 16 == 0: the whole chunk lies inside one filter tap
+      const int rs = k0 / d.Cin, ci0 = k0 - rs * d.Cin;
+      const int r = rs / d.KW, s = rs - r * d.KW;
+#pragma unroll
+      for (int i = 0; i < AU; ++i) {
+        long off = a_ok[i] ? gather_off(d, a_img[i], a_bh[i], a_bw[i], r, s, ci0 + a_kq[i] * 4) : -1;
+        ra[i] = off >= 0 ? ld4(x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < AU; ++i) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = k0 + a_kq[i] * 4 + j;
+          v[j] = 0.f;
+          if (a_ok[i] && k < d.K) {
+            const int rs = k / d.Cin, ci = k - rs * d.Cin;
+            const int r = rs / d.KW, s = rs - r * d.KW;
+            const long off = gather_off(d, a_img[i], a_bh[i], a_bw[i], r, s, ci);
+            if (off >= 0) v[j] = x[off];
+          }
+        }
+        ra[i] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BU; ++i) {
+      const int k = k0 + b_kr[i], n = n0 + b_nq[i] * 4;
+      const bool inb = (tid + i * kThreads < B_UNITS) && k < d.K;
+      if (VECB) {
+        rb[i] = (inb && n < d.Cout) ? ld4(w + (long)k * d.Cout + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (inb && n + j < d.Cout) ? w[(long)k * d.Cout + n + j] : 0.f;
+        rb[i] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AU; ++i) {
+      if (tid + i * kThreads < A_UNITS) {
+        float* p = &As[buf][a_row[i] * LDA + a_kq[i] * 4];
+        p[0] = ra[i].x; p[1] = ra[i].y; p[2] = ra[i].z; p[3] = ra[i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BU; ++i) {
+      if (tid + i * kThreads < B_UNITS)
+        *reinterpret_cast<float4*>(&Bs[buf][b_kr[i] * BN + b_nq[i] * 4]) = rb[i];
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  const int nchunks = (d.K + BK - 1) / BK;
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) load_chunk(c + 1);
+    const float* Ab = &As[buf][(wm * TM + l31) * LDA + lh];
+    const float* Bb = &Bs[buf][lh * BN + wn * TN + l31];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[MI], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = Ab[mi * 32 * LDA + kk];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b[ni] = Bb[kk * BN + ni * 32];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+    if (c + 1 < nchunks) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: bias + activation, 128-byte row segments per half-wave
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + wn * TN + ni * 32 + l31;
+    const float bv = (bias != nullptr && n < d.Cout) ? bias[n] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * TM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (m < d.M && n < d.Cout) y[(long)m * d.Cout + n] = ladder_act_fn(acc[mi][ni][e] + bv, d.act);
+      }
+    }
+  }
+}
+
+// dW[K x N] (+= over pixel split) = A_gather^T * dY.  GEMM-M here is the filter index k' = (r,s,ci).
+template <int BM, int BN, int WM, int WN, bool VECA, bool VECB>
+__global__ __launch_bounds__(kThreads) void igemm_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ out, const IgemmDesc d,
+                                                               const int tiles_n, const int m_per_split) {
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+  constexpr int A_UNITS = BK * (BM / 4), B_UNITS = BK * (BN / 4);
+  constexpr int AU = (A_UNITS + kThreads - 1) / kThreads, BU = (B_UNITS + kThreads - 1) / kThreads;
+  __shared__ __attribute__((aligned(16))) float At[2][BK * BM];
+  __shared__ __attribute__((aligned(16))) float Bt[2][BK * BN];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN;
+  const int tile = blockIdx.x;
+  const int k0t = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int HoWo = d.Ho * d.Wo;
+  const int p_begin = blockIdx.y * m_per_split;
+  const int p_end = min(d.M, p_begin + m_per_split);
+
+  // per-thread filter coordinates (fixed) for the A tile
+  int a_pr[AU], a_kq[AU], a_r[AU][VECA ? 1 : 4], a_s[AU][VECA ? 1 : 4], a_ci[AU][VECA ? 1 : 4];
+  bool a_kok[AU][VECA ? 1 : 4];
+#pragma unroll
+  for (int i = 0; i < AU; ++i) {
+    const int u = tid + i * kThreads;
+    a_pr[i] = u / (BM / 4);
+    a_kq[i] = u % (BM / 4);
+#pragma unroll
+    for (int j = 0; j < (VECA ? 1 : 4); ++j) {
+      const int k = k0t + a_kq[i] * 4 + j;
+      a_kok[i][j] = (u < A_UNITS) && k < d.K;
+      const int kk = a_kok[i][j] ? k : 0;
+      const int rs = kk / d.Cin;
+      a_ci[i][j] = kk - rs * d.Cin;
+      a_r[i][j] = rs / d.KW;
+      a_s[i][j] = rs - a_r[i][j] * d.KW;
+    }
+  }
+  int b_pr[BU], b_nq[BU];
+#pragma unroll
+  for (int i = 0; i < BU; ++i) {
+    const int u = tid + i * kThreads;
+    b_pr[i] = u / (BN / 4);
+    b_nq[i] = u % (BN / 4);
+  }
+
+  float4 ra[AU], rb[BU];
+  auto load_chunk = [&](int c) {
+    const int pc = p_begin + c * BK;
+#pragma unroll
+    for (int i = 0; i < AU; ++i) {
+      const int p = pc + a_pr[i];
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p < p_end) {
+        const int n_img = p / HoWo, rem = p - n_img * HoWo;
+        const int ho = rem / d.Wo, wo = rem - ho * d.Wo;
+        const long img = (long)n_img * d.H * d.W * d.Cin;
+        const int bh = ho * d.stride - d.pad_t, bw = wo * d.stride - d.pad_l;
+        if (VECA) {
+          if (a_kok[i][0]) {
+            const long off = gather_off(d, img, bh, bw, a_r[i][0], a_s[i][0], a_ci[i][0]);
+            if (off >= 0) {
+              const float4 t = ld4(x + off);
+              v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (a_kok[i][VECA ? 0 : j]) {
+              const long off = gather_off(d, img, bh, bw, a_r[i][VECA ? 0 : j], a_s[i][VECA ? 0 : j], a_ci[i][VECA ? 0 : j]);
+              if (off >= 0) v[j] = x[off];
+            }
+          }
+        }
+      }
+      ra[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+#pragma unroll
+    for (int i = 0; i < BU; ++i) {
+      const int p = pc + b_pr[i], n = n0 + b_nq[i] * 4;
+      const bool inb = (tid + i * kThreads < B_UNITS) && p < p_end;
+      if (VECB) {
+        rb[i] = (inb && n < d.Cout) ? ld4(dy + (long)p * d.Cout + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (inb && n + j < d.Cout) ? dy[(long)p * d.Cout + n + j] : 0.f;
+        rb[i] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AU; ++i)
+      if (tid + i * kThreads < A_UNITS) *reinterpret_cast<float4*>(&At[buf][a_pr[i] * BM + a_kq[i] * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BU; ++i)
+      if (tid + i * kThreads < B_UNITS) *reinterpret_cast<float4*>(&Bt[buf][b_pr[i] * BN + b_nq[i] * 4]) = rb[i];
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  const int nchunks = (p_end - p_begin + BK - 1) / BK;
+  if (nchunks > 0) {
+    load_chunk(0);
+    store_chunk(0);
+  }
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) load_chunk(c + 1);
+    const float* Ab = &At[buf][lh * BM + wm * TM + l31];
+    const float* Bb = &Bt[buf][lh * BN + wn * TN + l31];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[MI], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = Ab[kk * BM + mi * 32];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b[ni] = Bb[kk * BN + ni * 32];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+    if (c + 1 < nchunks) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* o = out + (size_t)blockIdx.y * d.K * d.Cout;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + wn * TN + ni * 32 + l31;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int k = k0t + wm * TM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (k < d.K && n < d.Cout) o[(long)k * d.Cout + n] = acc[mi][ni][e];
+      }
+    }
+  }
+}
+
+__global__ void reduce_splits_kernel(const float* __restrict__ ws, float* __restrict__ out, int S, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int z = 0; z < S; ++z) s += ws[(size_t)z * n + i];  // fixed order
+  out[i] = s;
+}
+
+__global__ void flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wT, int KH, int KW, int Cin, int Cout) {
+  // wT[KH-1-r][KW-1-s][co][ci] = w[r][s][ci][co]; 32x32 LDS tile transpose per tap
+  __shared__ float t[32][33];
+  const int tap = blockIdx.z, r = tap / KW, s = tap % KW;
+  const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+  const float* src = w + (size_t)tap * Cin * Cout;
+  float* dst = wT + (size_t)((KH - 1 - r) * KW + (KW - 1 - s)) * Cin * Cout;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int ci = ci0 + i, co = co0 + threadIdx.x;
+    t[i][threadIdx.x] = (ci < Cin && co < Cout) ? src[(size_t)ci * Cout + co] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int co = co0 + i, ci = ci0 + threadIdx.x;
+    if (co < Cout && ci < Cin) dst[(size_t)co * Cin + ci] = t[threadIdx.x][i];
+  }
+}
+
+// column sums of a [rows, C] matrix: stage 1 (row-chunks x column-blocks) -> ws, stage 2 fixed-order sum.
+__global__ void colsum_stage1(const float* __restrict__ x, float* __restrict__ ws, size_t rows, int C, size_t rows_per_blk) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;  // 4 row lanes
+  const size_t r0 = (size_t)blockIdx.y * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
+  float s = 0.f;
+  if (c < C)
+    for (size_t r = r0 + rl; r < r1; r += 4) s += x[r * C + c];
+  __shared__ float sm[4][64];
+  sm[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) ws[(size_t)blockIdx.y * C + c] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+__global__ void colsum_stage2(const float* __restrict__ ws, float* __restrict__ out, int nblk, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)ws[(size_t)b * C + c];
+  out[c] = (float)s;
+}
+
+struct TileCfg { int bm, bn; };
+
+template <int BM, int BN, int WM, int WN>
+int launch_fwd(const float* x, const float* w, const float* bias, float* y, const IgemmDesc& d, hipStream_t st) {
+  const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.Cout + BN - 1) / BN;
+  const bool veca = (d.Cin % BK) == 0, vecb = (d.Cout % 4) == 0;
+  dim3 grid(tiles_m * tiles_n), block(kThreads);
+  if (veca && vecb) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, x, w, bias, y, d, tiles_n);
+  else if (veca) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, st, x, w, bias, y, d, tiles_n);
+  else if (vecb) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, st, x, w, bias, y, d, tiles_n);
+  else hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, x, w, bias, y, d, tiles_n);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int dispatch_fwd(const float* x, const float* w, const float* bias, float* y, const IgemmDesc& d, hipStream_t st) {
+  if (d.M <= 0 || d.K <= 0 || d.Cout <= 0) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(x) || !ladder_aligned16(w) || !ladder_aligned16(y)) return LADDER_E_ALIGN;
+  const long big_tiles = (long)((d.M + 127) / 128) * ((d.Cout + 127) / 128);
+  if (d.Cout > 64) {
+    if (big_tiles >= 192) return launch_fwd<128, 128, 2, 2>(x, w, bias, y, d, st);
+    if (d.M > 32) return launch_fwd<64, 64, 2, 2>(x, w, bias, y, d, st);
+    return launch_fwd<32, 128, 1, 4>(x, w, bias, y, d, st);
+  }
+  if (d.Cout > 32) {
+    if ((d.M + 127) / 128 >= 192) return launch_fwd<128, 64, 4, 1>(x, w, bias, y, d, st);
+    return launch_fwd<64, 64, 2, 2>(x, w, bias, y, d, st);
+  }
+  return launch_fwd<128, 32, 4, 1>(x, w, bias, y, d, st);
+}
+
+// ---- wgrad planning (shared by the workspace query and the launcher)
+struct WgradPlan { int bm, bn, tiles_k, tiles_n, splits, m_per_split; };
+WgradPlan plan_wgrad(long M, int K, int Cout) {
+  WgradPlan p;
+  p.bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
+  p.bm = (K > 64 || p.bn != 64) ? 128 : 64;
+  if (p.bn == 128 && K <= 64) { p.bm = 64; p.bn = 64; }
+  p.tiles_k = (K + p.bm - 1) / p.bm;
+  p.tiles_n = (Cout + p.bn - 1) / p.bn;
+  const long tiles = (long)p.tiles_k * p.tiles_n;
+  long s = (1024 + tiles - 1) / tiles;             // aim for ~4 workgroups per CU
+  const long max_s = (M + 255) / 256;              // at least 256 pixels (16 chunks) per split
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  if (s > 512) s = 512;
+  long mps = (M + s - 1) / s;
+  mps = (mps + BK - 1) / BK * BK;
+  p.m_per_split = (int)mps;
+  p.splits = (int)((M + mps - 1) / mps);
+  return p;
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_wgrad(const float* x, const float* dy, float* out, const IgemmDesc& d, const WgradPlan& p, hipStream_t st) {
+  const bool veca = (d.Cin % 4) == 0, vecb = (d.Cout % 4) == 0;
+  dim3 grid(p.tiles_k * p.tiles_n, p.splits), block(kThreads);
+  if (veca && vecb) hipLaunchKernelGGL((igemm_wgrad_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, x, dy, out, d, p.tiles_n, p.m_per_split);
+  else if (veca) hipLaunchKernelGGL((igemm_wgrad_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, st, x, dy, out, d, p.tiles_n, p.m_per_split);
+  else if (vecb) hipLaunchKernelGGL((igemm_wgrad_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, st, x, dy, out, d, p.tiles_n, p.m_per_split);
+  else hipLaunchKernelGGL((igemm_wgrad_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, x, dy, out, d, p.tiles_n, p.m_per_split);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+size_t colsum_ws_bytes(size_t rows, int C) {
+  size_t nblk = (rows + 1023) / 1024;
+  if (nblk > 1024) nblk = 1024;
+  if (nblk < 1) nblk = 1;
+  return nblk * (size_t)C * sizeof(float);
+}
+
+int run_colsum(const float* x, float* out, size_t rows, int C, void* ws, size_t ws_bytes, hipStream_t st) {
+  size_t nblk = (rows + 1023) / 1024;
+  if (nblk > 1024) nblk = 1024;
+  if (nblk < 1) nblk = 1;
+  if (ws_bytes < nblk * (size_t)C * sizeof(float)) return LADDER_E_WORKSPACE;
+  const size_t rpb = (rows + nblk - 1) / nblk;
+  dim3 g1((C + 63) / 64, (unsigned)nblk);
+  hipLaunchKernelGGL(colsum_stage1, g1, dim3(256), 0, st, x, (float*)ws, rows, C, rpb);
+  hipLaunchKernelGGL(colsum_stage2, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)ws, out, (int)nblk, C);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+size_t wgrad_ws_bytes(long M, int K, int Cout) {
+  const WgradPlan p = plan_wgrad(M, K, Cout);
+  size_t a = p.splits > 1 ? (size_t)p.splits * K * Cout * sizeof(float) : 0;
+  size_t b = colsum_ws_bytes((size_t)M, Cout);
+  return a > b ? a : b;   // bias-grad colsum reuses the buffer after the split reduction
+}
+
+int run_wgrad(const float* x, const float* dy, float* dw, float* db, const IgemmDesc& d, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (d.M <= 0 || d.K <= 0 || d.Cout <= 0) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(x) || !ladder_aligned16(dy) || !ladder_aligned16(dw)) return LADDER_E_ALIGN;
+  if (ws_bytes < wgrad_ws_bytes(d.M, d.K, d.Cout)) return LADDER_E_WORKSPACE;
+  const WgradPlan p = plan_wgrad(d.M, d.K, d.Cout);
+  float* out = p.splits > 1 ? (float*)ws : dw;
+  int rc;
+  if (p.bm == 128 && p.bn == 128) rc = launch_wgrad<128, 128, 2, 2>(x, dy, out, d, p, st);
+  else if (p.bm == 128 && p.bn == 64) rc = launch_wgrad<128, 64, 4, 1>(x, dy, out, d, p, st);
+  else if (p.bm == 128 && p.bn == 32) rc = launch_wgrad<128, 32, 4, 1>(x, dy, out, d, p, st);
+  else rc = launch_wgrad<64, 64, 2, 2>(x, dy, out, d, p, st);
+  if (rc != LADDER_OK) return rc;
+  if (p.splits > 1) {
+    const size_t n = (size_t)d.K * d.Cout;
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws, dw, p.splits, n);
+    LADDER_CHECK_LAUNCH();
+  }
+  if (db != nullptr) return run_colsum(dy, db, (size_t)d.M, d.Cout, ws, ws_bytes, st);
+  return LADDER_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ladder_abi_version(void) { return 1; }
+
+int ladder_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin,
+                      int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int act,
+                      ladder_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return LADDER_E_SHAPE;
+  IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, 1, pad_t, pad_l, N * Ho * Wo, KH * KW * Cin, act};
+  return dispatch_fwd(x, w, bias, y, d, stream);
+}
+
+int ladder_filter_flip_transpose(const float* w, float* wT, int KH, int KW, int Cin, int Cout, ladder_stream_t stream) {
+  if (KH <= 0 || KW <= 0 || Cin <= 0 || Cout <= 0) return LADDER_E_SHAPE;
+  dim3 grid((Cout + 31) / 32, (Cin + 31) / 32, KH * KW), block(32, 8);
+  hipLaunchKernelGGL(flip_transpose_kernel, grid, block, 0, stream, w, wT, KH, KW, Cin, Cout);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_conv2d_bwd_data(const float* dy, const float* wT, float* dx, int N, int H, int W, int Cin, int Ho, int Wo,
+                           int Cout, int KH, int KW, int stride, int pad_t, int pad_l, ladder_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return LADDER_E_SHAPE;
+  // dx[hi] gathers dy[(hi + pad_t - r)/stride] = dy[(hi + r' - (KH-1-pad_t))/stride] with the flipped tap r'.
+  IgemmDesc d{N, Ho, Wo, Cout, H, W, Cin, KH, KW, 1, stride, KH - 1 - pad_t, KW - 1 - pad_l, N * H * W, KH * KW * Cout, LADDER_ACT_NONE};
+  return dispatch_fwd(dy, wT, nullptr, dx, d, stream);
+}
+
+size_t ladder_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW) {
+  (void)H; (void)W;
+  return wgrad_ws_bytes((long)N * Ho * Wo, KH * KW * Cin, Cout);
+}
+
+int ladder_conv2d_bwd_filter(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Ho,
+                             int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, void* ws, size_t ws_bytes,
+                             ladder_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return LADDER_E_SHAPE;
+  IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, 1, pad_t, pad_l, N * Ho * Wo, KH * KW * Cin, LADDER_ACT_NONE};
+  return run_wgrad(x, dy, dw, db, d, ws, ws_bytes, stream);
+}
+
+int ladder_dense_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act,
+                     ladder_stream_t stream) {
+  IgemmDesc d{M, 1, 1, K, 1, 1, N, 1, 1, 1, 1, 0, 0, M, K, act};
+  return dispatch_fwd(x, w, bias, y, d, stream);
+}
+
+int ladder_dense_bwd_data(const float* dy, const float* wT, float* dx, int M, int K, int N, ladder_stream_t stream) {
+  IgemmDesc d{M, 1, 1, N, 1, 1, K, 1, 1, 1, 1, 0, 0, M, N, LADDER_ACT_NONE};
+  return dispatch_fwd(dy, wT, nullptr, dx, d, stream);
+}
+
+size_t ladder_dense_bwd_weight_workspace_bytes(int M, int K, int N) { return wgrad_ws_bytes(M, K, N); }
+
+int ladder_dense_bwd_weight(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, void* ws,
+                            size_t ws_bytes, ladder_stream_t stream) {
+  IgemmDesc d{M, 1, 1, K, 1, 1, N, 1, 1, 1, 1, 0, 0, M, K, LADDER_ACT_NONE};
+  return run_wgrad(x, dy, dw, db, d, ws, ws_bytes, stream);
+}
+
+size_t ladder_colstats_workspace_bytes(size_t rows, int C) { return 2 * colsum_ws_bytes(rows, C); }
+
+int ladder_colsum(const float* x, float* out, size_t rows, int C, void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  if (rows == 0 || C <= 0) return LADDER_E_SHAPE;
+  return run_colsum(x, out, rows, C, ws, ws_bytes, stream);
+}
+
+}  // extern "C"

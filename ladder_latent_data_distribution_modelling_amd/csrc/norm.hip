@@ -1,0 +1,471 @@
+// HBM-bound passes of the LaDDer path for gfx950: batch-norm (train mode, two-phase so the host can
+// all-reduce the 2C statistics), instance-norm + style modulation + leaky-ReLU, TF1-legacy bilinear
+// resize, depth-to-space, symmetric pad, activation backward.  All tensors NHWC fp32: the channel
+// axis is contiguous, so a wavefront always touches >=256 contiguous bytes per row.
+#include "common.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------- column statistics
+// x viewed as [rows, C].  256 threads = 64 channels x 4 row-lanes; grid = (ceil(C/64), row-blocks).
+// MODE 1: (sum x, sum x^2)    MODE 2: BN backward (sum dp, sum dp*xhat)
+template <int MODE>
+__global__ __launch_bounds__(256) void colstats_stage1(const float* __restrict__ a, const float* __restrict__ b,
+                                                       const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ ws, size_t rows,
+                                                       int C, size_t rows_per_blk, int act) {
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const size_t r0 = (size_t)blockIdx.y * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C) {
+    if (MODE == 1) {
+      for (size_t r = r0 + rl; r < r1; r += 4) {
+        const float v = a[r * C + c];
+        s0 += v;
+        s1 += v * v;
+      }
+    } else {
+      const float mu = mean_rstd[c], rs = mean_rstd[C + c], g = gamma[c], be = beta[c];
+      for (size_t r = r0 + rl; r < r1; r += 4) {
+        const float xh = (b[r * C + c] - mu) * rs;
+        const float dp = a[r * C + c] * ladder_act_grad_from_out(g * xh + be, act);
+        s0 += dp;
+        s1 += dp * xh;
+      }
+    }
+  }
+  __shared__ float sm[2][4][64];
+  sm[0][rl][cl] = s0;
+  sm[1][rl][cl] = s1;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    ws[((size_t)blockIdx.y * 2 + 0) * C + c] = (sm[0][0][cl] + sm[0][1][cl]) + (sm[0][2][cl] + sm[0][3][cl]);
+    ws[((size_t)blockIdx.y * 2 + 1) * C + c] = (sm[1][0][cl] + sm[1][1][cl]) + (sm[1][2][cl] + sm[1][3][cl]);
+  }
+}
+__global__ void colstats_stage2(const float* __restrict__ ws, float* __restrict__ out, int nblk, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 2C
+  if (i >= 2 * C) return;
+  const int which = i / C, c = i - which * C;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)ws[((size_t)b * 2 + which) * C + c];
+  out[i] = (float)s;
+}
+
+size_t stats_nblk(size_t rows) {
+  size_t nblk = (rows + 511) / 512;
+  if (nblk > 2048) nblk = 2048;
+  if (nblk < 1) nblk = 1;
+  return nblk;
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, double count, float eps, float* __restrict__ mean_rstd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = (double)sums[c] / count;
+  double var = (double)sums[C + c] / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  mean_rstd[c] = (float)mean;
+  mean_rstd[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean_rstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ y, size_t n, int C, int act) {
+  // C % 4 == 0 path: float4 per thread, grid-stride
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n / 4; i += stride) {
+    const int c = (int)((i * 4) % C);
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 mu = *reinterpret_cast<const float4*>(mean_rstd + c);
+    const float4 rs = *reinterpret_cast<const float4*>(mean_rstd + C + c);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 be = *reinterpret_cast<const float4*>(beta + c);
+    float4 o;
+    o.x = ladder_act_fn(g.x * ((v.x - mu.x) * rs.x) + be.x, act);
+    o.y = ladder_act_fn(g.y * ((v.y - mu.y) * rs.y) + be.y, act);
+    o.z = ladder_act_fn(g.z * ((v.z - mu.z) * rs.z) + be.z, act);
+    o.w = ladder_act_fn(g.w * ((v.w - mu.w) * rs.w) + be.w, act);
+    reinterpret_cast<float4*>(y)[i] = o;
+  }
+}
+__global__ void bn_apply_scalar_kernel(const float* __restrict__ x, const float* __restrict__ mean_rstd,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       float* __restrict__ y, size_t n, int C, int act) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int c = (int)(i % C);
+    y[i] = ladder_act_fn(gamma[c] * ((x[i] - mean_rstd[c]) * mean_rstd[C + c]) + beta[c], act);
+  }
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                    const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const float* __restrict__ dsums, float inv_count,
+                                    float* __restrict__ dx, size_t n, int C, int act) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int c = (int)(i % C);
+    const float mu = mean_rstd[c], rs = mean_rstd[C + c], g = gamma[c];
+    const float xh = (x[i] - mu) * rs;
+    const float dp = dy[i] * ladder_act_grad_from_out(g * xh + beta[c], act);
+    dx[i] = g * rs * (dp - dsums[c] * inv_count - xh * dsums[C + c] * inv_count);
+  }
+}
+__global__ void bn_param_grad_kernel(const float* __restrict__ dsums, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dbeta[c] = dsums[c];
+  dgamma[c] = dsums[C + c];
+}
+
+// ----------------------------------------------------------------------------- instance norm + style + act
+// one workgroup per (sample n, 64-channel group); 4 row-lanes stride over HW.
+__device__ __forceinline__ float block_rowlane_sum(float v, float (*sm)[64], int rl, int cl) {
+  __syncthreads();
+  sm[rl][cl] = v;
+  __syncthreads();
+  return (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
+}
+
+__global__ __launch_bounds__(256) void in_style_fwd_kernel(const float* __restrict__ x, const float* __restrict__ style,
+                                                           float* __restrict__ y, float* __restrict__ mean_rstd, int HW, int C,
+                                                           float eps, int act) {
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int n = blockIdx.y, c = blockIdx.x * 64 + cl;
+  const bool ok = c < C;
+  const float* xp = x + (size_t)n * HW * C;
+  float* yp = y + (size_t)n * HW * C;
+  __shared__ float sm[4][64];
+  float s = 0.f;
+  if (ok)
+    for (int r = rl; r < HW; r += 4) s += xp[(size_t)r * C + c];
+  const float mean = block_rowlane_sum(s, sm, rl, cl) / (float)HW;
+  s = 0.f;
+  if (ok)
+    for (int r = rl; r < HW; r += 4) {
+      const float dlt = xp[(size_t)r * C + c] - mean;
+      s += dlt * dlt;
+    }
+  const float var = block_rowlane_sum(s, sm, rl, cl) / (float)HW;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  if (!ok) return;
+  const float s0 = style[(size_t)n * 2 * C + c] + 1.f, s1 = style[(size_t)n * 2 * C + C + c];
+  if (rl == 0) {
+    mean_rstd[(size_t)n * 2 * C + c] = mean;
+    mean_rstd[(size_t)n * 2 * C + C + c] = rstd;
+  }
+  for (int r = rl; r < HW; r += 4) {
+    const size_t i = (size_t)r * C + c;
+    yp[i] = ladder_act_fn((xp[i] - mean) * rstd * s0 + s1, act);
+  }
+}
+
+__global__ __launch_bounds__(256) void in_style_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ style, const float* __restrict__ mean_rstd,
+                                                           float* __restrict__ dx, float* __restrict__ dstyle, int HW, int C, int act) {
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int n = blockIdx.y, c = blockIdx.x * 64 + cl;
+  const bool ok = c < C;
+  const size_t base = (size_t)n * HW * C;
+  __shared__ float sm[4][64];
+  float mean = 0.f, rstd = 0.f, s0 = 0.f, s1 = 0.f;
+  if (ok) {
+    mean = mean_rstd[(size_t)n * 2 * C + c];
+    rstd = mean_rstd[(size_t)n * 2 * C + C + c];
+    s0 = style[(size_t)n * 2 * C + c] + 1.f;
+    s1 = style[(size_t)n * 2 * C + C + c];
+  }
+  float a0 = 0.f, a1 = 0.f;
+  if (ok)
+    for (int r = rl; r < HW; r += 4) {
+      const size_t i = base + (size_t)r * C + c;
+      const float xh = (x[i] - mean) * rstd;
+      const float dp = dy[i] * ladder_act_grad_from_out(xh * s0 + s1, act);
+      a0 += dp * xh;
+      a1 += dp;
+    }
+  const float ds0 = block_rowlane_sum(a0, sm, rl, cl);
+  const float ds1 = block_rowlane_sum(a1, sm, rl, cl);
+  if (!ok) return;
+  if (rl == 0) {
+    dstyle[(size_t)n * 2 * C + c] = ds0;
+    dstyle[(size_t)n * 2 * C + C + c] = ds1;
+  }
+  const float inv = 1.f / (float)HW;
+  for (int r = rl; r < HW; r += 4) {
+    const size_t i = base + (size_t)r * C + c;
+    const float xh = (x[i] - mean) * rstd;
+    const float dp = dy[i] * ladder_act_grad_from_out(xh * s0 + s1, act);
+    dx[i] = rstd * s0 * (dp - ds1 * inv - xh * ds0 * inv);
+  }
+}
+
+// ----------------------------------------------------------------------------- legacy bilinear resize (integer factors)
+template <int V>
+__global__ void resize_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C, int OH, int OW) {
+  const int CV = C / V;
+  const size_t total = (size_t)N * OH * OW * CV;
+  const int fy = OH / H, fx = OW / W;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int cv = (int)(i % CV);
+    size_t t = i / CV;
+    const int ox = (int)(t % OW);
+    t /= OW;
+    const int oy = (int)(t % OH);
+    const int n = (int)(t / OH);
+    const int ylo = oy / fy, xlo = ox / fx;
+    const int yhi = min(ylo + 1, H - 1), xhi = min(xlo + 1, W - 1);
+    const float yl = (float)(oy - ylo * fy) / (float)fy, xl = (float)(ox - xlo * fx) / (float)fx;
+    const float* p = x + (size_t)n * H * W * C + (size_t)cv * V;
+    float tl[V], tr[V], bl[V], br[V], o[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      tl[v] = p[((size_t)ylo * W + xlo) * C + v];
+      tr[v] = p[((size_t)ylo * W + xhi) * C + v];
+      bl[v] = p[((size_t)yhi * W + xlo) * C + v];
+      br[v] = p[((size_t)yhi * W + xhi) * C + v];
+      const float top = tl[v] + (tr[v] - tl[v]) * xl;
+      const float bot = bl[v] + (br[v] - bl[v]) * xl;
+      o[v] = top + (bot - top) * yl;
+    }
+    float* q = y + (((size_t)n * OH + oy) * OW + ox) * C + (size_t)cv * V;
+#pragma unroll
+    for (int v = 0; v < V; ++v) q[v] = o[v];
+  }
+}
+
+// transpose of the map above in gather form (no atomics): input pixel (iy,ix) collects every output
+// pixel whose lo or hi index equals it.
+template <int V>
+__global__ void resize_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C, int OH, int OW) {
+  const int CV = C / V;
+  const size_t total = (size_t)N * H * W * CV;
+  const int fy = OH / H, fx = OW / W;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int cv = (int)(i % CV);
+    size_t t = i / CV;
+    const int ix = (int)(t % W);
+    t /= W;
+    const int iy = (int)(t % H);
+    const int n = (int)(t / H);
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.f;
+    const int oy0 = max(0, (iy - 1) * fy), oy1 = min(OH, (iy + 1) * fy);
+    const int ox0 = max(0, (ix - 1) * fx), ox1 = min(OW, (ix + 1) * fx);
+    for (int oy = oy0; oy < oy1; ++oy) {
+      const int ylo = oy / fy, yhi = min(ylo + 1, H - 1);
+      const float yl = (float)(oy - ylo * fy) / (float)fy;
+      const float wy = (ylo == iy ? 1.f - yl : 0.f) + (yhi == iy ? yl : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = ox0; ox < ox1; ++ox) {
+        const int xlo = ox / fx, xhi = min(xlo + 1, W - 1);
+        const float xl = (float)(ox - xlo * fx) / (float)fx;
+        const float wx = (xlo == ix ? 1.f - xl : 0.f) + (xhi == ix ? xl : 0.f);
+        if (wx == 0.f) continue;
+        const float* q = dy + (((size_t)n * OH + oy) * OW + ox) * C + (size_t)cv * V;
+        const float wgt = wy * wx;
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] += wgt * q[v];
+      }
+    }
+    float* p = dx + (((size_t)n * H + iy) * W + ix) * C + (size_t)cv * V;
+#pragma unroll
+    for (int v = 0; v < V; ++v) p[v] = acc[v];
+  }
+}
+
+__global__ void d2s_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C, int r, int inverse) {
+  // forward: y[n, h*r+i, w*r+j, c'] = x[n, h, w, (i*r+j)*C' + c'] ; inverse swaps the roles.
+  const int Cp = C / (r * r);
+  const size_t total = (size_t)N * H * W * C;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+    const int cp = (int)(o % Cp);
+    size_t t = o / Cp;
+    const int ow = (int)(t % (W * r));
+    t /= (W * r);
+    const int oh = (int)(t % (H * r));
+    const int n = (int)(t / (H * r));
+    const int h = oh / r, i = oh - h * r, w = ow / r, j = ow - w * r;
+    const size_t small = (((size_t)n * H + h) * W + w) * C + (size_t)(i * r + j) * Cp + cp;
+    if (inverse) y[small] = x[o];
+    else y[o] = x[small];
+  }
+}
+
+__global__ void pad_sym_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C, int p) {
+  const int OH = H + 2 * p, OW = W + 2 * p;
+  const size_t total = (size_t)N * OH * OW * C;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+    const int c = (int)(o % C);
+    size_t t = o / C;
+    const int ow = (int)(t % OW);
+    t /= OW;
+    const int oh = (int)(t % OH);
+    const int n = (int)(t / OH);
+    int h = oh - p, w = ow - p;
+    h = h < 0 ? -h - 1 : (h >= H ? 2 * H - 1 - h : h);
+    w = w < 0 ? -w - 1 : (w >= W ? 2 * W - 1 - w : w);
+    y[o] = x[(((size_t)n * H + h) * W + w) * C + c];
+  }
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, size_t n, int act) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 g = reinterpret_cast<const float4*>(dy)[i];
+    const float4 v = reinterpret_cast<const float4*>(y)[i];
+    float4 o;
+    o.x = g.x * ladder_act_grad_from_out(v.x, act);
+    o.y = g.y * ladder_act_grad_from_out(v.y, act);
+    o.z = g.z * ladder_act_grad_from_out(v.z, act);
+    o.w = g.w * ladder_act_grad_from_out(v.w, act);
+    reinterpret_cast<float4*>(dx)[i] = o;
+  }
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    dx[i] = dy[i] * ladder_act_grad_from_out(y[i], act);
+}
+
+__global__ void axpy_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n, float scale, int accumulate) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = accumulate ? out[i] + scale * in[i] : scale * in[i];
+}
+
+inline unsigned ew_grid(size_t work_items) {
+  size_t g = (work_items + 255) / 256;
+  if (g > 256 * 8) g = 256 * 8;   // ~8 workgroups per CU, grid-stride the rest
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ladder_bn_fwd_stats(const float* x, float* sums, size_t rows, int C, void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  if (rows == 0 || C <= 0) return LADDER_E_SHAPE;
+  const size_t nblk = stats_nblk(rows);
+  if (ws_bytes < nblk * 2 * (size_t)C * sizeof(float)) return LADDER_E_WORKSPACE;
+  const size_t rpb = (rows + nblk - 1) / nblk;
+  hipLaunchKernelGGL(colstats_stage1<1>, dim3((C + 63) / 64, (unsigned)nblk), dim3(256), 0, stream, x, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)ws, rows, C, rpb, 0);
+  hipLaunchKernelGGL(colstats_stage2, dim3((2 * C + 255) / 256), dim3(256), 0, stream, (const float*)ws, sums, (int)nblk, C);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_bn_fwd_apply(const float* x, const float* sums, double count, const float* gamma, const float* beta, float* y,
+                        float* mean_rstd, size_t rows, int C, float eps, int act, ladder_stream_t stream) {
+  if (rows == 0 || C <= 0 || count <= 0) return LADDER_E_SHAPE;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sums, count, eps, mean_rstd, C);
+  const size_t n = rows * (size_t)C;
+  if (C % 4 == 0 && ladder_aligned16(x) && ladder_aligned16(y))
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, stream, x, mean_rstd, gamma, beta, y, n, C, act);
+  else
+    hipLaunchKernelGGL(bn_apply_scalar_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, x, mean_rstd, gamma, beta, y, n, C, act);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_bn_bwd_stats(const float* dy, const float* x, const float* mean_rstd, const float* gamma, const float* beta,
+                        float* dsums, size_t rows, int C, int act, void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  if (rows == 0 || C <= 0) return LADDER_E_SHAPE;
+  const size_t nblk = stats_nblk(rows);
+  if (ws_bytes < nblk * 2 * (size_t)C * sizeof(float)) return LADDER_E_WORKSPACE;
+  const size_t rpb = (rows + nblk - 1) / nblk;
+  hipLaunchKernelGGL(colstats_stage1<2>, dim3((C + 63) / 64, (unsigned)nblk), dim3(256), 0, stream, dy, x, mean_rstd, gamma, beta,
+                     (float*)ws, rows, C, rpb, act);
+  hipLaunchKernelGGL(colstats_stage2, dim3((2 * C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dsums, (int)nblk, C);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_bn_bwd_apply(const float* dy, const float* x, const float* mean_rstd, const float* gamma, const float* beta,
+                        const float* dsums, double count, float* dx, float* dgamma, float* dbeta, size_t rows, int C, int act,
+                        ladder_stream_t stream) {
+  if (rows == 0 || C <= 0 || count <= 0) return LADDER_E_SHAPE;
+  const size_t n = rows * (size_t)C;
+  if (dx != nullptr)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, dy, x, mean_rstd, gamma, beta, dsums,
+                       (float)(1.0 / count), dx, n, C, act);
+  if (dgamma != nullptr && dbeta != nullptr)
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, dsums, dgamma, dbeta, C);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+size_t ladder_bn_workspace_bytes(size_t rows, int C) { return stats_nblk(rows) * 2 * (size_t)C * sizeof(float); }
+
+int ladder_in_style_fwd(const float* x, const float* style, float* y, float* mean_rstd, int N, int HW, int C, float eps, int act,
+                        ladder_stream_t stream) {
+  if (N <= 0 || HW <= 0 || C <= 0) return LADDER_E_SHAPE;
+  hipLaunchKernelGGL(in_style_fwd_kernel, dim3((C + 63) / 64, N), dim3(256), 0, stream, x, style, y, mean_rstd, HW, C, eps, act);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_in_style_bwd(const float* dy, const float* x, const float* style, const float* mean_rstd, float* dx, float* dstyle,
+                        int N, int HW, int C, int act, ladder_stream_t stream) {
+  if (N <= 0 || HW <= 0 || C <= 0) return LADDER_E_SHAPE;
+  hipLaunchKernelGGL(in_style_bwd_kernel, dim3((C + 63) / 64, N), dim3(256), 0, stream, dy, x, style, mean_rstd, dx, dstyle, HW, C, act);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_resize_bilinear_fwd(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, ladder_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH < H || OW < W || OH % H || OW % W) return LADDER_E_SHAPE;
+  if (C % 4 == 0)
+    hipLaunchKernelGGL(resize_fwd_kernel<4>, dim3(ew_grid((size_t)N * OH * OW * (C / 4))), dim3(256), 0, stream, x, y, N, H, W, C, OH, OW);
+  else
+    hipLaunchKernelGGL(resize_fwd_kernel<1>, dim3(ew_grid((size_t)N * OH * OW * C)), dim3(256), 0, stream, x, y, N, H, W, C, OH, OW);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_resize_bilinear_bwd(const float* dy, float* dx, int N, int H, int W, int C, int OH, int OW, ladder_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH < H || OW < W || OH % H || OW % W) return LADDER_E_SHAPE;
+  if (C % 4 == 0)
+    hipLaunchKernelGGL(resize_bwd_kernel<4>, dim3(ew_grid((size_t)N * H * W * (C / 4))), dim3(256), 0, stream, dy, dx, N, H, W, C, OH, OW);
+  else
+    hipLaunchKernelGGL(resize_bwd_kernel<1>, dim3(ew_grid((size_t)N * H * W * C)), dim3(256), 0, stream, dy, dx, N, H, W, C, OH, OW);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_depth_to_space(const float* x, float* y, int N, int H, int W, int C, int r, int inverse, ladder_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || r <= 0 || C % (r * r)) return LADDER_E_SHAPE;
+  hipLaunchKernelGGL(d2s_kernel, dim3(ew_grid((size_t)N * H * W * C)), dim3(256), 0, stream, x, y, N, H, W, C, r, inverse);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_pad_symmetric(const float* x, float* y, int N, int H, int W, int C, int p, ladder_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || p < 0 || p > H || p > W) return LADDER_E_SHAPE;
+  hipLaunchKernelGGL(pad_sym_kernel, dim3(ew_grid((size_t)N * (H + 2 * p) * (W + 2 * p) * C)), dim3(256), 0, stream, x, y, N, H, W, C, p);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_act_bwd(const float* dy, const float* y, float* dx, size_t n, int act, ladder_stream_t stream) {
+  if (n == 0) return LADDER_OK;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, stream, dy, y, dx, n, act);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_axpy(const float* in, float* out, size_t n, float scale, int accumulate, ladder_stream_t stream) {
+  if (n == 0) return LADDER_OK;
+  hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, in, out, n, scale, accumulate);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+}  // extern "C"

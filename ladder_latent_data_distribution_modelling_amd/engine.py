@@ -1,0 +1,720 @@
+"""Host-side driver of the HIP LaDDer path: parameter store, layers with explicit backward,
+the three reference architectures and the four per-minibatch "runs" of the reference iteration
+(codes/base.py:583-641).  PyTorch supplies device memory, streams and torch.distributed only;
+every arithmetic op below is a call into libladder_hip.so (see _lib.py) -- there is no CPU path.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import arch
+
+BN_EPS = 1e-3      # tf.layers.batch_normalization default
+IN_EPS = 1e-6      # tf.contrib.layers.instance_norm default
+ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.95, 1e-8   # codes/base.py:459-461
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class Comm:
+    """Data-parallel exchange steps C1-C4 of SURVEY 2.3 over torch.distributed (RCCL on ROCm).
+    With world_size 1 every method is a no-op."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.group = group
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.rank = dist.get_rank(group) if self.on else 0
+
+    def allreduce_(self, t):
+        if self.on:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def broadcast_(self, t, src=0):
+        if self.on:
+            self.dist.broadcast(t, src=src, group=self.group)
+        return t
+
+
+class Ctx:
+    """Device context shared by all layers: stream handle, grow-only workspace, communicator."""
+
+    def __init__(self, device, comm=None):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.LadderHipError("the LaDDer HIP path needs a GPU device (got %s); there is no CPU fallback" % device)
+        L.load()
+        self.comm = comm or Comm()
+        self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
+
+    @property
+    def stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def ws(self, nbytes):
+        if self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+        return self._ws.data_ptr(), self._ws.numel()
+
+    def empty(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def zeros(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float32, device=self.device)
+
+
+class ParamStore:
+    """Flat fp32 buffers per optimiser group (theta, grad, m, v) with named views.
+
+    One flat gradient buffer per group = one all-reduce (C1/C4) and one clip+Adam launch (N11)."""
+
+    ALIGN = 64  # elements (256 B): keeps every view 16-byte aligned for float4 loads
+
+    def __init__(self, cfg, ctx, values=None, seed=1):
+        self.cfg, self.ctx = cfg, ctx
+        self.specs = arch.param_specs(cfg)
+        values = values if values is not None else arch.init_values(cfg, seed)
+        self.offsets, sizes = {}, {}
+        for name, shp in self.specs.items():
+            g = arch.group_of(name)
+            off = sizes.get(g, 0)
+            n = int(np.prod(shp)) if len(shp) else 1
+            self.offsets[name] = (g, off, n)
+            sizes[g] = off + (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.theta = {g: ctx.zeros(n) for g, n in sizes.items()}
+        self.grad = {g: ctx.zeros(n) for g, n in sizes.items()}
+        self.m = {g: ctx.zeros(n) for g, n in sizes.items()}
+        self.v = {g: ctx.zeros(n) for g, n in sizes.items()}
+        self.step = {g: 0 for g in sizes}
+        self.w, self.g = {}, {}
+        for name, shp in self.specs.items():
+            g, off, n = self.offsets[name]
+            self.w[name] = self.theta[g][off:off + n].view(*shp) if len(shp) else self.theta[g][off:off + 1]
+            self.g[name] = self.grad[g][off:off + n].view(*shp) if len(shp) else self.grad[g][off:off + 1]
+        self.load_dict(values)
+
+    def load_dict(self, values, strict=True):
+        for name in self.specs:
+            if name not in values:
+                if strict:
+                    raise KeyError("missing variable %s" % name)
+                continue
+            v = torch.as_tensor(np.asarray(values[name], np.float32).reshape(self.w[name].shape))
+            self.w[name].copy_(v.to(self.ctx.device))
+
+    def to_dict(self, groups=None):
+        return {n: self.w[n].detach().cpu().numpy().reshape(self.specs[n]) for n in self.specs
+                if groups is None or arch.group_of(n) in groups}
+
+    def num_params(self, prefix):
+        return sum(self.offsets[n][2] for n in self.specs if n.startswith(prefix))
+
+    def adam(self, group, lr, grad=None, n=None):
+        """clip to [-1,1] + TF-form Adam on the whole group (codes/base.py:459-517).  `grad` may be a
+        device pointer into the scalars vector (n = 1) for the two scalar optimisers."""
+        self.step[group] += 1
+        t = self.step[group]
+        lr_t = lr * math.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
+        g = self.grad[group] if grad is None else grad
+        L.call("ladder_adam_clip", _p(self.theta[group]), _p(g), _p(self.m[group]), _p(self.v[group]),
+               self.theta[group].numel() if n is None else n, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, 1.0, self.ctx.stream)
+
+
+# ------------------------------------------------------------------------------------------ layers
+class Conv2D:
+    """tf.layers.conv2d (NHWC / HWIO), bias + activation fused in the kernel epilogue."""
+
+    def __init__(self, ctx, ps, name, k, cin, cout, stride=1, padding="same", act=None):
+        self.ctx, self.ps, self.name = ctx, ps, name
+        self.k, self.cin, self.cout, self.stride, self.padding, self.act = k, cin, cout, stride, padding, act
+
+    def forward(self, x):
+        N, H, W, _ = x.shape
+        self.pt, Ho = arch.conv_out(H, self.k, self.stride, self.padding)
+        self.pl, Wo = arch.conv_out(W, self.k, self.stride, self.padding)
+        y = self.ctx.empty(N, Ho, Wo, self.cout)
+        L.call("ladder_conv2d_fwd", _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y),
+               N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl, L.ACT[self.act],
+               self.ctx.stream)
+        self.x, self.y = x, y
+        return y
+
+    def backward(self, dy, need_dx=True, wgrad=True):
+        x, y = self.x, self.y
+        N, H, W, _ = x.shape
+        _, Ho, Wo, _ = y.shape
+        st = self.ctx.stream
+        if self.act is not None:
+            L.call("ladder_act_bwd", _p(dy), _p(y), _p(dy), dy.numel(), L.ACT[self.act], st)
+        if wgrad:
+            nb = L.query("ladder_conv2d_bwd_filter_workspace_bytes", N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k)
+            wsp, wsn = self.ctx.ws(nb)
+            L.call("ladder_conv2d_bwd_filter", _p(x), _p(dy), _p(self.ps.g[self.name + "/kernel"]),
+                   _p(self.ps.g[self.name + "/bias"]), N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride,
+                   self.pt, self.pl, wsp, wsn, st)
+        dx = None
+        if need_dx:
+            w = self.ps.w[self.name + "/kernel"]
+            wT = self.ctx.empty(w.numel())
+            L.call("ladder_filter_flip_transpose", _p(w), _p(wT), self.k, self.k, self.cin, self.cout, st)
+            dx = self.ctx.empty(N, H, W, self.cin)
+            L.call("ladder_conv2d_bwd_data", _p(dy), _p(wT), _p(dx), N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k,
+                   self.stride, self.pt, self.pl, st)
+        self.x = self.y = None
+        return dx
+
+
+class Dense:
+    """tf.layers.dense, W [in,out]; MFMA-f32 GEMM with bias + activation epilogue."""
+
+    def __init__(self, ctx, ps, name, cin, cout, act=None):
+        self.ctx, self.ps, self.name, self.cin, self.cout, self.act = ctx, ps, name, cin, cout, act
+
+    def forward(self, x):
+        M = x.shape[0]
+        y = self.ctx.empty(M, self.cout)
+        L.call("ladder_dense_fwd", _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y),
+               M, self.cin, self.cout, L.ACT[self.act], self.ctx.stream)
+        self.x, self.y = x, y
+        return y
+
+    def backward(self, dy, need_dx=True, wgrad=True, act_done=False):
+        x, y, st = self.x, self.y, self.ctx.stream
+        M = x.shape[0]
+        if self.act is not None and not act_done:
+            L.call("ladder_act_bwd", _p(dy), _p(y), _p(dy), dy.numel(), L.ACT[self.act], st)
+        if wgrad:
+            nb = L.query("ladder_dense_bwd_weight_workspace_bytes", M, self.cin, self.cout)
+            wsp, wsn = self.ctx.ws(nb)
+            L.call("ladder_dense_bwd_weight", _p(x), _p(dy), _p(self.ps.g[self.name + "/kernel"]),
+                   _p(self.ps.g[self.name + "/bias"]), M, self.cin, self.cout, wsp, wsn, st)
+        dx = None
+        if need_dx:
+            w = self.ps.w[self.name + "/kernel"]
+            wT = self.ctx.empty(w.numel())
+            L.call("ladder_filter_flip_transpose", _p(w), _p(wT), 1, 1, self.cin, self.cout, st)
+            dx = self.ctx.empty(M, self.cin)
+            L.call("ladder_dense_bwd_data", _p(dy), _p(wT), _p(dx), M, self.cin, self.cout, st)
+        self.x = self.y = None
+        return dx
+
+
+class BatchNormAct:
+    """tf.layers.batch_normalization(training=True) + activation; statistics of the GLOBAL batch (C2)."""
+
+    def __init__(self, ctx, ps, name, C, act):
+        self.ctx, self.ps, self.name, self.C, self.act = ctx, ps, name, C, act
+
+    def forward(self, x):
+        C, ctx = self.C, self.ctx
+        rows = x.numel() // C
+        nb = L.query("ladder_bn_workspace_bytes", rows, C)
+        wsp, wsn = ctx.ws(nb)
+        sums = ctx.empty(2 * C)
+        L.call("ladder_bn_fwd_stats", _p(x), _p(sums), rows, C, wsp, wsn, ctx.stream)
+        ctx.comm.allreduce_(sums)
+        self.count = float(rows) * ctx.comm.world
+        y = torch.empty_like(x)
+        self.mean_rstd = ctx.empty(2 * C)
+        L.call("ladder_bn_fwd_apply", _p(x), _p(sums), self.count, _p(self.ps.w[self.name + "/gamma"]),
+               _p(self.ps.w[self.name + "/beta"]), _p(y), _p(self.mean_rstd), rows, C, BN_EPS, L.ACT[self.act], ctx.stream)
+        self.x = x
+        return y
+
+    def backward(self, dy, need_dx=True, wgrad=True):
+        C, ctx, x = self.C, self.ctx, self.x
+        rows = x.numel() // C
+        gam, bet = self.ps.w[self.name + "/gamma"], self.ps.w[self.name + "/beta"]
+        nb = L.query("ladder_bn_workspace_bytes", rows, C)
+        wsp, wsn = ctx.ws(nb)
+        dsums = ctx.empty(2 * C)
+        L.call("ladder_bn_bwd_stats", _p(dy), _p(x), _p(self.mean_rstd), _p(gam), _p(bet), _p(dsums), rows, C,
+               L.ACT[self.act], wsp, wsn, ctx.stream)
+        ctx.comm.allreduce_(dsums)
+        dx = torch.empty_like(x) if need_dx else None
+        # dgamma/dbeta are global sums already: written on every rank, the group all-reduce must not re-sum
+        # them -> the engine divides BN parameter grads by world size before the flat all-reduce.
+        L.call("ladder_bn_bwd_apply", _p(dy), _p(x), _p(self.mean_rstd), _p(gam), _p(bet), _p(dsums), self.count, _p(dx),
+               _p(self.ps.g[self.name + "/gamma"]) if wgrad else None, _p(self.ps.g[self.name + "/beta"]) if wgrad else None,
+               rows, C, L.ACT[self.act], ctx.stream)
+        if wgrad and ctx.comm.world > 1:
+            self.ps.g[self.name + "/gamma"].mul_(1.0 / ctx.comm.world)
+            self.ps.g[self.name + "/beta"].mul_(1.0 / ctx.comm.world)
+        self.x = None
+        return dx
+
+
+class InstanceNormStyleAct:
+    """instance_norm(center=False, scale=False) -> style_mod -> activation (models.py:522-528 ..., modules.py:6-10)."""
+
+    def __init__(self, ctx, C, act):
+        self.ctx, self.C, self.act = ctx, C, act
+
+    def forward(self, x, style):
+        N, H, W, C = x.shape
+        y = torch.empty_like(x)
+        self.mean_rstd = self.ctx.empty(N, 2 * C)
+        L.call("ladder_in_style_fwd", _p(x), _p(style), _p(y), _p(self.mean_rstd), N, H * W, C, IN_EPS, L.ACT[self.act],
+               self.ctx.stream)
+        self.x, self.style = x, style
+        return y
+
+    def backward(self, dy):
+        x = self.x
+        N, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        dstyle = self.ctx.empty(N, 2 * C)
+        L.call("ladder_in_style_bwd", _p(dy), _p(x), _p(self.style), _p(self.mean_rstd), _p(dx), _p(dstyle), N, H * W, C,
+               L.ACT[self.act], self.ctx.stream)
+        self.x = self.style = None
+        return dx, dstyle
+
+
+class Resize:
+    """tf.image.resize_images TF1-legacy bilinear."""
+
+    def __init__(self, ctx, oh, ow):
+        self.ctx, self.oh, self.ow = ctx, oh, ow
+
+    def forward(self, x):
+        N, H, W, C = x.shape
+        self.in_shape = (N, H, W, C)
+        if (H, W) == (self.oh, self.ow):
+            return x
+        y = self.ctx.empty(N, self.oh, self.ow, C)
+        L.call("ladder_resize_bilinear_fwd", _p(x), _p(y), N, H, W, C, self.oh, self.ow, self.ctx.stream)
+        return y
+
+    def backward(self, dy):
+        N, H, W, C = self.in_shape
+        if (H, W) == (self.oh, self.ow):
+            return dy
+        dx = self.ctx.empty(N, H, W, C)
+        L.call("ladder_resize_bilinear_bwd", _p(dy), _p(dx), N, H, W, C, self.oh, self.ow, self.ctx.stream)
+        return dx
+
+
+class DepthToSpace:
+    def __init__(self, ctx, r):
+        self.ctx, self.r = ctx, r
+
+    def forward(self, x):
+        N, H, W, C = x.shape
+        r = self.r
+        y = self.ctx.empty(N, H * r, W * r, C // (r * r))
+        L.call("ladder_depth_to_space", _p(x), _p(y), N, H, W, C, r, 0, self.ctx.stream)
+        return y
+
+    def backward(self, dy):
+        N, HR, WR, Cp = dy.shape
+        r = self.r
+        dx = self.ctx.empty(N, HR // r, WR // r, Cp * r * r)
+        L.call("ladder_depth_to_space", _p(dy), _p(dx), N, HR // r, WR // r, Cp * r * r, r, 1, self.ctx.stream)
+        return dx
+
+
+def pad_symmetric(ctx, x, p):
+    N, H, W, C = x.shape
+    y = ctx.empty(N, H + 2 * p, W + 2 * p, C)
+    L.call("ladder_pad_symmetric", _p(x), _p(y), N, H, W, C, p, ctx.stream)
+    return y
+
+
+def add_(ctx, out, inp):
+    L.call("ladder_axpy", _p(inp), _p(out), out.numel(), 1.0, 1, ctx.stream)
+    return out
+
+
+# ------------------------------------------------------------------------------------------ networks
+class Encoder:
+    def __init__(self, ctx, ps, cfg):
+        self.ctx, self.cfg = ctx, cfg
+        self.exp = cfg["exp_name"]
+        self.convs, self.bns = [], []
+        for i, (cin, cout, k, s, pad, act, bn) in enumerate(arch.encoder_convs(cfg)):
+            self.convs.append(Conv2D(ctx, ps, "encoder/" + arch.tfname("conv2d", i), k, cin, cout, s, pad, act))
+            self.bns.append(BatchNormAct(ctx, ps, "encoder/" + arch.tfname("batch_normalization", i), cout, "leaky_relu") if bn else None)
+        feat, hid = arch.encoder_flat_dim(cfg), arch.encoder_hidden(cfg)
+        self.hidden = Dense(ctx, ps, "encoder/dense", feat, hid, "leaky_relu") if hid is not None else None
+        feat = hid if hid is not None else feat
+        Z = int(cfg["code_size"])
+        self.head_mu = Dense(ctx, ps, "encoder/code_mean", feat, Z, None)
+        self.head_sd = Dense(ctx, ps, "encoder/code_std_dev", feat, Z, "relu")
+
+    def forward(self, x):
+        h = pad_symmetric(self.ctx, x, 2) if self.exp != "celeba" else x
+        for conv, bn in zip(self.convs, self.bns):
+            h = conv.forward(h)
+            if bn is not None:
+                h = bn.forward(h)
+        self.conv_shape = h.shape
+        h = h.reshape(h.shape[0], -1)
+        if self.hidden is not None:
+            h = self.hidden.forward(h)
+        return self.head_mu.forward(h), self.head_sd.forward(h)
+
+    def backward(self, dmu, dsd_raw):
+        dh = self.head_mu.backward(dmu)
+        add_(self.ctx, dh, self.head_sd.backward(dsd_raw, act_done=True))
+        if self.hidden is not None:
+            dh = self.hidden.backward(dh)
+        dh = dh.reshape(self.conv_shape)
+        for i in range(len(self.convs) - 1, -1, -1):
+            if self.bns[i] is not None:
+                dh = self.bns[i].backward(dh)
+            dh = self.convs[i].backward(dh, need_dx=(i > 0))
+
+
+class MnistDecoder:
+    def __init__(self, ctx, ps, cfg):
+        self.ctx = ctx
+        width, r0, convs = arch.mnist_decoder_convs(cfg)
+        self.dense = Dense(ctx, ps, "decoder/dense", int(cfg["code_size"]), width, "leaky_relu")
+        self.d2s0 = DepthToSpace(ctx, r0)
+        self.convs, self.d2s = [], []
+        for i, (k, ci, co, pad, act, d) in enumerate(convs):
+            self.convs.append(Conv2D(ctx, ps, "decoder/" + arch.tfname("conv2d", i), k, ci, co, 1, pad, act))
+            self.d2s.append(DepthToSpace(ctx, d) if d else None)
+
+    def forward(self, z):
+        h = self.dense.forward(z)
+        h = self.d2s0.forward(h.view(h.shape[0], 1, 1, -1))
+        for conv, d in zip(self.convs, self.d2s):
+            h = conv.forward(h)
+            if d is not None:
+                h = d.forward(h)
+        return h
+
+    def backward(self, dxhat, need_dz=True):
+        dh = dxhat
+        for conv, d in zip(reversed(self.convs), reversed(self.d2s)):
+            if d is not None:
+                dh = d.backward(dh)
+            dh = conv.backward(dh)
+        dh = self.d2s0.backward(dh)
+        return self.dense.backward(dh.reshape(dh.shape[0], -1), need_dx=need_dz)
+
+
+class CelebADecoder:
+    """codes/models.py:499-587: mapping MLP -> dlatent; 1x1 conv on `encoded`; 7 3x3 convs with
+    IN+style+leaky on four of them and legacy-bilinear upsampling in between; 1x1 conv to RGB."""
+
+    def __init__(self, ctx, ps, cfg):
+        self.ctx = ctx
+        nh, Z = int(cfg["num_hidden_units"]), int(cfg["code_size"])
+        self.nh = nh
+        self.dense0 = Dense(ctx, ps, "decoder/dense", Z, nh, "leaky_relu")
+        self.mapping = [Dense(ctx, ps, "decoder/dense_%d" % i, nh, nh, "leaky_relu") for i in range(1, 9)]
+        self.conv0 = Conv2D(ctx, ps, "decoder/conv2d", 1, nh, nh, 1, "same", None)
+        self.up0 = Resize(ctx, 2, 2)
+        self.blocks = []
+        si = 0
+        for i, (k, ci, co, styled, act, rs) in enumerate(arch.celeba_decoder_convs(cfg)):
+            conv = Conv2D(ctx, ps, "decoder/conv2d_%d" % (i + 1), k, ci, co, 1, "same", act)
+            sty = norm = None
+            if styled:
+                sty = Dense(ctx, ps, "decoder/StyleMod_%d/dense" % si, nh, 2 * co, None)
+                norm = InstanceNormStyleAct(ctx, co, "leaky_relu")
+                si += 1
+            self.blocks.append((conv, sty, norm, Resize(ctx, rs, rs) if rs else None))
+        self.conv_out = Conv2D(ctx, ps, "decoder/conv2d_8", 1, nh // 4, int(cfg["dim_input_channel"]), 1, "same", None)
+
+    def forward(self, z):
+        B = z.shape[0]
+        encoded = self.dense0.forward(z)
+        d = encoded
+        for lyr in self.mapping:
+            d = lyr.forward(d)
+        dlatent = d
+        h = self.up0.forward(self.conv0.forward(encoded.view(B, 1, 1, self.nh)))
+        for conv, sty, norm, rs in self.blocks:
+            h = conv.forward(h)
+            if norm is not None:
+                h = norm.forward(h, sty.forward(dlatent))
+            if rs is not None:
+                h = rs.forward(h)
+        return self.conv_out.forward(h)
+
+    def backward(self, dxhat, need_dz=True):
+        ctx = self.ctx
+        dh = self.conv_out.backward(dxhat)
+        ddlat = None
+        for conv, sty, norm, rs in reversed(self.blocks):
+            if rs is not None:
+                dh = rs.backward(dh)
+            if norm is not None:
+                dh, dstyle = norm.backward(dh)
+                g = sty.backward(dstyle)
+                ddlat = g if ddlat is None else add_(ctx, ddlat, g)
+            dh = conv.backward(dh)
+        dh = self.conv0.backward(self.up0.backward(dh))
+        denc = dh.reshape(dh.shape[0], self.nh)
+        for lyr in reversed(self.mapping):
+            ddlat = lyr.backward(ddlat)
+        add_(ctx, denc, ddlat)
+        return self.dense0.backward(denc, need_dx=need_dz)
+
+
+class InnerVAE:
+    """codes/base.py:127-213."""
+
+    def __init__(self, ctx, ps, cfg):
+        self.ctx = ctx
+        Z, H = int(cfg["code_size"]), int(cfg["num_hidden_units_inner_VAE"])
+        R, nl = int(cfg["representation_size"]), int(cfg["n_layers_inner_VAE"])
+        a = cfg["inner_activation"]
+        dims = [(Z, H)] + [(H, H)] * (nl - 1)
+        self.enc = [Dense(ctx, ps, "prior/" + arch.tfname("dense", i), ci, co, a) for i, (ci, co) in enumerate(dims)]
+        self.head_mu = Dense(ctx, ps, "prior/" + arch.tfname("dense", nl), H, R, None)
+        self.head_sd = Dense(ctx, ps, "prior/" + arch.tfname("dense", nl + 1), H, R, "relu")
+        dims = [(R, H)] + [(H, H)] * (nl - 1)
+        self.dec = [Dense(ctx, ps, "prior/" + arch.tfname("dense", nl + 2 + i), ci, co, a) for i, (ci, co) in enumerate(dims)]
+        self.dec_out = Dense(ctx, ps, "prior/" + arch.tfname("dense", 2 * nl + 2), H, Z, None)
+
+    def encode(self, z):
+        h = z
+        for lyr in self.enc:
+            h = lyr.forward(h)
+        return self.head_mu.forward(h), self.head_sd.forward(h)
+
+    def decode(self, t):
+        h = t
+        for lyr in self.dec:
+            h = lyr.forward(h)
+        return self.dec_out.forward(h)
+
+    def decode_backward(self, dzhat, wgrad):
+        dh = self.dec_out.backward(dzhat, wgrad=wgrad)
+        for lyr in reversed(self.dec):
+            dh = lyr.backward(dh, wgrad=wgrad)
+        return dh
+
+    def encode_backward(self, dmu, dsd_raw, wgrad, need_dz):
+        dh = self.head_mu.backward(dmu, wgrad=wgrad)
+        add_(self.ctx, dh, self.head_sd.backward(dsd_raw, wgrad=wgrad, act_done=True))
+        for i in range(len(self.enc) - 1, -1, -1):
+            dh = self.enc[i].backward(dh, need_dx=(need_dz or i > 0), wgrad=wgrad)
+        return dh
+
+
+# ------------------------------------------------------------------------------------------ engine
+class LadderEngine:
+    """Owns parameters + optimiser state and evaluates the reference's four per-minibatch runs.
+
+    run_ae          = RUN#1  (codes/base.py:587-594)   full fwd+bwd, clip+Adam on encoder+decoder
+    run_sigma       = RUN#2  (601-606)                 encoder+decoder fwd, scalar Adam on sigma/Variable
+    run_prior       = RUN#3  (615-622)                 encoder fwd, inner-VAE fwd+bwd, Adam on prior/*
+    run_inner_sigma = RUN#4  (636-639)                 encoder + inner-VAE fwd, scalar Adam on inner_sigma
+    evaluate        = val_step / test_step fetches     (643-679, 944-986)
+    """
+
+    def __init__(self, cfg, device="cuda:0", values=None, seed=1, comm=None, noise_seed=1234):
+        self.cfg = cfg
+        self.ctx = Ctx(device, comm)
+        self.ps = ParamStore(cfg, self.ctx, values, seed)
+        self.encoder = Encoder(self.ctx, self.ps, cfg)
+        self.decoder = (CelebADecoder if cfg["exp_name"] == "celeba" else MnistDecoder)(self.ctx, self.ps, cfg)
+        self.has_inner = cfg["prior"] == "ours"
+        if cfg["prior"] not in ("ours", "standard_gaussian"):
+            raise NotImplementedError("prior %r: the HIP path covers 'ours' and 'standard_gaussian' (SURVEY 8f4)" % cfg["prior"])
+        self.inner = InnerVAE(self.ctx, self.ps, cfg) if self.has_inner else None
+        self.Z = int(cfg["code_size"])
+        self.R = int(cfg.get("representation_size", 1))
+        self.K = int(cfg.get("n_mixtures", 1))
+        self.Lmc = int(cfg.get("n_MC_samples", 1))
+        self.D = int(cfg["dim_input_x"]) * int(cfg["dim_input_y"]) * int(cfg["dim_input_channel"])
+        self.lvp = float(cfg["latent_variance_precision"])
+        self.partials = self.ctx.zeros(L.P_FIXED + self.Z + self.R)
+        self.scalars = self.ctx.zeros(L.S_COUNT)
+        self.noise_seed, self.noise_offset = int(noise_seed) + 7919 * self.ctx.comm.rank, 0
+        self._gm_packed = None
+
+    # -- inputs ---------------------------------------------------------------------------------
+    def _dev(self, a):
+        if a is None:
+            return None
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.ctx.device, dtype=torch.float32).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(self.ctx.device)
+
+    def _randn(self, *shape):
+        t = self.ctx.empty(*shape)
+        L.call("ladder_randn", _p(t), t.numel(), self.noise_seed, self.noise_offset, self.ctx.stream)
+        self.noise_offset += 1
+        return t
+
+    def _noise(self, noise, key, shape):
+        if noise is not None and noise.get(key) is not None:
+            t = self._dev(noise[key])
+            assert tuple(t.shape) == tuple(shape), (key, t.shape, shape)
+            return t
+        return self._randn(*shape)
+
+    def set_mixture(self, weights, means, covs):
+        """Feed of prior_weight / prior_mean / prior_cov (codes/base.py:110-112, 870-888); fp32 like the placeholders."""
+        K, R = self.K, self.R
+        w, m, c = self._dev(weights), self._dev(means), self._dev(covs)
+        assert tuple(w.shape) == (K,) and tuple(m.shape) == (K, R) and tuple(c.shape) == (K, R, R)
+        stride = L.query("ladder_gmm_packed_stride", R)
+        packed = self.ctx.empty(K * stride)
+        L.call("ladder_gmm_prepare", _p(w), _p(m), _p(c), K, R, _p(packed), self.ctx.stream)
+        self._gm_packed = packed
+
+    def set_sg_mixture(self):
+        """The dummy N(0,I) mixture of the SG-pretraining feed (codes/base.py:870-876)."""
+        K, R = self.K, self.R
+        self.set_mixture(np.full(K, 1.0 / K), np.zeros((K, R)), np.tile(np.eye(R), (K, 1, 1)))
+
+    # -- forward --------------------------------------------------------------------------------
+    def forward(self, x, noise=None, use_sg=True, use_mask=False, parts=("dec", "inner", "gmm")):
+        ctx, st = self.ctx, self.ctx.stream
+        x = self._dev(x)
+        B = x.shape[0]
+        self.x, self.B = x, B
+        self.Bg = B * ctx.comm.world
+        Z, R = self.Z, self.R
+        P = self.partials
+        P.zero_()
+        mu, sd_raw = self.encoder.forward(x)
+        eps_z = self._noise(noise, "eps_z", (B, Z))
+        z, sd = ctx.empty(B, Z), ctx.empty(B, Z)
+        L.call("ladder_latent_fwd", _p(mu), _p(sd_raw), _p(eps_z), self.lvp, _p(z), _p(sd), _p(P[L.P_LOG_SDZ:]),
+               _p(P[L.P_MU2SD2_Z:]), _p(P[L.P_FIXED:]), B, Z, st)
+        self.lat_z = (mu, sd, sd_raw, eps_z, z)
+        self.xhat = None
+        if "dec" in parts:
+            xhat = self.decoder.forward(z)
+            nb = L.query("ladder_pixel_partials_workspace_bytes", x.numel())
+            wsp, wsn = ctx.ws(nb)
+            L.call("ladder_pixel_partials", _p(x), _p(xhat), x.numel(), _p(P[L.P_PIX_ABS:]), wsp, wsn, st)
+            self.xhat = xhat
+        inner_on = self.has_inner and "inner" in parts
+        if inner_on:
+            mu_t, sdraw_t = self.inner.encode(z)
+            eps_t = self._noise(noise, "eps_t", (B, R))
+            t, sd_t = ctx.empty(B, R), ctx.empty(B, R)
+            L.call("ladder_latent_fwd", _p(mu_t), _p(sdraw_t), _p(eps_t), self.lvp, _p(t), _p(sd_t), _p(P[L.P_LOG_SDT:]),
+                   _p(P[L.P_MU2SD2_T:]), _p(P[L.P_FIXED + Z:]), B, R, st)
+            zhat = self.inner.decode(t)
+            L.call("ladder_code_partials", _p(z), _p(zhat), _p(sd), int(use_mask), _p(P[L.P_CODE_ERR:]), B, Z, st)
+            self.lat_t = (mu_t, sd_t, sdraw_t, eps_t, t)
+            self.zhat = zhat
+            self.gmm_grads = None
+            if "gmm" in parts:
+                if self._gm_packed is None:
+                    raise L.LadderHipError("set_mixture()/set_sg_mixture() must be called before a run that evaluates the GM prior")
+                eps_mc = self._noise(noise, "eps_mc", (self.Lmc, B, R))
+                dmu, dsd = ctx.empty(B, R), ctx.empty(B, R)
+                nb = L.query("ladder_gmm_workspace_bytes", self.Lmc, B)
+                wsp, wsn = ctx.ws(nb)
+                L.call("ladder_gmm_logprob_fwd_bwd", _p(mu_t), _p(sd_t), _p(eps_mc), _p(self._gm_packed), self.Lmc, B, R,
+                       self.K, _p(P[L.P_LOGP:]), _p(dmu), _p(dsd), wsp, wsn, st)
+                self.gmm_grads = (dmu, dsd)
+        ctx.comm.allreduce_(P)                                   # C3: scalar partials of the GLOBAL batch
+        ecfg = L.LadderElboCfg(self.Bg, self.D, Z, R, self.Lmc,
+                               1 if (self.cfg["exp_name"] == "celeba" or int(self.cfg["TRAIN_sigma"]) == 1) else 0,
+                               1 if inner_on else 0, 1 if use_sg else 0,
+                               1 if (self.has_inner and int(self.cfg["TRAIN_inner_sigma"]) == 1) else 0,
+                               float(self.cfg.get("inner_sigma_lb", 0.0)), float(self.cfg.get("inner_sigma_ub", 0.0)))
+        L.call("ladder_elbo_finalize", _p(P), _p(self.ps.w["sigma/Variable"]),
+               _p(self.ps.w["inner_sigma/Variable"]) if self.has_inner else None, ecfg, _p(self.scalars), st)
+        self.use_sg, self.use_mask = use_sg, use_mask
+
+    def fetch(self, names=None):
+        """Host copy of the fetched scalars (ONE device->host sync)."""
+        s = self.scalars.detach().cpu().numpy()
+        names = names or [n for n in L.S_NAMES if not n.startswith("_")]
+        return {n: float(s[L.S_INDEX[n]]) for n in names}
+
+    def std_dev_code(self):
+        return (self.partials[L.P_FIXED:L.P_FIXED + self.Z] / self.Bg).cpu().numpy()
+
+    def std_dev_representation(self):
+        return (self.partials[L.P_FIXED + self.Z:L.P_FIXED + self.Z + self.R] / self.Bg).cpu().numpy()
+
+    # -- backward pieces ------------------------------------------------------------------------
+    def _sc(self, name):
+        return self.scalars[L.S_INDEX[name]:]
+
+    def _backward_ae(self):
+        ctx, st, B, Z, R = self.ctx, self.ctx.stream, self.B, self.Z, self.R
+        mu, sd, sd_raw, eps_z, z = self.lat_z
+        dxhat = torch.empty_like(self.xhat)
+        L.call("ladder_pixel_grad", _p(self.x), _p(self.xhat), _p(self._sc("_g_pix")), _p(dxhat), dxhat.numel(), st)
+        dz = self.decoder.backward(dxhat)
+        mode = 1
+        if self.has_inner and not self.use_sg:
+            mu_t, sd_t, sdraw_t, eps_t, t = self.lat_t
+            dzhat = ctx.empty(B, Z)
+            L.call("ladder_code_grad", _p(z), _p(self.zhat), _p(sd), int(self.use_mask), _p(self.scalars), _p(dz), _p(dzhat), B, Z, st)
+            dt = self.inner.decode_backward(dzhat, wgrad=False)
+            dmu_t, dsdraw_t = ctx.empty(B, R), ctx.empty(B, R)
+            L.call("ladder_latent_bwd", _p(dt), _p(mu_t), _p(sd_t), _p(sdraw_t), _p(eps_t), _p(self.gmm_grads[0]),
+                   _p(self.gmm_grads[1]), -1.0, _p(self.scalars), 1, _p(dmu_t), _p(dsdraw_t), B, R, st)
+            add_(ctx, dz, self.inner.encode_backward(dmu_t, dsdraw_t, wgrad=False, need_dz=True))
+        else:
+            mode = 3
+        dmu, dsdraw = ctx.empty(B, Z), ctx.empty(B, Z)
+        L.call("ladder_latent_bwd", _p(dz), _p(mu), _p(sd), _p(sd_raw), _p(eps_z), None, None, 0.0, _p(self.scalars), mode,
+               _p(dmu), _p(dsdraw), B, Z, st)
+        self.encoder.backward(dmu, dsdraw)
+
+    def _backward_prior(self):
+        ctx, st, B, Z, R = self.ctx, self.ctx.stream, self.B, self.Z, self.R
+        mu, sd, sd_raw, eps_z, z = self.lat_z
+        mu_t, sd_t, sdraw_t, eps_t, t = self.lat_t
+        dzhat = ctx.empty(B, Z)
+        L.call("ladder_code_grad", _p(z), _p(self.zhat), _p(sd), int(self.use_mask), _p(self.scalars), None, _p(dzhat), B, Z, st)
+        dt = self.inner.decode_backward(dzhat, wgrad=True)
+        dmu_t, dsdraw_t = ctx.empty(B, R), ctx.empty(B, R)
+        L.call("ladder_latent_bwd", _p(dt), _p(mu_t), _p(sd_t), _p(sdraw_t), _p(eps_t), _p(self.gmm_grads[0]),
+               _p(self.gmm_grads[1]), -1.0, _p(self.scalars), 1, _p(dmu_t), _p(dsdraw_t), B, R, st)
+        self.inner.encode_backward(dmu_t, dsdraw_t, wgrad=True, need_dz=False)
+
+    # -- the four runs --------------------------------------------------------------------------
+    def run_ae(self, x, lr, noise=None, use_sg=True, use_mask=False):
+        # in the SG regime the inner VAE does not enter loss_ae's gradient (tf.cond, base.py:318-320) nor its fetches
+        parts = ("dec",) if (use_sg or not self.has_inner) else ("dec", "inner", "gmm")
+        self.forward(x, noise, use_sg, use_mask, parts)
+        self._backward_ae()
+        self.ctx.comm.allreduce_(self.ps.grad["ae"])              # C1 (sum of per-rank grads of the global-mean loss)
+        self.ps.adam("ae", lr)
+
+    def run_sigma(self, x, lr, noise=None, use_sg=True, use_mask=False):
+        self.forward(x, noise, use_sg, use_mask, ("dec",))
+        self.ps.adam("sigma", lr, grad=self._sc("_g_sigma_var"), n=1)
+
+    def run_prior(self, x, lr, noise=None, use_sg=True, use_mask=False):
+        self.forward(x, noise, use_sg, use_mask, ("inner", "gmm"))
+        self._backward_prior()
+        self.ctx.comm.allreduce_(self.ps.grad["prior"])           # C4
+        self.ps.adam("prior", lr)
+
+    def run_inner_sigma(self, x, lr, noise=None, use_sg=True, use_mask=False):
+        self.forward(x, noise, use_sg, use_mask, ("inner",))
+        self.ps.adam("inner_sigma", lr, grad=self._sc("_g_inner_sigma_var"), n=1)
+
+    def evaluate(self, x, noise=None, use_sg=True, use_mask=False):
+        parts = ("dec", "inner", "gmm") if (self.has_inner and self._gm_packed is not None) else ("dec", "inner")
+        self.forward(x, noise, use_sg, use_mask, parts)
+
+    # -- generation -----------------------------------------------------------------------------
+    def decode(self, code):
+        """decoded given code_input (is_code_input=True; models.py:107,265,500)."""
+        return self.decoder.forward(self._dev(code))
+
+    def decode_representation(self, t):
+        """decoded_code given representation_input (base.py:171-186)."""
+        return self.inner.decode(self._dev(t))
+
+    def sample_representation(self, x, noise=None):
+        """representation_sample for fit_GMM_VI (base.py:683-698): encoder -> z -> inner encoder -> t."""
+        self.forward(x, noise, True, False, ("inner",))
+        return self.lat_t[4]

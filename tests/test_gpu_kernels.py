@@ -1,0 +1,292 @@
+"""Per-kernel parity of the HIP path (through the C ABI) against the CPU oracle (float64).
+
+Tolerances: fp32 kernels vs float64 oracle -- relative 2e-5 of the output scale for contractions
+(K up to ~4.6k fp32 FMAs), 1e-5 for element-wise / normalisation passes.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ladder_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from ladder_latent_data_distribution_modelling_amd import _lib as L
+    return L
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a, np.float32)).cuda()
+
+
+def p(t):
+    return None if t is None else t.data_ptr()
+
+
+def close(got, ref, rtol, what=""):
+    got = got.detach().cpu().numpy().astype(np.float64) if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    ref = ref.detach().numpy().astype(np.float64) if isinstance(ref, torch.Tensor) else np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(np.abs(ref).max(), 1e-30)
+    err = np.abs(got - ref).max() / scale
+    assert np.isfinite(got).all() and err < rtol, "%s: rel err %.3e (tol %.1e)" % (what, err, rtol)
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, padding, act
+    (2, 16, 16, 16, 32, 3, 1, "same", "leaky_relu"),
+    (3, 16, 16, 32, 160, 3, 1, "same", None),          # N tile edge (160 = 128 + 32)
+    (2, 32, 32, 3, 128, 3, 2, "same", None),           # Cin=3 scalar gather, TF asymmetric SAME pad
+    (2, 16, 16, 128, 128, 3, 2, "same", None),
+    (4, 4, 4, 64, 64, 3, 1, "valid", "leaky_relu"),
+    (5, 1, 1, 48, 48, 1, 1, "same", None),
+    (2, 32, 32, 4, 1, 5, 1, "valid", "relu"),          # MNIST output conv
+    (2, 8, 8, 128, 3, 1, 1, "same", None),             # CelebA output conv (Cout=3)
+    (1, 7, 9, 20, 36, 3, 1, "same", "relu"),           # ragged everything
+    (2, 9, 9, 16, 16, 3, 2, "same", None),             # odd size stride 2 (pad 1/1)
+    (64, 2, 2, 64, 64, 3, 1, "same", None),            # tiny-spatial decoder block
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_conv2d_fwd_bwd(gpu_ctx, case):
+    L = _lib()
+    from ladder_latent_data_distribution_modelling_amd import arch
+    N, H, W, Cin, Cout, k, s, pad, act = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    pre = O.conv2d_tf(xt, wt, bt, s, pad)
+    yr = O.act(pre, act)
+    dy = rng.standard_normal(tuple(yr.shape)).astype(np.float32)
+    yr.backward(torch.tensor(dy, dtype=torch.float64))
+
+    pt, Ho = arch.conv_out(H, k, s, pad)
+    pl, Wo = arch.conv_out(W, k, s, pad)
+    assert (Ho, Wo) == tuple(yr.shape[1:3])
+    st = gpu_ctx.stream
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    y = torch.empty(N, Ho, Wo, Cout, device="cuda")
+    L.call("ladder_conv2d_fwd", p(xd), p(wd), p(bd), p(y), N, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, L.ACT[act], st)
+    close(y, yr, 2e-5, "fwd")
+    dyd = dev(dy)
+    if act is not None:
+        L.call("ladder_act_bwd", p(dyd), p(y), p(dyd), dyd.numel(), L.ACT[act], st)
+    nb = L.query("ladder_conv2d_bwd_filter_workspace_bytes", N, H, W, Cin, Ho, Wo, Cout, k, k)
+    wsp, wsn = gpu_ctx.ws(nb)
+    dw, db = torch.empty_like(wd), torch.empty_like(bd)
+    L.call("ladder_conv2d_bwd_filter", p(xd), p(dyd), p(dw), p(db), N, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, wsp, wsn, st)
+    close(dw, wt.grad, 3e-5, "dw")
+    close(db, bt.grad, 3e-5, "db")
+    wT = torch.empty(wd.numel(), device="cuda")
+    L.call("ladder_filter_flip_transpose", p(wd), p(wT), k, k, Cin, Cout, st)
+    dx = torch.empty_like(xd)
+    L.call("ladder_conv2d_bwd_data", p(dyd), p(wT), p(dx), N, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, st)
+    close(dx, xt.grad, 3e-5, "dx")
+
+
+@pytest.mark.parametrize("M,K,N,act", [(128, 2048, 64, None), (128, 512, 512, "leaky_relu"), (7, 2, 32, "relu"),
+                                       (256, 64, 4096, "leaky_relu"), (100, 33, 2, None), (4, 16, 1024, "tanh")])
+def test_dense_fwd_bwd(gpu_ctx, M, K, N, act):
+    L = _lib()
+    rng = np.random.default_rng(M * 7 + K * 3 + N)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    xt, wt, bt = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (x, w, b))
+    yr = O.act(O.dense(xt, wt, bt), act)
+    dy = rng.standard_normal((M, N)).astype(np.float32)
+    yr.backward(torch.tensor(dy, dtype=torch.float64))
+    st = gpu_ctx.stream
+    xd, wd, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
+    y = torch.empty(M, N, device="cuda")
+    L.call("ladder_dense_fwd", p(xd), p(wd), p(bd), p(y), M, K, N, L.ACT[act], st)
+    close(y, yr, 2e-5, "fwd")
+    if act is not None:
+        L.call("ladder_act_bwd", p(dyd), p(y), p(dyd), dyd.numel(), L.ACT[act], st)
+    wsp, wsn = gpu_ctx.ws(L.query("ladder_dense_bwd_weight_workspace_bytes", M, K, N))
+    dw, db = torch.empty_like(wd), torch.empty_like(bd)
+    L.call("ladder_dense_bwd_weight", p(xd), p(dyd), p(dw), p(db), M, K, N, wsp, wsn, st)
+    close(dw, wt.grad, 3e-5, "dw")
+    close(db, bt.grad, 3e-5, "db")
+    wT = torch.empty(wd.numel(), device="cuda")
+    L.call("ladder_filter_flip_transpose", p(wd), p(wT), 1, 1, K, N, st)
+    dx = torch.empty_like(xd)
+    L.call("ladder_dense_bwd_data", p(dyd), p(wT), p(dx), M, K, N, st)
+    close(dx, xt.grad, 3e-5, "dx")
+
+
+@pytest.mark.parametrize("shape,act", [((4, 8, 8, 128), "leaky_relu"), ((3, 5, 7, 20), None), ((2, 2, 2, 512), "leaky_relu"),
+                                       ((16, 32, 32, 64), "leaky_relu")])
+def test_batch_norm(gpu_ctx, shape, act):
+    L = _lib()
+    rng = np.random.default_rng(sum(shape))
+    C = shape[-1]
+    rows = int(np.prod(shape[:-1]))
+    x = (rng.standard_normal(shape) * 1.7 + 0.6).astype(np.float32)
+    g = (1 + 0.3 * rng.standard_normal(C)).astype(np.float32)
+    be = (0.2 * rng.standard_normal(C)).astype(np.float32)
+    xt, gt, bt = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (x, g, be))
+    yr = O.act(O.batch_norm_train(xt, gt, bt), act)
+    dy = rng.standard_normal(shape).astype(np.float32)
+    yr.backward(torch.tensor(dy, dtype=torch.float64))
+    st = gpu_ctx.stream
+    xd, gd, bd, dyd = dev(x), dev(g), dev(be), dev(dy)
+    wsp, wsn = gpu_ctx.ws(L.query("ladder_bn_workspace_bytes", rows, C))
+    sums, mr = torch.empty(2 * C, device="cuda"), torch.empty(2 * C, device="cuda")
+    y = torch.empty_like(xd)
+    L.call("ladder_bn_fwd_stats", p(xd), p(sums), rows, C, wsp, wsn, st)
+    L.call("ladder_bn_fwd_apply", p(xd), p(sums), float(rows), p(gd), p(bd), p(y), p(mr), rows, C, 1e-3, L.ACT[act], st)
+    close(y, yr, 1e-5, "y")
+    ds = torch.empty(2 * C, device="cuda")
+    dx, dg, db = torch.empty_like(xd), torch.empty_like(gd), torch.empty_like(bd)
+    L.call("ladder_bn_bwd_stats", p(dyd), p(xd), p(mr), p(gd), p(bd), p(ds), rows, C, L.ACT[act], wsp, wsn, st)
+    L.call("ladder_bn_bwd_apply", p(dyd), p(xd), p(mr), p(gd), p(bd), p(ds), float(rows), p(dx), p(dg), p(db), rows, C, L.ACT[act], st)
+    close(dx, xt.grad, 2e-5, "dx")
+    close(dg, gt.grad, 2e-5, "dgamma")
+    close(db, bt.grad, 2e-5, "dbeta")
+
+
+@pytest.mark.parametrize("shape", [(3, 2, 2, 64), (2, 16, 16, 32), (2, 8, 8, 100), (4, 64, 64, 128)])
+def test_instance_norm_style(gpu_ctx, shape):
+    L = _lib()
+    rng = np.random.default_rng(sum(shape))
+    N, H, W, C = shape
+    x = (rng.standard_normal(shape) * 2 + 0.5).astype(np.float32)
+    sty = (0.5 * rng.standard_normal((N, 2 * C))).astype(np.float32)
+    xt, stt = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (x, sty))
+    yr = O.leaky_relu(O.style_mod(O.instance_norm(xt), stt))
+    dy = rng.standard_normal(shape).astype(np.float32)
+    yr.backward(torch.tensor(dy, dtype=torch.float64))
+    st = gpu_ctx.stream
+    xd, sd, dyd = dev(x), dev(sty), dev(dy)
+    y, mr = torch.empty_like(xd), torch.empty(N, 2 * C, device="cuda")
+    L.call("ladder_in_style_fwd", p(xd), p(sd), p(y), p(mr), N, H * W, C, 1e-6, 1, st)
+    close(y, yr, 1e-5, "y")
+    dx, dst = torch.empty_like(xd), torch.empty_like(sd)
+    L.call("ladder_in_style_bwd", p(dyd), p(xd), p(sd), p(mr), p(dx), p(dst), N, H * W, C, 1, st)
+    close(dst, stt.grad, 2e-5, "dstyle")
+    # instance-norm backward at 2x2 with eps=1e-6 is ill-conditioned (rstd up to 1e3): compare at 1e-3 of scale there
+    close(dx, xt.grad, 1e-3 if H * W <= 4 else 5e-5, "dx")
+
+
+@pytest.mark.parametrize("shape,out", [((2, 1, 1, 8), 2), ((2, 2, 2, 16), 8), ((1, 8, 8, 4), 16), ((2, 5, 5, 3), 10), ((2, 4, 4, 4), 4)])
+def test_resize_legacy_bilinear(gpu_ctx, shape, out):
+    L = _lib()
+    rng = np.random.default_rng(out)
+    N, H, W, C = shape
+    x = rng.standard_normal(shape).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    yr = O.resize_bilinear_legacy(xt, out, out)
+    dy = rng.standard_normal((N, out, out, C)).astype(np.float32)
+    (yr * torch.tensor(dy, dtype=torch.float64)).sum().backward()
+    st = gpu_ctx.stream
+    xd, dyd = dev(x), dev(dy)
+    y, dx = torch.empty(N, out, out, C, device="cuda"), torch.empty_like(xd)
+    L.call("ladder_resize_bilinear_fwd", p(xd), p(y), N, H, W, C, out, out, st)
+    L.call("ladder_resize_bilinear_bwd", p(dyd), p(dx), N, H, W, C, out, out, st)
+    close(y, yr, 1e-6, "y")
+    close(dx, xt.grad, 1e-6, "dx")
+
+
+def test_depth_to_space_and_pad(gpu_ctx):
+    L = _lib()
+    rng = np.random.default_rng(5)
+    st = gpu_ctx.stream
+    for (N, H, W, C, r) in [(2, 1, 1, 64, 4), (3, 4, 4, 16, 2), (1, 3, 5, 36, 3)]:
+        x = rng.standard_normal((N, H, W, C)).astype(np.float32)
+        yr = O.depth_to_space(torch.tensor(x), r)
+        xd = dev(x)
+        y = torch.empty(N, H * r, W * r, C // (r * r), device="cuda")
+        L.call("ladder_depth_to_space", p(xd), p(y), N, H, W, C, r, 0, st)
+        assert np.array_equal(y.cpu().numpy(), yr.numpy())
+        back = torch.empty_like(xd)
+        L.call("ladder_depth_to_space", p(y), p(back), N, H, W, C, r, 1, st)
+        assert np.array_equal(back.cpu().numpy(), x)
+    x = rng.standard_normal((2, 28, 28, 1)).astype(np.float32)
+    y = torch.empty(2, 32, 32, 1, device="cuda")
+    L.call("ladder_pad_symmetric", p(dev(x)), p(y), 2, 28, 28, 1, 2, st)
+    assert np.array_equal(y.cpu().numpy(), np.pad(x, ((0, 0), (2, 2), (2, 2), (0, 0)), mode="symmetric"))
+
+
+@pytest.mark.parametrize("K,R,Lmc,B", [(30, 2, 100, 16), (50, 8, 20, 8), (5, 1, 7, 3), (70, 3, 5, 4), (27, 2, 50, 128)])
+def test_gmm_logprob(gpu_ctx, golden_dir, K, R, Lmc, B):
+    """Mixture log-prob + gradient vs the oracle (which is itself pinned to scipy on the reference's fixture)."""
+    import os
+    L = _lib()
+    rng = np.random.default_rng(K + R)
+    fix = np.load(os.path.join(golden_dir, "GM_prior_info.npz"))
+    cfg = dict(n_mixtures=K, representation_size=R)
+    gm = {k: v.astype(np.float32) for k, v in O.synthetic_gm(cfg, rng, fix if K <= 50 else None).items()}
+    if K == 27:
+        gm = dict(weights=fix["w_active"].astype(np.float32), means=fix["m_active"].astype(np.float32), covs=fix["K_active"].astype(np.float32))
+    mu = rng.standard_normal((B, R)).astype(np.float32) * 2
+    sd = (0.05 + rng.random((B, R))).astype(np.float32)
+    eps = rng.standard_normal((Lmc, B, R)).astype(np.float32)
+    mut, sdt = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (mu, sd))
+    t = mut.unsqueeze(0) + sdt.unsqueeze(0) * torch.tensor(eps, dtype=torch.float64)
+    lp = O.gmm_log_prob(t, *(torch.tensor(gm[k], dtype=torch.float64) for k in ("weights", "means", "covs")))
+    lp.sum().backward()
+    st = gpu_ctx.stream
+    packed = torch.empty(K * L.query("ladder_gmm_packed_stride", R), device="cuda")
+    L.call("ladder_gmm_prepare", p(dev(gm["weights"])), p(dev(gm["means"])), p(dev(gm["covs"])), K, R, p(packed), st)
+    out, dmu, dsd = torch.empty(1, device="cuda"), torch.empty(B, R, device="cuda"), torch.empty(B, R, device="cuda")
+    wsp, wsn = gpu_ctx.ws(L.query("ladder_gmm_workspace_bytes", Lmc, B))
+    L.call("ladder_gmm_logprob_fwd_bwd", p(dev(mu)), p(dev(sd)), p(dev(eps)), p(packed), Lmc, B, R, K, p(out), p(dmu), p(dsd), wsp, wsn, st)
+    assert abs(out.item() - lp.sum().item()) < 2e-5 * abs(lp.sum().item()) + 1e-3
+    close(dmu, mut.grad, 5e-5, "dmu")
+    close(dsd, sdt.grad, 5e-5, "dsd")
+
+
+def test_adam_clip_matches_tf_form(gpu_ctx):
+    L = _lib()
+    rng = np.random.default_rng(0)
+    n = 1000
+    th = rng.standard_normal(n).astype(np.float32)
+    m = np.zeros(n, np.float32)
+    v = np.zeros(n, np.float32)
+    thd, md, vd = dev(th), dev(m), dev(v)
+    th64, m64, v64 = th.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
+    for t in range(1, 4):
+        g = (rng.standard_normal(n) * 2).astype(np.float32)     # many |g|>1 -> exercises the clip
+        O.adam_tf(th64, g.astype(np.float64), m64, v64, t, 3e-4)
+        lr_t = 3e-4 * np.sqrt(1 - 0.95 ** t) / (1 - 0.9 ** t)
+        L.call("ladder_adam_clip", p(thd), p(dev(g)), p(md), p(vd), n, float(lr_t), 0.9, 0.95, 1e-8, 1.0, gpu_ctx.stream)
+    close(thd, th64, 1e-6, "theta")
+    close(md, m64, 1e-6, "m")
+    close(vd, v64, 1e-6, "v")
+
+
+def test_randn_moments_and_determinism(gpu_ctx):
+    L = _lib()
+    a, b, c = (torch.empty(1 << 20, device="cuda") for _ in range(3))
+    L.call("ladder_randn", p(a), a.numel(), 42, 0, gpu_ctx.stream)
+    L.call("ladder_randn", p(b), b.numel(), 42, 0, gpu_ctx.stream)
+    L.call("ladder_randn", p(c), c.numel(), 42, 1, gpu_ctx.stream)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    x = a.double()
+    assert abs(x.mean().item()) < 5e-3 and abs(x.var().item() - 1) < 1e-2
+    assert abs((x ** 3).mean().item()) < 2e-2 and abs((x ** 4).mean().item() - 3) < 5e-2
+    assert abs((a * c).double().mean().item()) < 5e-3
+
+
+def test_pixel_partials_full_size(gpu_ctx):
+    """BASELINE-size pixel reduction (128 x 128x128x3): size-independent identities."""
+    L = _lib()
+    n = 128 * 49152
+    x = torch.rand(n, device="cuda")
+    xh = torch.rand(n, device="cuda")
+    out = torch.empty(2, device="cuda")
+    wsp, wsn = gpu_ctx.ws(L.query("ladder_pixel_partials_workspace_bytes", n))
+    L.call("ladder_pixel_partials", p(x), p(xh), n, p(out), wsp, wsn, gpu_ctx.stream)
+    d = (x.double() - xh.double())
+    assert abs(out[0].item() - d.abs().sum().item()) < 1e-6 * d.abs().sum().item()
+    assert abs(out[1].item() - (d * d).sum().item()) < 1e-6 * (d * d).sum().item()
+    L.call("ladder_pixel_partials", p(x), p(x), n, p(out), wsp, wsn, gpu_ctx.stream)
+    assert out[0].item() == 0.0 and out[1].item() == 0.0

@@ -1,0 +1,157 @@
+"""End-to-end parity of the HIP engine against (a) the committed golden vectors and (b) the oracle run live,
+on the tiny configurations of tests/golden/make_golden.py (all three architectures, 4-run regime).
+
+Tolerances (fp32 GPU vs float64 oracle): fetched scalars 2e-5 relative (BASELINE asks 1e-3 on the ELBO),
+decoded image 2e-5 of its scale, per-tensor gradients 2e-4 of the tensor's max |grad|.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ladder_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SCALARS_RUN1 = ["loss_ae", "elbo", "l1_reconstruction_error", "l2_reconstruction_error", "entropy_z", "crossEntropy_prior",
+                "sigma_regularisor", "reconstruction_likelihood", "sigma", "mean_pixel_error", "elbo_prior",
+                "crossEntropy_representation", "entropy_t", "code_reconstruction_likelihood", "code_l1_reconstruction_error",
+                "representation_regularisor", "inner_sigma", "mean_code_error", "crossEntropy_prior_sg"]
+SCALARS_RUN3 = ["elbo_prior", "code_l1_reconstruction_error", "code_reconstruction_likelihood", "entropy_t",
+                "crossEntropy_representation", "inner_sigma", "loss_prior"]
+
+
+def _engine(cfg, values=None):
+    from ladder_latent_data_distribution_modelling_amd.engine import LadderEngine
+    return LadderEngine(cfg, "cuda:0", values=values, seed=1)
+
+
+def _rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-6)
+
+
+def _lrs(cfg, epoch):
+    return (cfg["learning_rate_ae"], cfg["learning_rate_sigma"] * 0.99 ** (epoch - 1),
+            cfg["learning_rate_prior"] * 1.01 ** (epoch - 1), cfg["learning_rate_inner_sigma"] * 1.01 ** (epoch - 1))
+
+
+@pytest.mark.parametrize("exp", ["mnist_digit", "mnist_fashion", "celeba"])
+def test_golden_two_iterations(golden_dir, exp):
+    d = np.load(os.path.join(golden_dir, "oracle_%s.npz" % exp))
+    cfg = json.loads(str(d["config"]))
+    eng = _engine(cfg)
+    eng.set_mixture(d["gm_w"], d["gm_m"], d["gm_c"])
+    x = d["x"]
+    lr_ae, lr_s, lr_p, lr_i = _lrs(cfg, 2)
+    for it in range(2):
+        nz = [{k: d["it%d_run%d_%s" % (it, r, k)] for k in ("eps_z", "eps_t", "eps_mc")} for r in (1, 2, 3, 4)]
+        eng.run_ae(x, lr_ae, nz[0], use_sg=False, use_mask=False)
+        f = eng.fetch()
+        for k in SCALARS_RUN1:
+            assert _rel(f[k], float(d["it%d_run1_%s" % (it, k)])) < 2e-5, (it, k, f[k], float(d["it%d_run1_%s" % (it, k)]))
+        if it == 0:
+            ref = d["it0_run1_decoded"]
+            assert np.abs(eng.xhat.cpu().numpy() - ref).max() < 2e-5 * np.abs(ref).max()
+        assert np.abs(eng.lat_z[4].cpu().numpy() - d["it%d_run1_code_sample" % it]).max() < 1e-4
+        eng.run_sigma(x, lr_s, nz[1], False, False)
+        assert _rel(eng.fetch(["sigma"])["sigma"], float(d["it%d_run2_sigma" % it])) < 2e-5
+        eng.run_prior(x, lr_p, nz[2], False, False)
+        f = eng.fetch()
+        for k in SCALARS_RUN3:
+            assert _rel(f[k], float(d["it%d_run3_%s" % (it, k)])) < 5e-5, (it, k, f[k], float(d["it%d_run3_%s" % (it, k)]))
+        eng.run_inner_sigma(x, lr_i, nz[3], False, False)
+    got = eng.ps.to_dict()
+    for name, v in got.items():
+        ref = d["final/" + name]
+        diff = np.abs(v.astype(np.float64) - ref.astype(np.float64))
+        # Adam's first steps move every element by ~lr*sign(g): elements whose true gradient is ~0 (e.g. conv biases feeding
+        # batch-norm) may legitimately differ by up to 2 steps * lr; everything else must agree closely.
+        assert diff.max() <= 2.5 * 2 * max(lr_ae, lr_p, lr_s, lr_i), name
+        assert np.median(diff) < 2e-6, (name, np.median(diff))
+
+
+@pytest.mark.parametrize("exp,use_sg,use_mask", [("mnist_digit", False, False), ("mnist_digit", True, False), ("mnist_digit", False, True),
+                                                 ("mnist_fashion", False, False), ("celeba", False, False), ("celeba", True, False)])
+def test_gradients_vs_live_oracle(golden_dir, exp, use_sg, use_mask):
+    d = np.load(os.path.join(golden_dir, "oracle_%s.npz" % exp))
+    cfg = json.loads(str(d["config"]))
+    B = cfg["batch_size"]
+    rng = np.random.default_rng(11)
+    x = rng.random(d["x"].shape).astype(np.float32)
+    P = O.init_params(cfg, seed=5)
+    # make the mask bite: inflate the std head bias so that some sd_z > 1
+    if use_mask:
+        P["encoder/code_std_dev/bias"] = (P["encoder/code_std_dev/bias"] + rng.uniform(0.5, 1.5, P["encoder/code_std_dev/bias"].shape)).astype(np.float32)
+    gm = dict(weights=d["gm_w"], means=d["gm_m"], covs=d["gm_c"])
+    noise = O.make_noise(cfg, B, rng, np.float32)
+    st = O.OracleState(cfg, P, np.float64)
+    eng = _engine(cfg, values=P)
+    eng.set_mixture(gm["weights"], gm["means"], gm["covs"])
+    for group, runner in (("ae", eng.run_ae), ("prior", eng.run_prior)):
+        ref = O.run(st, x, noise, gm, use_sg, use_mask, train=group, lr=0.0)     # lr=0: parameters stay put
+        runner(x, 0.0, noise, use_sg, use_mask)
+        for name, g in ref["_grads"].items():
+            got = eng.ps.g[name].cpu().numpy().reshape(g.shape).astype(np.float64)
+            scale = np.abs(g).max()
+            if scale < 1e-9:      # exactly-zero true gradient (bias feeding batch-norm): noise must stay tiny
+                wscale = np.abs(ref["_grads"][name.replace("/bias", "/kernel")]).max()
+                assert np.abs(got).max() < 1e-4 * max(wscale, 1e-6), name
+                continue
+            assert np.abs(got - g).max() < 2e-4 * scale, (group, name, np.abs(got - g).max(), scale)
+    # scalar optimisers
+    ref = O.run(st, x, noise, gm, use_sg, use_mask, train="sigma", lr=0.0)
+    eng.run_sigma(x, 0.0, noise, use_sg, use_mask)
+    s = eng.scalars.cpu().numpy()
+    from ladder_latent_data_distribution_modelling_amd import _lib as L
+    assert _rel(s[L.S_INDEX["_g_sigma_var"]], float(ref["_grads"]["sigma/Variable"])) < 1e-4
+    ref = O.run(st, x, noise, gm, use_sg, use_mask, train="inner_sigma", lr=0.0)
+    eng.run_inner_sigma(x, 0.0, noise, use_sg, use_mask)
+    s = eng.scalars.cpu().numpy()
+    assert _rel(s[L.S_INDEX["_g_inner_sigma_var"]], float(ref["_grads"]["inner_sigma/Variable"])) < 1e-4
+
+
+def test_sg_feed_identity(golden_dir):
+    """With the SG-pretraining feed (K identical N(0,I) components) the MC cross-entropy equals the finite-sum
+    closed form mean_{l,b}[-R/2 log 2pi - 1/2 |t_mc|^2]."""
+    d = np.load(os.path.join(golden_dir, "oracle_mnist_digit.npz"))
+    cfg = json.loads(str(d["config"]))
+    eng = _engine(cfg)
+    eng.set_sg_mixture()
+    nz = {k: d["it0_run1_%s" % k] for k in ("eps_z", "eps_t", "eps_mc")}
+    eng.evaluate(d["x"], nz, use_sg=True, use_mask=False)
+    f = eng.fetch()
+    mu_t, sd_t = eng.lat_t[0].cpu().numpy().astype(np.float64), eng.lat_t[1].cpu().numpy().astype(np.float64)
+    t = mu_t[None] + sd_t[None] * nz["eps_mc"].astype(np.float64)
+    R = cfg["representation_size"]
+    closed = np.mean(-0.5 * R * np.log(2 * np.pi) - 0.5 * (t ** 2).sum(-1))
+    assert abs(f["crossEntropy_representation"] - closed) < 1e-5 * abs(closed)
+    assert f["crossEntropy_prior"] == f["crossEntropy_prior_sg"]
+
+
+def test_trainer_epoch_synthetic(tmp_path):
+    """The reference's trainer surface end to end on synthetic MNIST-shaped data: 2 epochs crossing the
+    SG-pretraining -> fitted-GM switch (sklearn fit on the host), result npz with the reference's keys."""
+    from ladder_latent_data_distribution_modelling_amd.codes.data_loader import DataGenerator
+    from ladder_latent_data_distribution_modelling_amd.codes.models import MNISTModel_digit
+    from ladder_latent_data_distribution_modelling_amd.codes.trainers import MNISTTrainer_joint_training
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import tiny_config
+    cfg = tiny_config("mnist_digit")
+    cfg.update(batch_size=64, num_epochs=2, sg_pretraining=1, accurate_fit=2, GM_fit_restart=1, synthetic_n_train=256,
+               synthetic_n_val=640, result_dir=str(tmp_path) + "/", checkpoint_dir=str(tmp_path) + "/", n_MC_samples=10)
+    data = DataGenerator(cfg, None)
+    assert data.synthetic
+    model = MNISTModel_digit(cfg)
+    tr = MNISTTrainer_joint_training(None, model, data, cfg)
+    tr.train()
+    assert tr.cur_epoch == 2 and tr.gm_params is not None
+    res = np.load(os.path.join(str(tmp_path), "mnist_digit-result.npz"))
+    for k in ("train_loss", "elbo_train", "val_loss", "code_elbo_train", "sigma"):
+        assert k in res.files
+    assert np.isfinite(res["elbo_train"]).all() and len(res["elbo_train"]) == 2 * tr.n_train_iter
+    assert os.path.isfile(os.path.join(str(tmp_path), "vae-model.npz")) and os.path.isfile(os.path.join(str(tmp_path), "GM_prior_info.npz"))
+    # losses should not blow up and the ELBO should improve over training on a fixed data set
+    assert np.mean(res["elbo_train"][-2:]) > np.mean(res["elbo_train"][:2])
