@@ -90,6 +90,9 @@ def load(path=None):
     if _lib is not None:
         return _lib
     path = path or os.environ.get("LADDER_HIP_LIB", LIB_PATH)
+    # PyTorch-ROCm is the device-memory / stream provider: its HIP runtime must be the one this library binds to,
+    # so make sure it is loaded first (loading libamdhip64 twice, or ours first, breaks kernel launches).
+    import torch  # noqa: F401
     if not os.path.exists(path):
         raise LadderHipError(
             "libladder_hip.so not found at %s: build it with `python -m "

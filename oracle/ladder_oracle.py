@@ -80,6 +80,21 @@ def relu(x):
     return torch.clamp_min(x, 0.0)
 
 
+def tf_maximum(x, y):
+    """tf.maximum with TF's gradient routing: to the first argument where x >= y (ties included)."""
+    return torch.where(x >= y, x, y)
+
+
+def tf_minimum(x, y):
+    """tf.minimum with TF's gradient routing: to the first argument where x <= y (ties included)."""
+    return torch.where(x <= y, x, y)
+
+
+def f32c(v, dt):
+    """A Python-float graph constant as TF sees it: rounded to float32 (then held in the working dtype)."""
+    return torch.tensor(float(np.float32(v)), dtype=dt)
+
+
 def act(x, name):
     if name is None or name == "none":
         return x
@@ -364,7 +379,7 @@ def _dn(P, n, x, a=None):
 def encoder(config, P, x, allreduce=None):
     """x [B,H,W,C] -> code_mean, code_std_dev [B,Z]."""
     exp = config["exp_name"]
-    lvp = float(config["latent_variance_precision"])
+    lvp = f32c(config["latent_variance_precision"], x.dtype)
     B = x.shape[0]
     if exp == "mnist_digit":            # codes/models.py:46-95
         h = pad_symmetric(x, 2)
@@ -450,7 +465,7 @@ def inner_encoder(config, P, z):
     for i in range(nl):
         h = _dn(P, _tfname("prior/dense", i), h, a)
     mean = _dn(P, _tfname("prior/dense", nl), h, None)
-    std = _dn(P, _tfname("prior/dense", nl + 1), h, "relu") + float(config["latent_variance_precision"])
+    std = _dn(P, _tfname("prior/dense", nl + 1), h, "relu") + f32c(config["latent_variance_precision"], z.dtype)
     return mean, std
 
 
@@ -500,7 +515,7 @@ def forward(config, P, x, eps_z, eps_t=None, eps_mc=None, gm=None,
     abs_sum = ar((xhat - x).abs().sum())
     mpe = abs_sum / (Bg * D)
     if config["exp_name"] == "celeba" or int(config["TRAIN_sigma"]) == 1:
-        sigma = torch.maximum(sigma, mpe)
+        sigma = tf_maximum(sigma, mpe)
     out.update(sigma=sigma, mean_pixel_error=mpe)
 
     out["std_dev_code"] = ar(sd_z.sum(0)) / Bg
@@ -519,8 +534,8 @@ def forward(config, P, x, eps_z, eps_t=None, eps_mc=None, gm=None,
         iv = P["inner_sigma/Variable"]
         inner_sigma = torch.sqrt(iv * iv)
         if int(config["TRAIN_inner_sigma"]) == 1:                # base.py:210-212
-            inner_sigma = torch.minimum(torch.maximum(inner_sigma, torch.tensor(float(config["inner_sigma_lb"]), dtype=dt)),
-                                        torch.tensor(float(config["inner_sigma_ub"]), dtype=dt))
+            inner_sigma = tf_minimum(tf_maximum(inner_sigma, f32c(config["inner_sigma_lb"], dt)),
+                                     f32c(config["inner_sigma_ub"], dt))
         out.update(representation_mean=mu_t, representation_std_dev=sd_t, representation_sample=t,
                    decoded_code=zhat, inner_sigma=inner_sigma)
         out["mean_code_error"] = ar((zhat - z).abs().sum()) / (Bg * Z)

@@ -47,6 +47,13 @@ CONV_CASES = [
     (1, 7, 9, 20, 36, 3, 1, "same", "relu"),           # ragged everything
     (2, 9, 9, 16, 16, 3, 2, "same", None),             # odd size stride 2 (pad 1/1)
     (64, 2, 2, 64, 64, 3, 1, "same", None),            # tiny-spatial decoder block
+    (4, 2, 2, 16, 64, 1, 1, "same", "leaky_relu"),     # fashion decoder 1x1 (M=16)
+    (4, 4, 4, 16, 64, 3, 1, "same", "leaky_relu"),
+    (2, 1, 1, 32, 32, 1, 1, "same", None),             # M=2
+    (4, 16, 16, 16, 64, 3, 1, "same", "leaky_relu"),
+    (4, 32, 32, 16, 1, 5, 1, "valid", "relu"),         # fashion output conv
+    (4, 8, 8, 16, 64, 3, 1, "same", "leaky_relu"),
+    (4, 4, 4, 32, 32, 3, 1, "valid", "leaky_relu"),    # fashion encoder valid conv
 ]
 
 
@@ -211,7 +218,8 @@ def test_depth_to_space_and_pad(gpu_ctx):
         assert np.array_equal(back.cpu().numpy(), x)
     x = rng.standard_normal((2, 28, 28, 1)).astype(np.float32)
     y = torch.empty(2, 32, 32, 1, device="cuda")
-    L.call("ladder_pad_symmetric", p(dev(x)), p(y), 2, 28, 28, 1, 2, st)
+    xd = dev(x)
+    L.call("ladder_pad_symmetric", p(xd), p(y), 2, 28, 28, 1, 2, st)
     assert np.array_equal(y.cpu().numpy(), np.pad(x, ((0, 0), (2, 2), (2, 2), (0, 0)), mode="symmetric"))
 
 
@@ -235,10 +243,12 @@ def test_gmm_logprob(gpu_ctx, golden_dir, K, R, Lmc, B):
     lp.sum().backward()
     st = gpu_ctx.stream
     packed = torch.empty(K * L.query("ladder_gmm_packed_stride", R), device="cuda")
-    L.call("ladder_gmm_prepare", p(dev(gm["weights"])), p(dev(gm["means"])), p(dev(gm["covs"])), K, R, p(packed), st)
+    wd, md, cd = dev(gm["weights"]), dev(gm["means"]), dev(gm["covs"])      # keep alive until the kernels ran
+    L.call("ladder_gmm_prepare", p(wd), p(md), p(cd), K, R, p(packed), st)
     out, dmu, dsd = torch.empty(1, device="cuda"), torch.empty(B, R, device="cuda"), torch.empty(B, R, device="cuda")
     wsp, wsn = gpu_ctx.ws(L.query("ladder_gmm_workspace_bytes", Lmc, B))
-    L.call("ladder_gmm_logprob_fwd_bwd", p(dev(mu)), p(dev(sd)), p(dev(eps)), p(packed), Lmc, B, R, K, p(out), p(dmu), p(dsd), wsp, wsn, st)
+    mud, sdd, epsd = dev(mu), dev(sd), dev(eps)
+    L.call("ladder_gmm_logprob_fwd_bwd", p(mud), p(sdd), p(epsd), p(packed), Lmc, B, R, K, p(out), p(dmu), p(dsd), wsp, wsn, st)
     assert abs(out.item() - lp.sum().item()) < 2e-5 * abs(lp.sum().item()) + 1e-3
     close(dmu, mut.grad, 5e-5, "dmu")
     close(dsd, sdt.grad, 5e-5, "dsd")
@@ -257,7 +267,8 @@ def test_adam_clip_matches_tf_form(gpu_ctx):
         g = (rng.standard_normal(n) * 2).astype(np.float32)     # many |g|>1 -> exercises the clip
         O.adam_tf(th64, g.astype(np.float64), m64, v64, t, 3e-4)
         lr_t = 3e-4 * np.sqrt(1 - 0.95 ** t) / (1 - 0.9 ** t)
-        L.call("ladder_adam_clip", p(thd), p(dev(g)), p(md), p(vd), n, float(lr_t), 0.9, 0.95, 1e-8, 1.0, gpu_ctx.stream)
+        gd = dev(g)
+        L.call("ladder_adam_clip", p(thd), p(gd), p(md), p(vd), n, float(lr_t), 0.9, 0.95, 1e-8, 1.0, gpu_ctx.stream)
     close(thd, th64, 1e-6, "theta")
     close(md, m64, 1e-6, "m")
     close(vd, v64, 1e-6, "v")
