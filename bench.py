@@ -1,0 +1,168 @@
+"""bench.py -- the reference's headline workload on MI355X: LaDDer training iterations, CelebA 128x128.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one pass of the hot path over one minibatch = the reference's four sess.run's (codes/base.py:583-641) in
+the post-pretraining regime (fitted-GM feed, prior + inner-sigma training on), through the trainer's own step functions.
+Workload at N=1: BASELINE.json configs[2] (codes/celeba_config.json: CelebA 128x128, nh=512, z=64, R=2, K=30, B=128);
+N>1: the same per-GPU batch on every rank (weak scaling, global batch N*128) with RCCL all-reduces C1-C4.
+Inputs are synthetic (x ~ U[0,1), seeded Glorot weights) and resident in HBM before the timed region starts.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FWD_FLOP_PER_IMG = {"celeba": 41.4e9}   # RUN#1 30.1 + RUN#2 10.0 + RUN#3 0.63 + RUN#4 0.62 GFLOP / image / iteration
+FP32_PEAK_TFLOPS = 157.3                # MI355X_MICROARCH.md: fp32 MFMA (= vector) dense peak
+
+
+def cpu_baseline(cfg, gm, seconds_budget=20.0, threads=None):
+    """The oracle (CPU restatement of the TF1 reference path, fp32) timed on a bounded sample of the same workload.
+    Thread count: min(host cores, 32) -- torch-CPU convolutions at this batch size get slower, not faster, beyond
+    that on the 256-thread GPU hosts (measured: 256 threads ran 100x slower than 8)."""
+    import numpy as np
+    import torch
+    from oracle import ladder_oracle as O
+    cores = threads or min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    Bc = 4
+    rng = np.random.default_rng(0)
+    x = rng.random((Bc, cfg["dim_input_x"], cfg["dim_input_y"], cfg["dim_input_channel"])).astype(np.float32)
+    st = O.OracleState(cfg, O.init_params(cfg, seed=1), np.float32)
+    nrng = np.random.default_rng(2)
+    epoch = int(cfg["sg_pretraining"]) + 1
+
+    def one(xb):
+        noises = [O.make_noise(cfg, xb.shape[0], nrng, np.float32) for _ in range(4)]
+        t0 = time.time()
+        O.train_iteration(st, xb, noises, gm, cur_epoch=epoch, lr_ae=cfg["learning_rate_ae"])
+        return time.time() - t0
+
+    one(x[:1])                                   # warm-up (thread pool, allocator), not timed
+    n_it, t_tot = 0, 0.0
+    while n_it < 1 or (t_tot < seconds_budget and n_it < 8):
+        t_tot += one(x)
+        n_it += 1
+    return dict(value=round(Bc * n_it / t_tot, 3), unit="images/sec", cores=cores, kind="port",
+                sample="%d full 4-run iterations at batch %d of the same CelebA 128x128 nh=512 z=64 K=30 network "
+                       "(oracle/ladder_oracle.py, torch-CPU fp32, %d threads)" % (n_it, Bc, cores))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default=os.path.join(ROOT, "codes", "celeba_config.json"))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (default: config batch_size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from ladder_latent_data_distribution_modelling_amd import engine as E
+    from ladder_latent_data_distribution_modelling_amd.codes.models import CelebAModel_densenet, MNISTModel_digit, MNISTModel_fashion
+    from ladder_latent_data_distribution_modelling_amd.codes.base import BaseTrain_joint
+
+    cfg = json.load(open(args.config))
+    if args.batch:
+        cfg["batch_size"] = args.batch
+    cfg.setdefault("checkpoint_dir", "/tmp/ladder_bench/")
+    cfg.setdefault("result_dir", "/tmp/ladder_bench/")
+    B = int(cfg["batch_size"])
+    Model = {"celeba": CelebAModel_densenet, "mnist_digit": MNISTModel_digit, "mnist_fashion": MNISTModel_fashion}[cfg["exp_name"]]
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = Model(cfg, device="cuda:%d" % local, seed=1)
+    trainer = BaseTrain_joint(None, model, None, cfg)
+    trainer.cur_epoch = int(cfg["sg_pretraining"]) + 1          # post-pretraining regime: all four runs active
+    fix = np.load(os.path.join(ROOT, "tests", "golden", "GM_prior_info.npz"))
+    K, R = int(cfg["n_mixtures"]), int(cfg["representation_size"])
+    if R == 2 and K <= 50:
+        w = fix["w_full"][:K] / fix["w_full"][:K].sum()
+        gm = dict(weights=w, means=fix["m_full"][:K], covs=fix["K_full"][:K])
+    else:
+        rng = np.random.default_rng(3)
+        A = rng.normal(0, 0.3, (K, R, R))
+        gm = dict(weights=rng.dirichlet(np.ones(K)), means=rng.normal(0, 1.5, (K, R)),
+                  covs=A @ A.transpose(0, 2, 1) / R + 0.05 * np.eye(R))
+    trainer.gm_params = (gm["weights"], gm["means"], gm["covs"])
+    x = torch.as_tensor(np.random.default_rng(rank).random((B, cfg["dim_input_x"], cfg["dim_input_y"], cfg["dim_input_channel"]),
+                                                          dtype=np.float32)).cuda()
+    lr = float(cfg["learning_rate_ae"])
+
+    def step():
+        trainer.train_step_ae(cur_lr=lr, batch_data=x)
+        trainer.train_step_prior(batch_data=x)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_profile:
+        E.PROF = E.KernelProfiler(128128)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = E.PROF.summary() if E.PROF is not None else None
+    E.PROF = None
+    tdt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+    dt = float(tdt.item())
+    value = B * world * args.steps / dt
+    f = trainer.last_fetch_ae
+    out = {
+        "metric": "training images/sec (full 4-run LaDDer iteration, CelebA 128x128)", "value": round(value, 2), "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: %s %dx%dx%d nh=%d z=%d R=%d K=%d L=%d per-GPU batch=%d, 4 runs/iteration "
+                               "(AE step, sigma step, prior step, inner-sigma step), fitted-GM regime" % (
+                                   cfg["exp_name"], cfg["dim_input_x"], cfg["dim_input_y"], cfg["dim_input_channel"],
+                                   cfg["num_hidden_units"], cfg["code_size"], R, K, cfg["n_MC_samples"], B),
+                   "global_batch": B * world, "parallelism": "dp%d" % world},
+        "elbo": f["elbo"], "elbo_prior": trainer.last_fetch_prior["elbo_prior"],
+    }
+    if prof is not None and prof["launches"]:
+        out["roofline"] = {"bound": "mfma", "kernel": "igemm_fwd_kernel<128,128,2,2,true,true> (conv fwd + bwd_data, fp32 MFMA 32x32x2)",
+                           "achieved": round(prof["tflops"], 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(prof["tflops"] / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                           "launches": prof["launches"], "avg_launch_ms": round(prof["avg_ms"], 4),
+                           "flop_per_launch": prof["flops_per_launch"]}
+    whole = FWD_FLOP_PER_IMG.get(cfg["exp_name"])
+    if whole and int(cfg["num_hidden_units"]) == 512 and int(cfg["code_size"]) == 64:
+        out["whole_step_tflops_per_gpu"] = round(whole * value / world / 1e12, 2)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, gm)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

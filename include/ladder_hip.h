@@ -35,6 +35,9 @@ enum { LADDER_ACT_NONE = 0, LADDER_ACT_LEAKY = 1 /* alpha 0.2 */, LADDER_ACT_REL
 
 /* Build/ABI identification. */
 int ladder_abi_version(void);
+/* BM*1000+BN of the implicit-GEMM instantiation a forward-type call (conv fwd / bwd_data / dense fwd / bwd_data) with
+ * GEMM extents M x (.) x Cout and gathered channel count Cin dispatches to; negative = non-vectorised variant. */
+int ladder_igemm_fwd_tile(long M, int Cin, int Cout);
 
 /* ---------------------------------------------------------------- N1: tf.layers.conv2d
  * codes/models.py:51-71,115-148,203-229,273-315,398-460,514-585.

@@ -20,6 +20,37 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+class KernelProfiler:
+    """HIP-event timing of every launch dispatched to ONE implicit-GEMM instantiation (bench.py's roofline leg).
+    Events are recorded on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self, tile=128128):
+        self.tile, self.records = tile, []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
+        fl = sum(f for _, _, f in self.records)
+        n = len(self.records)
+        return dict(launches=n, total_ms=ms, avg_ms=ms / max(n, 1), flops_per_launch=fl / max(n, 1),
+                    tflops=(fl / (ms * 1e-3) / 1e12) if ms > 0 else 0.0)
+
+
+PROF = None   # set to a KernelProfiler by bench.py
+
+
+def _igemm(name, M, Cin, Cout, Kdim, *args):
+    """Forward-type implicit-GEMM call (conv fwd / bwd_data / dense fwd / bwd_data) with optional event timing."""
+    if PROF is not None and L.query("ladder_igemm_fwd_tile", M, Cin, Cout) == PROF.tile:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        L.call(name, *args)
+        e.record()
+        PROF.records.append((s, e, 2.0 * M * Kdim * Cout))
+    else:
+        L.call(name, *args)
+
+
 class Comm:
     """Data-parallel exchange steps C1-C4 of SURVEY 2.3 over torch.distributed (RCCL on ROCm).
     With world_size 1 every method is a no-op."""
@@ -140,7 +171,8 @@ class Conv2D:
         self.pt, Ho = arch.conv_out(H, self.k, self.stride, self.padding)
         self.pl, Wo = arch.conv_out(W, self.k, self.stride, self.padding)
         y = self.ctx.empty(N, Ho, Wo, self.cout)
-        L.call("ladder_conv2d_fwd", _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y),
+        _igemm("ladder_conv2d_fwd", N * Ho * Wo, self.cin, self.cout, self.k * self.k * self.cin,
+               _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y),
                N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl, L.ACT[self.act],
                self.ctx.stream)
         self.x, self.y = x, y
@@ -165,7 +197,8 @@ class Conv2D:
             wT = self.ctx.empty(w.numel())
             L.call("ladder_filter_flip_transpose", _p(w), _p(wT), self.k, self.k, self.cin, self.cout, st)
             dx = self.ctx.empty(N, H, W, self.cin)
-            L.call("ladder_conv2d_bwd_data", _p(dy), _p(wT), _p(dx), N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k,
+            _igemm("ladder_conv2d_bwd_data", N * H * W, self.cout, self.cin, self.k * self.k * self.cout,
+                   _p(dy), _p(wT), _p(dx), N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k,
                    self.stride, self.pt, self.pl, st)
         self.x = self.y = None
         return dx
@@ -180,7 +213,8 @@ class Dense:
     def forward(self, x):
         M = x.shape[0]
         y = self.ctx.empty(M, self.cout)
-        L.call("ladder_dense_fwd", _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y),
+        _igemm("ladder_dense_fwd", M, self.cin, self.cout, self.cin,
+               _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y),
                M, self.cin, self.cout, L.ACT[self.act], self.ctx.stream)
         self.x, self.y = x, y
         return y
@@ -201,7 +235,7 @@ class Dense:
             wT = self.ctx.empty(w.numel())
             L.call("ladder_filter_flip_transpose", _p(w), _p(wT), 1, 1, self.cin, self.cout, st)
             dx = self.ctx.empty(M, self.cin)
-            L.call("ladder_dense_bwd_data", _p(dy), _p(wT), _p(dx), M, self.cin, self.cout, st)
+            _igemm("ladder_dense_bwd_data", M, self.cout, self.cin, self.cout, _p(dy), _p(wT), _p(dx), M, self.cin, self.cout, st)
         self.x = self.y = None
         return dx
 
