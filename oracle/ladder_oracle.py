@@ -491,10 +491,13 @@ def sg_feed(config, dtype=torch.float64):
 
 
 def forward(config, P, x, eps_z, eps_t=None, eps_mc=None, gm=None,
-            use_sg=True, use_mask=False, code_input=None, allreduce=None, global_batch=None):
+            use_sg=True, use_mask=False, code_input=None, allreduce=None, global_batch=None, stat_allreduce=None):
     """Evaluate every tensor the step functions fetch.  All batch means are over
     `global_batch` samples (defaults to the local batch); with `allreduce` given,
-    partial sums are summed over ranks first (data-parallel restatement)."""
+    partial sums are summed over ranks first (data-parallel restatement).
+    Two kinds of exchange: `allreduce` sums the scalar partials (C3) -- what follows is replicated scalar
+    algebra, so its backward is the identity; `stat_allreduce` sums batch-norm statistics (C2) -- their
+    consumers are the rank's own samples, so its backward must all-reduce the gradient as well."""
     dt = x.dtype
     B = x.shape[0]
     Bg = float(global_batch if global_batch is not None else B)
@@ -502,7 +505,7 @@ def forward(config, P, x, eps_z, eps_t=None, eps_mc=None, gm=None,
     Z = int(config["code_size"])
     D = int(config["dim_input_x"]) * int(config["dim_input_y"]) * int(config["dim_input_channel"])
     out = {}
-    mu_z, sd_z = encoder(config, P, x, allreduce)
+    mu_z, sd_z = encoder(config, P, x, stat_allreduce if stat_allreduce is not None else allreduce)
     z = mu_z + sd_z * eps_z                                     # models.py:97-103
     out.update(code_mean=mu_z, code_std_dev=sd_z, code_sample=z)
     dec_in = z if code_input is None else code_input           # models.py:107,265,500
@@ -616,7 +619,7 @@ def _gm_t(gm, dt):
 
 
 def run(state, x, noise, gm, use_sg, use_mask, train=None, lr=0.0, allreduce=None,
-        global_batch=None, grad_allreduce=None):
+        global_batch=None, grad_allreduce=None, stat_allreduce=None):
     """One `sess.run`: forward with `noise` = dict(eps_z, eps_t, eps_mc); if `train` names an
     optimiser group, differentiate its loss w.r.t. that group, (all-reduce,) clip, Adam.
     Returns {fetch: numpy}."""
@@ -625,7 +628,7 @@ def run(state, x, noise, gm, use_sg, use_mask, train=None, lr=0.0, allreduce=Non
     P = state.torch_params((train,) if train else ())
     out = forward(cfg, P, _TO(x, tdt), _TO(noise["eps_z"], tdt), _TO(noise.get("eps_t"), tdt),
                   _TO(noise.get("eps_mc"), tdt), _gm_t(gm, tdt), use_sg, use_mask,
-                  allreduce=allreduce, global_batch=global_batch)
+                  allreduce=allreduce, global_batch=global_batch, stat_allreduce=stat_allreduce)
     grads = None
     if train:
         loss = out["loss_ae"] if train in ("ae", "sigma") else out["loss_prior"]
