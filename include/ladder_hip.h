@@ -45,16 +45,23 @@ int ladder_igemm_fwd_tile(long M, int Cin, int Cout);
  * (out-of-range taps read 0).  Explicit top/left padding expresses TF SAME (asymmetric) and VALID. */
 int ladder_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
                       int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
-                      int KH, int KW, int stride, int pad_t, int pad_l, int act, ladder_stream_t stream);
+                      int KH, int KW, int stride, int pad_t, int pad_l, int act,
+                      void* ws, size_t ws_bytes, ladder_stream_t stream);
+/* Optional scratch of the forward-type calls (conv fwd / bwd_data, dense fwd / bwd_data): when the output tiling cannot
+ * fill the 256 CUs (small M*Cout, long K) the contraction is split over K into `ws` and summed in a fixed order by a
+ * second kernel (bias/activation applied there).  ws == NULL or too small => single-pass kernel.  M, K, Cout = GEMM extents. */
+size_t ladder_igemm_fwd_workspace_bytes(long M, int K, int Cout);
 /* wT[KH-1-r][KW-1-s][co][ci] = w[r][s][ci][co]: the filter bank bwd_data consumes. */
 int ladder_filter_flip_transpose(const float* w, float* wT, int KH, int KW, int Cin, int Cout, ladder_stream_t stream);
 /* dx[n,hi,wi,ci] = sum dy[n,ho,wo,co] * w[r,s,ci,co] over {hi = ho*stride + r - pad_t, ...}; wT from above.
  * (N,H,W,Cin) describe dx, (Ho,Wo,Cout) describe dy. */
 int ladder_conv2d_bwd_data(const float* dy, const float* wT, float* dx,
                            int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
-                           int KH, int KW, int stride, int pad_t, int pad_l, ladder_stream_t stream);
+                           int KH, int KW, int stride, int pad_t, int pad_l,
+                           void* ws, size_t ws_bytes, ladder_stream_t stream);
 size_t ladder_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW);
-/* dw[r,s,ci,co] = sum_{n,ho,wo} x[...] * dy[n,ho,wo,co];  db[co] = sum dy (db may be NULL). */
+/* dw[r,s,ci,co] = sum_{n,ho,wo} x[...] * dy[n,ho,wo,co];  db[co] = sum dy, accumulated inside the same kernel
+ * (db may be NULL: e.g. a conv feeding batch-/instance-norm, whose bias gradient is identically zero). */
 int ladder_conv2d_bwd_filter(const float* x, const float* dy, float* dw, float* db,
                              int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
                              int KH, int KW, int stride, int pad_t, int pad_l,
@@ -64,9 +71,10 @@ int ladder_conv2d_bwd_filter(const float* x, const float* dy, float* dw, float* 
  * codes/models.py:73-95,109,231-253,267,478-488,501-510; codes/modules.py:8; codes/base.py:145-186.
  * y[M,N] = act(x[M,K] @ w[K,N] + b).  MFMA-f32 (v_mfma_f32_32x32x2_f32). */
 int ladder_dense_fwd(const float* x, const float* w, const float* bias, float* y,
-                     int M, int K, int N, int act, ladder_stream_t stream);
+                     int M, int K, int N, int act, void* ws, size_t ws_bytes, ladder_stream_t stream);
 /* dx[M,K] = dy[M,N] @ w^T, wT = ladder_filter_flip_transpose(w, 1,1,K,N) i.e. [N,K]. */
-int ladder_dense_bwd_data(const float* dy, const float* wT, float* dx, int M, int K, int N, ladder_stream_t stream);
+int ladder_dense_bwd_data(const float* dy, const float* wT, float* dx, int M, int K, int N,
+                          void* ws, size_t ws_bytes, ladder_stream_t stream);
 size_t ladder_dense_bwd_weight_workspace_bytes(int M, int K, int N);
 int ladder_dense_bwd_weight(const float* x, const float* dy, float* dw, float* db,
                             int M, int K, int N, void* ws, size_t ws_bytes, ladder_stream_t stream);

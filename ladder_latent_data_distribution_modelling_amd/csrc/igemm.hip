@@ -20,20 +20,46 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+struct FastDiv {   // exact unsigned 32-bit division by a runtime constant (Granlund-Montgomery round-up method)
+  uint32_t m, s1, s2;
+};
 struct IgemmDesc {
   int N, H, W, Cin;      // gathered tensor
   int Ho, Wo, Cout;      // GEMM-M spatial extent and GEMM-N
   int KH, KW, stride, ups, pad_t, pad_l;
   int M, K;
   int act;
+  FastDiv div_howo, div_wo;
 };
 
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int BK = 16;
+#ifndef IGEMM_BK
+#define IGEMM_BK 16
+#endif
+#ifndef IGEMM_MINW
+#define IGEMM_MINW 1
+#endif
+#ifndef IGEMM_PIN
+#define IGEMM_PIN 0
+#endif
+constexpr int BK = IGEMM_BK;
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+  const uint32_t t = __umulhi(f.m, n);
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+inline FastDiv make_fastdiv(uint32_t d) {
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;
+  FastDiv f;
+  f.m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  f.s1 = l < 1 ? l : 1;
+  f.s2 = l > 1 ? l - 1 : 0;
+  return f;
+}
 
 // One gathered element of A: returns pointer offset or -1 when the tap falls outside / between samples.
 __device__ __forceinline__ long gather_off(const IgemmDesc& d, long img, int bh, int bw, int r, int s, int ci) {
@@ -49,9 +75,10 @@ __device__ __forceinline__ long gather_off(const IgemmDesc& d, long img, int bh,
 }
 
 template <int BM, int BN, int WM, int WN, bool VECA, bool VECB>
-__global__ __launch_bounds__(kThreads) void igemm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? 4 : IGEMM_MINW) void igemm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ y,
-                                                             const IgemmDesc d, const int tiles_n) {
+                                                             const IgemmDesc d, const int tiles_n, const bool fast,
+                                                             float* __restrict__ part, const int chunks_per_split) {
   constexpr int LDA = BK + 1;  // odd row stride: conflict-free ds_read_b32 of A fragments
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
   constexpr int A_UNITS = BM * (BK / 4), B_UNITS = BK * (BN / 4);
@@ -68,23 +95,37 @@ __global__ __launch_bounds__(kThreads) void igemm_fwd_kernel(const float* __rest
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
   const int HoWo = d.Ho * d.Wo;
 
-  // per-thread A rows (fixed for the whole K loop)
+  // per-thread A rows (fixed for the whole K loop): base pointer of tap (0,0) and a bitmask of the taps that
+  // fall inside the image, so the K loop only adds a wave-uniform tap offset and tests one bit.
+  constexpr bool FASTA = VECA;          // needs KH*KW <= 32 and ups == 1 (checked by the launcher via `fast`)
   int a_row[AU], a_kq[AU], a_bh[AU], a_bw[AU];
   long a_img[AU];
   bool a_ok[AU];
+  const float* a_ptr[AU];
+  uint32_t a_mask[AU];
 #pragma unroll
   for (int i = 0; i < AU; ++i) {
     const int u = tid + i * kThreads;
-    a_row[i] = u >> 2;
-    a_kq[i] = u & 3;
+    a_row[i] = u / (BK / 4);
+    a_kq[i] = u % (BK / 4);
     const int m = m0 + a_row[i];
     a_ok[i] = (u < A_UNITS) && (m < d.M);
-    const int mm = a_ok[i] ? m : 0;
-    const int n_img = mm / HoWo, rem = mm - n_img * HoWo;
-    const int ho = rem / d.Wo, wo = rem - ho * d.Wo;
-    a_bh[i] = ho * d.stride - d.pad_t;
-    a_bw[i] = wo * d.stride - d.pad_l;
+    const uint32_t mm = a_ok[i] ? m : 0;
+    const uint32_t n_img = fdiv(mm, d.div_howo), rem = mm - n_img * HoWo;
+    const uint32_t ho = fdiv(rem, d.div_wo), wo = rem - ho * d.Wo;
+    a_bh[i] = (int)ho * d.stride - d.pad_t;
+    a_bw[i] = (int)wo * d.stride - d.pad_l;
     a_img[i] = (long)n_img * d.H * d.W * d.Cin;
+    a_ptr[i] = x + a_img[i] + ((long)a_bh[i] * d.W + a_bw[i]) * d.Cin + a_kq[i] * 4;
+    uint32_t msk = 0;
+    if (FASTA && fast && a_ok[i]) {
+      for (int r = 0; r < d.KH; ++r)
+        for (int sx = 0; sx < d.KW; ++sx) {
+          const int nh = a_bh[i] + r, nw = a_bw[i] + sx;
+          if (nh >= 0 && nh < d.H && nw >= 0 && nw < d.W) msk |= 1u << (r * d.KW + sx);
+        }
+    }
+    a_mask[i] = msk;
   }
   int b_kr[BU], b_nq[BU];
 #pragma unroll
@@ -97,13 +138,20 @@ __global__ __launch_bounds__(kThreads) void igemm_fwd_kernel(const float* __rest
   float4 ra[AU], rb[BU];
   auto load_chunk = [&](int c) {
     const int k0 = c * BK;
-    if (VECA) {  // Cin % 16 == 0: the whole chunk lies inside one filter tap
+    if (VECA) {  // Cin % BK == 0: the whole chunk lies inside one filter tap (wave-uniform r, s, ci0)
       const int rs = k0 / d.Cin, ci0 = k0 - rs * d.Cin;
       const int r = rs / d.KW, s = rs - r * d.KW;
+      if (fast) {
+        const long coff = ((long)r * d.W + s) * d.Cin + ci0;
 #pragma unroll
-      for (int i = 0; i < AU; ++i) {
-        long off = a_ok[i] ? gather_off(d, a_img[i], a_bh[i], a_bw[i], r, s, ci0 + a_kq[i] * 4) : -1;
-        ra[i] = off >= 0 ? ld4(x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < AU; ++i)
+          ra[i] = ((a_mask[i] >> rs) & 1u) ? ld4(a_ptr[i] + coff) : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+#pragma unroll
+        for (int i = 0; i < AU; ++i) {
+          long off = a_ok[i] ? gather_off(d, a_img[i], a_bh[i], a_bw[i], r, s, ci0 + a_kq[i] * 4) : -1;
+          ra[i] = off >= 0 ? ld4(x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
       }
     } else {
 #pragma unroll
@@ -160,32 +208,55 @@ __global__ __launch_bounds__(kThreads) void igemm_fwd_kernel(const float* __rest
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-  const int nchunks = (d.K + BK - 1) / BK;
-  load_chunk(0);
+  // split-K: blockIdx.y owns the chunk range [c_begin, nchunks)
+  const int c_begin = blockIdx.y * chunks_per_split;
+  const int nchunks = min((d.K + BK - 1) / BK, c_begin + chunks_per_split);
+  load_chunk(c_begin);
   store_chunk(0);
   __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
-    const int buf = c & 1;
+  for (int c = c_begin; c < nchunks; ++c) {
+    const int buf = (c - c_begin) & 1;
     if (c + 1 < nchunks) load_chunk(c + 1);
     const float* Ab = &As[buf][(wm * TM + l31) * LDA + lh];
     const float* Bb = &Bs[buf][lh * BN + wn * TN + l31];
+    // all fragment reads of the chunk are issued before the MFMA block (one LDS round trip per chunk, not per k-step)
+    float af[BK / 2][MI], bf[BK / 2][NI];
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a[MI], b[NI];
+    for (int ks = 0; ks < BK / 2; ++ks) {
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) a[mi] = Ab[mi * 32 * LDA + kk];
+      for (int mi = 0; mi < MI; ++mi) af[ks][mi] = Ab[mi * 32 * LDA + 2 * ks];
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) b[ni] = Bb[kk * BN + ni * 32];
+      for (int ni = 0; ni < NI; ++ni) bf[ks][ni] = Bb[2 * ks * BN + ni * 32];
+    }
+#if IGEMM_PIN
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks)
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-    }
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks][mi], bf[ks][ni], acc[mi][ni], 0, 0, 0);
     if (c + 1 < nchunks) store_chunk(buf ^ 1);
     __syncthreads();
   }
 
+  if (part != nullptr) {   // split-K partial: raw accumulators, bias/activation applied by splitk_epilogue_kernel
+    float* o = part + (size_t)blockIdx.y * d.M * d.Cout;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + wn * TN + ni * 32 + l31;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wm * TM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (m < d.M && n < d.Cout) o[(long)m * d.Cout + n] = acc[mi][ni][e];
+        }
+    }
+    return;
+  }
   // epilogue: bias + activation, 128-byte row segments per half-wave
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
@@ -203,10 +274,13 @@ __global__ __launch_bounds__(kThreads) void igemm_fwd_kernel(const float* __rest
 }
 
 // dW[K x N] (+= over pixel split) = A_gather^T * dY.  GEMM-M here is the filter index k' = (r,s,ci).
+#ifndef IGEMM_WG_MINW
+#define IGEMM_WG_MINW 3
+#endif
 template <int BM, int BN, int WM, int WN, bool VECA, bool VECB>
-__global__ __launch_bounds__(kThreads) void igemm_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                               float* __restrict__ out, const IgemmDesc d,
-                                                               const int tiles_n, const int m_per_split) {
+__global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? IGEMM_WG_MINW : 1) void igemm_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ out, float* __restrict__ bias_part,
+                                                               const IgemmDesc d, const int tiles_n, const int m_per_split) {
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
   constexpr int A_UNITS = BK * (BM / 4), B_UNITS = BK * (BN / 4);
   constexpr int AU = (A_UNITS + kThreads - 1) / kThreads, BU = (B_UNITS + kThreads - 1) / kThreads;
@@ -250,6 +324,11 @@ __global__ __launch_bounds__(kThreads) void igemm_wgrad_kernel(const float* __re
     b_nq[i] = u % (BN / 4);
   }
 
+  // bias gradient (column sums of dY) rides along in the k'-tile-0 workgroups: they already stream every dY row
+  const bool do_bias = (bias_part != nullptr) && (tile / tiles_n == 0);
+  float4 bsum[BU];
+#pragma unroll
+  for (int i = 0; i < BU; ++i) bsum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 ra[AU], rb[BU];
   auto load_chunk = [&](int c) {
     const int pc = p_begin + c * BK;
@@ -258,8 +337,8 @@ __global__ __launch_bounds__(kThreads) void igemm_wgrad_kernel(const float* __re
       const int p = pc + a_pr[i];
       float v[4] = {0.f, 0.f, 0.f, 0.f};
       if (p < p_end) {
-        const int n_img = p / HoWo, rem = p - n_img * HoWo;
-        const int ho = rem / d.Wo, wo = rem - ho * d.Wo;
+        const uint32_t n_img = fdiv((uint32_t)p, d.div_howo), rem = (uint32_t)p - n_img * HoWo;
+        const int ho = (int)fdiv(rem, d.div_wo), wo = (int)rem - ho * d.Wo;
         const long img = (long)n_img * d.H * d.W * d.Cin;
         const int bh = ho * d.stride - d.pad_t, bw = wo * d.stride - d.pad_l;
         if (VECA) {
@@ -293,6 +372,9 @@ __global__ __launch_bounds__(kThreads) void igemm_wgrad_kernel(const float* __re
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = (inb && n + j < d.Cout) ? dy[(long)p * d.Cout + n + j] : 0.f;
         rb[i] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+      if (do_bias) {
+        bsum[i].x += rb[i].x; bsum[i].y += rb[i].y; bsum[i].z += rb[i].z; bsum[i].w += rb[i].w;
       }
     }
   };
@@ -354,6 +436,29 @@ __global__ __launch_bounds__(kThreads) void igemm_wgrad_kernel(const float* __re
       }
     }
   }
+  if (do_bias) {   // fixed-order reduction of the per-thread column sums through LDS (all MFMA reads of Bt are done)
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < BU; ++i)
+      if (tid + i * kThreads < B_UNITS) *reinterpret_cast<float4*>(&Bt[0][b_pr[i] * BN + b_nq[i] * 4]) = bsum[i];
+    __syncthreads();
+    if (tid < BN && n0 + tid < d.Cout) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int r = 0; r < BK; ++r) sacc += Bt[0][r * BN + tid];
+      bias_part[(size_t)blockIdx.y * d.Cout + n0 + tid] = sacc;
+    }
+  }
+}
+
+__global__ void splitk_epilogue_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ y,
+                                       int S, size_t MN, int N, int act) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= MN) return;
+  float s = 0.f;
+  for (int z = 0; z < S; ++z) s += part[(size_t)z * MN + i];   // fixed order
+  if (bias != nullptr) s += bias[i % N];
+  y[i] = ladder_act_fn(s, act);
 }
 
 __global__ void reduce_splits_kernel(const float* __restrict__ ws, float* __restrict__ out, int S, size_t n) {
@@ -405,15 +510,43 @@ __global__ void colsum_stage2(const float* __restrict__ ws, float* __restrict__ 
 
 struct TileCfg { int bm, bn; };
 
+struct SplitPlan { int splits, cps; };
+// split-K only when the output tiling cannot fill the chip and K is long enough to amortise the second pass
+SplitPlan plan_splitk(long M, int K, int Cout, int bm, int bn) {
+  const long tiles = ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn);
+  const int nchunks = (K + BK - 1) / BK;
+  SplitPlan p{1, nchunks};
+  if (tiles >= 640 || nchunks < 16) return p;
+  long s = tiles < 128 ? (384 + tiles - 1) / tiles : 1024 / tiles;   // small grids: >=1.5 wg/CU; mid grids: one full round of 4 wg/CU
+  if (s > nchunks / 8) s = nchunks / 8;
+  if (tiles < 128 && s < nchunks / 4 && s * tiles < 256) s = nchunks / 4;
+  if (s > 32) s = 32;
+  if (s < 2) return p;
+  p.cps = (int)((nchunks + s - 1) / s);
+  p.splits = (nchunks + p.cps - 1) / p.cps;
+  return p;
+}
+
 template <int BM, int BN, int WM, int WN>
-int launch_fwd(const float* x, const float* w, const float* bias, float* y, const IgemmDesc& d, hipStream_t st) {
+int launch_fwd(const float* x, const float* w, const float* bias, float* y, const IgemmDesc& d, void* ws, size_t ws_bytes,
+               hipStream_t st) {
   const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.Cout + BN - 1) / BN;
   const bool veca = (d.Cin % BK) == 0, vecb = (d.Cout % 4) == 0;
-  dim3 grid(tiles_m * tiles_n), block(kThreads);
-  if (veca && vecb) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, x, w, bias, y, d, tiles_n);
-  else if (veca) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, st, x, w, bias, y, d, tiles_n);
-  else if (vecb) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, st, x, w, bias, y, d, tiles_n);
-  else hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, x, w, bias, y, d, tiles_n);
+  const bool fast = d.ups == 1 && d.KH * d.KW <= 32;
+  SplitPlan sp = plan_splitk(d.M, d.K, d.Cout, BM, BN);
+  const size_t need = (size_t)sp.splits * d.M * d.Cout * sizeof(float);
+  if (sp.splits > 1 && (ws == nullptr || ws_bytes < need)) sp = SplitPlan{1, (d.K + BK - 1) / BK};
+  float* part = sp.splits > 1 ? (float*)ws : nullptr;
+  dim3 grid(tiles_m * tiles_n, sp.splits), block(kThreads);
+  if (veca && vecb) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, x, w, bias, y, d, tiles_n, fast, part, sp.cps);
+  else if (veca) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, st, x, w, bias, y, d, tiles_n, fast, part, sp.cps);
+  else if (vecb) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, st, x, w, bias, y, d, tiles_n, fast, part, sp.cps);
+  else hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, x, w, bias, y, d, tiles_n, fast, part, sp.cps);
+  if (part != nullptr) {
+    const size_t mn = (size_t)d.M * d.Cout;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, (const float*)part, bias, y,
+                       sp.splits, mn, d.Cout, d.act);
+  }
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
@@ -430,16 +563,23 @@ int select_fwd_tile(long M, int Cout) {
   return 128032;
 }
 
-int dispatch_fwd(const float* x, const float* w, const float* bias, float* y, const IgemmDesc& d, hipStream_t st) {
+int dispatch_fwd(const float* x, const float* w, const float* bias, float* y, const IgemmDesc& d, void* ws, size_t ws_bytes,
+                 hipStream_t st) {
   if (d.M <= 0 || d.K <= 0 || d.Cout <= 0) return LADDER_E_SHAPE;
   if (!ladder_aligned16(x) || !ladder_aligned16(w) || !ladder_aligned16(y)) return LADDER_E_ALIGN;
   switch (select_fwd_tile(d.M, d.Cout)) {
-    case 128128: return launch_fwd<128, 128, 2, 2>(x, w, bias, y, d, st);
-    case 64064: return launch_fwd<64, 64, 2, 2>(x, w, bias, y, d, st);
-    case 32128: return launch_fwd<32, 128, 1, 4>(x, w, bias, y, d, st);
-    case 128064: return launch_fwd<128, 64, 4, 1>(x, w, bias, y, d, st);
-    default: return launch_fwd<128, 32, 4, 1>(x, w, bias, y, d, st);
+    case 128128: return launch_fwd<128, 128, 2, 2>(x, w, bias, y, d, ws, ws_bytes, st);
+    case 64064: return launch_fwd<64, 64, 2, 2>(x, w, bias, y, d, ws, ws_bytes, st);
+    case 32128: return launch_fwd<32, 128, 1, 4>(x, w, bias, y, d, ws, ws_bytes, st);
+    case 128064: return launch_fwd<128, 64, 4, 1>(x, w, bias, y, d, ws, ws_bytes, st);
+    default: return launch_fwd<128, 32, 4, 1>(x, w, bias, y, d, ws, ws_bytes, st);
   }
+}
+
+size_t fwd_ws_bytes(long M, int K, int Cout) {
+  const int t = select_fwd_tile(M, Cout);
+  const SplitPlan sp = plan_splitk(M, K, Cout, t / 1000, t % 1000);
+  return sp.splits > 1 ? (size_t)sp.splits * M * Cout * sizeof(float) : 0;
 }
 
 // ---- wgrad planning (shared by the workspace query and the launcher)
@@ -452,11 +592,14 @@ WgradPlan plan_wgrad(long M, int K, int Cout) {
   p.tiles_k = (K + p.bm - 1) / p.bm;
   p.tiles_n = (Cout + p.bn - 1) / p.bn;
   const long tiles = (long)p.tiles_k * p.tiles_n;
-  long s = (1024 + tiles - 1) / tiles;             // aim for ~4 workgroups per CU
+  // fill whole rounds of the chip: 256 CUs x 3 resident workgroups; two rounds when the reduction is long enough
+  const long slots = 256 * 3;
+  long s = (2 * slots) / tiles;
   const long max_s = (M + 255) / 256;              // at least 256 pixels (16 chunks) per split
   if (s > max_s) s = max_s;
+  if (s * tiles > slots && s * tiles < 2 * slots) s = slots / tiles;   // avoid a partially filled second round
   if (s < 1) s = 1;
-  if (s > 512) s = 512;
+  if (s > 1024) s = 1024;
   long mps = (M + s - 1) / s;
   mps = (mps + BK - 1) / BK * BK;
   p.m_per_split = (int)mps;
@@ -465,13 +608,13 @@ WgradPlan plan_wgrad(long M, int K, int Cout) {
 }
 
 template <int BM, int BN, int WM, int WN>
-int launch_wgrad(const float* x, const float* dy, float* out, const IgemmDesc& d, const WgradPlan& p, hipStream_t st) {
+int launch_wgrad(const float* x, const float* dy, float* out, float* bias_part, const IgemmDesc& d, const WgradPlan& p, hipStream_t st) {
   const bool veca = (d.Cin % 4) == 0, vecb = (d.Cout % 4) == 0;
   dim3 grid(p.tiles_k * p.tiles_n, p.splits), block(kThreads);
-  if (veca && vecb) hipLaunchKernelGGL((igemm_wgrad_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, x, dy, out, d, p.tiles_n, p.m_per_split);
-  else if (veca) hipLaunchKernelGGL((igemm_wgrad_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, st, x, dy, out, d, p.tiles_n, p.m_per_split);
-  else if (vecb) hipLaunchKernelGGL((igemm_wgrad_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, st, x, dy, out, d, p.tiles_n, p.m_per_split);
-  else hipLaunchKernelGGL((igemm_wgrad_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, x, dy, out, d, p.tiles_n, p.m_per_split);
+  if (veca && vecb) hipLaunchKernelGGL((igemm_wgrad_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, x, dy, out, bias_part, d, p.tiles_n, p.m_per_split);
+  else if (veca) hipLaunchKernelGGL((igemm_wgrad_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, st, x, dy, out, bias_part, d, p.tiles_n, p.m_per_split);
+  else if (vecb) hipLaunchKernelGGL((igemm_wgrad_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, st, x, dy, out, bias_part, d, p.tiles_n, p.m_per_split);
+  else hipLaunchKernelGGL((igemm_wgrad_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, x, dy, out, bias_part, d, p.tiles_n, p.m_per_split);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
@@ -498,29 +641,30 @@ int run_colsum(const float* x, float* out, size_t rows, int C, void* ws, size_t 
 
 size_t wgrad_ws_bytes(long M, int K, int Cout) {
   const WgradPlan p = plan_wgrad(M, K, Cout);
-  size_t a = p.splits > 1 ? (size_t)p.splits * K * Cout * sizeof(float) : 0;
-  size_t b = colsum_ws_bytes((size_t)M, Cout);
-  return a > b ? a : b;   // bias-grad colsum reuses the buffer after the split reduction
+  const size_t a = p.splits > 1 ? (size_t)p.splits * K * Cout * sizeof(float) : 0;
+  return a + (size_t)p.splits * Cout * sizeof(float);   // + per-split bias partials
 }
 
 int run_wgrad(const float* x, const float* dy, float* dw, float* db, const IgemmDesc& d, void* ws, size_t ws_bytes, hipStream_t st) {
   if (d.M <= 0 || d.K <= 0 || d.Cout <= 0) return LADDER_E_SHAPE;
   if (!ladder_aligned16(x) || !ladder_aligned16(dy) || !ladder_aligned16(dw)) return LADDER_E_ALIGN;
-  if (ws_bytes < wgrad_ws_bytes(d.M, d.K, d.Cout)) return LADDER_E_WORKSPACE;
+  if (ws_bytes < wgrad_ws_bytes(d.M, d.K, d.Cout) || ws == nullptr) return LADDER_E_WORKSPACE;
   const WgradPlan p = plan_wgrad(d.M, d.K, d.Cout);
+  const size_t kn = (size_t)d.K * d.Cout;
   float* out = p.splits > 1 ? (float*)ws : dw;
+  float* bias_part = db != nullptr ? (float*)ws + (p.splits > 1 ? (size_t)p.splits * kn : 0) : nullptr;
   int rc;
-  if (p.bm == 128 && p.bn == 128) rc = launch_wgrad<128, 128, 2, 2>(x, dy, out, d, p, st);
-  else if (p.bm == 128 && p.bn == 64) rc = launch_wgrad<128, 64, 4, 1>(x, dy, out, d, p, st);
-  else if (p.bm == 128 && p.bn == 32) rc = launch_wgrad<128, 32, 4, 1>(x, dy, out, d, p, st);
-  else rc = launch_wgrad<64, 64, 2, 2>(x, dy, out, d, p, st);
+  if (p.bm == 128 && p.bn == 128) rc = launch_wgrad<128, 128, 2, 2>(x, dy, out, bias_part, d, p, st);
+  else if (p.bm == 128 && p.bn == 64) rc = launch_wgrad<128, 64, 4, 1>(x, dy, out, bias_part, d, p, st);
+  else if (p.bm == 128 && p.bn == 32) rc = launch_wgrad<128, 32, 4, 1>(x, dy, out, bias_part, d, p, st);
+  else rc = launch_wgrad<64, 64, 2, 2>(x, dy, out, bias_part, d, p, st);
   if (rc != LADDER_OK) return rc;
-  if (p.splits > 1) {
-    const size_t n = (size_t)d.K * d.Cout;
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws, dw, p.splits, n);
-    LADDER_CHECK_LAUNCH();
-  }
-  if (db != nullptr) return run_colsum(dy, db, (size_t)d.M, d.Cout, ws, ws_bytes, st);
+  if (p.splits > 1)
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, st, (const float*)ws, dw, p.splits, kn);
+  if (db != nullptr)
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((d.Cout + 255) / 256)), dim3(256), 0, st, (const float*)bias_part, db,
+                       p.splits, (size_t)d.Cout);
+  LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
 
@@ -539,11 +683,13 @@ int ladder_igemm_fwd_tile(long M, int Cin, int Cout) {
 
 int ladder_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin,
                       int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int act,
-                      ladder_stream_t stream) {
+                      void* ws, size_t ws_bytes, ladder_stream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return LADDER_E_SHAPE;
-  IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, 1, pad_t, pad_l, N * Ho * Wo, KH * KW * Cin, act};
-  return dispatch_fwd(x, w, bias, y, d, stream);
+  IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, 1, pad_t, pad_l, N * Ho * Wo, KH * KW * Cin, act, make_fastdiv(Ho * Wo), make_fastdiv(Wo)};
+  return dispatch_fwd(x, w, bias, y, d, ws, ws_bytes, stream);
 }
+
+size_t ladder_igemm_fwd_workspace_bytes(long M, int K, int Cout) { return fwd_ws_bytes(M, K, Cout); }
 
 int ladder_filter_flip_transpose(const float* w, float* wT, int KH, int KW, int Cin, int Cout, ladder_stream_t stream) {
   if (KH <= 0 || KW <= 0 || Cin <= 0 || Cout <= 0) return LADDER_E_SHAPE;
@@ -554,11 +700,12 @@ int ladder_filter_flip_transpose(const float* w, float* wT, int KH, int KW, int 
 }
 
 int ladder_conv2d_bwd_data(const float* dy, const float* wT, float* dx, int N, int H, int W, int Cin, int Ho, int Wo,
-                           int Cout, int KH, int KW, int stride, int pad_t, int pad_l, ladder_stream_t stream) {
+                           int Cout, int KH, int KW, int stride, int pad_t, int pad_l, void* ws, size_t ws_bytes,
+                           ladder_stream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return LADDER_E_SHAPE;
   // dx[hi] gathers dy[(hi + pad_t - r)/stride] = dy[(hi + r' - (KH-1-pad_t))/stride] with the flipped tap r'.
-  IgemmDesc d{N, Ho, Wo, Cout, H, W, Cin, KH, KW, 1, stride, KH - 1 - pad_t, KW - 1 - pad_l, N * H * W, KH * KW * Cout, LADDER_ACT_NONE};
-  return dispatch_fwd(dy, wT, nullptr, dx, d, stream);
+  IgemmDesc d{N, Ho, Wo, Cout, H, W, Cin, KH, KW, 1, stride, KH - 1 - pad_t, KW - 1 - pad_l, N * H * W, KH * KW * Cout, LADDER_ACT_NONE, make_fastdiv(H * W), make_fastdiv(W)};
+  return dispatch_fwd(dy, wT, nullptr, dx, d, ws, ws_bytes, stream);
 }
 
 size_t ladder_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW) {
@@ -570,26 +717,27 @@ int ladder_conv2d_bwd_filter(const float* x, const float* dy, float* dw, float* 
                              int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, void* ws, size_t ws_bytes,
                              ladder_stream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return LADDER_E_SHAPE;
-  IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, 1, pad_t, pad_l, N * Ho * Wo, KH * KW * Cin, LADDER_ACT_NONE};
+  IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, 1, pad_t, pad_l, N * Ho * Wo, KH * KW * Cin, LADDER_ACT_NONE, make_fastdiv(Ho * Wo), make_fastdiv(Wo)};
   return run_wgrad(x, dy, dw, db, d, ws, ws_bytes, stream);
 }
 
 int ladder_dense_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act,
-                     ladder_stream_t stream) {
-  IgemmDesc d{M, 1, 1, K, 1, 1, N, 1, 1, 1, 1, 0, 0, M, K, act};
-  return dispatch_fwd(x, w, bias, y, d, stream);
+                     void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  IgemmDesc d{M, 1, 1, K, 1, 1, N, 1, 1, 1, 1, 0, 0, M, K, act, make_fastdiv(1), make_fastdiv(1)};
+  return dispatch_fwd(x, w, bias, y, d, ws, ws_bytes, stream);
 }
 
-int ladder_dense_bwd_data(const float* dy, const float* wT, float* dx, int M, int K, int N, ladder_stream_t stream) {
-  IgemmDesc d{M, 1, 1, N, 1, 1, K, 1, 1, 1, 1, 0, 0, M, N, LADDER_ACT_NONE};
-  return dispatch_fwd(dy, wT, nullptr, dx, d, stream);
+int ladder_dense_bwd_data(const float* dy, const float* wT, float* dx, int M, int K, int N, void* ws, size_t ws_bytes,
+                          ladder_stream_t stream) {
+  IgemmDesc d{M, 1, 1, N, 1, 1, K, 1, 1, 1, 1, 0, 0, M, N, LADDER_ACT_NONE, make_fastdiv(1), make_fastdiv(1)};
+  return dispatch_fwd(dy, wT, nullptr, dx, d, ws, ws_bytes, stream);
 }
 
 size_t ladder_dense_bwd_weight_workspace_bytes(int M, int K, int N) { return wgrad_ws_bytes(M, K, N); }
 
 int ladder_dense_bwd_weight(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, void* ws,
                             size_t ws_bytes, ladder_stream_t stream) {
-  IgemmDesc d{M, 1, 1, K, 1, 1, N, 1, 1, 1, 1, 0, 0, M, K, LADDER_ACT_NONE};
+  IgemmDesc d{M, 1, 1, K, 1, 1, N, 1, 1, 1, 1, 0, 0, M, K, LADDER_ACT_NONE, make_fastdiv(1), make_fastdiv(1)};
   return run_wgrad(x, dy, dw, db, d, ws, ws_bytes, stream);
 }
 

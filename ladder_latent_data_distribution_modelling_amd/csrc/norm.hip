@@ -44,18 +44,25 @@ __global__ __launch_bounds__(256) void colstats_stage1(const float* __restrict__
     ws[((size_t)blockIdx.y * 2 + 1) * C + c] = (sm[1][0][cl] + sm[1][1][cl]) + (sm[1][2][cl] + sm[1][3][cl]);
   }
 }
-__global__ void colstats_stage2(const float* __restrict__ ws, float* __restrict__ out, int nblk, int C) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 2C
-  if (i >= 2 * C) return;
-  const int which = i / C, c = i - which * C;
+// stage 2: one workgroup per 64 (which,channel) columns; 4 row-lanes stride over the stage-1 partials, combined in a
+// fixed order (fp64) -> deterministic and ~nblk/4 dependent adds instead of nblk.
+__global__ __launch_bounds__(256) void colstats_stage2(const float* __restrict__ ws, float* __restrict__ out, int nblk, int C) {
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + cl;   // over 2C
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)ws[((size_t)b * 2 + which) * C + c];
-  out[i] = (float)s;
+  if (i < 2 * C) {
+    const int which = i / C, c = i - which * C;
+    for (int b = rl; b < nblk; b += 4) s += (double)ws[((size_t)b * 2 + which) * C + c];
+  }
+  __shared__ double sm[4][64];
+  sm[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && i < 2 * C) out[i] = (float)((sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]));
 }
 
 size_t stats_nblk(size_t rows) {
-  size_t nblk = (rows + 511) / 512;
-  if (nblk > 2048) nblk = 2048;
+  size_t nblk = (rows + 1023) / 1024;
+  if (nblk > 512) nblk = 512;
   if (nblk < 1) nblk = 1;
   return nblk;
 }
@@ -357,7 +364,7 @@ int ladder_bn_fwd_stats(const float* x, float* sums, size_t rows, int C, void* w
   const size_t rpb = (rows + nblk - 1) / nblk;
   hipLaunchKernelGGL(colstats_stage1<1>, dim3((C + 63) / 64, (unsigned)nblk), dim3(256), 0, stream, x, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)ws, rows, C, rpb, 0);
-  hipLaunchKernelGGL(colstats_stage2, dim3((2 * C + 255) / 256), dim3(256), 0, stream, (const float*)ws, sums, (int)nblk, C);
+  hipLaunchKernelGGL(colstats_stage2, dim3((2 * C + 63) / 64), dim3(256), 0, stream, (const float*)ws, sums, (int)nblk, C);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
@@ -383,7 +390,7 @@ int ladder_bn_bwd_stats(const float* dy, const float* x, const float* mean_rstd,
   const size_t rpb = (rows + nblk - 1) / nblk;
   hipLaunchKernelGGL(colstats_stage1<2>, dim3((C + 63) / 64, (unsigned)nblk), dim3(256), 0, stream, dy, x, mean_rstd, gamma, beta,
                      (float*)ws, rows, C, rpb, act);
-  hipLaunchKernelGGL(colstats_stage2, dim3((2 * C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dsums, (int)nblk, C);
+  hipLaunchKernelGGL(colstats_stage2, dim3((2 * C + 63) / 64), dim3(256), 0, stream, (const float*)ws, dsums, (int)nblk, C);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

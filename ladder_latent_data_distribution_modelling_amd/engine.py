@@ -39,9 +39,19 @@ class KernelProfiler:
 PROF = None   # set to a KernelProfiler by bench.py
 
 
-def _igemm(name, M, Cin, Cout, Kdim, *args):
-    """Forward-type implicit-GEMM call (conv fwd / bwd_data / dense fwd / bwd_data) with optional event timing."""
-    if PROF is not None and L.query("ladder_igemm_fwd_tile", M, Cin, Cout) == PROF.tile:
+_WS_NEED = {}
+
+
+def _igemm(ctx, name, M, Cin, Cout, Kdim, *args):
+    """Forward-type implicit-GEMM call (conv fwd / bwd_data / dense fwd / bwd_data): appends the split-K workspace and the
+    stream, with optional event timing of the launches that hit the profiled instantiation."""
+    key = (M, Kdim, Cout)
+    nb = _WS_NEED.get(key)
+    if nb is None:
+        nb = _WS_NEED[key] = L.query("ladder_igemm_fwd_workspace_bytes", M, Kdim, Cout)
+    wsp, wsn = ctx.ws(nb) if nb else (None, 0)
+    args = args + (wsp, wsn, ctx.stream)
+    if PROF is not None and nb == 0 and L.query("ladder_igemm_fwd_tile", M, Cin, Cout) == PROF.tile:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         L.call(name, *args)
@@ -162,19 +172,21 @@ class ParamStore:
 class Conv2D:
     """tf.layers.conv2d (NHWC / HWIO), bias + activation fused in the kernel epilogue."""
 
-    def __init__(self, ctx, ps, name, k, cin, cout, stride=1, padding="same", act=None):
+    def __init__(self, ctx, ps, name, k, cin, cout, stride=1, padding="same", act=None, bias_grad=True):
         self.ctx, self.ps, self.name = ctx, ps, name
         self.k, self.cin, self.cout, self.stride, self.padding, self.act = k, cin, cout, stride, padding, act
+        # a conv feeding batch-/instance-norm has an identically-zero bias gradient (the norm subtracts the mean):
+        # it is not computed and stays 0 in the flat gradient buffer
+        self.bias_grad = bias_grad
 
     def forward(self, x):
         N, H, W, _ = x.shape
         self.pt, Ho = arch.conv_out(H, self.k, self.stride, self.padding)
         self.pl, Wo = arch.conv_out(W, self.k, self.stride, self.padding)
         y = self.ctx.empty(N, Ho, Wo, self.cout)
-        _igemm("ladder_conv2d_fwd", N * Ho * Wo, self.cin, self.cout, self.k * self.k * self.cin,
+        _igemm(self.ctx, "ladder_conv2d_fwd", N * Ho * Wo, self.cin, self.cout, self.k * self.k * self.cin,
                _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y),
-               N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl, L.ACT[self.act],
-               self.ctx.stream)
+               N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl, L.ACT[self.act])
         self.x, self.y = x, y
         return y
 
@@ -189,7 +201,7 @@ class Conv2D:
             nb = L.query("ladder_conv2d_bwd_filter_workspace_bytes", N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k)
             wsp, wsn = self.ctx.ws(nb)
             L.call("ladder_conv2d_bwd_filter", _p(x), _p(dy), _p(self.ps.g[self.name + "/kernel"]),
-                   _p(self.ps.g[self.name + "/bias"]), N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride,
+                   _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride,
                    self.pt, self.pl, wsp, wsn, st)
         dx = None
         if need_dx:
@@ -197,9 +209,9 @@ class Conv2D:
             wT = self.ctx.empty(w.numel())
             L.call("ladder_filter_flip_transpose", _p(w), _p(wT), self.k, self.k, self.cin, self.cout, st)
             dx = self.ctx.empty(N, H, W, self.cin)
-            _igemm("ladder_conv2d_bwd_data", N * H * W, self.cout, self.cin, self.k * self.k * self.cout,
+            _igemm(self.ctx, "ladder_conv2d_bwd_data", N * H * W, self.cout, self.cin, self.k * self.k * self.cout,
                    _p(dy), _p(wT), _p(dx), N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k,
-                   self.stride, self.pt, self.pl, st)
+                   self.stride, self.pt, self.pl)
         self.x = self.y = None
         return dx
 
@@ -213,9 +225,9 @@ class Dense:
     def forward(self, x):
         M = x.shape[0]
         y = self.ctx.empty(M, self.cout)
-        _igemm("ladder_dense_fwd", M, self.cin, self.cout, self.cin,
+        _igemm(self.ctx, "ladder_dense_fwd", M, self.cin, self.cout, self.cin,
                _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y),
-               M, self.cin, self.cout, L.ACT[self.act], self.ctx.stream)
+               M, self.cin, self.cout, L.ACT[self.act])
         self.x, self.y = x, y
         return y
 
@@ -235,7 +247,7 @@ class Dense:
             wT = self.ctx.empty(w.numel())
             L.call("ladder_filter_flip_transpose", _p(w), _p(wT), 1, 1, self.cin, self.cout, st)
             dx = self.ctx.empty(M, self.cin)
-            _igemm("ladder_dense_bwd_data", M, self.cout, self.cin, self.cout, _p(dy), _p(wT), _p(dx), M, self.cin, self.cout, st)
+            _igemm(self.ctx, "ladder_dense_bwd_data", M, self.cout, self.cin, self.cout, _p(dy), _p(wT), _p(dx), M, self.cin, self.cout)
         self.x = self.y = None
         return dx
 
@@ -373,7 +385,7 @@ class Encoder:
         self.exp = cfg["exp_name"]
         self.convs, self.bns = [], []
         for i, (cin, cout, k, s, pad, act, bn) in enumerate(arch.encoder_convs(cfg)):
-            self.convs.append(Conv2D(ctx, ps, "encoder/" + arch.tfname("conv2d", i), k, cin, cout, s, pad, act))
+            self.convs.append(Conv2D(ctx, ps, "encoder/" + arch.tfname("conv2d", i), k, cin, cout, s, pad, act, bias_grad=not bn))
             self.bns.append(BatchNormAct(ctx, ps, "encoder/" + arch.tfname("batch_normalization", i), cout, "leaky_relu") if bn else None)
         feat, hid = arch.encoder_flat_dim(cfg), arch.encoder_hidden(cfg)
         self.hidden = Dense(ctx, ps, "encoder/dense", feat, hid, "leaky_relu") if hid is not None else None
@@ -451,7 +463,7 @@ class CelebADecoder:
         self.blocks = []
         si = 0
         for i, (k, ci, co, styled, act, rs) in enumerate(arch.celeba_decoder_convs(cfg)):
-            conv = Conv2D(ctx, ps, "decoder/conv2d_%d" % (i + 1), k, ci, co, 1, "same", act)
+            conv = Conv2D(ctx, ps, "decoder/conv2d_%d" % (i + 1), k, ci, co, 1, "same", act, bias_grad=not styled)
             sty = norm = None
             if styled:
                 sty = Dense(ctx, ps, "decoder/StyleMod_%d/dense" % si, nh, 2 * co, None)

@@ -54,6 +54,8 @@ CONV_CASES = [
     (4, 32, 32, 16, 1, 5, 1, "valid", "relu"),         # fashion output conv
     (4, 8, 8, 16, 64, 3, 1, "same", "leaky_relu"),
     (4, 4, 4, 32, 32, 3, 1, "valid", "leaky_relu"),    # fashion encoder valid conv
+    (32, 2, 2, 256, 256, 3, 1, "same", None),          # split-K regime (few tiles, long K)
+    (16, 4, 4, 512, 128, 3, 1, "valid", None),         # split-K regime, encoder conv6 style
 ]
 
 
@@ -80,7 +82,11 @@ def test_conv2d_fwd_bwd(gpu_ctx, case):
     st = gpu_ctx.stream
     xd, wd, bd = dev(x), dev(w), dev(b)
     y = torch.empty(N, Ho, Wo, Cout, device="cuda")
-    L.call("ladder_conv2d_fwd", p(xd), p(wd), p(bd), p(y), N, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, L.ACT[act], st)
+    M, Kd = N * Ho * Wo, k * k * Cin
+    fws, fwn = gpu_ctx.ws(max(L.query("ladder_igemm_fwd_workspace_bytes", M, Kd, Cout), 16))
+    L.call("ladder_conv2d_fwd", p(xd), p(wd), p(bd), p(y), N, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, L.ACT[act], fws, fwn, st)
+    close(y, yr, 2e-5, "fwd (split-K allowed)")
+    L.call("ladder_conv2d_fwd", p(xd), p(wd), p(bd), p(y), N, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, L.ACT[act], None, 0, st)
     close(y, yr, 2e-5, "fwd")
     dyd = dev(dy)
     if act is not None:
@@ -94,11 +100,16 @@ def test_conv2d_fwd_bwd(gpu_ctx, case):
     wT = torch.empty(wd.numel(), device="cuda")
     L.call("ladder_filter_flip_transpose", p(wd), p(wT), k, k, Cin, Cout, st)
     dx = torch.empty_like(xd)
-    L.call("ladder_conv2d_bwd_data", p(dyd), p(wT), p(dx), N, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, st)
+    dws = torch.empty(max(L.query("ladder_igemm_fwd_workspace_bytes", N * H * W, k * k * Cout, Cin), 16), dtype=torch.uint8, device="cuda")
+    L.call("ladder_conv2d_bwd_data", p(dyd), p(wT), p(dx), N, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, p(dws), dws.numel(), st)
     close(dx, xt.grad, 3e-5, "dx")
+    # db == NULL is allowed (conv feeding a norm layer): dw must be unaffected
+    dw2 = torch.empty_like(wd)
+    L.call("ladder_conv2d_bwd_filter", p(xd), p(dyd), p(dw2), None, N, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, wsp, wsn, st)
+    assert torch.equal(dw2, dw)
 
 
-@pytest.mark.parametrize("M,K,N,act", [(128, 2048, 64, None), (128, 512, 512, "leaky_relu"), (7, 2, 32, "relu"),
+@pytest.mark.parametrize("M,K,N,act", [(128, 2048, 64, None), (128, 4096, 64, "relu"), (128, 512, 512, "leaky_relu"), (7, 2, 32, "relu"),
                                        (256, 64, 4096, "leaky_relu"), (100, 33, 2, None), (4, 16, 1024, "tanh")])
 def test_dense_fwd_bwd(gpu_ctx, M, K, N, act):
     L = _lib()
@@ -113,7 +124,8 @@ def test_dense_fwd_bwd(gpu_ctx, M, K, N, act):
     st = gpu_ctx.stream
     xd, wd, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
     y = torch.empty(M, N, device="cuda")
-    L.call("ladder_dense_fwd", p(xd), p(wd), p(bd), p(y), M, K, N, L.ACT[act], st)
+    fws = torch.empty(max(L.query("ladder_igemm_fwd_workspace_bytes", M, K, N), 16), dtype=torch.uint8, device="cuda")
+    L.call("ladder_dense_fwd", p(xd), p(wd), p(bd), p(y), M, K, N, L.ACT[act], p(fws), fws.numel(), st)
     close(y, yr, 2e-5, "fwd")
     if act is not None:
         L.call("ladder_act_bwd", p(dyd), p(y), p(dyd), dyd.numel(), L.ACT[act], st)
@@ -125,7 +137,8 @@ def test_dense_fwd_bwd(gpu_ctx, M, K, N, act):
     wT = torch.empty(wd.numel(), device="cuda")
     L.call("ladder_filter_flip_transpose", p(wd), p(wT), 1, 1, K, N, st)
     dx = torch.empty_like(xd)
-    L.call("ladder_dense_bwd_data", p(dyd), p(wT), p(dx), M, K, N, st)
+    bws = torch.empty(max(L.query("ladder_igemm_fwd_workspace_bytes", M, N, K), 16), dtype=torch.uint8, device="cuda")
+    L.call("ladder_dense_bwd_data", p(dyd), p(wT), p(dx), M, K, N, p(bws), bws.numel(), st)
     close(dx, xt.grad, 3e-5, "dx")
 
 
