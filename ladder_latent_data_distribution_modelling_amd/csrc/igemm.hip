@@ -44,9 +44,27 @@ constexpr int kThreads = 256;
 #ifndef IGEMM_PIN
 #define IGEMM_PIN 0
 #endif
+#ifndef IGEMM_TAPINNER
+#define IGEMM_TAPINNER 1
+#endif
+#ifndef IGEMM_PF2
+#define IGEMM_PF2 0
+#endif
+#ifndef IGEMM_HALO
+#define IGEMM_HALO 1
+#endif
+#ifndef IGEMM_FWD_MINW
+#define IGEMM_FWD_MINW 4
+#endif
+#ifndef IGEMM_ABL   // ablation (profiling builds only): 1 = no global loads/LDS stores in the loop, 2 = +no barrier, 3 = +no LDS reads
+#define IGEMM_ABL 0
+#endif
 constexpr int BK = IGEMM_BK;
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// Source of out-of-image / out-of-range operands: loads stay unconditional (no exec-mask branches around VMEM in the
+// K loop); lanes that would read padding fetch these 16 zero bytes instead.
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
   const uint32_t t = __umulhi(f.m, n);
   return (t + ((n - t) >> f.s1)) >> f.s2;
@@ -75,7 +93,7 @@ __device__ __forceinline__ long gather_off(const IgemmDesc& d, long img, int bh,
 }
 
 template <int BM, int BN, int WM, int WN, bool VECA, bool VECB>
-__global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? 4 : IGEMM_MINW) void igemm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? IGEMM_FWD_MINW : IGEMM_MINW) void igemm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ y,
                                                              const IgemmDesc d, const int tiles_n, const bool fast,
                                                              float* __restrict__ part, const int chunks_per_split) {
@@ -135,22 +153,30 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? 4 : IGEMM_MINW) 
     b_nq[i] = u % (BN / 4);
   }
 
-  float4 ra[AU], rb[BU];
-  auto load_chunk = [&](int c) {
+  float4 ra0[AU], rb0[BU];
+#if IGEMM_PF2
+  float4 ra1[AU], rb1[BU];
+#endif
+  const int ntaps = d.KH * d.KW;
+  auto load_chunk = [&](int c, float4 (&ra)[AU], float4 (&rb)[BU]) {
+#if IGEMM_TAPINNER
+    // K order: channel slab outer, taps inner -> the kh*kw taps of one 16-channel slab re-read the same cache lines
+    const int k0 = VECA ? ((c % ntaps) * d.Cin + (c / ntaps) * BK) : c * BK;
+#else
     const int k0 = c * BK;
+#endif
     if (VECA) {  // Cin % BK == 0: the whole chunk lies inside one filter tap (wave-uniform r, s, ci0)
       const int rs = k0 / d.Cin, ci0 = k0 - rs * d.Cin;
       const int r = rs / d.KW, s = rs - r * d.KW;
       if (fast) {
         const long coff = ((long)r * d.W + s) * d.Cin + ci0;
 #pragma unroll
-        for (int i = 0; i < AU; ++i)
-          ra[i] = ((a_mask[i] >> rs) & 1u) ? ld4(a_ptr[i] + coff) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < AU; ++i) ra[i] = ld4(((a_mask[i] >> rs) & 1u) ? a_ptr[i] + coff : g_zero16);
       } else {
 #pragma unroll
         for (int i = 0; i < AU; ++i) {
           long off = a_ok[i] ? gather_off(d, a_img[i], a_bh[i], a_bw[i], r, s, ci0 + a_kq[i] * 4) : -1;
-          ra[i] = off >= 0 ? ld4(x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+          ra[i] = ld4(off >= 0 ? x + off : g_zero16);
         }
       }
     } else {
@@ -176,7 +202,7 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? 4 : IGEMM_MINW) 
       const int k = k0 + b_kr[i], n = n0 + b_nq[i] * 4;
       const bool inb = (tid + i * kThreads < B_UNITS) && k < d.K;
       if (VECB) {
-        rb[i] = (inb && n < d.Cout) ? ld4(w + (long)k * d.Cout + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[i] = ld4((inb && n < d.Cout) ? w + (long)k * d.Cout + n : g_zero16);
       } else {
         float v[4];
 #pragma unroll
@@ -185,7 +211,7 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? 4 : IGEMM_MINW) 
       }
     }
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, const float4 (&ra)[AU], const float4 (&rb)[BU]) {
 #pragma unroll
     for (int i = 0; i < AU; ++i) {
       if (tid + i * kThreads < A_UNITS) {
@@ -211,12 +237,8 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? 4 : IGEMM_MINW) 
   // split-K: blockIdx.y owns the chunk range [c_begin, nchunks)
   const int c_begin = blockIdx.y * chunks_per_split;
   const int nchunks = min((d.K + BK - 1) / BK, c_begin + chunks_per_split);
-  load_chunk(c_begin);
-  store_chunk(0);
-  __syncthreads();
-  for (int c = c_begin; c < nchunks; ++c) {
-    const int buf = (c - c_begin) & 1;
-    if (c + 1 < nchunks) load_chunk(c + 1);
+
+  auto mma_chunk = [&](int buf) {
     const float* Ab = &As[buf][(wm * TM + l31) * LDA + lh];
     const float* Bb = &Bs[buf][lh * BN + wn * TN + l31];
     // all fragment reads of the chunk are issued before the MFMA block (one LDS round trip per chunk, not per k-step)
@@ -228,9 +250,6 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? 4 : IGEMM_MINW) 
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) bf[ks][ni] = Bb[2 * ks * BN + ni * 32];
     }
-#if IGEMM_PIN
-    __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks)
 #pragma unroll
@@ -238,9 +257,38 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? 4 : IGEMM_MINW) 
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks][mi], bf[ks][ni], acc[mi][ni], 0, 0, 0);
-    if (c + 1 < nchunks) store_chunk(buf ^ 1);
+  };
+
+#if IGEMM_PF2
+  // global loads run TWO chunks ahead of the MFMA block (two register sets): chunk c+1 is written to LDS from the set
+  // loaded one iteration earlier while the loads of chunk c+2 are already in flight.
+  load_chunk(c_begin, ra0, rb0);
+  store_chunk(0, ra0, rb0);
+  if (c_begin + 1 < nchunks) load_chunk(c_begin + 1, ra1, rb1);
+  __syncthreads();
+  for (int c = c_begin; c < nchunks; c += 2) {
+    if (c + 2 < nchunks) load_chunk(c + 2, ra0, rb0);
+    mma_chunk(0);
+    if (c + 1 < nchunks) store_chunk(1, ra1, rb1);
+    __syncthreads();
+    if (c + 1 >= nchunks) break;
+    if (c + 3 < nchunks) load_chunk(c + 3, ra1, rb1);
+    mma_chunk(1);
+    if (c + 2 < nchunks) store_chunk(0, ra0, rb0);
     __syncthreads();
   }
+#else
+  load_chunk(c_begin, ra0, rb0);
+  store_chunk(0, ra0, rb0);
+  __syncthreads();
+  for (int c = c_begin; c < nchunks; ++c) {
+    const int buf = (c - c_begin) & 1;
+    if (c + 1 < nchunks) load_chunk(c + 1, ra0, rb0);
+    mma_chunk(buf);
+    if (c + 1 < nchunks) store_chunk(buf ^ 1, ra0, rb0);
+    __syncthreads();
+  }
+#endif
 
   if (part != nullptr) {   // split-K partial: raw accumulators, bias/activation applied by splitk_epilogue_kernel
     float* o = part + (size_t)blockIdx.y * d.M * d.Cout;
@@ -342,13 +390,9 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? IGEMM_WG_MINW : 
         const long img = (long)n_img * d.H * d.W * d.Cin;
         const int bh = ho * d.stride - d.pad_t, bw = wo * d.stride - d.pad_l;
         if (VECA) {
-          if (a_kok[i][0]) {
-            const long off = gather_off(d, img, bh, bw, a_r[i][0], a_s[i][0], a_ci[i][0]);
-            if (off >= 0) {
-              const float4 t = ld4(x + off);
-              v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-            }
-          }
+          const long off = a_kok[i][0] ? gather_off(d, img, bh, bw, a_r[i][0], a_s[i][0], a_ci[i][0]) : -1;
+          const float4 t = ld4(off >= 0 ? x + off : g_zero16);
+          v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -366,7 +410,7 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? IGEMM_WG_MINW : 
       const int p = pc + b_pr[i], n = n0 + b_nq[i] * 4;
       const bool inb = (tid + i * kThreads < B_UNITS) && p < p_end;
       if (VECB) {
-        rb[i] = (inb && n < d.Cout) ? ld4(dy + (long)p * d.Cout + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[i] = ld4((inb && n < d.Cout) ? dy + (long)p * d.Cout + n : g_zero16);
       } else {
         float v[4];
 #pragma unroll
@@ -510,6 +554,152 @@ __global__ void colsum_stage2(const float* __restrict__ ws, float* __restrict__ 
 
 struct TileCfg { int bm, bn; };
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / SAME convolution with an LDS-staged INPUT HALO tile (the decoder's dominant layers and their
+// backward-data passes).  One workgroup = 8 wavefronts = an 8x32-pixel output patch x 128 output channels.
+// For every 16-channel input slab the (8+2)x(32+2) halo patch is fetched from HBM/L2 ONCE and serves all 9 filter
+// taps straight out of LDS (the gather kernel above re-fetches it per tap); the filter slab [16 x 128] of each tap is
+// double-buffered.  Per 9 K-chunks a thread issues 12 global loads instead of 36, and the 256-pixel patch halves the
+// filter bytes per MFMA.  Wavefront (wm, wn) owns patch rows {2wm, 2wm+1} x channels [64wn, 64wn+64): an MFMA A
+// fragment is 32 consecutive pixels of one patch row, i.e. consecutive LDS rows of odd stride 17 -> conflict-free.
+constexpr int HT_H = 8, HT_W = 32, HT_PW = HT_W + 2, HT_PH = HT_H + 2, HT_LDA = BK + 1;
+constexpr int HT_THREADS = 512, HT_BN = 128;
+constexpr int HT_HALO_UNITS = HT_PH * HT_PW * (BK / 4);                      // float4 units per slab (1360)
+constexpr int HT_AU = (HT_HALO_UNITS + HT_THREADS - 1) / HT_THREADS;         // 3
+
+__global__ __launch_bounds__(HT_THREADS, 2) void conv3x3_halo_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                     const float* __restrict__ bias, float* __restrict__ y,
+                                                                     const int N, const int H, const int W, const int Cin,
+                                                                     const int Cout, const int act, const int tiles_n) {
+  static_assert(BK == 16, "halo kernel is written for 16-channel slabs");
+  __shared__ float Ah[2][HT_PH * HT_PW * HT_LDA];
+  __shared__ __attribute__((aligned(16))) float Bh[2][BK * HT_BN];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = tile / tiles_n, n0 = (tile % tiles_n) * HT_BN;
+  const int tw_n = W / HT_W, th_n = H / HT_H;
+  const int img = mt / (tw_n * th_n), rem = mt - img * (tw_n * th_n);
+  const int h0 = (rem / tw_n) * HT_H, w0 = (rem % tw_n) * HT_W;
+
+  // halo load units (fixed per workgroup): source pointer at channel 0 of the slab, or the zero buffer
+  const float* hsrc[HT_AU];
+  int hdst[HT_AU];
+#pragma unroll
+  for (int i = 0; i < HT_AU; ++i) {
+    const int u = tid + i * HT_THREADS;
+    const int pix = u >> 2, kq = u & 3;
+    const int hr = pix / HT_PW, hc = pix - hr * HT_PW;
+    const int hi = h0 - 1 + hr, wi = w0 - 1 + hc;
+    const bool ok = (u < HT_HALO_UNITS) && hi >= 0 && hi < H && wi >= 0 && wi < W;
+    hsrc[i] = ok ? x + (((long)img * H + hi) * W + wi) * Cin + kq * 4 : nullptr;
+    hdst[i] = pix * HT_LDA + kq * 4;
+  }
+  const int b_kr = tid >> 5, b_nq = tid & 31;                                // 16 rows x 32 float4 = 512 units
+  const bool b_ok = (n0 + b_nq * 4) < Cout;
+  const float* bsrc = w + (long)b_kr * Cout + n0 + b_nq * 4;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  float4 ha[HT_AU], rb;
+  auto load_halo = [&](int slab) {
+#pragma unroll
+    for (int i = 0; i < HT_AU; ++i) ha[i] = ld4(hsrc[i] != nullptr ? hsrc[i] + slab * BK : g_zero16);
+  };
+  auto store_halo = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < HT_AU; ++i)
+      if (tid + i * HT_THREADS < HT_HALO_UNITS) {
+        float* p = &Ah[buf][hdst[i]];
+        p[0] = ha[i].x; p[1] = ha[i].y; p[2] = ha[i].z; p[3] = ha[i].w;
+      }
+  };
+  auto load_b = [&](int slab, int tap) { rb = ld4(b_ok ? bsrc + ((long)tap * Cin + slab * BK) * Cout : g_zero16); };
+  auto store_b = [&](int buf) { *reinterpret_cast<float4*>(&Bh[buf][b_kr * HT_BN + b_nq * 4]) = rb; };
+
+  const int nslabs = Cin / BK;
+  load_halo(0);
+  load_b(0, 0);
+  store_halo(0);
+  store_b(0);
+  __syncthreads();
+  int bbuf = 0;
+  for (int slab = 0; slab < nslabs; ++slab) {
+    const int hb = slab & 1;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      // prefetch: next filter slab every tap; next input halo once per slab (issued at tap 0, written at tap 4)
+      const bool last = (slab + 1 == nslabs) && (tap == 8);
+      if (!last) load_b(tap == 8 ? slab + 1 : slab, tap == 8 ? 0 : tap + 1);
+      if (tap == 0 && slab + 1 < nslabs) load_halo(slab + 1);
+      const int r = tap / 3, sft = tap - 3 * r;
+      const float* Ab = &Ah[hb][((2 * wm + r) * HT_PW + sft + l31) * HT_LDA + lh];
+      const float* Bb = &Bh[bbuf][lh * HT_BN + wn * 64 + l31];
+#pragma unroll
+      for (int ks = 0; ks < BK / 2; ++ks) {
+        float a[2], b[2];
+        a[0] = Ab[2 * ks];
+        a[1] = Ab[HT_PW * HT_LDA + 2 * ks];
+        b[0] = Bb[2 * ks * HT_BN];
+        b[1] = Bb[2 * ks * HT_BN + 32];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+      }
+      if (tap == 4 && slab + 1 < nslabs) store_halo(hb ^ 1);
+      if (!last) store_b(bbuf ^ 1);
+      __syncthreads();
+      bbuf ^= 1;
+    }
+  }
+
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int n = n0 + wn * 64 + ni * 32 + l31;
+    const float bv = (bias != nullptr && n < Cout) ? bias[n] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const long rowbase = (((long)img * H + h0 + 2 * wm + mi) * W + w0) * Cout;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int px = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (n < Cout) y[rowbase + (long)px * Cout + n] = ladder_act_fn(acc[mi][ni][e] + bv, act);
+      }
+    }
+  }
+}
+
+bool halo_eligible(const IgemmDesc& d) {
+#if IGEMM_HALO
+  return d.KH == 3 && d.KW == 3 && d.stride == 1 && d.ups == 1 && d.pad_t == 1 && d.pad_l == 1 && d.Ho == d.H && d.Wo == d.W &&
+         (d.Cin % BK) == 0 && (d.Cout % 4) == 0 && (d.W % HT_W) == 0 && (d.H % HT_H) == 0 && d.Cout >= 64 &&
+         (long)d.N * (d.H / HT_H) * (d.W / HT_W) * ((d.Cout + HT_BN - 1) / HT_BN) >= 512;
+#else
+  return false;
+#endif
+}
+
+int launch_halo(const float* x, const float* w, const float* bias, float* y, const IgemmDesc& d, hipStream_t st) {
+  const int tiles_n = (d.Cout + HT_BN - 1) / HT_BN;
+  const int tiles_m = d.N * (d.H / HT_H) * (d.W / HT_W);
+  hipLaunchKernelGGL(conv3x3_halo_kernel, dim3(tiles_m * tiles_n), dim3(HT_THREADS), 0, st, x, w, bias, y, d.N, d.H, d.W, d.Cin,
+                     d.Cout, d.act, tiles_n);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
 struct SplitPlan { int splits, cps; };
 // split-K only when the output tiling cannot fill the chip and K is long enough to amortise the second pass
 SplitPlan plan_splitk(long M, int K, int Cout, int bm, int bn) {
@@ -567,6 +757,7 @@ int dispatch_fwd(const float* x, const float* w, const float* bias, float* y, co
                  hipStream_t st) {
   if (d.M <= 0 || d.K <= 0 || d.Cout <= 0) return LADDER_E_SHAPE;
   if (!ladder_aligned16(x) || !ladder_aligned16(w) || !ladder_aligned16(y)) return LADDER_E_ALIGN;
+  if (halo_eligible(d)) return launch_halo(x, w, bias, y, d, st);
   switch (select_fwd_tile(d.M, d.Cout)) {
     case 128128: return launch_fwd<128, 128, 2, 2>(x, w, bias, y, d, ws, ws_bytes, st);
     case 64064: return launch_fwd<64, 64, 2, 2>(x, w, bias, y, d, ws, ws_bytes, st);
@@ -678,7 +869,7 @@ int ladder_igemm_fwd_tile(long M, int Cin, int Cout) {
   // BM*1000+BN of the kernel instantiation ladder_conv2d_fwd / _bwd_data / ladder_dense_* dispatch to; negative when the
   // vectorised (Cin%16==0 && Cout%4==0) instantiation is not used.  Lets a profiler attribute a launch to a kernel name.
   const int t = select_fwd_tile(M, Cout);
-  return ((Cin % BK) == 0 && (Cout % 4) == 0) ? t : -t;
+  return ((Cin % BK) == 0 && (Cout % 4) == 0) ? t : -t;   // (the 3x3 halo kernel is reported by ladder_conv3x3_uses_halo)
 }
 
 int ladder_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin,
@@ -690,6 +881,14 @@ int ladder_conv2d_fwd(const float* x, const float* w, const float* bias, float* 
 }
 
 size_t ladder_igemm_fwd_workspace_bytes(long M, int K, int Cout) { return fwd_ws_bytes(M, K, Cout); }
+
+int ladder_conv2d_fwd_kernel_id(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int ups,
+                                int pad_t, int pad_l) {
+  // 256128 = conv3x3_halo_kernel (8x32-pixel x 128-channel LDS-halo tile); otherwise the code of ladder_igemm_fwd_tile
+  IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, ups, pad_t, pad_l, N * Ho * Wo, KH * KW * Cin, 0, make_fastdiv(1), make_fastdiv(1)};
+  if (halo_eligible(d)) return 256128;
+  return ladder_igemm_fwd_tile(d.M, Cin, Cout);
+}
 
 int ladder_filter_flip_transpose(const float* w, float* wT, int KH, int KW, int Cin, int Cout, ladder_stream_t stream) {
   if (KH <= 0 || KW <= 0 || Cin <= 0 || Cout <= 0) return LADDER_E_SHAPE;

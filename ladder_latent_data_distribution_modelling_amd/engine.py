@@ -21,42 +21,59 @@ def _p(t):
 
 
 class KernelProfiler:
-    """HIP-event timing of every launch dispatched to ONE implicit-GEMM instantiation (bench.py's roofline leg).
-    Events are recorded on the stream the kernels are launched on (torch's current stream)."""
+    """HIP-event timing of the forward-type contraction launches, grouped by the kernel they dispatch to (bench.py's
+    roofline leg).  Events are recorded on the stream the kernels are launched on (torch's current stream)."""
 
-    def __init__(self, tile=128128):
-        self.tile, self.records = tile, []
+    NAMES = {256128: "conv3x3_halo_kernel (8x32 px x 128 ch LDS-halo tile, 8 waves, fp32 MFMA 32x32x2)",
+             128128: "igemm_fwd_kernel<128,128,2,2,true,true> (gather implicit GEMM, fp32 MFMA 32x32x2)"}
+
+    def __init__(self):
+        self.records = {}
+
+    def add(self, kid, s, e, flops):
+        self.records.setdefault(kid, []).append((s, e, flops))
 
     def summary(self):
         torch.cuda.synchronize()
-        ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
-        fl = sum(f for _, _, f in self.records)
-        n = len(self.records)
-        return dict(launches=n, total_ms=ms, avg_ms=ms / max(n, 1), flops_per_launch=fl / max(n, 1),
-                    tflops=(fl / (ms * 1e-3) / 1e12) if ms > 0 else 0.0)
+        out = {}
+        for kid, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            fl = sum(f for _, _, f in recs)
+            n = len(recs)
+            out[kid] = dict(kernel=self.NAMES.get(kid, "igemm tile %d" % kid), launches=n, total_ms=ms, avg_ms=ms / n,
+                            flops_per_launch=fl / n, tflops=(fl / (ms * 1e-3) / 1e12) if ms > 0 else 0.0)
+        return out
 
 
 PROF = None   # set to a KernelProfiler by bench.py
+_WS_NEED, _KID = {}, {}
 
 
-_WS_NEED = {}
-
-
-def _igemm(ctx, name, M, Cin, Cout, Kdim, *args):
+def _igemm(ctx, name, M, Cin, Cout, Kdim, *args, conv=None):
     """Forward-type implicit-GEMM call (conv fwd / bwd_data / dense fwd / bwd_data): appends the split-K workspace and the
-    stream, with optional event timing of the launches that hit the profiled instantiation."""
+    stream; when a profiler is installed the launch is bracketed by HIP events and attributed to its kernel."""
     key = (M, Kdim, Cout)
     nb = _WS_NEED.get(key)
     if nb is None:
         nb = _WS_NEED[key] = L.query("ladder_igemm_fwd_workspace_bytes", M, Kdim, Cout)
     wsp, wsn = ctx.ws(nb) if nb else (None, 0)
     args = args + (wsp, wsn, ctx.stream)
-    if PROF is not None and nb == 0 and L.query("ladder_igemm_fwd_tile", M, Cin, Cout) == PROF.tile:
+    if PROF is None:
+        L.call(name, *args)
+        return
+    kkey = (M, Cin, Cout, conv)
+    kid = _KID.get(kkey)
+    if kid is None:
+        kid = L.query("ladder_conv2d_fwd_kernel_id", *conv) if conv else L.query("ladder_igemm_fwd_tile", M, Cin, Cout)
+        if kid != 256128 and nb:
+            kid = 0         # split-K launch: two kernels, not attributed
+        _KID[kkey] = kid
+    if kid in (256128, 128128):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         L.call(name, *args)
         e.record()
-        PROF.records.append((s, e, 2.0 * M * Kdim * Cout))
+        PROF.add(kid, s, e, 2.0 * M * Kdim * Cout)
     else:
         L.call(name, *args)
 
@@ -186,7 +203,8 @@ class Conv2D:
         y = self.ctx.empty(N, Ho, Wo, self.cout)
         _igemm(self.ctx, "ladder_conv2d_fwd", N * Ho * Wo, self.cin, self.cout, self.k * self.k * self.cin,
                _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y),
-               N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl, L.ACT[self.act])
+               N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl, L.ACT[self.act],
+               conv=(N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride, 1, self.pt, self.pl))
         self.x, self.y = x, y
         return y
 
@@ -211,7 +229,8 @@ class Conv2D:
             dx = self.ctx.empty(N, H, W, self.cin)
             _igemm(self.ctx, "ladder_conv2d_bwd_data", N * H * W, self.cout, self.cin, self.k * self.k * self.cout,
                    _p(dy), _p(wT), _p(dx), N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k,
-                   self.stride, self.pt, self.pl)
+                   self.stride, self.pt, self.pl,
+                   conv=(N, Ho, Wo, self.cout, H, W, self.cin, self.k, self.k, 1, self.stride, self.k - 1 - self.pt, self.k - 1 - self.pl))
         self.x = self.y = None
         return dx
 

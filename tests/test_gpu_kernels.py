@@ -56,6 +56,8 @@ CONV_CASES = [
     (4, 4, 4, 32, 32, 3, 1, "valid", "leaky_relu"),    # fashion encoder valid conv
     (32, 2, 2, 256, 256, 3, 1, "same", None),          # split-K regime (few tiles, long K)
     (16, 4, 4, 512, 128, 3, 1, "valid", None),         # split-K regime, encoder conv6 style
+    (16, 64, 64, 32, 256, 3, 1, "same", "leaky_relu"), # LDS-halo kernel (>=512 workgroups), fwd + bwd_data (Cin'=256)
+    (64, 32, 32, 16, 160, 3, 1, "same", None),         # LDS-halo kernel, Cout tile edge (160 = 128 + 32)
 ]
 
 
@@ -90,7 +92,10 @@ def test_conv2d_fwd_bwd(gpu_ctx, case):
     close(y, yr, 2e-5, "fwd")
     dyd = dev(dy)
     if act is not None:
-        L.call("ladder_act_bwd", p(dyd), p(y), p(dyd), dyd.numel(), L.ACT[act], st)
+        # the activation mask is taken from the ORACLE's output: with millions of outputs a few pre-activations sit within
+        # fp32 rounding of 0 and their leaky/relu mask legitimately differs between fp32 and float64 (each flip moves dw by O(1))
+        yref = dev(yr.detach().numpy())
+        L.call("ladder_act_bwd", p(dyd), p(yref), p(dyd), dyd.numel(), L.ACT[act], st)
     nb = L.query("ladder_conv2d_bwd_filter_workspace_bytes", N, H, W, Cin, Ho, Wo, Cout, k, k)
     wsp, wsn = gpu_ctx.ws(nb)
     dw, db = torch.empty_like(wd), torch.empty_like(bd)
