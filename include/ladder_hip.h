@@ -114,11 +114,16 @@ int ladder_bn_bwd_apply(const float* dy, const float* x, const float* mean_rstd,
 /* ---------------------------------------------------------------- N4+N5+N12: instance_norm + style_mod + leaky
  * codes/models.py:522-528,531-537,547-554,564-571; codes/modules.py:6-10.
  * x [N,HW,C]; style [N,2C] (raw output of the StyleMod dense: [:,0:C] scale-1, [:,C:2C] shift).
- * y = act(((x-mean)*rstd) * (style0+1) + style1), moments over HW per (n,c), biased var, eps. */
+ * y = act(((x-mean)*rstd) * (style0+1) + style1), moments over HW per (n,c), biased var, eps.
+ * With a workspace (ladder_in_style_workspace_bytes) and C%4==0 the H*W axis is split over several workgroups per
+ * (sample, 64 channels) and streamed with 16-byte loads (fixed-order second stage); ws == NULL selects the
+ * one-workgroup-per-slab kernels. */
+size_t ladder_in_style_workspace_bytes(int N, int HW, int C);
 int ladder_in_style_fwd(const float* x, const float* style, float* y, float* mean_rstd /*[N,2C]*/,
-                        int N, int HW, int C, float eps, int act, ladder_stream_t stream);
+                        int N, int HW, int C, float eps, int act, void* ws, size_t ws_bytes, ladder_stream_t stream);
 int ladder_in_style_bwd(const float* dy, const float* x, const float* style, const float* mean_rstd,
-                        float* dx, float* dstyle /*[N,2C]*/, int N, int HW, int C, int act, ladder_stream_t stream);
+                        float* dx, float* dstyle /*[N,2C]*/, int N, int HW, int C, int act,
+                        void* ws, size_t ws_bytes, ladder_stream_t stream);
 
 /* ---------------------------------------------------------------- N6: tf.image.resize_images (TF1 legacy bilinear)
  * codes/models.py:519,538,544,555,561,572,578.  align_corners=False, half_pixel_centers=False;

@@ -55,8 +55,9 @@ PROTOTYPES = {
     "ladder_bn_fwd_apply": (_i, [_p, _p, _d, _p, _p, _p, _p, _z, _i, _f, _i, _p]),
     "ladder_bn_bwd_stats": (_i, [_p, _p, _p, _p, _p, _p, _z, _i, _i, _p, _z, _p]),
     "ladder_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _d, _p, _p, _p, _z, _i, _i, _p]),
-    "ladder_in_style_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _p]),
-    "ladder_in_style_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "ladder_in_style_workspace_bytes": (_z, [_i, _i, _i]),
+    "ladder_in_style_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _z, _p]),
+    "ladder_in_style_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
     "ladder_resize_bilinear_fwd": (_i, [_p, _p] + [_i] * 6 + [_p]),
     "ladder_resize_bilinear_bwd": (_i, [_p, _p] + [_i] * 6 + [_p]),
     "ladder_depth_to_space": (_i, [_p, _p] + [_i] * 6 + [_p]),

@@ -44,6 +44,50 @@ __global__ __launch_bounds__(256) void colstats_stage1(const float* __restrict__
     ws[((size_t)blockIdx.y * 2 + 1) * C + c] = (sm[1][0][cl] + sm[1][1][cl]) + (sm[1][2][cl] + sm[1][3][cl]);
   }
 }
+template <int MODE>
+__global__ __launch_bounds__(256) void colstats_stage1_v4(const float* __restrict__ a, const float* __restrict__ b,
+                                                          const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ ws, size_t rows,
+                                                          int C, size_t rows_per_blk, int act) {
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;       // 16 float4 channel groups x 16 row lanes
+  const int c = blockIdx.x * 64 + cq * 4;
+  const size_t r0 = (size_t)blockIdx.y * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  if (c < C) {
+    if (MODE == 1) {
+      for (size_t r = r0 + rl; r < r1; r += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(a + r * C + c);
+        s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+        s1.x += v.x * v.x; s1.y += v.y * v.y; s1.z += v.z * v.z; s1.w += v.w * v.w;
+      }
+    } else {
+      const float4 mu = *reinterpret_cast<const float4*>(mean_rstd + c), rs = *reinterpret_cast<const float4*>(mean_rstd + C + c);
+      const float4 g = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+      for (size_t r = r0 + rl; r < r1; r += 16) {
+        const float4 xv = *reinterpret_cast<const float4*>(b + r * C + c), dv = *reinterpret_cast<const float4*>(a + r * C + c);
+        float xh, dp;
+        xh = (xv.x - mu.x) * rs.x; dp = dv.x * ladder_act_grad_from_out(g.x * xh + be.x, act); s0.x += dp; s1.x += dp * xh;
+        xh = (xv.y - mu.y) * rs.y; dp = dv.y * ladder_act_grad_from_out(g.y * xh + be.y, act); s0.y += dp; s1.y += dp * xh;
+        xh = (xv.z - mu.z) * rs.z; dp = dv.z * ladder_act_grad_from_out(g.z * xh + be.z, act); s0.z += dp; s1.z += dp * xh;
+        xh = (xv.w - mu.w) * rs.w; dp = dv.w * ladder_act_grad_from_out(g.w * xh + be.w, act); s0.w += dp; s1.w += dp * xh;
+      }
+    }
+  }
+  __shared__ float4 sm[2][16][16];
+  sm[0][rl][cq] = s0;
+  sm[1][rl][cq] = s1;
+  __syncthreads();
+  if (rl < 2 && c < C) {        // rl 0 -> sums, rl 1 -> second statistic; fixed-order tree over the 16 row lanes
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float4 v = sm[rl][k][cq];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    *reinterpret_cast<float4*>(ws + ((size_t)blockIdx.y * 2 + rl) * C + c) = t;
+  }
+}
+
 // stage 2: one workgroup per 64 (which,channel) columns; 4 row-lanes stride over the stage-1 partials, combined in a
 // fixed order (fp64) -> deterministic and ~nblk/4 dependent adds instead of nblk.
 __global__ __launch_bounds__(256) void colstats_stage2(const float* __restrict__ ws, float* __restrict__ out, int nblk, int C) {
@@ -118,6 +162,27 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
     const float xh = (x[i] - mu) * rs;
     const float dp = dy[i] * ladder_act_grad_from_out(g * xh + beta[c], act);
     dx[i] = g * rs * (dp - dsums[c] * inv_count - xh * dsums[C + c] * inv_count);
+  }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ dsums,
+                                                              float inv_count, float* __restrict__ dx, size_t n, int C, int act) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n / 4; i += stride) {
+    const int c = (int)((i * 4) % C);
+    const float4 xv = reinterpret_cast<const float4*>(x)[i], dv = reinterpret_cast<const float4*>(dy)[i];
+    const float* mr = mean_rstd + c;
+    float o[4];
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float rs = mr[C + j], g = gamma[c + j];
+      const float xh = (xs[j] - mr[j]) * rs;
+      const float dp = ds[j] * ladder_act_grad_from_out(g * xh + beta[c + j], act);
+      o[j] = g * rs * (dp - dsums[c + j] * inv_count - xh * dsums[C + c + j] * inv_count);
+    }
+    reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
 __global__ void bn_param_grad_kernel(const float* __restrict__ dsums, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
@@ -207,6 +272,174 @@ __global__ __launch_bounds__(256) void in_style_bwd_kernel(const float* __restri
     const float dp = dy[i] * ladder_act_grad_from_out(xh * s0 + s1, act);
     dx[i] = rstd * s0 * (dp - ds1 * inv - xh * ds0 * inv);
   }
+}
+
+// Vectorised instance-norm kernels (C % 4 == 0).  256 threads = 16 channel quads (64 channels) x 16 row lanes.
+// The H*W axis of one (sample, 64-channel) slab is split over `split` workgroups so that large maps expose enough
+// parallelism to stream at HBM rate; moments are accumulated about a per-channel pivot (the slab's first pixel), which
+// keeps the single-pass variance exact enough for eps = 1e-6.  Partials are combined in a fixed order.
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+__global__ __launch_bounds__(256) void in_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int HW, int C, int split) {
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int n = blockIdx.y, c = blockIdx.x * 64 + cq * 4, sp = blockIdx.z;
+  const float* xp = x + (size_t)n * HW * C;
+  const int per = (HW + split - 1) / split, r0 = sp * per, r1 = min(HW, r0 + per);
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  if (c < C) {
+    const float4 pv = *reinterpret_cast<const float4*>(xp + c);
+    for (int r = r0 + rl; r < r1; r += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(xp + (size_t)r * C + c);
+      const float dx = v.x - pv.x, dy = v.y - pv.y, dz = v.z - pv.z, dw = v.w - pv.w;
+      s0.x += dx; s0.y += dy; s0.z += dz; s0.w += dw;
+      s1.x += dx * dx; s1.y += dy * dy; s1.z += dz * dz; s1.w += dw * dw;
+    }
+  }
+  __shared__ float4 sm[2][16][16];
+  sm[0][rl][cq] = s0;
+  sm[1][rl][cq] = s1;
+  __syncthreads();
+  if (rl < 2 && c < C) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t = f4add(t, sm[rl][k][cq]);
+    *reinterpret_cast<float4*>(part + (((size_t)n * split + sp) * 2 + rl) * C + c) = t;
+  }
+}
+
+__global__ void in_finalize_kernel(const float* __restrict__ x, const float* __restrict__ part, float* __restrict__ mean_rstd,
+                                   int N, int HW, int C, int split, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i - n * C;
+  double s0 = 0.0, s1 = 0.0;
+  for (int sp = 0; sp < split; ++sp) {
+    s0 += (double)part[(((size_t)n * split + sp) * 2 + 0) * C + c];
+    s1 += (double)part[(((size_t)n * split + sp) * 2 + 1) * C + c];
+  }
+  const double pv = (double)x[(size_t)n * HW * C + c];
+  const double md = s0 / HW;
+  double var = s1 / HW - md * md;
+  if (var < 0.0) var = 0.0;
+  mean_rstd[(size_t)n * 2 * C + c] = (float)(pv + md);
+  mean_rstd[(size_t)n * 2 * C + C + c] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__ x, const float* __restrict__ style,
+                                                       const float* __restrict__ mean_rstd, float* __restrict__ y, int HW, int C,
+                                                       int act, int split) {
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int n = blockIdx.y, c = blockIdx.x * 64 + cq * 4, sp = blockIdx.z;
+  if (c >= C) return;
+  const size_t base = (size_t)n * HW * C;
+  const int per = (HW + split - 1) / split, r0 = sp * per, r1 = min(HW, r0 + per);
+  const float4 mu = *reinterpret_cast<const float4*>(mean_rstd + (size_t)n * 2 * C + c);
+  const float4 rs = *reinterpret_cast<const float4*>(mean_rstd + (size_t)n * 2 * C + C + c);
+  float4 s0 = *reinterpret_cast<const float4*>(style + (size_t)n * 2 * C + c);
+  const float4 s1 = *reinterpret_cast<const float4*>(style + (size_t)n * 2 * C + C + c);
+  s0.x += 1.f; s0.y += 1.f; s0.z += 1.f; s0.w += 1.f;
+  for (int r = r0 + rl; r < r1; r += 16) {
+    const size_t i = base + (size_t)r * C + c;
+    const float4 v = *reinterpret_cast<const float4*>(x + i);
+    float4 o;
+    o.x = ladder_act_fn((v.x - mu.x) * rs.x * s0.x + s1.x, act);
+    o.y = ladder_act_fn((v.y - mu.y) * rs.y * s0.y + s1.y, act);
+    o.z = ladder_act_fn((v.z - mu.z) * rs.z * s0.z + s1.z, act);
+    o.w = ladder_act_fn((v.w - mu.w) * rs.w * s0.w + s1.w, act);
+    *reinterpret_cast<float4*>(y + i) = o;
+  }
+}
+
+// backward statistics: part[.,0] = sum dp*xhat, part[.,1] = sum dp
+__global__ __launch_bounds__(256) void in_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ style, const float* __restrict__ mean_rstd,
+                                                           float* __restrict__ part, int HW, int C, int act, int split) {
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int n = blockIdx.y, c = blockIdx.x * 64 + cq * 4, sp = blockIdx.z;
+  const size_t base = (size_t)n * HW * C;
+  const int per = (HW + split - 1) / split, r0 = sp * per, r1 = min(HW, r0 + per);
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+  if (c < C) {
+    const float4 mu = *reinterpret_cast<const float4*>(mean_rstd + (size_t)n * 2 * C + c);
+    const float4 rs = *reinterpret_cast<const float4*>(mean_rstd + (size_t)n * 2 * C + C + c);
+    float4 s0 = *reinterpret_cast<const float4*>(style + (size_t)n * 2 * C + c);
+    const float4 s1 = *reinterpret_cast<const float4*>(style + (size_t)n * 2 * C + C + c);
+    s0.x += 1.f; s0.y += 1.f; s0.z += 1.f; s0.w += 1.f;
+    for (int r = r0 + rl; r < r1; r += 16) {
+      const size_t i = base + (size_t)r * C + c;
+      const float4 xv = *reinterpret_cast<const float4*>(x + i), dv = *reinterpret_cast<const float4*>(dy + i);
+      float xh, dp;
+      xh = (xv.x - mu.x) * rs.x; dp = dv.x * ladder_act_grad_from_out(xh * s0.x + s1.x, act); a0.x += dp * xh; a1.x += dp;
+      xh = (xv.y - mu.y) * rs.y; dp = dv.y * ladder_act_grad_from_out(xh * s0.y + s1.y, act); a0.y += dp * xh; a1.y += dp;
+      xh = (xv.z - mu.z) * rs.z; dp = dv.z * ladder_act_grad_from_out(xh * s0.z + s1.z, act); a0.z += dp * xh; a1.z += dp;
+      xh = (xv.w - mu.w) * rs.w; dp = dv.w * ladder_act_grad_from_out(xh * s0.w + s1.w, act); a0.w += dp * xh; a1.w += dp;
+    }
+  }
+  __shared__ float4 sm[2][16][16];
+  sm[0][rl][cq] = a0;
+  sm[1][rl][cq] = a1;
+  __syncthreads();
+  if (rl < 2 && c < C) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t = f4add(t, sm[rl][k][cq]);
+    *reinterpret_cast<float4*>(part + (((size_t)n * split + sp) * 2 + rl) * C + c) = t;
+  }
+}
+__global__ void in_bwd_finalize_kernel(const float* __restrict__ part, float* __restrict__ dstyle, int N, int C, int split) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i - n * C;
+  double s0 = 0.0, s1 = 0.0;
+  for (int sp = 0; sp < split; ++sp) {
+    s0 += (double)part[(((size_t)n * split + sp) * 2 + 0) * C + c];
+    s1 += (double)part[(((size_t)n * split + sp) * 2 + 1) * C + c];
+  }
+  dstyle[(size_t)n * 2 * C + c] = (float)s0;
+  dstyle[(size_t)n * 2 * C + C + c] = (float)s1;
+}
+__global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ style, const float* __restrict__ mean_rstd,
+                                                           const float* __restrict__ dstyle, float* __restrict__ dx, int HW, int C,
+                                                           int act, int split) {
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int n = blockIdx.y, c = blockIdx.x * 64 + cq * 4, sp = blockIdx.z;
+  if (c >= C) return;
+  const size_t base = (size_t)n * HW * C;
+  const int per = (HW + split - 1) / split, r0 = sp * per, r1 = min(HW, r0 + per);
+  const float inv = 1.f / (float)HW;
+  float mu[4], rs[4], s0[4], s1[4], d0[4], d1[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    mu[j] = mean_rstd[(size_t)n * 2 * C + c + j];
+    rs[j] = mean_rstd[(size_t)n * 2 * C + C + c + j];
+    s0[j] = style[(size_t)n * 2 * C + c + j] + 1.f;
+    s1[j] = style[(size_t)n * 2 * C + C + c + j];
+    d0[j] = dstyle[(size_t)n * 2 * C + c + j] * inv;
+    d1[j] = dstyle[(size_t)n * 2 * C + C + c + j] * inv;
+  }
+  for (int r = r0 + rl; r < r1; r += 16) {
+    const size_t i = base + (size_t)r * C + c;
+    const float4 xv = *reinterpret_cast<const float4*>(x + i), dv = *reinterpret_cast<const float4*>(dy + i);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (xs[j] - mu[j]) * rs[j];
+      const float dp = ds[j] * ladder_act_grad_from_out(xh * s0[j] + s1[j], act);
+      o[j] = rs[j] * s0[j] * (dp - d1[j] - xh * d0[j]);
+    }
+    *reinterpret_cast<float4*>(dx + i) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+inline int in_split(int N, int HW, int C) {
+  const long groups = (long)N * ((C + 63) / 64);
+  int sp = (int)((2048 + groups - 1) / groups);     // aim for ~8 workgroups per CU
+  const int max_sp = (HW + 63) / 64;                // at least 64 pixels (4 per row lane) per workgroup
+  if (sp > max_sp) sp = max_sp;
+  if (sp < 1) sp = 1;
+  return sp;
 }
 
 // ----------------------------------------------------------------------------- legacy bilinear resize (integer factors)
@@ -362,8 +595,12 @@ int ladder_bn_fwd_stats(const float* x, float* sums, size_t rows, int C, void* w
   const size_t nblk = stats_nblk(rows);
   if (ws_bytes < nblk * 2 * (size_t)C * sizeof(float)) return LADDER_E_WORKSPACE;
   const size_t rpb = (rows + nblk - 1) / nblk;
-  hipLaunchKernelGGL(colstats_stage1<1>, dim3((C + 63) / 64, (unsigned)nblk), dim3(256), 0, stream, x, (const float*)nullptr,
-                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)ws, rows, C, rpb, 0);
+  if (C % 4 == 0 && ladder_aligned16(x))
+    hipLaunchKernelGGL(colstats_stage1_v4<1>, dim3((C + 63) / 64, (unsigned)nblk), dim3(256), 0, stream, x, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)ws, rows, C, rpb, 0);
+  else
+    hipLaunchKernelGGL(colstats_stage1<1>, dim3((C + 63) / 64, (unsigned)nblk), dim3(256), 0, stream, x, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)ws, rows, C, rpb, 0);
   hipLaunchKernelGGL(colstats_stage2, dim3((2 * C + 63) / 64), dim3(256), 0, stream, (const float*)ws, sums, (int)nblk, C);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
@@ -388,8 +625,12 @@ int ladder_bn_bwd_stats(const float* dy, const float* x, const float* mean_rstd,
   const size_t nblk = stats_nblk(rows);
   if (ws_bytes < nblk * 2 * (size_t)C * sizeof(float)) return LADDER_E_WORKSPACE;
   const size_t rpb = (rows + nblk - 1) / nblk;
-  hipLaunchKernelGGL(colstats_stage1<2>, dim3((C + 63) / 64, (unsigned)nblk), dim3(256), 0, stream, dy, x, mean_rstd, gamma, beta,
-                     (float*)ws, rows, C, rpb, act);
+  if (C % 4 == 0 && ladder_aligned16(x) && ladder_aligned16(dy))
+    hipLaunchKernelGGL(colstats_stage1_v4<2>, dim3((C + 63) / 64, (unsigned)nblk), dim3(256), 0, stream, dy, x, mean_rstd, gamma, beta,
+                       (float*)ws, rows, C, rpb, act);
+  else
+    hipLaunchKernelGGL(colstats_stage1<2>, dim3((C + 63) / 64, (unsigned)nblk), dim3(256), 0, stream, dy, x, mean_rstd, gamma, beta,
+                       (float*)ws, rows, C, rpb, act);
   hipLaunchKernelGGL(colstats_stage2, dim3((2 * C + 63) / 64), dim3(256), 0, stream, (const float*)ws, dsums, (int)nblk, C);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
@@ -400,9 +641,14 @@ int ladder_bn_bwd_apply(const float* dy, const float* x, const float* mean_rstd,
                         ladder_stream_t stream) {
   if (rows == 0 || C <= 0 || count <= 0) return LADDER_E_SHAPE;
   const size_t n = rows * (size_t)C;
-  if (dx != nullptr)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, dy, x, mean_rstd, gamma, beta, dsums,
-                       (float)(1.0 / count), dx, n, C, act);
+  if (dx != nullptr) {
+    if (C % 4 == 0 && ladder_aligned16(x) && ladder_aligned16(dy) && ladder_aligned16(dx))
+      hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, stream, dy, x, mean_rstd, gamma, beta, dsums,
+                         (float)(1.0 / count), dx, n, C, act);
+    else
+      hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, dy, x, mean_rstd, gamma, beta, dsums,
+                         (float)(1.0 / count), dx, n, C, act);
+  }
   if (dgamma != nullptr && dbeta != nullptr)
     hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, dsums, dgamma, dbeta, C);
   LADDER_CHECK_LAUNCH();
@@ -411,17 +657,38 @@ int ladder_bn_bwd_apply(const float* dy, const float* x, const float* mean_rstd,
 
 size_t ladder_bn_workspace_bytes(size_t rows, int C) { return stats_nblk(rows) * 2 * (size_t)C * sizeof(float); }
 
+size_t ladder_in_style_workspace_bytes(int N, int HW, int C) { return (size_t)N * in_split(N, HW, C) * 2 * C * sizeof(float); }
+
 int ladder_in_style_fwd(const float* x, const float* style, float* y, float* mean_rstd, int N, int HW, int C, float eps, int act,
-                        ladder_stream_t stream) {
+                        void* ws, size_t ws_bytes, ladder_stream_t stream) {
   if (N <= 0 || HW <= 0 || C <= 0) return LADDER_E_SHAPE;
+  if (C % 4 == 0 && ws != nullptr && ws_bytes >= ladder_in_style_workspace_bytes(N, HW, C) && ladder_aligned16(x) && ladder_aligned16(y)) {
+    const int sp = in_split(N, HW, C);
+    dim3 grid((C + 63) / 64, N, sp);
+    hipLaunchKernelGGL(in_stats_kernel, grid, dim3(256), 0, stream, x, (float*)ws, HW, C, sp);
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, stream, x, (const float*)ws, mean_rstd, N, HW, C, sp, eps);
+    hipLaunchKernelGGL(in_apply_kernel, grid, dim3(256), 0, stream, x, style, (const float*)mean_rstd, y, HW, C, act, sp);
+    LADDER_CHECK_LAUNCH();
+    return LADDER_OK;
+  }
   hipLaunchKernelGGL(in_style_fwd_kernel, dim3((C + 63) / 64, N), dim3(256), 0, stream, x, style, y, mean_rstd, HW, C, eps, act);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
 
 int ladder_in_style_bwd(const float* dy, const float* x, const float* style, const float* mean_rstd, float* dx, float* dstyle,
-                        int N, int HW, int C, int act, ladder_stream_t stream) {
+                        int N, int HW, int C, int act, void* ws, size_t ws_bytes, ladder_stream_t stream) {
   if (N <= 0 || HW <= 0 || C <= 0) return LADDER_E_SHAPE;
+  if (C % 4 == 0 && ws != nullptr && ws_bytes >= ladder_in_style_workspace_bytes(N, HW, C) && ladder_aligned16(x) && ladder_aligned16(dy) &&
+      ladder_aligned16(dx)) {
+    const int sp = in_split(N, HW, C);
+    dim3 grid((C + 63) / 64, N, sp);
+    hipLaunchKernelGGL(in_bwd_stats_kernel, grid, dim3(256), 0, stream, dy, x, style, mean_rstd, (float*)ws, HW, C, act, sp);
+    hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dstyle, N, C, sp);
+    hipLaunchKernelGGL(in_bwd_apply_kernel, grid, dim3(256), 0, stream, dy, x, style, mean_rstd, (const float*)dstyle, dx, HW, C, act, sp);
+    LADDER_CHECK_LAUNCH();
+    return LADDER_OK;
+  }
   hipLaunchKernelGGL(in_style_bwd_kernel, dim3((C + 63) / 64, N), dim3(256), 0, stream, dy, x, style, mean_rstd, dx, dstyle, HW, C, act);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;

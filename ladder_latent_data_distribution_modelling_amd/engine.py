@@ -326,8 +326,9 @@ class InstanceNormStyleAct:
         N, H, W, C = x.shape
         y = torch.empty_like(x)
         self.mean_rstd = self.ctx.empty(N, 2 * C)
+        wsp, wsn = self.ctx.ws(L.query("ladder_in_style_workspace_bytes", N, H * W, C))
         L.call("ladder_in_style_fwd", _p(x), _p(style), _p(y), _p(self.mean_rstd), N, H * W, C, IN_EPS, L.ACT[self.act],
-               self.ctx.stream)
+               wsp, wsn, self.ctx.stream)
         self.x, self.style = x, style
         return y
 
@@ -336,8 +337,9 @@ class InstanceNormStyleAct:
         N, H, W, C = x.shape
         dx = torch.empty_like(x)
         dstyle = self.ctx.empty(N, 2 * C)
+        wsp, wsn = self.ctx.ws(L.query("ladder_in_style_workspace_bytes", N, H * W, C))
         L.call("ladder_in_style_bwd", _p(dy), _p(x), _p(self.style), _p(self.mean_rstd), _p(dx), _p(dstyle), N, H * W, C,
-               L.ACT[self.act], self.ctx.stream)
+               L.ACT[self.act], wsp, wsn, self.ctx.stream)
         self.x = self.style = None
         return dx, dstyle
 

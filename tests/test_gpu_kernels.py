@@ -192,10 +192,15 @@ def test_instance_norm_style(gpu_ctx, shape):
     st = gpu_ctx.stream
     xd, sd, dyd = dev(x), dev(sty), dev(dy)
     y, mr = torch.empty_like(xd), torch.empty(N, 2 * C, device="cuda")
-    L.call("ladder_in_style_fwd", p(xd), p(sd), p(y), p(mr), N, H * W, C, 1e-6, 1, st)
-    close(y, yr, 1e-5, "y")
+    wsp, wsn = gpu_ctx.ws(max(L.query("ladder_in_style_workspace_bytes", N, H * W, C), 16))
+    for use_ws in (False, True):       # one-workgroup-per-slab kernels, then the split / vectorised ones
+        y.zero_()
+        L.call("ladder_in_style_fwd", p(xd), p(sd), p(y), p(mr), N, H * W, C, 1e-6, 1, wsp if use_ws else None, wsn if use_ws else 0, st)
+        close(y, yr, 1e-5, "y ws=%s" % use_ws)
     dx, dst = torch.empty_like(xd), torch.empty_like(sd)
-    L.call("ladder_in_style_bwd", p(dyd), p(xd), p(sd), p(mr), p(dx), p(dst), N, H * W, C, 1, st)
+    L.call("ladder_in_style_bwd", p(dyd), p(xd), p(sd), p(mr), p(dx), p(dst), N, H * W, C, 1, None, 0, st)
+    close(dst, stt.grad, 2e-5, "dstyle (no ws)")
+    L.call("ladder_in_style_bwd", p(dyd), p(xd), p(sd), p(mr), p(dx), p(dst), N, H * W, C, 1, wsp, wsn, st)
     close(dst, stt.grad, 2e-5, "dstyle")
     # instance-norm backward at 2x2 with eps=1e-6 is ill-conditioned (rstd up to 1e3): compare at 1e-3 of scale there
     close(dx, xt.grad, 1e-3 if H * W <= 4 else 5e-5, "dx")
