@@ -69,6 +69,7 @@ class BaseTrain:
         if int(cfg["TRAIN_sigma"]) == 1:
             lr_s = float(cfg["learning_rate_sigma"]) * (0.99 ** (self.cur_epoch - 1))
             eng.run_sigma(batch_data, lr_s, noise[1] if noise else None, use_sg, use_mask)
+            self._enc_batch = batch_data      # RUN#2 evaluated the encoder with the post-RUN#1 weights on this batch
             self.last_fetch_sigma = eng.fetch(["sigma"])
             self.sigma_train.append(self.last_fetch_sigma["sigma"])
         return f["loss_ae"]
@@ -78,7 +79,10 @@ class BaseTrain:
         eng, cfg = self.engine, self.config
         use_sg, use_mask = self.compute_feeddict(batch_data, "prior")
         lr_p = float(cfg["learning_rate_prior"]) * (1.01 ** (self.cur_epoch - 1))
-        eng.run_prior(batch_data, lr_p, noise[0] if noise else None, use_sg, use_mask)
+        # RUN#3/#4 see the same encoder weights as RUN#2 (only sigma / prior variables changed since): reuse its output
+        reuse = getattr(self, "_enc_batch", None) is batch_data
+        eng.run_prior(batch_data, lr_p, noise[0] if noise else None, use_sg, use_mask, reuse_encoder=reuse)
+        self._enc_batch = batch_data
         f = eng.fetch()
         self.code_recons_error_train.append(f["code_l1_reconstruction_error"])
         self.code_recons_likelihood_train.append(f["code_reconstruction_likelihood"])
@@ -89,7 +93,7 @@ class BaseTrain:
         self.last_fetch_prior = f
         if int(cfg["TRAIN_inner_sigma"]) == 1:
             lr_i = float(cfg["learning_rate_inner_sigma"]) * (1.01 ** (self.cur_epoch - 1))
-            eng.run_inner_sigma(batch_data, lr_i, noise[1] if noise else None, use_sg, use_mask)
+            eng.run_inner_sigma(batch_data, lr_i, noise[1] if noise else None, use_sg, use_mask, reuse_encoder=True)
 
     def val_step(self, model_to_train, batch_data, noise=None):
         """codes/base.py:643-679."""

@@ -138,6 +138,25 @@ def test_gradients_vs_live_oracle(golden_dir, exp, use_sg, use_mask):
     assert _rel(s[L.S_INDEX["_g_inner_sigma_var"]], float(ref["_grads"]["inner_sigma/Variable"])) < 1e-4
 
 
+def test_encoder_reuse_is_bit_identical(golden_dir):
+    """RUN#2/#3/#4 may reuse the encoder output of the previous run on the same batch (no encoder variable changed):
+    the fetched scalars must be bit-identical to a full re-evaluation, and the guard must drop the cache after an AE step."""
+    d = np.load(os.path.join(golden_dir, "oracle_celeba.npz"))
+    cfg = json.loads(str(d["config"]))
+    eng = _engine(cfg)
+    eng.set_mixture(d["gm_w"], d["gm_m"], d["gm_c"])
+    nz = {k: d["it0_run3_%s" % k] for k in ("eps_z", "eps_t", "eps_mc")}
+    eng.forward(d["x"], nz, False, False, ("inner", "gmm"))
+    a = eng.scalars.clone()
+    eng.forward(d["x"], nz, False, False, ("inner", "gmm"), reuse_encoder=True)
+    assert torch.equal(a, eng.scalars)
+    eng.run_ae(d["x"], 1e-3, nz, False, False)                      # encoder weights change -> cache must be ignored
+    eng.forward(d["x"], nz, False, False, ("inner", "gmm"), reuse_encoder=True)
+    b = eng.scalars.clone()
+    eng.forward(d["x"], nz, False, False, ("inner", "gmm"))
+    assert torch.equal(b, eng.scalars) and not torch.equal(a, b)
+
+
 def test_sg_feed_identity(golden_dir):
     """With the SG-pretraining feed (K identical N(0,I) components) the MC cross-entropy equals the finite-sum
     closed form mean_{l,b}[-R/2 log 2pi - 1/2 |t_mc|^2]."""
