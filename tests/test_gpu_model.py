@@ -200,3 +200,80 @@ def test_trainer_epoch_synthetic(tmp_path):
     assert os.path.isfile(os.path.join(str(tmp_path), "vae-model.npz")) and os.path.isfile(os.path.join(str(tmp_path), "GM_prior_info.npz"))
     # losses should not blow up and the ELBO should improve over training on a fixed data set
     assert np.mean(res["elbo_train"][-2:]) > np.mean(res["elbo_train"][:2])
+
+
+DP_GPU_WORKER = r'''
+import json, os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+rank = int(sys.argv[1])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=2)
+from ladder_latent_data_distribution_modelling_amd.engine import LadderEngine
+from ladder_latent_data_distribution_modelling_amd import arch
+d = np.load(os.path.join(%(root)r, "tests", "golden", "oracle_celeba.npz"))
+cfg = json.loads(str(d["config"]))
+rng = np.random.default_rng(0)
+x = rng.random((4, 128, 128, 3)).astype(np.float32)
+Z, R, Lmc = cfg["code_size"], cfg["representation_size"], cfg["n_MC_samples"]
+noise = [dict(eps_z=rng.standard_normal((4, Z)).astype(np.float32), eps_t=rng.standard_normal((4, R)).astype(np.float32),
+              eps_mc=rng.standard_normal((Lmc, 4, R)).astype(np.float32)) for _ in range(4)]
+sl = slice(2 * rank, 2 * rank + 2)
+shard = [dict(eps_z=n["eps_z"][sl], eps_t=n["eps_t"][sl], eps_mc=n["eps_mc"][:, sl]) for n in noise]
+vals = arch.init_values(cfg, seed=1)
+eng = LadderEngine(cfg, "cuda:0", values=vals)          # Comm() picks up the initialised 2-rank group
+assert eng.ctx.comm.world == 2
+eng.set_mixture(d["gm_w"], d["gm_m"], d["gm_c"])
+out = {}
+eng.run_ae(x[sl], 1e-3, shard[0], False, False); out["ae"] = eng.fetch()
+eng.run_sigma(x[sl], 1e-3, shard[1], False, False); out["sigma"] = eng.fetch(["sigma"])
+eng.run_prior(x[sl], 1e-3, shard[2], False, False); out["prior"] = eng.fetch()
+eng.run_inner_sigma(x[sl], 1e-3, shard[3], False, False)
+params = eng.ps.to_dict()
+if rank == 0:
+    np.savez(sys.argv[2], fetch=json.dumps(out), **{"p/" + k: v for k, v in params.items()})
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_two_ranks_one_gpu(golden_dir, tmp_path):
+    """The PRODUCT data-parallel path (HIP kernels + C1-C4 exchanges through engine.Comm) with 2 processes sharing cuda:0 over
+    gloo (RCCL refuses two ranks on one device): one full 4-run iteration on half batches must reproduce the single-process
+    iteration on the whole batch -- fetches to 1e-5, updated parameters to Adam-noise level."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script, outp = tmp_path / "dp_gpu_worker.py", str(tmp_path / "dp_out.npz")
+    script.write_text(DP_GPU_WORKER % dict(root=root, port=30500 + os.getpid() % 2000))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), outp], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    got = np.load(outp)
+    gf = json.loads(str(got["fetch"]))
+    # single-process reference on the full batch with the same noise
+    d = np.load(os.path.join(golden_dir, "oracle_celeba.npz"))
+    cfg = json.loads(str(d["config"]))
+    rng = np.random.default_rng(0)
+    x = rng.random((4, 128, 128, 3)).astype(np.float32)
+    Z, R, Lmc = cfg["code_size"], cfg["representation_size"], cfg["n_MC_samples"]
+    noise = [dict(eps_z=rng.standard_normal((4, Z)).astype(np.float32), eps_t=rng.standard_normal((4, R)).astype(np.float32),
+                  eps_mc=rng.standard_normal((Lmc, 4, R)).astype(np.float32)) for _ in range(4)]
+    eng = _engine(cfg)
+    eng.set_mixture(d["gm_w"], d["gm_m"], d["gm_c"])
+    eng.run_ae(x, 1e-3, noise[0], False, False)
+    ref_ae = eng.fetch()
+    eng.run_sigma(x, 1e-3, noise[1], False, False)
+    ref_sigma = eng.fetch(["sigma"])
+    eng.run_prior(x, 1e-3, noise[2], False, False)
+    ref_prior = eng.fetch()
+    eng.run_inner_sigma(x, 1e-3, noise[3], False, False)
+    for k in SCALARS_RUN1:
+        assert _ok(gf["ae"][k], ref_ae[k], 1e-5), (k, gf["ae"][k], ref_ae[k])
+    assert _ok(gf["sigma"]["sigma"], ref_sigma["sigma"], 1e-5)
+    for k in SCALARS_RUN3:
+        assert _ok(gf["prior"][k], ref_prior[k], 2e-4), (k, gf["prior"][k], ref_prior[k])
+    ref_p = eng.ps.to_dict()
+    for k, v in ref_p.items():
+        diff = np.abs(got["p/" + k].astype(np.float64) - v.astype(np.float64))
+        assert np.median(diff) < 2e-6 and diff.max() <= 2.5e-3, (k, np.median(diff), diff.max())
