@@ -30,7 +30,31 @@ struct IgemmDesc {
   int M, K;
   int act;
   FastDiv div_howo, div_wo;
+  // fast path (Cin % 16 == 0): explicit tap table.  K order = channel slab outer, taps inner; tap t reads the input at
+  // (base_h + tap_dh[t], base_w + tap_dw[t]) and the filter tap tap_w[t] (= r*KW + s of the HWIO bank).
+  int ntaps;
+  signed char tap_dh[28], tap_dw[28], tap_w[28];
+  // output pixel (ho, wo) of the M space is stored at y[n, out_h0 + ho*out_sh, out_w0 + wo*out_sw, :] of an OH x OW map
+  int out_sh, out_sw, out_h0, out_w0, OH, OW;
 };
+
+// Fills the tap table / output mapping of an ordinary convolution (all KH*KW taps, dense output).
+inline bool set_conv_taps(IgemmDesc& d) {
+  d.out_sh = d.out_sw = 1;
+  d.out_h0 = d.out_w0 = 0;
+  d.OH = d.Ho;
+  d.OW = d.Wo;
+  d.ntaps = 0;
+  if (d.ups != 1 || d.KH * d.KW > 28) return false;
+  for (int r = 0; r < d.KH; ++r)
+    for (int sx = 0; sx < d.KW; ++sx) {
+      d.tap_dh[d.ntaps] = (signed char)r;
+      d.tap_dw[d.ntaps] = (signed char)sx;
+      d.tap_w[d.ntaps] = (signed char)(r * d.KW + sx);
+      ++d.ntaps;
+    }
+  return true;
+}
 
 namespace {
 
@@ -41,23 +65,11 @@ constexpr int kThreads = 256;
 #ifndef IGEMM_MINW
 #define IGEMM_MINW 1
 #endif
-#ifndef IGEMM_PIN
-#define IGEMM_PIN 0
-#endif
-#ifndef IGEMM_TAPINNER
-#define IGEMM_TAPINNER 1
-#endif
-#ifndef IGEMM_PF2
-#define IGEMM_PF2 0
-#endif
 #ifndef IGEMM_HALO
 #define IGEMM_HALO 1
 #endif
 #ifndef IGEMM_FWD_MINW
 #define IGEMM_FWD_MINW 4
-#endif
-#ifndef IGEMM_ABL   // ablation (profiling builds only): 1 = no global loads/LDS stores in the loop, 2 = +no barrier, 3 = +no LDS reads
-#define IGEMM_ABL 0
 #endif
 constexpr int BK = IGEMM_BK;
 
@@ -137,11 +149,10 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? IGEMM_FWD_MINW :
     a_ptr[i] = x + a_img[i] + ((long)a_bh[i] * d.W + a_bw[i]) * d.Cin + a_kq[i] * 4;
     uint32_t msk = 0;
     if (FASTA && fast && a_ok[i]) {
-      for (int r = 0; r < d.KH; ++r)
-        for (int sx = 0; sx < d.KW; ++sx) {
-          const int nh = a_bh[i] + r, nw = a_bw[i] + sx;
-          if (nh >= 0 && nh < d.H && nw >= 0 && nw < d.W) msk |= 1u << (r * d.KW + sx);
-        }
+      for (int t = 0; t < d.ntaps; ++t) {
+        const int nh = a_bh[i] + d.tap_dh[t], nw = a_bw[i] + d.tap_dw[t];
+        if (nh >= 0 && nh < d.H && nw >= 0 && nw < d.W) msk |= 1u << t;
+      }
     }
     a_mask[i] = msk;
   }
@@ -154,25 +165,19 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? IGEMM_FWD_MINW :
   }
 
   float4 ra0[AU], rb0[BU];
-#if IGEMM_PF2
-  float4 ra1[AU], rb1[BU];
-#endif
-  const int ntaps = d.KH * d.KW;
   auto load_chunk = [&](int c, float4 (&ra)[AU], float4 (&rb)[BU]) {
-#if IGEMM_TAPINNER
-    // K order: channel slab outer, taps inner -> the kh*kw taps of one 16-channel slab re-read the same cache lines
-    const int k0 = VECA ? ((c % ntaps) * d.Cin + (c / ntaps) * BK) : c * BK;
-#else
-    const int k0 = c * BK;
-#endif
-    if (VECA) {  // Cin % BK == 0: the whole chunk lies inside one filter tap (wave-uniform r, s, ci0)
-      const int rs = k0 / d.Cin, ci0 = k0 - rs * d.Cin;
-      const int r = rs / d.KW, s = rs - r * d.KW;
+    // K order on the fast path: channel slab outer, taps inner -> the taps of one 16-channel slab re-read the same cache lines
+    int k0 = c * BK;     // row of the [K x Cout] filter matrix this chunk starts at
+    if (VECA) {  // Cin % BK == 0: the whole chunk lies inside one filter tap (wave-uniform tap, ci0)
       if (fast) {
-        const long coff = ((long)r * d.W + s) * d.Cin + ci0;
+        const int t = c % d.ntaps, ci0 = (c / d.ntaps) * BK;
+        k0 = (int)d.tap_w[t] * d.Cin + ci0;
+        const long coff = ((long)d.tap_dh[t] * d.W + d.tap_dw[t]) * d.Cin + ci0;
 #pragma unroll
-        for (int i = 0; i < AU; ++i) ra[i] = ld4(((a_mask[i] >> rs) & 1u) ? a_ptr[i] + coff : g_zero16);
+        for (int i = 0; i < AU; ++i) ra[i] = ld4(((a_mask[i] >> t) & 1u) ? a_ptr[i] + coff : g_zero16);
       } else {
+        const int rs = k0 / d.Cin, ci0 = k0 - rs * d.Cin;
+        const int r = rs / d.KW, s = rs - r * d.KW;
 #pragma unroll
         for (int i = 0; i < AU; ++i) {
           long off = a_ok[i] ? gather_off(d, a_img[i], a_bh[i], a_bw[i], r, s, ci0 + a_kq[i] * 4) : -1;
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? IGEMM_FWD_MINW :
 #pragma unroll
     for (int i = 0; i < BU; ++i) {
       const int k = k0 + b_kr[i], n = n0 + b_nq[i] * 4;
-      const bool inb = (tid + i * kThreads < B_UNITS) && k < d.K;
+      const bool inb = (tid + i * kThreads < B_UNITS) && k < d.KH * d.KW * d.Cin;
       if (VECB) {
         rb[i] = ld4((inb && n < d.Cout) ? w + (long)k * d.Cout + n : g_zero16);
       } else {
@@ -259,25 +264,6 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? IGEMM_FWD_MINW :
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks][mi], bf[ks][ni], acc[mi][ni], 0, 0, 0);
   };
 
-#if IGEMM_PF2
-  // global loads run TWO chunks ahead of the MFMA block (two register sets): chunk c+1 is written to LDS from the set
-  // loaded one iteration earlier while the loads of chunk c+2 are already in flight.
-  load_chunk(c_begin, ra0, rb0);
-  store_chunk(0, ra0, rb0);
-  if (c_begin + 1 < nchunks) load_chunk(c_begin + 1, ra1, rb1);
-  __syncthreads();
-  for (int c = c_begin; c < nchunks; c += 2) {
-    if (c + 2 < nchunks) load_chunk(c + 2, ra0, rb0);
-    mma_chunk(0);
-    if (c + 1 < nchunks) store_chunk(1, ra1, rb1);
-    __syncthreads();
-    if (c + 1 >= nchunks) break;
-    if (c + 3 < nchunks) load_chunk(c + 3, ra1, rb1);
-    mma_chunk(1);
-    if (c + 2 < nchunks) store_chunk(0, ra0, rb0);
-    __syncthreads();
-  }
-#else
   load_chunk(c_begin, ra0, rb0);
   store_chunk(0, ra0, rb0);
   __syncthreads();
@@ -288,7 +274,6 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? IGEMM_FWD_MINW :
     if (c + 1 < nchunks) store_chunk(buf ^ 1, ra0, rb0);
     __syncthreads();
   }
-#endif
 
   if (part != nullptr) {   // split-K partial: raw accumulators, bias/activation applied by splitk_epilogue_kernel
     float* o = part + (size_t)blockIdx.y * d.M * d.Cout;
@@ -306,6 +291,7 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? IGEMM_FWD_MINW :
     return;
   }
   // epilogue: bias + activation, 128-byte row segments per half-wave
+  const bool dense_out = d.out_sh == 1 && d.out_sw == 1 && d.OH == d.Ho && d.OW == d.Wo;
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int n = n0 + wn * TN + ni * 32 + l31;
@@ -315,7 +301,15 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? IGEMM_FWD_MINW :
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = m0 + wm * TM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (m < d.M && n < d.Cout) y[(long)m * d.Cout + n] = ladder_act_fn(acc[mi][ni][e] + bv, d.act);
+        if (m < d.M && n < d.Cout) {
+          long row = m;
+          if (!dense_out) {   // phased backward-data: the M space is one parity class of the output map
+            const uint32_t n_img = fdiv((uint32_t)m, d.div_howo), rem = (uint32_t)m - n_img * HoWo;
+            const uint32_t ho = fdiv(rem, d.div_wo), wo = rem - ho * d.Wo;
+            row = ((long)n_img * d.OH + d.out_h0 + (long)ho * d.out_sh) * d.OW + d.out_w0 + (long)wo * d.out_sw;
+          }
+          y[row * d.Cout + n] = ladder_act_fn(acc[mi][ni][e] + bv, d.act);
+        }
       }
     }
   }
@@ -722,8 +716,9 @@ int launch_fwd(const float* x, const float* w, const float* bias, float* y, cons
                hipStream_t st) {
   const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.Cout + BN - 1) / BN;
   const bool veca = (d.Cin % BK) == 0, vecb = (d.Cout % 4) == 0;
-  const bool fast = d.ups == 1 && d.KH * d.KW <= 32;
-  SplitPlan sp = plan_splitk(d.M, d.K, d.Cout, BM, BN);
+  const bool fast = d.ntaps > 0;
+  const bool dense_out = d.out_sh == 1 && d.out_sw == 1 && d.OH == d.Ho && d.OW == d.Wo;
+  SplitPlan sp = dense_out ? plan_splitk(d.M, d.K, d.Cout, BM, BN) : SplitPlan{1, (d.K + BK - 1) / BK};
   const size_t need = (size_t)sp.splits * d.M * d.Cout * sizeof(float);
   if (sp.splits > 1 && (ws == nullptr || ws_bytes < need)) sp = SplitPlan{1, (d.K + BK - 1) / BK};
   float* part = sp.splits > 1 ? (float*)ws : nullptr;
@@ -877,6 +872,7 @@ int ladder_conv2d_fwd(const float* x, const float* w, const float* bias, float* 
                       void* ws, size_t ws_bytes, ladder_stream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return LADDER_E_SHAPE;
   IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, 1, pad_t, pad_l, N * Ho * Wo, KH * KW * Cin, act, make_fastdiv(Ho * Wo), make_fastdiv(Wo)};
+  set_conv_taps(d);
   return dispatch_fwd(x, w, bias, y, d, ws, ws_bytes, stream);
 }
 
@@ -886,6 +882,7 @@ int ladder_conv2d_fwd_kernel_id(int N, int H, int W, int Cin, int Ho, int Wo, in
                                 int pad_t, int pad_l) {
   // 256128 = conv3x3_halo_kernel (8x32-pixel x 128-channel LDS-halo tile); otherwise the code of ladder_igemm_fwd_tile
   IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, ups, pad_t, pad_l, N * Ho * Wo, KH * KW * Cin, 0, make_fastdiv(1), make_fastdiv(1)};
+  set_conv_taps(d);
   if (halo_eligible(d)) return 256128;
   return ladder_igemm_fwd_tile(d.M, Cin, Cout);
 }
@@ -904,7 +901,42 @@ int ladder_conv2d_bwd_data(const float* dy, const float* wT, float* dx, int N, i
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return LADDER_E_SHAPE;
   // dx[hi] gathers dy[(hi + pad_t - r)/stride] = dy[(hi + r' - (KH-1-pad_t))/stride] with the flipped tap r'.
   IgemmDesc d{N, Ho, Wo, Cout, H, W, Cin, KH, KW, 1, stride, KH - 1 - pad_t, KW - 1 - pad_l, N * H * W, KH * KW * Cout, LADDER_ACT_NONE, make_fastdiv(H * W), make_fastdiv(W)};
-  return dispatch_fwd(dy, wT, nullptr, dx, d, ws, ws_bytes, stream);
+  set_conv_taps(d);   // stride 1: full tap table; stride > 1: dense output mapping only (ntaps = 0 -> generic gather)
+  if (stride == 1) return dispatch_fwd(dy, wT, nullptr, dx, d, ws, ws_bytes, stream);
+  if (stride == 2 && (Cout % BK) == 0 && KH * KW <= 28) {
+    // Parity-class decomposition of the transposed convolution: output pixels with (hi, wi) parity (ch, cw) only ever see the
+    // flipped taps r' = (pad' + ch) mod 2 (+2), so each class is a dense stride-1 gather over ~1/4 of the taps written to every
+    // other output pixel -- no zero taps enter the MFMA pipeline.
+    const int padh = KH - 1 - pad_t, padw = KW - 1 - pad_l;
+    for (int ch = 0; ch < 2; ++ch)
+      for (int cw = 0; cw < 2; ++cw) {
+        const int Hc = (H - ch + 1) / 2, Wc = (W - cw + 1) / 2;
+        if (Hc <= 0 || Wc <= 0) continue;
+        IgemmDesc c = d;
+        c.Ho = Hc; c.Wo = Wc; c.stride = 1; c.ups = 1; c.pad_t = 0; c.pad_l = 0;
+        c.M = N * Hc * Wc;
+        c.div_howo = make_fastdiv(Hc * Wc);
+        c.div_wo = make_fastdiv(Wc);
+        c.out_sh = c.out_sw = 2; c.out_h0 = ch; c.out_w0 = cw; c.OH = H; c.OW = W;
+        c.ntaps = 0;
+        for (int r = 0; r < KH; ++r) {
+          if (((r + padh + ch) & 1) != 0) continue;
+          for (int sx = 0; sx < KW; ++sx) {
+            if (((sx + padw + cw) & 1) != 0) continue;
+            c.tap_dh[c.ntaps] = (signed char)((ch + r - padh) / 2);     // exact: numerator is even
+            c.tap_dw[c.ntaps] = (signed char)((cw + sx - padw) / 2);
+            c.tap_w[c.ntaps] = (signed char)(r * KW + sx);
+            ++c.ntaps;
+          }
+        }
+        if (c.ntaps == 0) return dispatch_fwd(dy, wT, nullptr, dx, d, ws, ws_bytes, stream);   // degenerate: legacy path writes the zeros
+        c.K = c.ntaps * Cout;
+        const int rc = dispatch_fwd(dy, wT, nullptr, dx, c, nullptr, 0, stream);
+        if (rc != LADDER_OK) return rc;
+      }
+    return LADDER_OK;
+  }
+  return dispatch_fwd(dy, wT, nullptr, dx, d, ws, ws_bytes, stream);   // generic strided gather (ups > 1)
 }
 
 size_t ladder_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW) {
@@ -923,12 +955,14 @@ int ladder_conv2d_bwd_filter(const float* x, const float* dy, float* dw, float* 
 int ladder_dense_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act,
                      void* ws, size_t ws_bytes, ladder_stream_t stream) {
   IgemmDesc d{M, 1, 1, K, 1, 1, N, 1, 1, 1, 1, 0, 0, M, K, act, make_fastdiv(1), make_fastdiv(1)};
+  set_conv_taps(d);
   return dispatch_fwd(x, w, bias, y, d, ws, ws_bytes, stream);
 }
 
 int ladder_dense_bwd_data(const float* dy, const float* wT, float* dx, int M, int K, int N, void* ws, size_t ws_bytes,
                           ladder_stream_t stream) {
   IgemmDesc d{M, 1, 1, N, 1, 1, K, 1, 1, 1, 1, 0, 0, M, N, LADDER_ACT_NONE, make_fastdiv(1), make_fastdiv(1)};
+  set_conv_taps(d);
   return dispatch_fwd(dy, wT, nullptr, dx, d, ws, ws_bytes, stream);
 }
 

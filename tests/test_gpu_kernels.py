@@ -46,6 +46,9 @@ CONV_CASES = [
     (2, 8, 8, 128, 3, 1, 1, "same", None),             # CelebA output conv (Cout=3)
     (1, 7, 9, 20, 36, 3, 1, "same", "relu"),           # ragged everything
     (2, 9, 9, 16, 16, 3, 2, "same", None),             # odd size stride 2 (pad 1/1)
+    (2, 10, 14, 16, 32, 5, 2, "same", None),           # 5x5 stride 2: parity-class bwd_data with 9/6/6/4 taps
+    (3, 7, 9, 32, 16, 3, 2, "valid", "leaky_relu"),    # stride 2 VALID, odd sizes
+    (2, 8, 8, 16, 48, 1, 2, "same", None),             # 1x1 stride 2: three parity classes have no tap (zeros)
     (64, 2, 2, 64, 64, 3, 1, "same", None),            # tiny-spatial decoder block
     (4, 2, 2, 16, 64, 1, 1, "same", "leaky_relu"),     # fashion decoder 1x1 (M=16)
     (4, 4, 4, 16, 64, 3, 1, "same", "leaky_relu"),
