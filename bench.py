@@ -149,8 +149,14 @@ def main():
     }
     if prof:
         dom = max(prof.values(), key=lambda r: r["total_ms"])       # the dominant kernel = largest share of GPU time
+        traffic = None      # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json), same launch mix
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.isfile(tpath) and cfg["exp_name"] == "celeba" and B == 128:
+            tj = json.load(open(tpath))
+            if tj.get("kernel", "") in dom["kernel"]:
+                traffic = tj["hbm_bytes_per_launch"]
         out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2), "peak": FP32_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(dom["tflops"] / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                           "unit": "TFLOP/s", "frac": round(dom["tflops"] / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
                            "launches": dom["launches"], "avg_launch_ms": round(dom["avg_ms"], 4),
                            "flop_per_launch": dom["flops_per_launch"],
                            "share_of_step_time": round(dom["total_ms"] / (1e3 * dt), 3),
