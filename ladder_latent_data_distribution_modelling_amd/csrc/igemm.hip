@@ -68,6 +68,9 @@ constexpr int kThreads = 256;
 #ifndef IGEMM_HALO
 #define IGEMM_HALO 1
 #endif
+#ifndef IGEMM_WH_BLOCKS     // workgroups per CU (x rounds) the halo filter-gradient plan aims for
+#define IGEMM_WH_BLOCKS 2
+#endif
 #ifndef IGEMM_FWD_MINW
 #define IGEMM_FWD_MINW 4
 #endif
@@ -825,16 +828,186 @@ int run_colsum(const float* x, float* out, size_t rows, int C, void* ws, size_t 
   return LADDER_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Filter gradient of a 3x3 / stride 1 / SAME convolution with an LDS-staged input halo patch (tap-fused).
+// One workgroup = 12 wavefronts = the 9 filter taps x 4 output-channel blocks (36 MFMA tiles of 32x32, 3 per wavefront: a
+// balanced 3 waves per SIMD) of a (32 input channels x 128 output channels) slab of dW, reduced over a range of 1x32-pixel
+// patches.  Per patch the 3x(32+2) input halo (32 channels, 13 KB) and the 32x128 dY tile (16 KB) are brought into LDS ONCE by
+// LDS-DMA (global_load_lds, no staging registers) and serve all 9 taps; the generic kernel streams both operands once per
+// tap (~2.5x the bytes per MAC, 5x over-fetch at the fabric).  A fragment = halo shifted by (r,s), lane = ci; B = dY rows.
+constexpr int WH_CI = 32, WH_CO = 128, WH_PH = 1, WH_PW = 32, WH_HW = WH_PW + 2, WH_HH = WH_PH + 2;
+constexpr int WH_THREADS = 768, WH_PIX = WH_PH * WH_PW;
+constexpr int WH_XU = WH_HH * WH_HW * (WH_CI / 4), WH_DU = WH_PIX * (WH_CO / 4);           // float4 units per patch
+constexpr int WH_XN = (WH_XU + WH_THREADS - 1) / WH_THREADS, WH_DN = (WH_DU + WH_THREADS - 1) / WH_THREADS;   // 2, 2
+constexpr int WH_XF = WH_HH * WH_HW * WH_CI, WH_DF = WH_PIX * WH_CO;                       // floats per buffer
+#ifndef IGEMM_WH_MINW
+#define IGEMM_WH_MINW 3
+#endif
+__global__ __launch_bounds__(WH_THREADS, IGEMM_WH_MINW) void wgrad3x3_halo_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                  float* __restrict__ out, float* __restrict__ bias_part,
+                                                                  const int N, const int H, const int W, const int Cin,
+                                                                  const int Cout, const int tiles_co, const int patches_per_split) {
+  // ONE LDS object (hipcc serialises LDS-DMA against ds_reads when several __shared__ objects exist): [buf][halo | dY]
+  __shared__ __attribute__((aligned(16))) float lds[2 * (WH_XF + WH_DF)];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;            // 12 wavefronts
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int ci0 = (blockIdx.x / tiles_co) * WH_CI, co0 = (blockIdx.x % tiles_co) * WH_CO;
+  const int WP = W / WH_PW, HP = H / WH_PH;
+  const int q_total = N * HP * WP;
+  const int q0 = blockIdx.y * patches_per_split, q1 = min(q_total, q0 + patches_per_split);
+  // tiles 3wv .. 3wv+2 of the (tap, channel block) grid, tap = t >> 2, nj = t & 3
+  int a_off[3], b_off[3], t_tap[3], t_nj[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int t = 3 * wv + i;
+    t_tap[i] = t >> 2;
+    t_nj[i] = t & 3;
+    const int r = t_tap[i] / 3, sft = t_tap[i] - 3 * r;
+    a_off[i] = (r * WH_HW + sft + lh) * WH_CI + l31;
+    b_off[i] = WH_XF + lh * WH_CO + t_nj[i] * 32 + l31;
+  }
+  // bias: the centre tap (4) tiles are t = 16..19 -> waves 5 (t=15,16,17 -> i=1,2) and 6 (t=18,19,20 -> i=0,1); each of those
+  // tiles covers one channel block nj exactly once.
+  const bool do_bias = (bias_part != nullptr) && (ci0 == 0);
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  float bsum[3] = {0.f, 0.f, 0.f};
+
+  auto stage_patch = [&](int q, int buf) {
+    const int n = q / (HP * WP), rem = q - n * (HP * WP);
+    const int hp = rem / WP, h0 = hp * WH_PH, w0 = (rem - hp * WP) * WH_PW;
+    float* xb = &lds[buf * (WH_XF + WH_DF)];
+    float* db = xb + WH_XF;
+#pragma unroll
+    for (int i = 0; i < WH_XN; ++i) {
+      const int u = tid + i * WH_THREADS;
+      if (u < WH_XU) {
+        const int pix = u >> 3, q4 = u & 7;
+        const int hr = pix / WH_HW, hc = pix - hr * WH_HW;
+        const int hi = h0 - 1 + hr, wi = w0 - 1 + hc;
+        const bool ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
+        const float* src = ok ? x + (((long)n * H + hi) * W + wi) * Cin + ci0 + q4 * 4 : g_zero16;
+        __builtin_amdgcn_global_load_lds(src, xb + u * 4, 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WH_DN; ++i) {
+      const int u = tid + i * WH_THREADS;
+      if (u < WH_DU) {
+        const int p = u >> 5, q4 = u & 31;
+        const bool ok = (co0 + q4 * 4) < Cout;
+        const float* src = ok ? dy + (((long)n * H + h0 + (p >> 5)) * W + w0 + (p & 31)) * Cout + co0 + q4 * 4 : g_zero16;
+        __builtin_amdgcn_global_load_lds(src, db + u * 4, 16, 0, 0);
+      }
+    }
+  };
+
+  if (q0 < q1) stage_patch(q0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int q = q0; q < q1; ++q) {
+    const int buf = (q - q0) & 1;
+    if (q + 1 < q1) stage_patch(q + 1, buf ^ 1);
+    const float* base = &lds[buf * (WH_XF + WH_DF)];
+#pragma unroll 4
+    for (int ks = 0; ks < WH_PIX / 2; ++ks) {
+      float a[3], b[3];
+      const int arow = ((ks >> 4) * WH_HW + ((2 * ks) & 31)) * WH_CI;     // pixel 2ks(+lh) of the patch -> halo row/col
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        a[i] = base[a_off[i] + arow];
+        b[i] = base[b_off[i] + 2 * ks * WH_CO];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc[i], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) bsum[i] += b[i];
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's LDS-DMA pieces of the next patch have landed
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float* o = out + ((size_t)blockIdx.y * 9 + t_tap[i]) * Cin * Cout;
+    const int n = co0 + t_nj[i] * 32 + l31;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ci = ci0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      if (n < Cout) o[(size_t)ci * Cout + n] = acc[i][e];
+    }
+    if (do_bias && t_tap[i] == 4) {
+      const float v = bsum[i] + __shfl_down(bsum[i], 32, 64);   // odd + even pixels of the k-step pairs
+      if (lh == 0 && n < Cout) bias_part[(size_t)blockIdx.y * Cout + n] = v;
+    }
+  }
+}
+
+struct WgradHaloPlan { bool ok; int tiles_ci, tiles_co, splits, pps; };
+WgradHaloPlan plan_wgrad_halo(const IgemmDesc& d) {
+  WgradHaloPlan p{false, 0, 0, 1, 0};
+#if IGEMM_HALO
+  if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.ups == 1 && d.pad_t == 1 && d.pad_l == 1 && d.Ho == d.H && d.Wo == d.W &&
+        (d.Cin % WH_CI) == 0 && (d.Cout % 4) == 0 && d.Cout >= 64 && (d.W % WH_PW) == 0 && (d.H % WH_PH) == 0))
+    return p;
+  const long q_total = (long)d.N * (d.H / WH_PH) * (d.W / WH_PW);
+  if (q_total * WH_PH < 4096) return p;                       // small maps stay on the generic kernel
+  p.tiles_ci = d.Cin / WH_CI;
+  p.tiles_co = (d.Cout + WH_CO - 1) / WH_CO;
+  const long pairs = (long)p.tiles_ci * p.tiles_co;
+  long s = (IGEMM_WH_BLOCKS * 256L) / pairs;          // whole rounds of the chip
+  if (s > q_total / 16) s = q_total / 16;
+  if (s < 1) s = 1;
+  p.pps = (int)((q_total + s - 1) / s);
+  p.splits = (int)((q_total + p.pps - 1) / p.pps);
+  p.ok = true;
+#endif
+  return p;
+}
+
 size_t wgrad_ws_bytes(long M, int K, int Cout) {
   const WgradPlan p = plan_wgrad(M, K, Cout);
   const size_t a = p.splits > 1 ? (size_t)p.splits * K * Cout * sizeof(float) : 0;
   return a + (size_t)p.splits * Cout * sizeof(float);   // + per-split bias partials
 }
 
+size_t wgrad_ws_bytes_desc(const IgemmDesc& d) {
+  const WgradHaloPlan hp = plan_wgrad_halo(d);
+  size_t need = wgrad_ws_bytes(d.M, d.K, d.Cout);
+  if (hp.ok) {
+    const size_t h = ((hp.splits > 1 ? (size_t)hp.splits * d.K * d.Cout : 0) + (size_t)hp.splits * d.Cout) * sizeof(float);
+    if (h > need) need = h;
+  }
+  return need;
+}
+
 int run_wgrad(const float* x, const float* dy, float* dw, float* db, const IgemmDesc& d, void* ws, size_t ws_bytes, hipStream_t st) {
   if (d.M <= 0 || d.K <= 0 || d.Cout <= 0) return LADDER_E_SHAPE;
   if (!ladder_aligned16(x) || !ladder_aligned16(dy) || !ladder_aligned16(dw)) return LADDER_E_ALIGN;
-  if (ws_bytes < wgrad_ws_bytes(d.M, d.K, d.Cout) || ws == nullptr) return LADDER_E_WORKSPACE;
+  if (ws_bytes < wgrad_ws_bytes_desc(d) || ws == nullptr) return LADDER_E_WORKSPACE;
+  const WgradHaloPlan hp = plan_wgrad_halo(d);
+  if (hp.ok) {
+    const size_t kn = (size_t)d.K * d.Cout;
+    float* out = hp.splits > 1 ? (float*)ws : dw;
+    float* bias_part = db != nullptr ? (float*)ws + (hp.splits > 1 ? (size_t)hp.splits * kn : 0) : nullptr;
+    hipLaunchKernelGGL(wgrad3x3_halo_kernel, dim3(hp.tiles_ci * hp.tiles_co, hp.splits), dim3(WH_THREADS), 0, st, x, dy, out, bias_part,
+                       d.N, d.H, d.W, d.Cin, d.Cout, hp.tiles_co, hp.pps);
+    if (hp.splits > 1)
+      hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, st, (const float*)ws, dw, hp.splits, kn);
+    if (db != nullptr)
+      hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((d.Cout + 255) / 256)), dim3(256), 0, st, (const float*)bias_part, db,
+                         hp.splits, (size_t)d.Cout);
+    LADDER_CHECK_LAUNCH();
+    return LADDER_OK;
+  }
   const WgradPlan p = plan_wgrad(d.M, d.K, d.Cout);
   const size_t kn = (size_t)d.K * d.Cout;
   float* out = p.splits > 1 ? (float*)ws : dw;
@@ -940,8 +1113,9 @@ int ladder_conv2d_bwd_data(const float* dy, const float* wT, float* dx, int N, i
 }
 
 size_t ladder_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW) {
-  (void)H; (void)W;
-  return wgrad_ws_bytes((long)N * Ho * Wo, KH * KW * Cin, Cout);
+  // upper bound over the stride/pad variants of this geometry (the halo path needs stride 1 / pad 1 / Ho==H)
+  IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, 1, 1, 1, 1, N * Ho * Wo, KH * KW * Cin, 0, make_fastdiv(1), make_fastdiv(1)};
+  return wgrad_ws_bytes_desc(d);
 }
 
 int ladder_conv2d_bwd_filter(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Ho,
