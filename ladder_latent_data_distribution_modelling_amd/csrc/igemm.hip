@@ -16,6 +16,7 @@
 // through double-buffered LDS (global -> registers issued before the MFMA block of the current
 // chunk, registers -> LDS after it, one barrier per chunk).  NHWC keeps ci contiguous, so every
 // global load is a 16-byte, 64-byte-per-row-segment coalesced access.
+#include <cstdlib>
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -678,7 +679,15 @@ __global__ __launch_bounds__(HT_THREADS, 2) void conv3x3_halo_kernel(const float
   }
 }
 
+// Debug / validation switch: LADDER_DISABLE_HALO=1 in the environment routes every convolution through the generic gather
+// kernels (used by the tests to cross-check the halo kernels in situ at full size).  Read on every call: no cached state.
+inline bool halo_disabled() {
+  const char* e = getenv("LADDER_DISABLE_HALO");
+  return e != nullptr && e[0] == '1';
+}
+
 bool halo_eligible(const IgemmDesc& d) {
+  if (halo_disabled()) return false;
 #if IGEMM_HALO
   return d.KH == 3 && d.KW == 3 && d.stride == 1 && d.ups == 1 && d.pad_t == 1 && d.pad_l == 1 && d.Ho == d.H && d.Wo == d.W &&
          (d.Cin % BK) == 0 && (d.Cout % 4) == 0 && (d.W % HT_W) == 0 && (d.H % HT_H) == 0 && d.Cout >= 64 &&
@@ -954,6 +963,7 @@ __global__ __launch_bounds__(WH_THREADS, IGEMM_WH_MINW) void wgrad3x3_halo_kerne
 struct WgradHaloPlan { bool ok; int tiles_ci, tiles_co, splits, pps; };
 WgradHaloPlan plan_wgrad_halo(const IgemmDesc& d) {
   WgradHaloPlan p{false, 0, 0, 1, 0};
+  if (halo_disabled()) return p;
 #if IGEMM_HALO
   if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.ups == 1 && d.pad_t == 1 && d.pad_l == 1 && d.Ho == d.H && d.Wo == d.W &&
         (d.Cin % WH_CI) == 0 && (d.Cout % 4) == 0 && d.Cout >= 64 && (d.W % WH_PW) == 0 && (d.H % WH_PH) == 0))

@@ -277,3 +277,86 @@ def test_data_parallel_two_ranks_one_gpu(golden_dir, tmp_path):
     for k, v in ref_p.items():
         diff = np.abs(got["p/" + k].astype(np.float64) - v.astype(np.float64))
         assert np.median(diff) < 2e-6 and diff.max() <= 2.5e-3, (k, np.median(diff), diff.max())
+
+
+@pytest.mark.parametrize("exp", ["mnist_digit", "mnist_fashion"])
+def test_baseline_mnist_configs_full_size_vs_oracle(exp):
+    """BASELINE.json configs[0] / configs[1] at their full sizes (codes/<exp>_config.json: nh=256, batch 128 / 256, K=10 / 20):
+    one complete 4-run iteration vs the float64 oracle -- ELBO fetches to 1e-4 (bar 1e-3), sigma, elbo_prior."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = json.load(open(os.path.join(root, "codes", "%s_config.json" % exp)))
+    B = cfg["batch_size"]
+    rng = np.random.default_rng(21)
+    x = rng.random((B, 28, 28, 1)).astype(np.float32)
+    P = O.init_params(cfg, seed=3)
+    fix = np.load(os.path.join(root, "tests", "golden", "GM_prior_info.npz"))
+    gm = {k: v.astype(np.float32) for k, v in O.synthetic_gm(cfg, fixture=fix).items()}
+    noises = [O.make_noise(cfg, B, rng, np.float32) for _ in range(4)]
+    epoch = cfg["sg_pretraining"] + 1
+    st = O.OracleState(cfg, P, np.float64)
+    ref = O.train_iteration(st, x, noises, gm, cur_epoch=epoch, lr_ae=cfg["learning_rate_ae"])
+    eng = _engine(cfg, values=P)
+    eng.set_mixture(gm["weights"], gm["means"], gm["covs"])
+    lr_ae, lr_s, lr_p, lr_i = _lrs(cfg, epoch)
+    eng.run_ae(x, lr_ae, noises[0], False, False)
+    f = eng.fetch()
+    for k in SCALARS_RUN1:
+        assert _ok(f[k], float(ref["run1"][k]), 1e-4), (k, f[k], float(ref["run1"][k]))
+    eng.run_sigma(x, lr_s, noises[1], False, False)
+    assert _ok(eng.fetch(["sigma"])["sigma"], float(ref["run2"]["sigma"]), 1e-4)
+    eng.run_prior(x, lr_p, noises[2], False, False)
+    f = eng.fetch()
+    for k in SCALARS_RUN3:
+        assert _ok(f[k], float(ref["run3"][k]), 3e-4), (k, f[k], float(ref["run3"][k]))
+
+
+HALO_WORKER = r'''
+import json, os, sys
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+from ladder_latent_data_distribution_modelling_amd.engine import LadderEngine
+cfg = json.load(open(os.path.join(%(root)r, "codes", "celeba_config.json")))
+B = 128
+x = torch.rand(B, 128, 128, 3, generator=torch.Generator().manual_seed(5)).numpy()
+eng = LadderEngine(cfg, "cuda:0", seed=1, noise_seed=99)
+fix = np.load(os.path.join(%(root)r, "tests", "golden", "GM_prior_info.npz"))
+K = cfg["n_mixtures"]
+eng.set_mixture(fix["w_full"][:K] / fix["w_full"][:K].sum(), fix["m_full"][:K], fix["K_full"][:K])
+out = {}
+eng.run_ae(x, 2.5e-4, None, False, False); out["ae"] = eng.fetch()
+g = eng.ps.grad["ae"].double()
+out["grad_norm"] = float(g.norm()); out["grad_abs_sum"] = float(g.abs().sum())
+sel = {n: eng.ps.g[n].detach().cpu().numpy().copy() for n in ("decoder/conv2d_7/kernel", "decoder/conv2d_6/kernel", "decoder/conv2d_5/kernel",
+                                                            "decoder/conv2d_7/bias", "encoder/conv2d_1/kernel", "decoder/dense/kernel")}
+eng.run_prior(x, 1e-4, None, False, False); out["prior"] = eng.fetch()
+np.savez(sys.argv[1], fetch=json.dumps(out), **{k.replace("/", "."): v for k, v in sel.items()})
+'''
+
+
+def test_celeba_full_size_halo_kernels_in_situ(tmp_path):
+    """BASELINE configs[2] at full size (nh=512, z=64, K=30, batch 128): the LDS-halo conv / filter-gradient kernels (engaged only
+    at this scale) must reproduce the generic gather kernels inside the complete training step -- same seeds, same device noise:
+    fetched ELBO terms to 2e-6 relative, selected gradient tensors to 1e-4 of their scale, finite everywhere."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "halo_worker.py"
+    script.write_text(HALO_WORKER % dict(root=root))
+    res = {}
+    for tag, env in (("halo", {}), ("generic", {"LADDER_DISABLE_HALO": "1"})):
+        outp = str(tmp_path / (tag + ".npz"))
+        e = dict(os.environ, **env)
+        p = subprocess.run([sys.executable, str(script), outp], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-2000:]
+        res[tag] = np.load(outp)
+    fa, fb = json.loads(str(res["halo"]["fetch"])), json.loads(str(res["generic"]["fetch"]))
+    for k in SCALARS_RUN1:
+        assert np.isfinite(fa["ae"][k]) and _ok(fa["ae"][k], fb["ae"][k], 2e-6, 1e-5), (k, fa["ae"][k], fb["ae"][k])
+    for k in SCALARS_RUN3:
+        assert _ok(fa["prior"][k], fb["prior"][k], 1e-5, 1e-5), (k, fa["prior"][k], fb["prior"][k])
+    assert _rel(fa["grad_norm"], fb["grad_norm"]) < 1e-5 and _rel(fa["grad_abs_sum"], fb["grad_abs_sum"]) < 1e-5
+    for k in res["halo"].files:
+        if k == "fetch":
+            continue
+        a, b = res["halo"][k].astype(np.float64), res["generic"][k].astype(np.float64)
+        assert np.isfinite(a).all() and np.abs(a - b).max() < 1e-4 * np.abs(b).max(), (k, np.abs(a - b).max(), np.abs(b).max())
