@@ -137,10 +137,12 @@ def main():
     value = B * world * args.steps / dt
     f = trainer.last_fetch_ae
     out = {
-        "metric": "training images/sec (full 4-run LaDDer iteration, CelebA 128x128)", "value": round(value, 2), "unit": "images/sec",
+        "metric": "training images/sec (full 4-run LaDDer iteration, %s %dx%d)" % (
+            {"celeba": "CelebA", "mnist_digit": "MNIST-digit", "mnist_fashion": "MNIST-fashion"}[cfg["exp_name"]],
+            cfg["dim_input_x"], cfg["dim_input_y"]), "value": round(value, 2), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[2]: %s %dx%dx%d nh=%d z=%d R=%d K=%d L=%d per-GPU batch=%d, 4 runs/iteration "
+        "config": {"workload": "BASELINE configs[" + {"mnist_digit": "0", "mnist_fashion": "1", "celeba": "2"}[cfg["exp_name"]] + "]: %s %dx%dx%d nh=%d z=%d R=%d K=%d L=%d per-GPU batch=%d, 4 runs/iteration "
                                "(AE step, sigma step, prior step, inner-sigma step), fitted-GM regime" % (
                                    cfg["exp_name"], cfg["dim_input_x"], cfg["dim_input_y"], cfg["dim_input_channel"],
                                    cfg["num_hidden_units"], cfg["code_size"], R, K, cfg["n_MC_samples"], B),

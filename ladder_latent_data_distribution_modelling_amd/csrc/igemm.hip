@@ -1,21 +1,22 @@
-// Implicit-GEMM convolution / dense kernels for gfx950 (MI355X), fp32 in / fp32 accumulate on the
-// matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain at the fp32 vector rate).
+// Convolution / dense kernels for gfx950 (MI355X), fp32 in / fp32 accumulate on the matrix cores
+// (v_mfma_f32_32x32x2_f32: an exact fp32 FMA chain at the fp32 vector rate, 157.3 TFLOP/s peak).  Four kernel families:
 //
-//   fwd / bwd_data / dense :  C[M x N] = A_gather[M x K] * B[K x N]
-//        M = N_img*Ho*Wo output pixels, N = Cout, K = KH*KW*Cin ordered (r,s,ci), ci fastest.
-//        A is gathered on the fly from the NHWC input (no im2col buffer): tap (r,s) of pixel
-//        (n,ho,wo) reads x[n, (ho*S + r - pad_t)/U, (wo*S + s - pad_l)/U, :] (U = 1 for a forward
-//        conv; U = stride with S = 1 for the backward-data pass of a strided conv, where only
-//        positions divisible by U exist).  B is the HWIO filter bank viewed as a row-major
-//        [K x Cout] matrix -- exactly the reference's checkpoint layout.
-//   bwd_filter / dense bwd_weight : dW[K x N] = A_gather^T[K x M] * dY[M x N], split over M with a
-//        fixed-order second-stage reduction (bit-reproducible).
+//   conv3x3_halo_kernel     3x3 / stride 1 / SAME forward and backward-data of large maps: 8x32-pixel x 128-channel tile,
+//                           the input halo of each 16-channel slab staged once in LDS for all 9 taps (dominant kernel, ~134 TF).
+//   wgrad3x3_halo_kernel    filter gradient of the same layers, all 9 taps fused over LDS-DMA-staged 1x32-pixel patches,
+//                           12 balanced wavefronts (~105 TF).
+//   igemm_fwd_kernel<...>   everything else that is forward-shaped (conv fwd / bwd_data of any size, stride, kernel; dense):
+//                           C[M x N] = A_gather[M x K] * B[K x N], M = pixels, N = Cout, K = (tap, ci).  A is gathered on the
+//                           fly from the NHWC input (no im2col buffer); B is the HWIO filter bank viewed as a row-major
+//                           [K x Cout] matrix -- exactly the reference's checkpoint layout.  Tap table + per-row validity
+//                           bitmask on the fast path, split-K when the grid cannot fill the chip, stride-2 backward-data
+//                           decomposed into its four output-parity classes.
+//   igemm_wgrad_kernel<...> every other filter / weight gradient: dW[K x N] = A_gather^T[K x M] * dY[M x N], split over M with a
+//                           fixed-order second-stage reduction (bit-reproducible), bias gradient fused.
 //
-// Tiling: 256-thread workgroups (4 wavefronts of 64), BMxBN output tile, each wavefront owns a
-// (BM/WM)x(BN/WN) sub-tile built from 32x32 MFMA blocks; K is consumed in 16-deep chunks staged
-// through double-buffered LDS (global -> registers issued before the MFMA block of the current
-// chunk, registers -> LDS after it, one barrier per chunk).  NHWC keeps ci contiguous, so every
-// global load is a 16-byte, 64-byte-per-row-segment coalesced access.
+// Common structure: 16-deep K chunks staged through double-buffered LDS (global -> registers issued before the MFMA block of
+// the current chunk, registers -> LDS after it, one barrier per chunk); NHWC keeps ci contiguous, so every global load is a
+// 16-byte access; padding lanes read a 16-byte zero buffer so loads stay unconditional.
 #include <cstdlib>
 #include "common.h"
 
