@@ -59,10 +59,13 @@ size_t ladder_igemm_fwd_workspace_bytes(long M, int K, int Cout);
 /* wT[KH-1-r][KW-1-s][co][ci] = w[r][s][ci][co]: the filter bank bwd_data consumes. */
 int ladder_filter_flip_transpose(const float* w, float* wT, int KH, int KW, int Cin, int Cout, ladder_stream_t stream);
 /* dx[n,hi,wi,ci] = sum dy[n,ho,wo,co] * w[r,s,ci,co] over {hi = ho*stride + r - pad_t, ...}; wT from above.
- * (N,H,W,Cin) describe dx, (Ho,Wo,Cout) describe dy. */
+ * (N,H,W,Cin) describe dx, (Ho,Wo,Cout) describe dy.  Optional gate (gate_y != NULL, same shape as dx): the result is
+ * multiplied by act'(gate_y) with gate_act in LADDER_ACT_*, i.e. the activation backward of the layer that PRODUCED this
+ * conv's input is fused into the epilogue (gate_y = that layer's activation output = this conv's forward input). */
 int ladder_conv2d_bwd_data(const float* dy, const float* wT, float* dx,
                            int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
                            int KH, int KW, int stride, int pad_t, int pad_l,
+                           const float* gate_y, int gate_act,
                            void* ws, size_t ws_bytes, ladder_stream_t stream);
 size_t ladder_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW);
 /* dw[r,s,ci,co] = sum_{n,ho,wo} x[...] * dy[n,ho,wo,co];  db[co] = sum dy, accumulated inside the same kernel
@@ -79,7 +82,7 @@ int ladder_dense_fwd(const float* x, const float* w, const float* bias, float* y
                      int M, int K, int N, int act, void* ws, size_t ws_bytes, ladder_stream_t stream);
 /* dx[M,K] = dy[M,N] @ w^T, wT = ladder_filter_flip_transpose(w, 1,1,K,N) i.e. [N,K]. */
 int ladder_dense_bwd_data(const float* dy, const float* wT, float* dx, int M, int K, int N,
-                          void* ws, size_t ws_bytes, ladder_stream_t stream);
+                          const float* gate_y, int gate_act, void* ws, size_t ws_bytes, ladder_stream_t stream);
 size_t ladder_dense_bwd_weight_workspace_bytes(int M, int K, int N);
 int ladder_dense_bwd_weight(const float* x, const float* dy, float* dw, float* db,
                             int M, int K, int N, void* ws, size_t ws_bytes, ladder_stream_t stream);

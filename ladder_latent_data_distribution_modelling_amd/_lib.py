@@ -42,11 +42,11 @@ PROTOTYPES = {
     "ladder_conv2d_fwd": (_i, [_p, _p, _p, _p] + [_i] * 13 + [_p, _z, _p]),
     "ladder_igemm_fwd_workspace_bytes": (_z, [C.c_long, _i, _i]),
     "ladder_filter_flip_transpose": (_i, [_p, _p, _i, _i, _i, _i, _p]),
-    "ladder_conv2d_bwd_data": (_i, [_p, _p, _p] + [_i] * 12 + [_p, _z, _p]),
+    "ladder_conv2d_bwd_data": (_i, [_p, _p, _p] + [_i] * 12 + [_p, _i, _p, _z, _p]),
     "ladder_conv2d_bwd_filter_workspace_bytes": (_z, [_i] * 9),
     "ladder_conv2d_bwd_filter": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p, _z, _p]),
     "ladder_dense_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
-    "ladder_dense_bwd_data": (_i, [_p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "ladder_dense_bwd_data": (_i, [_p, _p, _p, _i, _i, _i, _p, _i, _p, _z, _p]),
     "ladder_dense_bwd_weight_workspace_bytes": (_z, [_i, _i, _i]),
     "ladder_dense_bwd_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "ladder_act_bwd": (_i, [_p, _p, _p, _z, _i, _p]),

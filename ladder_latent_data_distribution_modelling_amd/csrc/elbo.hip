@@ -43,15 +43,17 @@ __global__ __launch_bounds__(256) void pixel_partials_stage1(const float* __rest
     ws[2 * blockIdx.x + 1] = tq;
   }
 }
-__global__ void pixel_partials_stage2(const double* __restrict__ ws, int nblk, float* __restrict__ out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double a = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-      a += ws[2 * b];
-      q += ws[2 * b + 1];
-    }
-    out[0] = (float)a;
-    out[1] = (float)q;
+__global__ __launch_bounds__(256) void pixel_partials_stage2(const double* __restrict__ ws, int nblk, float* __restrict__ out) {
+  double a = 0.0, q = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) {     // fixed assignment + fixed-order tree: deterministic
+    a += ws[2 * b];
+    q += ws[2 * b + 1];
+  }
+  __shared__ double sm[4];
+  const double ta = block_sum_256(a, sm), tq = block_sum_256(q, sm);
+  if (threadIdx.x == 0) {
+    out[0] = (float)ta;
+    out[1] = (float)tq;
   }
 }
 inline int pixel_nblk(size_t n) {
@@ -468,7 +470,7 @@ int ladder_pixel_partials(const float* x, const float* xhat, size_t n, float* ou
   const int nblk = pixel_nblk(n);
   if (ws_bytes < (size_t)nblk * 2 * sizeof(double)) return LADDER_E_WORKSPACE;
   hipLaunchKernelGGL(pixel_partials_stage1, dim3(nblk), dim3(256), 0, stream, x, xhat, n, (double*)ws);
-  hipLaunchKernelGGL(pixel_partials_stage2, dim3(1), dim3(64), 0, stream, (const double*)ws, nblk, out);
+  hipLaunchKernelGGL(pixel_partials_stage2, dim3(1), dim3(256), 0, stream, (const double*)ws, nblk, out);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

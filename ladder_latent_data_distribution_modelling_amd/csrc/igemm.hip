@@ -113,7 +113,8 @@ template <int BM, int BN, int WM, int WN, bool VECA, bool VECB>
 __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? IGEMM_FWD_MINW : IGEMM_MINW) void igemm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ y,
                                                              const IgemmDesc d, const int tiles_n, const bool fast,
-                                                             float* __restrict__ part, const int chunks_per_split) {
+                                                             float* __restrict__ part, const int chunks_per_split,
+                                                             const float* __restrict__ gate, const int gate_act) {
   constexpr int LDA = BK + 1;  // odd row stride: conflict-free ds_read_b32 of A fragments
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
   constexpr int A_UNITS = BM * (BK / 4), B_UNITS = BK * (BN / 4);
@@ -313,7 +314,11 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? IGEMM_FWD_MINW :
             const uint32_t ho = fdiv(rem, d.div_wo), wo = rem - ho * d.Wo;
             row = ((long)n_img * d.OH + d.out_h0 + (long)ho * d.out_sh) * d.OW + d.out_w0 + (long)wo * d.out_sw;
           }
-          y[row * d.Cout + n] = ladder_act_fn(acc[mi][ni][e] + bv, d.act);
+          float v = ladder_act_fn(acc[mi][ni][e] + bv, d.act);
+          // optional gate: multiply by act'(gate) evaluated from the producer layer's activation OUTPUT at the same element
+          // (fuses the previous layer's activation backward into this backward-data pass)
+          if (gate != nullptr) v *= ladder_act_grad_from_out(gate[row * d.Cout + n], gate_act);
+          y[row * d.Cout + n] = v;
         }
       }
     }
@@ -495,13 +500,15 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? IGEMM_WG_MINW : 
 }
 
 __global__ void splitk_epilogue_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ y,
-                                       int S, size_t MN, int N, int act) {
+                                       int S, size_t MN, int N, int act, const float* __restrict__ gate, int gate_act) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= MN) return;
   float s = 0.f;
   for (int z = 0; z < S; ++z) s += part[(size_t)z * MN + i];   // fixed order
   if (bias != nullptr) s += bias[i % N];
-  y[i] = ladder_act_fn(s, act);
+  s = ladder_act_fn(s, act);
+  if (gate != nullptr) s *= ladder_act_grad_from_out(gate[i], gate_act);
+  y[i] = s;
 }
 
 __global__ void reduce_splits_kernel(const float* __restrict__ ws, float* __restrict__ out, int S, size_t n) {
@@ -726,7 +733,7 @@ SplitPlan plan_splitk(long M, int K, int Cout, int bm, int bn) {
 
 template <int BM, int BN, int WM, int WN>
 int launch_fwd(const float* x, const float* w, const float* bias, float* y, const IgemmDesc& d, void* ws, size_t ws_bytes,
-               hipStream_t st) {
+               hipStream_t st, const float* gate = nullptr, int gate_act = 0) {
   const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.Cout + BN - 1) / BN;
   const bool veca = (d.Cin % BK) == 0, vecb = (d.Cout % 4) == 0;
   const bool fast = d.ntaps > 0;
@@ -736,14 +743,14 @@ int launch_fwd(const float* x, const float* w, const float* bias, float* y, cons
   if (sp.splits > 1 && (ws == nullptr || ws_bytes < need)) sp = SplitPlan{1, (d.K + BK - 1) / BK};
   float* part = sp.splits > 1 ? (float*)ws : nullptr;
   dim3 grid(tiles_m * tiles_n, sp.splits), block(kThreads);
-  if (veca && vecb) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, x, w, bias, y, d, tiles_n, fast, part, sp.cps);
-  else if (veca) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, st, x, w, bias, y, d, tiles_n, fast, part, sp.cps);
-  else if (vecb) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, st, x, w, bias, y, d, tiles_n, fast, part, sp.cps);
-  else hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, x, w, bias, y, d, tiles_n, fast, part, sp.cps);
+  if (veca && vecb) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, x, w, bias, y, d, tiles_n, fast, part, sp.cps, part ? nullptr : gate, gate_act);
+  else if (veca) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, st, x, w, bias, y, d, tiles_n, fast, part, sp.cps, part ? nullptr : gate, gate_act);
+  else if (vecb) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, st, x, w, bias, y, d, tiles_n, fast, part, sp.cps, part ? nullptr : gate, gate_act);
+  else hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, x, w, bias, y, d, tiles_n, fast, part, sp.cps, part ? nullptr : gate, gate_act);
   if (part != nullptr) {
     const size_t mn = (size_t)d.M * d.Cout;
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, (const float*)part, bias, y,
-                       sp.splits, mn, d.Cout, d.act);
+                       sp.splits, mn, d.Cout, d.act, gate, gate_act);
   }
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
@@ -762,16 +769,16 @@ int select_fwd_tile(long M, int Cout) {
 }
 
 int dispatch_fwd(const float* x, const float* w, const float* bias, float* y, const IgemmDesc& d, void* ws, size_t ws_bytes,
-                 hipStream_t st) {
+                 hipStream_t st, const float* gate = nullptr, int gate_act = 0) {
   if (d.M <= 0 || d.K <= 0 || d.Cout <= 0) return LADDER_E_SHAPE;
   if (!ladder_aligned16(x) || !ladder_aligned16(w) || !ladder_aligned16(y)) return LADDER_E_ALIGN;
-  if (halo_eligible(d)) return launch_halo(x, w, bias, y, d, st);
+  if (gate == nullptr && halo_eligible(d)) return launch_halo(x, w, bias, y, d, st);
   switch (select_fwd_tile(d.M, d.Cout)) {
-    case 128128: return launch_fwd<128, 128, 2, 2>(x, w, bias, y, d, ws, ws_bytes, st);
-    case 64064: return launch_fwd<64, 64, 2, 2>(x, w, bias, y, d, ws, ws_bytes, st);
-    case 32128: return launch_fwd<32, 128, 1, 4>(x, w, bias, y, d, ws, ws_bytes, st);
-    case 128064: return launch_fwd<128, 64, 4, 1>(x, w, bias, y, d, ws, ws_bytes, st);
-    default: return launch_fwd<128, 32, 4, 1>(x, w, bias, y, d, ws, ws_bytes, st);
+    case 128128: return launch_fwd<128, 128, 2, 2>(x, w, bias, y, d, ws, ws_bytes, st, gate, gate_act);
+    case 64064: return launch_fwd<64, 64, 2, 2>(x, w, bias, y, d, ws, ws_bytes, st, gate, gate_act);
+    case 32128: return launch_fwd<32, 128, 1, 4>(x, w, bias, y, d, ws, ws_bytes, st, gate, gate_act);
+    case 128064: return launch_fwd<128, 64, 4, 1>(x, w, bias, y, d, ws, ws_bytes, st, gate, gate_act);
+    default: return launch_fwd<128, 32, 4, 1>(x, w, bias, y, d, ws, ws_bytes, st, gate, gate_act);
   }
 }
 
@@ -797,6 +804,8 @@ WgradPlan plan_wgrad(long M, int K, int Cout) {
   const long max_s = (M + 255) / 256;              // at least 256 pixels (16 chunks) per split
   if (s > max_s) s = max_s;
   if (s * tiles > slots && s * tiles < 2 * slots) s = slots / tiles;   // avoid a partially filled second round
+  // the partial sums are written and re-read once: keep them <= ~48 MB (one round of the chip is enough for wide filters)
+  if (s * tiles > slots && (size_t)s * K * Cout * sizeof(float) > ((size_t)48 << 20)) s = slots / tiles > 0 ? slots / tiles : 1;
   if (s < 1) s = 1;
   if (s > 1024) s = 1024;
   long mps = (M + s - 1) / s;
@@ -1080,13 +1089,13 @@ int ladder_filter_flip_transpose(const float* w, float* wT, int KH, int KW, int 
 }
 
 int ladder_conv2d_bwd_data(const float* dy, const float* wT, float* dx, int N, int H, int W, int Cin, int Ho, int Wo,
-                           int Cout, int KH, int KW, int stride, int pad_t, int pad_l, void* ws, size_t ws_bytes,
-                           ladder_stream_t stream) {
+                           int Cout, int KH, int KW, int stride, int pad_t, int pad_l, const float* gate_y, int gate_act,
+                           void* ws, size_t ws_bytes, ladder_stream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return LADDER_E_SHAPE;
   // dx[hi] gathers dy[(hi + pad_t - r)/stride] = dy[(hi + r' - (KH-1-pad_t))/stride] with the flipped tap r'.
   IgemmDesc d{N, Ho, Wo, Cout, H, W, Cin, KH, KW, 1, stride, KH - 1 - pad_t, KW - 1 - pad_l, N * H * W, KH * KW * Cout, LADDER_ACT_NONE, make_fastdiv(H * W), make_fastdiv(W)};
   set_conv_taps(d);   // stride 1: full tap table; stride > 1: dense output mapping only (ntaps = 0 -> generic gather)
-  if (stride == 1) return dispatch_fwd(dy, wT, nullptr, dx, d, ws, ws_bytes, stream);
+  if (stride == 1) return dispatch_fwd(dy, wT, nullptr, dx, d, ws, ws_bytes, stream, gate_y, gate_act);
   if (stride == 2 && (Cout % BK) == 0 && KH * KW <= 28) {
     // Parity-class decomposition of the transposed convolution: output pixels with (hi, wi) parity (ch, cw) only ever see the
     // flipped taps r' = (pad' + ch) mod 2 (+2), so each class is a dense stride-1 gather over ~1/4 of the taps written to every
@@ -1113,14 +1122,14 @@ int ladder_conv2d_bwd_data(const float* dy, const float* wT, float* dx, int N, i
             ++c.ntaps;
           }
         }
-        if (c.ntaps == 0) return dispatch_fwd(dy, wT, nullptr, dx, d, ws, ws_bytes, stream);   // degenerate: legacy path writes the zeros
+        if (c.ntaps == 0) return dispatch_fwd(dy, wT, nullptr, dx, d, ws, ws_bytes, stream, gate_y, gate_act);   // degenerate: legacy path writes the zeros
         c.K = c.ntaps * Cout;
-        const int rc = dispatch_fwd(dy, wT, nullptr, dx, c, nullptr, 0, stream);
+        const int rc = dispatch_fwd(dy, wT, nullptr, dx, c, nullptr, 0, stream, gate_y, gate_act);
         if (rc != LADDER_OK) return rc;
       }
     return LADDER_OK;
   }
-  return dispatch_fwd(dy, wT, nullptr, dx, d, ws, ws_bytes, stream);   // generic strided gather (ups > 1)
+  return dispatch_fwd(dy, wT, nullptr, dx, d, ws, ws_bytes, stream, gate_y, gate_act);   // generic strided gather (ups > 1)
 }
 
 size_t ladder_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW) {
@@ -1144,11 +1153,11 @@ int ladder_dense_fwd(const float* x, const float* w, const float* bias, float* y
   return dispatch_fwd(x, w, bias, y, d, ws, ws_bytes, stream);
 }
 
-int ladder_dense_bwd_data(const float* dy, const float* wT, float* dx, int M, int K, int N, void* ws, size_t ws_bytes,
-                          ladder_stream_t stream) {
+int ladder_dense_bwd_data(const float* dy, const float* wT, float* dx, int M, int K, int N, const float* gate_y, int gate_act,
+                          void* ws, size_t ws_bytes, ladder_stream_t stream) {
   IgemmDesc d{M, 1, 1, N, 1, 1, K, 1, 1, 1, 1, 0, 0, M, N, LADDER_ACT_NONE, make_fastdiv(1), make_fastdiv(1)};
   set_conv_taps(d);
-  return dispatch_fwd(dy, wT, nullptr, dx, d, ws, ws_bytes, stream);
+  return dispatch_fwd(dy, wT, nullptr, dx, d, ws, ws_bytes, stream, gate_y, gate_act);
 }
 
 size_t ladder_dense_bwd_weight_workspace_bytes(int M, int K, int N) { return wgrad_ws_bytes(M, K, N); }

@@ -208,12 +208,15 @@ class Conv2D:
         self.x, self.y = x, y
         return y
 
-    def backward(self, dy, need_dx=True, wgrad=True):
+    def backward(self, dy, need_dx=True, wgrad=True, act_done=False, gate_prev=None):
+        """`act_done`: dy already carries this layer's activation derivative (fused into the consumer's epilogue).
+        `gate_prev`: activation name of the layer that produced this conv's input x: its derivative act'(x) is fused into
+        the backward-data epilogue, so that layer must then be called with act_done=True."""
         x, y = self.x, self.y
         N, H, W, _ = x.shape
         _, Ho, Wo, _ = y.shape
         st = self.ctx.stream
-        if self.act is not None:
+        if self.act is not None and not act_done:
             L.call("ladder_act_bwd", _p(dy), _p(y), _p(dy), dy.numel(), L.ACT[self.act], st)
         if wgrad:
             nb = L.query("ladder_conv2d_bwd_filter_workspace_bytes", N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k)
@@ -229,7 +232,7 @@ class Conv2D:
             dx = self.ctx.empty(N, H, W, self.cin)
             _igemm(self.ctx, "ladder_conv2d_bwd_data", N * H * W, self.cout, self.cin, self.k * self.k * self.cout,
                    _p(dy), _p(wT), _p(dx), N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k,
-                   self.stride, self.pt, self.pl,
+                   self.stride, self.pt, self.pl, _p(x) if gate_prev else None, L.ACT[gate_prev] if gate_prev else 0,
                    # a strided backward-data call is several parity-class launches: not attributed by the profiler
                    conv=(N, Ho, Wo, self.cout, H, W, self.cin, self.k, self.k, 1, 1, self.k - 1 - self.pt, self.k - 1 - self.pl)
                    if self.stride == 1 else "skip")
@@ -252,7 +255,7 @@ class Dense:
         self.x, self.y = x, y
         return y
 
-    def backward(self, dy, need_dx=True, wgrad=True, act_done=False):
+    def backward(self, dy, need_dx=True, wgrad=True, act_done=False, gate_prev=None):
         x, y, st = self.x, self.y, self.ctx.stream
         M = x.shape[0]
         if self.act is not None and not act_done:
@@ -268,7 +271,8 @@ class Dense:
             wT = self.ctx.empty(w.numel())
             L.call("ladder_filter_flip_transpose", _p(w), _p(wT), 1, 1, self.cin, self.cout, st)
             dx = self.ctx.empty(M, self.cin)
-            _igemm(self.ctx, "ladder_dense_bwd_data", M, self.cout, self.cin, self.cout, _p(dy), _p(wT), _p(dx), M, self.cin, self.cout)
+            _igemm(self.ctx, "ladder_dense_bwd_data", M, self.cout, self.cin, self.cout, _p(dy), _p(wT), _p(dx), M, self.cin, self.cout,
+                   _p(x) if gate_prev else None, L.ACT[gate_prev] if gate_prev else 0)
         self.x = self.y = None
         return dx
 
@@ -513,20 +517,26 @@ class CelebADecoder:
 
     def backward(self, dxhat, need_dz=True):
         ctx = self.ctx
-        dh = self.conv_out.backward(dxhat)
+        # the last 3x3 conv feeds conv_out directly (its resize is the identity at full resolution): its leaky-ReLU
+        # backward is fused into conv_out's backward-data epilogue (saves a read+write pass over the largest map)
+        last_conv, _, last_norm, last_rs = self.blocks[-1]
+        fuse_last = (last_norm is None and last_conv.act is not None
+                     and (last_rs is None or tuple(last_rs.in_shape[1:3]) == (last_rs.oh, last_rs.ow)))
+        dh = self.conv_out.backward(dxhat, gate_prev=last_conv.act if fuse_last else None)
         ddlat = None
-        for conv, sty, norm, rs in reversed(self.blocks):
+        for bi, (conv, sty, norm, rs) in enumerate(reversed(self.blocks)):
             if rs is not None:
                 dh = rs.backward(dh)
             if norm is not None:
                 dh, dstyle = norm.backward(dh)
                 g = sty.backward(dstyle)
                 ddlat = g if ddlat is None else add_(ctx, ddlat, g)
-            dh = conv.backward(dh)
+            dh = conv.backward(dh, act_done=(bi == 0 and fuse_last))
         dh = self.conv0.backward(self.up0.backward(dh))
         denc = dh.reshape(dh.shape[0], self.nh)
-        for lyr in reversed(self.mapping):
-            ddlat = lyr.backward(ddlat)
+        # mapping MLP: each layer's backward-data epilogue applies the previous layer's leaky-ReLU derivative
+        for i in range(len(self.mapping) - 1, -1, -1):
+            ddlat = self.mapping[i].backward(ddlat, act_done=(i < len(self.mapping) - 1), gate_prev="leaky_relu" if i > 0 else None)
         add_(ctx, denc, ddlat)
         return self.dense0.backward(denc, need_dx=need_dz)
 
@@ -560,16 +570,22 @@ class InnerVAE:
         return self.dec_out.forward(h)
 
     def decode_backward(self, dzhat, wgrad):
-        dh = self.dec_out.backward(dzhat, wgrad=wgrad)
-        for lyr in reversed(self.dec):
-            dh = lyr.backward(dh, wgrad=wgrad)
+        # every backward-data epilogue applies the activation derivative of the layer below it (its input)
+        a = self.dec[0].act
+        dh = self.dec_out.backward(dzhat, wgrad=wgrad, gate_prev=a)
+        for i in range(len(self.dec) - 1, -1, -1):
+            dh = self.dec[i].backward(dh, wgrad=wgrad, act_done=True, gate_prev=a if i > 0 else None)
         return dh
 
     def encode_backward(self, dmu, dsd_raw, wgrad, need_dz):
         dh = self.head_mu.backward(dmu, wgrad=wgrad)
         add_(self.ctx, dh, self.head_sd.backward(dsd_raw, wgrad=wgrad, act_done=True))
+        a = self.enc[0].act
         for i in range(len(self.enc) - 1, -1, -1):
-            dh = self.enc[i].backward(dh, need_dx=(need_dz or i > 0), wgrad=wgrad)
+            # the head gradients were summed with a separate add, so the top hidden layer applies its own activation
+            # derivative; below it each backward-data epilogue carries the derivative of the layer underneath
+            dh = self.enc[i].backward(dh, need_dx=(need_dz or i > 0), wgrad=wgrad, act_done=(i < len(self.enc) - 1),
+                                      gate_prev=a if i > 0 else None)
         return dh
 
 

@@ -111,8 +111,12 @@ def test_conv2d_fwd_bwd(gpu_ctx, case):
     L.call("ladder_filter_flip_transpose", p(wd), p(wT), k, k, Cin, Cout, st)
     dx = torch.empty_like(xd)
     dws = torch.empty(max(L.query("ladder_igemm_fwd_workspace_bytes", N * H * W, k * k * Cout, Cin), 16), dtype=torch.uint8, device="cuda")
-    L.call("ladder_conv2d_bwd_data", p(dyd), p(wT), p(dx), N, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, p(dws), dws.numel(), st)
+    L.call("ladder_conv2d_bwd_data", p(dyd), p(wT), p(dx), N, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, None, 0, p(dws), dws.numel(), st)
     close(dx, xt.grad, 3e-5, "dx")
+    # gated epilogue: dx * leaky'(gate) with the conv input as gate (what the engine fuses for the producer layer)
+    dxg = torch.empty_like(xd)
+    L.call("ladder_conv2d_bwd_data", p(dyd), p(wT), p(dxg), N, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, p(xd), 1, p(dws), dws.numel(), st)
+    assert torch.equal(dxg, dx * torch.where(xd > 0, 1.0, 0.2))
     # db == NULL is allowed (conv feeding a norm layer): dw must be unaffected
     dw2 = torch.empty_like(wd)
     L.call("ladder_conv2d_bwd_filter", p(xd), p(dyd), p(dw2), None, N, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, wsp, wsn, st)
@@ -148,7 +152,10 @@ def test_dense_fwd_bwd(gpu_ctx, M, K, N, act):
     L.call("ladder_filter_flip_transpose", p(wd), p(wT), 1, 1, K, N, st)
     dx = torch.empty_like(xd)
     bws = torch.empty(max(L.query("ladder_igemm_fwd_workspace_bytes", M, N, K), 16), dtype=torch.uint8, device="cuda")
-    L.call("ladder_dense_bwd_data", p(dyd), p(wT), p(dx), M, K, N, p(bws), bws.numel(), st)
+    L.call("ladder_dense_bwd_data", p(dyd), p(wT), p(dx), M, K, N, None, 0, p(bws), bws.numel(), st)
+    dxg = torch.empty_like(xd)
+    L.call("ladder_dense_bwd_data", p(dyd), p(wT), p(dxg), M, K, N, p(xd), 2, p(bws), bws.numel(), st)      # relu gate
+    assert torch.equal(dxg, dx * (xd > 0))
     close(dx, xt.grad, 3e-5, "dx")
 
 
