@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (default: config batch_size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--graphs", type=int, default=-1,
+                    help="1: replay each run as a captured hipGraph (per-kernel HIP-event profile then comes from a second, eager "
+                         "pass after the timed region); 0: eager launches; default: config key use_hip_graphs")
     args = ap.parse_args()
 
     import numpy as np
@@ -92,7 +95,10 @@ def main():
     import io
     with contextlib.redirect_stdout(io.StringIO()):
         model = Model(cfg, device="cuda:%d" % local, seed=1)
+    if args.graphs >= 0:
+        cfg["use_hip_graphs"] = args.graphs
     trainer = BaseTrain_joint(None, model, None, cfg)
+    graphs = trainer.engine.use_graphs and world == 1
     trainer.cur_epoch = int(cfg["sg_pretraining"]) + 1          # post-pretraining regime: all four runs active
     fix = np.load(os.path.join(ROOT, "tests", "golden", "GM_prior_info.npz"))
     K, R = int(cfg["n_mixtures"]), int(cfg["representation_size"])
@@ -118,9 +124,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if graphs:                                                  # set-up, not warm-up: capture the four run graphs first
+        for _ in range(8):
+            step()
+        assert len(trainer.engine._graphs) >= 4, "hipGraph capture did not settle"
     for _ in range(args.warmup):
         step()
-    if not args.no_profile:
+    if not args.no_profile and not graphs:
         E.PROF = E.KernelProfiler()
     barrier()
     t0 = time.perf_counter()
@@ -128,6 +138,12 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    if graphs and not args.no_profile:                         # per-kernel HIP events need individual launches: eager pass, untimed
+        trainer.engine.use_graphs = False
+        E.PROF = E.KernelProfiler()
+        for _ in range(args.steps):
+            step()
+        barrier()
     prof = E.PROF.summary() if E.PROF is not None else None
     E.PROF = None
     tdt = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -147,6 +163,7 @@ def main():
                                    cfg["exp_name"], cfg["dim_input_x"], cfg["dim_input_y"], cfg["dim_input_channel"],
                                    cfg["num_hidden_units"], cfg["code_size"], R, K, cfg["n_MC_samples"], B),
                    "global_batch": B * world, "parallelism": "dp%d" % world},
+        "launch": "hipGraph replay (4 graphs/iteration)" if graphs else "eager",
         "elbo": f["elbo"], "elbo_prior": trainer.last_fetch_prior["elbo_prior"],
     }
     if prof:

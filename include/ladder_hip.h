@@ -223,6 +223,15 @@ int ladder_latent_bwd(const float* g_sample, const float* mu, const float* sd, c
 int ladder_adam_clip(float* theta, const float* g, float* m, float* v, size_t n,
                      float lr_t, float beta1, float beta2, float eps, float clip, ladder_stream_t stream);
 
+/* hipGraph-friendly variants: every per-step scalar lives in DEVICE memory, so a captured run can be replayed verbatim.
+ *   state = {float lr, float lr_t, int step}: the call first bumps `step` and refreshes lr_t = lr*sqrt(1-b2^t)/(1-b1^t) on
+ *   the device, then applies clip+Adam with it.  The host only rewrites state[0] when the learning rate changes. */
+int ladder_adam_clip_dev(float* theta, const float* g, float* m, float* v, size_t n, float* state,
+                         float beta1, float beta2, float eps, float clip, ladder_stream_t stream);
+/* Philox stream position = *offset_base + offset_add (offset_base: device counter advanced by ladder_u64_add). */
+int ladder_randn_dev(float* out, size_t n, uint64_t seed, const uint64_t* offset_base, uint64_t offset_add, ladder_stream_t stream);
+int ladder_u64_add(uint64_t* p, uint64_t inc, ladder_stream_t stream);
+
 /* ---------------------------------------------------------------- helpers */
 size_t ladder_colstats_workspace_bytes(size_t rows, int C);
 /* out[i] (+)= scale * in[i]. accumulate!=0 adds into out. */

@@ -76,6 +76,9 @@ PROTOTYPES = {
     "ladder_code_grad": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _p]),
     "ladder_latent_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _i, _p, _p, _i, _i, _p]),
     "ladder_adam_clip": (_i, [_p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _p]),
+    "ladder_adam_clip_dev": (_i, [_p, _p, _p, _p, _z, _p, _f, _f, _f, _f, _p]),
+    "ladder_randn_dev": (_i, [_p, _z, _u64, _p, _u64, _p]),
+    "ladder_u64_add": (_i, [_p, _u64, _p]),
     "ladder_axpy": (_i, [_p, _p, _z, _f, _i, _p]),
     "ladder_colstats_workspace_bytes": (_z, [_z, _i]),
     "ladder_colsum": (_i, [_p, _p, _z, _i, _p, _z, _p]),

@@ -15,6 +15,8 @@ class BaseTrain:
     def __init__(self, sess, model, data, config):
         self.model, self.config, self.sess, self.data = model, config, sess, data
         self.engine = model.engine
+        # replay each run as one captured hipGraph after two eager warm-ups (config key `use_hip_graphs`, default on)
+        self.engine.use_graphs = bool(int(config.get("use_hip_graphs", 1)))
         self.cur_epoch = 0
         # same record lists as codes/base.py:531-570
         for name in ("train_loss train_loss_prior val_loss val_loss_prior train_loss_ave_epoch val_loss_ave_epoch elbo_train "

@@ -425,6 +425,32 @@ __global__ void adam_clip_kernel(float* __restrict__ theta, const float* __restr
   }
 }
 
+// Device-resident optimiser state {lr, lr_t, step}: lets a captured hipGraph replay the step without re-baking host scalars.
+__global__ void adam_prepare_kernel(float* __restrict__ state, float b1, float b2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int* step = reinterpret_cast<int*>(state + 2);
+  const int t = *step + 1;
+  *step = t;
+  state[1] = (float)((double)state[0] * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+}
+__global__ void adam_clip_dev_kernel(float* __restrict__ theta, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                     size_t n, const float* __restrict__ state, float b1, float b2, float eps, float clip) {
+  const float lr_t = state[1];
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float gi = g[i];
+    gi = fminf(fmaxf(gi, -clip), clip);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    theta[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+__global__ void u64_add_kernel(unsigned long long* __restrict__ p, unsigned long long inc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *p += inc;
+}
+
 // ----------------------------------------------------------------------------- Philox4x32-10 normals
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
   const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
@@ -432,9 +458,11 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint
   const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
   c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
-__global__ void randn_kernel(float* __restrict__ out, size_t n, uint64_t seed, uint64_t offset) {
+__global__ void randn_kernel(float* __restrict__ out, size_t n, uint64_t seed, uint64_t offset,
+                             const unsigned long long* __restrict__ offset_base) {
   const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // 4 normals per thread
   if (q * 4 >= n) return;
+  if (offset_base != nullptr) offset += *offset_base;                // device-resident stream position (graph replay)
   uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
@@ -575,7 +603,36 @@ int ladder_adam_clip(float* theta, const float* g, float* m, float* v, size_t n,
 int ladder_randn(float* out, size_t n, uint64_t seed, uint64_t offset, ladder_stream_t stream) {
   if (n == 0) return LADDER_OK;
   const size_t q = (n + 3) / 4;
-  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, stream, out, n, seed, offset);
+  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, stream, out, n, seed, offset,
+                     (const unsigned long long*)nullptr);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_randn_dev(float* out, size_t n, uint64_t seed, const uint64_t* offset_base, uint64_t offset_add, ladder_stream_t stream) {
+  if (n == 0) return LADDER_OK;
+  if (offset_base == nullptr) return LADDER_E_SHAPE;
+  const size_t q = (n + 3) / 4;
+  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, stream, out, n, seed, offset_add,
+                     (const unsigned long long*)offset_base);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_u64_add(uint64_t* p, uint64_t inc, ladder_stream_t stream) {
+  hipLaunchKernelGGL(u64_add_kernel, dim3(1), dim3(64), 0, stream, (unsigned long long*)p, (unsigned long long)inc);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_adam_clip_dev(float* theta, const float* g, float* m, float* v, size_t n, float* state, float beta1, float beta2,
+                         float eps, float clip, ladder_stream_t stream) {
+  if (n == 0 || state == nullptr) return LADDER_E_SHAPE;
+  hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, stream, state, beta1, beta2);
+  size_t gr = (n + 255) / 256;
+  if (gr > 2048) gr = 2048;
+  hipLaunchKernelGGL(adam_clip_dev_kernel, dim3((unsigned)gr), dim3(256), 0, stream, theta, g, m, v, n, (const float*)state, beta1, beta2,
+                     eps, clip);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

@@ -150,7 +150,10 @@ class ParamStore:
         self.grad = {g: ctx.zeros(n) for g, n in sizes.items()}
         self.m = {g: ctx.zeros(n) for g, n in sizes.items()}
         self.v = {g: ctx.zeros(n) for g, n in sizes.items()}
-        self.step = {g: 0 for g in sizes}
+        self.step = {g: 0 for g in sizes}                       # host mirror of the per-optimiser step counters
+        # device-resident optimiser state {lr, lr_t, step}: a captured hipGraph replays the step without host scalars
+        self.adam_state = {g: ctx.zeros(4) for g in sizes}
+        self._lr_host = {g: None for g in sizes}
         self.w, self.g = {}, {}
         for name, shp in self.specs.items():
             g, off, n = self.offsets[name]
@@ -174,15 +177,22 @@ class ParamStore:
     def num_params(self, prefix):
         return sum(self.offsets[n][2] for n in self.specs if n.startswith(prefix))
 
+    def set_lr(self, group, lr):
+        """Write the learning rate into the device state (only when it changed; never inside a graph capture)."""
+        if self._lr_host[group] != lr:
+            self.adam_state[group][0:1].fill_(float(lr))
+            self._lr_host[group] = lr
+
     def adam(self, group, lr, grad=None, n=None):
-        """clip to [-1,1] + TF-form Adam on the whole group (codes/base.py:459-517).  `grad` may be a
-        device pointer into the scalars vector (n = 1) for the two scalar optimisers."""
+        """clip to [-1,1] + TF-form Adam on the whole group (codes/base.py:459-517); lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is
+        evaluated on the device from the device step counter.  `grad` may be a device pointer into the scalars vector
+        (n = 1) for the two scalar optimisers."""
+        self.set_lr(group, lr)
         self.step[group] += 1
-        t = self.step[group]
-        lr_t = lr * math.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
         g = self.grad[group] if grad is None else grad
-        L.call("ladder_adam_clip", _p(self.theta[group]), _p(g), _p(self.m[group]), _p(self.v[group]),
-               self.theta[group].numel() if n is None else n, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, 1.0, self.ctx.stream)
+        L.call("ladder_adam_clip_dev", _p(self.theta[group]), _p(g), _p(self.m[group]), _p(self.v[group]),
+               self.theta[group].numel() if n is None else n, _p(self.adam_state[group]), ADAM_B1, ADAM_B2, ADAM_EPS, 1.0,
+               self.ctx.stream)
 
 
 # ------------------------------------------------------------------------------------------ layers
@@ -618,8 +628,12 @@ class LadderEngine:
         self.lvp = float(cfg["latent_variance_precision"])
         self.partials = self.ctx.zeros(L.P_FIXED + self.Z + self.R)
         self.scalars = self.ctx.zeros(L.S_COUNT)
-        self.noise_seed, self.noise_offset = int(noise_seed) + 7919 * self.ctx.comm.rank, 0
+        self.noise_seed = int(noise_seed) + 7919 * self.ctx.comm.rank
+        self.rng_counter = torch.zeros(1, dtype=torch.int64, device=self.ctx.device)   # Philox stream position (device)
+        self._run_calls = 0
         self._gm_packed = None
+        self.use_graphs = False
+        self._graphs, self._warm = {}, {}
 
     # -- inputs ---------------------------------------------------------------------------------
     def _dev(self, a):
@@ -631,8 +645,8 @@ class LadderEngine:
 
     def _randn(self, *shape):
         t = self.ctx.empty(*shape)
-        L.call("ladder_randn", _p(t), t.numel(), self.noise_seed, self.noise_offset, self.ctx.stream)
-        self.noise_offset += 1
+        L.call("ladder_randn_dev", _p(t), t.numel(), self.noise_seed, _p(self.rng_counter), self._run_calls, self.ctx.stream)
+        self._run_calls += 1
         return t
 
     def _noise(self, noise, key, shape):
@@ -648,9 +662,11 @@ class LadderEngine:
         w, m, c = self._dev(weights), self._dev(means), self._dev(covs)
         assert tuple(w.shape) == (K,) and tuple(m.shape) == (K, R) and tuple(c.shape) == (K, R, R)
         stride = L.query("ladder_gmm_packed_stride", R)
-        packed = self.ctx.empty(K * stride)
-        L.call("ladder_gmm_prepare", _p(w), _p(m), _p(c), K, R, _p(packed), self.ctx.stream)
-        self._gm_packed = packed
+        if getattr(self, "_gm_buf", None) is None:
+            self._gm_buf = self.ctx.empty(K * stride)       # persistent: captured graphs keep pointing at the current mixture
+        L.call("ladder_gmm_prepare", _p(w), _p(m), _p(c), K, R, _p(self._gm_buf), self.ctx.stream)
+        torch.cuda.current_stream(self.ctx.device).synchronize()   # w, m, c are temporaries: keep them alive until the kernel ran
+        self._gm_packed = self._gm_buf
 
     def set_sg_mixture(self):
         """The dummy N(0,I) mixture of the SG-pretraining feed (codes/base.py:870-876)."""
@@ -668,6 +684,7 @@ class LadderEngine:
         Z, R = self.Z, self.R
         P = self.partials
         P.zero_()
+        self._run_calls = 0
         cache = getattr(self, "_enc_cache", None)
         if reuse_encoder and cache is not None and cache[0] == self.ps.step["ae"] and not self._enc_needs_grad(parts):
             _, x, mu, sd_raw = cache
@@ -720,6 +737,8 @@ class LadderEngine:
                                float(self.cfg.get("inner_sigma_lb", 0.0)), float(self.cfg.get("inner_sigma_ub", 0.0)))
         L.call("ladder_elbo_finalize", _p(P), _p(self.ps.w["sigma/Variable"]),
                _p(self.ps.w["inner_sigma/Variable"]) if self.has_inner else None, ecfg, _p(self.scalars), st)
+        if self._run_calls:
+            L.call("ladder_u64_add", _p(self.rng_counter), self._run_calls, st)      # advance the device noise stream
         self.use_sg, self.use_mask = use_sg, use_mask
 
     @staticmethod
@@ -778,7 +797,7 @@ class LadderEngine:
         self.inner.encode_backward(dmu_t, dsdraw_t, wgrad=True, need_dz=False)
 
     # -- the four runs --------------------------------------------------------------------------
-    def run_ae(self, x, lr, noise=None, use_sg=True, use_mask=False):
+    def _ae(self, x, lr, noise, use_sg, use_mask, reuse_encoder=False):
         # in the SG regime the inner VAE does not enter loss_ae's gradient (tf.cond, base.py:318-320) nor its fetches
         parts = ("dec",) if (use_sg or not self.has_inner) else ("dec", "inner", "gmm")
         self.forward(x, noise, use_sg, use_mask, parts)
@@ -786,19 +805,74 @@ class LadderEngine:
         self.ctx.comm.allreduce_(self.ps.grad["ae"])              # C1 (sum of per-rank grads of the global-mean loss)
         self.ps.adam("ae", lr)
 
-    def run_sigma(self, x, lr, noise=None, use_sg=True, use_mask=False, reuse_encoder=False):
+    def _sigma(self, x, lr, noise, use_sg, use_mask, reuse_encoder=False):
         self.forward(x, noise, use_sg, use_mask, ("dec",), reuse_encoder)
         self.ps.adam("sigma", lr, grad=self._sc("_g_sigma_var"), n=1)
 
-    def run_prior(self, x, lr, noise=None, use_sg=True, use_mask=False, reuse_encoder=False):
+    def _prior(self, x, lr, noise, use_sg, use_mask, reuse_encoder=False):
         self.forward(x, noise, use_sg, use_mask, ("inner", "gmm"), reuse_encoder)
         self._backward_prior()
         self.ctx.comm.allreduce_(self.ps.grad["prior"])           # C4
         self.ps.adam("prior", lr)
 
-    def run_inner_sigma(self, x, lr, noise=None, use_sg=True, use_mask=False, reuse_encoder=False):
+    def _inner_sigma(self, x, lr, noise, use_sg, use_mask, reuse_encoder=False):
         self.forward(x, noise, use_sg, use_mask, ("inner",), reuse_encoder)
         self.ps.adam("inner_sigma", lr, grad=self._sc("_g_inner_sigma_var"), n=1)
+
+    _GROUP = {"ae": "ae", "sigma": "sigma", "prior": "prior", "inner_sigma": "inner_sigma"}
+    _SNAP = ("x", "B", "Bg", "lat_z", "lat_t", "xhat", "zhat", "gmm_grads", "use_sg", "use_mask")
+
+    def _run(self, kind, x, lr, noise, use_sg, use_mask, reuse_encoder):
+        """Eager, or -- with `use_graphs` -- one captured hipGraph per (run kind, regime, batch shape): after two eager
+        warm-up calls the run's ~10^2..10^3 launches are replayed as a single graph launch.  Every per-step scalar (Adam step /
+        lr_t, noise stream position) lives in device memory, so a replay is exactly the eager run."""
+        fn = getattr(self, "_" + kind)
+        if not self.use_graphs or noise is not None or self.ctx.comm.on:
+            return fn(x, lr, noise, use_sg, use_mask, reuse_encoder)
+        group = self._GROUP[kind]
+        xin = self._dev(x)
+        cache = getattr(self, "_enc_cache", None)
+        reuse = bool(reuse_encoder and cache is not None and cache[0] == self.ps.step["ae"])
+        key = (kind, bool(use_sg), bool(use_mask), tuple(xin.shape), cache[2].data_ptr() if reuse else 0, self._gm_packed.data_ptr()
+               if self._gm_packed is not None else 0)
+        ent = self._graphs.get(key)
+        if ent is None:
+            if self._warm.get(key, 0) < 2:                         # eager warm-up: sizes the workspace and the allocator
+                self._warm[key] = self._warm.get(key, 0) + 1
+                return fn(xin, lr, None, use_sg, use_mask, reuse_encoder)
+            static_x = cache[1] if reuse else xin.clone()
+            self.ps.set_lr(group, lr)
+            steps, calls = dict(self.ps.step), self._run_calls
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):                          # records the launches; nothing executes, host counters restored
+                fn(static_x, lr, None, use_sg, use_mask, reuse_encoder)
+            snap = {k: getattr(self, k, None) for k in self._SNAP}
+            enc = None if reuse else self._enc_cache[1:]
+            self.ps.step, self._run_calls = steps, calls
+            ent = self._graphs[key] = (graph, static_x, snap, enc)
+        graph, static_x, snap, enc = ent
+        if not reuse and static_x.data_ptr() != xin.data_ptr():
+            static_x.copy_(xin)
+        self.ps.set_lr(group, lr)
+        if enc is not None:
+            self._enc_cache = (self.ps.step["ae"],) + tuple(enc)   # as the eager forward does (pre-update step)
+        graph.replay()
+        self.ps.step[group] += 1
+        for k, v in snap.items():
+            setattr(self, k, v)
+
+    def run_ae(self, x, lr, noise=None, use_sg=True, use_mask=False):
+        self._run("ae", x, lr, noise, use_sg, use_mask, False)
+
+    def run_sigma(self, x, lr, noise=None, use_sg=True, use_mask=False, reuse_encoder=False):
+        self._run("sigma", x, lr, noise, use_sg, use_mask, reuse_encoder)
+
+    def run_prior(self, x, lr, noise=None, use_sg=True, use_mask=False, reuse_encoder=False):
+        self._run("prior", x, lr, noise, use_sg, use_mask, reuse_encoder)
+
+    def run_inner_sigma(self, x, lr, noise=None, use_sg=True, use_mask=False, reuse_encoder=False):
+        self._run("inner_sigma", x, lr, noise, use_sg, use_mask, reuse_encoder)
 
     def evaluate(self, x, noise=None, use_sg=True, use_mask=False):
         parts = ("dec", "inner", "gmm") if (self.has_inner and self._gm_packed is not None) else ("dec", "inner")
