@@ -181,6 +181,21 @@ def main():
                            "share_of_step_time": round(dom["total_ms"] / (1e3 * dt), 3),
                            "other_kernels": [{"kernel": r["kernel"], "achieved": round(r["tflops"], 2), "launches": r["launches"],
                                               "avg_launch_ms": round(r["avg_ms"], 4)} for r in prof.values() if r is not dom]}
+    # also the AE-step-only (RUN#1) and forward-only (val_step, VAE fetches) rates; untimed extras after the metric
+    def rate(fn, n=max(3, args.steps // 2)):
+        fn()
+        barrier()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return round(B * world * n / float(t.item()), 2)
+    use_sg, use_mask = trainer.compute_feeddict(x, "VAE")
+    out["ae_step_only_images_per_sec"] = rate(lambda: (trainer.engine.run_ae(x, lr, None, use_sg, use_mask), trainer.engine.fetch()))
+    out["forward_only_images_per_sec"] = rate(lambda: trainer.val_step("VAE", x))
     whole = FWD_FLOP_PER_IMG.get(cfg["exp_name"])
     if whole and int(cfg["num_hidden_units"]) == 512 and int(cfg["code_size"]) == 64:
         out["whole_step_tflops_per_gpu"] = round(whole * value / world / 1e12, 2)

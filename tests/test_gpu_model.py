@@ -394,3 +394,35 @@ def test_hip_graph_replay_equals_eager(golden_dir, exp):
     for k in pa:
         assert np.array_equal(pa[k], pb[k]), k
     assert engs[0].ps.step == engs[1].ps.step
+
+
+def test_two_rung_r8_k50_vs_oracle(golden_dir):
+    """BASELINE.json configs[4]'s hyper-prior shape (representation_size 8, K=50 full-covariance components, L MC samples) on the
+    tiny CelebA net: the RUN#1 and RUN#3 fetches and the prior-group gradients against the float64 oracle.  This is the
+    `gmm_logprob_kernel<8>` instantiation inside the real training graph."""
+    d = np.load(os.path.join(golden_dir, "oracle_celeba.npz"))
+    cfg = json.loads(str(d["config"]))
+    cfg.update(representation_size=8, n_mixtures=50)
+    B = cfg["batch_size"]
+    rng = np.random.default_rng(29)
+    x = rng.random(d["x"].shape).astype(np.float32)
+    P = O.init_params(cfg, seed=8)
+    gm = {k: v.astype(np.float32) for k, v in O.synthetic_gm(cfg).items()}
+    noise = O.make_noise(cfg, B, rng, np.float32)
+    st = O.OracleState(cfg, P, np.float64)
+    eng = _engine(cfg, values=P)
+    eng.set_mixture(gm["weights"], gm["means"], gm["covs"])
+    ref = O.run(st, x, noise, gm, False, False, train="ae", lr=0.0)
+    eng.run_ae(x, 0.0, noise, False, False)
+    f = eng.fetch()
+    for k in SCALARS_RUN1:
+        assert _ok(f[k], float(ref[k]), 5e-5), (k, f[k], float(ref[k]))
+    ref = O.run(st, x, noise, gm, False, False, train="prior", lr=0.0)
+    eng.run_prior(x, 0.0, noise, False, False)
+    f = eng.fetch()
+    for k in SCALARS_RUN3:
+        assert _ok(f[k], float(ref[k]), 5e-5), (k, f[k], float(ref[k]))
+    for name, g in ref["_grads"].items():
+        got = eng.ps.g[name].cpu().numpy().reshape(g.shape).astype(np.float64)
+        scale = np.abs(g).max()
+        assert np.abs(got - g).max() < 5e-4 * max(scale, 1e-9), (name, np.abs(got - g).max(), scale)
