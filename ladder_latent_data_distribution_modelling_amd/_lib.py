@@ -79,6 +79,7 @@ PROTOTYPES = {
     "ladder_adam_clip_dev": (_i, [_p, _p, _p, _p, _z, _p, _f, _f, _f, _f, _p]),
     "ladder_randn_dev": (_i, [_p, _z, _u64, _p, _u64, _p]),
     "ladder_u64_add": (_i, [_p, _u64, _p]),
+    "ladder_crc32c_extend": (C.c_uint32, [C.c_uint32, _p, _z]),
     "ladder_axpy": (_i, [_p, _p, _z, _f, _i, _p]),
     "ladder_colstats_workspace_bytes": (_z, [_z, _i]),
     "ladder_colsum": (_i, [_p, _p, _z, _i, _p, _z, _p]),

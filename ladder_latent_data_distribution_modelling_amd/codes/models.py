@@ -39,14 +39,23 @@ class BaseModel:
                 weight_concentration_prior_type="dirichlet_distribution", weight_concentration_prior=0.1, warm_start=True)
 
     # codes/base.py:37-85 -- two savers: vae-model (encoder+decoder+sigma), prior-model (prior/* + inner sigma).
-    # Adam slots / epoch counter are not saved by the reference either.  Format: npz keyed by TF variable name.
+    # Adam slots / epoch counter are not saved by the reference either.  Format: the reference's own -- a TensorFlow
+    # checkpoint-v2 bundle (<prefix>.index/.data-00000-of-00001/.meta + `checkpoint`) keyed by the TF variable names, written
+    # and read by codes/tf_bundle.py without TensorFlow, so checkpoints are interchangeable with the reference in both
+    # directions.  config["checkpoint_format"] = "npz" selects a plain numpy archive instead.
     def init_saver(self):
         self.saver_path_ae = os.path.join(self.config.get("checkpoint_dir", "."), "vae-model")
         self.saver_path_prior = os.path.join(self.config.get("checkpoint_dir", "."), "prior-model")
 
     def _save(self, path, groups):
-        if self.engine.ctx.comm.rank == 0:
-            np.savez(path + ".npz", **self.engine.ps.to_dict(groups))
+        if self.engine.ctx.comm.rank != 0:
+            return
+        tensors = self.engine.ps.to_dict(groups)
+        if self.config.get("checkpoint_format", "tf_bundle") == "npz":
+            np.savez(path + ".npz", **tensors)
+        else:
+            from . import tf_bundle
+            tf_bundle.save_checkpoint(path, tensors)
 
     def save(self, sess, model):
         print("Saving model...")
@@ -59,14 +68,29 @@ class BaseModel:
             print("Prior model saved.")
 
     def load(self, sess, model):
+        """Restores like saver.restore: every variable of the saver's list must be in the checkpoint with its shape
+        (a mismatch raises, as TF's restore does); a missing checkpoint only prints (base.py:66-85)."""
         print("\ncheckpoint_dir to be loaded:\n{}\n".format(self.config.get("checkpoint_dir")))
-        path = (self.saver_path_ae if model == "VAE" else self.saver_path_prior) + ".npz"
+        path = self.saver_path_ae if model == "VAE" else self.saver_path_prior
+        groups = ("ae", "sigma") if model == "VAE" else ("prior", "inner_sigma")
         label = "Outer VAE" if model == "VAE" else "Prior"
-        if os.path.isfile(path):
-            self.engine.ps.load_dict(dict(np.load(path)), strict=False)
-            print("%s model loaded." % label)
+        if os.path.isfile(path + ".index"):          # (the reference tests for the .meta file; the .index is what restore reads)
+            from . import tf_bundle
+            values = tf_bundle.load_checkpoint(path)
+        elif os.path.isfile(path + ".npz"):
+            values = dict(np.load(path + ".npz"))
         else:
             print("No %s model found. No %s model loaded." % (label.lower(), "VAE" if model == "VAE" else "prior"))
+            return
+        ps = self.engine.ps
+        want = {n: tuple(ps.specs[n]) for n in ps.specs if arch.group_of(n) in groups}
+        for n, shp in want.items():
+            if n not in values:
+                raise KeyError("checkpoint %s has no variable %s" % (path, n))
+            if tuple(values[n].shape) != shp and values[n].size != int(np.prod(shp, dtype=np.int64)):
+                raise ValueError("checkpoint %s: %s has shape %s, the model needs %s" % (path, n, values[n].shape, shp))
+        ps.load_dict({n: values[n] for n in want}, strict=False)
+        print("%s model loaded." % label)
 
     @staticmethod
     def ClipIfNotNone(grad):

@@ -197,7 +197,16 @@ def test_trainer_epoch_synthetic(tmp_path):
     for k in ("train_loss", "elbo_train", "val_loss", "code_elbo_train", "sigma"):
         assert k in res.files
     assert np.isfinite(res["elbo_train"]).all() and len(res["elbo_train"]) == 2 * tr.n_train_iter
-    assert os.path.isfile(os.path.join(str(tmp_path), "vae-model.npz")) and os.path.isfile(os.path.join(str(tmp_path), "GM_prior_info.npz"))
+    assert os.path.isfile(os.path.join(str(tmp_path), "GM_prior_info.npz"))
+    # checkpoints in the reference's own format (tf.train.Saver checkpoint-v2 bundle), restorable into a fresh model
+    for f in ("vae-model.index", "vae-model.data-00000-of-00001", "vae-model.meta", "prior-model.index", "checkpoint"):
+        assert os.path.isfile(os.path.join(str(tmp_path), f)), f
+    fresh = MNISTModel_digit(cfg, seed=77)
+    assert not np.array_equal(fresh.engine.ps.to_dict()["decoder/conv2d/kernel"], model.engine.ps.to_dict()["decoder/conv2d/kernel"])
+    fresh.load(None, "VAE")
+    fresh.load(None, "prior")
+    a, b = fresh.engine.ps.to_dict(), model.engine.ps.to_dict()
+    assert all(np.array_equal(a[k], b[k]) for k in b)
     # losses should not blow up and the ELBO should improve over training on a fixed data set
     assert np.mean(res["elbo_train"][-2:]) > np.mean(res["elbo_train"][:2])
 

@@ -204,3 +204,79 @@ dist.destroy_process_group()
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("COMM_OK" in o for o in outs)
+
+
+# ------------------------------------------------------------------------------------------------ TF checkpoint-v2 bundles
+REF_INDEX = [(m, ck) for m in ("celeba", "mnist_digit", "mnist_fashion") for ck in ("vae-model", "prior-model")]
+
+
+@pytest.mark.parametrize("model,ck", REF_INDEX)
+def test_tf_bundle_index_reproduces_reference_bytes(golden_dir, tmp_path, model, ck):
+    """tests/golden/ref_ckpt_index/*.index are the reference's own TensorFlow-written `pretrained_models/<model>/<ck>.index`
+    data files.  Reading one (every block's masked CRC-32C is verified, which pins crc32c + masking against TF-produced
+    bytes) and re-serialising the parsed entries must give the identical file: table blocks, prefix compression, restart
+    arrays, index separators, footer and BundleEntryProto encoding all as TensorFlow writes them."""
+    from ladder_latent_data_distribution_modelling_amd.codes import tf_bundle as T
+    src = os.path.join(golden_dir, "ref_ckpt_index", "%s_%s.index" % (model, ck))
+    ents = T.read_index(src, verify=True)
+    inv = json.load(open(os.path.join(golden_dir, "ckpt_inventory.json")))[model][ck]
+    assert {k: v["shape"] for k, v in ents.items()} == inv
+    assert all(e["dtype"] == 1 and e["size"] == 4 * int(np.prod(e["shape"] or [1])) for e in ents.values())
+    offs = sorted((e["offset"], e["size"]) for e in ents.values())       # tensors are packed back to back in key order
+    assert offs[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(offs, offs[1:]))
+    out = str(tmp_path / "rewritten.index")
+    T.write_index(out, ents)
+    assert open(out, "rb").read() == open(src, "rb").read()
+
+
+def test_tf_bundle_crc32c_known_answers():
+    from ladder_latent_data_distribution_modelling_amd.codes import tf_bundle as T
+    assert T.crc32c(b"123456789") == 0xE3069283                       # the standard CRC-32C check value
+    assert T.crc32c(b"\x00" * 32) == 0x8A9136AA and T.crc32c(b"\xff" * 32) == 0x62A8AB43   # RFC 3720 B.4
+    assert T.unmask_crc(T.mask_crc(0x12345678)) == 0x12345678
+    a = np.random.default_rng(0).integers(0, 255, 100003, dtype=np.uint8)
+    assert T.crc32c(a) == T._crc32c_py(a.tobytes())                    # C ABI slicing-by-8 == bytewise table
+    assert T.crc32c(a[3:]) == T._crc32c_py(a[3:].tobytes())            # unaligned start
+    half = T.crc32c(a[:50000])
+    from ladder_latent_data_distribution_modelling_amd import _lib as L
+    assert L.query("ladder_crc32c_extend", half, a[50000:].ctypes.data, a.size - 50000) == T.crc32c(a)   # chainable
+
+
+def test_tf_bundle_checkpoint_roundtrip_and_corruption(tmp_path, monkeypatch):
+    from ladder_latent_data_distribution_modelling_amd.codes import tf_bundle as T
+    rng = np.random.default_rng(4)
+    tens = {"encoder/conv2d/kernel": rng.normal(size=(3, 3, 1, 16)).astype(np.float32),
+            "encoder/conv2d/bias": np.zeros(16, np.float32), "sigma/Variable": np.float32(0.5),
+            "decoder/dense/kernel": rng.normal(size=(300, 40)).astype(np.float32)}
+    tens.update({"prior/dense_%d/kernel" % i: rng.normal(size=(7, i + 1)).astype(np.float32) for i in range(40)})
+    prefix = str(tmp_path / "vae-model")
+    T.save_checkpoint(prefix, tens)
+    back = T.load_checkpoint(prefix)
+    assert set(back) == set(tens) and back["sigma/Variable"].shape == ()
+    assert all(np.array_equal(back[k], tens[k]) for k in tens)
+    assert open(str(tmp_path / "checkpoint")).read().startswith('model_checkpoint_path: "vae-model"')
+    only = T.load_checkpoint(prefix, names={"sigma/Variable"})
+    assert list(only) == ["sigma/Variable"]
+    # several data blocks + a multi-entry index block (TensorFlow's 256 KiB block size never splits these models' indices)
+    monkeypatch.setattr(T, "BLOCK_SIZE", 256)
+    T.save_checkpoint(str(tmp_path / "small-blocks"), tens)
+    back = T.load_checkpoint(str(tmp_path / "small-blocks"))
+    assert all(np.array_equal(back[k], tens[k]) for k in tens)
+    # a flipped payload byte, a flipped index byte and a missing shard are all detected
+    data = prefix + ".data-00000-of-00001"
+    raw = bytearray(open(data, "rb").read())
+    raw[1000] ^= 1
+    open(data, "wb").write(bytes(raw))
+    with pytest.raises(T.BundleError, match="checksum"):
+        T.load_checkpoint(prefix)
+    idx = bytearray(open(prefix + ".index", "rb").read())
+    idx[20] ^= 1
+    open(prefix + ".index", "wb").write(bytes(idx))
+    with pytest.raises(T.BundleError, match="checksum"):
+        T.read_index(prefix + ".index")
+    os.remove(str(tmp_path / "small-blocks") + ".data-00000-of-00001")
+    with pytest.raises(T.BundleError, match="missing"):
+        T.load_checkpoint(str(tmp_path / "small-blocks"))
+    with pytest.raises(T.BundleError, match="magic"):
+        open(str(tmp_path / "junk.index"), "wb").write(b"x" * 100)
+        T.read_index(str(tmp_path / "junk.index"))
