@@ -28,6 +28,8 @@ class BaseModel:
         self.num_para_list = [self.num_encoder, self.num_decoder, self.num_sigma, self.num_prior_ae, self.num_prior_sigma]
         print("Total number of trainable parameters in VAE network is:\n{}k\n".format(np.around(sum(self.num_para_list) / 1000, 2)))
         self.init_saver()
+        from .session import attach_handles
+        attach_handles(self)          # graph-tensor attribute surface for `sess.run(fetches, feed_dict)` (codes/session.py)
 
     # codes/base.py:88-106 -- the producer of (prior_weight, prior_mean, prior_cov)
     def define_GM_prior(self):

@@ -9,11 +9,8 @@ import os
 from codes.data_loader import DataGenerator
 from codes.models import MNISTModel_digit, MNISTModel_fashion, CelebAModel_densenet
 from codes.trainers import MNISTTrainer_joint_training, CelebATrainer_joint_training
+from codes.session import Session          # stands in for tf.Session (train.py:41-47 of the reference)
 from codes.utils import process_config, create_dirs, get_args, save_config
-
-
-class Session:
-    """Placeholder for the reference's tf.Session argument (accepted and ignored by the HIP path)."""
 
 
 def main():
