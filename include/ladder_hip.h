@@ -39,7 +39,9 @@ int ladder_abi_version(void);
  * GEMM extents M x (.) x Cout and gathered channel count Cin dispatches to; negative = non-vectorised variant. */
 int ladder_igemm_fwd_tile(long M, int Cin, int Cout);
 /* Kernel a conv forward-type call dispatches to: 256128 = conv3x3_halo_kernel (3x3, stride 1, SAME, W%32==0, H%8==0: an
- * 8x32-pixel x 128-channel tile whose input halo is staged once in LDS for all 9 taps), else as ladder_igemm_fwd_tile.
+ * 8x32-pixel x 128-channel tile whose input halo is staged once in LDS for all 9 taps); 9003 = conv_smallcin_kernel (1x1
+ * from 3 channels to a power-of-two 16..256 channels, i.e. the output conv's backward-data: direct, HBM-bound); else as
+ * ladder_igemm_fwd_tile.
  * For bwd_data pass the dy geometry (N,Ho,Wo,Cout as input; H,W,Cin as output), stride 1, ups = stride, flipped pads. */
 int ladder_conv2d_fwd_kernel_id(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int ups,
                                 int pad_t, int pad_l);

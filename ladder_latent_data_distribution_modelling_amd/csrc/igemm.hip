@@ -768,6 +768,100 @@ int select_fwd_tile(long M, int Cout) {
   return 128032;
 }
 
+// ---- direct convolution from a 3-channel tensor: backward-data of the CelebA output conv (1x1, 3 -> 128 channels) ----------------
+// K = 3 is far too short for an MFMA K-loop; the call is bound by reading the activation-derivative gate and writing dx (1.07 GB
+// each at B=128): the generic gather kernel ran it at 2.2 TB/s, this one at 4.6 TB/s.  One thread owns 4 output channels, holds
+// their K x 4 filter taps in registers for the whole launch and walks output pixels grid-stride; the lanes of a pixel read the same
+// input words (broadcast, L1-resident) and store one contiguous Cout*4-byte row.  Accumulation order = (kh, kw, ci).
+// (A 3x3 / Cin=3 instantiation for enc.conv2d forward measured 176 us against 133 us for the MFMA gather kernel -- VALU-bound on
+// its 27 broadcast loads + 108 FMAs per thread -- so the forward keeps the gather kernel.)
+template <int KH_, int KW_, int CIN, bool GATE>
+__global__ __launch_bounds__(256) void conv_smallcin_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ y,
+                                                            const float* __restrict__ gate, int H, int W, int Wo, int Cout,
+                                                            int stride, int pad_t, int pad_l, int act, int M, FastDiv div_howo,
+                                                            FastDiv div_wo, int HoWo) {
+  constexpr int K = KH_ * KW_ * CIN;
+  const int cq = Cout >> 2;                         // channel quads per pixel (power of two, 4..64)
+  const int q = threadIdx.x & (cq - 1);
+  const int ppb = 256 / cq;                         // pixels per block step
+  const int pl = threadIdx.x / cq;
+  float4 wr[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) wr[k] = *reinterpret_cast<const float4*>(w + (size_t)k * Cout + q * 4);
+  float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias != nullptr) b4 = *reinterpret_cast<const float4*>(bias + q * 4);
+  for (int m = blockIdx.x * ppb + pl; m < M; m += gridDim.x * ppb) {
+    const int n = (int)fdiv((uint32_t)m, div_howo);
+    const int r = m - n * HoWo;
+    const int oh = (int)fdiv((uint32_t)r, div_wo), ow = r - oh * Wo;
+    const int ih0 = oh * stride - pad_t, iw0 = ow * stride - pad_l;
+    const float* xn = x + (size_t)n * H * W * CIN;
+    float4 acc = b4;
+#pragma unroll
+    for (int kh = 0; kh < KH_; ++kh) {
+      const int ih = ih0 + kh;
+      const bool okh = (unsigned)ih < (unsigned)H;
+#pragma unroll
+      for (int kw = 0; kw < KW_; ++kw) {
+        const int iw = iw0 + kw;
+        const bool ok = okh && (unsigned)iw < (unsigned)W;
+        const float* px = xn + ((ok ? ih : 0) * W + (ok ? iw : 0)) * CIN;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+          const float v = ok ? px[ci] : 0.f;
+          const float4 ww = wr[(kh * KW_ + kw) * CIN + ci];
+          acc.x = fmaf(v, ww.x, acc.x);
+          acc.y = fmaf(v, ww.y, acc.y);
+          acc.z = fmaf(v, ww.z, acc.z);
+          acc.w = fmaf(v, ww.w, acc.w);
+        }
+      }
+    }
+    const size_t o = (size_t)m * Cout + q * 4;
+    if (GATE) {                                     // dx *= act'(y_prev) evaluated from the layer-below's OUTPUT
+      const float4 g = *reinterpret_cast<const float4*>(gate + o);
+      acc.x *= ladder_act_grad_from_out(g.x, act);
+      acc.y *= ladder_act_grad_from_out(g.y, act);
+      acc.z *= ladder_act_grad_from_out(g.z, act);
+      acc.w *= ladder_act_grad_from_out(g.w, act);
+    } else {
+      acc.x = ladder_act_fn(acc.x, act);
+      acc.y = ladder_act_fn(acc.y, act);
+      acc.z = ladder_act_fn(acc.z, act);
+      acc.w = ladder_act_fn(acc.w, act);
+    }
+    *reinterpret_cast<float4*>(y + o) = acc;
+  }
+}
+
+bool smallcin_eligible(int Cin, int Cout, int KH, int KW) {
+  static const bool off = getenv("LADDER_DISABLE_SMALLCIN") != nullptr;
+  const int cq = Cout >> 2;
+  return !off && KH == 1 && KW == 1 && Cin == 3 && (Cout & 3) == 0 && cq >= 4 && cq <= 64 && (cq & (cq - 1)) == 0;
+}
+
+int launch_smallcin(const float* x, const float* w, const float* bias, float* y, const float* gate, int N, int H, int W, int Cin,
+                    int Ho, int Wo, int Cout, int KH, int stride, int pad_t, int pad_l, int act, hipStream_t st) {
+  if (!ladder_aligned16(w) || !ladder_aligned16(y) || (bias != nullptr && !ladder_aligned16(bias)) ||
+      (gate != nullptr && !ladder_aligned16(gate)))
+    return LADDER_E_ALIGN;
+  const long Ml = (long)N * Ho * Wo;
+  if (Ml >= (1L << 31)) return LADDER_E_SHAPE;
+  const int M = (int)Ml, ppb = 256 / (Cout >> 2);
+  long blocks = (Ml + ppb - 1) / ppb;
+  if (blocks > 256L * 16) blocks = 256L * 16;        // two residency rounds of the chip, grid-stride beyond that
+  const FastDiv dhw = make_fastdiv(Ho * Wo), dw = make_fastdiv(Wo);
+#define LADDER_SMALLCIN(KH_, KW_, CIN_, G_)                                                                                      \
+  hipLaunchKernelGGL((conv_smallcin_kernel<KH_, KW_, CIN_, G_>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, bias, y, gate, H, W, \
+                     Wo, Cout, stride, pad_t, pad_l, act, M, dhw, dw, Ho * Wo)
+  if (KH != 1 || Cin != 3) return LADDER_E_SHAPE;
+  if (gate != nullptr) LADDER_SMALLCIN(1, 1, 3, true); else LADDER_SMALLCIN(1, 1, 3, false);
+#undef LADDER_SMALLCIN
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
 int dispatch_fwd(const float* x, const float* w, const float* bias, float* y, const IgemmDesc& d, void* ws, size_t ws_bytes,
                  hipStream_t st, const float* gate = nullptr, int gate_act = 0) {
   if (d.M <= 0 || d.K <= 0 || d.Cout <= 0) return LADDER_E_SHAPE;
@@ -1077,6 +1171,7 @@ int ladder_conv2d_fwd_kernel_id(int N, int H, int W, int Cin, int Ho, int Wo, in
   IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, ups, pad_t, pad_l, N * Ho * Wo, KH * KW * Cin, 0, make_fastdiv(1), make_fastdiv(1)};
   set_conv_taps(d);
   if (halo_eligible(d)) return 256128;
+  if (ups == 1 && stride == 1 && smallcin_eligible(Cin, Cout, KH, KW)) return 9003;     // conv_smallcin_kernel (direct, output-write bound)
   return ladder_igemm_fwd_tile(d.M, Cin, Cout);
 }
 
@@ -1095,6 +1190,8 @@ int ladder_conv2d_bwd_data(const float* dy, const float* wT, float* dx, int N, i
   // dx[hi] gathers dy[(hi + pad_t - r)/stride] = dy[(hi + r' - (KH-1-pad_t))/stride] with the flipped tap r'.
   IgemmDesc d{N, Ho, Wo, Cout, H, W, Cin, KH, KW, 1, stride, KH - 1 - pad_t, KW - 1 - pad_l, N * H * W, KH * KW * Cout, LADDER_ACT_NONE, make_fastdiv(H * W), make_fastdiv(W)};
   set_conv_taps(d);   // stride 1: full tap table; stride > 1: dense output mapping only (ntaps = 0 -> generic gather)
+  if (stride == 1 && smallcin_eligible(Cout, Cin, KH, KW))             // 1x1 from a 3-channel dy (CelebA output conv), gate fused
+    return launch_smallcin(dy, wT, nullptr, dx, gate_y, N, Ho, Wo, Cout, H, W, Cin, KH, 1, 0, 0, gate_y != nullptr ? gate_act : 0, stream);
   if (stride == 1) return dispatch_fwd(dy, wT, nullptr, dx, d, ws, ws_bytes, stream, gate_y, gate_act);
   if (stride == 2 && (Cout % BK) == 0 && KH * KW <= 28) {
     // Parity-class decomposition of the transposed convolution: output pixels with (hi, wi) parity (ch, cw) only ever see the

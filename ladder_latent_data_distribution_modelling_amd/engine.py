@@ -25,7 +25,8 @@ class KernelProfiler:
     roofline leg).  Events are recorded on the stream the kernels are launched on (torch's current stream)."""
 
     NAMES = {256128: "conv3x3_halo_kernel (8x32 px x 128 ch LDS-halo tile, 8 waves, fp32 MFMA 32x32x2)",
-             128128: "igemm_fwd_kernel<128,128,2,2,true,true> (gather implicit GEMM, fp32 MFMA 32x32x2)"}
+             128128: "igemm_fwd_kernel<128,128,2,2,true,true> (gather implicit GEMM, fp32 MFMA 32x32x2)",
+             9003: "conv_smallcin_kernel (direct 1x1 from 3 channels, HBM-bound)"}
 
     def __init__(self):
         self.records = {}

@@ -39,6 +39,11 @@ CONV_CASES = [
     (2, 16, 16, 16, 32, 3, 1, "same", "leaky_relu"),
     (3, 16, 16, 32, 160, 3, 1, "same", None),          # N tile edge (160 = 128 + 32)
     (2, 32, 32, 3, 128, 3, 2, "same", None),           # Cin=3 scalar gather, TF asymmetric SAME pad
+    (5, 32, 32, 1, 16, 3, 2, "same", "leaky_relu"),    # MNIST-digit encoder conv (Cin=1)
+    (3, 32, 32, 1, 64, 3, 2, "same", "leaky_relu"),    # MNIST-fashion encoder conv
+    (24, 128, 128, 128, 3, 1, 1, "same", None),        # CelebA output conv at full resolution: bwd_data = conv_smallcin_kernel
+                                                       # (1x1 from 3 channels), more pixels than one grid pass, gated variant too
+    (2, 9, 11, 24, 3, 1, 1, "same", None),             # same shape class, 24 output channels of bwd_data: generic gather kernel
     (2, 16, 16, 128, 128, 3, 2, "same", None),
     (4, 4, 4, 64, 64, 3, 1, "valid", "leaky_relu"),
     (5, 1, 1, 48, 48, 1, 1, "same", None),
