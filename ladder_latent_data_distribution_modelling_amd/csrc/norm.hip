@@ -443,80 +443,80 @@ inline int in_split(int N, int HW, int C) {
 }
 
 // ----------------------------------------------------------------------------- legacy bilinear resize (integer factors)
+// Source-centric mapping: `bpr` consecutive blocks cover one source row n*H + iy, walking (ix, channel vector).  A thread
+// loads the 4 corner vectors of its source pixel once and writes the fy x fx output pixels whose lower corner it is, so the
+// forward reads every source vector ~4x from L1/L2 and once from HBM, and all index arithmetic is 32-bit.  V = 4 uses 16-byte
+// accesses (C % 4 == 0 and 16-byte aligned bases).
+template <int V> struct ResizeVec;
+template <> struct ResizeVec<4> { using T = float4; };
+template <> struct ResizeVec<1> { using T = float; };
+__device__ __forceinline__ float4 rz_lerp(const float4& a, const float4& b, float t) {
+  return make_float4(a.x + (b.x - a.x) * t, a.y + (b.y - a.y) * t, a.z + (b.z - a.z) * t, a.w + (b.w - a.w) * t);
+}
+__device__ __forceinline__ float rz_lerp(float a, float b, float t) { return a + (b - a) * t; }
+__device__ __forceinline__ void rz_fma(float4& acc, float w, const float4& q) {
+  acc.x += w * q.x; acc.y += w * q.y; acc.z += w * q.z; acc.w += w * q.w;
+}
+__device__ __forceinline__ void rz_fma(float& acc, float w, float q) { acc += w * q; }
+__device__ __forceinline__ void rz_zero(float4& a) { a = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void rz_zero(float& a) { a = 0.f; }
+
 template <int V>
-__global__ void resize_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C, int OH, int OW) {
-  const int CV = C / V;
-  const size_t total = (size_t)N * OH * OW * CV;
-  const int fy = OH / H, fx = OW / W;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int cv = (int)(i % CV);
-    size_t t = i / CV;
-    const int ox = (int)(t % OW);
-    t /= OW;
-    const int oy = (int)(t % OH);
-    const int n = (int)(t / OH);
-    const int ylo = oy / fy, xlo = ox / fx;
-    const int yhi = min(ylo + 1, H - 1), xhi = min(xlo + 1, W - 1);
-    const float yl = (float)(oy - ylo * fy) / (float)fy, xl = (float)(ox - xlo * fx) / (float)fx;
-    const float* p = x + (size_t)n * H * W * C + (size_t)cv * V;
-    float tl[V], tr[V], bl[V], br[V], o[V];
-#pragma unroll
-    for (int v = 0; v < V; ++v) {
-      tl[v] = p[((size_t)ylo * W + xlo) * C + v];
-      tr[v] = p[((size_t)ylo * W + xhi) * C + v];
-      bl[v] = p[((size_t)yhi * W + xlo) * C + v];
-      br[v] = p[((size_t)yhi * W + xhi) * C + v];
-      const float top = tl[v] + (tr[v] - tl[v]) * xl;
-      const float bot = bl[v] + (br[v] - bl[v]) * xl;
-      o[v] = top + (bot - top) * yl;
+__global__ __launch_bounds__(256) void resize_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int CV,
+                                                         int fy, int fx, int bpr) {
+  using T = typename ResizeVec<V>::T;
+  const int row = blockIdx.x / bpr;                 // n*H + iy (wave-uniform)
+  const int j = (blockIdx.x - row * bpr) * blockDim.x + threadIdx.x;
+  if (j >= W * CV) return;
+  const int n = row / H, iy = row - n * H;
+  const int ix = j / CV, cv = j - ix * CV;
+  const int yhi = min(iy + 1, H - 1), xhi = min(ix + 1, W - 1);
+  const T* r0 = reinterpret_cast<const T*>(x) + (size_t)row * W * CV;
+  const T* r1 = reinterpret_cast<const T*>(x) + ((size_t)n * H + yhi) * W * CV;
+  const T tl = r0[ix * CV + cv], tr = r0[xhi * CV + cv], bl = r1[ix * CV + cv], br = r1[xhi * CV + cv];
+  const int OW = W * fx;
+  T* out = reinterpret_cast<T*>(y) + (((size_t)row * fy) * OW + (size_t)ix * fx) * CV + cv;
+  for (int dy = 0; dy < fy; ++dy) {
+    const float yl = (float)dy / (float)fy;
+    for (int dx = 0; dx < fx; ++dx) {
+      const float xl = (float)dx / (float)fx;
+      const T top = rz_lerp(tl, tr, xl), bot = rz_lerp(bl, br, xl);
+      out[((size_t)dy * OW + dx) * CV] = rz_lerp(top, bot, yl);
     }
-    float* q = y + (((size_t)n * OH + oy) * OW + ox) * C + (size_t)cv * V;
-#pragma unroll
-    for (int v = 0; v < V; ++v) q[v] = o[v];
   }
 }
 
 // transpose of the map above in gather form (no atomics): input pixel (iy,ix) collects every output
-// pixel whose lo or hi index equals it.
+// pixel whose lo or hi index equals it, in (oy, ox) order.
 template <int V>
-__global__ void resize_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C, int OH, int OW) {
-  const int CV = C / V;
-  const size_t total = (size_t)N * H * W * CV;
-  const int fy = OH / H, fx = OW / W;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int cv = (int)(i % CV);
-    size_t t = i / CV;
-    const int ix = (int)(t % W);
-    t /= W;
-    const int iy = (int)(t % H);
-    const int n = (int)(t / H);
-    float acc[V];
-#pragma unroll
-    for (int v = 0; v < V; ++v) acc[v] = 0.f;
-    const int oy0 = max(0, (iy - 1) * fy), oy1 = min(OH, (iy + 1) * fy);
-    const int ox0 = max(0, (ix - 1) * fx), ox1 = min(OW, (ix + 1) * fx);
-    for (int oy = oy0; oy < oy1; ++oy) {
-      const int ylo = oy / fy, yhi = min(ylo + 1, H - 1);
-      const float yl = (float)(oy - ylo * fy) / (float)fy;
-      const float wy = (ylo == iy ? 1.f - yl : 0.f) + (yhi == iy ? yl : 0.f);
-      if (wy == 0.f) continue;
-      for (int ox = ox0; ox < ox1; ++ox) {
-        const int xlo = ox / fx, xhi = min(xlo + 1, W - 1);
-        const float xl = (float)(ox - xlo * fx) / (float)fx;
-        const float wx = (xlo == ix ? 1.f - xl : 0.f) + (xhi == ix ? xl : 0.f);
-        if (wx == 0.f) continue;
-        const float* q = dy + (((size_t)n * OH + oy) * OW + ox) * C + (size_t)cv * V;
-        const float wgt = wy * wx;
-#pragma unroll
-        for (int v = 0; v < V; ++v) acc[v] += wgt * q[v];
-      }
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int CV,
+                                                         int fy, int fx, int bpr) {
+  using T = typename ResizeVec<V>::T;
+  const int row = blockIdx.x / bpr;
+  const int j = (blockIdx.x - row * bpr) * blockDim.x + threadIdx.x;
+  if (j >= W * CV) return;
+  const int n = row / H, iy = row - n * H;
+  const int ix = j / CV, cv = j - ix * CV;
+  const int OH = H * fy, OW = W * fx;
+  T acc;
+  rz_zero(acc);
+  const int oy0 = max(0, (iy - 1) * fy), oy1 = min(OH, (iy + 1) * fy);
+  const int ox0 = max(0, (ix - 1) * fx), ox1 = min(OW, (ix + 1) * fx);
+  const T* base = reinterpret_cast<const T*>(dy) + (size_t)n * OH * OW * CV + cv;
+  for (int oy = oy0; oy < oy1; ++oy) {
+    const int ylo = oy / fy, yhi = min(ylo + 1, H - 1);
+    const float yl = (float)(oy - ylo * fy) / (float)fy;
+    const float wy = (ylo == iy ? 1.f - yl : 0.f) + (yhi == iy ? yl : 0.f);
+    if (wy == 0.f) continue;
+    for (int ox = ox0; ox < ox1; ++ox) {
+      const int xlo = ox / fx, xhi = min(xlo + 1, W - 1);
+      const float xl = (float)(ox - xlo * fx) / (float)fx;
+      const float wx = (xlo == ix ? 1.f - xl : 0.f) + (xhi == ix ? xl : 0.f);
+      if (wx == 0.f) continue;
+      rz_fma(acc, wy * wx, base[((size_t)oy * OW + ox) * CV]);
     }
-    float* p = dx + (((size_t)n * H + iy) * W + ix) * C + (size_t)cv * V;
-#pragma unroll
-    for (int v = 0; v < V; ++v) p[v] = acc[v];
   }
+  reinterpret_cast<T*>(dx)[((size_t)row * W + ix) * CV + cv] = acc;
 }
 
 __global__ void d2s_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C, int r, int inverse) {
@@ -694,24 +694,32 @@ int ladder_in_style_bwd(const float* dy, const float* x, const float* style, con
   return LADDER_OK;
 }
 
-int ladder_resize_bilinear_fwd(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, ladder_stream_t stream) {
+static int resize_launch(bool fwd, const float* a, float* b, int N, int H, int W, int C, int OH, int OW, hipStream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH < H || OW < W || OH % H || OW % W) return LADDER_E_SHAPE;
-  if (C % 4 == 0)
-    hipLaunchKernelGGL(resize_fwd_kernel<4>, dim3(ew_grid((size_t)N * OH * OW * (C / 4))), dim3(256), 0, stream, x, y, N, H, W, C, OH, OW);
-  else
-    hipLaunchKernelGGL(resize_fwd_kernel<1>, dim3(ew_grid((size_t)N * OH * OW * C)), dim3(256), 0, stream, x, y, N, H, W, C, OH, OW);
+  const bool v4 = (C % 4 == 0) && ladder_aligned16(a) && ladder_aligned16(b);
+  const int CV = v4 ? C / 4 : C;
+  const long bprl = ((long)W * CV + 255) / 256;
+  if (bprl * N * H >= (1L << 31)) return LADDER_E_SHAPE;
+  const int bpr = (int)bprl;
+  const dim3 grid((unsigned)(bprl * N * H)), block(256);
+  const int fy = OH / H, fx = OW / W;
+  if (fwd) {
+    if (v4) hipLaunchKernelGGL(resize_fwd_kernel<4>, grid, block, 0, stream, a, b, H, W, CV, fy, fx, bpr);
+    else hipLaunchKernelGGL(resize_fwd_kernel<1>, grid, block, 0, stream, a, b, H, W, CV, fy, fx, bpr);
+  } else {
+    if (v4) hipLaunchKernelGGL(resize_bwd_kernel<4>, grid, block, 0, stream, a, b, H, W, CV, fy, fx, bpr);
+    else hipLaunchKernelGGL(resize_bwd_kernel<1>, grid, block, 0, stream, a, b, H, W, CV, fy, fx, bpr);
+  }
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
 
+int ladder_resize_bilinear_fwd(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, ladder_stream_t stream) {
+  return resize_launch(true, x, y, N, H, W, C, OH, OW, stream);
+}
+
 int ladder_resize_bilinear_bwd(const float* dy, float* dx, int N, int H, int W, int C, int OH, int OW, ladder_stream_t stream) {
-  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH < H || OW < W || OH % H || OW % W) return LADDER_E_SHAPE;
-  if (C % 4 == 0)
-    hipLaunchKernelGGL(resize_bwd_kernel<4>, dim3(ew_grid((size_t)N * H * W * (C / 4))), dim3(256), 0, stream, dy, dx, N, H, W, C, OH, OW);
-  else
-    hipLaunchKernelGGL(resize_bwd_kernel<1>, dim3(ew_grid((size_t)N * H * W * C)), dim3(256), 0, stream, dy, dx, N, H, W, C, OH, OW);
-  LADDER_CHECK_LAUNCH();
-  return LADDER_OK;
+  return resize_launch(false, dy, dx, N, H, W, C, OH, OW, stream);
 }
 
 int ladder_depth_to_space(const float* x, float* y, int N, int H, int W, int C, int r, int inverse, ladder_stream_t stream) {
