@@ -234,6 +234,21 @@ int ladder_adam_clip_dev(float* theta, const float* g, float* m, float* v, size_
 int ladder_randn_dev(float* out, size_t n, uint64_t seed, const uint64_t* offset_base, uint64_t offset_add, ladder_stream_t stream);
 int ladder_u64_add(uint64_t* p, uint64_t inc, ladder_stream_t stream);
 
+/* ---------------------------------------------------------------- N13: the mixture fit that produces the hyper-prior feed
+ * sklearn.mixture.BayesianGaussianMixture(K, 'full', weight_concentration_prior_type=..., weight_concentration_prior=0.1,
+ * warm_start=True).fit(samples) of codes/base.py:93-99 (per-epoch "fast" fit, 681-721) and 723-789 ("accurate" fit), as ONE
+ * persistent-workgroup launch running the whole variational loop in float64 (csrc/vbgmm.hip).
+ *   X [N,R] fp32 samples (R <= 8, K <= 64, N >= K); labels [N] int32 = hard initial assignment (k-means labels) or NULL to
+ *   warm-start from `state` (ladder_vbgmm_state_doubles(K,R) doubles, caller-owned, persists between fits; its last three
+ *   entries are lower_bound_, n_iter_, converged_ (-1 = ill-defined covariance, sklearn raises ValueError there)).
+ *   prior_type 0 = dirichlet_distribution, 1 = dirichlet_process.  mean/covariance priors are taken from X as sklearn does.
+ *   Outputs weights [K], means [K,R], covs [K,R,R] fp32 = weights_, means_, covariances_ (float64 copies live in `state`). */
+size_t ladder_vbgmm_state_doubles(int K, int R);
+size_t ladder_vbgmm_workspace_bytes(int N, int K);
+int ladder_vbgmm_fit(const float* X, int N, int K, int R, const int* labels, double* state, int prior_type, double wc_prior,
+                     double mean_prec_prior, double reg_covar, double tol, int max_iter, float* weights, float* means,
+                     float* covs, void* ws, size_t ws_bytes, ladder_stream_t stream);
+
 /* ---------------------------------------------------------------- helpers */
 /* HOST function (no device work): CRC-32C (Castagnoli) of host memory, crc = 0 to start, chainable.  Used by the
  * tf.train.Saver checkpoint-v2 reader/writer (codes/base.py:37-85: saver_ae / saver_prior) for block and tensor checksums. */

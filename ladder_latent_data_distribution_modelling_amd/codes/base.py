@@ -118,6 +118,7 @@ class BaseTrain:
 
     # ------------------------------------------------------------------ GM fit (base.py:681-789)
     def _draw_t_samples(self, iterator, n_batch):
+        """t-samples of n_batch minibatches as ONE device tensor [n, R] (every rank's, in rank order, under data parallelism)."""
         eng = self.engine
         chunks = []
         for _ in range(n_batch):
@@ -126,11 +127,11 @@ class BaseTrain:
                 parts = [torch.empty_like(t) for _ in range(eng.ctx.comm.world)]
                 eng.ctx.comm.dist.all_gather(parts, t.contiguous(), group=eng.ctx.comm.group)
                 t = torch.cat(parts, 0)
-            chunks.append(t.cpu().numpy())
-        return np.concatenate(chunks, 0).astype(np.float64)
+            chunks.append(t.clone())
+        return torch.cat(chunks, 0)
 
     def _share_gm(self, gm):
-        """rank 0 fits, every rank receives (weights, means, covs)."""
+        """sklearn backend: rank 0 fits on the host, every rank receives (weights, means, covs)."""
         eng = self.engine
         K, R = int(self.config["n_mixtures"]), int(self.config["representation_size"])
         buf = torch.zeros(K + K * R + K * R * R, dtype=torch.float64, device=eng.ctx.device)
@@ -141,37 +142,55 @@ class BaseTrain:
         a = buf.cpu().numpy()
         return a[:K].copy(), a[K:K + K * R].reshape(K, R).copy(), a[K + K * R:].reshape(K, R, R).copy()
 
+    def _fit(self, gm, samples):
+        """-> (weights, means, covs) to feed.  Device backend: every rank runs the same deterministic fit on the same gathered
+        samples (only a cold start's k-means labels come from rank 0), the parameters never leave the GPU.  sklearn backend:
+        rank 0 fits on a host copy and broadcasts."""
+        from .vbgmm import DeviceBayesianGaussianMixture
+        if isinstance(gm, DeviceBayesianGaussianMixture):
+            gm.fit(samples)
+            return gm.weights_dev, gm.means_dev, gm.covariances_dev
+        if self.engine.ctx.comm.rank == 0:
+            gm.fit(samples.cpu().numpy().astype(np.float64))
+        return self._share_gm(gm)
+
     def fit_GMM_VI(self, iterator, mode="fast", space="t"):
         if space != "t":
             raise NotImplementedError("prior 'GMM' (mixture on z) is a later row (SURVEY 8f4)")
-        bs_global = int(self.config["batch_size"]) * self.engine.ctx.comm.world
-        rank0 = self.engine.ctx.comm.rank == 0
+        comm = self.engine.ctx.comm
+        bs_global = int(self.config["batch_size"]) * comm.world
+        rank0 = comm.rank == 0
         if mode == "fast":
             samples = self._draw_t_samples(iterator, 2000 // bs_global + 1)
-            gm = self.model.GM_prior_training
-            if rank0:
-                gm.fit(samples)
-            self.gm_params = self._share_gm(gm)
+            self.gm_params = self._fit(self.model.GM_prior_training, samples)
             w = self.gm_params[0]
         else:
-            from sklearn.mixture import BayesianGaussianMixture
             samples = self._draw_t_samples(iterator, 20000 // bs_global + 1)
-            self.GM_prior_final = BayesianGaussianMixture(
-                n_components=int(self.config["n_mixtures"]), covariance_type="full", max_iter=2000,
-                n_init=int(self.config["GM_fit_restart"]), weight_concentration_prior_type="dirichlet_process",
-                weight_concentration_prior=0.1, warm_start=False)
-            if rank0:
-                self.GM_prior_final.fit(samples)
-            self.gm_final_params = self._share_gm(self.GM_prior_final)
-            w, m, K = self.gm_final_params
+            kw = dict(n_components=int(self.config["n_mixtures"]), covariance_type="full", max_iter=2000,
+                      n_init=int(self.config["GM_fit_restart"]), weight_concentration_prior_type="dirichlet_process",
+                      weight_concentration_prior=0.1, warm_start=False)
+            if self.config.get("gm_fit_backend", "hip") == "hip":
+                from .vbgmm import DeviceBayesianGaussianMixture
+                self.GM_prior_final = DeviceBayesianGaussianMixture(
+                    device=self.engine.ctx.device, label_broadcast=(lambda t: comm.broadcast_(t, 0)) if comm.on else None, **kw)
+            else:
+                from sklearn.mixture import BayesianGaussianMixture
+                self.GM_prior_final = BayesianGaussianMixture(**kw)
+            self.gm_final_params = self._fit(self.GM_prior_final, samples)
+            gmf = self.GM_prior_final
+            if rank0 or hasattr(gmf, "weights_dev"):
+                w, m, K = np.asarray(gmf.weights_), np.asarray(gmf.means_), np.asarray(gmf.covariances_)   # float64, like sklearn's
+            else:
+                w, m, K = self.gm_final_params
             idx = np.flatnonzero(w >= 1e-2)
             if rank0:
                 aw = w[idx] / np.sum(w[idx]) if len(idx) else w[idx]
                 np.savez("{}GM_prior_info.npz".format(self.config["result_dir"]), w_active=aw, m_active=m[idx],
                          K_active=K[idx], w_full=w, m_full=m, K_full=K)          # same keys as base.py:772-777
                 print("Final fitted prior saved.")
+        w = w.cpu().numpy() if isinstance(w, torch.Tensor) else np.asarray(w)
         print("There are {} active mixtures.".format(int(np.sum(w >= 1e-2))))
-        return samples
+        return samples.cpu().numpy().astype(np.float64)
 
     def save_variables_VAE(self):
         """<result_dir>/<exp_name>-result.npz with the reference's keys (codes/base.py:791-823)."""
@@ -239,6 +258,7 @@ class BaseTrain_joint(BaseTrain):
         if cfg["prior"] == "ours" and self.cur_epoch > int(cfg["sg_pretraining"]) and self.gm_params is not None:
             accurate = (self.cur_epoch % int(cfg["accurate_fit"]) == 0 or self.cur_epoch == int(cfg["num_epochs"]))
             w, m, K = self.gm_final_params if (accurate and self.GM_prior_final is not None) else self.gm_params
+            w, m, K = (np.asarray(a.cpu() if isinstance(a, torch.Tensor) else a, np.float64) for a in (w, m, K))
             w = np.clip(w, 0, None)
             comp = rng.choice(len(w), size=n, p=w / w.sum())
             Lc = np.linalg.cholesky(K)

@@ -31,14 +31,22 @@ class BaseModel:
         from .session import attach_handles
         attach_handles(self)          # graph-tensor attribute surface for `sess.run(fetches, feed_dict)` (codes/session.py)
 
-    # codes/base.py:88-106 -- the producer of (prior_weight, prior_mean, prior_cov)
+    # codes/base.py:88-106 -- the producer of (prior_weight, prior_mean, prior_cov).  config["gm_fit_backend"]: "hip" (default)
+    # runs the variational fit on the device (codes/vbgmm.py -> csrc/vbgmm.hip, sklearn-parity tested); "sklearn" keeps the
+    # reference's host object.
     def define_GM_prior(self):
         self.GM_prior_training = None
         if self.config["prior"] == "ours":
-            from sklearn.mixture import BayesianGaussianMixture
-            self.GM_prior_training = BayesianGaussianMixture(
-                n_components=int(self.config["n_mixtures"]), covariance_type="full", max_iter=1000, n_init=1,
-                weight_concentration_prior_type="dirichlet_distribution", weight_concentration_prior=0.1, warm_start=True)
+            kw = dict(n_components=int(self.config["n_mixtures"]), covariance_type="full", max_iter=1000, n_init=1,
+                      weight_concentration_prior_type="dirichlet_distribution", weight_concentration_prior=0.1, warm_start=True)
+            if self.config.get("gm_fit_backend", "hip") == "hip":
+                from .vbgmm import DeviceBayesianGaussianMixture
+                comm = self.engine.ctx.comm
+                self.GM_prior_training = DeviceBayesianGaussianMixture(
+                    device=self.engine.ctx.device, label_broadcast=(lambda t: comm.broadcast_(t, 0)) if comm.on else None, **kw)
+            else:
+                from sklearn.mixture import BayesianGaussianMixture
+                self.GM_prior_training = BayesianGaussianMixture(**kw)
 
     # codes/base.py:37-85 -- two savers: vae-model (encoder+decoder+sigma), prior-model (prior/* + inner sigma).
     # Adam slots / epoch counter are not saved by the reference either.  Format: the reference's own -- a TensorFlow

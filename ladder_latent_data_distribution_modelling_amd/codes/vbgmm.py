@@ -1,0 +1,111 @@
+"""Device-resident replacement for the sklearn mixture object of codes/base.py:93-99.
+
+`DeviceBayesianGaussianMixture` keeps sklearn.mixture.BayesianGaussianMixture's constructor arguments and fitted
+attributes (`weights_`, `means_`, `covariances_`, `n_iter_`, `lower_bound_`, `converged_`) for the options the reference
+uses (covariance_type='full'; dirichlet_distribution for the per-epoch "fast" fit, dirichlet_process for the final
+"accurate" fit; warm_start; n_init restarts), but runs the variational loop as one persistent-workgroup HIP launch
+(`ladder_vbgmm_fit`, csrc/vbgmm.hip) on samples that never leave the GPU.  Only the k-means initialisation of a cold fit runs on
+the host (sklearn.cluster.KMeans, exactly the call BaseMixture._initialize_parameters makes), so with the same `random_state`
+a fit reproduces sklearn's to float64 round-off (tests/test_gpu_vbgmm.py).
+"""
+import warnings
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+
+
+class DeviceBayesianGaussianMixture:
+    def __init__(self, n_components=1, covariance_type="full", tol=1e-3, reg_covar=1e-6, max_iter=100, n_init=1,
+                 init_params="kmeans", weight_concentration_prior_type="dirichlet_process", weight_concentration_prior=None,
+                 mean_precision_prior=None, warm_start=False, random_state=None, device="cuda:0", label_broadcast=None):
+        if covariance_type != "full" or init_params != "kmeans":
+            raise NotImplementedError("the HIP fit covers covariance_type='full', init_params='kmeans' (what the reference uses)")
+        if weight_concentration_prior_type not in ("dirichlet_distribution", "dirichlet_process"):
+            raise ValueError(weight_concentration_prior_type)
+        self.n_components, self.tol, self.reg_covar, self.max_iter, self.n_init = int(n_components), tol, reg_covar, int(max_iter), int(n_init)
+        self.weight_concentration_prior_type = weight_concentration_prior_type
+        self.weight_concentration_prior = weight_concentration_prior
+        self.mean_precision_prior = mean_precision_prior
+        self.warm_start, self.random_state = warm_start, random_state
+        self.device = torch.device(device)
+        self._label_broadcast = label_broadcast       # data-parallel hook: rank 0's k-means labels -> every rank
+        self._state = None
+
+    # -------------------------------------------------------------------------------------------------------------
+    def _kmeans_labels(self, X_host, rs):
+        from sklearn import cluster
+        return cluster.KMeans(n_clusters=self.n_components, n_init=1, random_state=rs).fit(X_host).labels_.astype(np.int32)
+
+    def fit(self, X, y=None):
+        """X: [N,R] torch tensor on the device (preferred) or array-like."""
+        from sklearn.utils import check_random_state
+        K = self.n_components
+        Xd = X if isinstance(X, torch.Tensor) else torch.as_tensor(np.asarray(X, dtype=np.float32))
+        Xd = Xd.to(device=self.device, dtype=torch.float32).contiguous()
+        N, R = Xd.shape
+        if N < K:
+            raise ValueError("Expected n_samples >= n_components but got n_components = %d, n_samples = %d" % (K, N))
+        wc = 1.0 / K if self.weight_concentration_prior is None else float(self.weight_concentration_prior)
+        mp = 1.0 if self.mean_precision_prior is None else float(self.mean_precision_prior)
+        ptype = 0 if self.weight_concentration_prior_type == "dirichlet_distribution" else 1
+        nstate = L.query("ladder_vbgmm_state_doubles", K, R)
+        ws = torch.empty(L.query("ladder_vbgmm_workspace_bytes", N, K), dtype=torch.uint8, device=self.device)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        do_init = not (self.warm_start and self._state is not None and hasattr(self, "converged_"))
+        rs = check_random_state(self.random_state)
+        best = None
+        for _ in range(self.n_init if do_init else 1):
+            state = torch.zeros(nstate, dtype=torch.float64, device=self.device) if do_init else self._state
+            labels = None
+            if do_init:
+                lab = self._kmeans_labels(Xd.cpu().numpy().astype(np.float64), rs)
+                labels = torch.as_tensor(lab).to(self.device)
+                if self._label_broadcast is not None:
+                    self._label_broadcast(labels)
+            w, m, c = (torch.empty(K, device=self.device), torch.empty(K, R, device=self.device), torch.empty(K, R, R, device=self.device))
+            L.call("ladder_vbgmm_fit", Xd.data_ptr(), N, K, R, labels.data_ptr() if labels is not None else None, state.data_ptr(),
+                   ptype, wc, mp, float(self.reg_covar), float(self.tol), self.max_iter, w.data_ptr(), m.data_ptr(), c.data_ptr(),
+                   ws.data_ptr(), ws.numel(), st)
+            tail = state[-3:].cpu().numpy()                # the one host sync of the fit: lower_bound_, n_iter_, converged_
+            if tail[2] < 0:
+                raise ValueError("Fitting the mixture model failed because some components have ill-defined empirical covariance "
+                                 "(for instance caused by singleton or collapsed samples). Try to decrease the number of "
+                                 "components, increase reg_covar, or scale the input data.")
+            if best is None or tail[0] > best[0]:
+                best = (float(tail[0]), int(tail[1]), bool(tail[2] > 0), state, w, m, c)
+        self.lower_bound_, self.n_iter_, self.converged_, self._state, self.weights_dev, self.means_dev, self.covariances_dev = best
+        if not self.converged_ and self.max_iter > 0:
+            from sklearn.exceptions import ConvergenceWarning
+            warnings.warn("Best performing initialization did not converge. Try different init parameters, or increase max_iter, "
+                          "tol, or check for degenerate data.", ConvergenceWarning)
+        return self
+
+    # float64 views of the fitted parameters, as sklearn exposes them
+    def _unpack(self):
+        K = self.n_components
+        s = self._state.cpu().numpy()
+        R = self.means_dev.shape[1]
+        wa, wb = s[:K], s[K:2 * K]
+        means = s[4 * K:4 * K + K * R].reshape(K, R)
+        cov = s[4 * K + K * R:4 * K + K * R + K * R * R].reshape(K, R, R)
+        if self.weight_concentration_prior_type == "dirichlet_distribution":
+            w = wa / wa.sum()
+        else:
+            tot = wa + wb
+            w = wa / tot * np.hstack((1, np.cumprod((wb / tot)[:-1])))
+            w = w / w.sum()
+        return w, means.copy(), cov.copy()
+
+    @property
+    def weights_(self):
+        return self._unpack()[0]
+
+    @property
+    def means_(self):
+        return self._unpack()[1]
+
+    @property
+    def covariances_(self):
+        return self._unpack()[2]

@@ -175,9 +175,10 @@ def test_sg_feed_identity(golden_dir):
     assert f["crossEntropy_prior"] == f["crossEntropy_prior_sg"]
 
 
-def test_trainer_epoch_synthetic(tmp_path):
+@pytest.mark.parametrize("backend", ["hip", "sklearn"])
+def test_trainer_epoch_synthetic(tmp_path, backend):
     """The reference's trainer surface end to end on synthetic MNIST-shaped data: 2 epochs crossing the
-    SG-pretraining -> fitted-GM switch (sklearn fit on the host), result npz with the reference's keys."""
+    SG-pretraining -> fitted-GM switch (mixture fit on the device, or sklearn on the host), result npz with the reference's keys."""
     from ladder_latent_data_distribution_modelling_amd.codes.data_loader import DataGenerator
     from ladder_latent_data_distribution_modelling_amd.codes.models import MNISTModel_digit
     from ladder_latent_data_distribution_modelling_amd.codes.trainers import MNISTTrainer_joint_training
@@ -186,7 +187,8 @@ def test_trainer_epoch_synthetic(tmp_path):
     from make_golden import tiny_config
     cfg = tiny_config("mnist_digit")
     cfg.update(batch_size=64, num_epochs=2, sg_pretraining=1, accurate_fit=2, GM_fit_restart=1, synthetic_n_train=256,
-               synthetic_n_val=640, result_dir=str(tmp_path) + "/", checkpoint_dir=str(tmp_path) + "/", n_MC_samples=10)
+               synthetic_n_val=640, result_dir=str(tmp_path) + "/", checkpoint_dir=str(tmp_path) + "/", n_MC_samples=10,
+               gm_fit_backend=backend)
     data = DataGenerator(cfg, None)
     assert data.synthetic
     model = MNISTModel_digit(cfg)
@@ -197,7 +199,10 @@ def test_trainer_epoch_synthetic(tmp_path):
     for k in ("train_loss", "elbo_train", "val_loss", "code_elbo_train", "sigma"):
         assert k in res.files
     assert np.isfinite(res["elbo_train"]).all() and len(res["elbo_train"]) == 2 * tr.n_train_iter
-    assert os.path.isfile(os.path.join(str(tmp_path), "GM_prior_info.npz"))
+    gmi = np.load(os.path.join(str(tmp_path), "GM_prior_info.npz"))          # written by the "accurate" fit (base.py:772-777)
+    assert set(gmi.files) == {"w_active", "m_active", "K_active", "w_full", "m_full", "K_full"}
+    assert abs(gmi["w_full"].sum() - 1) < 1e-9 and gmi["K_full"].shape == (cfg["n_mixtures"], 2, 2)
+    assert isinstance(tr.gm_params[0], torch.Tensor) == (backend == "hip")    # device fit: the feed never left the GPU
     # checkpoints in the reference's own format (tf.train.Saver checkpoint-v2 bundle), restorable into a fresh model
     for f in ("vae-model.index", "vae-model.data-00000-of-00001", "vae-model.meta", "prior-model.index", "checkpoint"):
         assert os.path.isfile(os.path.join(str(tmp_path), f)), f
