@@ -184,10 +184,12 @@ enum { LADDER_S_SIGMA = 0, LADDER_S_MPE = 1, LADDER_S_ENTROPY_Z = 2, LADDER_S_XE
 typedef struct {
   int B_global, D, Z, R, L;
   int sigma_uses_mpe;    /* celeba: 1 ; mnist: TRAIN_sigma (models.py:158,325,597) */
-  int has_inner;         /* prior == "ours" */
+  int has_inner;         /* prior in {"ours", "hierarchical"} */
   int use_sg;            /* use_standard_gaussian_prior feed (base.py:318-320) */
   int clamp_inner_sigma; /* TRAIN_inner_sigma (base.py:210-212) */
   float inner_sigma_lb, inner_sigma_ub;
+  int hierarchical;      /* prior == "hierarchical" (base.py:331-359): crossEntropy_representation in closed form against N(0,I)
+                          * from P_MU2SD2_T (no mixture term), entropy_t with the reference's hard-coded dimension 2 */
 } LadderElboCfg;
 
 /* out[0] = sum |x-xhat|, out[1] = sum (x-xhat)^2 over n elements (fp64 accumulation across workgroups). */

@@ -29,7 +29,8 @@ S_COUNT = 32
 class LadderElboCfg(C.Structure):
     _fields_ = [("B_global", C.c_int), ("D", C.c_int), ("Z", C.c_int), ("R", C.c_int), ("L", C.c_int),
                 ("sigma_uses_mpe", C.c_int), ("has_inner", C.c_int), ("use_sg", C.c_int),
-                ("clamp_inner_sigma", C.c_int), ("inner_sigma_lb", C.c_float), ("inner_sigma_ub", C.c_float)]
+                ("clamp_inner_sigma", C.c_int), ("inner_sigma_lb", C.c_float), ("inner_sigma_ub", C.c_float),
+                ("hierarchical", C.c_int)]
 
 
 _p, _i, _f, _d, _z, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_uint64

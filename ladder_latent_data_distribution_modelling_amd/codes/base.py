@@ -45,6 +45,8 @@ class BaseTrain:
         cfg, eng = self.config, self.engine
         if cfg["prior"] == "standard_gaussian":
             return True, False
+        if cfg["prior"] == "hierarchical":            # codes/base.py:901-911: no mixture feed, no mask
+            return self.cur_epoch <= int(cfg["sg_pretraining"]), False
         use_sg = self.cur_epoch <= int(cfg["sg_pretraining"])
         if use_sg or self.gm_params is None:
             if getattr(self, "_fed", None) != "sg":

@@ -188,8 +188,10 @@ __global__ void elbo_finalize_kernel(const float* __restrict__ P, const float* _
     const double E = P[LADDER_P_CODE_ERR];
     const double code_ll = -E / (2.0 * isg * isg * B);
     const double rep_reg = -Z * log(isg) - 0.5 * Z * kLog2Pi;
-    const double entropy_t = -0.5 * R * kLog2Pi - 0.5 * R - (double)P[LADDER_P_LOG_SDT] / B;
-    const double xent_t = (double)P[LADDER_P_LOGP] / (L * B);
+    const double Re = cfg.hierarchical ? 2.0 : R;      // base.py:346-347 hard-codes 2 in the hierarchical branch
+    const double entropy_t = -0.5 * Re * kLog2Pi - 0.5 * Re - (double)P[LADDER_P_LOG_SDT] / B;
+    const double xent_t = cfg.hierarchical ? -0.5 * R * kLog2Pi - 0.5 * (double)P[LADDER_P_MU2SD2_T] / B   // base.py:350-353
+                                           : (double)P[LADDER_P_LOGP] / (L * B);
     const double elbo_prior = code_ll + rep_reg - entropy_t + xent_t;
     S[LADDER_S_INNER_SIGMA] = (float)isg;
     S[LADDER_S_MEAN_CODE_ERROR] = (float)((double)P[LADDER_P_CODE_ABS] / (B * Z));

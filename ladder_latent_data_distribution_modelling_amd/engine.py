@@ -617,9 +617,11 @@ class LadderEngine:
         self.ps = ParamStore(cfg, self.ctx, values, seed)
         self.encoder = Encoder(self.ctx, self.ps, cfg)
         self.decoder = (CelebADecoder if cfg["exp_name"] == "celeba" else MnistDecoder)(self.ctx, self.ps, cfg)
-        self.has_inner = cfg["prior"] == "ours"
-        if cfg["prior"] not in ("ours", "standard_gaussian"):
-            raise NotImplementedError("prior %r: the HIP path covers 'ours' and 'standard_gaussian' (SURVEY 8f4)" % cfg["prior"])
+        self.has_inner = cfg["prior"] in ("ours", "hierarchical")
+        self.hier = cfg["prior"] == "hierarchical"          # inner VAE against N(0,I): no mixture term, no mask (base.py:331-359)
+        if cfg["prior"] not in ("ours", "hierarchical", "standard_gaussian"):
+            raise NotImplementedError("prior %r: the HIP path covers 'ours', 'hierarchical' and 'standard_gaussian' "
+                                      "(SURVEY 8f4)" % cfg["prior"])
         self.inner = InnerVAE(self.ctx, self.ps, cfg) if self.has_inner else None
         self.Z = int(cfg["code_size"])
         self.R = int(cfg.get("representation_size", 1))
@@ -686,6 +688,7 @@ class LadderEngine:
         P = self.partials
         P.zero_()
         self._run_calls = 0
+        use_mask = bool(use_mask) and not self.hier
         cache = getattr(self, "_enc_cache", None)
         if reuse_encoder and cache is not None and cache[0] == self.ps.step["ae"] and not self._enc_needs_grad(parts):
             _, x, mu, sd_raw = cache
@@ -720,7 +723,7 @@ class LadderEngine:
             self.lat_t = (mu_t, sd_t, sdraw_t, eps_t, t)
             self.zhat = zhat
             self.gmm_grads = None
-            if "gmm" in parts:
+            if "gmm" in parts and not self.hier:
                 if self._gm_packed is None:
                     raise L.LadderHipError("set_mixture()/set_sg_mixture() must be called before a run that evaluates the GM prior")
                 eps_mc = self._noise(noise, "eps_mc", (self.Lmc, B, R))
@@ -735,7 +738,8 @@ class LadderEngine:
                                1 if (self.cfg["exp_name"] == "celeba" or int(self.cfg["TRAIN_sigma"]) == 1) else 0,
                                1 if inner_on else 0, 1 if use_sg else 0,
                                1 if (self.has_inner and int(self.cfg["TRAIN_inner_sigma"]) == 1) else 0,
-                               float(self.cfg.get("inner_sigma_lb", 0.0)), float(self.cfg.get("inner_sigma_ub", 0.0)))
+                               float(self.cfg.get("inner_sigma_lb", 0.0)), float(self.cfg.get("inner_sigma_ub", 0.0)),
+                               1 if self.hier else 0)
         L.call("ladder_elbo_finalize", _p(P), _p(self.ps.w["sigma/Variable"]),
                _p(self.ps.w["inner_sigma/Variable"]) if self.has_inner else None, ecfg, _p(self.scalars), st)
         if self._run_calls:
@@ -775,8 +779,9 @@ class LadderEngine:
             L.call("ladder_code_grad", _p(z), _p(self.zhat), _p(sd), int(self.use_mask), _p(self.scalars), _p(dz), _p(dzhat), B, Z, st)
             dt = self.inner.decode_backward(dzhat, wgrad=False)
             dmu_t, dsdraw_t = ctx.empty(B, R), ctx.empty(B, R)
-            L.call("ladder_latent_bwd", _p(dt), _p(mu_t), _p(sd_t), _p(sdraw_t), _p(eps_t), _p(self.gmm_grads[0]),
-                   _p(self.gmm_grads[1]), -1.0, _p(self.scalars), 1, _p(dmu_t), _p(dsdraw_t), B, R, st)
+            gm_mu, gm_sd = (None, None) if self.hier else self.gmm_grads       # hierarchical: closed-form N(0,I) term (mode bit 1)
+            L.call("ladder_latent_bwd", _p(dt), _p(mu_t), _p(sd_t), _p(sdraw_t), _p(eps_t), _p(gm_mu),
+                   _p(gm_sd), -1.0, _p(self.scalars), 3 if self.hier else 1, _p(dmu_t), _p(dsdraw_t), B, R, st)
             add_(ctx, dz, self.inner.encode_backward(dmu_t, dsdraw_t, wgrad=False, need_dz=True))
         else:
             mode = 3
@@ -793,8 +798,9 @@ class LadderEngine:
         L.call("ladder_code_grad", _p(z), _p(self.zhat), _p(sd), int(self.use_mask), _p(self.scalars), None, _p(dzhat), B, Z, st)
         dt = self.inner.decode_backward(dzhat, wgrad=True)
         dmu_t, dsdraw_t = ctx.empty(B, R), ctx.empty(B, R)
-        L.call("ladder_latent_bwd", _p(dt), _p(mu_t), _p(sd_t), _p(sdraw_t), _p(eps_t), _p(self.gmm_grads[0]),
-               _p(self.gmm_grads[1]), -1.0, _p(self.scalars), 1, _p(dmu_t), _p(dsdraw_t), B, R, st)
+        gm_mu, gm_sd = (None, None) if self.hier else self.gmm_grads
+        L.call("ladder_latent_bwd", _p(dt), _p(mu_t), _p(sd_t), _p(sdraw_t), _p(eps_t), _p(gm_mu),
+               _p(gm_sd), -1.0, _p(self.scalars), 3 if self.hier else 1, _p(dmu_t), _p(dsdraw_t), B, R, st)
         self.inner.encode_backward(dmu_t, dsdraw_t, wgrad=True, need_dz=False)
 
     # -- the four runs --------------------------------------------------------------------------

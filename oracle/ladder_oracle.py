@@ -529,7 +529,8 @@ def forward(config, P, x, eps_z, eps_t=None, eps_mc=None, gm=None,
     prior = config["prior"]
     if prior == "standard_gaussian":
         out["crossEntropy_prior"] = out["crossEntropy_prior_sg"]
-    elif prior == "ours":
+    elif prior in ("ours", "hierarchical"):
+        hier = prior == "hierarchical"
         R = int(config["representation_size"])
         mu_t, sd_t = inner_encoder(config, P, z)
         t = mu_t + sd_t * eps_t                                  # base.py:164-167
@@ -544,22 +545,27 @@ def forward(config, P, x, eps_z, eps_t=None, eps_mc=None, gm=None,
         out["mean_code_error"] = ar((zhat - z).abs().sum()) / (Bg * Z)
         out["std_dev_representation"] = ar(sd_t.sum(0)) / Bg
         err = (z - zhat) ** 2                                    # base.py:286-297
-        if use_mask:
+        if use_mask and not hier:                                # the hierarchical branch never masks (base.py:334)
             err = torch.where(sd_z > 1.0, torch.zeros_like(err), err)
         out["code_reconstruction_likelihood"] = -ar((err / (2.0 * inner_sigma ** 2)).sum()) / Bg
         out["code_l1_reconstruction_error"] = ar(torch.sqrt(err).sum()) / Bg
         out["representation_regularisor"] = -Z * torch.log(inner_sigma) - 0.5 * Z * LOG_2PI
-        out["entropy_t"] = ar((-0.5 * R * LOG_2PI - 0.5 * R - 0.5 * (2.0 * torch.log(sd_t)).sum(1)).sum()) / Bg
-        L = eps_mc.shape[0]
-        t_mc = mu_t.unsqueeze(0) + sd_t.unsqueeze(0) * eps_mc    # base.py:308-311
-        lp = gmm_log_prob(t_mc, gm["weights"], gm["means"], gm["covs"])
-        out["crossEntropy_representation"] = ar(lp.sum()) / (L * Bg)
+        Re = 2 if hier else R                                    # base.py:346-347 hard-codes "2" in the hierarchical entropy
+        out["entropy_t"] = ar((-0.5 * Re * LOG_2PI - 0.5 * Re - 0.5 * (2.0 * torch.log(sd_t)).sum(1)).sum()) / Bg
+        if hier:                                                 # base.py:350-353: closed form against N(0, I)
+            out["crossEntropy_representation"] = ar((-0.5 * R * LOG_2PI
+                                                     - 0.5 * ((mu_t ** 2).sum(1) + (sd_t ** 2).sum(1))).sum()) / Bg
+        else:
+            L = eps_mc.shape[0]
+            t_mc = mu_t.unsqueeze(0) + sd_t.unsqueeze(0) * eps_mc    # base.py:308-311
+            lp = gmm_log_prob(t_mc, gm["weights"], gm["means"], gm["covs"])
+            out["crossEntropy_representation"] = ar(lp.sum()) / (L * Bg)
         out["elbo_prior"] = (out["code_reconstruction_likelihood"] + out["representation_regularisor"]
                              - out["entropy_t"] + out["crossEntropy_representation"])
         out["crossEntropy_prior"] = out["crossEntropy_prior_sg"] if use_sg else out["elbo_prior"]
         out["loss_prior"] = -out["elbo_prior"]
     else:
-        raise NotImplementedError("oracle covers prior in {'ours','standard_gaussian'}")
+        raise NotImplementedError("oracle covers prior in {'ours','hierarchical','standard_gaussian'}")
 
     diff = x - xhat                                             # base.py:374-396
     out["l2_reconstruction_error"] = ar((diff ** 2).sum()) / Bg
