@@ -3,8 +3,9 @@
 //
 //   conv3x3_halo_kernel     3x3 / stride 1 / SAME forward and backward-data of large maps: 8x32-pixel x 128-channel tile,
 //                           the input halo of each 16-channel slab staged once in LDS for all 9 taps (dominant kernel, ~134 TF).
-//   wgrad3x3_halo_kernel    filter gradient of the same layers, all 9 taps fused over LDS-DMA-staged 1x32-pixel patches,
-//                           12 balanced wavefronts (~105 TF).
+//   wgrad3x3_halo_kernel    filter gradient of the same layers (Cin % 64 == 0), all 9 taps fused over LDS-DMA-staged 1x32-pixel patches,
+//                           12 balanced wavefronts x 6 MFMA tiles (~120 TF; ablation: 126 without staging, 133 without the
+//                           per-patch barrier as well).
 //   igemm_fwd_kernel<...>   everything else that is forward-shaped (conv fwd / bwd_data of any size, stride, kernel; dense):
 //                           C[M x N] = A_gather[M x K] * B[K x N], M = pixels, N = Cout, K = (tap, ci).  A is gathered on the
 //                           fly from the NHWC input (no im2col buffer); B is the HWIO filter bank viewed as a row-major
@@ -971,15 +972,17 @@ int run_colsum(const float* x, float* out, size_t rows, int C, void* ws, size_t 
 
 // ---------------------------------------------------------------------------------------------------------------
 // Filter gradient of a 3x3 / stride 1 / SAME convolution with an LDS-staged input halo patch (tap-fused).
-// One workgroup = 12 wavefronts = the 9 filter taps x 4 output-channel blocks (36 MFMA tiles of 32x32, 3 per wavefront: a
-// balanced 3 waves per SIMD) of a (32 input channels x 128 output channels) slab of dW, reduced over a range of 1x32-pixel
-// patches.  Per patch the 3x(32+2) input halo (32 channels, 13 KB) and the 32x128 dY tile (16 KB) are brought into LDS ONCE by
-// LDS-DMA (global_load_lds, no staging registers) and serve all 9 taps; the generic kernel streams both operands once per
-// tap (~2.5x the bytes per MAC, 5x over-fetch at the fabric).  A fragment = halo shifted by (r,s), lane = ci; B = dY rows.
-constexpr int WH_CI = 32, WH_CO = 128, WH_PH = 1, WH_PW = 32, WH_HW = WH_PW + 2, WH_HH = WH_PH + 2;
+// One workgroup = 12 wavefronts (a balanced 3 per SIMD) owns a (64 input channels x 128 output channels) slab of dW for all 9
+// taps = 72 MFMA tiles of 32x32, reduced over a range of 1x32-pixel patches.  Wavefront -> (filter row r, input-channel half cb,
+// output-channel pair njp); its 6 tiles are the taps (r, 0..2) x the 2 channel blocks of the pair: per 2-pixel k-step it reads
+// 3 halo fragments (one per column shift) and 2 dY fragments and issues 6 MFMAs -- 0.83 LDS reads per MFMA (the first version
+// of this kernel: 2.0, 111 TF/s; shared-dY assignment: 1.33, 119 TF/s).  Per patch the 3x(32+2) input halo (64 channels, 26 KB)
+// and the 32x128 dY tile (16 KB) are brought into LDS ONCE by LDS-DMA (global_load_lds, no staging registers) and serve all 9
+// taps; the generic kernel streams both operands once per tap.  A fragment = halo shifted by (r,s), lane = ci; B = dY rows.
+constexpr int WH_CI = 64, WH_CO = 128, WH_PH = 1, WH_PW = 32, WH_HW = WH_PW + 2, WH_HH = WH_PH + 2;
 constexpr int WH_THREADS = 768, WH_PIX = WH_PH * WH_PW;
 constexpr int WH_XU = WH_HH * WH_HW * (WH_CI / 4), WH_DU = WH_PIX * (WH_CO / 4);           // float4 units per patch
-constexpr int WH_XN = (WH_XU + WH_THREADS - 1) / WH_THREADS, WH_DN = (WH_DU + WH_THREADS - 1) / WH_THREADS;   // 2, 2
+constexpr int WH_XN = (WH_XU + WH_THREADS - 1) / WH_THREADS, WH_DN = (WH_DU + WH_THREADS - 1) / WH_THREADS;   // 3, 2
 constexpr int WH_XF = WH_HH * WH_HW * WH_CI, WH_DF = WH_PIX * WH_CO;                       // floats per buffer
 #ifndef IGEMM_WH_MINW
 #define IGEMM_WH_MINW 3
@@ -997,27 +1000,18 @@ __global__ __launch_bounds__(WH_THREADS, IGEMM_WH_MINW) void wgrad3x3_halo_kerne
   const int WP = W / WH_PW, HP = H / WH_PH;
   const int q_total = N * HP * WP;
   const int q0 = blockIdx.y * patches_per_split, q1 = min(q_total, q0 + patches_per_split);
-  // tiles 3wv .. 3wv+2 of the (tap, channel block) grid, tap = t >> 2, nj = t & 3
-  int a_off[3], b_off[3], t_tap[3], t_nj[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int t = 3 * wv + i;
-    t_tap[i] = t >> 2;
-    t_nj[i] = t & 3;
-    const int r = t_tap[i] / 3, sft = t_tap[i] - 3 * r;
-    a_off[i] = (r * WH_HW + sft + lh) * WH_CI + l31;
-    b_off[i] = WH_XF + lh * WH_CO + t_nj[i] * 32 + l31;
-  }
-  // bias: the centre tap (4) tiles are t = 16..19 -> waves 5 (t=15,16,17 -> i=1,2) and 6 (t=18,19,20 -> i=0,1); each of those
-  // tiles covers one channel block nj exactly once.
-  const bool do_bias = (bias_part != nullptr) && (ci0 == 0);
+  const int r = wv >> 2, cb = (wv >> 1) & 1, njp = wv & 1;
+  const int a_off = (r * WH_HW + lh) * WH_CI + cb * 32 + l31;          // + s * WH_CI for the column shift s
+  const int b_off = WH_XF + lh * WH_CO + njp * 64 + l31;               // + j * 32 for the second block of the pair
+  // bias: the centre-tap tiles (r = 1, s = 1) of the cb = 0 wavefronts cover every output channel exactly once.
+  const bool do_bias = (bias_part != nullptr) && (ci0 == 0) && r == 1 && cb == 0;
 
-  f32x16 acc[3];
+  f32x16 acc[6];                                       // [j][s]
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < 6; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-  float bsum[3] = {0.f, 0.f, 0.f};
+  float bsum[2] = {0.f, 0.f};
 
   auto stage_patch = [&](int q, int buf) {
     const int n = q / (HP * WP), rem = q - n * (HP * WP);
@@ -1028,7 +1022,7 @@ __global__ __launch_bounds__(WH_THREADS, IGEMM_WH_MINW) void wgrad3x3_halo_kerne
     for (int i = 0; i < WH_XN; ++i) {
       const int u = tid + i * WH_THREADS;
       if (u < WH_XU) {
-        const int pix = u >> 3, q4 = u & 7;
+        const int pix = u >> 4, q4 = u & 15;
         const int hr = pix / WH_HW, hc = pix - hr * WH_HW;
         const int hi = h0 - 1 + hr, wi = w0 - 1 + hc;
         const bool ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
@@ -1057,18 +1051,19 @@ __global__ __launch_bounds__(WH_THREADS, IGEMM_WH_MINW) void wgrad3x3_halo_kerne
     const float* base = &lds[buf * (WH_XF + WH_DF)];
 #pragma unroll 4
     for (int ks = 0; ks < WH_PIX / 2; ++ks) {
-      float a[3], b[3];
+      float a[3], b[2];
       const int arow = ((ks >> 4) * WH_HW + ((2 * ks) & 31)) * WH_CI;     // pixel 2ks(+lh) of the patch -> halo row/col
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        a[i] = base[a_off[i] + arow];
-        b[i] = base[b_off[i] + 2 * ks * WH_CO];
-      }
+      for (int s = 0; s < 3; ++s) a[s] = base[a_off + s * WH_CI + arow];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc[i], 0, 0, 0);
+      for (int j = 0; j < 2; ++j) b[j] = base[b_off + j * 32 + 2 * ks * WH_CO];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) acc[j * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[j], acc[j * 3 + s], 0, 0, 0);
       if (do_bias) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) bsum[i] += b[i];
+        bsum[0] += b[0];
+        bsum[1] += b[1];
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's LDS-DMA pieces of the next patch have landed
@@ -1076,16 +1071,19 @@ __global__ __launch_bounds__(WH_THREADS, IGEMM_WH_MINW) void wgrad3x3_halo_kerne
   }
 
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    float* o = out + ((size_t)blockIdx.y * 9 + t_tap[i]) * Cin * Cout;
-    const int n = co0 + t_nj[i] * 32 + l31;
+  for (int j = 0; j < 2; ++j) {
+    const int n = co0 + njp * 64 + j * 32 + l31;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int ci = ci0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-      if (n < Cout) o[(size_t)ci * Cout + n] = acc[i][e];
+    for (int s = 0; s < 3; ++s) {
+      float* o = out + ((size_t)blockIdx.y * 9 + (3 * r + s)) * Cin * Cout;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ci = ci0 + cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (n < Cout) o[(size_t)ci * Cout + n] = acc[j * 3 + s][e];
+      }
     }
-    if (do_bias && t_tap[i] == 4) {
-      const float v = bsum[i] + __shfl_down(bsum[i], 32, 64);   // odd + even pixels of the k-step pairs
+    if (do_bias) {
+      const float v = bsum[j] + __shfl_down(bsum[j], 32, 64);   // odd + even pixels of the k-step pairs
       if (lh == 0 && n < Cout) bias_part[(size_t)blockIdx.y * Cout + n] = v;
     }
   }

@@ -66,8 +66,10 @@ CONV_CASES = [
     (16, 4, 4, 512, 128, 3, 1, "valid", None),         # split-K regime, encoder conv6 style
     (16, 64, 64, 32, 256, 3, 1, "same", "leaky_relu"), # LDS-halo kernel (>=512 workgroups), fwd + bwd_data (Cin'=256)
     (64, 32, 32, 16, 160, 3, 1, "same", None),         # LDS-halo kernel, Cout tile edge (160 = 128 + 32)
-    (32, 64, 64, 32, 128, 3, 1, "same", None),         # halo filter-gradient kernel (>= 4096 patches)
-    (8, 128, 128, 64, 160, 3, 1, "same", "leaky_relu"),  # halo filter-gradient kernel: 2 ci slabs, Cout edge
+    (32, 64, 64, 64, 128, 3, 1, "same", None),         # halo filter-gradient kernel (>= 4096 patches, Cin % 64 == 0)
+    (8, 128, 128, 64, 160, 3, 1, "same", "leaky_relu"),  # halo filter-gradient kernel: Cout edge (second 128-block has 32 channels)
+    (32, 64, 64, 128, 64, 3, 1, "same", None),         # halo filter-gradient kernel: 2 ci slabs, Cout = 64 (half a channel pair idle)
+    (32, 64, 64, 32, 128, 3, 1, "same", None),         # Cin = 32: halo forward / backward-data, generic filter gradient
 ]
 
 
