@@ -236,6 +236,13 @@ int ladder_adam_clip_dev(float* theta, const float* g, float* m, float* v, size_
 int ladder_randn_dev(float* out, size_t n, uint64_t seed, const uint64_t* offset_base, uint64_t offset_add, ladder_stream_t stream);
 int ladder_u64_add(uint64_t* p, uint64_t inc, ladder_stream_t stream);
 
+/* ---------------------------------------------------------------- N14: minibatch assembly (the input pipeline)
+ * models.py:354-371 (CelebA: uint8 HWC pixels * 1/255), data_loader.py:19-33 (MNIST floats), shuffle + batch of models.py:33-40:
+ * out[b, :] = scale * float(src[idx[b], :]) for a data set resident in device memory; src is uint8 (src_is_u8) or float32 rows of
+ * D elements, idx = int64 row indices of the minibatch (a slice of the epoch's permutation). */
+int ladder_gather_rows(const void* src, int src_is_u8, const int64_t* idx, float* out, int B, int64_t D, float scale,
+                       ladder_stream_t stream);
+
 /* ---------------------------------------------------------------- N13: the mixture fit that produces the hyper-prior feed
  * sklearn.mixture.BayesianGaussianMixture(K, 'full', weight_concentration_prior_type=..., weight_concentration_prior=0.1,
  * warm_start=True).fit(samples) of codes/base.py:93-99 (per-epoch "fast" fit, 681-721) and 723-789 ("accurate" fit), as ONE

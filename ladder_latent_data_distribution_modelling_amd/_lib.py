@@ -81,6 +81,7 @@ PROTOTYPES = {
     "ladder_randn_dev": (_i, [_p, _z, _u64, _p, _u64, _p]),
     "ladder_u64_add": (_i, [_p, _u64, _p]),
     "ladder_crc32c_extend": (C.c_uint32, [C.c_uint32, _p, _z]),
+    "ladder_gather_rows": (_i, [_p, _i, _p, _p, _i, C.c_int64, _f, _p]),
     "ladder_vbgmm_state_doubles": (_z, [_i, _i]),
     "ladder_vbgmm_workspace_bytes": (_z, [_i, _i]),
     "ladder_vbgmm_fit": (_i, [_p, _i, _i, _i, _p, _p, _i, _d, _d, _d, _d, _i, _p, _p, _p, _p, _z, _p]),

@@ -125,6 +125,49 @@ class BatchIterator:
         return np.ascontiguousarray(self.images[idx], dtype=np.float32)
 
 
+class DeviceBatchIterator:
+    """BatchIterator over a data set that is RESIDENT IN HBM (MI355X: 288 GB; the CelebA train split is 8.8 GB as uint8).
+    Same epoch-seeded permutation and drop_remainder as BatchIterator; `next()` returns a float32 device tensor assembled by
+    `ladder_gather_rows` (index gather + uint8 -> float * 1/255 in one pass), so the hot loop does no host work and no
+    host->device copy.  `images`: numpy / torch array [n, ...] of uint8 (scaled by 1/255, models.py:361,370) or float32."""
+
+    def __init__(self, images, batch_size, seed=0, shuffle=True, device="cuda:0"):
+        import torch
+        from .. import _lib as L
+        self._torch, self._L = torch, L
+        if isinstance(images, torch.Tensor):
+            t = images
+        else:
+            a = np.ascontiguousarray(images)
+            if a.dtype != np.uint8:
+                a = a.astype(np.float32, copy=False)
+            t = torch.as_tensor(a)
+        self.data = t.to(device).contiguous()                 # one upload; callers cache and pass the device tensor back in
+        if self.data.dtype not in (torch.uint8, torch.float32):
+            raise TypeError("device-resident data must be uint8 or float32, got %s" % self.data.dtype)
+        self.is_u8 = self.data.dtype == torch.uint8
+        self.shape = tuple(self.data.shape[1:])
+        self.D = int(np.prod(self.shape))
+        self.bs = int(batch_size)
+        self.rng = np.random.default_rng(seed)
+        self.shuffle = shuffle
+        self._order, self._pos = None, 0
+
+    def next(self):
+        torch, L = self._torch, self._L
+        n = self.data.shape[0]
+        if self._order is None or self._pos + self.bs > n:
+            order = self.rng.permutation(n) if self.shuffle else np.arange(n)
+            self._order = torch.as_tensor(order.astype(np.int64)).to(self.data.device)      # one small upload per epoch
+            self._pos = 0
+        idx = self._order[self._pos:self._pos + self.bs]
+        self._pos += self.bs
+        out = torch.empty((self.bs,) + self.shape, dtype=torch.float32, device=self.data.device)
+        L.call("ladder_gather_rows", self.data.data_ptr(), 1 if self.is_u8 else 0, idx.data_ptr(), out.data_ptr(), self.bs, self.D,
+               (1.0 / 255.0) if self.is_u8 else 1.0, torch.cuda.current_stream(self.data.device).cuda_stream)
+        return out
+
+
 class DataGenerator:
     def __init__(self, config, sess=None):
         self.config, self.sess = config, sess
@@ -134,7 +177,7 @@ class DataGenerator:
             self.load_MNIST_dataset("digit" if exp == "mnist_digit" else "fashion")
         elif exp == "celeba":
             self.n_train, self.n_val = 180000, 20000          # data_loader.py:15-17
-            self._celeba = {}
+            self._celeba, self._celeba_u8 = {}, {}
         else:
             raise ValueError("unknown exp_name %r" % exp)
 
@@ -189,29 +232,40 @@ class DataGenerator:
             self.class_name = ("top", "trousers", "pullover", "dress", "coat", "sandal", "shirt", "sneaker", "bag", "ankle boot")
 
     # ---------------------------------------------------------------- CelebA
-    def celeba_images(self, split, limit=None):
-        """float32 [n,H,W,C] in [0,1] for split in {'train','val','test'} (models.py:354-371)."""
-        if split in self._celeba:
-            return self._celeba[split]
+    def celeba_images_u8(self, split, limit=None):
+        """uint8 [n,H,W,C] exactly as stored in celebA_<split>.tfrecords (tf.Example, bytes feature 'X', models.py:354-371);
+        seeded synthetic uint8 images when the file is absent."""
+        key = (split, limit)
+        if key in self._celeba_u8:
+            return self._celeba_u8[key]
         H, W, Cc = int(self.config["dim_input_x"]), int(self.config["dim_input_y"]), int(self.config["dim_input_channel"])
         path = os.path.join(self.config.get("data_path", ""), "celebA_%s.tfrecords" % split)
         if os.path.isfile(path):
             imgs = []
             for rec in tfrecord_iterator(path):
-                raw = np.frombuffer(parse_example_bytes(rec), np.uint8)
-                imgs.append(raw.reshape(H, W, Cc))
+                imgs.append(np.frombuffer(parse_example_bytes(rec), np.uint8).reshape(H, W, Cc))
                 if limit and len(imgs) >= limit:
                     break
-            arr = np.stack(imgs).astype(np.float32) * np.float32(1.0 / 255)
+            arr = np.stack(imgs)
         else:
             self.synthetic = True
             bs = int(self.config["batch_size"])
             n = int(self.config.get("synthetic_n_train", 4 * bs)) if split == "train" else 2 * bs
             rng = np.random.default_rng({"train": 0, "val": 1, "test": 2}[split])
-            arr = rng.random((n, H, W, Cc), dtype=np.float32)
+            arr = rng.integers(0, 256, (n, H, W, Cc), dtype=np.uint8)
+            if limit:
+                arr = arr[:limit]
             if split == "train":
                 self.n_train = n
             elif split == "val":
                 self.n_val = n
-        self._celeba[split] = arr
+        self._celeba_u8[key] = arr
         return arr
+
+    def celeba_images(self, split, limit=None):
+        """float32 [n,H,W,C] in [0,1] = uint8 * 1/255 (models.py:361,370).  The trainers use the uint8 form (HBM-resident,
+        normalised on the device); this float view is for small slices (test batch, demos)."""
+        key = (split, limit)
+        if key not in self._celeba:
+            self._celeba[key] = self.celeba_images_u8(split, limit).astype(np.float32) * np.float32(1.0 / 255)
+        return self._celeba[key]

@@ -2,7 +2,7 @@
 import numpy as np
 
 from .base import BaseTrain, BaseTrain_joint  # noqa: F401
-from .data_loader import BatchIterator
+from .data_loader import BatchIterator, DeviceBatchIterator
 
 
 class _JointEpochMixin:
@@ -10,6 +10,20 @@ class _JointEpochMixin:
 
     def _iterators(self):
         raise NotImplementedError
+
+    def _make_iterator(self, key, images, shuffle=True):
+        """config["device_resident_data"] (default 1): the rank's shard of the split is uploaded to HBM once (uint8 for CelebA)
+        and minibatches are gathered + normalised on the device; 0 keeps the host iterator (float32 numpy batches)."""
+        bs = int(self.config["batch_size"])
+        if not int(self.config.get("device_resident_data", 1)):
+            img = images() if callable(images) else images
+            if img.dtype == np.uint8:
+                img = img.astype(np.float32) * np.float32(1.0 / 255)
+            return BatchIterator(img, bs, seed=self.cur_epoch, shuffle=shuffle)
+        cache = self.__dict__.setdefault("_dev_sets", {})
+        if key not in cache:
+            cache[key] = DeviceBatchIterator(images() if callable(images) else images, bs, device=self.engine.ctx.device).data
+        return DeviceBatchIterator(cache[key], bs, seed=self.cur_epoch, shuffle=shuffle, device=self.engine.ctx.device)
 
     def _prior_training_on(self):
         cfg = self.config
@@ -64,9 +78,8 @@ class MNISTTrainer_joint_training(_JointEpochMixin, BaseTrain_joint):
         return images[c.rank::c.world] if c.on else images
 
     def _iterators(self):
-        bs = int(self.config["batch_size"])
-        return (BatchIterator(self._shard(self.data.train_set["image"]), bs, seed=self.cur_epoch),
-                BatchIterator(self._shard(self.data.val_set["image"]), bs, seed=self.cur_epoch))
+        return (self._make_iterator("train", lambda: self._shard(self.data.train_set["image"])),
+                self._make_iterator("val", lambda: self._shard(self.data.val_set["image"])))
 
     def compute_cur_lr(self):
         self.cur_lr = float(self.config["learning_rate_ae"]) * (0.99 ** (self.cur_epoch - 1))     # trainers.py:30
@@ -76,8 +89,8 @@ class CelebATrainer_joint_training(_JointEpochMixin, BaseTrain_joint):
     def __init__(self, sess, model, data, config):
         super().__init__(sess, model, data, config)
         bs = int(config["batch_size"])
-        self.test_batch = self.data.celeba_images("test")[:bs]
-        self._train, self._val = self.data.celeba_images("train"), self.data.celeba_images("val")
+        self.test_batch = self.data.celeba_images("test", limit=bs)[:bs]
+        self._train, self._val = self.data.celeba_images_u8("train"), self.data.celeba_images_u8("val")     # uint8, as on disk
         world = self.engine.ctx.comm.world
         n_train = self.data.n_train if not self.data.synthetic else self._train.shape[0]
         n_val = self.data.n_val if not self.data.synthetic else self._val.shape[0]
@@ -85,10 +98,9 @@ class CelebATrainer_joint_training(_JointEpochMixin, BaseTrain_joint):
         self.n_val_iter = n_val // (bs * world)
 
     def _iterators(self):
-        c, bs = self.engine.ctx.comm, int(self.config["batch_size"])
-        tr = self._train[c.rank::c.world] if c.on else self._train
-        va = self._val[c.rank::c.world] if c.on else self._val
-        return BatchIterator(tr, bs, seed=self.cur_epoch), BatchIterator(va, bs, seed=self.cur_epoch, shuffle=False)
+        c = self.engine.ctx.comm
+        return (self._make_iterator("train", lambda: self._train[c.rank::c.world] if c.on else self._train),
+                self._make_iterator("val", lambda: self._val[c.rank::c.world] if c.on else self._val, shuffle=False))
 
     def compute_cur_lr(self):
         """Piecewise schedule of codes/trainers.py:200-209."""

@@ -519,6 +519,38 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict
   reinterpret_cast<T*>(dx)[((size_t)row * W + ix) * CV + cv] = acc;
 }
 
+// ----------------------------------------------------------------------------- minibatch assembly from an HBM-resident data set
+// out[b, :] = scale * float(src[idx[b], :]): the reference's input pipeline (uint8 CelebA pixels * 1/255, models.py:354-371;
+// MNIST floats, data_loader.py:19-33) for a data set that lives in device memory (CelebA train split as uint8 = 8.8 GB of the
+// 288 GB): shuffle by index, gather and normalise in one pass, no host work per step.  16 source bytes -> 16 floats per thread.
+__global__ __launch_bounds__(256) void gather_rows_u8_kernel(const unsigned char* __restrict__ src, const long long* __restrict__ idx,
+                                                             float* __restrict__ out, int B, long long D, float scale) {
+  const long long D16 = D >> 4;
+  const long long total = (long long)B * D16;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / D16);
+    const long long c = i - (long long)b * D16;
+    const uint4 v = *reinterpret_cast<const uint4*>(src + idx[b] * D + c * 16);
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    float4* o = reinterpret_cast<float4*>(out + (long long)b * D + c * 16);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      o[k] = make_float4((float)(w[k] & 0xFF) * scale, (float)((w[k] >> 8) & 0xFF) * scale, (float)((w[k] >> 16) & 0xFF) * scale,
+                         (float)(w[k] >> 24) * scale);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_scalar_kernel(const T* __restrict__ src, const long long* __restrict__ idx,
+                                                                 float* __restrict__ out, int B, long long D, float scale) {
+  const long long total = (long long)B * D;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / D);
+    const long long c = i - (long long)b * D;
+    out[i] = (float)src[idx[b] * D + c] * scale;
+  }
+}
+
 __global__ void d2s_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C, int r, int inverse) {
   // forward: y[n, h*r+i, w*r+j, c'] = x[n, h, w, (i*r+j)*C' + c'] ; inverse swaps the roles.
   const int Cp = C / (r * r);
@@ -720,6 +752,24 @@ int ladder_resize_bilinear_fwd(const float* x, float* y, int N, int H, int W, in
 
 int ladder_resize_bilinear_bwd(const float* dy, float* dx, int N, int H, int W, int C, int OH, int OW, ladder_stream_t stream) {
   return resize_launch(false, dy, dx, N, H, W, C, OH, OW, stream);
+}
+
+int ladder_gather_rows(const void* src, int src_is_u8, const int64_t* idx, float* out, int B, int64_t D, float scale,
+                       ladder_stream_t stream) {
+  if (B <= 0 || D <= 0) return LADDER_E_SHAPE;
+  const long long total = (long long)B * D;
+  if (src_is_u8 && (D % 16) == 0 && ladder_aligned16(src) && ladder_aligned16(out)) {
+    hipLaunchKernelGGL(gather_rows_u8_kernel, dim3(ew_grid((size_t)(total / 16))), dim3(256), 0, stream, (const unsigned char*)src,
+                       (const long long*)idx, out, B, (long long)D, scale);
+  } else if (src_is_u8) {
+    hipLaunchKernelGGL(gather_rows_scalar_kernel<unsigned char>, dim3(ew_grid((size_t)total)), dim3(256), 0, stream,
+                       (const unsigned char*)src, (const long long*)idx, out, B, (long long)D, scale);
+  } else {
+    hipLaunchKernelGGL(gather_rows_scalar_kernel<float>, dim3(ew_grid((size_t)total)), dim3(256), 0, stream, (const float*)src,
+                       (const long long*)idx, out, B, (long long)D, scale);
+  }
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
 }
 
 int ladder_depth_to_space(const float* x, float* y, int N, int H, int W, int C, int r, int inverse, ladder_stream_t stream) {

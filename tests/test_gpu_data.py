@@ -1,0 +1,52 @@
+"""HBM-resident input pipeline: `ladder_gather_rows` / DeviceBatchIterator against the host BatchIterator (bit-identical
+minibatches, same epoch-seeded order), and the CelebA trainer end to end from TFRecord files (uint8 on disk -> uint8 in HBM ->
+float32 * 1/255 on the device)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape,dtype", [((40, 16, 16, 3), np.uint8), ((33, 5, 7, 3), np.uint8), ((50, 28, 28, 1), np.float32)])
+def test_device_batch_iterator_equals_host_iterator(shape, dtype):
+    from ladder_latent_data_distribution_modelling_amd.codes.data_loader import BatchIterator, DeviceBatchIterator
+    rng = np.random.default_rng(1)
+    imgs = rng.integers(0, 256, shape).astype(np.uint8) if dtype == np.uint8 else rng.random(shape, dtype=np.float32)
+    host_src = imgs.astype(np.float32) * np.float32(1.0 / 255) if dtype == np.uint8 else imgs      # models.py:361,370
+    for shuffle in (True, False):
+        h = BatchIterator(host_src, 8, seed=5, shuffle=shuffle)
+        d = DeviceBatchIterator(imgs, 8, seed=5, shuffle=shuffle)
+        for _ in range(2 * (shape[0] // 8) + 1):                      # crosses two epoch boundaries (drop_remainder + reshuffle)
+            a, b = h.next(), d.next()
+            assert b.is_cuda and b.dtype == torch.float32 and tuple(b.shape) == a.shape
+            assert np.array_equal(a, b.cpu().numpy())
+
+
+def test_celeba_trainer_from_tfrecords(tmp_path):
+    from ladder_latent_data_distribution_modelling_amd.codes import data_loader as dl
+    from ladder_latent_data_distribution_modelling_amd.codes.models import CelebAModel_densenet
+    from ladder_latent_data_distribution_modelling_amd.codes.trainers import CelebATrainer_joint_training
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import tiny_config
+    rng = np.random.default_rng(0)
+    base = rng.integers(0, 256, (1, 128, 128, 3))
+    for split, n in (("train", 8), ("val", 4), ("test", 2)):
+        imgs = np.clip(base + rng.integers(-40, 40, (n, 128, 128, 3)), 0, 255).astype(np.uint8)
+        dl.write_tfrecord(str(tmp_path / ("celebA_%s.tfrecords" % split)), imgs)
+    cfg = tiny_config("celeba")
+    cfg.update(batch_size=2, num_epochs=1, sg_pretraining=0, accurate_fit=5, GM_fit_restart=1, n_mixtures=2, data_path=str(tmp_path) + "/",
+               result_dir=str(tmp_path) + "/", checkpoint_dir=str(tmp_path) + "/")
+    data = dl.DataGenerator(cfg, None)
+    data.n_train, data.n_val = 8, 4                       # (the reference hard-codes the 180 000 / 20 000 split sizes)
+    model = CelebAModel_densenet(cfg)
+    tr = CelebATrainer_joint_training(None, model, data, cfg)
+    assert not data.synthetic and tr._train.dtype == np.uint8 and tr.n_train_iter == 4
+    it, _ = tr._iterators()
+    assert it.data.dtype == torch.uint8 and it.data.is_cuda     # the split lives in HBM as uint8
+    tr.train_epoch()
+    assert len(tr.elbo_train) == 4 and np.isfinite(tr.elbo_train).all() and np.isfinite(tr.code_elbo_train).all()
+    assert tr.gm_params is not None
