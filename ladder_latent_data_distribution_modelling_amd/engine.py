@@ -96,6 +96,11 @@ class Comm:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def allreduce_async_(self, t):
+        """Start the all-reduce and return a handle (None with one rank): the collective runs on the process group's own
+        stream, so kernels enqueued afterwards on the compute stream overlap it; `wait()` orders the compute stream after it."""
+        return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True) if self.on else None
+
     def broadcast_(self, t, src=0):
         if self.on:
             self.dist.broadcast(t, src=src, group=self.group)
@@ -161,6 +166,20 @@ class ParamStore:
             self.w[name] = self.theta[g][off:off + n].view(*shp) if len(shp) else self.theta[g][off:off + 1]
             self.g[name] = self.grad[g][off:off + n].view(*shp) if len(shp) else self.grad[g][off:off + 1]
         self.load_dict(values)
+
+    def prefix_range(self, group, prefix):
+        """[lo, hi) of the flat `group` buffers covered by the variables whose name starts with `prefix`, or None if they are
+        not one contiguous run (param_specs orders names, so each scope is contiguous)."""
+        runs = [(off, off + (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN, name.startswith(prefix))
+                for name, (g, off, n) in self.offsets.items() if g == group]
+        runs.sort()
+        inside = [r for r in runs if r[2]]
+        if not inside:
+            return None
+        lo, hi = inside[0][0], inside[-1][1]
+        if any(lo <= r[0] < hi and not r[2] for r in runs):
+            return None
+        return lo, hi
 
     def load_dict(self, values, strict=True):
         for name in self.specs:
@@ -637,6 +656,7 @@ class LadderEngine:
         self._gm_packed = None
         self.use_graphs = False
         self._graphs, self._warm = {}, {}
+        self._dec_range = self.ps.prefix_range("ae", "decoder/")   # C1 bucket boundary (data parallel)
 
     # -- inputs ---------------------------------------------------------------------------------
     def _dev(self, a):
@@ -772,6 +792,12 @@ class LadderEngine:
         dxhat = torch.empty_like(self.xhat)
         L.call("ladder_pixel_grad", _p(self.x), _p(self.xhat), _p(self._sc("_g_pix")), _p(dxhat), dxhat.numel(), st)
         dz = self.decoder.backward(dxhat)
+        self._c1_pending = None
+        if ctx.comm.on and self._dec_range is not None:
+            # C1, first bucket: every decoder gradient is final here (~3/4 of the 72 MB); its all-reduce runs over xGMI
+            # while the inner-VAE and encoder backward kernels keep the CUs busy.  The rest follows in _ae.
+            lo, hi = self._dec_range
+            self._c1_pending = ctx.comm.allreduce_async_(self.ps.grad["ae"][lo:hi])
         mode = 1
         if self.has_inner and not self.use_sg:
             mu_t, sd_t, sdraw_t, eps_t, t = self.lat_t
@@ -809,7 +835,17 @@ class LadderEngine:
         parts = ("dec",) if (use_sg or not self.has_inner) else ("dec", "inner", "gmm")
         self.forward(x, noise, use_sg, use_mask, parts)
         self._backward_ae()
-        self.ctx.comm.allreduce_(self.ps.grad["ae"])              # C1 (sum of per-rank grads of the global-mean loss)
+        g = self.ps.grad["ae"]                                    # C1 (sum of per-rank grads of the global-mean loss)
+        if getattr(self, "_c1_pending", None) is not None:
+            lo, hi = self._dec_range                              # decoder bucket already in flight: reduce what is left
+            if lo > 0:
+                self.ctx.comm.allreduce_(g[:lo])
+            if hi < g.numel():
+                self.ctx.comm.allreduce_(g[hi:])
+            self._c1_pending.wait()
+            self._c1_pending = None
+        else:
+            self.ctx.comm.allreduce_(g)
         self.ps.adam("ae", lr)
 
     def _sigma(self, x, lr, noise, use_sg, use_mask, reuse_encoder=False):
