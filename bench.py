@@ -77,9 +77,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook (tests/test_gpu_model.py): all ranks on cuda:0 over gloo, to exercise the multi-rank path of this script on a
+    # 1-GPU box (RCCL refuses two ranks on one device).  Never set by the driver.
+    one_dev = os.environ.get("LADDER_BENCH_SINGLE_DEVICE") == "1"
+    if one_dev:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from ladder_latent_data_distribution_modelling_amd import engine as E
     from ladder_latent_data_distribution_modelling_amd.codes.models import CelebAModel_densenet, MNISTModel_digit, MNISTModel_fashion

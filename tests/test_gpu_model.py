@@ -476,3 +476,23 @@ def test_hierarchical_prior_vs_oracle(golden_dir, exp, use_sg):
     ref = O.run(st, x, noise, None, use_sg, True, train="inner_sigma", lr=0.0)
     eng.run_inner_sigma(x, 0.0, noise, use_sg, True)
     assert _rel(eng.scalars.cpu().numpy()[L.S_INDEX["_g_inner_sigma_var"]], float(ref["_grads"]["inner_sigma/Variable"])) < 1e-4
+
+
+def test_bench_script_two_ranks_one_gpu(tmp_path):
+    """bench.py launched exactly as the driver does for N > 1 (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py
+    --gpus 2`), with the test hook that puts both ranks on cuda:0 over gloo: the multi-rank control flow of the script (process
+    group, barriers, max-over-ranks timing, one JSON line from rank 0, weak scaling of the global batch) runs end to end."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LADDER_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--config", os.path.join(root, "codes", "mnist_fashion_config.json")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["config"]["global_batch"] == 512
+    assert j["config"]["parallelism"] == "dp2" and j["value"] > 0 and np.isfinite(j["elbo"]) and "cpu_baseline" not in j
