@@ -190,6 +190,8 @@ typedef struct {
   float inner_sigma_lb, inner_sigma_ub;
   int hierarchical;      /* prior == "hierarchical" (base.py:331-359): crossEntropy_representation in closed form against N(0,I)
                           * from P_MU2SD2_T (no mixture term), entropy_t with the reference's hard-coded dimension 2 */
+  int prior_gmm;         /* prior == "GMM" (base.py:322-329): crossEntropy_prior = P_LOGP / (L*B), the MC mean of the mixture
+                          * log-prob of z samples; no standard-Gaussian switch */
 } LadderElboCfg;
 
 /* out[0] = sum |x-xhat|, out[1] = sum (x-xhat)^2 over n elements (fp64 accumulation across workgroups). */
@@ -235,6 +237,18 @@ int ladder_adam_clip_dev(float* theta, const float* g, float* m, float* v, size_
 /* Philox stream position = *offset_base + offset_add (offset_base: device counter advanced by ladder_u64_add). */
 int ladder_randn_dev(float* out, size_t n, uint64_t seed, const uint64_t* offset_base, uint64_t offset_add, ladder_stream_t stream);
 int ladder_u64_add(uint64_t* p, uint64_t inc, ladder_stream_t stream);
+
+/* ---- the same mixture on a WIDE latent (prior "GMM": the mixture sits on z, R = code_size; codes/base.py:101-106, 322-329).
+ * 8 < R <= 64, R % 4 == 0.  The whitening of all components is one GEMM on the dense MFMA kernel (see csrc/elbo.hip);
+ * params = ladder_gmm_dense_param_floats(K,R) floats filled by ladder_gmm_prepare_dense (float64 Cholesky per component).
+ * Same outputs / conventions as ladder_gmm_logprob_fwd_bwd; dmu = dsd = NULL evaluates the log-prob only. */
+size_t ladder_gmm_dense_param_floats(int K, int R);
+int ladder_gmm_prepare_dense(const float* weights, const float* means, const float* covs, int K, int R, float* params,
+                             ladder_stream_t stream);
+size_t ladder_gmm_dense_workspace_bytes(int L, int B, int R, int K);
+int ladder_gmm_dense_logprob_fwd_bwd(const float* mu, const float* sd, const float* eps, const float* params, int L, int B, int R,
+                                     int K, float* sum_logp, float* dmu, float* dsd, void* ws, size_t ws_bytes,
+                                     ladder_stream_t stream);
 
 /* ---------------------------------------------------------------- N14: minibatch assembly (the input pipeline)
  * models.py:354-371 (CelebA: uint8 HWC pixels * 1/255), data_loader.py:19-33 (MNIST floats), shuffle + batch of models.py:33-40:

@@ -30,7 +30,7 @@ class LadderElboCfg(C.Structure):
     _fields_ = [("B_global", C.c_int), ("D", C.c_int), ("Z", C.c_int), ("R", C.c_int), ("L", C.c_int),
                 ("sigma_uses_mpe", C.c_int), ("has_inner", C.c_int), ("use_sg", C.c_int),
                 ("clamp_inner_sigma", C.c_int), ("inner_sigma_lb", C.c_float), ("inner_sigma_ub", C.c_float),
-                ("hierarchical", C.c_int)]
+                ("hierarchical", C.c_int), ("prior_gmm", C.c_int)]
 
 
 _p, _i, _f, _d, _z, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_uint64
@@ -81,6 +81,10 @@ PROTOTYPES = {
     "ladder_randn_dev": (_i, [_p, _z, _u64, _p, _u64, _p]),
     "ladder_u64_add": (_i, [_p, _u64, _p]),
     "ladder_crc32c_extend": (C.c_uint32, [C.c_uint32, _p, _z]),
+    "ladder_gmm_dense_param_floats": (_z, [_i, _i]),
+    "ladder_gmm_prepare_dense": (_i, [_p, _p, _p, _i, _i, _p, _p]),
+    "ladder_gmm_dense_workspace_bytes": (_z, [_i, _i, _i, _i]),
+    "ladder_gmm_dense_logprob_fwd_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _z, _p]),
     "ladder_gather_rows": (_i, [_p, _i, _p, _p, _i, C.c_int64, _f, _p]),
     "ladder_vbgmm_state_doubles": (_z, [_i, _i]),
     "ladder_vbgmm_workspace_bytes": (_z, [_i, _i]),

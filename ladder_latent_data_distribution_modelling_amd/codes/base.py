@@ -47,6 +47,16 @@ class BaseTrain:
             return True, False
         if cfg["prior"] == "hierarchical":            # codes/base.py:901-911: no mixture feed, no mask
             return self.cur_epoch <= int(cfg["sg_pretraining"]), False
+        if cfg["prior"] == "GMM":                     # codes/base.py:912-933: dummy N(0,I) mixture in epoch 1, then the fit + 0.01 I
+            if self.cur_epoch == 1 or self.gm_params is None:
+                if getattr(self, "_fed", None) != "sg":
+                    eng.set_sg_mixture()
+                    self._fed = "sg"
+            elif getattr(self, "_fed", None) is not self.gm_params:
+                w, m, c = self.gm_params
+                eng.set_mixture(w, m, np.asarray(c) + 0.01 * np.eye(int(cfg["code_size"])))
+                self._fed = self.gm_params
+            return False, False
         use_sg = self.cur_epoch <= int(cfg["sg_pretraining"])
         if use_sg or self.gm_params is None:
             if getattr(self, "_fed", None) != "sg":
@@ -119,12 +129,13 @@ class BaseTrain:
         return f["loss_prior"]
 
     # ------------------------------------------------------------------ GM fit (base.py:681-789)
-    def _draw_t_samples(self, iterator, n_batch):
-        """t-samples of n_batch minibatches as ONE device tensor [n, R] (every rank's, in rank order, under data parallelism)."""
+    def _draw_t_samples(self, iterator, n_batch, space="t"):
+        """t- (or z-) samples of n_batch minibatches as ONE device tensor [n, R] (every rank's, in rank order, under data
+        parallelism)."""
         eng = self.engine
         chunks = []
         for _ in range(n_batch):
-            t = eng.sample_representation(iterator.next())
+            t = eng.sample_representation(iterator.next()) if space == "t" else eng.sample_code(iterator.next())
             if eng.ctx.comm.on:   # C5: gather every rank's samples
                 parts = [torch.empty_like(t) for _ in range(eng.ctx.comm.world)]
                 eng.ctx.comm.dist.all_gather(parts, t.contiguous(), group=eng.ctx.comm.group)
@@ -157,8 +168,8 @@ class BaseTrain:
         return self._share_gm(gm)
 
     def fit_GMM_VI(self, iterator, mode="fast", space="t"):
-        if space != "t":
-            raise NotImplementedError("prior 'GMM' (mixture on z) is a later row (SURVEY 8f4)")
+        if space == "z":
+            return self._fit_GMM_z(iterator, mode)
         comm = self.engine.ctx.comm
         bs_global = int(self.config["batch_size"]) * comm.world
         rank0 = comm.rank == 0
@@ -191,6 +202,38 @@ class BaseTrain:
                          K_active=K[idx], w_full=w, m_full=m, K_full=K)          # same keys as base.py:772-777
                 print("Final fitted prior saved.")
         w = w.cpu().numpy() if isinstance(w, torch.Tensor) else np.asarray(w)
+        print("There are {} active mixtures.".format(int(np.sum(w >= 1e-2))))
+        return samples.cpu().numpy().astype(np.float64)
+
+    def _fit_GMM_z(self, iterator, mode):
+        """prior "GMM" (base.py:699-710, 749-789): sklearn EM mixture on z samples, host fit on rank 0 + broadcast."""
+        from sklearn.mixture import GaussianMixture
+        comm = self.engine.ctx.comm
+        bs_global = int(self.config["batch_size"]) * comm.world
+        samples = self._draw_t_samples(iterator, (2000 if mode == "fast" else 20000) // bs_global + 1, space="z")
+        if mode == "fast":
+            gm = self.model.GM_prior_training
+        else:
+            gm = self.GM_prior_final = GaussianMixture(n_components=int(self.config["n_mixtures"]), covariance_type="full",
+                                                       max_iter=2000, n_init=1, warm_start=False)
+        K, R = int(self.config["n_mixtures"]), int(self.config["code_size"])
+        if comm.rank == 0:
+            gm.fit(samples.cpu().numpy().astype(np.float64))
+        buf = torch.zeros(K + K * R + K * R * R, dtype=torch.float64, device=self.engine.ctx.device)
+        if comm.rank == 0:
+            buf.copy_(torch.as_tensor(np.concatenate([gm.weights_.ravel(), gm.means_.ravel(), gm.covariances_.ravel()])))
+        comm.broadcast_(buf, 0)
+        a = buf.cpu().numpy()
+        w, m, c = a[:K].copy(), a[K:K + K * R].reshape(K, R).copy(), a[K + K * R:].reshape(K, R, R).copy()
+        if mode == "fast":
+            self.gm_params = (w, m, c)
+        else:
+            self.gm_final_params = (w, m, c)
+            idx = np.flatnonzero(w >= 1e-2)
+            if comm.rank == 0:
+                np.savez("{}GM_prior_info.npz".format(self.config["result_dir"]), w_active=w[idx] / np.sum(w[idx]) if len(idx) else w[idx],
+                         m_active=m[idx], K_active=c[idx], w_full=w, m_full=m, K_full=c)
+                print("Final fitted prior saved.")
         print("There are {} active mixtures.".format(int(np.sum(w >= 1e-2))))
         return samples.cpu().numpy().astype(np.float64)
 
@@ -251,6 +294,9 @@ class BaseTrain_joint(BaseTrain):
             self.fit_GMM_VI(iterator=iterator, mode="fast", space="t")
             if self.cur_epoch % int(self.config["accurate_fit"]) == 0 or self.cur_epoch == int(self.config["num_epochs"]):
                 self.fit_GMM_VI(iterator=iterator, mode="accurate", space="t")
+        elif self.config["prior"] == "GMM":               # base.py:1000-1010
+            self.fit_GMM_VI(iterator=iterator, mode="fast" if self.cur_epoch < int(self.config["num_epochs"]) else "accurate",
+                            space="z")
 
     def generate_samples_from_prior(self, n_sample=10):
         """Latent samples -> decoded images (codes/base.py:1064-1168, figure writing omitted)."""
@@ -266,6 +312,11 @@ class BaseTrain_joint(BaseTrain):
             Lc = np.linalg.cholesky(K)
             t = m[comp] + np.einsum("nij,nj->ni", Lc[comp], rng.standard_normal((n, m.shape[1])))
             code = eng.decode_representation(t)
+        elif cfg["prior"] == "GMM" and self.gm_params is not None:     # ancestral sample of the mixture on z
+            w, m, K = (np.asarray(a, np.float64) for a in self.gm_params)
+            comp = rng.choice(len(w), size=n, p=np.clip(w, 0, None) / np.clip(w, 0, None).sum())
+            Lc = np.linalg.cholesky(K + 0.01 * np.eye(K.shape[-1]))
+            code = m[comp] + np.einsum("nij,nj->ni", Lc[comp], rng.standard_normal((n, m.shape[1])))
         else:
             code = rng.standard_normal((n, int(cfg["code_size"])))
         self.generated_samples = eng.decode(code).cpu().numpy()

@@ -47,6 +47,10 @@ class BaseModel:
             else:
                 from sklearn.mixture import BayesianGaussianMixture
                 self.GM_prior_training = BayesianGaussianMixture(**kw)
+        elif self.config["prior"] == "GMM":          # base.py:101-106: plain EM mixture on z (R = code_size), host fit
+            from sklearn.mixture import GaussianMixture
+            self.GM_prior_training = GaussianMixture(n_components=int(self.config["n_mixtures"]), covariance_type="full",
+                                                     max_iter=1000, n_init=1, warm_start=True)
 
     # codes/base.py:37-85 -- two savers: vae-model (encoder+decoder+sigma), prior-model (prior/* + inner sigma).
     # Adam slots / epoch counter are not saved by the reference either.  Format: the reference's own -- a TensorFlow

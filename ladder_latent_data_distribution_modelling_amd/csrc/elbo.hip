@@ -172,7 +172,7 @@ __global__ void elbo_finalize_kernel(const float* __restrict__ P, const float* _
   const double sigma_reg = -D * log(2.0 * sigma);
   const double entropy_z = -0.5 * Z * kLog2Pi - 0.5 * Z - (double)P[LADDER_P_LOG_SDZ] / B;
   const double xent_sg = -0.5 * Z * kLog2Pi - 0.5 * (double)P[LADDER_P_MU2SD2_Z] / B;
-  double xent_prior = xent_sg;
+  double xent_prior = cfg.prior_gmm ? (double)P[LADDER_P_LOGP] / (L * B) : xent_sg;
   double g_code = 0.0, g_isv = 0.0;
   if (cfg.has_inner) {
     const double iv = inner_sigma_var[0];
@@ -412,6 +412,131 @@ __global__ void gmm_sum_kernel(const double* __restrict__ ws, int B, float* __re
   }
 }
 
+// ----------------------------------------------------------------------------- mixture log-prob for WIDE latents (prior "GMM")
+// prior == "GMM" puts the K-component full-covariance mixture on z itself (R = code_size = 16 / 64; codes/base.py:101-106,
+// 322-329).  At that width the whitening y_k = Linv_k (t - m_k) of all components is a GEMM:  Y[S, K*R] = T[S, R] . Bmat[R, K*R]
+// + bias with S = L*B MC samples, Bmat[:, kR+i] = Linv_k[i, :], bias[kR+i] = -(Linv_k m_k)[i]  (1.6 GMAC at R = 64, K = 30,
+// L*B = 12 800) -- it runs on the dense MFMA kernel, and so does its transpose for the gradient dT = dY . Bmat^T with
+// dY[s, kR+i] = -resp[s,k] * Y[s, kR+i].  The kernels below are the glue: parameter preparation (float64 Cholesky in LDS),
+// MC sample assembly, the per-sample logsumexp / responsibilities over the Y blocks, and the reduction of dT over the L samples.
+constexpr int GD_MAXR = 64;
+
+__global__ __launch_bounds__(64) void gmm_prepare_dense_kernel(const float* __restrict__ w, const float* __restrict__ m,
+                                                               const float* __restrict__ cov, int K, int R, float* __restrict__ Bmat,
+                                                               float* __restrict__ BmatT, float* __restrict__ bias,
+                                                               float* __restrict__ logc) {
+  __shared__ double A[GD_MAXR * GD_MAXR];      // covariance -> Cholesky factor L (lower)
+  __shared__ double Li[GD_MAXR * GD_MAXR];     // L^-1 (lower)
+  __shared__ double sw;
+  const int k = blockIdx.x, i = threadIdx.x;
+  for (int e = i; e < R * R; e += 64) A[e] = (double)cov[(size_t)k * R * R + e];
+  if (i == 0) {
+    double t = 0.0;
+    for (int q = 0; q < K; ++q) t += (double)w[q];
+    sw = t;
+  }
+  __syncthreads();
+  for (int j = 0; j < R; ++j) {
+    if (i == j) {
+      double d = A[j * R + j];
+      for (int p = 0; p < j; ++p) d -= A[j * R + p] * A[j * R + p];
+      A[j * R + j] = sqrt(d);
+    }
+    __syncthreads();
+    if (i > j && i < R) {
+      double v = A[i * R + j];
+      for (int p = 0; p < j; ++p) v -= A[i * R + p] * A[j * R + p];
+      A[i * R + j] = v / A[j * R + j];
+    }
+    __syncthreads();
+  }
+  if (i < R) {                                   // column i of L^-1 by forward substitution
+    for (int r = 0; r < R; ++r) {
+      double v = (r == i) ? 1.0 : 0.0;
+      for (int p = i; p < r; ++p) v -= A[r * R + p] * Li[p * R + i];
+      Li[r * R + i] = (r < i) ? 0.0 : v / A[r * R + r];
+    }
+  }
+  __syncthreads();
+  if (i < R) {                                   // row i of L^-1: whitening direction i of this component
+    double b = 0.0;
+    for (int j = 0; j < R; ++j) {
+      const double v = Li[i * R + j];
+      Bmat[(size_t)j * K * R + (size_t)k * R + i] = (float)v;
+      BmatT[((size_t)k * R + i) * R + j] = (float)v;
+      b -= v * (double)m[(size_t)k * R + j];
+    }
+    bias[(size_t)k * R + i] = (float)b;
+  }
+  if (i == 0) {
+    double ld = 0.0;
+    for (int j = 0; j < R; ++j) ld += log(A[j * R + j]);
+    logc[k] = (float)(log((double)w[k]) - log(sw) - ld - 0.5 * R * kLog2Pi);
+  }
+}
+
+__global__ void mc_samples_kernel(const float* __restrict__ mu, const float* __restrict__ sd, const float* __restrict__ eps,
+                                  float* __restrict__ T, size_t n, int BR) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int br = (int)(i % BR);
+  T[i] = mu[br] + sd[br] * eps[i];               // eps, T: [L, B, R]; mu, sd: [B, R]
+}
+
+// one wavefront per MC sample: lp_k = logc_k - 0.5 |Y_k|^2, logsumexp over k, responsibilities; Y <- dlogp/dY = -resp_k * Y_k.
+__global__ __launch_bounds__(256) void gmm_dense_resp_kernel(float* __restrict__ Y, const float* __restrict__ logc, int S, int K, int R,
+                                                             int write_dy, double* __restrict__ ws_lse) {
+  extern __shared__ float lp_sh[];               // [4 waves][K]
+  __shared__ double blk[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int s = blockIdx.x * 4 + wv;
+  float* lp = lp_sh + (size_t)wv * K;
+  double lse_d = 0.0;
+  if (s < S) {
+    float* row = Y + (size_t)s * K * R;
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+      float q = 0.f;
+      for (int i = lane; i < R; i += 64) {
+        const float y = row[(size_t)k * R + i];
+        q += y * y;
+      }
+      q = wave_sum(q);
+      const float v = logc[k] - 0.5f * q;
+      lp[k] = v;                                 // every lane holds the reduced value: no cross-lane dependency
+      mx = fmaxf(mx, v);
+    }
+    float se = 0.f;
+    for (int k = lane; k < K; k += 64) se += __expf(lp[k] - mx);
+    se = wave_sum(se);
+    const float lse = mx + __logf(se);
+    lse_d = (double)lse;
+    if (write_dy)
+      for (int k = 0; k < K; ++k) {
+        const float r = __expf(lp[k] - lse);
+        for (int i = lane; i < R; i += 64) row[(size_t)k * R + i] *= -r;
+      }
+  }
+  if (lane == 0) blk[wv] = lse_d;
+  __syncthreads();
+  if (threadIdx.x == 0) ws_lse[blockIdx.x] = (blk[0] + blk[1]) + (blk[2] + blk[3]);
+}
+
+// dmu[b,r] = sum_l dT[l,b,r] ; dsd[b,r] = sum_l dT[l,b,r] * eps[l,b,r]   (fixed order over l)
+__global__ void gmm_dense_reduce_kernel(const float* __restrict__ dT, const float* __restrict__ eps, float* __restrict__ dmu,
+                                        float* __restrict__ dsd, int L, int BR) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BR) return;
+  float a = 0.f, b = 0.f;
+  for (int l = 0; l < L; ++l) {
+    const float g = dT[(size_t)l * BR + i];
+    a += g;
+    b += g * eps[(size_t)l * BR + i];
+  }
+  dmu[i] = a;
+  dsd[i] = b;
+}
+
 // ----------------------------------------------------------------------------- clip + Adam (TF form)
 __global__ void adam_clip_kernel(float* __restrict__ theta, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                  size_t n, float lr_t, float b1, float b2, float eps, float clip) {
@@ -588,6 +713,63 @@ int ladder_gmm_logprob_fwd_bwd(const float* mu, const float* sd, const float* ep
   if (ws_bytes < (size_t)B * sizeof(double)) return LADDER_E_WORKSPACE;
   LADDER_R_SWITCH(R, hipLaunchKernelGGL(gmm_logprob_kernel<RR>, dim3(B), dim3(256), 0, stream, mu, sd, eps, packed, L, B, K, dmu, dsd, (double*)ws));
   hipLaunchKernelGGL(gmm_sum_kernel, dim3(1), dim3(64), 0, stream, (const double*)ws, B, sum_logp);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+size_t ladder_gmm_dense_param_floats(int K, int R) { return (size_t)2 * K * R * R + (size_t)K * R + K; }
+
+int ladder_gmm_prepare_dense(const float* weights, const float* means, const float* covs, int K, int R, float* params,
+                             ladder_stream_t stream) {
+  if (K <= 0 || K > 1024 || R <= 0 || R > GD_MAXR || (R % 4) != 0) return LADDER_E_SHAPE;
+  float* Bmat = params;
+  float* BmatT = Bmat + (size_t)K * R * R;
+  float* bias = BmatT + (size_t)K * R * R;
+  float* logc = bias + (size_t)K * R;
+  hipLaunchKernelGGL(gmm_prepare_dense_kernel, dim3(K), dim3(64), 0, stream, weights, means, covs, K, R, Bmat, BmatT, bias, logc);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+static size_t gd_align(size_t n) { return (n + 255) & ~(size_t)255; }
+
+size_t ladder_gmm_dense_workspace_bytes(int L, int B, int R, int K) {
+  const size_t S = (size_t)L * B;
+  const size_t gemm = ladder_igemm_fwd_workspace_bytes((long)S, R, K * R) > ladder_igemm_fwd_workspace_bytes((long)S, K * R, R)
+                          ? ladder_igemm_fwd_workspace_bytes((long)S, R, K * R) : ladder_igemm_fwd_workspace_bytes((long)S, K * R, R);
+  return gd_align(S * R * 4) * 2 + gd_align(S * K * R * 4) + gd_align(((S + 3) / 4) * 8) + gd_align(gemm) + 256;
+}
+
+int ladder_gmm_dense_logprob_fwd_bwd(const float* mu, const float* sd, const float* eps, const float* params, int L, int B, int R,
+                                     int K, float* sum_logp, float* dmu, float* dsd, void* ws, size_t ws_bytes,
+                                     ladder_stream_t stream) {
+  if (L <= 0 || B <= 0 || K <= 0 || K > 1024 || R <= 0 || R > GD_MAXR || (R % 4) != 0) return LADDER_E_SHAPE;
+  if (ws == nullptr || ws_bytes < ladder_gmm_dense_workspace_bytes(L, B, R, K)) return LADDER_E_WORKSPACE;
+  const size_t S = (size_t)L * B;
+  char* p = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  float* T = (float*)p;               p += gd_align(S * R * 4);
+  float* dT = (float*)p;              p += gd_align(S * R * 4);
+  float* Y = (float*)p;               p += gd_align(S * K * R * 4);
+  double* lse = (double*)p;           p += gd_align(((S + 3) / 4) * 8);
+  void* gws = p;
+  const size_t gws_bytes = ws_bytes - (size_t)(p - (char*)ws);
+  const float* Bmat = params;
+  const float* BmatT = Bmat + (size_t)K * R * R;
+  const float* bias = BmatT + (size_t)K * R * R;
+  const float* logc = bias + (size_t)K * R;
+  const size_t n = S * R;
+  hipLaunchKernelGGL(mc_samples_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, mu, sd, eps, T, n, B * R);
+  int rc = ladder_dense_fwd(T, Bmat, bias, Y, (int)S, R, K * R, LADDER_ACT_NONE, gws, gws_bytes, stream);
+  if (rc != LADDER_OK) return rc;
+  const int nblk = (int)((S + 3) / 4);
+  hipLaunchKernelGGL(gmm_dense_resp_kernel, dim3(nblk), dim3(256), 4 * (size_t)K * sizeof(float), stream, Y, logc, (int)S, K, R,
+                     dmu != nullptr ? 1 : 0, lse);
+  hipLaunchKernelGGL(gmm_sum_kernel, dim3(1), dim3(64), 0, stream, (const double*)lse, nblk, sum_logp);
+  if (dmu != nullptr) {
+    rc = ladder_dense_bwd_data(Y, BmatT, dT, (int)S, R, K * R, nullptr, 0, gws, gws_bytes, stream);
+    if (rc != LADDER_OK) return rc;
+    hipLaunchKernelGGL(gmm_dense_reduce_kernel, dim3((B * R + 255) / 256), dim3(256), 0, stream, dT, eps, dmu, dsd, L, B * R);
+  }
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

@@ -638,12 +638,13 @@ class LadderEngine:
         self.decoder = (CelebADecoder if cfg["exp_name"] == "celeba" else MnistDecoder)(self.ctx, self.ps, cfg)
         self.has_inner = cfg["prior"] in ("ours", "hierarchical")
         self.hier = cfg["prior"] == "hierarchical"          # inner VAE against N(0,I): no mixture term, no mask (base.py:331-359)
-        if cfg["prior"] not in ("ours", "hierarchical", "standard_gaussian"):
-            raise NotImplementedError("prior %r: the HIP path covers 'ours', 'hierarchical' and 'standard_gaussian' "
+        self.gmm_z = cfg["prior"] == "GMM"                   # mixture directly on z (R = code_size), no inner VAE (base.py:322-329)
+        if cfg["prior"] not in ("ours", "hierarchical", "GMM", "standard_gaussian"):
+            raise NotImplementedError("prior %r: the HIP path covers 'ours', 'hierarchical', 'GMM' and 'standard_gaussian' "
                                       "(SURVEY 8f4)" % cfg["prior"])
         self.inner = InnerVAE(self.ctx, self.ps, cfg) if self.has_inner else None
         self.Z = int(cfg["code_size"])
-        self.R = int(cfg.get("representation_size", 1))
+        self.R = int(cfg["code_size"]) if cfg["prior"] == "GMM" else int(cfg.get("representation_size", 1))   # mixture dimension
         self.K = int(cfg.get("n_mixtures", 1))
         self.Lmc = int(cfg.get("n_MC_samples", 1))
         self.D = int(cfg["dim_input_x"]) * int(cfg["dim_input_y"]) * int(cfg["dim_input_channel"])
@@ -684,10 +685,12 @@ class LadderEngine:
         K, R = self.K, self.R
         w, m, c = self._dev(weights), self._dev(means), self._dev(covs)
         assert tuple(w.shape) == (K,) and tuple(m.shape) == (K, R) and tuple(c.shape) == (K, R, R)
-        stride = L.query("ladder_gmm_packed_stride", R)
-        if getattr(self, "_gm_buf", None) is None:
-            self._gm_buf = self.ctx.empty(K * stride)       # persistent: captured graphs keep pointing at the current mixture
-        L.call("ladder_gmm_prepare", _p(w), _p(m), _p(c), K, R, _p(self._gm_buf), self.ctx.stream)
+        self._gm_dense = R > 8                               # wide latent (prior "GMM"): whitening as a GEMM on the dense kernel
+        if getattr(self, "_gm_buf", None) is None:           # persistent: captured graphs keep pointing at the current mixture
+            self._gm_buf = self.ctx.empty(L.query("ladder_gmm_dense_param_floats", K, R) if self._gm_dense
+                                          else K * L.query("ladder_gmm_packed_stride", R))
+        L.call("ladder_gmm_prepare_dense" if self._gm_dense else "ladder_gmm_prepare", _p(w), _p(m), _p(c), K, R, _p(self._gm_buf),
+               self.ctx.stream)
         torch.cuda.current_stream(self.ctx.device).synchronize()   # w, m, c are temporaries: keep them alive until the kernel ran
         self._gm_packed = self._gm_buf
 
@@ -731,6 +734,8 @@ class LadderEngine:
             wsp, wsn = ctx.ws(nb)
             L.call("ladder_pixel_partials", _p(x), _p(xhat), x.numel(), _p(P[L.P_PIX_ABS:]), wsp, wsn, st)
             self.xhat = xhat
+        if self.gmm_z and "gmm" in parts:
+            self.gmm_grads = self._mixture_term(mu, sd, noise, B, need_grad="gmm_grad" in parts)
         inner_on = self.has_inner and "inner" in parts
         if inner_on:
             mu_t, sdraw_t = self.inner.encode(z)
@@ -746,25 +751,39 @@ class LadderEngine:
             if "gmm" in parts and not self.hier:
                 if self._gm_packed is None:
                     raise L.LadderHipError("set_mixture()/set_sg_mixture() must be called before a run that evaluates the GM prior")
-                eps_mc = self._noise(noise, "eps_mc", (self.Lmc, B, R))
-                dmu, dsd = ctx.empty(B, R), ctx.empty(B, R)
-                nb = L.query("ladder_gmm_workspace_bytes", self.Lmc, B)
-                wsp, wsn = ctx.ws(nb)
-                L.call("ladder_gmm_logprob_fwd_bwd", _p(mu_t), _p(sd_t), _p(eps_mc), _p(self._gm_packed), self.Lmc, B, R,
-                       self.K, _p(P[L.P_LOGP:]), _p(dmu), _p(dsd), wsp, wsn, st)
-                self.gmm_grads = (dmu, dsd)
+                self.gmm_grads = self._mixture_term(mu_t, sd_t, noise, B)
         ctx.comm.allreduce_(P)                                   # C3: scalar partials of the GLOBAL batch
         ecfg = L.LadderElboCfg(self.Bg, self.D, Z, R, self.Lmc,
                                1 if (self.cfg["exp_name"] == "celeba" or int(self.cfg["TRAIN_sigma"]) == 1) else 0,
                                1 if inner_on else 0, 1 if use_sg else 0,
                                1 if (self.has_inner and int(self.cfg["TRAIN_inner_sigma"]) == 1) else 0,
                                float(self.cfg.get("inner_sigma_lb", 0.0)), float(self.cfg.get("inner_sigma_ub", 0.0)),
-                               1 if self.hier else 0)
+                               1 if self.hier else 0, 1 if self.gmm_z else 0)
         L.call("ladder_elbo_finalize", _p(P), _p(self.ps.w["sigma/Variable"]),
                _p(self.ps.w["inner_sigma/Variable"]) if self.has_inner else None, ecfg, _p(self.scalars), st)
         if self._run_calls:
             L.call("ladder_u64_add", _p(self.rng_counter), self._run_calls, st)      # advance the device noise stream
         self.use_sg, self.use_mask = use_sg, use_mask
+
+    def _mixture_term(self, mu, sd, noise, B, need_grad=True):
+        """MC estimate of E_q[log p_GM] over L samples of N(mu, sd^2) (base.py:308-313 on t, 322-329 on z): writes the sum of
+        the log-probs into the partials and returns (sum_l dlogp/dt, sum_l dlogp/dt * eps) for the latent backward."""
+        ctx, st, R, P = self.ctx, self.ctx.stream, self.R, self.partials
+        if self._gm_packed is None:
+            raise L.LadderHipError("set_mixture()/set_sg_mixture() must be called before a run that evaluates the GM prior")
+        eps_mc = self._noise(noise, "eps_mc", (self.Lmc, B, R))
+        dmu, dsd = (ctx.empty(B, R), ctx.empty(B, R)) if need_grad else (None, None)
+        if self._gm_dense:
+            wsp, wsn = ctx.ws(L.query("ladder_gmm_dense_workspace_bytes", self.Lmc, B, R, self.K))
+            L.call("ladder_gmm_dense_logprob_fwd_bwd", _p(mu), _p(sd), _p(eps_mc), _p(self._gm_packed), self.Lmc, B, R, self.K,
+                   _p(P[L.P_LOGP:]), _p(dmu), _p(dsd), wsp, wsn, st)
+        else:
+            if dmu is None:
+                dmu, dsd = ctx.empty(B, R), ctx.empty(B, R)
+            wsp, wsn = ctx.ws(L.query("ladder_gmm_workspace_bytes", self.Lmc, B))
+            L.call("ladder_gmm_logprob_fwd_bwd", _p(mu), _p(sd), _p(eps_mc), _p(self._gm_packed), self.Lmc, B, R, self.K,
+                   _p(P[L.P_LOGP:]), _p(dmu), _p(dsd), wsp, wsn, st)
+        return dmu, dsd
 
     @staticmethod
     def _enc_needs_grad(parts):
@@ -811,8 +830,11 @@ class LadderEngine:
             add_(ctx, dz, self.inner.encode_backward(dmu_t, dsdraw_t, wgrad=False, need_dz=True))
         else:
             mode = 3
+        ex_mu, ex_sd = (None, None)
+        if self.gmm_z:                                        # -crossEntropy_prior = -(1/LB) sum log p_GM(z_l): mixture grads, no SG term
+            mode, (ex_mu, ex_sd) = 1, self.gmm_grads
         dmu, dsdraw = ctx.empty(B, Z), ctx.empty(B, Z)
-        L.call("ladder_latent_bwd", _p(dz), _p(mu), _p(sd), _p(sd_raw), _p(eps_z), None, None, 0.0, _p(self.scalars), mode,
+        L.call("ladder_latent_bwd", _p(dz), _p(mu), _p(sd), _p(sd_raw), _p(eps_z), _p(ex_mu), _p(ex_sd), -1.0, _p(self.scalars), mode,
                _p(dmu), _p(dsdraw), B, Z, st)
         self.encoder.backward(dmu, dsdraw)
 
@@ -833,6 +855,8 @@ class LadderEngine:
     def _ae(self, x, lr, noise, use_sg, use_mask, reuse_encoder=False):
         # in the SG regime the inner VAE does not enter loss_ae's gradient (tf.cond, base.py:318-320) nor its fetches
         parts = ("dec",) if (use_sg or not self.has_inner) else ("dec", "inner", "gmm")
+        if self.gmm_z:
+            parts = ("dec", "gmm", "gmm_grad")
         self.forward(x, noise, use_sg, use_mask, parts)
         self._backward_ae()
         g = self.ps.grad["ae"]                                    # C1 (sum of per-rank grads of the global-mean loss)
@@ -918,7 +942,7 @@ class LadderEngine:
         self._run("inner_sigma", x, lr, noise, use_sg, use_mask, reuse_encoder)
 
     def evaluate(self, x, noise=None, use_sg=True, use_mask=False):
-        parts = ("dec", "inner", "gmm") if (self.has_inner and self._gm_packed is not None) else ("dec", "inner")
+        parts = ("dec", "inner", "gmm") if ((self.has_inner or self.gmm_z) and self._gm_packed is not None) else ("dec", "inner")
         self.forward(x, noise, use_sg, use_mask, parts)
 
     # -- generation -----------------------------------------------------------------------------
@@ -929,6 +953,11 @@ class LadderEngine:
     def decode_representation(self, t):
         """decoded_code given representation_input (base.py:171-186)."""
         return self.inner.decode(self._dev(t))
+
+    def sample_code(self, x, noise=None):
+        """code_sample for fit_GMM_VI(space="z") (base.py:699-710): encoder -> z."""
+        self.forward(x, noise, True, False, ())
+        return self.lat_z[4]
 
     def sample_representation(self, x, noise=None):
         """representation_sample for fit_GMM_VI (base.py:683-698): encoder -> z -> inner encoder -> t."""

@@ -529,6 +529,11 @@ def forward(config, P, x, eps_z, eps_t=None, eps_mc=None, gm=None,
     prior = config["prior"]
     if prior == "standard_gaussian":
         out["crossEntropy_prior"] = out["crossEntropy_prior_sg"]
+    elif prior == "GMM":                                         # base.py:322-329: MC mean of the mixture log-prob of z samples
+        L = eps_mc.shape[0]
+        z_mc = mu_z.unsqueeze(0) + sd_z.unsqueeze(0) * eps_mc
+        lp = gmm_log_prob(z_mc, gm["weights"], gm["means"], gm["covs"])
+        out["crossEntropy_prior"] = ar(lp.sum()) / (L * Bg)
     elif prior in ("ours", "hierarchical"):
         hier = prior == "hierarchical"
         R = int(config["representation_size"])
@@ -565,7 +570,7 @@ def forward(config, P, x, eps_z, eps_t=None, eps_mc=None, gm=None,
         out["crossEntropy_prior"] = out["crossEntropy_prior_sg"] if use_sg else out["elbo_prior"]
         out["loss_prior"] = -out["elbo_prior"]
     else:
-        raise NotImplementedError("oracle covers prior in {'ours','hierarchical','standard_gaussian'}")
+        raise NotImplementedError("oracle covers prior in {'ours','hierarchical','GMM','standard_gaussian'}")
 
     diff = x - xhat                                             # base.py:374-396
     out["l2_reconstruction_error"] = ar((diff ** 2).sum()) / Bg
@@ -678,10 +683,11 @@ def train_iteration(state, x, noises, gm, cur_epoch, lr_ae, allreduce=None, glob
 
 
 def make_noise(config, B, rng, dtype=np.float64):
-    Z, R, L = int(config["code_size"]), int(config["representation_size"]), int(config["n_MC_samples"])
+    Z, R, L = int(config["code_size"]), int(config.get("representation_size", 1)), int(config["n_MC_samples"])
+    Rmc = Z if config.get("prior") == "GMM" else R             # prior "GMM": the MC samples are z samples (base.py:324-327)
     return dict(eps_z=rng.standard_normal((B, Z)).astype(dtype),
                 eps_t=rng.standard_normal((B, R)).astype(dtype),
-                eps_mc=rng.standard_normal((L, B, R)).astype(dtype))
+                eps_mc=rng.standard_normal((L, B, Rmc)).astype(dtype))
 
 
 def synthetic_gm(config, rng=None, fixture=None):

@@ -296,6 +296,37 @@ def test_gmm_logprob(gpu_ctx, golden_dir, K, R, Lmc, B):
     close(dsd, sdt.grad, 5e-5, "dsd")
 
 
+@pytest.mark.parametrize("K,R,Lmc,B", [(30, 64, 100, 128), (20, 16, 12, 10), (7, 12, 3, 5), (30, 64, 5, 2)])
+def test_gmm_dense_logprob(gpu_ctx, K, R, Lmc, B):
+    """prior "GMM": the mixture on a wide latent (R = code_size 16 / 64) through the dense MFMA path, vs the oracle; the first
+    case is the full BASELINE 'optional extra' shape (R = Z = 64, K = 30, L = 100, B = 128: 12 800 samples x 1 920 whitened
+    coordinates).  Forward-only mode (dmu = dsd = NULL) gives the same sum."""
+    L = _lib()
+    rng = np.random.default_rng(K * 7 + R)
+    gm = {k: v.astype(np.float32) for k, v in O.synthetic_gm(dict(n_mixtures=K, representation_size=R), rng).items()}
+    mu = (rng.standard_normal((B, R)) * 1.5).astype(np.float32)
+    sd = (0.05 + rng.random((B, R))).astype(np.float32)
+    eps = rng.standard_normal((Lmc, B, R)).astype(np.float32)
+    mut, sdt = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (mu, sd))
+    t = mut.unsqueeze(0) + sdt.unsqueeze(0) * torch.tensor(eps, dtype=torch.float64)
+    lp = O.gmm_log_prob(t, *(torch.tensor(gm[k], dtype=torch.float64) for k in ("weights", "means", "covs")))
+    lp.sum().backward()
+    st = gpu_ctx.stream
+    params = torch.empty(L.query("ladder_gmm_dense_param_floats", K, R), device="cuda")
+    wd, md, cd = dev(gm["weights"]), dev(gm["means"]), dev(gm["covs"])
+    L.call("ladder_gmm_prepare_dense", p(wd), p(md), p(cd), K, R, p(params), st)
+    out, out2, dmu, dsd = torch.empty(1, device="cuda"), torch.empty(1, device="cuda"), torch.empty(B, R, device="cuda"), torch.empty(B, R, device="cuda")
+    ws = torch.empty(L.query("ladder_gmm_dense_workspace_bytes", Lmc, B, R, K), dtype=torch.uint8, device="cuda")
+    mud, sdd, epsd = dev(mu), dev(sd), dev(eps)
+    L.call("ladder_gmm_dense_logprob_fwd_bwd", p(mud), p(sdd), p(epsd), p(params), Lmc, B, R, K, p(out), p(dmu), p(dsd), p(ws), ws.numel(), st)
+    L.call("ladder_gmm_dense_logprob_fwd_bwd", p(mud), p(sdd), p(epsd), p(params), Lmc, B, R, K, p(out2), None, None, p(ws), ws.numel(), st)
+    ref = lp.sum().item()
+    assert abs(out.item() - ref) < 3e-5 * abs(ref) + 1e-3 and out2.item() == out.item()
+    close(dmu, mut.grad, 1e-4, "dmu")
+    close(dsd, sdt.grad, 1e-4, "dsd")
+    assert L.query("ladder_gmm_prepare_dense", p(wd), p(md), p(cd), K, 72, p(params), st) != 0       # R > 64: LADDER_E_SHAPE
+
+
 def test_adam_clip_matches_tf_form(gpu_ctx):
     L = _lib()
     rng = np.random.default_rng(0)
