@@ -276,11 +276,8 @@ int ladder_vbgmm_fit(const float* X, int N, int K, int R, const int* labels, dou
 /* HOST function (no device work): CRC-32C (Castagnoli) of host memory, crc = 0 to start, chainable.  Used by the
  * tf.train.Saver checkpoint-v2 reader/writer (codes/base.py:37-85: saver_ae / saver_prior) for block and tensor checksums. */
 uint32_t ladder_crc32c_extend(uint32_t crc, const void* data, size_t n);
-size_t ladder_colstats_workspace_bytes(size_t rows, int C);
 /* out[i] (+)= scale * in[i]. accumulate!=0 adds into out. */
 int ladder_axpy(const float* in, float* out, size_t n, float scale, int accumulate, ladder_stream_t stream);
-/* out[c] = sum_rows x[row,c] (fixed-order two-stage). */
-int ladder_colsum(const float* x, float* out, size_t rows, int C, void* ws, size_t ws_bytes, ladder_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -90,8 +90,6 @@ PROTOTYPES = {
     "ladder_vbgmm_workspace_bytes": (_z, [_i, _i]),
     "ladder_vbgmm_fit": (_i, [_p, _i, _i, _i, _p, _p, _i, _d, _d, _d, _d, _i, _p, _p, _p, _p, _z, _p]),
     "ladder_axpy": (_i, [_p, _p, _z, _f, _i, _p]),
-    "ladder_colstats_workspace_bytes": (_z, [_z, _i]),
-    "ladder_colsum": (_i, [_p, _p, _z, _i, _p, _z, _p]),
 }
 
 _lib = None

@@ -565,27 +565,6 @@ __global__ void flip_transpose_kernel(const float* __restrict__ w, float* __rest
   }
 }
 
-// column sums of a [rows, C] matrix: stage 1 (row-chunks x column-blocks) -> ws, stage 2 fixed-order sum.
-__global__ void colsum_stage1(const float* __restrict__ x, float* __restrict__ ws, size_t rows, int C, size_t rows_per_blk) {
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rl = threadIdx.x >> 6;  // 4 row lanes
-  const size_t r0 = (size_t)blockIdx.y * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
-  float s = 0.f;
-  if (c < C)
-    for (size_t r = r0 + rl; r < r1; r += 4) s += x[r * C + c];
-  __shared__ float sm[4][64];
-  sm[rl][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (rl == 0 && c < C) ws[(size_t)blockIdx.y * C + c] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
-}
-__global__ void colsum_stage2(const float* __restrict__ ws, float* __restrict__ out, int nblk, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)ws[(size_t)b * C + c];
-  out[c] = (float)s;
-}
-
 struct TileCfg { int bm, bn; };
 
 
@@ -949,26 +928,6 @@ int launch_wgrad(const float* x, const float* dy, float* out, float* bias_part, 
   return LADDER_OK;
 }
 
-size_t colsum_ws_bytes(size_t rows, int C) {
-  size_t nblk = (rows + 1023) / 1024;
-  if (nblk > 1024) nblk = 1024;
-  if (nblk < 1) nblk = 1;
-  return nblk * (size_t)C * sizeof(float);
-}
-
-int run_colsum(const float* x, float* out, size_t rows, int C, void* ws, size_t ws_bytes, hipStream_t st) {
-  size_t nblk = (rows + 1023) / 1024;
-  if (nblk > 1024) nblk = 1024;
-  if (nblk < 1) nblk = 1;
-  if (ws_bytes < nblk * (size_t)C * sizeof(float)) return LADDER_E_WORKSPACE;
-  const size_t rpb = (rows + nblk - 1) / nblk;
-  dim3 g1((C + 63) / 64, (unsigned)nblk);
-  hipLaunchKernelGGL(colsum_stage1, g1, dim3(256), 0, st, x, (float*)ws, rows, C, rpb);
-  hipLaunchKernelGGL(colsum_stage2, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)ws, out, (int)nblk, C);
-  LADDER_CHECK_LAUNCH();
-  return LADDER_OK;
-}
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // Filter gradient of a 3x3 / stride 1 / SAME convolution with an LDS-staged input halo patch (tap-fused).
@@ -1290,11 +1249,5 @@ int ladder_dense_bwd_weight(const float* x, const float* dy, float* dw, float* d
   return run_wgrad(x, dy, dw, db, d, ws, ws_bytes, stream);
 }
 
-size_t ladder_colstats_workspace_bytes(size_t rows, int C) { return 2 * colsum_ws_bytes(rows, C); }
-
-int ladder_colsum(const float* x, float* out, size_t rows, int C, void* ws, size_t ws_bytes, ladder_stream_t stream) {
-  if (rows == 0 || C <= 0) return LADDER_E_SHAPE;
-  return run_colsum(x, out, rows, C, ws, ws_bytes, stream);
-}
 
 }  // extern "C"
