@@ -140,6 +140,8 @@ int ladder_resize_bilinear_bwd(const float* dy, float* dx, int N, int H, int W, 
  * codes/models.py:48-50,113,122,131,140,200-202,271,...,307.  inverse!=0 gives space_to_depth (the backward). */
 int ladder_depth_to_space(const float* x, float* y, int N, int H, int W, int C, int r, int inverse, ladder_stream_t stream);
 int ladder_pad_symmetric(const float* x, float* y, int N, int H, int W, int C, int p, ladder_stream_t stream);
+/* its transpose (gradient w.r.t. the unpadded input; only the VampPrior pseudo-inputs need it). */
+int ladder_pad_symmetric_bwd(const float* dy, float* dx, int N, int H, int W, int C, int p, ladder_stream_t stream);
 
 /* ---------------------------------------------------------------- N8: reparameterised sampling
  * codes/models.py:97-103,255-262,490-497; codes/base.py:164-167.  Philox4x32-10 + Box-Muller normals. */
@@ -249,6 +251,15 @@ size_t ladder_gmm_dense_workspace_bytes(int L, int B, int R, int K);
 int ladder_gmm_dense_logprob_fwd_bwd(const float* mu, const float* sd, const float* eps, const float* params, int L, int B, int R,
                                      int K, float* sum_logp, float* dmu, float* dsd, void* ws, size_t ws_bytes,
                                      ladder_stream_t stream);
+
+/* ---- VampPrior (codes/base.py:216-254, 361-370): equally weighted mixture of K DIAGONAL Gaussians on z (Z <= 64) whose
+ * components (comp_mean, comp_sd [K,Z]) are the encoder's outputs on the trainable pseudo-inputs.  sum_logp = sum over the L*B MC
+ * samples of log p(z); dmu/dsd as in ladder_gmm_logprob_fwd_bwd; dcomp_mean/dcomp_sd [K,Z] = sum over samples of
+ * dlog p/d comp_mean, dlog p/d comp_sd (fixed-order reduction) -- the gradient entering the pseudo-input encoder pass. */
+size_t ladder_diag_mixture_workspace_bytes(int B, int Z, int K);
+int ladder_diag_mixture_fwd_bwd(const float* mu, const float* sd, const float* eps, const float* comp_mean, const float* comp_sd,
+                                int L, int B, int Z, int K, float* sum_logp, float* dmu, float* dsd, float* dcomp_mean,
+                                float* dcomp_sd, void* ws, size_t ws_bytes, ladder_stream_t stream);
 
 /* ---------------------------------------------------------------- N14: minibatch assembly (the input pipeline)
  * models.py:354-371 (CelebA: uint8 HWC pixels * 1/255), data_loader.py:19-33 (MNIST floats), shuffle + batch of models.py:33-40:

@@ -126,6 +126,8 @@ def param_specs(cfg):
         for i, (a, b) in enumerate(dims):
             add_dense("prior/" + tfname("dense", i), a, b)
         specs["inner_sigma/Variable"] = ()
+    elif cfg["prior"] == "vampPrior":                     # trainable pseudo-inputs (codes/base.py:216-226), scope "prior"
+        specs["prior/Variable"] = (int(cfg["n_mixtures"]), int(cfg["dim_input_x"]), int(cfg["dim_input_y"]), int(cfg["dim_input_channel"]))
     return specs
 
 
@@ -157,6 +159,8 @@ def init_values(cfg, seed=1):
             out[name] = np.asarray(cfg["sigma"], np.float32)
         elif name == "inner_sigma/Variable":
             out[name] = np.asarray(cfg["inner_sigma"], np.float32)
+        elif name == "prior/Variable":                      # tf.random.normal (base.py:224)
+            out[name] = rng.standard_normal(shp).astype(np.float32)
         else:
             out[name] = np.zeros(shp, np.float32)
     return out

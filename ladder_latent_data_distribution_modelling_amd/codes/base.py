@@ -45,7 +45,7 @@ class BaseTrain:
         cfg, eng = self.config, self.engine
         if cfg["prior"] == "standard_gaussian":
             return True, False
-        if cfg["prior"] == "hierarchical":            # codes/base.py:901-911: no mixture feed, no mask
+        if cfg["prior"] in ("hierarchical", "vampPrior"):   # codes/base.py:901-911, 934-941: no mixture feed, no mask
             return self.cur_epoch <= int(cfg["sg_pretraining"]), False
         if cfg["prior"] == "GMM":                     # codes/base.py:912-933: dummy N(0,I) mixture in epoch 1, then the fit + 0.01 I
             if self.cur_epoch == 1 or self.gm_params is None:
@@ -98,6 +98,11 @@ class BaseTrain:
         eng.run_prior(batch_data, lr_p, noise[0] if noise else None, use_sg, use_mask, reuse_encoder=reuse)
         self._enc_batch = batch_data
         f = eng.fetch()
+        self.last_fetch_prior = f
+        if cfg["prior"] == "vampPrior":               # base.py:629-634: loss_prior = -elbo, crossEntropy_prior
+            self.train_loss_prior.append(f["loss_ae"])
+            self.vampPrior_crossEntropy_prior_train.append(f["crossEntropy_prior"])
+            return
         self.code_recons_error_train.append(f["code_l1_reconstruction_error"])
         self.code_recons_likelihood_train.append(f["code_reconstruction_likelihood"])
         self.entropy_t_train.append(f["entropy_t"])
@@ -120,6 +125,10 @@ class BaseTrain:
             self.entropy_z_val.append(f["entropy_z"])
             self.elbo_val.append(f["elbo"])
             self.crossEntropy_prior_val.append(f["crossEntropy_prior"])
+            return f["loss_ae"]
+        if self.config["prior"] == "vampPrior":       # base.py:674-677
+            self.val_loss_prior.append(f["loss_ae"])
+            self.vampPrior_crossEntropy_prior_val.append(f["crossEntropy_prior"])
             return f["loss_ae"]
         self.val_loss_prior.append(f["loss_prior"])
         self.code_recons_error_val.append(f["code_l1_reconstruction_error"])

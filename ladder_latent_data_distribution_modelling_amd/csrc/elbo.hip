@@ -537,6 +537,100 @@ __global__ void gmm_dense_reduce_kernel(const float* __restrict__ dT, const floa
   dsd[i] = b;
 }
 
+// ----------------------------------------------------------------------------- VampPrior: equally weighted diagonal mixture
+// crossEntropy_prior of prior "vampPrior" (codes/base.py:216-254, 361-370): log (1/K) sum_k N(z; m_k, diag(s_k^2)) over L MC
+// samples of q(z|x), where (m_k, s_k) are the encoder's outputs on K trainable pseudo-inputs.  One workgroup per batch row,
+// wavefronts stride over the L samples, LANE = LATENT DIMENSION (Z <= 64): the per-component squared distance is a wave reduction,
+// the gradients w.r.t. the sample (-> code_mean / code_std_dev) and w.r.t. every component (-> pseudo-input path) are lane-local.
+// Component gradients accumulate per wavefront in LDS and leave as one [K, Z] partial per workgroup (summed in fixed order by
+// diag_mixture_reduce_kernel).
+__global__ __launch_bounds__(256) void diag_mixture_kernel(const float* __restrict__ mu, const float* __restrict__ sd,
+                                                           const float* __restrict__ eps, const float* __restrict__ cm,
+                                                           const float* __restrict__ cs, int L, int B, int Z, int K,
+                                                           float* __restrict__ dmu, float* __restrict__ dsd, float* __restrict__ part_m,
+                                                           float* __restrict__ part_s, double* __restrict__ ws_logp) {
+  extern __shared__ float sh[];                   // [4 waves][2][K*Z] component-gradient accumulators, then [4][K] log-probs
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int KZ = K * Z;
+  float* acc_m = sh + (size_t)wv * 2 * KZ;
+  float* acc_s = acc_m + KZ;
+  float* lp = sh + (size_t)8 * KZ + (size_t)wv * K;
+  const bool on = lane < Z;
+  for (int i = lane; i < 2 * KZ; i += 64) acc_m[i] = 0.f;
+  const float m_ = on ? mu[(size_t)b * Z + lane] : 0.f, s_ = on ? sd[(size_t)b * Z + lane] : 0.f;
+  const float logK = __logf((float)K);
+  double acc_lp = 0.0;
+  float g_mu = 0.f, g_sd = 0.f;
+  for (int l = wv; l < L; l += 4) {
+    const float e = on ? eps[((size_t)l * B + b) * Z + lane] : 0.f;
+    const float t = m_ + s_ * e;
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+      float q = 0.f, ls = 0.f;
+      if (on) {
+        const float sk = cs[(size_t)k * Z + lane];
+        const float u = (t - cm[(size_t)k * Z + lane]) / sk;
+        q = u * u;
+        ls = __logf(sk);
+      }
+      q = wave_sum(q);
+      ls = wave_sum(ls);
+      const float v = -0.5f * q - ls - 0.5f * (float)Z * (float)kLog2Pi - logK;
+      lp[k] = v;
+      mx = fmaxf(mx, v);
+    }
+    float se = 0.f;
+    for (int k = lane; k < K; k += 64) se += __expf(lp[k] - mx);
+    se = wave_sum(se);
+    const float lse = mx + __logf(se);
+    acc_lp += (double)lse;
+    if (on) {
+      float gt = 0.f;
+      for (int k = 0; k < K; ++k) {
+        const float r = __expf(lp[k] - lse);
+        const float sk = cs[(size_t)k * Z + lane];
+        const float u = (t - cm[(size_t)k * Z + lane]) / sk;
+        const float g = r * u / sk;                 // -dlogp/dt contribution = +dlogp/dm_k
+        gt -= g;
+        acc_m[k * Z + lane] += g;
+        acc_s[k * Z + lane] += r * (u * u - 1.f) / sk;
+      }
+      g_mu += gt;
+      g_sd += gt * e;
+    }
+  }
+  __shared__ float red[2][4][64];
+  __shared__ double red_lp[4];
+  red[0][wv][lane] = g_mu;
+  red[1][wv][lane] = g_sd;
+  if (lane == 0) red_lp[wv] = acc_lp;
+  __syncthreads();
+  if (wv == 0) {
+    if (on) {
+      dmu[(size_t)b * Z + lane] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+      dsd[(size_t)b * Z + lane] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    }
+    if (lane == 0) ws_logp[b] = (red_lp[0] + red_lp[1]) + (red_lp[2] + red_lp[3]);
+  }
+  for (int i = threadIdx.x; i < KZ; i += 256) {
+    part_m[(size_t)b * KZ + i] = (sh[i] + sh[2 * KZ + i]) + (sh[4 * KZ + i] + sh[6 * KZ + i]);
+    part_s[(size_t)b * KZ + i] = (sh[KZ + i] + sh[3 * KZ + i]) + (sh[5 * KZ + i] + sh[7 * KZ + i]);
+  }
+}
+
+__global__ void diag_mixture_reduce_kernel(const float* __restrict__ part_m, const float* __restrict__ part_s, int B, int KZ,
+                                           float* __restrict__ dcm, float* __restrict__ dcs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= KZ) return;
+  float a = 0.f, c = 0.f;
+  for (int b = 0; b < B; ++b) {                     // fixed order
+    a += part_m[(size_t)b * KZ + i];
+    c += part_s[(size_t)b * KZ + i];
+  }
+  dcm[i] = a;
+  dcs[i] = c;
+}
+
 // ----------------------------------------------------------------------------- clip + Adam (TF form)
 __global__ void adam_clip_kernel(float* __restrict__ theta, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                  size_t n, float lr_t, float b1, float b2, float eps, float clip) {
@@ -770,6 +864,34 @@ int ladder_gmm_dense_logprob_fwd_bwd(const float* mu, const float* sd, const flo
     if (rc != LADDER_OK) return rc;
     hipLaunchKernelGGL(gmm_dense_reduce_kernel, dim3((B * R + 255) / 256), dim3(256), 0, stream, dT, eps, dmu, dsd, L, B * R);
   }
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+size_t ladder_diag_mixture_workspace_bytes(int B, int Z, int K) {
+  return gd_align((size_t)B * sizeof(double)) + 2 * gd_align((size_t)B * K * Z * sizeof(float)) + 256;
+}
+
+int ladder_diag_mixture_fwd_bwd(const float* mu, const float* sd, const float* eps, const float* comp_mean, const float* comp_sd,
+                                int L, int B, int Z, int K, float* sum_logp, float* dmu, float* dsd, float* dcomp_mean,
+                                float* dcomp_sd, void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  if (L <= 0 || B <= 0 || K <= 0 || Z <= 0 || Z > 64) return LADDER_E_SHAPE;
+  const size_t lds = ((size_t)8 * K * Z + (size_t)4 * K) * sizeof(float);
+  if (lds > 150 * 1024) return LADDER_E_SHAPE;
+  if (ws == nullptr || ws_bytes < ladder_diag_mixture_workspace_bytes(B, Z, K)) return LADDER_E_WORKSPACE;
+  char* p = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  double* lpw = (double*)p;          p += gd_align((size_t)B * sizeof(double));
+  float* pm = (float*)p;             p += gd_align((size_t)B * K * Z * sizeof(float));
+  float* psd = (float*)p;
+  static bool attr_set = false;
+  if (!attr_set) {                   // allow > 64 KB of dynamic LDS for this kernel (gfx950: 160 KB per workgroup)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(diag_mixture_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+      return LADDER_E_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(diag_mixture_kernel, dim3(B), dim3(256), lds, stream, mu, sd, eps, comp_mean, comp_sd, L, B, Z, K, dmu, dsd, pm, psd, lpw);
+  hipLaunchKernelGGL(gmm_sum_kernel, dim3(1), dim3(64), 0, stream, (const double*)lpw, B, sum_logp);
+  hipLaunchKernelGGL(diag_mixture_reduce_kernel, dim3((K * Z + 255) / 256), dim3(256), 0, stream, pm, psd, B, K * Z, dcomp_mean, dcomp_sd);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

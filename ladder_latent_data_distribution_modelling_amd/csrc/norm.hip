@@ -588,6 +588,33 @@ __global__ void pad_sym_kernel(const float* __restrict__ x, float* __restrict__ 
   }
 }
 
+// transpose of the SYMMETRIC pad in gather form: an input pixel collects its own position and its mirror images (p <= H, W).
+__global__ void pad_sym_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C, int p) {
+  const int OH = H + 2 * p, OW = W + 2 * p;
+  const size_t total = (size_t)N * H * W * C;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+    const int c = (int)(o % C);
+    size_t t = o / C;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    // padded rows that read input row h: p + h, and the mirrors p - 1 - h (top, if h < p) and p + 2H - 1 - h (bottom, if h >= H - p)
+    int rows[3], cols[3], nr = 0, nc = 0;
+    rows[nr++] = p + h;
+    if (h < p) rows[nr++] = p - 1 - h;
+    if (h >= H - p) rows[nr++] = p + 2 * H - 1 - h;
+    cols[nc++] = p + w;
+    if (w < p) cols[nc++] = p - 1 - w;
+    if (w >= W - p) cols[nc++] = p + 2 * W - 1 - w;
+    float a = 0.f;
+    for (int i = 0; i < nr; ++i)
+      for (int j = 0; j < nc; ++j) a += dy[(((size_t)n * OH + rows[i]) * OW + cols[j]) * C + c];
+    dx[o] = a;
+  }
+}
+
 __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, size_t n, int act) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t n4 = n / 4;
@@ -782,6 +809,13 @@ int ladder_depth_to_space(const float* x, float* y, int N, int H, int W, int C, 
 int ladder_pad_symmetric(const float* x, float* y, int N, int H, int W, int C, int p, ladder_stream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || p < 0 || p > H || p > W) return LADDER_E_SHAPE;
   hipLaunchKernelGGL(pad_sym_kernel, dim3(ew_grid((size_t)N * (H + 2 * p) * (W + 2 * p) * C)), dim3(256), 0, stream, x, y, N, H, W, C, p);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_pad_symmetric_bwd(const float* dy, float* dx, int N, int H, int W, int C, int p, ladder_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || p < 0 || p > H || p > W) return LADDER_E_SHAPE;
+  hipLaunchKernelGGL(pad_sym_bwd_kernel, dim3(ew_grid((size_t)N * H * W * C)), dim3(256), 0, stream, dy, dx, N, H, W, C, p);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

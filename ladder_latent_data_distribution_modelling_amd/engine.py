@@ -107,6 +107,20 @@ class Comm:
         return t
 
 
+class _NoComm:
+    """Communicator stand-in for computations that are REPLICATED on every rank (the VampPrior pseudo-input pass)."""
+    on, world, rank = False, 1, 0
+
+    def allreduce_(self, t):
+        return t
+
+    def allreduce_async_(self, t):
+        return None
+
+    def broadcast_(self, t, src=0):
+        return t
+
+
 class Ctx:
     """Device context shared by all layers: stream handle, grow-only workspace, communicator."""
 
@@ -132,6 +146,13 @@ class Ctx:
 
     def zeros(self, *shape):
         return torch.zeros(*shape, dtype=torch.float32, device=self.device)
+
+    def local(self):
+        """The same device context without cross-rank exchange (batch statistics of a replicated batch stay local)."""
+        import copy
+        c = copy.copy(self)
+        c.comm = _NoComm()
+        return c
 
 
 class ParamStore:
@@ -463,16 +484,23 @@ class Encoder:
             h = self.hidden.forward(h)
         return self.head_mu.forward(h), self.head_sd.forward(h)
 
-    def backward(self, dmu, dsd_raw):
-        dh = self.head_mu.backward(dmu)
-        add_(self.ctx, dh, self.head_sd.backward(dsd_raw, act_done=True))
+    def backward(self, dmu, dsd_raw, wgrad=True, need_input_dx=False):
+        """`need_input_dx`: also return d loss / d x (only the VampPrior pseudo-inputs are trainable inputs)."""
+        dh = self.head_mu.backward(dmu, wgrad=wgrad)
+        add_(self.ctx, dh, self.head_sd.backward(dsd_raw, wgrad=wgrad, act_done=True))
         if self.hidden is not None:
-            dh = self.hidden.backward(dh)
+            dh = self.hidden.backward(dh, wgrad=wgrad)
         dh = dh.reshape(self.conv_shape)
         for i in range(len(self.convs) - 1, -1, -1):
             if self.bns[i] is not None:
-                dh = self.bns[i].backward(dh)
-            dh = self.convs[i].backward(dh, need_dx=(i > 0))
+                dh = self.bns[i].backward(dh, wgrad=wgrad)
+            dh = self.convs[i].backward(dh, need_dx=(i > 0 or need_input_dx), wgrad=wgrad)
+        if need_input_dx and self.exp != "celeba":                 # undo the SYMMETRIC 28 -> 32 pad
+            N, Hp, Wp, C = dh.shape
+            dx = self.ctx.empty(N, Hp - 4, Wp - 4, C)
+            L.call("ladder_pad_symmetric_bwd", _p(dh), _p(dx), N, Hp - 4, Wp - 4, C, 2, self.ctx.stream)
+            dh = dx
+        return dh if need_input_dx else None
 
 
 class MnistDecoder:
@@ -639,12 +667,17 @@ class LadderEngine:
         self.has_inner = cfg["prior"] in ("ours", "hierarchical")
         self.hier = cfg["prior"] == "hierarchical"          # inner VAE against N(0,I): no mixture term, no mask (base.py:331-359)
         self.gmm_z = cfg["prior"] == "GMM"                   # mixture directly on z (R = code_size), no inner VAE (base.py:322-329)
-        if cfg["prior"] not in ("ours", "hierarchical", "GMM", "standard_gaussian"):
-            raise NotImplementedError("prior %r: the HIP path covers 'ours', 'hierarchical', 'GMM' and 'standard_gaussian' "
-                                      "(SURVEY 8f4)" % cfg["prior"])
+        self.vamp = cfg["prior"] == "vampPrior"              # diagonal mixture on z from trainable pseudo-inputs (base.py:216-254)
+        if cfg["prior"] not in ("ours", "hierarchical", "GMM", "vampPrior", "standard_gaussian"):
+            raise ValueError("unknown prior %r" % cfg["prior"])
+        if self.vamp:
+            # second pass of the SAME encoder weights over the K pseudo-inputs (tf.variable_scope('encoder', reuse=True)); the
+            # pseudo-inputs are replicated on every rank, so its batch-norm statistics are not exchanged
+            self.encoder_p = Encoder(self.ctx.local(), self.ps, cfg)
+            self._enc_range = self.ps.prefix_range("ae", "encoder/")
         self.inner = InnerVAE(self.ctx, self.ps, cfg) if self.has_inner else None
         self.Z = int(cfg["code_size"])
-        self.R = int(cfg["code_size"]) if cfg["prior"] == "GMM" else int(cfg.get("representation_size", 1))   # mixture dimension
+        self.R = int(cfg["code_size"]) if cfg["prior"] in ("GMM", "vampPrior") else int(cfg.get("representation_size", 1))   # mixture dimension
         self.K = int(cfg.get("n_mixtures", 1))
         self.Lmc = int(cfg.get("n_MC_samples", 1))
         self.D = int(cfg["dim_input_x"]) * int(cfg["dim_input_y"]) * int(cfg["dim_input_channel"])
@@ -736,6 +769,9 @@ class LadderEngine:
             self.xhat = xhat
         if self.gmm_z and "gmm" in parts:
             self.gmm_grads = self._mixture_term(mu, sd, noise, B, need_grad="gmm_grad" in parts)
+        vamp_on = self.vamp and "gmm" in parts and not use_sg
+        if vamp_on:
+            self.gmm_grads = self._vamp_term(mu, sd, noise, B)
         inner_on = self.has_inner and "inner" in parts
         if inner_on:
             mu_t, sdraw_t = self.inner.encode(z)
@@ -758,7 +794,7 @@ class LadderEngine:
                                1 if inner_on else 0, 1 if use_sg else 0,
                                1 if (self.has_inner and int(self.cfg["TRAIN_inner_sigma"]) == 1) else 0,
                                float(self.cfg.get("inner_sigma_lb", 0.0)), float(self.cfg.get("inner_sigma_ub", 0.0)),
-                               1 if self.hier else 0, 1 if self.gmm_z else 0)
+                               1 if self.hier else 0, 1 if (self.gmm_z or vamp_on) else 0)
         L.call("ladder_elbo_finalize", _p(P), _p(self.ps.w["sigma/Variable"]),
                _p(self.ps.w["inner_sigma/Variable"]) if self.has_inner else None, ecfg, _p(self.scalars), st)
         if self._run_calls:
@@ -785,6 +821,30 @@ class LadderEngine:
                    _p(P[L.P_LOGP:]), _p(dmu), _p(dsd), wsp, wsn, st)
         return dmu, dsd
 
+    def _vamp_term(self, mu, sd, noise, B):
+        """crossEntropy_prior of the VampPrior (base.py:361-370): encoder pass over the pseudo-inputs -> K diagonal components,
+        then the MC mixture term and its gradients towards both the posterior heads and the components."""
+        ctx, st, Z, K, P = self.ctx, self.ctx.stream, self.Z, self.K, self.partials
+        mu_p, sdraw_p = self.encoder_p.forward(self.ps.w["prior/Variable"])
+        eps0, sd_p, scratch = ctx.zeros(K, Z), ctx.empty(K, Z), ctx.zeros(4)
+        L.call("ladder_latent_fwd", _p(mu_p), _p(sdraw_p), _p(eps0), self.lvp, None, _p(sd_p), _p(scratch), _p(scratch[1:]), None, K, Z, st)
+        eps_mc = self._noise(noise, "eps_mc", (self.Lmc, B, Z))
+        dmu, dsd, dcm, dcs = ctx.empty(B, Z), ctx.empty(B, Z), ctx.empty(K, Z), ctx.empty(K, Z)
+        wsp, wsn = ctx.ws(L.query("ladder_diag_mixture_workspace_bytes", B, Z, K))
+        L.call("ladder_diag_mixture_fwd_bwd", _p(mu), _p(sd), _p(eps_mc), _p(mu_p), _p(sd_p), self.Lmc, B, Z, K, _p(P[L.P_LOGP:]),
+               _p(dmu), _p(dsd), _p(dcm), _p(dcs), wsp, wsn, st)
+        self.vamp_state = (mu_p, sd_p, sdraw_p, eps0, dcm, dcs)
+        return dmu, dsd
+
+    def _vamp_backward(self, wgrad, need_input_dx):
+        """Backward of the pseudo-input pass: d loss/d components = -(1/LB) * (dcomp_mean, dcomp_sd) through the heads."""
+        ctx, st, Z, K = self.ctx, self.ctx.stream, self.Z, self.K
+        mu_p, sd_p, sdraw_p, eps0, dcm, dcs = self.vamp_state
+        dmu_h, dsdraw_h = ctx.empty(K, Z), ctx.empty(K, Z)
+        L.call("ladder_latent_bwd", None, _p(mu_p), _p(sd_p), _p(sdraw_p), _p(eps0), _p(dcm), _p(dcs), -1.0, _p(self.scalars), 0,
+               _p(dmu_h), _p(dsdraw_h), K, Z, st)
+        return self.encoder_p.backward(dmu_h, dsdraw_h, wgrad=wgrad, need_input_dx=need_input_dx)
+
     @staticmethod
     def _enc_needs_grad(parts):
         return False          # only run_ae back-propagates into the encoder, and it never asks for reuse
@@ -808,6 +868,14 @@ class LadderEngine:
     def _backward_ae(self):
         ctx, st, B, Z, R = self.ctx, self.ctx.stream, self.B, self.Z, self.R
         mu, sd, sd_raw, eps_z, z = self.lat_z
+        vamp_on = self.vamp and not self.use_sg
+        saved_enc = None
+        if vamp_on:
+            # the encoder weights receive two gradient contributions (data pass + pseudo-input pass); the filter-gradient kernels
+            # overwrite, so the pseudo-pass result is parked and added back after the data pass
+            self._vamp_backward(wgrad=True, need_input_dx=False)
+            lo, hi = self._enc_range
+            saved_enc = self.ps.grad["ae"][lo:hi].clone()
         dxhat = torch.empty_like(self.xhat)
         L.call("ladder_pixel_grad", _p(self.x), _p(self.xhat), _p(self._sc("_g_pix")), _p(dxhat), dxhat.numel(), st)
         dz = self.decoder.backward(dxhat)
@@ -831,12 +899,15 @@ class LadderEngine:
         else:
             mode = 3
         ex_mu, ex_sd = (None, None)
-        if self.gmm_z:                                        # -crossEntropy_prior = -(1/LB) sum log p_GM(z_l): mixture grads, no SG term
+        if self.gmm_z or vamp_on:                             # -crossEntropy_prior = -(1/LB) sum log p(z_l): mixture grads, no SG term
             mode, (ex_mu, ex_sd) = 1, self.gmm_grads
         dmu, dsdraw = ctx.empty(B, Z), ctx.empty(B, Z)
         L.call("ladder_latent_bwd", _p(dz), _p(mu), _p(sd), _p(sd_raw), _p(eps_z), _p(ex_mu), _p(ex_sd), -1.0, _p(self.scalars), mode,
                _p(dmu), _p(dsdraw), B, Z, st)
         self.encoder.backward(dmu, dsdraw)
+        if saved_enc is not None:
+            lo, hi = self._enc_range
+            add_(ctx, self.ps.grad["ae"][lo:hi], saved_enc)
 
     def _backward_prior(self):
         ctx, st, B, Z, R = self.ctx, self.ctx.stream, self.B, self.Z, self.R
@@ -857,6 +928,8 @@ class LadderEngine:
         parts = ("dec",) if (use_sg or not self.has_inner) else ("dec", "inner", "gmm")
         if self.gmm_z:
             parts = ("dec", "gmm", "gmm_grad")
+        if self.vamp:
+            parts = ("dec", "gmm")
         self.forward(x, noise, use_sg, use_mask, parts)
         self._backward_ae()
         g = self.ps.grad["ae"]                                    # C1 (sum of per-rank grads of the global-mean loss)
@@ -877,6 +950,18 @@ class LadderEngine:
         self.ps.adam("sigma", lr, grad=self._sc("_g_sigma_var"), n=1)
 
     def _prior(self, x, lr, noise, use_sg, use_mask, reuse_encoder=False):
+        if self.vamp:
+            # loss_prior = -elbo w.r.t. the pseudo-inputs (base.py:408-409, 474-481): only the mixture term depends on them; with
+            # the standard-Gaussian switch on, the gradient is identically zero (the optimiser still steps, as tf.cond does)
+            self.forward(x, noise, use_sg, use_mask, ("dec", "gmm"), reuse_encoder)
+            g = self.ps.g["prior/Variable"]
+            if use_sg:
+                g.zero_()
+            else:
+                g.copy_(self._vamp_backward(wgrad=False, need_input_dx=True))
+            self.ctx.comm.allreduce_(self.ps.grad["prior"])       # C4
+            self.ps.adam("prior", lr)
+            return
         self.forward(x, noise, use_sg, use_mask, ("inner", "gmm"), reuse_encoder)
         self._backward_prior()
         self.ctx.comm.allreduce_(self.ps.grad["prior"])           # C4
@@ -887,7 +972,7 @@ class LadderEngine:
         self.ps.adam("inner_sigma", lr, grad=self._sc("_g_inner_sigma_var"), n=1)
 
     _GROUP = {"ae": "ae", "sigma": "sigma", "prior": "prior", "inner_sigma": "inner_sigma"}
-    _SNAP = ("x", "B", "Bg", "lat_z", "lat_t", "xhat", "zhat", "gmm_grads", "use_sg", "use_mask")
+    _SNAP = ("x", "B", "Bg", "lat_z", "lat_t", "xhat", "zhat", "gmm_grads", "vamp_state", "use_sg", "use_mask")
 
     def _run(self, kind, x, lr, noise, use_sg, use_mask, reuse_encoder):
         """Eager, or -- with `use_graphs` -- one captured hipGraph per (run kind, regime, batch shape): after two eager
@@ -942,7 +1027,7 @@ class LadderEngine:
         self._run("inner_sigma", x, lr, noise, use_sg, use_mask, reuse_encoder)
 
     def evaluate(self, x, noise=None, use_sg=True, use_mask=False):
-        parts = ("dec", "inner", "gmm") if ((self.has_inner or self.gmm_z) and self._gm_packed is not None) else ("dec", "inner")
+        parts = ("dec", "inner", "gmm") if (((self.has_inner or self.gmm_z) and self._gm_packed is not None) or self.vamp) else ("dec", "inner")
         self.forward(x, noise, use_sg, use_mask, parts)
 
     # -- generation -----------------------------------------------------------------------------

@@ -321,6 +321,9 @@ def param_specs(config):
             dens(pr, H, H)
         dens(pr, H, Z)
         specs["inner_sigma/Variable"] = ()
+    elif config["prior"] == "vampPrior":                 # codes/base.py:216-226: trainable pseudo-inputs, scope "prior"
+        specs["prior/Variable"] = (int(config["n_mixtures"]), int(config["dim_input_x"]), int(config["dim_input_y"]),
+                                   int(config["dim_input_channel"]))
     return specs
 
 
@@ -347,6 +350,8 @@ def init_params(config, seed=1):
             P[name] = np.float32(config["sigma"]).reshape(())
         elif name == "inner_sigma/Variable":
             P[name] = np.float32(config["inner_sigma"]).reshape(())
+        elif name == "prior/Variable":                      # tf.random.normal (base.py:224)
+            P[name] = rng.standard_normal(shp).astype(np.float32)
         else:
             P[name] = np.zeros(shp, np.float32)
     return P
@@ -529,6 +534,18 @@ def forward(config, P, x, eps_z, eps_t=None, eps_mc=None, gm=None,
     prior = config["prior"]
     if prior == "standard_gaussian":
         out["crossEntropy_prior"] = out["crossEntropy_prior_sg"]
+    elif prior == "vampPrior":                                   # base.py:216-254, 361-370
+        # the encoder (shared weights, batch statistics of the K pseudo-inputs themselves) maps the trainable pseudo-inputs to the
+        # components of an equally weighted diagonal-Gaussian mixture on z; pseudo-inputs are replicated under data parallelism
+        mu_p, sd_p = encoder(config, P, P["prior/Variable"], None)
+        K = mu_p.shape[0]
+        L = eps_mc.shape[0]
+        z_mc = (mu_z.unsqueeze(0) + sd_z.unsqueeze(0) * eps_mc).unsqueeze(2)          # [L,B,1,Z]
+        u = (z_mc - mu_p) / sd_p                                                       # [L,B,K,Z]
+        lp = -0.5 * (u ** 2).sum(-1) - torch.log(sd_p).sum(-1) - 0.5 * Z * LOG_2PI - math.log(K)
+        vamp = ar(torch.logsumexp(lp, dim=-1).sum()) / (L * Bg)
+        out["crossEntropy_prior_vamp"] = vamp
+        out["crossEntropy_prior"] = out["crossEntropy_prior_sg"] if use_sg else vamp
     elif prior == "GMM":                                         # base.py:322-329: MC mean of the mixture log-prob of z samples
         L = eps_mc.shape[0]
         z_mc = mu_z.unsqueeze(0) + sd_z.unsqueeze(0) * eps_mc
@@ -570,7 +587,7 @@ def forward(config, P, x, eps_z, eps_t=None, eps_mc=None, gm=None,
         out["crossEntropy_prior"] = out["crossEntropy_prior_sg"] if use_sg else out["elbo_prior"]
         out["loss_prior"] = -out["elbo_prior"]
     else:
-        raise NotImplementedError("oracle covers prior in {'ours','hierarchical','GMM','standard_gaussian'}")
+        raise NotImplementedError("unknown prior %r" % prior)
 
     diff = x - xhat                                             # base.py:374-396
     out["l2_reconstruction_error"] = ar((diff ** 2).sum()) / Bg
@@ -580,6 +597,8 @@ def forward(config, P, x, eps_z, eps_t=None, eps_mc=None, gm=None,
     out["elbo"] = (out["reconstruction_likelihood"] + out["sigma_regularisor"]
                    - out["entropy_z"] + out["crossEntropy_prior"])
     out["loss_ae"] = -out["elbo"]
+    if prior == "vampPrior":
+        out["loss_prior"] = -out["elbo"]                         # base.py:408-409
     return out
 
 
@@ -684,7 +703,7 @@ def train_iteration(state, x, noises, gm, cur_epoch, lr_ae, allreduce=None, glob
 
 def make_noise(config, B, rng, dtype=np.float64):
     Z, R, L = int(config["code_size"]), int(config.get("representation_size", 1)), int(config["n_MC_samples"])
-    Rmc = Z if config.get("prior") == "GMM" else R             # prior "GMM": the MC samples are z samples (base.py:324-327)
+    Rmc = Z if config.get("prior") in ("GMM", "vampPrior") else R   # these priors sample z, not t (base.py:324-327, 363-366)
     return dict(eps_z=rng.standard_normal((B, Z)).astype(dtype),
                 eps_t=rng.standard_normal((B, R)).astype(dtype),
                 eps_mc=rng.standard_normal((L, B, Rmc)).astype(dtype))

@@ -327,6 +327,50 @@ def test_gmm_dense_logprob(gpu_ctx, K, R, Lmc, B):
     assert L.query("ladder_gmm_prepare_dense", p(wd), p(md), p(cd), K, 72, p(params), st) != 0       # R > 64: LADDER_E_SHAPE
 
 
+@pytest.mark.parametrize("K,Z,Lmc,B", [(30, 64, 100, 16), (10, 8, 7, 5), (3, 16, 2, 3), (70, 5, 9, 4)])
+def test_diag_mixture_vamp(gpu_ctx, K, Z, Lmc, B):
+    """VampPrior term: log of an equally weighted diagonal mixture over L MC samples, with the gradients to the posterior heads
+    AND to the K components (the pseudo-input path), vs float64 autograd of the formula in codes/base.py:244-254, 361-370."""
+    L = _lib()
+    rng = np.random.default_rng(K + Z)
+    mu = (rng.standard_normal((B, Z)) * 1.2).astype(np.float32)
+    sd = (0.1 + rng.random((B, Z))).astype(np.float32)
+    eps = rng.standard_normal((Lmc, B, Z)).astype(np.float32)
+    cm = rng.standard_normal((K, Z)).astype(np.float32)
+    cs = (0.3 + rng.random((K, Z))).astype(np.float32)
+    mut, sdt, cmt, cst = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (mu, sd, cm, cs))
+    z = (mut.unsqueeze(0) + sdt.unsqueeze(0) * torch.tensor(eps, dtype=torch.float64)).unsqueeze(2)
+    u = (z - cmt) / cst
+    lp = -0.5 * (u ** 2).sum(-1) - torch.log(cst).sum(-1) - 0.5 * Z * np.log(2 * np.pi) - np.log(K)
+    tot = torch.logsumexp(lp, dim=-1).sum()
+    tot.backward()
+    st = gpu_ctx.stream
+    out = torch.empty(1, device="cuda")
+    dmu, dsd, dcm, dcs = (torch.empty(B, Z, device="cuda"), torch.empty(B, Z, device="cuda"), torch.empty(K, Z, device="cuda"),
+                          torch.empty(K, Z, device="cuda"))
+    ws = torch.empty(L.query("ladder_diag_mixture_workspace_bytes", B, Z, K), dtype=torch.uint8, device="cuda")
+    a = [dev(v) for v in (mu, sd, eps, cm, cs)]
+    L.call("ladder_diag_mixture_fwd_bwd", *(p(t) for t in a), Lmc, B, Z, K, p(out), p(dmu), p(dsd), p(dcm), p(dcs), p(ws), ws.numel(), st)
+    assert abs(out.item() - tot.item()) < 3e-5 * abs(tot.item()) + 1e-3
+    close(dmu, mut.grad, 1e-4, "dmu")
+    close(dsd, sdt.grad, 1e-4, "dsd")
+    close(dcm, cmt.grad, 1e-4, "dcomp_mean")
+    close(dcs, cst.grad, 1e-4, "dcomp_sd")
+
+
+def test_pad_symmetric_bwd(gpu_ctx):
+    L = _lib()
+    rng = np.random.default_rng(2)
+    for (N, H, W, C, pp) in ((3, 28, 28, 1, 2), (2, 5, 7, 3, 3), (1, 4, 4, 2, 4)):
+        x = torch.tensor(rng.standard_normal((N, H, W, C)), dtype=torch.float64, requires_grad=True)
+        y = O.pad_symmetric(x, pp)
+        dy = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+        y.backward(torch.tensor(dy, dtype=torch.float64))
+        dyd, dx = dev(dy), torch.empty(N, H, W, C, device="cuda")
+        L.call("ladder_pad_symmetric_bwd", p(dyd), p(dx), N, H, W, C, pp, gpu_ctx.stream)
+        close(dx, x.grad, 1e-6, "pad_sym_bwd")
+
+
 def test_adam_clip_matches_tf_form(gpu_ctx):
     L = _lib()
     rng = np.random.default_rng(0)
