@@ -94,12 +94,30 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(const float* __restrict
     p_log[0] = (float)a;
     p_mu2sd2[0] = (float)b;
   }
-  if (p_sdsum != nullptr)
-    for (int j = threadIdx.x; j < Z; j += 256) {
+  if (p_sdsum != nullptr) {
+    if (Z <= 256) {
+      // column sums over the batch: G = 256/Z thread groups each take every G-th row (B dependent loads per thread made this tiny
+      // kernel 25 us at B = 256), then a fixed-order combine over the groups
+      __shared__ double col[256];
+      const int G = 256 / Z, j = (int)threadIdx.x % Z, g = (int)threadIdx.x / Z;
       double s = 0.0;
-      for (int bb = 0; bb < B; ++bb) s += (double)(sd_raw[bb * Z + j] + lvp);
-      p_sdsum[j] = (float)s;
+      if (g < G)
+        for (int bb = g; bb < B; bb += G) s += (double)(sd_raw[bb * Z + j] + lvp);
+      col[threadIdx.x] = s;
+      __syncthreads();
+      if (g == 0) {
+        double t = 0.0;
+        for (int q = 0; q < G; ++q) t += col[q * Z + j];
+        p_sdsum[j] = (float)t;
+      }
+    } else {
+      for (int j = threadIdx.x; j < Z; j += 256) {
+        double s = 0.0;
+        for (int bb = 0; bb < B; ++bb) s += (double)(sd_raw[bb * Z + j] + lvp);
+        p_sdsum[j] = (float)s;
+      }
     }
+  }
 }
 
 __global__ __launch_bounds__(256) void code_partials_kernel(const float* __restrict__ z, const float* __restrict__ zhat,
@@ -404,12 +422,11 @@ __global__ __launch_bounds__(256) void gmm_logprob_kernel(const float* __restric
   }
   if (threadIdx.x == 0) ws_logp[b] = (sm_lp[0] + sm_lp[1]) + (sm_lp[2] + sm_lp[3]);
 }
-__global__ void gmm_sum_kernel(const double* __restrict__ ws, int B, float* __restrict__ out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0.0;
-    for (int b = 0; b < B; ++b) s += ws[b];
-    out[0] = (float)s;
-  }
+__global__ __launch_bounds__(64) void gmm_sum_kernel(const double* __restrict__ ws, int B, float* __restrict__ out) {
+  double s = 0.0;                                    // one wavefront: lane-strided partial sums, then a fixed-order shuffle tree
+  for (int b = threadIdx.x; b < B; b += 64) s += ws[b];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) out[0] = (float)s;
 }
 
 // ----------------------------------------------------------------------------- mixture log-prob for WIDE latents (prior "GMM")

@@ -551,23 +551,23 @@ __global__ __launch_bounds__(256) void gather_rows_scalar_kernel(const T* __rest
   }
 }
 
-__global__ void d2s_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C, int r, int inverse) {
-  // forward: y[n, h*r+i, w*r+j, c'] = x[n, h, w, (i*r+j)*C' + c'] ; inverse swaps the roles.
-  const int Cp = C / (r * r);
-  const size_t total = (size_t)N * H * W * C;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
-    const int cp = (int)(o % Cp);
-    size_t t = o / Cp;
-    const int ow = (int)(t % (W * r));
-    t /= (W * r);
-    const int oh = (int)(t % (H * r));
-    const int n = (int)(t / (H * r));
-    const int h = oh / r, i = oh - h * r, w = ow / r, j = ow - w * r;
-    const size_t small = (((size_t)n * H + h) * W + w) * C + (size_t)(i * r + j) * Cp + cp;
-    if (inverse) y[small] = x[o];
-    else y[o] = x[small];
-  }
+// forward: y[n, h*r+i, w*r+j, c'] = x[n, h, w, (i*r+j)*C' + c'] (DCR) ; inverse swaps the roles.  For a fixed output row (n, h*r+i) the
+// r*C' floats of every w are one contiguous segment in BOTH layouts (source offset w*C + i*r*C', output offset w*r*C'), so the op is
+// a row-wise copy of W segments: `bpr` blocks per output row, V floats per thread, 32-bit index arithmetic.
+template <int V>
+__global__ __launch_bounds__(256) void d2s_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C, int r,
+                                                  int inverse, int bpr) {
+  using T = typename ResizeVec<V>::T;
+  const int row = blockIdx.x / bpr;                  // n*H*r + oh
+  const int e = ((blockIdx.x - row * bpr) * blockDim.x + threadIdx.x) * V;
+  const int seg = C / r;                             // r * C'
+  if (e >= W * seg) return;
+  const int nh = row / r, i = row - nh * r;          // nh = n*H + h
+  const int w = e / seg, q = e - w * seg;
+  const size_t small = ((size_t)nh * W + w) * C + (size_t)i * seg + q;
+  const size_t big = (size_t)row * W * seg + e;
+  if (inverse) *reinterpret_cast<T*>(y + small) = *reinterpret_cast<const T*>(x + big);
+  else *reinterpret_cast<T*>(y + big) = *reinterpret_cast<const T*>(x + small);
 }
 
 __global__ void pad_sym_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C, int p) {
@@ -801,7 +801,13 @@ int ladder_gather_rows(const void* src, int src_is_u8, const int64_t* idx, float
 
 int ladder_depth_to_space(const float* x, float* y, int N, int H, int W, int C, int r, int inverse, ladder_stream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || r <= 0 || C % (r * r)) return LADDER_E_SHAPE;
-  hipLaunchKernelGGL(d2s_kernel, dim3(ew_grid((size_t)N * H * W * C)), dim3(256), 0, stream, x, y, N, H, W, C, r, inverse);
+  const int seg = C / r;                              // contiguous run shared by both layouts
+  const bool v4 = (seg % 4 == 0) && ladder_aligned16(x) && ladder_aligned16(y);
+  const long per_row = (long)W * seg / (v4 ? 4 : 1);
+  const long bpr = (per_row + 255) / 256, rows = (long)N * H * r;
+  if (bpr * rows >= (1L << 31) || (long)W * seg >= (1L << 31)) return LADDER_E_SHAPE;
+  if (v4) hipLaunchKernelGGL(d2s_kernel<4>, dim3((unsigned)(bpr * rows)), dim3(256), 0, stream, x, y, H, W, C, r, inverse, (int)bpr);
+  else hipLaunchKernelGGL(d2s_kernel<1>, dim3((unsigned)(bpr * rows)), dim3(256), 0, stream, x, y, H, W, C, r, inverse, (int)bpr);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
