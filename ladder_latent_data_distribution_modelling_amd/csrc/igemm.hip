@@ -540,6 +540,27 @@ __global__ __launch_bounds__(256) void reduce_splits_wide_kernel(const float* __
   }
 }
 
+// Block partials with a trailing bias slot, ws[S][n+1]: out[i] = sum_s ws[s][i] (i < n), bias_out[0] = sum_s ws[s][n].
+// 16 threads per output, each summing every 16th partial, then a fixed-order LDS combine (as reduce_splits_wide_kernel).
+__global__ __launch_bounds__(256) void reduce_partials_bias_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                                   float* __restrict__ bias_out, int S, int n) {
+  __shared__ float part[16][17];
+  const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + o;
+  float a = 0.f;
+  if (i <= n)
+    for (int z = g; z < S; z += 16) a += ws[(size_t)z * (n + 1) + i];
+  part[g][o] = a;
+  __syncthreads();
+  if (g == 0 && i <= n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][o];
+    if (i < n) out[i] = t;
+    else if (bias_out != nullptr) bias_out[0] = t;
+  }
+}
+
 static inline void launch_reduce_splits(const float* ws, float* out, int S, size_t n, hipStream_t st) {
   if (S >= 32 && n * 16 <= ((size_t)1 << 24))
     hipLaunchKernelGGL(reduce_splits_wide_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, ws, out, S, n);
@@ -869,6 +890,98 @@ int launch_smallcin(const float* x, const float* w, const float* bias, float* y,
   return LADDER_OK;
 }
 
+// ---- single-output-channel 5x5 VALID convolution: the MNIST decoders' output layer (codes/models.py:141-148, 308-315) -----------
+// [B,32,32,Cin] -> [B,28,28,1] is a per-pixel dot product of length 25*Cin: as a GEMM it wastes 31/32 of an N tile (329 us forward,
+// 381 us filter gradient at B = 256, Cin = 64 -- a fifth of the MNIST-fashion iteration).  Direct form: lane = input channel, a
+// wavefront walks one output row (64/Cin rows when Cin < 64) left to right keeping the KH x KW input window in registers -- each
+// step loads ONE new column (KH loads) instead of KH*KW -- and reduces over the channel lanes with shuffles.  The filter gradient
+// uses the same sliding window with dy as the broadcast scalar and 25 accumulators per lane.
+template <int KH_, int KW_, int CL, bool WGRAD>
+__global__ __launch_bounds__(256) void conv_cout1_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         const float* __restrict__ dy, float* __restrict__ part, int H, int W, int Ho,
+                                                         int Wo, int act, int rows_total) {
+  constexpr int RPW = 64 / CL, KT = KH_ * KW_;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ci = lane % CL, rg = lane / CL;
+  float wr[KT], acc[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    wr[t] = WGRAD ? 0.f : w[t * CL + ci];
+    acc[t] = 0.f;
+  }
+  const float b = (!WGRAD && bias != nullptr) ? bias[0] : 0.f;
+  float bsum = 0.f;
+  for (int rb = (blockIdx.x * 4 + wv) * RPW; rb < rows_total; rb += gridDim.x * 4 * RPW) {
+    const int row = rb + rg;
+    const bool valid = row < rows_total;
+    const int rc = valid ? row : rows_total - 1;
+    const int n = rc / Ho, oh = rc - n * Ho;
+    const float* xr = x + ((size_t)n * H + oh) * W * CL + ci;         // input row oh (pad 0), column 0
+    float win[KH_][KW_];
+#pragma unroll
+    for (int kh = 0; kh < KH_; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < KW_ - 1; ++kw) win[kh][kw] = xr[((size_t)kh * W + kw) * CL];
+    for (int ow0 = 0; ow0 < Wo; ow0 += KW_) {
+#pragma unroll
+      for (int p = 0; p < KW_; ++p) {
+        const int ow = ow0 + p;
+        if (ow < Wo) {                                                 // wave-uniform
+#pragma unroll
+          for (int kh = 0; kh < KH_; ++kh) win[kh][(p + KW_ - 1) % KW_] = xr[((size_t)kh * W + ow + KW_ - 1) * CL];
+          if (WGRAD) {
+            const float g = valid ? dy[(size_t)rc * Wo + ow] : 0.f;
+#pragma unroll
+            for (int kh = 0; kh < KH_; ++kh)
+#pragma unroll
+              for (int kw = 0; kw < KW_; ++kw) acc[kh * KW_ + kw] = fmaf(win[kh][(p + kw) % KW_], g, acc[kh * KW_ + kw]);
+            bsum += g;
+          } else {
+            float s = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < KH_; ++kh)
+#pragma unroll
+              for (int kw = 0; kw < KW_; ++kw) s = fmaf(win[kh][(p + kw) % KW_], wr[kh * KW_ + kw], s);
+#pragma unroll
+            for (int o = CL / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (ci == 0 && valid) y[(size_t)row * Wo + ow] = ladder_act_fn(s + b, act);
+          }
+        }
+      }
+    }
+  }
+  if (WGRAD) {
+    // block partial [KT][CL] (+ bias): sum the 4 waves x RPW row groups in LDS in a fixed order
+    __shared__ float red[4][64];
+    float* out = part + (size_t)blockIdx.x * (KT * CL + 1);
+    for (int t = 0; t <= KT; ++t) {
+      red[wv][lane] = t < KT ? acc[t] : bsum;
+      __syncthreads();
+      if (threadIdx.x < CL) {
+        float v = 0.f;
+        for (int q = 0; q < 4; ++q)
+          for (int g2 = 0; g2 < RPW; ++g2) v += red[q][g2 * CL + threadIdx.x];
+        if (t < KT) out[t * CL + threadIdx.x] = v;
+        else if (threadIdx.x == 0) out[KT * CL] = v;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+bool cout1_eligible(int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int H, int W, int Ho, int Wo) {
+  static const bool off = getenv("LADDER_DISABLE_COUT1") != nullptr;
+  return !off && Cout == 1 && KH == 5 && KW == 5 && stride == 1 && pad_t == 0 && pad_l == 0 && Ho == H - 4 && Wo == W - 4 &&
+         (Cin == 16 || Cin == 32 || Cin == 64);
+}
+int cout1_blocks(int rows, int Cin) {
+  const int rpb = 4 * (64 / Cin);
+  int b = (rows + rpb - 1) / rpb;
+  return b > 1024 ? 1024 : b;
+}
+size_t cout1_wgrad_ws_bytes(int N, int Ho, int Cin) { return (size_t)cout1_blocks(N * Ho, Cin) * (25 * Cin + 1) * sizeof(float); }
+
 int dispatch_fwd(const float* x, const float* w, const float* bias, float* y, const IgemmDesc& d, void* ws, size_t ws_bytes,
                  hipStream_t st, const float* gate = nullptr, int gate_act = 0) {
   if (d.M <= 0 || d.K <= 0 || d.Cout <= 0) return LADDER_E_SHAPE;
@@ -1144,6 +1257,15 @@ int ladder_conv2d_fwd(const float* x, const float* w, const float* bias, float* 
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return LADDER_E_SHAPE;
   IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, 1, pad_t, pad_l, N * Ho * Wo, KH * KW * Cin, act, make_fastdiv(Ho * Wo), make_fastdiv(Wo)};
   set_conv_taps(d);
+  if (cout1_eligible(Cin, Cout, KH, KW, stride, pad_t, pad_l, H, W, Ho, Wo)) {
+    const int rows = N * Ho, blocks = cout1_blocks(rows, Cin);
+#define LADDER_COUT1_FWD(CL_) hipLaunchKernelGGL((conv_cout1_kernel<5, 5, CL_, false>), dim3(blocks), dim3(256), 0, stream, x, w, bias, y, \
+                                                 (const float*)nullptr, (float*)nullptr, H, W, Ho, Wo, act, rows)
+    if (Cin == 64) LADDER_COUT1_FWD(64); else if (Cin == 32) LADDER_COUT1_FWD(32); else LADDER_COUT1_FWD(16);
+#undef LADDER_COUT1_FWD
+    LADDER_CHECK_LAUNCH();
+    return LADDER_OK;
+  }
   return dispatch_fwd(x, w, bias, y, d, ws, ws_bytes, stream);
 }
 
@@ -1216,7 +1338,9 @@ int ladder_conv2d_bwd_data(const float* dy, const float* wT, float* dx, int N, i
 size_t ladder_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW) {
   // upper bound over the stride/pad variants of this geometry (the halo path needs stride 1 / pad 1 / Ho==H)
   IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, 1, 1, 1, 1, N * Ho * Wo, KH * KW * Cin, 0, make_fastdiv(1), make_fastdiv(1)};
-  return wgrad_ws_bytes_desc(d);
+  size_t need = wgrad_ws_bytes_desc(d);
+  if (cout1_eligible(Cin, Cout, KH, KW, 1, 0, 0, H, W, Ho, Wo) && cout1_wgrad_ws_bytes(N, Ho, Cin) > need) need = cout1_wgrad_ws_bytes(N, Ho, Cin);
+  return need;
 }
 
 int ladder_conv2d_bwd_filter(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Ho,
@@ -1224,6 +1348,18 @@ int ladder_conv2d_bwd_filter(const float* x, const float* dy, float* dw, float* 
                              ladder_stream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return LADDER_E_SHAPE;
   IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, 1, pad_t, pad_l, N * Ho * Wo, KH * KW * Cin, LADDER_ACT_NONE, make_fastdiv(Ho * Wo), make_fastdiv(Wo)};
+  if (cout1_eligible(Cin, Cout, KH, KW, stride, pad_t, pad_l, H, W, Ho, Wo)) {
+    if (ws == nullptr || ws_bytes < cout1_wgrad_ws_bytes(N, Ho, Cin)) return LADDER_E_WORKSPACE;
+    const int rows = N * Ho, blocks = cout1_blocks(rows, Cin), kn = 25 * Cin;
+    float* part = (float*)ws;
+#define LADDER_COUT1_WG(CL_) hipLaunchKernelGGL((conv_cout1_kernel<5, 5, CL_, true>), dim3(blocks), dim3(256), 0, stream, x, (const float*)nullptr, \
+                                                (const float*)nullptr, (float*)nullptr, dy, part, H, W, Ho, Wo, 0, rows)
+    if (Cin == 64) LADDER_COUT1_WG(64); else if (Cin == 32) LADDER_COUT1_WG(32); else LADDER_COUT1_WG(16);
+#undef LADDER_COUT1_WG
+    hipLaunchKernelGGL(reduce_partials_bias_kernel, dim3((kn + 1 + 15) / 16), dim3(256), 0, stream, (const float*)part, dw, db, blocks, kn);
+    LADDER_CHECK_LAUNCH();
+    return LADDER_OK;
+  }
   return run_wgrad(x, dy, dw, db, d, ws, ws_bytes, stream);
 }
 

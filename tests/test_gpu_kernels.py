@@ -59,7 +59,10 @@ CONV_CASES = [
     (4, 4, 4, 16, 64, 3, 1, "same", "leaky_relu"),
     (2, 1, 1, 32, 32, 1, 1, "same", None),             # M=2
     (4, 16, 16, 16, 64, 3, 1, "same", "leaky_relu"),
-    (4, 32, 32, 16, 1, 5, 1, "valid", "relu"),         # fashion output conv
+    (4, 32, 32, 16, 1, 5, 1, "valid", "relu"),         # MNIST-digit output conv: conv_cout1_kernel, 4 rows per wavefront
+    (9, 32, 32, 64, 1, 5, 1, "valid", "relu"),         # MNIST-fashion output conv: conv_cout1_kernel (lane = input channel)
+    (300, 32, 32, 32, 1, 5, 1, "valid", None),         # more rows than one grid pass (grid-stride), 2 rows per wavefront
+    (3, 12, 9, 64, 1, 5, 1, "valid", None),            # non-square map, Wo = 5 (one window group)
     (4, 8, 8, 16, 64, 3, 1, "same", "leaky_relu"),
     (4, 4, 4, 32, 32, 3, 1, "valid", "leaky_relu"),    # fashion encoder valid conv
     (32, 2, 2, 256, 256, 3, 1, "same", None),          # split-K regime (few tiles, long K)
