@@ -77,6 +77,15 @@ int ladder_conv2d_bwd_filter(const float* x, const float* dy, float* dw, float* 
                              int KH, int KW, int stride, int pad_t, int pad_l,
                              void* ws, size_t ws_bytes, ladder_stream_t stream);
 
+/* ---- fused backward of a 1x1 convolution to <= 4 channels over a wide map (the CelebA output conv, codes/models.py:580-586):
+ * ONE pass over x [M, Cin] (the producing layer's OUTPUT) yields dx = (dy . W^T) * act'(x) (gate_act = that layer's activation,
+ * 0 = none; dx may be NULL), dw [Cin, Cout] and db [Cout] (may be NULL).  Eligible: Cout <= 4, Cin/4 a power of two in 4..64,
+ * M >= 65536 (ladder_conv1x1_smallcout_eligible).  ladder_conv2d_fwd uses the matching forward kernel for the same shapes. */
+int ladder_conv1x1_smallcout_eligible(long M, int Cin, int Cout);
+size_t ladder_conv1x1_smallcout_bwd_workspace_bytes(long M, int Cin, int Cout);
+int ladder_conv1x1_smallcout_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long M, int Cin,
+                                 int Cout, int gate_act, void* ws, size_t ws_bytes, ladder_stream_t stream);
+
 /* ---------------------------------------------------------------- N2: tf.layers.dense
  * codes/models.py:73-95,109,231-253,267,478-488,501-510; codes/modules.py:8; codes/base.py:145-186.
  * y[M,N] = act(x[M,K] @ w[K,N] + b).  MFMA-f32 (v_mfma_f32_32x32x2_f32). */

@@ -88,6 +88,9 @@ PROTOTYPES = {
     "ladder_diag_mixture_workspace_bytes": (_z, [_i, _i, _i]),
     "ladder_diag_mixture_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
     "ladder_pad_symmetric_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "ladder_conv1x1_smallcout_eligible": (_i, [C.c_long, _i, _i]),
+    "ladder_conv1x1_smallcout_bwd_workspace_bytes": (_z, [C.c_long, _i, _i]),
+    "ladder_conv1x1_smallcout_bwd": (_i, [_p, _p, _p, _p, _p, _p, C.c_long, _i, _i, _i, _p, _z, _p]),
     "ladder_gather_rows": (_i, [_p, _i, _p, _p, _i, C.c_int64, _f, _p]),
     "ladder_vbgmm_state_doubles": (_z, [_i, _i]),
     "ladder_vbgmm_workspace_bytes": (_z, [_i, _i]),

@@ -269,6 +269,16 @@ class Conv2D:
         st = self.ctx.stream
         if self.act is not None and not act_done:
             L.call("ladder_act_bwd", _p(dy), _p(y), _p(dy), dy.numel(), L.ACT[self.act], st)
+        if (wgrad and self.k == 1 and self.stride == 1 and L.query("ladder_conv1x1_smallcout_eligible", N * H * W, self.cin, self.cout)):
+            # 1x1 to <= 4 channels over a wide map (the CelebA output conv): dx, dW and db from ONE pass over x
+            M = N * H * W
+            wsp, wsn = self.ctx.ws(L.query("ladder_conv1x1_smallcout_bwd_workspace_bytes", M, self.cin, self.cout))
+            dx = self.ctx.empty(N, H, W, self.cin) if need_dx else None
+            L.call("ladder_conv1x1_smallcout_bwd", _p(x), _p(dy), _p(self.ps.w[self.name + "/kernel"]), _p(dx),
+                   _p(self.ps.g[self.name + "/kernel"]), _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, M, self.cin,
+                   self.cout, L.ACT[gate_prev] if gate_prev else 0, wsp, wsn, st)
+            self.x = self.y = None
+            return dx
         if wgrad:
             nb = L.query("ladder_conv2d_bwd_filter_workspace_bytes", N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k)
             wsp, wsn = self.ctx.ws(nb)

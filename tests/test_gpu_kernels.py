@@ -374,6 +374,37 @@ def test_pad_symmetric_bwd(gpu_ctx):
         close(dx, x.grad, 1e-6, "pad_sym_bwd")
 
 
+@pytest.mark.parametrize("N,H,Cin,Cout,gate", [(8, 128, 128, 3, "leaky_relu"), (5, 128, 64, 1, None), (70, 32, 16, 4, "relu")])
+def test_conv1x1_smallcout_fused_backward(gpu_ctx, N, H, Cin, Cout, gate):
+    """The CelebA output conv (1x1, 128 -> 3) at full resolution: dedicated forward kernel (via ladder_conv2d_fwd) and the fused
+    backward -- dx with the producer's activation-derivative gate, dW and db from one pass over x -- vs float64 autograd."""
+    L = _lib()
+    rng = np.random.default_rng(N + Cin)
+    M = N * H * H
+    assert L.query("ladder_conv1x1_smallcout_eligible", M, Cin, Cout) == 1
+    pre = rng.standard_normal((N, H, H, Cin)).astype(np.float32)
+    w = (rng.standard_normal((1, 1, Cin, Cout)) / np.sqrt(Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    dy = rng.standard_normal((N, H, H, Cout)).astype(np.float32)
+    pt = torch.tensor(pre, dtype=torch.float64, requires_grad=True)
+    wt, bt = torch.tensor(w, dtype=torch.float64, requires_grad=True), torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    xt = O.act(pt, gate)                                   # x = the producing layer's OUTPUT
+    yt = O.conv2d_tf(xt, wt, bt, 1, "same")
+    yt.backward(torch.tensor(dy, dtype=torch.float64))
+    st = gpu_ctx.stream
+    xd, wd, bd, dyd = dev(xt.detach().numpy().astype(np.float32)), dev(w), dev(b), dev(dy)
+    y = torch.empty(N, H, H, Cout, device="cuda")
+    L.call("ladder_conv2d_fwd", p(xd), p(wd), p(bd), p(y), N, H, H, Cin, H, H, Cout, 1, 1, 1, 0, 0, 0, None, 0, st)
+    close(y, yt, 2e-5, "fwd")
+    dx, dw, db = torch.empty_like(xd), torch.empty_like(wd), torch.empty_like(bd)
+    ws = torch.empty(L.query("ladder_conv1x1_smallcout_bwd_workspace_bytes", M, Cin, Cout), dtype=torch.uint8, device="cuda")
+    L.call("ladder_conv1x1_smallcout_bwd", p(xd), p(dyd), p(wd), p(dx), p(dw), p(db), M, Cin, Cout, L.ACT[gate], p(ws), ws.numel(), st)
+    close(dx, pt.grad, 3e-5, "dx (gated)")
+    close(dw, wt.grad, 3e-5, "dw")
+    close(db, bt.grad, 3e-5, "db")
+    assert L.query("ladder_conv1x1_smallcout_eligible", 1000, Cin, Cout) == 0 and L.query("ladder_conv1x1_smallcout_eligible", M, Cin, 5) == 0
+
+
 def test_adam_clip_matches_tf_form(gpu_ctx):
     L = _lib()
     rng = np.random.default_rng(0)
