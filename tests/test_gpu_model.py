@@ -635,3 +635,76 @@ def test_trainer_vamp_prior_epochs(tmp_path):
     assert list(ck) == ["prior/Variable"] and np.array_equal(ck["prior/Variable"], p1)
     res = np.load(os.path.join(str(tmp_path), "mnist_digit-result.npz"))
     assert len(res["vampPrior_crossEntropy_z_train_prior"]) == 2 * n_it
+
+
+DP_PRIOR_WORKER = r'''
+import json, os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+rank, prior = int(sys.argv[1]), sys.argv[3]
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=2)
+from ladder_latent_data_distribution_modelling_amd.engine import LadderEngine
+from oracle import ladder_oracle as O
+d = np.load(os.path.join(%(root)r, "tests", "golden", "oracle_celeba.npz"))
+cfg = json.loads(str(d["config"]))
+cfg.update(prior=prior, code_size=16, n_mixtures=5, n_MC_samples=6)
+rng = np.random.default_rng(3)
+x = rng.random((4, 128, 128, 3)).astype(np.float32)
+noise = O.make_noise(cfg, 4, rng, np.float32)
+P = O.init_params(cfg, seed=14)
+P["encoder/code_std_dev/bias"] = (P["encoder/code_std_dev/bias"] + 0.7).astype(np.float32)
+gm = {k: v.astype(np.float32) for k, v in O.synthetic_gm(dict(n_mixtures=5, representation_size=16), rng).items()}
+world = int(sys.argv[4])
+sl = slice(2 * rank, 2 * rank + 2) if world == 2 else slice(0, 4)
+shard = dict(eps_z=noise["eps_z"][sl], eps_t=noise["eps_t"][sl], eps_mc=noise["eps_mc"][:, sl])
+eng = LadderEngine(cfg, "cuda:0", values=P)
+if prior == "GMM":
+    eng.set_mixture(gm["weights"], gm["means"], gm["covs"])
+out = {}
+eng.run_ae(x[sl], 0.0, shard, False, False)
+out["f_ae"] = json.dumps(eng.fetch())
+out.update({"ae/" + k: v.cpu().numpy() for k, v in eng.ps.g.items() if k.startswith(("encoder/", "decoder/"))})
+if prior == "vampPrior":
+    eng.run_prior(x[sl], 0.0, shard, False, False)
+    out["prior/Variable"] = eng.ps.g["prior/Variable"].cpu().numpy()
+if rank == 0:
+    np.savez(sys.argv[2], **out)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("prior", ["vampPrior", "GMM"])
+def test_data_parallel_other_priors(tmp_path, prior):
+    """Data-parallel parity of the two mixture-on-z priors (2 ranks on cuda:0 over gloo vs 1 rank on the whole batch): the
+    all-reduced gradients -- incl. the VampPrior pseudo-input pass, which is replicated (local batch-norm statistics, no exchange)
+    but differentiates each rank's own MC samples -- and the globally reduced fetches must agree."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "dp_prior_worker.py"
+    res = {}
+    for world in (2, 1):
+        outp = str(tmp_path / ("dp_%d.npz" % world))
+        script.write_text(DP_PRIOR_WORKER % dict(root=root, port=31500 + os.getpid() % 2000 + world))
+        if world == 2:
+            procs = [subprocess.Popen([sys.executable, str(script), str(r), outp, prior, "2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                      text=True) for r in range(2)]
+        else:
+            script.write_text((DP_PRIOR_WORKER % dict(root=root, port=31500 + os.getpid() % 2000 + world)).replace("world_size=2", "world_size=1"))
+            procs = [subprocess.Popen([sys.executable, str(script), "0", outp, prior, "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)]
+        outs = [p.communicate(timeout=900)[0] for p in procs]
+        assert all(p.returncode == 0 for p in procs), outs
+        res[world] = np.load(outp)
+    f2, f1 = json.loads(str(res[2]["f_ae"])), json.loads(str(res[1]["f_ae"]))
+    for k in ("elbo", "crossEntropy_prior", "l1_reconstruction_error", "entropy_z", "sigma"):
+        assert _ok(f2[k], f1[k], 1e-5), (k, f2[k], f1[k])
+    for k in res[1].files:
+        if k == "f_ae":
+            continue
+        a, b = res[2][k].astype(np.float64), res[1][k].astype(np.float64)
+        scale = np.abs(b).max()
+        if scale < 1e-9:
+            assert np.abs(a).max() < 1e-6, k
+            continue
+        assert np.abs(a - b).max() < 2e-3 * scale, (k, np.abs(a - b).max(), scale)
