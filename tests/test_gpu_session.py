@@ -113,3 +113,40 @@ def test_session_train_ops_equal_engine_runs(golden_dir):
     pa, pb = a.engine.ps.to_dict(), b.engine.ps.to_dict()
     assert all(np.array_equal(pa[k], pb[k]) for k in pa)
     assert a.engine.ps.step == {"ae": 1, "sigma": 1, "prior": 1, "inner_sigma": 1}
+
+
+def test_slp_interpolation_vs_autograd(golden_dir):
+    """The notebook's shortest-likely-path optimisation (cells 18-21): 40 clip+Adam iterations of the three-term objective with the
+    mixture term from the HIP kernel, against the same loop in float64 torch autograd on the oracle's mixture log-prob; the optimised
+    path decodes to images through inner decoder -> decoder."""
+    from ladder_latent_data_distribution_modelling_amd.codes.interpolation import SLPInterpolator
+    from ladder_latent_data_distribution_modelling_amd.engine import LadderEngine
+    d = np.load(os.path.join(golden_dir, "oracle_mnist_digit.npz"))
+    cfg = json.loads(str(d["config"]))
+    eng = LadderEngine(cfg, "cuda:0", seed=2)
+    fix = np.load(os.path.join(golden_dir, "GM_prior_info.npz"))
+    w, m, K = fix["w_active"], fix["m_active"], fix["K_active"]
+    slp = SLPInterpolator(eng, w, m, K)
+    start, end = np.array([-2.0, 1.5]), np.array([2.5, -1.0])
+    pts, rec = slp.optimise(start, end, n_step=5, n_iter=40, lr=1e-2)
+    # float64 autograd reference of the same loop
+    wt, mt, Kt = (torch.tensor(a, dtype=torch.float64) for a in (w, m, K))
+    p = torch.tensor(np.linspace(start, end, 6, endpoint=False)[1:], dtype=torch.float64, requires_grad=True)
+    mom, var = torch.zeros_like(p), torch.zeros_like(p)
+    s, e = torch.tensor(start), torch.tensor(end)
+    for t in range(1, 41):
+        a, b = torch.cat([s[None], p]), torch.cat([p, e[None]])
+        ln = torch.sqrt(((b - a) ** 2).sum(1))
+        obj = 10.0 * ln.sum() + 100.0 * ln.std(unbiased=False) - O.gmm_log_prob(p, wt, mt, Kt).sum()
+        (g,) = torch.autograd.grad(obj, p)
+        # the element-wise clip makes the trajectory piecewise: fp32-vs-fp64 differences of the mixture gradient stay at 1e-6 for the
+        # first iterations and grow slowly afterwards as elements cross the +-1 clip boundary at slightly different iterations
+        assert abs(rec["loss"][t - 1] - obj.item()) < (1e-5 if t <= 10 else 2e-3) * abs(obj.item()) + 1e-4, t
+        g = g.clamp(-1, 1)
+        mom = 0.9 * mom + 0.1 * g
+        var = 0.95 * var + 0.05 * g * g
+        p = (p - 1e-2 * np.sqrt(1 - 0.95 ** t) / (1 - 0.9 ** t) * mom / (var.sqrt() + 1e-8)).detach().requires_grad_(True)
+    assert np.abs(pts - p.detach().numpy()).max() < 2e-2
+    assert rec["loss"][-1] < rec["loss"][0]
+    imgs = slp.decode_path(start, pts, end)
+    assert imgs.shape == (7, 28, 28, 1) and imgs.min() >= 0.0 and imgs.max() <= 1.0
