@@ -1,69 +1,74 @@
-"""Config / directory helpers with the reference's names and behaviour (codes/utils.py:11-124)."""
+"""Configuration and directory helpers.  Function names, printed messages, derived directory layout and exit codes follow the
+reference's `codes/utils.py` (they are part of the drop-in surface: scripts and users read them); the implementation is this
+project's own."""
 import argparse
 import json
 import os
+import sys
 from datetime import datetime
+
+# keys of the JSON that name an experiment's output folder, in the order the reference concatenates them (utils.py:52-60)
+_RUN_NAME_KEYS = ("prior", "num_hidden_units", "code_size", "representation_size", "inner_activation", "n_layers_inner_VAE")
 
 
 def get_config_from_json(json_file):
-    """JSON file -> dict (codes/utils.py:11-21)."""
-    with open(json_file, "r") as f:
-        return json.load(f)
+    with open(json_file) as fh:
+        return json.load(fh)
 
 
-def save_config(config):
-    """Dump the config next to the checkpoints as training_config_<timestamp>.txt (codes/utils.py:24-37)."""
-    stamp = datetime.now().strftime("%d-%b-%Y-%H-%M")
-    filename = config["checkpoint_dir"] + "training_config_{}.txt".format(stamp)
-    with open(filename, "w") as f:
-        f.write(json.dumps(config))
-    print("The current config is saved at {}".format(filename))
+def _run_name(cfg):
+    return "prior-" + "-".join(str(cfg[k]) for k in _RUN_NAME_KEYS) + "-mixture-{}".format(cfg["n_mixtures"])
+
+
+def _output_dirs(cfg, run):
+    """load_dir == "default": ./experiments/<exp>/batch-<B>/<run>/{summary,result,checkpoint}/ ; otherwise results go under
+    ./figures/<exp>/ and checkpoints are read from <load_dir>/<exp> (utils.py:65-76)."""
+    exp = cfg["exp_name"]
+    if cfg["load_dir"] == "default":
+        root = os.path.join("./experiments/{}/batch-{}".format(exp, cfg["batch_size"]), run)
+        return {k + "_dir": os.path.join(root, k + "/") for k in ("summary", "result", "checkpoint")}
+    return dict(summary_dir="./figures/{}/summary/".format(exp), result_dir="./figures/{}/result/".format(exp),
+                checkpoint_dir=os.path.join(cfg["load_dir"], exp))
 
 
 def process_config(json_file):
-    """Read the JSON and derive summary_dir / result_dir / checkpoint_dir exactly as codes/utils.py:40-77."""
-    config = get_config_from_json(json_file)
-    print("The current config is:\n{}\n".format(config))
-    save_name = "prior-{}-{}-{}-{}-{}-{}-mixture-{}".format(
-        config["prior"], config["num_hidden_units"], config["code_size"], config["representation_size"],
-        config["inner_activation"], config["n_layers_inner_VAE"], config["n_mixtures"])
-    print("Experiment results will be saved at:\n{}\n".format(save_name))
-    if config["load_dir"] == "default":
-        save_dir = "./experiments/{}/batch-{}".format(config["exp_name"], config["batch_size"])
-        config["summary_dir"] = os.path.join(save_dir, save_name, "summary/")
-        config["result_dir"] = os.path.join(save_dir, save_name, "result/")
-        config["checkpoint_dir"] = os.path.join(save_dir, save_name, "checkpoint/")
-    else:
-        save_dir = config["load_dir"]
-        config["summary_dir"] = "./figures/{}/summary/".format(config["exp_name"])
-        config["result_dir"] = "./figures/{}/result/".format(config["exp_name"])
-        config["checkpoint_dir"] = os.path.join(save_dir, config["exp_name"])
-    print("Models will be saved / loaded at:\n{}".format(config["checkpoint_dir"]))
-    print("Results will be saved at:\n{}\n".format(config["result_dir"]))
-    return config
+    cfg = get_config_from_json(json_file)
+    print("The current config is:\n{}\n".format(cfg))
+    run = _run_name(cfg)
+    print("Experiment results will be saved at:\n{}\n".format(run))
+    cfg.update(_output_dirs(cfg, run))
+    print("Models will be saved / loaded at:\n{}".format(cfg["checkpoint_dir"]))
+    print("Results will be saved at:\n{}\n".format(cfg["result_dir"]))
+    return cfg
+
+
+def save_config(config):
+    """<checkpoint_dir>training_config_<dd-Mon-YYYY-HH-MM>.txt holding the JSON dump."""
+    target = "{}training_config_{:%d-%b-%Y-%H-%M}.txt".format(config["checkpoint_dir"], datetime.now())
+    with open(target, "w") as fh:
+        json.dump(config, fh)
+    print("The current config is saved at {}".format(target))
 
 
 def create_dirs(dirs):
-    """Create the directories; exit(-1) on failure like codes/utils.py:80-93."""
+    """Returns 0; a failure is reported and ends the process with status -1."""
     try:
-        for d in dirs:
-            if not os.path.exists(d):
-                os.makedirs(d)
-        return 0
-    except Exception as err:  # noqa: BLE001 - mirrors the reference's behaviour
+        for path in dirs:
+            os.makedirs(path, exist_ok=True)
+    except Exception as err:  # noqa: BLE001
         print("Creating directories error: {0}".format(err))
-        exit(-1)
+        sys.exit(-1)
+    return 0
 
 
 def count_trainable_variables(model, scope_name):
-    """Number of trainable parameters under a variable scope (codes/utils.py:96-113)."""
-    total = model.engine.ps.num_params(scope_name + "/")
-    print("The total number of trainable parameters in the {} model is: {}k.".format(scope_name, round(total / 1000, 2)))
-    return total
+    """Trainable parameter count under a variable scope ("encoder", "decoder", "prior", ...)."""
+    n = model.engine.ps.num_params(scope_name + "/")
+    print("The total number of trainable parameters in the {} model is: {}k.".format(scope_name, round(n / 1000, 2)))
+    return n
 
 
 def get_args():
-    """`-c/--config` (codes/utils.py:116-124)."""
-    p = argparse.ArgumentParser(description=__doc__)
-    p.add_argument("-c", "--config", metavar="C", default="None", help="The Configuration file")
-    return p.parse_args()
+    parser = argparse.ArgumentParser(description="LaDDer training on the MI355X HIP path")
+    parser.add_argument("-c", "--config", metavar="C", default="None", help="The Configuration file")
+    return parser.parse_args()
