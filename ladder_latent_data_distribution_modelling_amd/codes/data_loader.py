@@ -111,6 +111,9 @@ class BatchIterator:
 
     def __init__(self, images, batch_size, seed=0, shuffle=True):
         self.images, self.bs = images, int(batch_size)
+        if self.images.shape[0] < self.bs:
+            raise ValueError("data set of %d samples is smaller than one minibatch of %d (drop_remainder leaves no batch)"
+                             % (self.images.shape[0], self.bs))
         self.rng = np.random.default_rng(seed)
         self.shuffle = shuffle
         self._order, self._pos = None, 0
@@ -149,6 +152,9 @@ class DeviceBatchIterator:
         self.shape = tuple(self.data.shape[1:])
         self.D = int(np.prod(self.shape))
         self.bs = int(batch_size)
+        if self.data.shape[0] < self.bs:
+            raise ValueError("data set of %d samples is smaller than one minibatch of %d (drop_remainder leaves no batch)"
+                             % (self.data.shape[0], self.bs))
         self.rng = np.random.default_rng(seed)
         self.shuffle = shuffle
         self._order, self._pos = None, 0

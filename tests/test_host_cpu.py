@@ -98,6 +98,8 @@ def test_data_loader_mnist_synthetic_and_tfrecords(tmp_path):
         dl.DataGenerator(dict(exp_name="mnist_digit", batch_size=100, data_path=str(tmp_path)), None)
     it = dl.BatchIterator(d.train_set["image"], 64, seed=1)
     assert it.next().shape == (64, 28, 28, 1) and it.next().dtype == np.float32
+    with pytest.raises(ValueError, match="smaller than one minibatch"):
+        dl.BatchIterator(d.train_set["image"][:10], 64)
     # CelebA TFRecord round trip (tf.Example, bytes feature 'X' = raw uint8 HWC, models.py:354-371)
     imgs = np.random.default_rng(0).integers(0, 256, (5, 8, 8, 3), dtype=np.uint8)
     dl.write_tfrecord(str(tmp_path / "celebA_train.tfrecords"), imgs)
