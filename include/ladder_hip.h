@@ -69,6 +69,10 @@ int ladder_conv2d_bwd_data(const float* dy, const float* wT, float* dx,
                            int KH, int KW, int stride, int pad_t, int pad_l,
                            const float* gate_y, int gate_act,
                            void* ws, size_t ws_bytes, ladder_stream_t stream);
+/* Kernel a filter-gradient call dispatches to: 9128 = wgrad3x3_halo_kernel (3x3, stride 1, SAME, Cin % 64 == 0, W % 32 == 0,
+ * >= 4096 row patches), 0 = any other path (bench.py's per-kernel profile). */
+int ladder_conv2d_bwd_filter_kernel_id(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t,
+                                       int pad_l);
 size_t ladder_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW);
 /* dw[r,s,ci,co] = sum_{n,ho,wo} x[...] * dy[n,ho,wo,co];  db[co] = sum dy, accumulated inside the same kernel
  * (db may be NULL: e.g. a conv feeding batch-/instance-norm, whose bias gradient is identically zero). */

@@ -40,6 +40,7 @@ PROTOTYPES = {
     "ladder_abi_version": (_i, []),
     "ladder_igemm_fwd_tile": (_i, [C.c_long, _i, _i]),
     "ladder_conv2d_fwd_kernel_id": (_i, [_i] * 13),
+    "ladder_conv2d_bwd_filter_kernel_id": (_i, [_i] * 12),
     "ladder_conv2d_fwd": (_i, [_p, _p, _p, _p] + [_i] * 13 + [_p, _z, _p]),
     "ladder_igemm_fwd_workspace_bytes": (_z, [C.c_long, _i, _i]),
     "ladder_filter_flip_transpose": (_i, [_p, _p, _i, _i, _i, _i, _p]),

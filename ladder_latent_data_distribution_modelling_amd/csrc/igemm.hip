@@ -1464,6 +1464,13 @@ size_t ladder_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, int Cin, in
   return need;
 }
 
+int ladder_conv2d_bwd_filter_kernel_id(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t,
+                                       int pad_l) {
+  // 9128 = wgrad3x3_halo_kernel (tap-fused, LDS-DMA staged); 0 = any other filter-gradient path
+  IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, 1, pad_t, pad_l, N * Ho * Wo, KH * KW * Cin, 0, make_fastdiv(1), make_fastdiv(1)};
+  return plan_wgrad_halo(d).ok ? 9128 : 0;
+}
+
 int ladder_conv2d_bwd_filter(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Ho,
                              int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, void* ws, size_t ws_bytes,
                              ladder_stream_t stream) {
