@@ -9,6 +9,9 @@ Outputs (all data, no reference source text):
   ckpt_inventory.json    {model: {ckpt: {variable_name: shape}}} parsed from the reference's
                          pretrained_models/*/*.index (TF bundle index = leveldb-format table of
                          BundleEntryProto), no TensorFlow needed
+  ref_ckpt_index/*.index copies of the reference's six TensorFlow-written checkpoint index DATA files (1-3 KB each; variable names,
+                         shapes, offsets and CRCs, no tensor data): tests/test_host_cpu.py re-serialises the parsed entries with
+                         codes/tf_bundle.py and requires the identical bytes
   oracle_*.npz           inputs + float64 oracle outputs on tiny shapes (see make_oracle_vectors)
 """
 import json
@@ -178,8 +181,17 @@ def make_oracle_vectors():
         print(exp, "elbo it0:", save["it0_run1_elbo"], "it1:", save["it1_run1_elbo"])
 
 
+def copy_index_fixtures():
+    os.makedirs(os.path.join(HERE, "ref_ckpt_index"), exist_ok=True)
+    for model in ("celeba", "mnist_digit", "mnist_fashion"):
+        for ck in ("vae-model", "prior-model"):
+            shutil.copyfile(os.path.join(REF, "pretrained_models", model, ck + ".index"),
+                            os.path.join(HERE, "ref_ckpt_index", "%s_%s.index" % (model, ck)))
+
+
 if __name__ == "__main__":
     shutil.copyfile(os.path.join(REF, "figures/mnist_digit/result/GM_prior_info.npz"),
                     os.path.join(HERE, "GM_prior_info.npz"))
+    copy_index_fixtures()
     make_ckpt_inventory()
     make_oracle_vectors()
