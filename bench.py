@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default=os.path.join(ROOT, "codes", "celeba_config.json"))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (default: config batch_size)")
+    ap.add_argument("--precision", default="", help="matmul_precision override: f32 | bf16x6 | bf16x3 (default: the engine's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--graphs", type=int, default=-1,
@@ -97,6 +98,9 @@ def main():
     cfg = json.load(open(args.config))
     if args.batch:
         cfg["batch_size"] = args.batch
+    if args.precision:
+        cfg["matmul_precision"] = args.precision
+    precision = str(cfg.get("matmul_precision", E.DEFAULT_PRECISION))
     cfg.setdefault("checkpoint_dir", "/tmp/ladder_bench/")
     cfg.setdefault("result_dir", "/tmp/ladder_bench/")
     B = int(cfg["batch_size"])
@@ -172,7 +176,7 @@ def main():
                                    cfg["exp_name"], cfg["dim_input_x"], cfg["dim_input_y"], cfg["dim_input_channel"],
                                    cfg["num_hidden_units"], cfg["code_size"], R, K, cfg["n_MC_samples"], B),
                    "global_batch": B * world, "parallelism": "dp%d" % world},
-        "launch": "hipGraph replay (4 graphs/iteration)" if graphs else "eager",
+        "launch": "hipGraph replay (4 graphs/iteration)" if graphs else "eager", "matmul_precision": precision,
         "elbo": f["elbo"], "elbo_prior": trainer.last_fetch_prior["elbo_prior"],
     }
     if prof:

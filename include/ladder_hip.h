@@ -90,6 +90,32 @@ size_t ladder_conv1x1_smallcout_bwd_workspace_bytes(long M, int Cin, int Cout);
 int ladder_conv1x1_smallcout_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long M, int Cin,
                                  int Cout, int gate_act, void* ws, size_t ws_bytes, ladder_stream_t stream);
 
+/* ---------------------------------------------------------------- N1s: the same convolutions on the 16-bit matrix cores
+ * (operand splitting; csrc/convsplit.hip).  gfx950 has no TF32-class MFMA and its f32-input MFMA runs at the f32 vector rate;
+ * v_mfma_f32_32x32x16_{f16,bf16} are 16x faster.  Each fp32 operand is split into 16-bit planes whose cross products are
+ * accumulated in fp32 (`prec`):
+ *   LADDER_PREC_F16X3   2 fp16 planes = 22 bits, 3 products, dropped term <= 2^-22 relative (fp32 class); operands are scaled per
+ *                       tensor by a power of two derived from their absolute maximum (x_absmax, a device scalar from ladder_absmax;
+ *                       the filter's is taken by the pack call).
+ *   LADDER_PREC_BF16X6  3 bf16 planes = 24 bits, 6 products, dropped terms <= 2^-23 relative (fp32 class); no scaling.
+ *   LADDER_PREC_BF16X3  2 bf16 planes = 16 bits, 3 products, <= 3 * 2^-17 relative.
+ * Replaces the same call sites as ladder_conv2d_fwd / ladder_conv2d_bwd_data for 3x3 / stride 1 / SAME layers with W % 32 == 0,
+ * H % 8 == 0, Cin % 16 == 0, Cout % 4 == 0, Cout >= 64 and >= 512 workgroups (codes/models.py:538-578: the decoder's
+ * 32x32 ... 128x128 maps). */
+enum { LADDER_PREC_F32 = 0, LADDER_PREC_BF16X3 = 2, LADDER_PREC_BF16X6 = 3, LADDER_PREC_F16X3 = 4 };
+/* out[0] = max |x[i]| (device scalar; exact and order-independent). */
+int ladder_absmax(const float* x, size_t n, float* out, ladder_stream_t stream);
+/* ladder_conv3x3_pack: once per weight update, HWIO fp32 bank -> split planes in the kernel's LDS layout.
+ *   transpose_flip = 0: `w` = [3][3][Cin][Cout] (forward).  transpose_flip = 1: `w` = the layer's bank [3][3][Cout][Cin] read as the
+ *   flipped, transposed filter of its backward-data pass (Cin = dy channels, Cout = dx channels). */
+size_t ladder_conv3x3_pack_bytes(int Cin, int Cout, int prec);
+int ladder_conv3x3_pack(const float* w, void* packed, int Cin, int Cout, int transpose_flip, int prec, ladder_stream_t stream);
+int ladder_conv3x3_split_eligible(int N, int H, int W, int Cin, int Cout);
+/* y = act(conv3x3_same(x, F) + bias) with F as packed above (bias may be NULL; x_absmax is read only for LADDER_PREC_F16X3 and may
+ * be any upper bound of max |x|: a looser bound only raises the absolute representation floor 2^-39 * bound). */
+int ladder_conv3x3_split(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, int N, int H, int W,
+                         int Cin, int Cout, int act, int prec, ladder_stream_t stream);
+
 /* ---------------------------------------------------------------- N2: tf.layers.dense
  * codes/models.py:73-95,109,231-253,267,478-488,501-510; codes/modules.py:8; codes/base.py:145-186.
  * y[M,N] = act(x[M,K] @ w[K,N] + b).  MFMA-f32 (v_mfma_f32_32x32x2_f32). */

@@ -1,0 +1,386 @@
+// fp32 convolutions on the 16-bit matrix cores by operand splitting (gfx950, MI355X).
+//
+// gfx950 has no TF32/xf32 MFMA; its f32-input MFMA runs at the f32 vector rate (157 TFLOP/s) while the 16-bit-input
+// v_mfma_f32_32x32x16_{bf16,f16} run 16x faster (2.5 PFLOP/s nominal; ~1.5-1.8 PFLOP/s sustained on random operands, where the chip
+// is power-limited -- see DESIGN.md).  Every fp32 operand is split into NS 16-bit "planes"
+//     x = x0 + x1 (+ x2) + residual,   x0 = rn16(x), x1 = rn16(x - x0), x2 = rn16(x - x0 - x1)
+// (each subtraction is exact in fp32) and the product a*b is evaluated as the sum of the plane products whose weight is above
+// the fp32 rounding level, all accumulated in ONE fp32 MFMA accumulator (16-bit x 16-bit products are exact in fp32):
+//
+//   LADDER_PREC_F16X3   2 fp16 planes (11 + 11 = 22 significand bits), a0b0 + a0b1 + a1b0; dropped a1b1 <= 2^-22 |ab|
+//                       -> fp32-class result from 3 MFMAs.  fp16 has a 5-bit exponent, so each operand TENSOR is scaled by a
+//                       power of two taken from its absolute maximum (|x| c < 2^14; ladder_absmax / the pack kernel): an element
+//                       is then represented to max(2^-23 |x|, 2^-39 max|x|), i.e. exactly like fp32 down to 2^-16 of the
+//                       tensor's largest magnitude and with an absolute floor of 2e-12 of it below; the result is un-scaled
+//                       in the epilogue.
+//   LADDER_PREC_BF16X6  3 bf16 planes (24 bits), a0b0 + a0b1 + a1b0 + a0b2 + a2b0 + a1b1; dropped terms <= 2^-23 |ab|
+//                       -> fp32-class result from 6 MFMAs, no scaling (bf16 has the fp32 exponent).
+//   LADDER_PREC_BF16X3  2 bf16 planes (16 bits), 3 MFMAs; dropped terms <= 3 * 2^-17 |ab|  (between TF32 and fp32).
+//
+// Kernels here:
+//   absmax_kernel               max |x| of a tensor into a device scalar (order-independent atomic max on the bit pattern).
+//   filter_pack_kernel          once per weight update: HWIO fp32 filter bank (optionally flipped + transposed for backward-data)
+//                               -> split planes laid out exactly as the conv kernel's LDS image (one contiguous 16-byte
+//                               chunk per thread, no transposition in the hot loop).
+//   conv3x3_halo_split_kernel   3x3 / stride 1 / SAME forward and backward-data of the large decoder maps: the 8x32-pixel x
+//                               128-channel LDS-halo tiling of conv3x3_halo_kernel (igemm.hip) with the input halo split into
+//                               planes while it is staged into LDS.
+#include <cstdlib>
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+__device__ __attribute__((aligned(16))) float gs_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+// Precision format of a split contraction: number of planes and the 16-bit element type.
+template <int PREC> struct Fmt;
+template <> struct Fmt<LADDER_PREC_BF16X6> { static constexpr int NS = 3; static constexpr bool F16 = false; };
+template <> struct Fmt<LADDER_PREC_BF16X3> { static constexpr int NS = 2; static constexpr bool F16 = false; };
+template <> struct Fmt<LADDER_PREC_F16X3>  { static constexpr int NS = 2; static constexpr bool F16 = true; };
+inline bool prec_ok(int prec) { return prec == LADDER_PREC_BF16X6 || prec == LADDER_PREC_BF16X3 || prec == LADDER_PREC_F16X3; }
+inline int prec_planes(int prec) { return prec == LADDER_PREC_BF16X6 ? 3 : 2; }
+
+// packed pair of 16-bit floats, round-to-nearest-even (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32): low half = a, high half = b;
+// `back` = the pair converted back to fp32 (exact)
+template <bool F16>
+__device__ __forceinline__ uint32_t pk16(float a, float b, float& back_a, float& back_b) {
+  const f32x2 v = {a, b};
+  if (F16) {
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f32x2 f = __builtin_convertvector(h, f32x2);
+    back_a = f.x;
+    back_b = f.y;
+    return __builtin_bit_cast(uint32_t, h);
+  } else {
+    const uint32_t p = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    back_a = __builtin_bit_cast(float, p << 16);
+    back_b = __builtin_bit_cast(float, p & 0xffff0000u);
+    return p;
+  }
+}
+
+// Splits 4 floats into NS planes of 4 packed 16-bit values each (plane p -> out[p] = {elements 0,1 | elements 2,3}).
+template <int NS, bool F16>
+__device__ __forceinline__ void split4(const float4 v, uint2 (&out)[NS]) {
+  float a = v.x, b = v.y, c = v.z, d = v.w;
+#pragma unroll
+  for (int p = 0; p < NS; ++p) {
+    float fa, fb, fc, fd;
+    const uint32_t q0 = pk16<F16>(a, b, fa, fb), q1 = pk16<F16>(c, d, fc, fd);
+    out[p] = make_uint2(q0, q1);
+    if (p + 1 < NS) {
+      a -= fa;
+      b -= fb;
+      c -= fc;
+      d -= fd;
+    }
+  }
+}
+
+// Power-of-two scale c with |x| c < 2^14 for every |x| <= amax (fp16 tops out at 65504; the planes of the largest elements then keep
+// 2 binades of headroom); 1 for an all-zero or non-finite tensor.
+__device__ __forceinline__ float scale_from_absmax(float amax) {
+  const uint32_t bits = __builtin_bit_cast(uint32_t, amax);
+  const int e = (int)((bits >> 23) & 0xff);               // biased exponent: amax < 2^(e - 126)
+  if (e == 0 || e == 255) return 1.f;
+  int se = 127 + 14 - (e - 126);                          // biased exponent of 2^(14 - (e - 126))
+  se = se < 1 ? 1 : (se > 254 ? 254 : se);
+  return __builtin_bit_cast(float, (uint32_t)se << 23);
+}
+
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(const uint4 a, const uint4 b, const f32x16 c) {
+  if (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// ---- absolute maximum ------------------------------------------------------------------------------------------------------
+// Non-negative floats order like their bit patterns, so an unsigned atomic max is exact and order-independent (deterministic).
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n4, size_t n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (blockIdx.x == 0)
+    for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(x[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));
+}
+
+// ---- filter packing ----------------------------------------------------------------------------------------------------
+// Logical filter F[tap][ci][co] (tap = r*3+s, ci < Cin, co < Cout):
+//   transpose_flip = 0:  F[tap][ci][co] = w[tap][ci][co]           (w is the HWIO bank [9][Cin][Cout])              forward
+//   transpose_flip = 1:  F[tap][ci][co] = w[8 - tap][co][ci]       (w is the HWIO bank [9][Cout][Cin] of the layer)  backward-data
+// Packed image (16-bit elements): P[tap][slab = ci/16][cot = co/128][plane][kg = (ci%16)/8][co % 128][ci % 8]; one (tap, slab, cot)
+// block is the contiguous NS * 4096 bytes a workgroup stages per K-step.  The last 16 bytes of the buffer hold the filter's
+// absolute maximum (f16x3 only; the kernels derive the power-of-two scale from it).
+constexpr int SP_BN = 128;
+
+template <int PREC>
+__global__ __launch_bounds__(256) void filter_pack_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cin, int Cout,
+                                                          int transpose_flip, int total, const float* __restrict__ wamax) {
+  constexpr int NS = Fmt<PREC>::NS;
+  constexpr bool F16 = Fmt<PREC>::F16;
+  const int i = blockIdx.x * 256 + threadIdx.x;     // one thread per (tap, slab, cot, kg, co)
+  if (i >= total) return;
+  const float c = F16 ? scale_from_absmax(*wamax) : 1.f;
+  const int cots = (Cout + SP_BN - 1) / SP_BN, nslabs = Cin / 16;
+  const int col = i % SP_BN;
+  int t = i / SP_BN;
+  const int kg = t & 1;
+  t >>= 1;
+  const int cot = t % cots;
+  t /= cots;
+  const int slab = t % nslabs, tap = t / nslabs;
+  const int co = cot * SP_BN + col, ci0 = slab * 16 + kg * 8;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float f = 0.f;
+    if (co < Cout) f = transpose_flip ? w[((size_t)(8 - tap) * Cout + co) * Cin + ci0 + j] : w[((size_t)tap * Cin + ci0 + j) * Cout + co];
+    v[j] = f * c;
+  }
+  uint2 lo[NS], hi[NS];
+  split4<NS, F16>(make_float4(v[0], v[1], v[2], v[3]), lo);
+  split4<NS, F16>(make_float4(v[4], v[5], v[6], v[7]), hi);
+  const size_t blk = ((size_t)(tap * nslabs + slab) * cots + cot) * (NS * 256);   // uint4 units
+#pragma unroll
+  for (int p = 0; p < NS; ++p) out[blk + (size_t)p * 256 + kg * 128 + col] = make_uint4(lo[p].x, lo[p].y, hi[p].x, hi[p].y);
+}
+
+// ---- 3x3 halo convolution on split operands -------------------------------------------------------------------------------
+// Workgroup = 8 wavefronts = an 8x32-pixel output patch x 128 output channels; wavefront (wm, wn) owns patch rows {2wm, 2wm+1} x
+// channels [64wn, 64wn+64) = 2x2 MFMA tiles of 32x32.  K-step = (16-channel input slab, filter tap) = ONE 32x32x16 MFMA K.
+// LDS image of the input halo, per plane: [kg = channel octet 0/1][halo pixel 10x34][8 x 16 bit] -> the A fragment of a patch row
+// at column shift s is 32 consecutive 16-byte slots (conflict-free ds_read_b128); the filter block per plane is
+// [kg][128 channels][8 x 16 bit], same property.  The halo of the next slab is fetched as fp32 at tap 0 and split + written at
+// tap 4; the packed filter block of the next K-step is double-buffered every tap.
+constexpr int SP_H = 8, SP_W = 32, SP_PW = SP_W + 2, SP_PH = SP_H + 2, SP_NPIX = SP_PH * SP_PW;   // 340 halo pixels
+constexpr int SP_THREADS = 512;
+constexpr int SP_A_PLANE = 2 * SP_NPIX * 16;            // bytes per plane (10880)
+constexpr int SP_B_PLANE = 2 * SP_BN * 16;              // bytes per plane (4096)
+constexpr int SP_HALO_UNITS = SP_NPIX * 4;              // float4 units per slab (1360)
+constexpr int SP_AU = (SP_HALO_UNITS + SP_THREADS - 1) / SP_THREADS;   // 3
+
+template <int PREC>
+__global__ __launch_bounds__(SP_THREADS, 2) void conv3x3_halo_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
+                                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                                          const int N, const int H, const int W, const int Cin,
+                                                                          const int Cout, const int act, const int tiles_n,
+                                                                          const float* __restrict__ xamax,
+                                                                          const float* __restrict__ wamax) {
+  constexpr int NS = Fmt<PREC>::NS;
+  constexpr bool F16 = Fmt<PREC>::F16;
+  constexpr int A_BUF = NS * SP_A_PLANE, B_BUF = NS * SP_B_PLANE;
+  constexpr int B_CHUNKS = NS * 256;                                       // 16-byte chunks per filter block
+  constexpr int BU = (B_CHUNKS + SP_THREADS - 1) / SP_THREADS;             // 2 (NS=3: 1.5) / 1 (NS=2)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * A_BUF + 2 * B_BUF];
+  unsigned char* const Abase = lds;
+  unsigned char* const Bbase = lds + 2 * A_BUF;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = tile / tiles_n, cot = tile % tiles_n, n0 = cot * SP_BN;
+  const int tw_n = W / SP_W, th_n = H / SP_H;
+  const int img = mt / (tw_n * th_n), rem = mt - img * (tw_n * th_n);
+  const int h0 = (rem / tw_n) * SP_H, w0 = (rem % tw_n) * SP_W;
+  const int nslabs = Cin / 16;
+  float cx = 1.f, unscale = 1.f;
+  if (F16) {
+    cx = scale_from_absmax(*xamax);
+    unscale = 1.f / (cx * scale_from_absmax(*wamax));      // exact: powers of two
+  }
+
+  const float* hsrc[SP_AU];
+  int hdst[SP_AU];
+#pragma unroll
+  for (int i = 0; i < SP_AU; ++i) {
+    const int u = tid + i * SP_THREADS;
+    const int pix = u >> 2, kq = u & 3;
+    const int hr = pix / SP_PW, hc = pix - hr * SP_PW;
+    const int hi = h0 - 1 + hr, wi = w0 - 1 + hc;
+    const bool ok = (u < SP_HALO_UNITS) && hi >= 0 && hi < H && wi >= 0 && wi < W;
+    hsrc[i] = ok ? x + (((long)img * H + hi) * W + wi) * Cin + kq * 4 : nullptr;
+    hdst[i] = ((kq >> 1) * SP_NPIX + pix) * 16 + (kq & 1) * 8;
+  }
+  const uint4* const bsrc = wp + (size_t)cot * B_CHUNKS + tid;             // + (tap*nslabs + slab) * tiles_n * B_CHUNKS
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  float4 ha[SP_AU];
+  uint4 rb0, rb1;                                                         // (named: an array here is demoted to LDS by hipcc)
+  const bool b_second = BU > 1 && tid + SP_THREADS < B_CHUNKS;
+  auto load_halo = [&](int slab) {
+#pragma unroll
+    for (int i = 0; i < SP_AU; ++i) ha[i] = *reinterpret_cast<const float4*>(hsrc[i] != nullptr ? hsrc[i] + slab * 16 : gs_zero16);
+  };
+  auto store_halo = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < SP_AU; ++i)
+      if (tid + i * SP_THREADS < SP_HALO_UNITS) {
+        uint2 pl[NS];
+        float4 v = ha[i];
+        if (F16) v = make_float4(v.x * cx, v.y * cx, v.z * cx, v.w * cx);
+        split4<NS, F16>(v, pl);
+#pragma unroll
+        for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(Abase + buf * A_BUF + p * SP_A_PLANE + hdst[i]) = pl[p];
+      }
+  };
+  auto load_b = [&](int slab, int tap) {
+    const uint4* s = bsrc + (size_t)(tap * nslabs + slab) * tiles_n * B_CHUNKS;
+    rb0 = s[0];
+    if (b_second) rb1 = s[SP_THREADS];
+  };
+  auto store_b = [&](int buf) {
+    *reinterpret_cast<uint4*>(Bbase + buf * B_BUF + tid * 16) = rb0;
+    if (b_second) *reinterpret_cast<uint4*>(Bbase + buf * B_BUF + (tid + SP_THREADS) * 16) = rb1;
+  };
+
+  load_halo(0);
+  load_b(0, 0);
+  store_halo(0);
+  store_b(0);
+  __syncthreads();
+  int bbuf = 0;
+  for (int slab = 0; slab < nslabs; ++slab) {
+    const int hb = slab & 1;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const bool last = (slab + 1 == nslabs) && (tap == 8);
+      if (!last) load_b(tap == 8 ? slab + 1 : slab, tap == 8 ? 0 : tap + 1);
+      if (tap == 0 && slab + 1 < nslabs) load_halo(slab + 1);
+      const int r = tap / 3, sft = tap - 3 * r;
+      const unsigned char* Ab = Abase + hb * A_BUF + (lh * SP_NPIX + (2 * wm + r) * SP_PW + sft + l31) * 16;
+      const unsigned char* Bb = Bbase + bbuf * B_BUF + (lh * SP_BN + wn * 64 + l31) * 16;
+      uint4 a[2][NS], b[2][NS];
+#pragma unroll
+      for (int p = 0; p < NS; ++p) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) a[mi][p] = *reinterpret_cast<const uint4*>(Ab + p * SP_A_PLANE + mi * SP_PW * 16);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) b[ni][p] = *reinterpret_cast<const uint4*>(Bb + p * SP_B_PLANE + ni * 32 * 16);
+      }
+      // plane products, smallest weights first: (pa, pb) with pa + pb < NS
+#pragma unroll
+      for (int sum = NS - 1; sum >= 0; --sum)
+#pragma unroll
+        for (int pa = 0; pa <= sum; ++pa) {
+          const int pb = sum - pa;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma16<F16>(a[mi][pa], b[ni][pb], acc[mi][ni]);
+        }
+      if (tap == 4 && slab + 1 < nslabs) store_halo(hb ^ 1);
+      if (!last) store_b(bbuf ^ 1);
+      __syncthreads();
+      bbuf ^= 1;
+    }
+  }
+
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int n = n0 + wn * 64 + ni * 32 + l31;
+    const float bv = (bias != nullptr && n < Cout) ? bias[n] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const long rowbase = (((long)img * H + h0 + 2 * wm + mi) * W + w0) * Cout;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int px = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        float v = acc[mi][ni][e];
+        if (F16) v *= unscale;
+        if (n < Cout) y[rowbase + (long)px * Cout + n] = ladder_act_fn(v + bv, act);
+      }
+    }
+  }
+}
+
+bool split_halo_ok(int N, int H, int W, int Cin, int Cout) {
+  return N > 0 && (Cin % 16) == 0 && (Cout % 4) == 0 && Cout >= 64 && (W % SP_W) == 0 && (H % SP_H) == 0 &&
+         (long)N * (H / SP_H) * (W / SP_W) * ((Cout + SP_BN - 1) / SP_BN) >= 512;
+}
+
+inline size_t pack_payload_bytes(int Cin, int Cout, int prec) {
+  return (size_t)9 * (Cin / 16) * ((Cout + SP_BN - 1) / SP_BN) * prec_planes(prec) * 4096;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ladder_absmax(const float* x, size_t n, float* out, ladder_stream_t stream) {
+  if (n == 0) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(x)) return LADDER_E_ALIGN;
+  if (hipMemsetAsync(out, 0, sizeof(float), stream) != hipSuccess) return LADDER_E_LAUNCH;
+  const size_t n4 = n / 4;
+  size_t blocks = (n4 + 256 * 8 - 1) / (256 * 8);
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n4, n, (unsigned*)out);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+size_t ladder_conv3x3_pack_bytes(int Cin, int Cout, int prec) {
+  if (Cin <= 0 || Cout <= 0 || (Cin % 16) != 0 || !prec_ok(prec)) return 0;
+  return pack_payload_bytes(Cin, Cout, prec) + 16;
+}
+
+int ladder_conv3x3_pack(const float* w, void* packed, int Cin, int Cout, int transpose_flip, int prec, ladder_stream_t stream) {
+  if (Cin <= 0 || Cout <= 0 || (Cin % 16) != 0 || !prec_ok(prec)) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(packed) || !ladder_aligned16(w)) return LADDER_E_ALIGN;
+  const int total = 9 * (Cin / 16) * ((Cout + SP_BN - 1) / SP_BN) * 2 * SP_BN;
+  const dim3 grid((total + 255) / 256), block(256);
+  float* wamax = reinterpret_cast<float*>(static_cast<unsigned char*>(packed) + pack_payload_bytes(Cin, Cout, prec));
+  if (prec == LADDER_PREC_F16X3) {
+    const int rc = ladder_absmax(w, (size_t)9 * Cin * Cout, wamax, stream);
+    if (rc != LADDER_OK) return rc;
+    hipLaunchKernelGGL(filter_pack_kernel<LADDER_PREC_F16X3>, grid, block, 0, stream, w, (uint4*)packed, Cin, Cout, transpose_flip, total, wamax);
+  } else if (prec == LADDER_PREC_BF16X6) {
+    hipLaunchKernelGGL(filter_pack_kernel<LADDER_PREC_BF16X6>, grid, block, 0, stream, w, (uint4*)packed, Cin, Cout, transpose_flip, total, wamax);
+  } else {
+    hipLaunchKernelGGL(filter_pack_kernel<LADDER_PREC_BF16X3>, grid, block, 0, stream, w, (uint4*)packed, Cin, Cout, transpose_flip, total, wamax);
+  }
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_conv3x3_split_eligible(int N, int H, int W, int Cin, int Cout) { return split_halo_ok(N, H, W, Cin, Cout) ? 1 : 0; }
+
+int ladder_conv3x3_split(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, int N, int H, int W,
+                         int Cin, int Cout, int act, int prec, ladder_stream_t stream) {
+  if (!split_halo_ok(N, H, W, Cin, Cout) || !prec_ok(prec)) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(x) || !ladder_aligned16(packed) || !ladder_aligned16(y)) return LADDER_E_ALIGN;
+  if (prec == LADDER_PREC_F16X3 && x_absmax == nullptr) return LADDER_E_SHAPE;
+  const int tiles_n = (Cout + SP_BN - 1) / SP_BN;
+  const int tiles_m = N * (H / SP_H) * (W / SP_W);
+  const dim3 grid(tiles_m * tiles_n), block(SP_THREADS);
+  const float* wamax = reinterpret_cast<const float*>(static_cast<const unsigned char*>(packed) + pack_payload_bytes(Cin, Cout, prec));
+#define LADDER_SPLIT_LAUNCH(P_) \
+  hipLaunchKernelGGL(conv3x3_halo_split_kernel<P_>, grid, block, 0, stream, x, (const uint4*)packed, bias, y, N, H, W, Cin, Cout, act, tiles_n, x_absmax, wamax)
+  if (prec == LADDER_PREC_F16X3) LADDER_SPLIT_LAUNCH(LADDER_PREC_F16X3);
+  else if (prec == LADDER_PREC_BF16X6) LADDER_SPLIT_LAUNCH(LADDER_PREC_BF16X6);
+  else LADDER_SPLIT_LAUNCH(LADDER_PREC_BF16X3);
+#undef LADDER_SPLIT_LAUNCH
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+}  // extern "C"

@@ -25,6 +25,9 @@ class KernelProfiler:
     roofline leg).  Events are recorded on the stream the kernels are launched on (torch's current stream)."""
 
     NAMES = {256128: "conv3x3_halo_kernel (8x32 px x 128 ch LDS-halo tile, 8 waves, fp32 MFMA 32x32x2)",
+             256123: "conv3x3_halo_split_kernel<bf16x6> (8x32 px x 128 ch LDS-halo tile, 8 waves, fp32 operands as 3 bf16 planes, 6 x MFMA 32x32x16 bf16)",
+             256122: "conv3x3_halo_split_kernel<bf16x3> (8x32 px x 128 ch LDS-halo tile, 8 waves, fp32 operands as 2 bf16 planes, 3 x MFMA 32x32x16 bf16)",
+             256124: "conv3x3_halo_split_kernel<f16x3> (8x32 px x 128 ch LDS-halo tile, 8 waves, fp32 operands as 2 scaled fp16 planes, 3 x MFMA 32x32x16 f16)",
              128128: "igemm_fwd_kernel<128,128,2,2,true,true> (gather implicit GEMM, fp32 MFMA 32x32x2)",
              9003: "conv_smallcin_kernel (direct 1x1 from 3 channels, HBM-bound)",
              9128: "wgrad3x3_halo_kernel (64ci x 128co slab x 9 taps, 12 waves, LDS-DMA staged 1x32-pixel patches, fp32 MFMA 32x32x2)"}
@@ -46,6 +49,15 @@ class KernelProfiler:
                             flops_per_launch=fl / n, tflops=(fl / (ms * 1e-3) / 1e12) if ms > 0 else 0.0)
         return out
 
+
+# config key `matmul_precision`: how the large 3x3 convolutions are contracted (csrc/convsplit.hip; values = LADDER_PREC_*).
+#   "f32"     v_mfma_f32_32x32x2_f32: bit-exact fp32 FMA chains at the fp32 vector rate
+#   "f16x3"   fp32 operands scaled per tensor by a power of two (from their absolute maximum) and split into 2 fp16 planes (22 bits),
+#             3 plane products on the fp16 matrix cores, fp32 accumulate: fp32-class error (measured: below the f32 FMA chain's)
+#   "bf16x6"  3 bf16 planes (24 bits), 6 plane products, no scaling: fp32-class error
+#   "bf16x3"  2 bf16 planes (16 bits), 3 products (error ~1e-5 relative per product: between TF32 and fp32)
+PRECISIONS = {"f32": 0, "bf16x3": 2, "bf16x6": 3, "f16x3": 4}
+DEFAULT_PRECISION = "f16x3"
 
 PROF = None   # set to a KernelProfiler by bench.py
 _WS_NEED, _KID = {}, {}
@@ -78,6 +90,18 @@ def _igemm(ctx, name, M, Cin, Cout, Kdim, *args, conv=None):
         PROF.add(kid, s, e, 2.0 * M * Kdim * Cout)
     else:
         L.call(name, *args)
+
+
+def _timed(kid, flops, name, args):
+    """One launch, bracketed by HIP events on the launch stream when a profiler is installed (bench.py's roofline leg)."""
+    if PROF is None:
+        L.call(name, *args)
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    L.call(name, *args)
+    e.record()
+    PROF.add(kid, s, e, flops)
 
 
 class Comm:
@@ -132,6 +156,7 @@ class Ctx:
         L.load()
         self.comm = comm or Comm()
         self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
+        self.ns = 0          # LADDER_PREC_* of the split-precision contraction kernels (0 = native f32 MFMA); set by the engine
 
     @property
     def stream(self):
@@ -144,6 +169,14 @@ class Ctx:
 
     def empty(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def absmax(self, t):
+        """Device scalar max|t| (the per-tensor scale of the f16x3 split kernels); None when the precision mode needs none."""
+        if self.ns != 4:
+            return None
+        out = torch.empty(4, dtype=torch.float32, device=self.device)
+        L.call("ladder_absmax", _p(t), t.numel(), _p(out), self.stream)
+        return out
 
     def zeros(self, *shape):
         return torch.zeros(*shape, dtype=torch.float32, device=self.device)
@@ -179,6 +212,7 @@ class ParamStore:
         self.m = {g: ctx.zeros(n) for g, n in sizes.items()}
         self.v = {g: ctx.zeros(n) for g, n in sizes.items()}
         self.step = {g: 0 for g in sizes}                       # host mirror of the per-optimiser step counters
+        self.version = {g: 0 for g in sizes}                    # bumped whenever a group's values change (packed-filter caches)
         # device-resident optimiser state {lr, lr_t, step}: a captured hipGraph replays the step without host scalars
         self.adam_state = {g: ctx.zeros(4) for g in sizes}
         self._lr_host = {g: None for g in sizes}
@@ -211,6 +245,7 @@ class ParamStore:
                 continue
             v = torch.as_tensor(np.asarray(values[name], np.float32).reshape(self.w[name].shape))
             self.w[name].copy_(v.to(self.ctx.device))
+            self.version[arch.group_of(name)] += 1
 
     def to_dict(self, groups=None):
         return {n: self.w[n].detach().cpu().numpy().reshape(self.specs[n]) for n in self.specs
@@ -231,6 +266,7 @@ class ParamStore:
         (n = 1) for the two scalar optimisers."""
         self.set_lr(group, lr)
         self.step[group] += 1
+        self.version[group] += 1
         g = self.grad[group] if grad is None else grad
         L.call("ladder_adam_clip_dev", _p(self.theta[group]), _p(g), _p(self.m[group]), _p(self.v[group]),
                self.theta[group].numel() if n is None else n, _p(self.adam_state[group]), ADAM_B1, ADAM_B2, ADAM_EPS, 1.0,
@@ -247,12 +283,40 @@ class Conv2D:
         # a conv feeding batch-/instance-norm has an identically-zero bias gradient (the norm subtracts the mean):
         # it is not computed and stays 0 in the flat gradient buffer
         self.bias_grad = bias_grad
+        self._packed = {}      # (transpose_flip, ns) -> [weight version, packed bf16 planes]
+
+    def _split_ok(self, N, H, W, cin, cout):
+        """The layer runs on the split-bf16 halo kernel (csrc/convsplit.hip) in the configured precision mode."""
+        return bool(self.ctx.ns and self.k == 3 and self.stride == 1 and self.padding == "same"
+                    and L.query("ladder_conv3x3_split_eligible", N, H, W, cin, cout))
+
+    def _packed_filter(self, transpose_flip):
+        """Split bf16 planes of the filter bank in the kernel's LDS layout, re-packed when the weights changed (always while a
+        hipGraph is being captured, so that a replay re-packs the then-current weights)."""
+        ns, ps = self.ctx.ns, self.ps
+        cin, cout = (self.cout, self.cin) if transpose_flip else (self.cin, self.cout)
+        ent = self._packed.get((transpose_flip, ns))
+        if ent is None:
+            nb = L.query("ladder_conv3x3_pack_bytes", cin, cout, ns)
+            ent = self._packed[(transpose_flip, ns)] = [-1, torch.empty(nb, dtype=torch.uint8, device=self.ctx.device)]
+        ver = ps.version["ae"]
+        if ent[0] != ver or torch.cuda.is_current_stream_capturing():
+            L.call("ladder_conv3x3_pack", _p(ps.w[self.name + "/kernel"]), _p(ent[1]), cin, cout, transpose_flip, ns, self.ctx.stream)
+            ent[0] = ver
+        return ent[1]
 
     def forward(self, x):
         N, H, W, _ = x.shape
         self.pt, Ho = arch.conv_out(H, self.k, self.stride, self.padding)
         self.pl, Wo = arch.conv_out(W, self.k, self.stride, self.padding)
         y = self.ctx.empty(N, Ho, Wo, self.cout)
+        if self._split_ok(N, H, W, self.cin, self.cout):
+            self.x_amax = self.ctx.absmax(x)
+            args = (_p(x), _p(self.x_amax), _p(self._packed_filter(0)), _p(self.ps.w[self.name + "/bias"]), _p(y), N, H, W, self.cin,
+                    self.cout, L.ACT[self.act], self.ctx.ns, self.ctx.stream)
+            _timed(256120 + self.ctx.ns, 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_split", args)
+            self.x, self.y = x, y
+            return y
         _igemm(self.ctx, "ladder_conv2d_fwd", N * Ho * Wo, self.cin, self.cout, self.k * self.k * self.cin,
                _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y),
                N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl, L.ACT[self.act],
@@ -295,7 +359,12 @@ class Conv2D:
             else:
                 L.call("ladder_conv2d_bwd_filter", *wargs)
         dx = None
-        if need_dx:
+        if need_dx and not gate_prev and self._split_ok(N, Ho, Wo, self.cout, self.cin):
+            dx = self.ctx.empty(N, H, W, self.cin)
+            args = (_p(dy), _p(self.ctx.absmax(dy)), _p(self._packed_filter(1)), None, _p(dx), N, H, W, self.cout, self.cin, 0,
+                    self.ctx.ns, st)
+            _timed(256120 + self.ctx.ns, 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_split", args)
+        elif need_dx:
             w = self.ps.w[self.name + "/kernel"]
             wT = self.ctx.empty(w.numel())
             L.call("ladder_filter_flip_transpose", _p(w), _p(wT), self.k, self.k, self.cin, self.cout, st)
@@ -680,6 +749,7 @@ class LadderEngine:
     def __init__(self, cfg, device="cuda:0", values=None, seed=1, comm=None, noise_seed=1234):
         self.cfg = cfg
         self.ctx = Ctx(device, comm)
+        self.ctx.ns = PRECISIONS[str(cfg.get("matmul_precision", DEFAULT_PRECISION))]
         self.ps = ParamStore(cfg, self.ctx, values, seed)
         self.encoder = Encoder(self.ctx, self.ps, cfg)
         self.decoder = (CelebADecoder if cfg["exp_name"] == "celeba" else MnistDecoder)(self.ctx, self.ps, cfg)
