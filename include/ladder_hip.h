@@ -116,6 +116,17 @@ int ladder_conv3x3_split_eligible(int N, int H, int W, int Cin, int Cout);
 int ladder_conv3x3_split(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, int N, int H, int W,
                          int Cin, int Cout, int act, int prec, ladder_stream_t stream);
 
+/* Filter gradient of the same layers on split operands (Cin % 64 == 0, W % 32 == 0, >= 4096 row patches): dw[3][3][Cin][Cout] =
+ * sum x (*) dy, db[co] = sum dy (db may be NULL).  The reduction index of the matrix instruction is the pixel: fragments are read
+ * with the transposing LDS load (ds_read_b64_tr_b16) from channel-contiguous images.  Replaces ladder_conv2d_bwd_filter's call sites
+ * for the decoder's 32x32 ... 128x128 maps. */
+int ladder_conv3x3_wgrad_split_eligible(int N, int H, int W, int Cin, int Cout);
+size_t ladder_conv3x3_wgrad_split_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int ladder_conv3x3_wgrad_split(const float* x, const float* x_absmax, const float* dy, const float* dy_absmax, float* dw, float* db,
+                               int N, int H, int W, int Cin, int Cout, int prec, void* ws, size_t ws_bytes, ladder_stream_t stream);
+/* out[i] = sum_s ws[s*n + i] in the fixed order s = 0..splits-1 (second stage of every split reduction). */
+int ladder_reduce_splits(const float* ws, float* out, int splits, size_t n, ladder_stream_t stream);
+
 /* ---------------------------------------------------------------- N2: tf.layers.dense
  * codes/models.py:73-95,109,231-253,267,478-488,501-510; codes/modules.py:8; codes/base.py:145-186.
  * y[M,N] = act(x[M,K] @ w[K,N] + b).  MFMA-f32 (v_mfma_f32_32x32x2_f32). */

@@ -313,6 +313,220 @@ __global__ __launch_bounds__(SP_THREADS, 2) void conv3x3_halo_split_kernel(const
   }
 }
 
+// ---- 3x3 filter gradient on split operands -----------------------------------------------------------------------------------
+// dW[tap][ci][co] = sum_pixels x[pix + tap][ci] * dy[pix][co]: the reduction index of the MFMA is the PIXEL, so both fragments need
+// 8 consecutive pixels of one channel per lane while NHWC memory (and the LDS image a coalesced staging pass writes) has the
+// channels contiguous.  gfx950's transposing LDS read closes the gap: ds_read_b64_tr_b16 lets every 16-lane group read a
+// [4 pixels][16 channels] block of a channel-contiguous image and hands each lane the 4 pixels of ITS channel, so
+//   * the LDS images stay [32-channel block][pixel][32 channels x 16 bit] (64-byte pixel rows: the 4 rows x 64 B a half-wave
+//     touches are one contiguous 256-byte bank row -> conflict-free), written by plain 8-byte stores of split float4s;
+//   * a filter tap is a whole-pixel address offset into the halo image (no misaligned or shifted copies).
+// Work decomposition as wgrad3x3_halo_kernel (igemm.hip): one workgroup = 12 wavefronts owns a 64 ci x 128 co slab of dW for all 9
+// taps (72 MFMA tiles), wavefront -> (filter row r, ci half cb, co pair njp) with 6 tiles; it walks 1x32-pixel row patches
+// (K = 2 x 16 pixels), double-buffered in LDS; partial sums over the patch split are reduced in a fixed order by the caller.
+constexpr int WS_CI = 64, WS_CO = 128, WS_PW = 32, WS_HW = WS_PW + 2;
+constexpr int WS_THREADS = 768;
+constexpr int WS_XPIX = 3 * WS_HW;                                  // 102 halo pixels
+constexpr int WS_XBLK = WS_XPIX * 64 + 64, WS_DBLK = WS_PW * 64 + 64;   // bytes per 32-channel block (+64: blocks land on different banks)
+constexpr int WS_XPLANE = 2 * WS_XBLK, WS_DPLANE = 4 * WS_DBLK;
+constexpr int WS_XU = WS_XPIX * (WS_CI / 4), WS_DU = WS_PW * (WS_CO / 4);                     // float4 units per patch: 1632, 1024
+static_assert(WS_XU + WS_DU <= 4 * WS_THREADS, "four staging rounds");
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 lds_tr_frag(const unsigned char* p) {
+  // 8 consecutive pixels (rows of 64 B) of this lane's channel: two transposing reads of 4 pixels each
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * 64));
+  const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+  return make_uint4(a.x, a.y, b.x, b.y);
+}
+
+// sum of the 8 16-bit values of a fragment register quad, in fp32
+template <bool F16>
+__device__ __forceinline__ float frag_sum(const uint4 f) {
+  const uint32_t w[4] = {f.x, f.y, f.z, f.w};
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (F16) {
+      const f32x2 v = __builtin_convertvector(__builtin_bit_cast(f16x2, w[i]), f32x2);
+      s += v.x + v.y;
+    } else {
+      s += __builtin_bit_cast(float, w[i] << 16) + __builtin_bit_cast(float, w[i] & 0xffff0000u);
+    }
+  }
+  return s;
+}
+
+template <int PREC>
+__global__ __launch_bounds__(WS_THREADS, 3) void wgrad3x3_split_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                      float* __restrict__ out, float* __restrict__ bias_part,
+                                                                      const int N, const int H, const int W, const int Cin,
+                                                                      const int Cout, const int tiles_co, const int patches_per_split,
+                                                                      const float* __restrict__ xamax, const float* __restrict__ damax) {
+  constexpr int NS = Fmt<PREC>::NS;
+  constexpr bool F16 = Fmt<PREC>::F16;
+  constexpr int BUF = NS * (WS_XPLANE + WS_DPLANE);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;            // 12 wavefronts
+  const int l31 = lane & 31, lh = lane >> 5, l15 = lane & 15;
+  const int ci0 = (blockIdx.x / tiles_co) * WS_CI, co0 = (blockIdx.x % tiles_co) * WS_CO;
+  const int WP = W / WS_PW;
+  const int q_total = N * H * WP;
+  const int q0 = blockIdx.y * patches_per_split, q1 = min(q_total, q0 + patches_per_split);
+  const int r = wv >> 2, cb = (wv >> 1) & 1, njp = wv & 1;
+  float cx = 1.f, cd = 1.f;
+  if (F16) {
+    cx = scale_from_absmax(*xamax);
+    cd = scale_from_absmax(*damax);
+  }
+  // fragment addresses (bytes inside a buffer): pixel row of 64 B, this lane's 4-channel group inside its 16-lane block
+  const int frag_lane = (8 * lh + (l15 >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (l15 & 3)) * 2;
+  const int a_off = cb * WS_XBLK + r * WS_HW * 64 + frag_lane;                        // + plane*WS_XPLANE + (16 ks + s) * 64
+  const int b_off = NS * WS_XPLANE + (njp * 2) * WS_DBLK + frag_lane;                 // + plane*WS_DPLANE + j*WS_DBLK + 16 ks * 64
+  // bias gradient = column sums of dy, read off the centre-row B fragments (every output channel is covered exactly once by the
+  // r = 1, cb = 0 wavefronts): the two planes of a fragment add up to dy * cd to 2^-23 relative.
+  const bool do_bias = (bias_part != nullptr) && (ci0 == 0) && r == 1 && cb == 0;
+
+  f32x16 acc[6];                                       // [j][s]
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  float bsum[2] = {0.f, 0.f};
+
+  // staging: the 1632 halo units and the 1024 dy units of a patch form ONE list of float4 units, 4 rounds of 768 threads; two rounds
+  // are in flight across each of the two MFMA blocks of a patch (8 staging registers)
+  float4 r0, r1;
+  auto patch_coords = [&](int q, int& n, int& h, int& w0) {
+    n = q / (H * WP);
+    const int rem = q - n * (H * WP);
+    h = rem / WP;
+    w0 = (rem - h * WP) * WS_PW;
+  };
+  auto load_unit = [&](int q, int i) -> float4 {
+    const int u = tid + i * WS_THREADS;
+    int n, h, w0;
+    patch_coords(q, n, h, w0);
+    const float* src = gs_zero16;
+    if (u < WS_XU) {
+      const int pix = u >> 4, q4 = u & 15;
+      const int hr = pix / WS_HW, hc = pix - hr * WS_HW;
+      const int hi = h - 1 + hr, wi = w0 - 1 + hc;
+      if (hi >= 0 && hi < H && wi >= 0 && wi < W) src = x + (((long)n * H + hi) * W + wi) * Cin + ci0 + q4 * 4;
+    } else if (u < WS_XU + WS_DU) {
+      const int v = u - WS_XU, p = v >> 5, q4 = v & 31;
+      if ((co0 + q4 * 4) < Cout) src = dy + (((long)n * H + h) * W + w0 + p) * Cout + co0 + q4 * 4;
+    }
+    return *reinterpret_cast<const float4*>(src);
+  };
+  auto store_unit = [&](int buf, int i, float4 v) {
+    const int u = tid + i * WS_THREADS;
+    if (u >= WS_XU + WS_DU) return;
+    const bool isx = u < WS_XU;
+    const int w = isx ? u : u - WS_XU;
+    const int pix = isx ? (w >> 4) : (w >> 5), q4 = isx ? (w & 15) : (w & 31);
+    const float c = isx ? cx : cd;
+    if (F16) v = make_float4(v.x * c, v.y * c, v.z * c, v.w * c);
+    uint2 pl[NS];
+    split4<NS, F16>(v, pl);
+    const int off = (isx ? (q4 >> 3) * WS_XBLK : NS * WS_XPLANE + (q4 >> 3) * WS_DBLK) + pix * 64 + (q4 & 7) * 8;
+#pragma unroll
+    for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(lds + buf * BUF + off + p * (isx ? WS_XPLANE : WS_DPLANE)) = pl[p];
+  };
+  auto mma_step = [&](int buf, int ks) {
+    const unsigned char* base = lds + buf * BUF + ks * 16 * 64;
+    uint4 a[3][NS], b[2][NS];
+#pragma unroll
+    for (int p = 0; p < NS; ++p) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) a[s][p] = lds_tr_frag(base + a_off + p * WS_XPLANE + s * 64);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j][p] = lds_tr_frag(base + b_off + p * WS_DPLANE + j * WS_DBLK);
+    }
+#pragma unroll
+    for (int sum = NS - 1; sum >= 0; --sum)
+#pragma unroll
+      for (int pa = 0; pa <= sum; ++pa) {
+        const int pb = sum - pa;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int s = 0; s < 3; ++s) acc[j * 3 + s] = mfma16<F16>(a[s][pa], b[j][pb], acc[j * 3 + s]);
+      }
+    if (do_bias) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int p = NS - 1; p >= 0; --p) bsum[j] += frag_sum<F16>(b[j][p]);
+    }
+  };
+
+  if (q0 < q1) {
+    r0 = load_unit(q0, 0); r1 = load_unit(q0, 1);
+    store_unit(0, 0, r0); store_unit(0, 1, r1);
+    r0 = load_unit(q0, 2); r1 = load_unit(q0, 3);
+    store_unit(0, 2, r0); store_unit(0, 3, r1);
+  }
+  __syncthreads();
+  for (int q = q0; q < q1; ++q) {
+    const int buf = (q - q0) & 1;
+    const bool more = q + 1 < q1;
+    if (more) { r0 = load_unit(q + 1, 0); r1 = load_unit(q + 1, 1); }
+    mma_step(buf, 0);
+    if (more) {
+      store_unit(buf ^ 1, 0, r0); store_unit(buf ^ 1, 1, r1);
+      r0 = load_unit(q + 1, 2); r1 = load_unit(q + 1, 3);
+    }
+    mma_step(buf, 1);
+    if (more) { store_unit(buf ^ 1, 2, r0); store_unit(buf ^ 1, 3, r1); }
+    __syncthreads();
+  }
+
+  const float unscale = F16 ? 1.f / (cx * cd) : 1.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = co0 + njp * 64 + j * 32 + l31;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      float* o = out + ((size_t)blockIdx.y * 9 + (3 * r + s)) * Cin * Cout;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ci = ci0 + cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (n < Cout) o[(size_t)ci * Cout + n] = acc[j * 3 + s][e] * unscale;
+      }
+    }
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = co0 + njp * 64 + j * 32 + l31;
+      const float v = (bsum[j] + __shfl_down(bsum[j], 32, 64)) * (F16 ? 1.f / cd : 1.f);   // pixels 0-7 + 8-15 of every k-step
+      if (lh == 0 && n < Cout) bias_part[(size_t)blockIdx.y * Cout + n] = v;
+    }
+  }
+}
+
+struct WgradSplitPlan { bool ok; int tiles_ci, tiles_co, splits, pps; };
+WgradSplitPlan plan_wgrad_split(int N, int H, int W, int Cin, int Cout) {
+  WgradSplitPlan p{false, 0, 0, 1, 0};
+  if (!(N > 0 && (Cin % WS_CI) == 0 && (Cout % 4) == 0 && Cout >= 64 && (W % WS_PW) == 0)) return p;
+  const long q_total = (long)N * H * (W / WS_PW);
+  if (q_total < 4096) return p;                                // small maps stay on the generic kernel
+  p.tiles_ci = Cin / WS_CI;
+  p.tiles_co = (Cout + WS_CO - 1) / WS_CO;
+  const long pairs = (long)p.tiles_ci * p.tiles_co;
+  long s = (2 * 256L) / pairs;                                 // two whole rounds of the chip (one 12-wave workgroup per CU)
+  if (s > q_total / 16) s = q_total / 16;
+  if (s < 1) s = 1;
+  p.pps = (int)((q_total + s - 1) / s);
+  p.splits = (int)((q_total + p.pps - 1) / p.pps);
+  p.ok = true;
+  return p;
+}
+
 bool split_halo_ok(int N, int H, int W, int Cin, int Cout) {
   return N > 0 && (Cin % 16) == 0 && (Cout % 4) == 0 && Cout >= 64 && (W % SP_W) == 0 && (H % SP_H) == 0 &&
          (long)N * (H / SP_H) * (W / SP_W) * ((Cout + SP_BN - 1) / SP_BN) >= 512;
@@ -381,6 +595,38 @@ int ladder_conv3x3_split(const float* x, const float* x_absmax, const void* pack
 #undef LADDER_SPLIT_LAUNCH
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
+}
+
+int ladder_conv3x3_wgrad_split_eligible(int N, int H, int W, int Cin, int Cout) { return plan_wgrad_split(N, H, W, Cin, Cout).ok ? 1 : 0; }
+
+size_t ladder_conv3x3_wgrad_split_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+  const WgradSplitPlan p = plan_wgrad_split(N, H, W, Cin, Cout);
+  if (!p.ok) return 0;
+  return ((size_t)p.splits * 9 * Cin * Cout + (size_t)p.splits * Cout) * sizeof(float);
+}
+
+int ladder_conv3x3_wgrad_split(const float* x, const float* x_absmax, const float* dy, const float* dy_absmax, float* dw, float* db,
+                               int N, int H, int W, int Cin, int Cout, int prec, void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  const WgradSplitPlan p = plan_wgrad_split(N, H, W, Cin, Cout);
+  if (!p.ok || !prec_ok(prec)) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(x) || !ladder_aligned16(dy) || !ladder_aligned16(dw)) return LADDER_E_ALIGN;
+  if (prec == LADDER_PREC_F16X3 && (x_absmax == nullptr || dy_absmax == nullptr)) return LADDER_E_SHAPE;
+  if (ws == nullptr || ws_bytes < ladder_conv3x3_wgrad_split_workspace_bytes(N, H, W, Cin, Cout)) return LADDER_E_WORKSPACE;
+  const size_t kn = (size_t)9 * Cin * Cout;
+  float* part = (float*)ws;
+  float* bias_part = db != nullptr ? part + (size_t)p.splits * kn : nullptr;
+  const dim3 grid(p.tiles_ci * p.tiles_co, p.splits), block(WS_THREADS);
+#define LADDER_WS_LAUNCH(P_) \
+  hipLaunchKernelGGL(wgrad3x3_split_kernel<P_>, grid, block, 0, stream, x, dy, part, bias_part, N, H, W, Cin, Cout, p.tiles_co, p.pps, x_absmax, dy_absmax)
+  if (prec == LADDER_PREC_F16X3) LADDER_WS_LAUNCH(LADDER_PREC_F16X3);
+  else if (prec == LADDER_PREC_BF16X6) LADDER_WS_LAUNCH(LADDER_PREC_BF16X6);
+  else LADDER_WS_LAUNCH(LADDER_PREC_BF16X3);
+#undef LADDER_WS_LAUNCH
+  LADDER_CHECK_LAUNCH();
+  int rc = ladder_reduce_splits(part, dw, p.splits, kn, stream);
+  if (rc != LADDER_OK) return rc;
+  if (db != nullptr) rc = ladder_reduce_splits(bias_part, db, p.splits, (size_t)Cout, stream);
+  return rc;
 }
 
 }  // extern "C"

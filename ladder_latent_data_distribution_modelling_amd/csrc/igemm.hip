@@ -1402,6 +1402,13 @@ int ladder_conv2d_fwd_kernel_id(int N, int H, int W, int Cin, int Ho, int Wo, in
   return ladder_igemm_fwd_tile(d.M, Cin, Cout);
 }
 
+int ladder_reduce_splits(const float* ws, float* out, int splits, size_t n, ladder_stream_t stream) {
+  if (splits <= 0 || n == 0) return LADDER_E_SHAPE;
+  launch_reduce_splits(ws, out, splits, n, stream);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
 int ladder_filter_flip_transpose(const float* w, float* wT, int KH, int KW, int Cin, int Cout, ladder_stream_t stream) {
   if (KH <= 0 || KW <= 0 || Cin <= 0 || Cout <= 0) return LADDER_E_SHAPE;
   dim3 grid((Cout + 31) / 32, (Cin + 31) / 32, KH * KW), block(32, 8);

@@ -30,6 +30,8 @@ class KernelProfiler:
              256124: "conv3x3_halo_split_kernel<f16x3> (8x32 px x 128 ch LDS-halo tile, 8 waves, fp32 operands as 2 scaled fp16 planes, 3 x MFMA 32x32x16 f16)",
              128128: "igemm_fwd_kernel<128,128,2,2,true,true> (gather implicit GEMM, fp32 MFMA 32x32x2)",
              9003: "conv_smallcin_kernel (direct 1x1 from 3 channels, HBM-bound)",
+             9124: "wgrad3x3_split_kernel<f16x3> (64ci x 128co slab x 9 taps, 12 waves, transposing LDS reads, 3 x MFMA 32x32x16 f16; incl. its split reduction)",
+             9122: "wgrad3x3_split_kernel<bf16x3>", 9123: "wgrad3x3_split_kernel<bf16x6>",
              9128: "wgrad3x3_halo_kernel (64ci x 128co slab x 9 taps, 12 waves, LDS-DMA staged 1x32-pixel patches, fp32 MFMA 32x32x2)"}
 
     def __init__(self):
@@ -310,6 +312,7 @@ class Conv2D:
         self.pt, Ho = arch.conv_out(H, self.k, self.stride, self.padding)
         self.pl, Wo = arch.conv_out(W, self.k, self.stride, self.padding)
         y = self.ctx.empty(N, Ho, Wo, self.cout)
+        self.x_amax = None
         if self._split_ok(N, H, W, self.cin, self.cout):
             self.x_amax = self.ctx.absmax(x)
             args = (_p(x), _p(self.x_amax), _p(self._packed_filter(0)), _p(self.ps.w[self.name + "/bias"]), _p(y), N, H, W, self.cin,
@@ -344,7 +347,20 @@ class Conv2D:
                    self.cout, L.ACT[gate_prev] if gate_prev else 0, wsp, wsn, st)
             self.x = self.y = None
             return dx
-        if wgrad:
+        dy_amax = None
+        split_w = bool(wgrad and self._split_ok(N, H, W, self.cin, self.cout)
+                       and L.query("ladder_conv3x3_wgrad_split_eligible", N, H, W, self.cin, self.cout))
+        if split_w and self.ctx.ns == 4 and getattr(self, "x_amax", None) is None:
+            self.x_amax = self.ctx.absmax(x)
+        split_d = bool(need_dx and not gate_prev and self._split_ok(N, Ho, Wo, self.cout, self.cin))
+        if split_w or split_d:
+            dy_amax = self.ctx.absmax(dy)               # one pass serves the filter gradient and the backward-data call
+        if split_w:
+            wsp, wsn = self.ctx.ws(L.query("ladder_conv3x3_wgrad_split_workspace_bytes", N, H, W, self.cin, self.cout))
+            args = (_p(x), _p(self.x_amax), _p(dy), _p(dy_amax), _p(self.ps.g[self.name + "/kernel"]),
+                    _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, N, H, W, self.cin, self.cout, self.ctx.ns, wsp, wsn, st)
+            _timed(9120 + self.ctx.ns, 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_wgrad_split", args)
+        elif wgrad:
             nb = L.query("ladder_conv2d_bwd_filter_workspace_bytes", N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k)
             wsp, wsn = self.ctx.ws(nb)
             wargs = (_p(x), _p(dy), _p(self.ps.g[self.name + "/kernel"]), _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None,
@@ -359,9 +375,9 @@ class Conv2D:
             else:
                 L.call("ladder_conv2d_bwd_filter", *wargs)
         dx = None
-        if need_dx and not gate_prev and self._split_ok(N, Ho, Wo, self.cout, self.cin):
+        if split_d:
             dx = self.ctx.empty(N, H, W, self.cin)
-            args = (_p(dy), _p(self.ctx.absmax(dy)), _p(self._packed_filter(1)), None, _p(dx), N, H, W, self.cout, self.cin, 0,
+            args = (_p(dy), _p(dy_amax), _p(self._packed_filter(1)), None, _p(dx), N, H, W, self.cout, self.cin, 0,
                     self.ctx.ns, st)
             _timed(256120 + self.ctx.ns, 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_split", args)
         elif need_dx:
