@@ -105,17 +105,38 @@ int ladder_conv1x1_smallcout_bwd(const float* x, const float* dy, const float* w
 enum { LADDER_PREC_F32 = 0, LADDER_PREC_BF16X3 = 2, LADDER_PREC_BF16X6 = 3, LADDER_PREC_F16X3 = 4 };
 /* out[0] = max |x[i]| (device scalar; exact and order-independent). */
 int ladder_absmax(const float* x, size_t n, float* out, ladder_stream_t stream);
-/* ladder_conv3x3_pack: once per weight update, HWIO fp32 bank -> split planes in the kernel's LDS layout.
- *   transpose_flip = 0: `w` = [3][3][Cin][Cout] (forward).  transpose_flip = 1: `w` = the layer's bank [3][3][Cout][Cin] read as the
- *   flipped, transposed filter of its backward-data pass (Cin = dy channels, Cout = dx channels). */
-size_t ladder_conv3x3_pack_bytes(int Cin, int Cout, int prec);
-int ladder_conv3x3_pack(const float* w, void* packed, int Cin, int Cout, int transpose_flip, int prec, ladder_stream_t stream);
+/* ladder_filter_pack_split: once per weight update, HWIO fp32 bank of ntaps = KH*KW taps -> split planes in the kernels' LDS layout
+ * (Cin % 16 == 0; output channels zero-padded to a multiple of 128).
+ *   transpose_flip = 0: `w` = [KH][KW][Cin][Cout] (forward).  transpose_flip = 1: `w` = the layer's bank [KH][KW][Cout][Cin] read as
+ *   the flipped, transposed filter of its backward-data pass (Cin = dy channels, Cout = dx channels). */
+size_t ladder_filter_pack_split_bytes(int ntaps, int Cin, int Cout, int prec);
+int ladder_filter_pack_split(const float* w, void* packed, int ntaps, int Cin, int Cout, int transpose_flip, int prec,
+                             ladder_stream_t stream);
 int ladder_conv3x3_split_eligible(int N, int H, int W, int Cin, int Cout);
 /* y = act(conv3x3_same(x, F) + bias) with F as packed above (bias may be NULL; x_absmax is read only for LADDER_PREC_F16X3 and may
  * be any upper bound of max |x|: a looser bound only raises the absolute representation floor 2^-39 * bound). */
 int ladder_conv3x3_split(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, int N, int H, int W,
                          int Cin, int Cout, int act, int prec, ladder_stream_t stream);
 
+/* The gather kernel on split operands: every other large convolution (128x128 output tiles; gathered channels % 32 == 0; tap table
+ * <= 28 taps), i.e. the strided encoder layers and the 8x8 / 16x16 decoder maps (codes/models.py:398-460, 522-547) and their
+ * backward-data passes (stride 2: the four output-parity classes).  Same semantics as ladder_conv2d_fwd / ladder_conv2d_bwd_data with
+ * `packed` from ladder_filter_pack_split (transpose_flip = 1 for backward-data) and the gathered tensor's absolute maximum.
+ * *_eligible: 1 when EVERY launch of the call runs on the split kernel (call the fp32 entry point otherwise). */
+int ladder_conv2d_fwd_split_eligible(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t,
+                                     int pad_l);
+size_t ladder_conv2d_fwd_split_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                                               int pad_t, int pad_l);
+int ladder_conv2d_fwd_split(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, int N, int H, int W,
+                            int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int act, int prec,
+                            void* ws, size_t ws_bytes, ladder_stream_t stream);
+int ladder_conv2d_bwd_data_split_eligible(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t,
+                                          int pad_l, int gated);
+size_t ladder_conv2d_bwd_data_split_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                                                    int pad_t, int pad_l);
+int ladder_conv2d_bwd_data_split(const float* dy, const float* dy_absmax, const void* packed_T, float* dx, int N, int H, int W, int Cin,
+                                 int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, const float* gate_y,
+                                 int gate_act, int prec, void* ws, size_t ws_bytes, ladder_stream_t stream);
 /* Filter gradient of the same layers on split operands (Cin % 64 == 0, W % 32 == 0, >= 4096 row patches): dw[3][3][Cin][Cout] =
  * sum x (*) dy, db[co] = sum dy (db may be NULL).  The reduction index of the matrix instruction is the pixel: fragments are read
  * with the transposing LDS load (ds_read_b64_tr_b16) from channel-contiguous images.  Replaces ladder_conv2d_bwd_filter's call sites

@@ -97,8 +97,14 @@ PROTOTYPES = {
     "ladder_vbgmm_workspace_bytes": (_z, [_i, _i]),
     "ladder_vbgmm_fit": (_i, [_p, _i, _i, _i, _p, _p, _i, _d, _d, _d, _d, _i, _p, _p, _p, _p, _z, _p]),
     "ladder_axpy": (_i, [_p, _p, _z, _f, _i, _p]),
-    "ladder_conv3x3_pack_bytes": (_z, [_i, _i, _i]),
-    "ladder_conv3x3_pack": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "ladder_filter_pack_split_bytes": (_z, [_i, _i, _i, _i]),
+    "ladder_filter_pack_split": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "ladder_conv2d_fwd_split_eligible": (_i, [_i] * 12),
+    "ladder_conv2d_fwd_split_workspace_bytes": (_z, [_i] * 12),
+    "ladder_conv2d_fwd_split": (_i, [_p, _p, _p, _p, _p] + [_i] * 14 + [_p, _z, _p]),
+    "ladder_conv2d_bwd_data_split_eligible": (_i, [_i] * 13),
+    "ladder_conv2d_bwd_data_split_workspace_bytes": (_z, [_i] * 12),
+    "ladder_conv2d_bwd_data_split": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p, _i, _i, _p, _z, _p]),
     "ladder_conv3x3_split_eligible": (_i, [_i] * 5),
     "ladder_conv3x3_split": (_i, [_p, _p, _p, _p, _p] + [_i] * 7 + [_p]),
     "ladder_absmax": (_i, [_p, _z, _p, _p]),

@@ -19,7 +19,7 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, "common.h"),
+    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, "common.h"), os.path.join(HERE, "split16.h"),
                                                        os.path.join(ROOT, "include", "ladder_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 

@@ -26,107 +26,53 @@
 //                               128-channel LDS-halo tiling of conv3x3_halo_kernel (igemm.hip) with the input halo split into
 //                               planes while it is staged into LDS.
 #include <cstdlib>
-#include "common.h"
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "split16.h"
 
 namespace {
 
 __device__ __attribute__((aligned(16))) float gs_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
-// Precision format of a split contraction: number of planes and the 16-bit element type.
-template <int PREC> struct Fmt;
-template <> struct Fmt<LADDER_PREC_BF16X6> { static constexpr int NS = 3; static constexpr bool F16 = false; };
-template <> struct Fmt<LADDER_PREC_BF16X3> { static constexpr int NS = 2; static constexpr bool F16 = false; };
-template <> struct Fmt<LADDER_PREC_F16X3>  { static constexpr int NS = 2; static constexpr bool F16 = true; };
-inline bool prec_ok(int prec) { return prec == LADDER_PREC_BF16X6 || prec == LADDER_PREC_BF16X3 || prec == LADDER_PREC_F16X3; }
-inline int prec_planes(int prec) { return prec == LADDER_PREC_BF16X6 ? 3 : 2; }
-
-// packed pair of 16-bit floats, round-to-nearest-even (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32): low half = a, high half = b;
-// `back` = the pair converted back to fp32 (exact)
-template <bool F16>
-__device__ __forceinline__ uint32_t pk16(float a, float b, float& back_a, float& back_b) {
-  const f32x2 v = {a, b};
-  if (F16) {
-    const f16x2 h = __builtin_convertvector(v, f16x2);
-    const f32x2 f = __builtin_convertvector(h, f32x2);
-    back_a = f.x;
-    back_b = f.y;
-    return __builtin_bit_cast(uint32_t, h);
-  } else {
-    const uint32_t p = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-    back_a = __builtin_bit_cast(float, p << 16);
-    back_b = __builtin_bit_cast(float, p & 0xffff0000u);
-    return p;
-  }
-}
-
-// Splits 4 floats into NS planes of 4 packed 16-bit values each (plane p -> out[p] = {elements 0,1 | elements 2,3}).
-template <int NS, bool F16>
-__device__ __forceinline__ void split4(const float4 v, uint2 (&out)[NS]) {
-  float a = v.x, b = v.y, c = v.z, d = v.w;
-#pragma unroll
-  for (int p = 0; p < NS; ++p) {
-    float fa, fb, fc, fd;
-    const uint32_t q0 = pk16<F16>(a, b, fa, fb), q1 = pk16<F16>(c, d, fc, fd);
-    out[p] = make_uint2(q0, q1);
-    if (p + 1 < NS) {
-      a -= fa;
-      b -= fb;
-      c -= fc;
-      d -= fd;
-    }
-  }
-}
-
-// Power-of-two scale c with |x| c < 2^14 for every |x| <= amax (fp16 tops out at 65504; the planes of the largest elements then keep
-// 2 binades of headroom); 1 for an all-zero or non-finite tensor.
-__device__ __forceinline__ float scale_from_absmax(float amax) {
-  const uint32_t bits = __builtin_bit_cast(uint32_t, amax);
-  const int e = (int)((bits >> 23) & 0xff);               // biased exponent: amax < 2^(e - 126)
-  if (e == 0 || e == 255) return 1.f;
-  int se = 127 + 14 - (e - 126);                          // biased exponent of 2^(14 - (e - 126))
-  se = se < 1 ? 1 : (se > 254 ? 254 : se);
-  return __builtin_bit_cast(float, (uint32_t)se << 23);
-}
-
-template <bool F16>
-__device__ __forceinline__ f32x16 mfma16(const uint4 a, const uint4 b, const f32x16 c) {
-  if (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
 // ---- absolute maximum ------------------------------------------------------------------------------------------------------
 // Non-negative floats order like their bit patterns, so an unsigned atomic max is exact and order-independent (deterministic).
+// One atomic per WORKGROUP: same-address atomics serialise at ~12 ns each in the L2 (a per-wavefront atomic from 2048 blocks cost
+// 100 us, 4x the streaming time of a 1 GB tensor), so a launch is 512 blocks x 8 float4 loads in flight per thread.
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n4, size_t n, unsigned* __restrict__ out) {
+  __shared__ float red[4];
+  const float4* x4 = reinterpret_cast<const float4*>(x);
   float m = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 7 * stride < n4; i += 8 * stride) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = x4[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+  }
+  for (; i < n4; i += stride) {
+    const float4 v = x4[i];
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
   if (blockIdx.x == 0)
-    for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(x[i]));
+    for (size_t t = n4 * 4 + threadIdx.x; t < n; t += 256) m = fmaxf(m, fabsf(x[t]));
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, __builtin_bit_cast(unsigned, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
 }
 
 // ---- filter packing ----------------------------------------------------------------------------------------------------
-// Logical filter F[tap][ci][co] (tap = r*3+s, ci < Cin, co < Cout):
-//   transpose_flip = 0:  F[tap][ci][co] = w[tap][ci][co]           (w is the HWIO bank [9][Cin][Cout])              forward
-//   transpose_flip = 1:  F[tap][ci][co] = w[8 - tap][co][ci]       (w is the HWIO bank [9][Cout][Cin] of the layer)  backward-data
+// Logical filter F[tap][ci][co] (tap = r*KW+s < ntaps, ci < Cin, co < Cout):
+//   transpose_flip = 0:  F[tap][ci][co] = w[tap][ci][co]               (w is the HWIO bank [ntaps][Cin][Cout])              forward
+//   transpose_flip = 1:  F[tap][ci][co] = w[ntaps - 1 - tap][co][ci]   (w is the HWIO bank [ntaps][Cout][Cin] of the layer)  backward-data
 // Packed image (16-bit elements): P[tap][slab = ci/16][cot = co/128][plane][kg = (ci%16)/8][co % 128][ci % 8]; one (tap, slab, cot)
 // block is the contiguous NS * 4096 bytes a workgroup stages per K-step.  The last 16 bytes of the buffer hold the filter's
 // absolute maximum (f16x3 only; the kernels derive the power-of-two scale from it).
 constexpr int SP_BN = 128;
 
 template <int PREC>
-__global__ __launch_bounds__(256) void filter_pack_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cin, int Cout,
-                                                          int transpose_flip, int total, const float* __restrict__ wamax) {
+__global__ __launch_bounds__(256) void filter_pack_kernel(const float* __restrict__ w, uint4* __restrict__ out, int ntaps, int Cin,
+                                                          int Cout, int transpose_flip, int total, const float* __restrict__ wamax) {
   constexpr int NS = Fmt<PREC>::NS;
   constexpr bool F16 = Fmt<PREC>::F16;
   const int i = blockIdx.x * 256 + threadIdx.x;     // one thread per (tap, slab, cot, kg, co)
@@ -145,7 +91,7 @@ __global__ __launch_bounds__(256) void filter_pack_kernel(const float* __restric
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     float f = 0.f;
-    if (co < Cout) f = transpose_flip ? w[((size_t)(8 - tap) * Cout + co) * Cin + ci0 + j] : w[((size_t)tap * Cin + ci0 + j) * Cout + co];
+    if (co < Cout) f = transpose_flip ? w[((size_t)(ntaps - 1 - tap) * Cout + co) * Cin + ci0 + j] : w[((size_t)tap * Cin + ci0 + j) * Cout + co];
     v[j] = f * c;
   }
   uint2 lo[NS], hi[NS];
@@ -532,10 +478,6 @@ bool split_halo_ok(int N, int H, int W, int Cin, int Cout) {
          (long)N * (H / SP_H) * (W / SP_W) * ((Cout + SP_BN - 1) / SP_BN) >= 512;
 }
 
-inline size_t pack_payload_bytes(int Cin, int Cout, int prec) {
-  return (size_t)9 * (Cin / 16) * ((Cout + SP_BN - 1) / SP_BN) * prec_planes(prec) * 4096;
-}
-
 }  // namespace
 
 extern "C" {
@@ -546,31 +488,34 @@ int ladder_absmax(const float* x, size_t n, float* out, ladder_stream_t stream) 
   if (hipMemsetAsync(out, 0, sizeof(float), stream) != hipSuccess) return LADDER_E_LAUNCH;
   const size_t n4 = n / 4;
   size_t blocks = (n4 + 256 * 8 - 1) / (256 * 8);
-  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n4, n, (unsigned*)out);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
 
-size_t ladder_conv3x3_pack_bytes(int Cin, int Cout, int prec) {
-  if (Cin <= 0 || Cout <= 0 || (Cin % 16) != 0 || !prec_ok(prec)) return 0;
-  return pack_payload_bytes(Cin, Cout, prec) + 16;
+size_t ladder_filter_pack_split_bytes(int ntaps, int Cin, int Cout, int prec) {
+  if (ntaps <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 16) != 0 || !prec_ok(prec)) return 0;
+  return pack_payload_bytes(ntaps, Cin, Cout, prec) + 16;
 }
 
-int ladder_conv3x3_pack(const float* w, void* packed, int Cin, int Cout, int transpose_flip, int prec, ladder_stream_t stream) {
-  if (Cin <= 0 || Cout <= 0 || (Cin % 16) != 0 || !prec_ok(prec)) return LADDER_E_SHAPE;
+int ladder_filter_pack_split(const float* w, void* packed, int ntaps, int Cin, int Cout, int transpose_flip, int prec,
+                             ladder_stream_t stream) {
+  if (ntaps <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 16) != 0 || !prec_ok(prec)) return LADDER_E_SHAPE;
   if (!ladder_aligned16(packed) || !ladder_aligned16(w)) return LADDER_E_ALIGN;
-  const int total = 9 * (Cin / 16) * ((Cout + SP_BN - 1) / SP_BN) * 2 * SP_BN;
+  const long total_l = (long)ntaps * (Cin / 16) * ((Cout + SP_BN - 1) / SP_BN) * 2 * SP_BN;
+  if (total_l >= (1L << 31)) return LADDER_E_SHAPE;
+  const int total = (int)total_l;
   const dim3 grid((total + 255) / 256), block(256);
-  float* wamax = reinterpret_cast<float*>(static_cast<unsigned char*>(packed) + pack_payload_bytes(Cin, Cout, prec));
+  float* wamax = reinterpret_cast<float*>(static_cast<unsigned char*>(packed) + pack_payload_bytes(ntaps, Cin, Cout, prec));
   if (prec == LADDER_PREC_F16X3) {
-    const int rc = ladder_absmax(w, (size_t)9 * Cin * Cout, wamax, stream);
+    const int rc = ladder_absmax(w, (size_t)ntaps * Cin * Cout, wamax, stream);
     if (rc != LADDER_OK) return rc;
-    hipLaunchKernelGGL(filter_pack_kernel<LADDER_PREC_F16X3>, grid, block, 0, stream, w, (uint4*)packed, Cin, Cout, transpose_flip, total, wamax);
+    hipLaunchKernelGGL(filter_pack_kernel<LADDER_PREC_F16X3>, grid, block, 0, stream, w, (uint4*)packed, ntaps, Cin, Cout, transpose_flip, total, wamax);
   } else if (prec == LADDER_PREC_BF16X6) {
-    hipLaunchKernelGGL(filter_pack_kernel<LADDER_PREC_BF16X6>, grid, block, 0, stream, w, (uint4*)packed, Cin, Cout, transpose_flip, total, wamax);
+    hipLaunchKernelGGL(filter_pack_kernel<LADDER_PREC_BF16X6>, grid, block, 0, stream, w, (uint4*)packed, ntaps, Cin, Cout, transpose_flip, total, wamax);
   } else {
-    hipLaunchKernelGGL(filter_pack_kernel<LADDER_PREC_BF16X3>, grid, block, 0, stream, w, (uint4*)packed, Cin, Cout, transpose_flip, total, wamax);
+    hipLaunchKernelGGL(filter_pack_kernel<LADDER_PREC_BF16X3>, grid, block, 0, stream, w, (uint4*)packed, ntaps, Cin, Cout, transpose_flip, total, wamax);
   }
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
@@ -586,7 +531,7 @@ int ladder_conv3x3_split(const float* x, const float* x_absmax, const void* pack
   const int tiles_n = (Cout + SP_BN - 1) / SP_BN;
   const int tiles_m = N * (H / SP_H) * (W / SP_W);
   const dim3 grid(tiles_m * tiles_n), block(SP_THREADS);
-  const float* wamax = reinterpret_cast<const float*>(static_cast<const unsigned char*>(packed) + pack_payload_bytes(Cin, Cout, prec));
+  const float* wamax = reinterpret_cast<const float*>(static_cast<const unsigned char*>(packed) + pack_payload_bytes(9, Cin, Cout, prec));
 #define LADDER_SPLIT_LAUNCH(P_) \
   hipLaunchKernelGGL(conv3x3_halo_split_kernel<P_>, grid, block, 0, stream, x, (const uint4*)packed, bias, y, N, H, W, Cin, Cout, act, tiles_n, x_absmax, wamax)
   if (prec == LADDER_PREC_F16X3) LADDER_SPLIT_LAUNCH(LADDER_PREC_F16X3);

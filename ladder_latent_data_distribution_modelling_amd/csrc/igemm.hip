@@ -19,7 +19,7 @@
 // the current chunk, registers -> LDS after it, one barrier per chunk); NHWC keeps ci contiguous, so every global load is a
 // 16-byte access; padding lanes read a 16-byte zero buffer so loads stay unconditional.
 #include <cstdlib>
-#include "common.h"
+#include "split16.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -318,6 +318,186 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? IGEMM_FWD_MINW :
           float v = ladder_act_fn(acc[mi][ni][e] + bv, d.act);
           // optional gate: multiply by act'(gate) evaluated from the producer layer's activation OUTPUT at the same element
           // (fuses the previous layer's activation backward into this backward-data pass)
+          if (gate != nullptr) v *= ladder_act_grad_from_out(gate[row * d.Cout + n], gate_act);
+          y[row * d.Cout + n] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The gather kernel on split operands (precision formats of split16.h / convsplit.hip): 128x128 tile, 4 wavefronts of 64x64, 32-channel
+// K chunks = two 32x32x16 MFMA K-steps.  A is gathered as fp32 exactly like igemm_fwd_kernel's fast path (tap table + validity mask)
+// and split into 16-bit planes while it is written to LDS ([plane][k-step][channel octet][row][8 x 16 bit]: a fragment = 32 consecutive
+// 16-byte slots); B comes pre-split from ladder_filter_pack_split, whose blocks already have that layout, by plain 16-byte copies.
+constexpr int GS_BM = 128, GS_BN = 128, GS_BK = 32;
+constexpr int GS_PLANE = 2 * 2 * 128 * 16;      // bytes per plane of either operand tile (8192)
+
+template <int PREC>
+__global__ __launch_bounds__(kThreads, 2) void igemm_fwd_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
+                                                                     const float* __restrict__ bias, float* __restrict__ y,
+                                                                     const IgemmDesc d, const int tiles_n, float* __restrict__ part,
+                                                                     const int chunks_per_split, const float* __restrict__ gate,
+                                                                     const int gate_act, const float* __restrict__ xamax,
+                                                                     const float* __restrict__ wamax) {
+  constexpr int NS = Fmt<PREC>::NS;
+  constexpr bool F16 = Fmt<PREC>::F16;
+  constexpr int OPB = NS * GS_PLANE;                       // bytes of one operand tile
+  constexpr int AU = GS_BM * (GS_BK / 4) / kThreads;       // 4 float4 gathers per thread
+  constexpr int B_CHUNKS = 2 * NS * 256;                   // 16-byte chunks of the B tile (two packed blocks)
+  constexpr int BU = B_CHUNKS / kThreads;                  // 4 (NS=2) / 6 (NS=3)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * OPB];   // [buffer][A | B]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / tiles_n) * GS_BM, cot = tile % tiles_n, n0 = cot * GS_BN;
+  const int HoWo = d.Ho * d.Wo;
+  const int nslabs16 = d.Cin / 16;
+  float cx = 1.f, unscale = 1.f;
+  if (F16) {
+    cx = scale_from_absmax(*xamax);
+    unscale = 1.f / (cx * scale_from_absmax(*wamax));
+  }
+
+  const float* a_ptr[AU];
+  uint32_t a_mask[AU];
+  int a_dst[AU];
+#pragma unroll
+  for (int i = 0; i < AU; ++i) {
+    const int u = tid + i * kThreads;
+    const int row = u >> 3, kq = u & 7;
+    const int m = m0 + row;
+    const bool ok = m < d.M;
+    const uint32_t mm = ok ? m : 0;
+    const uint32_t n_img = fdiv(mm, d.div_howo), rem = mm - n_img * HoWo;
+    const uint32_t ho = fdiv(rem, d.div_wo), wo = rem - ho * d.Wo;
+    const int bh = (int)ho * d.stride - d.pad_t, bw = (int)wo * d.stride - d.pad_l;
+    a_ptr[i] = x + (long)n_img * d.H * d.W * d.Cin + ((long)bh * d.W + bw) * d.Cin + kq * 4;
+    uint32_t msk = 0;
+    if (ok)
+      for (int t = 0; t < d.ntaps; ++t) {
+        const int nh = bh + d.tap_dh[t], nw = bw + d.tap_dw[t];
+        if (nh >= 0 && nh < d.H && nw >= 0 && nw < d.W) msk |= 1u << t;
+      }
+    a_mask[i] = msk;
+    a_dst[i] = (((kq >> 2) * 2 + ((kq >> 1) & 1)) * 128 + row) * 16 + (kq & 1) * 8;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  float4 ra[AU];
+  uint4 rb0, rb1, rb2, rb3, rb4, rb5;                      // (named: hipcc demotes a uint4 array captured by two lambdas to LDS)
+  static_assert(BU == 4 || BU == 6, "B staging rounds");
+  auto load_chunk = [&](int c) {
+    const int t = c % d.ntaps, ci0 = (c / d.ntaps) * GS_BK;
+    const long coff = ((long)d.tap_dh[t] * d.W + d.tap_dw[t]) * d.Cin + ci0;
+#pragma unroll
+    for (int i = 0; i < AU; ++i) ra[i] = ld4(((a_mask[i] >> t) & 1u) ? a_ptr[i] + coff : g_zero16);
+    const uint4* bs = wp + (((size_t)d.tap_w[t] * nslabs16 + ci0 / 16) * tiles_n + cot) * (NS * 256);
+    // unit i = (k-step i / NS, plane i % NS), 256 threads x 16 B each
+#define GS_BSRC(i_) bs[(size_t)((i_) / NS) * tiles_n * (NS * 256) + ((i_) % NS) * 256 + tid]
+    rb0 = GS_BSRC(0); rb1 = GS_BSRC(1); rb2 = GS_BSRC(2); rb3 = GS_BSRC(3);
+    if (BU > 4) { rb4 = GS_BSRC(4); rb5 = GS_BSRC(5); }
+#undef GS_BSRC
+  };
+  auto store_chunk = [&](int buf) {
+    unsigned char* Ab = lds + buf * 2 * OPB;
+#pragma unroll
+    for (int i = 0; i < AU; ++i) {
+      float4 v = ra[i];
+      if (F16) v = make_float4(v.x * cx, v.y * cx, v.z * cx, v.w * cx);
+      uint2 pl[NS];
+      split4<NS, F16>(v, pl);
+#pragma unroll
+      for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(Ab + p * GS_PLANE + a_dst[i]) = pl[p];
+    }
+#define GS_BDST(i_) *reinterpret_cast<uint4*>(Ab + OPB + ((i_) % NS) * GS_PLANE + (((i_) / NS) * 256 + tid) * 16)
+    GS_BDST(0) = rb0; GS_BDST(1) = rb1; GS_BDST(2) = rb2; GS_BDST(3) = rb3;
+    if (BU > 4) { GS_BDST(4) = rb4; GS_BDST(5) = rb5; }
+#undef GS_BDST
+  };
+  auto mma_chunk = [&](int buf) {
+    const unsigned char* Ab = lds + buf * 2 * OPB + (lh * 128 + wm * 64 + l31) * 16;
+    const unsigned char* Bb = lds + buf * 2 * OPB + OPB + (lh * 128 + wn * 64 + l31) * 16;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 a[2][NS], b[2][NS];
+#pragma unroll
+      for (int p = 0; p < NS; ++p) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) a[mi][p] = *reinterpret_cast<const uint4*>(Ab + p * GS_PLANE + ks * 4096 + mi * 512);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) b[ni][p] = *reinterpret_cast<const uint4*>(Bb + p * GS_PLANE + ks * 4096 + ni * 512);
+      }
+#pragma unroll
+      for (int sum = NS - 1; sum >= 0; --sum)
+#pragma unroll
+        for (int pa = 0; pa <= sum; ++pa) {
+          const int pb = sum - pa;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma16<F16>(a[mi][pa], b[ni][pb], acc[mi][ni]);
+        }
+    }
+  };
+
+  const int c_begin = blockIdx.y * chunks_per_split;
+  const int nchunks = min(d.ntaps * (d.Cin / GS_BK), c_begin + chunks_per_split);
+  load_chunk(c_begin);
+  store_chunk(0);
+  __syncthreads();
+  for (int c = c_begin; c < nchunks; ++c) {
+    const int buf = (c - c_begin) & 1;
+    if (c + 1 < nchunks) load_chunk(c + 1);
+    mma_chunk(buf);
+    if (c + 1 < nchunks) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (part != nullptr) {   // split-K partial: un-scaled accumulators, bias/activation applied by splitk_epilogue_kernel
+    float* o = part + (size_t)blockIdx.y * d.M * d.Cout;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = n0 + wn * 64 + ni * 32 + l31;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (m < d.M && n < d.Cout) o[(long)m * d.Cout + n] = acc[mi][ni][e] * unscale;
+        }
+    }
+    return;
+  }
+  const bool dense_out = d.out_sh == 1 && d.out_sw == 1 && d.OH == d.Ho && d.OW == d.Wo;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int n = n0 + wn * 64 + ni * 32 + l31;
+    const float bv = (bias != nullptr && n < d.Cout) ? bias[n] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (m < d.M && n < d.Cout) {
+          long row = m;
+          if (!dense_out) {
+            const uint32_t n_img = fdiv((uint32_t)m, d.div_howo), rem = (uint32_t)m - n_img * HoWo;
+            const uint32_t ho = fdiv(rem, d.div_wo), wo = rem - ho * d.Wo;
+            row = ((long)n_img * d.OH + d.out_h0 + (long)ho * d.out_sh) * d.OW + d.out_w0 + (long)wo * d.out_sw;
+          }
+          float v = ladder_act_fn(acc[mi][ni][e] * unscale + bv, d.act);
           if (gate != nullptr) v *= ladder_act_grad_from_out(gate[row * d.Cout + n], gate_act);
           y[row * d.Cout + n] = v;
         }
@@ -794,6 +974,57 @@ int select_fwd_tile(long M, int Cout) {
   }
   if (Cout > 32) return ((M + 127) / 128 >= 192) ? 128064 : 64064;
   return 128032;
+}
+
+
+bool split_gather_ok(const IgemmDesc& d) {
+  return d.ntaps > 0 && d.ntaps <= 28 && d.ups == 1 && (d.Cin % GS_BK) == 0 && d.M > 0 && select_fwd_tile(d.M, d.Cout) == 128128;
+}
+
+// the split-K plan of the fp32 kernel (16-deep chunks) re-expressed in this kernel's 32-deep chunks
+SplitPlan plan_splitk32(const IgemmDesc& d, bool dense_out) {
+  const int nchunks = d.ntaps * (d.Cin / GS_BK);
+  if (!dense_out) return SplitPlan{1, nchunks};
+  const SplitPlan p16 = plan_splitk(d.M, d.ntaps * d.Cin, d.Cout, GS_BM, GS_BN);
+  if (p16.splits <= 1) return SplitPlan{1, nchunks};
+  SplitPlan p;
+  p.cps = (p16.cps + 1) / 2;
+  p.splits = (nchunks + p.cps - 1) / p.cps;
+  return p;
+}
+
+size_t fwd_split_ws_bytes(const IgemmDesc& d) {
+  const SplitPlan sp = plan_splitk32(d, true);
+  return sp.splits > 1 ? (size_t)sp.splits * d.M * d.Cout * sizeof(float) : 0;
+}
+
+int launch_fwd_split(const float* x, const float* xamax, const void* packed, const float* bias, float* y, const IgemmDesc& d, int prec,
+                     void* ws, size_t ws_bytes, hipStream_t st, const float* gate, int gate_act) {
+  if (!split_gather_ok(d) || !prec_ok(prec)) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(x) || !ladder_aligned16(packed) || !ladder_aligned16(y)) return LADDER_E_ALIGN;
+  if (prec == LADDER_PREC_F16X3 && xamax == nullptr) return LADDER_E_SHAPE;
+  const int tiles_m = (d.M + GS_BM - 1) / GS_BM, tiles_n = (d.Cout + GS_BN - 1) / GS_BN;
+  const bool dense_out = d.out_sh == 1 && d.out_sw == 1 && d.OH == d.Ho && d.OW == d.Wo;
+  SplitPlan sp = plan_splitk32(d, dense_out);
+  const size_t need = (size_t)sp.splits * d.M * d.Cout * sizeof(float);
+  if (sp.splits > 1 && (ws == nullptr || ws_bytes < need)) sp = SplitPlan{1, d.ntaps * (d.Cin / GS_BK)};
+  float* part = sp.splits > 1 ? (float*)ws : nullptr;
+  const float* wamax = reinterpret_cast<const float*>(static_cast<const unsigned char*>(packed) + pack_payload_bytes(d.KH * d.KW, d.Cin, d.Cout, prec));
+  const dim3 grid(tiles_m * tiles_n, sp.splits), block(kThreads);
+#define LADDER_GS_LAUNCH(P_) \
+  hipLaunchKernelGGL(igemm_fwd_split_kernel<P_>, grid, block, 0, st, x, (const uint4*)packed, bias, y, d, tiles_n, part, sp.cps, \
+                     part ? nullptr : gate, gate_act, xamax, wamax)
+  if (prec == LADDER_PREC_F16X3) LADDER_GS_LAUNCH(LADDER_PREC_F16X3);
+  else if (prec == LADDER_PREC_BF16X6) LADDER_GS_LAUNCH(LADDER_PREC_BF16X6);
+  else LADDER_GS_LAUNCH(LADDER_PREC_BF16X3);
+#undef LADDER_GS_LAUNCH
+  if (part != nullptr) {
+    const size_t mn = (size_t)d.M * d.Cout;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, (const float*)part, bias, y,
+                       sp.splits, mn, d.Cout, d.act, gate, gate_act);
+  }
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
 }
 
 // ---- direct convolution from a 3-channel tensor: backward-data of the CelebA output conv (1x1, 3 -> 128 channels) ----------------
@@ -1461,6 +1692,114 @@ int ladder_conv2d_bwd_data(const float* dy, const float* wT, float* dx, int N, i
     return LADDER_OK;
   }
   return dispatch_fwd(dy, wT, nullptr, dx, d, ws, ws_bytes, stream, gate_y, gate_act);   // generic strided gather (ups > 1)
+}
+
+// ---- split-precision variants of the forward-type convolution calls (gather kernel; the 3x3 halo layers have their own entry points
+// in convsplit.hip).  `dry` = only report whether every launch of the call would run on the split kernel.
+static int conv2d_fwd_split_impl(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, int N, int H,
+                                 int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int act,
+                                 int prec, void* ws, size_t ws_bytes, ladder_stream_t stream, bool dry, size_t* ws_need) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return LADDER_E_SHAPE;
+  IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, 1, pad_t, pad_l, N * Ho * Wo, KH * KW * Cin, act, make_fastdiv(Ho * Wo), make_fastdiv(Wo)};
+  set_conv_taps(d);
+  if (!split_gather_ok(d) || halo_eligible(d)) return LADDER_E_SHAPE;
+  if (ws_need != nullptr) *ws_need = fwd_split_ws_bytes(d);
+  if (dry) return LADDER_OK;
+  return launch_fwd_split(x, x_absmax, packed, bias, y, d, prec, ws, ws_bytes, stream, nullptr, 0);
+}
+
+static int conv2d_bwd_data_split_impl(const float* dy, const float* dy_absmax, const void* packed, float* dx, int N, int H, int W, int Cin,
+                                      int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, const float* gate_y,
+                                      int gate_act, int prec, void* ws, size_t ws_bytes, ladder_stream_t stream, bool dry, size_t* ws_need) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return LADDER_E_SHAPE;
+  IgemmDesc d{N, Ho, Wo, Cout, H, W, Cin, KH, KW, 1, stride, KH - 1 - pad_t, KW - 1 - pad_l, N * H * W, KH * KW * Cout, LADDER_ACT_NONE, make_fastdiv(H * W), make_fastdiv(W)};
+  set_conv_taps(d);
+  if (ws_need != nullptr) *ws_need = 0;
+  if (stride == 1) {
+    if (!split_gather_ok(d) || (gate_y == nullptr && halo_eligible(d))) return LADDER_E_SHAPE;
+    if (ws_need != nullptr) *ws_need = fwd_split_ws_bytes(d);
+    if (dry) return LADDER_OK;
+    return launch_fwd_split(dy, dy_absmax, packed, nullptr, dx, d, prec, ws, ws_bytes, stream, gate_y, gate_act);
+  }
+  if (stride != 2 || KH * KW > 28) return LADDER_E_SHAPE;
+  const int padh = KH - 1 - pad_t, padw = KW - 1 - pad_l;
+  for (int pass = 0; pass < 2; ++pass) {                 // pass 0: every parity class must be eligible; pass 1: launch
+    for (int ch = 0; ch < 2; ++ch)
+      for (int cw = 0; cw < 2; ++cw) {
+        const int Hc = (H - ch + 1) / 2, Wc = (W - cw + 1) / 2;
+        if (Hc <= 0 || Wc <= 0) return LADDER_E_SHAPE;
+        IgemmDesc c = d;
+        c.Ho = Hc; c.Wo = Wc; c.stride = 1; c.ups = 1; c.pad_t = 0; c.pad_l = 0;
+        c.M = N * Hc * Wc;
+        c.div_howo = make_fastdiv(Hc * Wc);
+        c.div_wo = make_fastdiv(Wc);
+        c.out_sh = c.out_sw = 2; c.out_h0 = ch; c.out_w0 = cw; c.OH = H; c.OW = W;
+        c.ntaps = 0;
+        for (int r = 0; r < KH; ++r) {
+          if (((r + padh + ch) & 1) != 0) continue;
+          for (int sx = 0; sx < KW; ++sx) {
+            if (((sx + padw + cw) & 1) != 0) continue;
+            c.tap_dh[c.ntaps] = (signed char)((ch + r - padh) / 2);
+            c.tap_dw[c.ntaps] = (signed char)((cw + sx - padw) / 2);
+            c.tap_w[c.ntaps] = (signed char)(r * KW + sx);
+            ++c.ntaps;
+          }
+        }
+        c.K = c.ntaps * Cout;
+        if (pass == 0) {
+          if (c.ntaps == 0 || !split_gather_ok(c)) return LADDER_E_SHAPE;
+        } else {
+          const int rc = launch_fwd_split(dy, dy_absmax, packed, nullptr, dx, c, prec, nullptr, 0, stream, gate_y, gate_act);
+          if (rc != LADDER_OK) return rc;
+        }
+      }
+    if (dry) return LADDER_OK;
+  }
+  return LADDER_OK;
+}
+
+int ladder_conv2d_fwd_split_eligible(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t,
+                                     int pad_l) {
+  return conv2d_fwd_split_impl(nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_t, pad_l, 0,
+                               LADDER_PREC_F16X3, nullptr, 0, nullptr, true, nullptr) == LADDER_OK ? 1 : 0;
+}
+
+size_t ladder_conv2d_fwd_split_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                                               int pad_t, int pad_l) {
+  size_t need = 0;
+  conv2d_fwd_split_impl(nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_t, pad_l, 0,
+                        LADDER_PREC_F16X3, nullptr, 0, nullptr, true, &need);
+  return need;
+}
+
+int ladder_conv2d_fwd_split(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, int N, int H, int W,
+                            int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int act, int prec,
+                            void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  return conv2d_fwd_split_impl(x, x_absmax, packed, bias, y, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_t, pad_l, act, prec, ws,
+                               ws_bytes, stream, false, nullptr);
+}
+
+int ladder_conv2d_bwd_data_split_eligible(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t,
+                                          int pad_l, int gated) {
+  static const float dummy = 0.f;
+  return conv2d_bwd_data_split_impl(nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_t, pad_l,
+                                    gated ? &dummy : nullptr, 0, LADDER_PREC_F16X3, nullptr, 0, nullptr, true, nullptr) == LADDER_OK ? 1 : 0;
+}
+
+size_t ladder_conv2d_bwd_data_split_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                                                    int pad_t, int pad_l) {
+  size_t need = 0;
+  static const float dummy = 0.f;
+  conv2d_bwd_data_split_impl(nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_t, pad_l, &dummy, 0,
+                             LADDER_PREC_F16X3, nullptr, 0, nullptr, true, &need);
+  return need;
+}
+
+int ladder_conv2d_bwd_data_split(const float* dy, const float* dy_absmax, const void* packed_T, float* dx, int N, int H, int W, int Cin,
+                                 int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, const float* gate_y,
+                                 int gate_act, int prec, void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  return conv2d_bwd_data_split_impl(dy, dy_absmax, packed_T, dx, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_t, pad_l, gate_y, gate_act,
+                                    prec, ws, ws_bytes, stream, false, nullptr);
 }
 
 size_t ladder_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW) {

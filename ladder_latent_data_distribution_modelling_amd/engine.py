@@ -29,6 +29,8 @@ class KernelProfiler:
              256122: "conv3x3_halo_split_kernel<bf16x3> (8x32 px x 128 ch LDS-halo tile, 8 waves, fp32 operands as 2 bf16 planes, 3 x MFMA 32x32x16 bf16)",
              256124: "conv3x3_halo_split_kernel<f16x3> (8x32 px x 128 ch LDS-halo tile, 8 waves, fp32 operands as 2 scaled fp16 planes, 3 x MFMA 32x32x16 f16)",
              128128: "igemm_fwd_kernel<128,128,2,2,true,true> (gather implicit GEMM, fp32 MFMA 32x32x2)",
+             128124: "igemm_fwd_split_kernel<f16x3> (gather implicit GEMM, 128x128 tile, 3 x MFMA 32x32x16 f16)",
+             128122: "igemm_fwd_split_kernel<bf16x3>", 128123: "igemm_fwd_split_kernel<bf16x6>",
              9003: "conv_smallcin_kernel (direct 1x1 from 3 channels, HBM-bound)",
              9124: "wgrad3x3_split_kernel<f16x3> (64ci x 128co slab x 9 taps, 12 waves, transposing LDS reads, 3 x MFMA 32x32x16 f16; incl. its split reduction)",
              9122: "wgrad3x3_split_kernel<bf16x3>", 9123: "wgrad3x3_split_kernel<bf16x6>",
@@ -299,11 +301,12 @@ class Conv2D:
         cin, cout = (self.cout, self.cin) if transpose_flip else (self.cin, self.cout)
         ent = self._packed.get((transpose_flip, ns))
         if ent is None:
-            nb = L.query("ladder_conv3x3_pack_bytes", cin, cout, ns)
+            nb = L.query("ladder_filter_pack_split_bytes", self.k * self.k, cin, cout, ns)
             ent = self._packed[(transpose_flip, ns)] = [-1, torch.empty(nb, dtype=torch.uint8, device=self.ctx.device)]
         ver = ps.version["ae"]
         if ent[0] != ver or torch.cuda.is_current_stream_capturing():
-            L.call("ladder_conv3x3_pack", _p(ps.w[self.name + "/kernel"]), _p(ent[1]), cin, cout, transpose_flip, ns, self.ctx.stream)
+            L.call("ladder_filter_pack_split", _p(ps.w[self.name + "/kernel"]), _p(ent[1]), self.k * self.k, cin, cout, transpose_flip, ns,
+                   self.ctx.stream)
             ent[0] = ver
         return ent[1]
 
@@ -318,6 +321,19 @@ class Conv2D:
             args = (_p(x), _p(self.x_amax), _p(self._packed_filter(0)), _p(self.ps.w[self.name + "/bias"]), _p(y), N, H, W, self.cin,
                     self.cout, L.ACT[self.act], self.ctx.ns, self.ctx.stream)
             _timed(256120 + self.ctx.ns, 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_split", args)
+            self.x, self.y = x, y
+            return y
+        geo = (N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl)
+        if self.ctx.ns and L.query("ladder_conv2d_fwd_split_eligible", *geo):
+            self.x_amax = self.ctx.absmax(x)
+            nb = L.query("ladder_conv2d_fwd_split_workspace_bytes", *geo)
+            wsp, wsn = self.ctx.ws(nb)
+            args = (_p(x), _p(self.x_amax), _p(self._packed_filter(0)), _p(self.ps.w[self.name + "/bias"]), _p(y)) + geo + (
+                L.ACT[self.act], self.ctx.ns, wsp, wsn, self.ctx.stream)
+            if nb:                                       # split-K launch: two kernels, not attributed by the profiler
+                L.call("ladder_conv2d_fwd_split", *args)
+            else:
+                _timed(128120 + self.ctx.ns, 2.0 * N * Ho * Wo * self.k * self.k * self.cin * self.cout, "ladder_conv2d_fwd_split", args)
             self.x, self.y = x, y
             return y
         _igemm(self.ctx, "ladder_conv2d_fwd", N * Ho * Wo, self.cin, self.cout, self.k * self.k * self.cin,
@@ -380,6 +396,15 @@ class Conv2D:
             args = (_p(dy), _p(dy_amax), _p(self._packed_filter(1)), None, _p(dx), N, H, W, self.cout, self.cin, 0,
                     self.ctx.ns, st)
             _timed(256120 + self.ctx.ns, 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_split", args)
+        elif need_dx and self.ctx.ns and L.query("ladder_conv2d_bwd_data_split_eligible", N, H, W, self.cin, Ho, Wo, self.cout, self.k,
+                                                 self.k, self.stride, self.pt, self.pl, 1 if gate_prev else 0):
+            geo = (N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl)
+            if dy_amax is None:
+                dy_amax = self.ctx.absmax(dy)
+            wsp, wsn = self.ctx.ws(L.query("ladder_conv2d_bwd_data_split_workspace_bytes", *geo))
+            dx = self.ctx.empty(N, H, W, self.cin)
+            L.call("ladder_conv2d_bwd_data_split", _p(dy), _p(dy_amax), _p(self._packed_filter(1)), _p(dx), *geo,
+                   _p(x) if gate_prev else None, L.ACT[gate_prev] if gate_prev else 0, self.ctx.ns, wsp, wsn, st)
         elif need_dx:
             w = self.ps.w[self.name + "/kernel"]
             wT = self.ctx.empty(w.numel())
