@@ -145,6 +145,15 @@ int ladder_conv3x3_wgrad_split_eligible(int N, int H, int W, int Cin, int Cout);
 size_t ladder_conv3x3_wgrad_split_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int ladder_conv3x3_wgrad_split(const float* x, const float* x_absmax, const float* dy, const float* dy_absmax, float* dw, float* db,
                                int N, int H, int W, int Cin, int Cout, int prec, void* ws, size_t ws_bytes, ladder_stream_t stream);
+/* Every other large filter gradient on split operands (Cin % 128 == 0, Cout > 64, >= 4096 output pixels; transposing LDS reads as
+ * above; 128 x 128 tiles of dW, pixel range split over the grid, fixed-order second stage).  Same semantics as
+ * ladder_conv2d_bwd_filter for the strided encoder layers and the 8x8 / 16x16 decoder maps. */
+int ladder_conv2d_bwd_filter_split_eligible(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t,
+                                            int pad_l);
+size_t ladder_conv2d_bwd_filter_split_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW);
+int ladder_conv2d_bwd_filter_split(const float* x, const float* x_absmax, const float* dy, const float* dy_absmax, float* dw, float* db,
+                                   int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l,
+                                   int prec, void* ws, size_t ws_bytes, ladder_stream_t stream);
 /* out[i] = sum_s ws[s*n + i] in the fixed order s = 0..splits-1 (second stage of every split reduction). */
 int ladder_reduce_splits(const float* ws, float* out, int splits, size_t n, ladder_stream_t stream);
 

@@ -112,6 +112,9 @@ PROTOTYPES = {
     "ladder_conv3x3_wgrad_split_workspace_bytes": (_z, [_i] * 5),
     "ladder_conv3x3_wgrad_split": (_i, [_p, _p, _p, _p, _p, _p] + [_i] * 6 + [_p, _z, _p]),
     "ladder_reduce_splits": (_i, [_p, _p, _i, _z, _p]),
+    "ladder_conv2d_bwd_filter_split_eligible": (_i, [_i] * 12),
+    "ladder_conv2d_bwd_filter_split_workspace_bytes": (_z, [_i] * 9),
+    "ladder_conv2d_bwd_filter_split": (_i, [_p, _p, _p, _p, _p, _p] + [_i] * 13 + [_p, _z, _p]),
 }
 
 _lib = None

@@ -680,6 +680,180 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? IGEMM_WG_MINW : 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Filter / weight gradient on split operands: dW[k' x n] = sum_pixels A[pixel][k'] * dY[pixel][n], k' = (tap, ci).  The reduction index
+// is the pixel while both operands are channel-contiguous in memory, so the LDS images stay [32-channel block][pixel][32 ch x 16 bit]
+// (written by plain 8-byte stores of split float4s) and the MFMA fragments -- 8 consecutive pixels of one channel per lane -- are
+// fetched with the transposing LDS read (ds_read_b64_tr_b16; see wgrad3x3_split_kernel in convsplit.hip for the layout argument).
+// 128 x 128 tile (one filter tap x 128 input channels, Cin % 128 == 0), 4 wavefronts of 64x64, 32-pixel chunks, pixel range split
+// over gridDim.y with a fixed-order second stage.
+constexpr int GW_BLK = 32 * 64;                 // bytes of one 32-channel block of a 32-pixel chunk (2048)
+constexpr int GW_PLANE = 4 * GW_BLK;            // 128 channels (8192)
+typedef short gw_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 gw_tr_frag(const unsigned char* p) {
+  const gw_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gw_s16x4*)(p));
+  const gw_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gw_s16x4*)(p + 4 * 64));
+  const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+  return make_uint4(a.x, a.y, b.x, b.y);
+}
+template <bool F16>
+__device__ __forceinline__ float gw_frag_sum(const uint4 f) {
+  const uint32_t w[4] = {f.x, f.y, f.z, f.w};
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (F16) {
+      const f32x2 v = __builtin_convertvector(__builtin_bit_cast(f16x2, w[i]), f32x2);
+      s += v.x + v.y;
+    } else {
+      s += __builtin_bit_cast(float, w[i] << 16) + __builtin_bit_cast(float, w[i] & 0xffff0000u);
+    }
+  }
+  return s;
+}
+
+template <int PREC>
+__global__ __launch_bounds__(kThreads, 2) void igemm_wgrad_split_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                       float* __restrict__ out, float* __restrict__ bias_part,
+                                                                       const IgemmDesc d, const int tiles_n, const int m_per_split,
+                                                                       const float* __restrict__ xamax, const float* __restrict__ damax) {
+  constexpr int NS = Fmt<PREC>::NS;
+  constexpr bool F16 = Fmt<PREC>::F16;
+  constexpr int OPB = NS * GW_PLANE;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * OPB];     // [buffer][A | dY]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5, l15 = lane & 15;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tile = blockIdx.x;
+  const int k0t = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * 128;
+  const int HoWo = d.Ho * d.Wo;
+  const int p_begin = blockIdx.y * m_per_split;
+  const int p_end = min(d.M, p_begin + m_per_split);
+  const int tap = k0t / d.Cin, ci0 = k0t - tap * d.Cin;       // the tile lies inside one tap (Cin % 128 == 0)
+  const int tr = tap / d.KW, ts = tap - tr * d.KW;
+  float cx = 1.f, cd = 1.f;
+  if (F16) {
+    cx = scale_from_absmax(*xamax);
+    cd = scale_from_absmax(*damax);
+  }
+  const bool do_bias = (bias_part != nullptr) && (tile / tiles_n == 0) && wm == 0;
+  float bsum[2] = {0.f, 0.f};
+
+  // staging units: 32 pixels x 32 float4 per operand = 1024 units = 4 per thread; unit u -> pixel u >> 5, channel quad u & 31
+  const int s_pix = tid >> 5, s_q4 = tid & 31;                // + 8 pixels per round
+  const int s_dst = (s_q4 >> 3) * GW_BLK + s_pix * 64 + (s_q4 & 7) * 8;     // + round * 8 * 64
+  const bool n_ok = (n0 + s_q4 * 4) < d.Cout;
+  const int frag_lane = (8 * lh + (l15 >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (l15 & 3)) * 2;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  float4 ra0, ra1, ra2, ra3, rd0, rd1, rd2, rd3;
+  auto load_a = [&](int pc, int round) -> float4 {
+    const int p = pc + s_pix + round * 8;
+    const float* src = g_zero16;
+    if (p < p_end) {
+      const uint32_t n_img = fdiv((uint32_t)p, d.div_howo), rem = (uint32_t)p - n_img * HoWo;
+      const int ho = (int)fdiv(rem, d.div_wo), wo = (int)rem - ho * d.Wo;
+      const int hi = ho * d.stride - d.pad_t + tr, wi = wo * d.stride - d.pad_l + ts;
+      if (hi >= 0 && hi < d.H && wi >= 0 && wi < d.W) src = x + (((long)n_img * d.H + hi) * d.W + wi) * d.Cin + ci0 + s_q4 * 4;
+    }
+    return ld4(src);
+  };
+  auto load_d = [&](int pc, int round) -> float4 {
+    const int p = pc + s_pix + round * 8;
+    return ld4((p < p_end && n_ok) ? dy + (long)p * d.Cout + n0 + s_q4 * 4 : g_zero16);
+  };
+  auto store_op = [&](unsigned char* base, int round, float4 v, float c) {
+    if (F16) v = make_float4(v.x * c, v.y * c, v.z * c, v.w * c);
+    uint2 pl[NS];
+    split4<NS, F16>(v, pl);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(base + p * GW_PLANE + s_dst + round * 8 * 64) = pl[p];
+  };
+  auto load_chunk = [&](int c) {
+    const int pc = p_begin + c * 32;
+    ra0 = load_a(pc, 0); ra1 = load_a(pc, 1); ra2 = load_a(pc, 2); ra3 = load_a(pc, 3);
+    rd0 = load_d(pc, 0); rd1 = load_d(pc, 1); rd2 = load_d(pc, 2); rd3 = load_d(pc, 3);
+  };
+  auto store_chunk = [&](int buf) {
+    unsigned char* Ab = lds + buf * 2 * OPB;
+    store_op(Ab, 0, ra0, cx); store_op(Ab, 1, ra1, cx); store_op(Ab, 2, ra2, cx); store_op(Ab, 3, ra3, cx);
+    store_op(Ab + OPB, 0, rd0, cd); store_op(Ab + OPB, 1, rd1, cd); store_op(Ab + OPB, 2, rd2, cd); store_op(Ab + OPB, 3, rd3, cd);
+  };
+  auto mma_chunk = [&](int buf) {
+    const unsigned char* Ab = lds + buf * 2 * OPB + frag_lane + wm * 2 * GW_BLK;
+    const unsigned char* Bb = lds + buf * 2 * OPB + OPB + frag_lane + wn * 2 * GW_BLK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 a[2][NS], b[2][NS];
+#pragma unroll
+      for (int p = 0; p < NS; ++p) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) a[mi][p] = gw_tr_frag(Ab + p * GW_PLANE + mi * GW_BLK + ks * 16 * 64);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) b[ni][p] = gw_tr_frag(Bb + p * GW_PLANE + ni * GW_BLK + ks * 16 * 64);
+      }
+#pragma unroll
+      for (int sum = NS - 1; sum >= 0; --sum)
+#pragma unroll
+        for (int pa = 0; pa <= sum; ++pa) {
+          const int pb = sum - pa;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma16<F16>(a[mi][pa], b[ni][pb], acc[mi][ni]);
+        }
+      if (do_bias) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int p = NS - 1; p >= 0; --p) bsum[ni] += gw_frag_sum<F16>(b[ni][p]);
+      }
+    }
+  };
+
+  const int nchunks = (p_end - p_begin + 31) / 32;
+  if (nchunks > 0) {
+    load_chunk(0);
+    store_chunk(0);
+  }
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) load_chunk(c + 1);
+    mma_chunk(buf);
+    if (c + 1 < nchunks) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  const float unscale = F16 ? 1.f / (cx * cd) : 1.f;
+  float* o = out + (size_t)blockIdx.y * d.K * d.Cout;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int n = n0 + wn * 64 + ni * 32 + l31;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int k = k0t + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (k < d.K && n < d.Cout) o[(long)k * d.Cout + n] = acc[mi][ni][e] * unscale;
+      }
+    }
+    if (do_bias) {
+      const float v = (bsum[ni] + __shfl_down(bsum[ni], 32, 64)) * (F16 ? 1.f / cd : 1.f);
+      if (lh == 0 && n < d.Cout) bias_part[(size_t)blockIdx.y * d.Cout + n] = v;
+    }
+  }
+}
+
 __global__ void splitk_epilogue_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ y,
                                        int S, size_t MN, int N, int act, const float* __restrict__ gate, int gate_act) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1581,6 +1755,46 @@ int run_wgrad(const float* x, const float* dy, float* dw, float* db, const Igemm
   return LADDER_OK;
 }
 
+// ---- split filter gradient: planning shared by the workspace query and the launcher
+bool wgrad_split_ok(const IgemmDesc& d) {
+  if (d.ups != 1 || (d.Cin % 128) != 0 || d.Cout <= 64 || d.M < 4096) return false;
+  const WgradPlan p = plan_wgrad(d.M, d.K, d.Cout);
+  return p.bm == 128 && p.bn == 128;
+}
+WgradPlan plan_wgrad_split32(const IgemmDesc& d) {
+  WgradPlan p = plan_wgrad(d.M, d.K, d.Cout);
+  long mps = (p.m_per_split + 31) / 32 * 32;           // 32-pixel chunks
+  p.m_per_split = (int)mps;
+  p.splits = (int)((d.M + mps - 1) / mps);
+  return p;
+}
+size_t wgrad_split_ws_bytes(const IgemmDesc& d) {
+  const WgradPlan p = plan_wgrad_split32(d);
+  return ((size_t)p.splits * d.K * d.Cout + (size_t)p.splits * d.Cout) * sizeof(float);
+}
+int run_wgrad_split(const float* x, const float* xamax, const float* dy, const float* damax, float* dw, float* db, const IgemmDesc& d,
+                    int prec, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!wgrad_split_ok(d) || !prec_ok(prec)) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(x) || !ladder_aligned16(dy) || !ladder_aligned16(dw)) return LADDER_E_ALIGN;
+  if (prec == LADDER_PREC_F16X3 && (xamax == nullptr || damax == nullptr)) return LADDER_E_SHAPE;
+  if (ws == nullptr || ws_bytes < wgrad_split_ws_bytes(d)) return LADDER_E_WORKSPACE;
+  const WgradPlan p = plan_wgrad_split32(d);
+  const size_t kn = (size_t)d.K * d.Cout;
+  float* part = (float*)ws;
+  float* bias_part = db != nullptr ? part + (size_t)p.splits * kn : nullptr;
+  const dim3 grid(p.tiles_k * p.tiles_n, p.splits), block(kThreads);
+#define LADDER_GW_LAUNCH(P_) \
+  hipLaunchKernelGGL(igemm_wgrad_split_kernel<P_>, grid, block, 0, st, x, dy, part, bias_part, d, p.tiles_n, p.m_per_split, xamax, damax)
+  if (prec == LADDER_PREC_F16X3) LADDER_GW_LAUNCH(LADDER_PREC_F16X3);
+  else if (prec == LADDER_PREC_BF16X6) LADDER_GW_LAUNCH(LADDER_PREC_BF16X6);
+  else LADDER_GW_LAUNCH(LADDER_PREC_BF16X3);
+#undef LADDER_GW_LAUNCH
+  launch_reduce_splits((const float*)part, dw, p.splits, kn, st);
+  if (db != nullptr) launch_reduce_splits((const float*)bias_part, db, p.splits, (size_t)d.Cout, st);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1835,6 +2049,26 @@ int ladder_conv2d_bwd_filter(const float* x, const float* dy, float* dw, float* 
     return LADDER_OK;
   }
   return run_wgrad(x, dy, dw, db, d, ws, ws_bytes, stream);
+}
+
+int ladder_conv2d_bwd_filter_split_eligible(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t,
+                                            int pad_l) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return 0;
+  IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, 1, pad_t, pad_l, N * Ho * Wo, KH * KW * Cin, 0, make_fastdiv(Ho * Wo), make_fastdiv(Wo)};
+  return (wgrad_split_ok(d) && !plan_wgrad_halo(d).ok) ? 1 : 0;
+}
+
+size_t ladder_conv2d_bwd_filter_split_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW) {
+  IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, 1, 1, 0, 0, N * Ho * Wo, KH * KW * Cin, 0, make_fastdiv(Ho * Wo), make_fastdiv(Wo)};
+  return wgrad_split_ws_bytes(d);
+}
+
+int ladder_conv2d_bwd_filter_split(const float* x, const float* x_absmax, const float* dy, const float* dy_absmax, float* dw, float* db,
+                                   int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l,
+                                   int prec, void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return LADDER_E_SHAPE;
+  IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, 1, pad_t, pad_l, N * Ho * Wo, KH * KW * Cin, LADDER_ACT_NONE, make_fastdiv(Ho * Wo), make_fastdiv(Wo)};
+  return run_wgrad_split(x, x_absmax, dy, dy_absmax, dw, db, d, prec, ws, ws_bytes, stream);
 }
 
 int ladder_conv1x1_smallcout_eligible(long M, int Cin, int Cout) { return smallcout_eligible(Cin, Cout, 1, 1, 1, M) ? 1 : 0; }

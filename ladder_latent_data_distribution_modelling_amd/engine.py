@@ -376,6 +376,16 @@ class Conv2D:
             args = (_p(x), _p(self.x_amax), _p(dy), _p(dy_amax), _p(self.ps.g[self.name + "/kernel"]),
                     _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, N, H, W, self.cin, self.cout, self.ctx.ns, wsp, wsn, st)
             _timed(9120 + self.ctx.ns, 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_wgrad_split", args)
+        elif wgrad and self.ctx.ns and L.query("ladder_conv2d_bwd_filter_split_eligible", N, H, W, self.cin, Ho, Wo, self.cout, self.k,
+                                               self.k, self.stride, self.pt, self.pl):
+            if self.ctx.ns == 4:
+                if getattr(self, "x_amax", None) is None:
+                    self.x_amax = self.ctx.absmax(x)
+                dy_amax = self.ctx.absmax(dy)
+            wsp, wsn = self.ctx.ws(L.query("ladder_conv2d_bwd_filter_split_workspace_bytes", N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k))
+            L.call("ladder_conv2d_bwd_filter_split", _p(x), _p(self.x_amax), _p(dy), _p(dy_amax), _p(self.ps.g[self.name + "/kernel"]),
+                   _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k,
+                   self.stride, self.pt, self.pl, self.ctx.ns, wsp, wsn, st)
         elif wgrad:
             nb = L.query("ladder_conv2d_bwd_filter_workspace_bytes", N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k)
             wsp, wsn = self.ctx.ws(nb)
