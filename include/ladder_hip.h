@@ -141,7 +141,7 @@ int ladder_conv2d_bwd_data_split(const float* dy, const float* dy_absmax, const 
  * sum x (*) dy, db[co] = sum dy (db may be NULL).  The reduction index of the matrix instruction is the pixel: fragments are read
  * with the transposing LDS load (ds_read_b64_tr_b16) from channel-contiguous images.  Replaces ladder_conv2d_bwd_filter's call sites
  * for the decoder's 32x32 ... 128x128 maps. */
-int ladder_conv3x3_wgrad_split_eligible(int N, int H, int W, int Cin, int Cout);
+int ladder_conv3x3_wgrad_split_eligible(int N, int H, int W, int Cin, int Cout, int prec);
 size_t ladder_conv3x3_wgrad_split_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int ladder_conv3x3_wgrad_split(const float* x, const float* x_absmax, const float* dy, const float* dy_absmax, float* dw, float* db,
                                int N, int H, int W, int Cin, int Cout, int prec, void* ws, size_t ws_bytes, ladder_stream_t stream);

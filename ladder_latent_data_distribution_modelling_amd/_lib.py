@@ -108,7 +108,7 @@ PROTOTYPES = {
     "ladder_conv3x3_split_eligible": (_i, [_i] * 5),
     "ladder_conv3x3_split": (_i, [_p, _p, _p, _p, _p] + [_i] * 7 + [_p]),
     "ladder_absmax": (_i, [_p, _z, _p, _p]),
-    "ladder_conv3x3_wgrad_split_eligible": (_i, [_i] * 5),
+    "ladder_conv3x3_wgrad_split_eligible": (_i, [_i] * 6),
     "ladder_conv3x3_wgrad_split_workspace_bytes": (_z, [_i] * 5),
     "ladder_conv3x3_wgrad_split": (_i, [_p, _p, _p, _p, _p, _p] + [_i] * 6 + [_p, _z, _p]),
     "ladder_reduce_splits": (_i, [_p, _p, _i, _z, _p]),

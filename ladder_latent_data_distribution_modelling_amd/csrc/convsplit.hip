@@ -268,15 +268,17 @@ __global__ __launch_bounds__(SP_THREADS, 2) void conv3x3_halo_split_kernel(const
 //     touches are one contiguous 256-byte bank row -> conflict-free), written by plain 8-byte stores of split float4s;
 //   * a filter tap is a whole-pixel address offset into the halo image (no misaligned or shifted copies).
 // Work decomposition as wgrad3x3_halo_kernel (igemm.hip): one workgroup = 12 wavefronts owns a 64 ci x 128 co slab of dW for all 9
-// taps (72 MFMA tiles), wavefront -> (filter row r, ci half cb, co pair njp) with 6 tiles; it walks 1x32-pixel row patches
-// (K = 2 x 16 pixels), double-buffered in LDS; partial sums over the patch split are reduced in a fixed order by the caller.
-constexpr int WS_CI = 64, WS_CO = 128, WS_PW = 32, WS_HW = WS_PW + 2;
+// taps (72 MFMA tiles), wavefront -> (filter row r, ci half cb, co pair njp) with 6 tiles; it walks 2x32-pixel patches
+// (K = 4 x 16 pixels; 4x34 halo), double-buffered in LDS; partial sums over the patch split are reduced in a fixed order by the caller.
+constexpr int WS_CI = 64, WS_CO = 128, WS_PH = 2, WS_PW = 32, WS_HW = WS_PW + 2, WS_HH = WS_PH + 2;
 constexpr int WS_THREADS = 768;
-constexpr int WS_XPIX = 3 * WS_HW;                                  // 102 halo pixels
-constexpr int WS_XBLK = WS_XPIX * 64 + 64, WS_DBLK = WS_PW * 64 + 64;   // bytes per 32-channel block (+64: blocks land on different banks)
+constexpr int WS_XPIX = WS_HH * WS_HW, WS_DPIX = WS_PH * WS_PW;      // 136 halo pixels, 64 output pixels per patch
+constexpr int WS_XBLK = WS_XPIX * 64 + 64, WS_DBLK = WS_DPIX * 64 + 64;   // bytes per 32-channel block (+64: blocks land on different banks)
 constexpr int WS_XPLANE = 2 * WS_XBLK, WS_DPLANE = 4 * WS_DBLK;
-constexpr int WS_XU = WS_XPIX * (WS_CI / 4), WS_DU = WS_PW * (WS_CO / 4);                     // float4 units per patch: 1632, 1024
-static_assert(WS_XU + WS_DU <= 4 * WS_THREADS, "four staging rounds");
+constexpr int WS_XU = WS_XPIX * (WS_CI / 4), WS_DU = WS_DPIX * (WS_CO / 4);                     // float4 units per patch: 2176, 2048
+constexpr int WS_ROUNDS = (WS_XU + WS_DU + WS_THREADS - 1) / WS_THREADS;                        // 6 staging rounds
+constexpr int WS_KSTEPS = WS_DPIX / 16;                                                          // 4 MFMA K-steps per patch
+static_assert(WS_ROUNDS == 6 && WS_KSTEPS == 4, "staging schedule below is written for 2x32 patches");
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 lds_tr_frag(const unsigned char* p) {
@@ -319,8 +321,8 @@ __global__ __launch_bounds__(WS_THREADS, 3) void wgrad3x3_split_kernel(const flo
   const int lane = tid & 63, wv = tid >> 6;            // 12 wavefronts
   const int l31 = lane & 31, lh = lane >> 5, l15 = lane & 15;
   const int ci0 = (blockIdx.x / tiles_co) * WS_CI, co0 = (blockIdx.x % tiles_co) * WS_CO;
-  const int WP = W / WS_PW;
-  const int q_total = N * H * WP;
+  const int WP = W / WS_PW, HP = H / WS_PH;
+  const int q_total = N * HP * WP;
   const int q0 = blockIdx.y * patches_per_split, q1 = min(q_total, q0 + patches_per_split);
   const int r = wv >> 2, cb = (wv >> 1) & 1, njp = wv & 1;
   float cx = 1.f, cd = 1.f;
@@ -330,8 +332,8 @@ __global__ __launch_bounds__(WS_THREADS, 3) void wgrad3x3_split_kernel(const flo
   }
   // fragment addresses (bytes inside a buffer): pixel row of 64 B, this lane's 4-channel group inside its 16-lane block
   const int frag_lane = (8 * lh + (l15 >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (l15 & 3)) * 2;
-  const int a_off = cb * WS_XBLK + r * WS_HW * 64 + frag_lane;                        // + plane*WS_XPLANE + (16 ks + s) * 64
-  const int b_off = NS * WS_XPLANE + (njp * 2) * WS_DBLK + frag_lane;                 // + plane*WS_DPLANE + j*WS_DBLK + 16 ks * 64
+  const int a_off = cb * WS_XBLK + r * WS_HW * 64 + frag_lane;                        // + plane*WS_XPLANE + (halo pixel of the k-step + s) * 64
+  const int b_off = NS * WS_XPLANE + (njp * 2) * WS_DBLK + frag_lane;                 // + plane*WS_DPLANE + j*WS_DBLK + (pixel of the k-step) * 64
   // bias gradient = column sums of dy, read off the centre-row B fragments (every output channel is covered exactly once by the
   // r = 1, cb = 0 wavefronts): the two planes of a fragment add up to dy * cd to 2^-23 relative.
   const bool do_bias = (bias_part != nullptr) && (ci0 == 0) && r == 1 && cb == 0;
@@ -343,28 +345,39 @@ __global__ __launch_bounds__(WS_THREADS, 3) void wgrad3x3_split_kernel(const flo
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
   float bsum[2] = {0.f, 0.f};
 
-  // staging: the 1632 halo units and the 1024 dy units of a patch form ONE list of float4 units, 4 rounds of 768 threads; two rounds
-  // are in flight across each of the two MFMA blocks of a patch (8 staging registers)
+  // staging: the 2176 halo units and the 2048 dy units of a patch form ONE list of float4 units, 6 rounds of 768 threads; two rounds
+  // are in flight across each of the first three MFMA blocks of a patch (8 staging registers)
   float4 r0, r1;
-  auto patch_coords = [&](int q, int& n, int& h, int& w0) {
-    n = q / (H * WP);
-    const int rem = q - n * (H * WP);
-    h = rem / WP;
-    w0 = (rem - h * WP) * WS_PW;
+  // coordinates of the patch being staged (the next one), advanced incrementally: no divisions in the loop
+  int pn = q0 / (HP * WP), ph0, pw0;
+  {
+    const int rem = q0 - pn * (HP * WP), hp = rem / WP;
+    ph0 = hp * WS_PH;
+    pw0 = (rem - hp * WP) * WS_PW;
+  }
+  auto next_patch = [&]() {
+    pw0 += WS_PW;
+    if (pw0 >= W) {
+      pw0 = 0;
+      ph0 += WS_PH;
+      if (ph0 >= H) {
+        ph0 = 0;
+        ++pn;
+      }
+    }
   };
-  auto load_unit = [&](int q, int i) -> float4 {
+  auto load_unit = [&](int i) -> float4 {
     const int u = tid + i * WS_THREADS;
-    int n, h, w0;
-    patch_coords(q, n, h, w0);
+    const int n = pn, h0 = ph0, w0 = pw0;
     const float* src = gs_zero16;
     if (u < WS_XU) {
       const int pix = u >> 4, q4 = u & 15;
       const int hr = pix / WS_HW, hc = pix - hr * WS_HW;
-      const int hi = h - 1 + hr, wi = w0 - 1 + hc;
+      const int hi = h0 - 1 + hr, wi = w0 - 1 + hc;
       if (hi >= 0 && hi < H && wi >= 0 && wi < W) src = x + (((long)n * H + hi) * W + wi) * Cin + ci0 + q4 * 4;
     } else if (u < WS_XU + WS_DU) {
       const int v = u - WS_XU, p = v >> 5, q4 = v & 31;
-      if ((co0 + q4 * 4) < Cout) src = dy + (((long)n * H + h) * W + w0 + p) * Cout + co0 + q4 * 4;
+      if ((co0 + q4 * 4) < Cout) src = dy + (((long)n * H + h0 + (p >> 5)) * W + w0 + (p & 31)) * Cout + co0 + q4 * 4;
     }
     return *reinterpret_cast<const float4*>(src);
   };
@@ -383,14 +396,15 @@ __global__ __launch_bounds__(WS_THREADS, 3) void wgrad3x3_split_kernel(const flo
     for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(lds + buf * BUF + off + p * (isx ? WS_XPLANE : WS_DPLANE)) = pl[p];
   };
   auto mma_step = [&](int buf, int ks) {
-    const unsigned char* base = lds + buf * BUF + ks * 16 * 64;
+    const int prow = ks >> 1, pcol = (ks & 1) * 16;                                   // 16 pixels of patch row prow starting at pcol
+    const unsigned char* base = lds + buf * BUF;
     uint4 a[3][NS], b[2][NS];
 #pragma unroll
     for (int p = 0; p < NS; ++p) {
 #pragma unroll
-      for (int s = 0; s < 3; ++s) a[s][p] = lds_tr_frag(base + a_off + p * WS_XPLANE + s * 64);
+      for (int s = 0; s < 3; ++s) a[s][p] = lds_tr_frag(base + a_off + p * WS_XPLANE + (prow * WS_HW + pcol + s) * 64);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j][p] = lds_tr_frag(base + b_off + p * WS_DPLANE + j * WS_DBLK);
+      for (int j = 0; j < 2; ++j) b[j][p] = lds_tr_frag(base + b_off + p * WS_DPLANE + j * WS_DBLK + (prow * WS_PW + pcol) * 64);
     }
 #pragma unroll
     for (int sum = NS - 1; sum >= 0; --sum)
@@ -411,23 +425,23 @@ __global__ __launch_bounds__(WS_THREADS, 3) void wgrad3x3_split_kernel(const flo
   };
 
   if (q0 < q1) {
-    r0 = load_unit(q0, 0); r1 = load_unit(q0, 1);
-    store_unit(0, 0, r0); store_unit(0, 1, r1);
-    r0 = load_unit(q0, 2); r1 = load_unit(q0, 3);
-    store_unit(0, 2, r0); store_unit(0, 3, r1);
+#pragma unroll
+    for (int i = 0; i < WS_ROUNDS; i += 2) {
+      r0 = load_unit(i); r1 = load_unit(i + 1);
+      store_unit(0, i, r0); store_unit(0, i + 1, r1);
+    }
   }
   __syncthreads();
   for (int q = q0; q < q1; ++q) {
     const int buf = (q - q0) & 1;
     const bool more = q + 1 < q1;
-    if (more) { r0 = load_unit(q + 1, 0); r1 = load_unit(q + 1, 1); }
-    mma_step(buf, 0);
-    if (more) {
-      store_unit(buf ^ 1, 0, r0); store_unit(buf ^ 1, 1, r1);
-      r0 = load_unit(q + 1, 2); r1 = load_unit(q + 1, 3);
+    next_patch();
+#pragma unroll 1
+    for (int ks = 0; ks < WS_KSTEPS; ++ks) {
+      if (more && ks < 3) { r0 = load_unit(2 * ks); r1 = load_unit(2 * ks + 1); }
+      mma_step(buf, ks);
+      if (more && ks < 3) { store_unit(buf ^ 1, 2 * ks, r0); store_unit(buf ^ 1, 2 * ks + 1, r1); }
     }
-    mma_step(buf, 1);
-    if (more) { store_unit(buf ^ 1, 2, r0); store_unit(buf ^ 1, 3, r1); }
     __syncthreads();
   }
 
@@ -458,9 +472,9 @@ __global__ __launch_bounds__(WS_THREADS, 3) void wgrad3x3_split_kernel(const flo
 struct WgradSplitPlan { bool ok; int tiles_ci, tiles_co, splits, pps; };
 WgradSplitPlan plan_wgrad_split(int N, int H, int W, int Cin, int Cout) {
   WgradSplitPlan p{false, 0, 0, 1, 0};
-  if (!(N > 0 && (Cin % WS_CI) == 0 && (Cout % 4) == 0 && Cout >= 64 && (W % WS_PW) == 0)) return p;
-  const long q_total = (long)N * H * (W / WS_PW);
-  if (q_total < 4096) return p;                                // small maps stay on the generic kernel
+  if (!(N > 0 && (Cin % WS_CI) == 0 && (Cout % 4) == 0 && Cout >= 64 && (W % WS_PW) == 0 && (H % WS_PH) == 0)) return p;
+  const long q_total = (long)N * (H / WS_PH) * (W / WS_PW);
+  if (q_total * WS_PH < 4096) return p;                        // small maps stay on the generic kernel
   p.tiles_ci = Cin / WS_CI;
   p.tiles_co = (Cout + WS_CO - 1) / WS_CO;
   const long pairs = (long)p.tiles_ci * p.tiles_co;
@@ -542,7 +556,10 @@ int ladder_conv3x3_split(const float* x, const float* x_absmax, const void* pack
   return LADDER_OK;
 }
 
-int ladder_conv3x3_wgrad_split_eligible(int N, int H, int W, int Cin, int Cout) { return plan_wgrad_split(N, H, W, Cin, Cout).ok ? 1 : 0; }
+// (two-plane formats only: the double-buffered 2x32-pixel patch images of a three-plane format exceed the 160 KB of LDS)
+int ladder_conv3x3_wgrad_split_eligible(int N, int H, int W, int Cin, int Cout, int prec) {
+  return (prec_ok(prec) && prec_planes(prec) == 2 && plan_wgrad_split(N, H, W, Cin, Cout).ok) ? 1 : 0;
+}
 
 size_t ladder_conv3x3_wgrad_split_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
   const WgradSplitPlan p = plan_wgrad_split(N, H, W, Cin, Cout);
@@ -553,7 +570,7 @@ size_t ladder_conv3x3_wgrad_split_workspace_bytes(int N, int H, int W, int Cin, 
 int ladder_conv3x3_wgrad_split(const float* x, const float* x_absmax, const float* dy, const float* dy_absmax, float* dw, float* db,
                                int N, int H, int W, int Cin, int Cout, int prec, void* ws, size_t ws_bytes, ladder_stream_t stream) {
   const WgradSplitPlan p = plan_wgrad_split(N, H, W, Cin, Cout);
-  if (!p.ok || !prec_ok(prec)) return LADDER_E_SHAPE;
+  if (!p.ok || !prec_ok(prec) || prec_planes(prec) != 2) return LADDER_E_SHAPE;
   if (!ladder_aligned16(x) || !ladder_aligned16(dy) || !ladder_aligned16(dw)) return LADDER_E_ALIGN;
   if (prec == LADDER_PREC_F16X3 && (x_absmax == nullptr || dy_absmax == nullptr)) return LADDER_E_SHAPE;
   if (ws == nullptr || ws_bytes < ladder_conv3x3_wgrad_split_workspace_bytes(N, H, W, Cin, Cout)) return LADDER_E_WORKSPACE;
@@ -564,7 +581,6 @@ int ladder_conv3x3_wgrad_split(const float* x, const float* x_absmax, const floa
 #define LADDER_WS_LAUNCH(P_) \
   hipLaunchKernelGGL(wgrad3x3_split_kernel<P_>, grid, block, 0, stream, x, dy, part, bias_part, N, H, W, Cin, Cout, p.tiles_co, p.pps, x_absmax, dy_absmax)
   if (prec == LADDER_PREC_F16X3) LADDER_WS_LAUNCH(LADDER_PREC_F16X3);
-  else if (prec == LADDER_PREC_BF16X6) LADDER_WS_LAUNCH(LADDER_PREC_BF16X6);
   else LADDER_WS_LAUNCH(LADDER_PREC_BF16X3);
 #undef LADDER_WS_LAUNCH
   LADDER_CHECK_LAUNCH();

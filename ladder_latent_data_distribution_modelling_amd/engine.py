@@ -365,7 +365,7 @@ class Conv2D:
             return dx
         dy_amax = None
         split_w = bool(wgrad and self._split_ok(N, H, W, self.cin, self.cout)
-                       and L.query("ladder_conv3x3_wgrad_split_eligible", N, H, W, self.cin, self.cout))
+                       and L.query("ladder_conv3x3_wgrad_split_eligible", N, H, W, self.cin, self.cout, self.ctx.ns))
         if split_w and self.ctx.ns == 4 and getattr(self, "x_amax", None) is None:
             self.x_amax = self.ctx.absmax(x)
         split_d = bool(need_dx and not gate_prev and self._split_ok(N, Ho, Wo, self.cout, self.cin))
