@@ -114,7 +114,7 @@ int ladder_filter_pack_split(const float* w, void* packed, int ntaps, int Cin, i
                              ladder_stream_t stream);
 int ladder_conv3x3_split_eligible(int N, int H, int W, int Cin, int Cout);
 /* y = act(conv3x3_same(x, F) + bias) with F as packed above (bias may be NULL; x_absmax is read only for LADDER_PREC_F16X3 and may
- * be any upper bound of max |x|: a looser bound only raises the absolute representation floor 2^-39 * bound). */
+ * be any upper bound of max |x|: a looser bound only raises the absolute representation floor 2^-38 * bound). */
 int ladder_conv3x3_split(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, int N, int H, int W,
                          int Cin, int Cout, int act, int prec, ladder_stream_t stream);
 

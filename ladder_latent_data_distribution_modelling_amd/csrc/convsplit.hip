@@ -10,8 +10,8 @@
 //   LADDER_PREC_F16X3   2 fp16 planes (11 + 11 = 22 significand bits), a0b0 + a0b1 + a1b0; dropped a1b1 <= 2^-22 |ab|
 //                       -> fp32-class result from 3 MFMAs.  fp16 has a 5-bit exponent, so each operand TENSOR is scaled by a
 //                       power of two taken from its absolute maximum (|x| c < 2^14; ladder_absmax / the pack kernel): an element
-//                       is then represented to max(2^-23 |x|, 2^-39 max|x|), i.e. exactly like fp32 down to 2^-16 of the
-//                       tensor's largest magnitude and with an absolute floor of 2e-12 of it below; the result is un-scaled
+//                       is then represented to max(2^-23 |x|, 2^-38 max|x|), i.e. exactly like fp32 down to 2^-16 of the
+//                       tensor's largest magnitude and with an absolute floor of 4e-12 of it below; the result is un-scaled
 //                       in the epilogue.
 //   LADDER_PREC_BF16X6  3 bf16 planes (24 bits), a0b0 + a0b1 + a1b0 + a0b2 + a2b0 + a1b1; dropped terms <= 2^-23 |ab|
 //                       -> fp32-class result from 6 MFMAs, no scaling (bf16 has the fp32 exponent).

@@ -1,0 +1,245 @@
+"""Parity of the split-precision contraction kernels (csrc/convsplit.hip, the *_split kernels of csrc/igemm.hip) against the
+float64 CPU oracle, through the C ABI.
+
+Tolerances (relative to the output scale, as tests/test_gpu_kernels.py): the two fp32-class formats -- f16x3 (2 scaled fp16
+planes, 3 MFMAs) and bf16x6 (3 bf16 planes, 6 MFMAs) -- must meet the SAME bounds as the native fp32 kernels (2e-5 forward,
+3e-5 gradients); bf16x3 (16 significand bits) gets 4e-4.  The f16x3 cases include operands whose magnitudes straddle the fp16
+exponent range (per-tensor power-of-two scaling), heavy-tailed tensors and an all-zero operand.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ladder_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+PREC = {"f16x3": 4, "bf16x6": 3, "bf16x3": 2}
+TOL = {"f16x3": (2e-5, 3e-5), "bf16x6": (2e-5, 3e-5), "bf16x3": (4e-4, 4e-4)}
+
+
+def _lib():
+    from ladder_latent_data_distribution_modelling_amd import _lib as L
+    return L
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a, np.float32)).cuda()
+
+
+def p(t):
+    return None if t is None else t.data_ptr()
+
+
+def close(got, ref, rtol, what=""):
+    got = got.detach().cpu().numpy().astype(np.float64) if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    ref = ref.detach().numpy().astype(np.float64) if isinstance(ref, torch.Tensor) else np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(np.abs(ref).max(), 1e-300)
+    err = np.abs(got - ref).max() / scale
+    assert np.isfinite(got).all() and err < rtol, "%s: rel err %.3e (tol %.1e)" % (what, err, rtol)
+
+
+def absmax(L, t, st):
+    out = torch.empty(4, device="cuda")
+    L.call("ladder_absmax", p(t), t.numel(), p(out), st)
+    return out
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 1023, 4096 + 5, 1 << 22])
+def test_absmax_is_exact(gpu_ctx, n):
+    L = _lib()
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n).astype(np.float32)
+    x[rng.integers(n)] = -77.25 if n % 2 else 1e-30            # a negative maximum / a tiny tensor maximum
+    if n % 2 == 0:
+        x = (x * 1e-33).astype(np.float32)
+    xd = dev(x)
+    got = absmax(L, xd, gpu_ctx.stream)[0].item()
+    assert got == float(np.abs(x).max())
+    z = torch.zeros(n, device="cuda")
+    assert absmax(L, z, gpu_ctx.stream)[0].item() == 0.0
+
+
+def _fill(rng, shape, kind):
+    x = rng.standard_normal(shape).astype(np.float32)
+    if kind == "heavy":            # heavy tail: a handful of elements 4 decades above the bulk
+        idx = rng.integers(0, x.size, 16)
+        x.reshape(-1)[idx] *= 1e4
+    elif kind == "tiny":           # the whole tensor far below the fp16 range
+        x *= np.float32(3e-22)
+    elif kind == "huge":           # ... and far above it
+        x *= np.float32(7e17)
+    elif kind == "zero":
+        x[:] = 0
+    return x
+
+
+# halo (3x3 / stride 1 / SAME, >= 512 workgroups) cases: N, H, W, Cin, Cout, act, x-kind, dy-kind
+HALO_CASES = [
+    (16, 64, 64, 32, 256, "leaky_relu", "normal", "normal"),
+    (64, 32, 32, 16, 160, None, "heavy", "normal"),            # Cout tile edge (160 = 128 + 32), heavy-tailed input
+    (32, 64, 64, 64, 128, None, "tiny", "huge"),               # filter-gradient split kernel (>= 4096 row patches, Cin % 64 == 0)
+    (32, 64, 64, 128, 64, "leaky_relu", "normal", "heavy"),    # 2 ci slabs, Cout = 64
+    (32, 64, 64, 32, 128, None, "zero", "normal"),             # all-zero input: absmax 0 -> scale 1, output = bias
+]
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x6", "bf16x3"])
+@pytest.mark.parametrize("case", HALO_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_conv3x3_split_fwd_bwd(gpu_ctx, case, prec):
+    L = _lib()
+    N, H, W, Cin, Cout, act, xk, dk = case
+    P = PREC[prec]
+    tf, tb = TOL[prec]
+    rng = np.random.default_rng(abs(hash(case)) % 2**31)
+    x = _fill(rng, (N, H, W, Cin), xk)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = (rng.standard_normal(Cout) * np.abs(x).max() * 0.01).astype(np.float32) if xk != "zero" else rng.standard_normal(Cout).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    yr = O.act(O.conv2d_tf(xt, wt, bt, 1, "same"), act)
+    dy = _fill(rng, tuple(yr.shape), dk)
+    yr.backward(torch.tensor(dy, dtype=torch.float64))
+    st = gpu_ctx.stream
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    assert L.query("ladder_conv3x3_split_eligible", N, H, W, Cin, Cout) == 1
+    pk = torch.empty(L.query("ladder_filter_pack_split_bytes", 9, Cin, Cout, P), dtype=torch.uint8, device="cuda")
+    L.call("ladder_filter_pack_split", p(wd), p(pk), 9, Cin, Cout, 0, P, st)
+    xa = absmax(L, xd, st)
+    y = torch.empty(N, H, W, Cout, device="cuda")
+    L.call("ladder_conv3x3_split", p(xd), p(xa), p(pk), p(bd), p(y), N, H, W, Cin, Cout, L.ACT[act], P, st)
+    close(y, yr, tf, "fwd")
+    # a looser (x8) absmax bound only moves the representation floor
+    if prec == "f16x3":
+        y2 = torch.empty_like(y)
+        L.call("ladder_conv3x3_split", p(xd), p(xa * 8), p(pk), p(bd), p(y2), N, H, W, Cin, Cout, L.ACT[act], P, st)
+        close(y2, yr, tf, "fwd with a x8 absmax bound")
+    dyd = dev(dy)
+    if act is not None:
+        L.call("ladder_act_bwd", p(dyd), p(dev(yr.detach().numpy())), p(dyd), dyd.numel(), L.ACT[act], st)
+    da = absmax(L, dyd, st)
+    # backward-data: the same kernel on dy with the flipped / transposed pack (Cin' = Cout, Cout' = Cin)
+    if L.query("ladder_conv3x3_split_eligible", N, H, W, Cout, Cin):
+        pkT = torch.empty(L.query("ladder_filter_pack_split_bytes", 9, Cout, Cin, P), dtype=torch.uint8, device="cuda")
+        L.call("ladder_filter_pack_split", p(wd), p(pkT), 9, Cout, Cin, 1, P, st)
+        dx = torch.empty_like(xd)
+        L.call("ladder_conv3x3_split", p(dyd), p(da), p(pkT), None, p(dx), N, H, W, Cout, Cin, 0, P, st)
+        close(dx, xt.grad, tb, "dx")
+    if L.query("ladder_conv3x3_wgrad_split_eligible", N, H, W, Cin, Cout, P):
+        wsp, wsn = gpu_ctx.ws(L.query("ladder_conv3x3_wgrad_split_workspace_bytes", N, H, W, Cin, Cout))
+        dw, db = torch.empty_like(wd), torch.empty_like(bd)
+        L.call("ladder_conv3x3_wgrad_split", p(xd), p(xa), p(dyd), p(da), p(dw), p(db), N, H, W, Cin, Cout, P, wsp, wsn, st)
+        if xk != "zero":
+            close(dw, wt.grad, tb, "dw")
+        else:
+            assert float(dw.abs().max()) == 0.0
+        close(db, bt.grad, tb, "db")
+        dw2 = torch.empty_like(wd)
+        L.call("ladder_conv3x3_wgrad_split", p(xd), p(xa), p(dyd), p(da), p(dw2), None, N, H, W, Cin, Cout, P, wsp, wsn, st)
+        assert torch.equal(dw2, dw)              # db == NULL leaves dw untouched; the split reduction is bit-reproducible
+    else:
+        assert prec == "bf16x6" or Cin % 64 != 0 or N * H * (W // 32) < 4096
+
+
+# gather-kernel cases (128x128 tiles, gathered channels % 32 == 0): N, H, W, Cin, Cout, k, stride, padding, act
+GATHER_CASES = [
+    (48, 16, 16, 64, 256, 3, 1, "same", "leaky_relu"),     # decoder 16x16 map (W % 32 != 0: no halo tiling)
+    (96, 32, 32, 128, 128, 3, 2, "same", None),            # strided encoder layer: forward + 4 parity classes of backward-data
+    (160, 32, 32, 128, 160, 3, 2, "valid", "leaky_relu"),  # stride 2 VALID (15x15 output), Cout tile edge
+    (13, 24, 40, 32, 192, 5, 1, "same", None),             # 5x5, ragged M (13*24*40 not a multiple of 128)
+]
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x6"])
+@pytest.mark.parametrize("case", GATHER_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_conv2d_split_gather_fwd_bwd(gpu_ctx, case, prec):
+    L = _lib()
+    from ladder_latent_data_distribution_modelling_amd import arch
+    N, H, W, Cin, Cout, k, s, pad, act = case
+    P = PREC[prec]
+    tf, tb = TOL[prec]
+    rng = np.random.default_rng(abs(hash(case)) % 2**31)
+    x = _fill(rng, (N, H, W, Cin), "heavy")
+    w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    yr = O.act(O.conv2d_tf(xt, wt, bt, s, pad), act)
+    dy = (rng.standard_normal(tuple(yr.shape)) * 1e-3).astype(np.float32)
+    yr.backward(torch.tensor(dy, dtype=torch.float64))
+    pt, Ho = arch.conv_out(H, k, s, pad)
+    pl, Wo = arch.conv_out(W, k, s, pad)
+    geo = (N, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl)
+    st = gpu_ctx.stream
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    xa = absmax(L, xd, st)
+    assert L.query("ladder_conv2d_fwd_split_eligible", *geo) == 1
+    pk = torch.empty(L.query("ladder_filter_pack_split_bytes", k * k, Cin, Cout, P), dtype=torch.uint8, device="cuda")
+    L.call("ladder_filter_pack_split", p(wd), p(pk), k * k, Cin, Cout, 0, P, st)
+    y = torch.empty(N, Ho, Wo, Cout, device="cuda")
+    wsp, wsn = gpu_ctx.ws(max(L.query("ladder_conv2d_fwd_split_workspace_bytes", *geo), 16))
+    L.call("ladder_conv2d_fwd_split", p(xd), p(xa), p(pk), p(bd), p(y), *geo, L.ACT[act], P, wsp, wsn, st)
+    close(y, yr, tf, "fwd (split-K allowed)")
+    L.call("ladder_conv2d_fwd_split", p(xd), p(xa), p(pk), p(bd), p(y), *geo, L.ACT[act], P, None, 0, st)
+    close(y, yr, tf, "fwd")
+    dyd = dev(dy)
+    if act is not None:
+        L.call("ladder_act_bwd", p(dyd), p(dev(yr.detach().numpy())), p(dyd), dyd.numel(), L.ACT[act], st)
+    da = absmax(L, dyd, st)
+    if L.query("ladder_conv2d_bwd_data_split_eligible", *geo, 0):
+        pkT = torch.empty(L.query("ladder_filter_pack_split_bytes", k * k, Cout, Cin, P), dtype=torch.uint8, device="cuda")
+        L.call("ladder_filter_pack_split", p(wd), p(pkT), k * k, Cout, Cin, 1, P, st)
+        wsp, wsn = gpu_ctx.ws(max(L.query("ladder_conv2d_bwd_data_split_workspace_bytes", *geo), 16))
+        dx = torch.empty_like(xd)
+        L.call("ladder_conv2d_bwd_data_split", p(dyd), p(da), p(pkT), p(dx), *geo, None, 0, P, wsp, wsn, st)
+        close(dx, xt.grad, tb, "dx")
+        dxg = torch.empty_like(xd)
+        L.call("ladder_conv2d_bwd_data_split", p(dyd), p(da), p(pkT), p(dxg), *geo, p(xd), 1, P, wsp, wsn, st)
+        assert torch.equal(dxg, dx * torch.where(xd > 0, 1.0, 0.2))
+        checked_dx = True
+    else:
+        checked_dx = False                      # (dx tile narrower than 128 channels: the fp32 kernel keeps this call)
+    if L.query("ladder_conv2d_bwd_filter_split_eligible", *geo):
+        wsp, wsn = gpu_ctx.ws(L.query("ladder_conv2d_bwd_filter_split_workspace_bytes", *geo[:9]))
+        dw, db = torch.empty_like(wd), torch.empty_like(bd)
+        L.call("ladder_conv2d_bwd_filter_split", p(xd), p(xa), p(dyd), p(da), p(dw), p(db), *geo, P, wsp, wsn, st)
+        close(dw, wt.grad, tb, "dw")
+        close(db, bt.grad, tb, "db")
+        checked_dw = True
+    else:
+        checked_dw = False
+    # the cases are chosen so that every entry point is exercised by at least one of them
+    assert checked_dx == (case in (GATHER_CASES[1], GATHER_CASES[2])), case
+    assert checked_dw == (Cin % 128 == 0), case
+
+
+def test_split_abi_errors(gpu_ctx):
+    """Shape / alignment / workspace / missing-scale errors are returned, never launched."""
+    L = _lib()
+    lib = L.load()
+    st = gpu_ctx.stream
+    x = torch.zeros(32 * 64 * 64 * 32 + 4, device="cuda")
+    pk = torch.empty(L.query("ladder_filter_pack_split_bytes", 9, 32, 128, 4), dtype=torch.uint8, device="cuda")
+    y = torch.empty(32 * 64 * 64 * 128, device="cuda")
+    am = torch.zeros(4, device="cuda")
+    assert L.query("ladder_filter_pack_split_bytes", 9, 24, 128, 4) == 0             # Cin % 16 != 0
+    assert L.query("ladder_filter_pack_split_bytes", 9, 32, 128, 1) == 0             # unknown precision
+    assert lib.ladder_filter_pack_split(p(x), p(pk), 9, 24, 128, 0, 4, st) == -1
+    assert lib.ladder_conv3x3_split(p(x), p(am), p(pk), None, p(y), 32, 64, 64, 32, 128, 0, 7, st) == -1      # precision
+    assert lib.ladder_conv3x3_split(p(x), p(am), p(pk), None, p(y), 32, 60, 64, 32, 128, 0, 4, st) == -1      # H % 8
+    assert lib.ladder_conv3x3_split(p(x), None, p(pk), None, p(y), 32, 64, 64, 32, 128, 0, 4, st) == -1       # f16x3 needs the scale
+    assert lib.ladder_conv3x3_split(p(x) + 4, p(am), p(pk), None, p(y), 32, 64, 64, 32, 128, 0, 4, st) == -2   # alignment
+    assert lib.ladder_conv3x3_split(p(x), None, p(pk), None, p(y), 32, 64, 64, 32, 128, 0, 3, st) == 0        # bf16 needs none
+    assert L.query("ladder_conv3x3_wgrad_split_eligible", 32, 64, 64, 64, 128, 3) == 0          # three planes do not fit LDS
+    assert L.query("ladder_conv3x3_wgrad_split_eligible", 32, 64, 64, 64, 128, 4) == 1
+    assert L.query("ladder_conv3x3_wgrad_split_eligible", 32, 63, 64, 64, 128, 4) == 0          # H % 2
+    xw = torch.zeros(32 * 64 * 64 * 64, device="cuda")
+    dyw = torch.zeros(32 * 64 * 64 * 128, device="cuda")
+    dw = torch.empty(9 * 64 * 128, device="cuda")
+    assert lib.ladder_conv3x3_wgrad_split(p(xw), p(am), p(dyw), p(am), p(dw), None, 32, 64, 64, 64, 128, 4, None, 0, st) == -3   # workspace
+    assert lib.ladder_conv2d_fwd_split_eligible(2, 16, 16, 64, 16, 16, 256, 3, 3, 1, 1, 1) == 0                # too few tiles for 128x128
+    assert lib.ladder_conv2d_fwd_split_eligible(48, 16, 16, 48, 16, 16, 256, 3, 3, 1, 1, 1) == 0               # Cin % 32
+    torch.cuda.synchronize()
