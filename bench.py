@@ -21,6 +21,9 @@ sys.path.insert(0, ROOT)
 
 FWD_FLOP_PER_IMG = {"celeba": 41.4e9}   # RUN#1 30.1 + RUN#2 10.0 + RUN#3 0.63 + RUN#4 0.62 GFLOP / image / iteration
 FP32_PEAK_TFLOPS = 157.3                # MI355X_MICROARCH.md: fp32 MFMA (= vector) dense peak
+F16_PEAK_TFLOPS = 2516.6                # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak (256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz)
+# matrix instructions issued per algorithmic fp32 multiply-add by each matmul_precision (csrc/convsplit.hip)
+MFMA_PER_PRODUCT = {"f32": 1, "f16x3": 3, "bf16x3": 3, "bf16x6": 6}
 
 
 def cpu_baseline(cfg, gm, seconds_budget=20.0, threads=None):
@@ -65,6 +68,7 @@ def main():
     ap.add_argument("--precision", default="", help="matmul_precision override: f32 | bf16x6 | bf16x3 (default: the engine's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-compare", action="store_true", help="skip the native-fp32 comparison run after the timed region")
     ap.add_argument("--graphs", type=int, default=-1,
                     help="0: eager launches, the dominant kernel is timed with HIP events INSIDE the timed region (default for "
                          "CelebA, where replay changes nothing); 1: replay each run as a captured hipGraph (default for the MNIST "
@@ -170,7 +174,9 @@ def main():
             {"celeba": "CelebA", "mnist_digit": "MNIST-digit", "mnist_fashion": "MNIST-fashion"}[cfg["exp_name"]],
             cfg["dim_input_x"], cfg["dim_input_y"]), "value": round(value, 2), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if precision == "f32" else "f32 (%s split MFMA)" % precision,
+        "data": "synthetic",
         "config": {"workload": "BASELINE configs[" + {"mnist_digit": "0", "mnist_fashion": "1", "celeba": "2"}[cfg["exp_name"]] + "]: %s %dx%dx%d nh=%d z=%d R=%d K=%d L=%d per-GPU batch=%d, 4 runs/iteration "
                                "(AE step, sigma step, prior step, inner-sigma step), fitted-GM regime" % (
                                    cfg["exp_name"], cfg["dim_input_x"], cfg["dim_input_y"], cfg["dim_input_channel"],
@@ -182,13 +188,21 @@ def main():
     if prof:
         dom = max(prof.values(), key=lambda r: r["total_ms"])       # the dominant kernel = largest share of GPU time
         traffic = None      # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json), same launch mix
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json" if precision == "f16x3" else "r01_pmc_traffic.json")
         if os.path.isfile(tpath) and cfg["exp_name"] == "celeba" and B == 128:
             tj = json.load(open(tpath))
             if tj.get("kernel", "") in dom["kernel"]:
                 traffic = tj["hbm_bytes_per_launch"]
-        out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2), "peak": FP32_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(dom["tflops"] / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
+        split = "split" in dom["kernel"]
+        nm = MFMA_PER_PRODUCT[precision] if split else 1
+        # peak for the ALGORITHMIC (fp32) flops of the dominant kernel: the dense MFMA peak of the instruction it issues divided by
+        # the number of matrix instructions it needs per fp32 product (f16x3: 2516.6 / 3); native fp32 kernels: the fp32 MFMA peak
+        peak = (F16_PEAK_TFLOPS / nm) if split else FP32_PEAK_TFLOPS
+        out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2), "peak": round(peak, 1),
+                           "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": traffic,
+                           "peak_basis": ("dense %s MFMA peak %.1f TFLOP/s / %d matrix instructions per fp32 product" % (
+                               "fp16" if precision == "f16x3" else "bf16", F16_PEAK_TFLOPS, nm)) if split else "fp32 MFMA peak",
+                           "mfma_issued_tflops": round(dom["tflops"] * nm, 1),
                            "launches": dom["launches"], "avg_launch_ms": round(dom["avg_ms"], 4),
                            "flop_per_launch": dom["flops_per_launch"],
                            "share_of_step_time": round(dom["total_ms"] / (1e3 * dt), 3),
@@ -209,6 +223,15 @@ def main():
     use_sg, use_mask = trainer.compute_feeddict(x, "VAE")
     out["ae_step_only_images_per_sec"] = rate(lambda: (trainer.engine.run_ae(x, lr, None, use_sg, use_mask), trainer.engine.fetch()))
     out["forward_only_images_per_sec"] = rate(lambda: trainer.val_step("VAE", x))
+    if precision != "f32" and cfg["exp_name"] == "celeba" and not args.no_compare:
+        # the same iteration with every contraction on the native fp32 MFMA kernels (round-1 path), untimed extra for comparison
+        cfg32 = dict(cfg, matmul_precision="f32")
+        with contextlib.redirect_stdout(io.StringIO()):
+            model32 = Model(cfg32, device="cuda:%d" % local, seed=1)
+        tr32 = BaseTrain_joint(None, model32, None, cfg32)
+        tr32.cur_epoch, tr32.gm_params = trainer.cur_epoch, trainer.gm_params
+        out["native_f32_images_per_sec"] = rate(lambda: (tr32.train_step_ae(cur_lr=lr, batch_data=x), tr32.train_step_prior(batch_data=x)))
+        del tr32, model32
     whole = FWD_FLOP_PER_IMG.get(cfg["exp_name"])
     if whole and int(cfg["num_hidden_units"]) == 512 and int(cfg["code_size"]) == 64:
         out["whole_step_tflops_per_gpu"] = round(whole * value / world / 1e12, 2)

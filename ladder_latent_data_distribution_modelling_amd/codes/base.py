@@ -116,6 +116,7 @@ class BaseTrain:
 
     def val_step(self, model_to_train, batch_data, noise=None):
         """codes/base.py:643-679."""
+        self._enc_batch = None          # this call overwrites the engine's encoder cache with another batch
         use_sg, use_mask = self.compute_feeddict(batch_data, model_to_train)
         self.engine.evaluate(batch_data, noise, use_sg, use_mask)
         f = self.engine.fetch()
@@ -177,6 +178,7 @@ class BaseTrain:
         return self._share_gm(gm)
 
     def fit_GMM_VI(self, iterator, mode="fast", space="t"):
+        self._enc_batch = None          # this call overwrites the engine's encoder cache with another batch
         if space == "z":
             return self._fit_GMM_z(iterator, mode)
         comm = self.engine.ctx.comm
@@ -278,6 +280,7 @@ class BaseTrain_joint(BaseTrain):
 
     def test_step(self, batch_data, print_result=False, noise=None):
         """codes/base.py:944-986."""
+        self._enc_batch = None          # this call overwrites the engine's encoder cache with another batch
         use_sg, use_mask = self.compute_feeddict(batch_data)
         eng = self.engine
         eng.evaluate(batch_data, noise, use_sg, use_mask)

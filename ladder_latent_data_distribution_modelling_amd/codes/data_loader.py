@@ -70,17 +70,37 @@ def parse_example_bytes(record, key=b"X"):
     raise KeyError("feature %r not found" % key)
 
 
-def tfrecord_iterator(path):
-    """Yield the payload of each record of a TFRecord file (length:u64, crc:u32, data, crc:u32)."""
+def tfrecord_iterator(path, rank=0, world=1):
+    """Yield the payload of each record of a TFRecord file (length:u64, crc:u32, data, crc:u32).  With world > 1 only the records
+    whose index i satisfies i % world == rank are read; the others are seeked over (a data-parallel rank never touches the bytes of
+    another rank's shard)."""
     with open(path, "rb") as f:
+        i = 0
         while True:
             head = f.read(12)
             if len(head) < 12:
                 return
             (n,) = struct.unpack("<Q", head[:8])
-            data = f.read(n)
-            f.read(4)
-            yield data
+            if i % world == rank:
+                data = f.read(n)
+                f.seek(4, 1)
+                yield data
+            else:
+                f.seek(n + 4, 1)
+            i += 1
+
+
+def tfrecord_count(path):
+    """Number of records, from the framing only (payloads are seeked over)."""
+    n_rec = 0
+    with open(path, "rb") as f:
+        while True:
+            head = f.read(12)
+            if len(head) < 12:
+                return n_rec
+            (n,) = struct.unpack("<Q", head[:8])
+            f.seek(n + 4, 1)
+            n_rec += 1
 
 
 def write_tfrecord(path, images_uint8):
@@ -238,33 +258,39 @@ class DataGenerator:
             self.class_name = ("top", "trousers", "pullover", "dress", "coat", "sandal", "shirt", "sneaker", "bag", "ankle boot")
 
     # ---------------------------------------------------------------- CelebA
-    def celeba_images_u8(self, split, limit=None):
+    def celeba_images_u8(self, split, limit=None, rank=0, world=1):
         """uint8 [n,H,W,C] exactly as stored in celebA_<split>.tfrecords (tf.Example, bytes feature 'X', models.py:354-371);
-        seeded synthetic uint8 images when the file is absent."""
-        key = (split, limit)
+        seeded synthetic uint8 images when the file is absent.  rank / world select the data-parallel shard (records rank::world):
+        the array is allocated once at its final size and only this rank's records are parsed (the full 180 000-image split is
+        8.8 GB; a per-image list + np.stack, or a full parse on every rank of an 8-GPU node, would multiply that on the host)."""
+        key = (split, limit, rank, world)
         if key in self._celeba_u8:
             return self._celeba_u8[key]
         H, W, Cc = int(self.config["dim_input_x"]), int(self.config["dim_input_y"]), int(self.config["dim_input_channel"])
         path = os.path.join(self.config.get("data_path", ""), "celebA_%s.tfrecords" % split)
         if os.path.isfile(path):
-            imgs = []
-            for rec in tfrecord_iterator(path):
-                imgs.append(np.frombuffer(parse_example_bytes(rec), np.uint8).reshape(H, W, Cc))
-                if limit and len(imgs) >= limit:
+            total = tfrecord_count(path)
+            n = len(range(rank, total, world))
+            if limit:
+                n = min(n, limit)
+            arr = np.empty((n, H, W, Cc), np.uint8)
+            for i, rec in enumerate(tfrecord_iterator(path, rank, world)):
+                if i >= n:
                     break
-            arr = np.stack(imgs)
+                arr[i] = np.frombuffer(parse_example_bytes(rec), np.uint8).reshape(H, W, Cc)
         else:
             self.synthetic = True
             bs = int(self.config["batch_size"])
             n = int(self.config.get("synthetic_n_train", 4 * bs)) if split == "train" else 2 * bs
             rng = np.random.default_rng({"train": 0, "val": 1, "test": 2}[split])
             arr = rng.integers(0, 256, (n, H, W, Cc), dtype=np.uint8)
-            if limit:
-                arr = arr[:limit]
             if split == "train":
                 self.n_train = n
             elif split == "val":
                 self.n_val = n
+            arr = arr[rank::world]
+            if limit:
+                arr = arr[:limit]
         self._celeba_u8[key] = arr
         return arr
 

@@ -105,7 +105,9 @@ class Session:
                 raise ValueError("You must feed a value for placeholder %r" % k)      # TF: InvalidArgumentError
             return feeds[k]
 
-        if all(k in feeds for k in ("prior_weight", "prior_mean", "prior_cov")) and eng.has_inner:
+        uses_mixture = eng.has_inner or eng.gmm_z                       # priors whose graph holds the GM placeholders (base.py:88-124)
+        fed_mixture = all(k in feeds for k in ("prior_weight", "prior_mean", "prior_cov"))
+        if fed_mixture and uses_mixture:
             eng.set_mixture(feeds["prior_weight"], feeds["prior_mean"], feeds["prior_cov"])
         use_sg = flag("use_standard_gaussian_prior", True)
         use_mask = flag("use_mask", False)
@@ -139,8 +141,17 @@ class Session:
             parts = ["dec"] if (wants_scalar or "decoded" in want) else []
             if eng.has_inner:
                 parts.append("inner")
-                if wants_scalar and eng._gm_packed is not None:
+            if wants_scalar:
+                # the loss graph reads use_standard_gaussian_prior and, for the mixture priors, the three GM placeholders: TF raises
+                # InvalidArgumentError for an unfed placeholder, it never falls back to a default
+                if eng.cfg["prior"] != "standard_gaussian":
+                    need("use_standard_gaussian_prior")
+                if eng.gmm_z or (eng.has_inner and not eng.hier):
+                    if not fed_mixture and eng._gm_packed is None:
+                        need("prior_weight"), need("prior_mean"), need("prior_cov")
                     parts.append("gmm")
+                elif eng.vamp:
+                    parts.append("gmm")                                 # encoder pass over the pseudo-inputs (base.py:216-254)
             eng.forward(x, None, use_sg, use_mask, tuple(parts))
             self._collect(vals, want, eng, x)
             return vals

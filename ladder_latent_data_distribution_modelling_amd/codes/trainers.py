@@ -6,7 +6,15 @@ from .data_loader import BatchIterator, DeviceBatchIterator
 
 
 class _JointEpochMixin:
-    """The per-epoch sequence shared by both trainers (trainers.py:23-83 and 141-198)."""
+    """The per-epoch sequence shared by both trainers (trainers.py:23-83 and 141-198); the three places where the reference's two
+    trainers differ are class attributes / hooks overridden by CelebATrainer_joint_training."""
+    EPOCH_BANNER = "{}/{}:"                                                   # trainers.py:25
+    AVERAGE_MSG = "Average overall negative ELBO loss:\ntrain: {:.4f}, val: {:.4f}"   # trainers.py:66-68
+
+    def _val_gates(self):
+        """(run val_step('VAE'), run val_step('prior')) of the validation loop: MNIST trainer, trainers.py:57-63."""
+        cfg = self.config
+        return True, self.cur_epoch > int(cfg["sg_pretraining"]) - 1 and cfg["prior"] in ("ours", "hierarchical", "vampPrior")
 
     def _iterators(self):
         raise NotImplementedError
@@ -33,7 +41,7 @@ class _JointEpochMixin:
     def train_epoch(self):
         cfg = self.config
         self.cur_epoch += 1
-        print("{}/{}:".format(self.cur_epoch, cfg["num_epochs"]))
+        print(self.EPOCH_BANNER.format(self.cur_epoch, cfg["num_epochs"]))
         train_it, val_it = self._iterators()
         self.compute_cur_lr()
         train_loss_cur_epoch = 0.0
@@ -53,15 +61,16 @@ class _JointEpochMixin:
         self.generate_samples_from_prior()
         self.test_step(batch_data=self.test_batch, print_result=True)
         val_loss_cur_epoch = 0.0
+        val_vae, val_prior = self._val_gates()
         for i in range(self.n_val_iter):
             vb = val_it.next()
-            val_loss_cur_epoch += self.val_step(batch_data=vb, model_to_train="VAE")
-            if self.cur_epoch > int(cfg["sg_pretraining"]) - 1 and cfg["prior"] in ("ours", "hierarchical", "vampPrior"):
+            if val_vae:
+                val_loss_cur_epoch += self.val_step(batch_data=vb, model_to_train="VAE")
+            if val_prior:
                 self.val_step(batch_data=vb, model_to_train="prior")
         self.val_loss_ave_epoch.append(val_loss_cur_epoch / max(self.n_val_iter, 1))
         if int(cfg["TRAIN_VAE"]) == 1:
-            print("Average overall negative ELBO loss:\ntrain: {:.4f}, val: {:.4f}".format(
-                self.train_loss_ave_epoch[self.cur_epoch - 1], self.val_loss_ave_epoch[self.cur_epoch - 1]))
+            print(self.AVERAGE_MSG.format(self.train_loss_ave_epoch[self.cur_epoch - 1], self.val_loss_ave_epoch[self.cur_epoch - 1]))
         self.save_variables_VAE()
 
 
@@ -86,21 +95,33 @@ class MNISTTrainer_joint_training(_JointEpochMixin, BaseTrain_joint):
 
 
 class CelebATrainer_joint_training(_JointEpochMixin, BaseTrain_joint):
+    EPOCH_BANNER = "Training epoch: {}/{}"                                    # trainers.py:143
+    AVERAGE_MSG = "Average:\ntrain: {:.4f}, val: {:.4f}"                      # trainers.py:186-188
+
+    def _val_gates(self):
+        """trainers.py:178-183: the VAE validation pass only when the VAE trains, the prior pass only when the prior trains."""
+        cfg = self.config
+        return (int(cfg["TRAIN_VAE"]) == 1,
+                self.cur_epoch > int(cfg["sg_pretraining"]) - 1 and int(cfg["TRAIN_prior"]) == 1
+                and cfg["prior"] in ("ours", "hierarchical", "vampPrior"))
+
     def __init__(self, sess, model, data, config):
         super().__init__(sess, model, data, config)
         bs = int(config["batch_size"])
         self.test_batch = self.data.celeba_images("test", limit=bs)[:bs]
-        self._train, self._val = self.data.celeba_images_u8("train"), self.data.celeba_images_u8("val")     # uint8, as on disk
-        world = self.engine.ctx.comm.world
-        n_train = self.data.n_train if not self.data.synthetic else self._train.shape[0]
-        n_val = self.data.n_val if not self.data.synthetic else self._val.shape[0]
-        self.n_train_iter = n_train // (bs * world)
-        self.n_val_iter = n_val // (bs * world)
+        c = self.engine.ctx.comm
+        # this rank's shard only (records rank::world), uint8 as on disk
+        self._train = self.data.celeba_images_u8("train", rank=c.rank, world=c.world)
+        self._val = self.data.celeba_images_u8("val", rank=c.rank, world=c.world)
+        n_train = self.data.n_train if not self.data.synthetic else self._train.shape[0] * c.world
+        n_val = self.data.n_val if not self.data.synthetic else self._val.shape[0] * c.world
+        self.n_train_iter = min(n_train // (bs * c.world), self._train.shape[0] // bs)
+        self.n_val_iter = min(n_val // (bs * c.world), self._val.shape[0] // bs)
 
     def _iterators(self):
-        c = self.engine.ctx.comm
-        return (self._make_iterator("train", lambda: self._train[c.rank::c.world] if c.on else self._train),
-                self._make_iterator("val", lambda: self._val[c.rank::c.world] if c.on else self._val, shuffle=False))
+        return (self._make_iterator("train", lambda: self._train),
+                # the reference re-initialises the SAME (shuffling) iterator on the validation file (trainers.py:173-174, models.py:354-386)
+                self._make_iterator("val", lambda: self._val, shuffle=True))
 
     def compute_cur_lr(self):
         """Piecewise schedule of codes/trainers.py:200-209."""

@@ -160,6 +160,7 @@ class Ctx:
         L.load()
         self.comm = comm or Comm()
         self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
+        self._ws_retired, self.ws_generation = [], 0
         self.ns = 0          # LADDER_PREC_* of the split-precision contraction kernels (0 = native f32 MFMA); set by the engine
 
     @property
@@ -168,7 +169,12 @@ class Ctx:
 
     def ws(self, nbytes):
         if self._ws.numel() < nbytes:
+            # a captured hipGraph has the pointer of the workspace it was recorded with baked in: superseded buffers stay alive (the
+            # caching allocator must never hand their memory to a live tensor) and every graph recorded so far is dropped, so the
+            # next call of a run re-captures against the new buffer
+            self._ws_retired.append(self._ws)
             self._ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+            self.ws_generation += 1
         return self._ws.data_ptr(), self._ws.numel()
 
     def empty(self, *shape):
@@ -887,8 +893,16 @@ class LadderEngine:
         use_mask = bool(use_mask) and not self.hier
         cache = getattr(self, "_enc_cache", None)
         if reuse_encoder and cache is not None and cache[0] == self.ps.step["ae"] and not self._enc_needs_grad(parts):
-            _, x, mu, sd_raw = cache
+            _, xc, mu, sd_raw = cache
+            # the cached codes belong to ONE minibatch: a caller handing in another tensor (or another shape) gets a fresh encoder
+            # pass, never stale codes (an in-place refill of the same buffer must go through a run without reuse_encoder first)
+            if isinstance(x, torch.Tensor) and x.device == xc.device and (x.data_ptr() != xc.data_ptr() or x.shape != xc.shape):
+                cache = None
+            else:
+                x = xc
         else:
+            cache = None
+        if cache is None:
             x = self._dev(x)
             mu, sd_raw = self.encoder.forward(x)
             self._enc_cache = (self.ps.step["ae"], x, mu, sd_raw)
@@ -1126,7 +1140,7 @@ class LadderEngine:
         cache = getattr(self, "_enc_cache", None)
         reuse = bool(reuse_encoder and cache is not None and cache[0] == self.ps.step["ae"])
         key = (kind, bool(use_sg), bool(use_mask), tuple(xin.shape), cache[2].data_ptr() if reuse else 0, self._gm_packed.data_ptr()
-               if self._gm_packed is not None else 0)
+               if self._gm_packed is not None else 0, self.ctx.ws_generation)
         ent = self._graphs.get(key)
         if ent is None:
             if self._warm.get(key, 0) < 2:                         # eager warm-up: sizes the workspace and the allocator
@@ -1142,6 +1156,9 @@ class LadderEngine:
             snap = {k: getattr(self, k, None) for k in self._SNAP}
             enc = None if reuse else self._enc_cache[1:]
             self.ps.step, self._run_calls = steps, calls
+            if self.ctx.ws_generation != key[-1]:                  # the workspace grew while recording: this graph is void
+                self._warm[key[:-1] + (self.ctx.ws_generation,)] = 2
+                return self._run(kind, x, lr, noise, use_sg, use_mask, reuse_encoder)
             ent = self._graphs[key] = (graph, static_x, snap, enc)
         graph, static_x, snap, enc = ent
         if not reuse and static_x.data_ptr() != xin.data_ptr():
