@@ -144,8 +144,8 @@ class Session:
             if wants_scalar:
                 # the loss graph reads use_standard_gaussian_prior and, for the mixture priors, the three GM placeholders: TF raises
                 # InvalidArgumentError for an unfed placeholder, it never falls back to a default
-                if eng.cfg["prior"] != "standard_gaussian":
-                    need("use_standard_gaussian_prior")
+                if eng.cfg["prior"] in ("ours", "hierarchical", "vampPrior"):   # the priors whose loss goes through the tf.cond
+                    need("use_standard_gaussian_prior")                         # (base.py:318-320, 357-359, 368-370; "GMM" has none)
                 if eng.gmm_z or (eng.has_inner and not eng.hier):
                     if not fed_mixture and eng._gm_packed is None:
                         need("prior_weight"), need("prior_mean"), need("prior_cov")

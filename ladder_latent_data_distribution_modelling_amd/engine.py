@@ -846,6 +846,14 @@ class LadderEngine:
             return a.to(device=self.ctx.device, dtype=torch.float32).contiguous()
         return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(self.ctx.device)
 
+    @staticmethod
+    def _batch_token(x):
+        """(address, shape) of a minibatch as the caller holds it: the key of the encoder-output cache."""
+        if isinstance(x, torch.Tensor):
+            return ("t", x.data_ptr(), tuple(x.shape))
+        a = np.asarray(x)
+        return ("n", a.__array_interface__["data"][0], tuple(a.shape))
+
     def _randn(self, *shape):
         t = self.ctx.empty(*shape)
         L.call("ladder_randn_dev", _p(t), t.numel(), self.noise_seed, _p(self.rng_counter), self._run_calls, self.ctx.stream)
@@ -891,21 +899,18 @@ class LadderEngine:
         P.zero_()
         self._run_calls = 0
         use_mask = bool(use_mask) and not self.hier
+        # identity of the minibatch the caller handed in (set by _run; direct callers of forward() are identified by their tensor)
+        tok = self.__dict__.pop("_x_token", None) or self._batch_token(x)
         cache = getattr(self, "_enc_cache", None)
-        if reuse_encoder and cache is not None and cache[0] == self.ps.step["ae"] and not self._enc_needs_grad(parts):
-            _, xc, mu, sd_raw = cache
-            # the cached codes belong to ONE minibatch: a caller handing in another tensor (or another shape) gets a fresh encoder
-            # pass, never stale codes (an in-place refill of the same buffer must go through a run without reuse_encoder first)
-            if isinstance(x, torch.Tensor) and x.device == xc.device and (x.data_ptr() != xc.data_ptr() or x.shape != xc.shape):
-                cache = None
-            else:
-                x = xc
+        if (reuse_encoder and cache is not None and cache[0] == self.ps.step["ae"] and cache[4] == tok
+                and not self._enc_needs_grad(parts)):
+            # the cached codes belong to ONE minibatch: a caller handing in another tensor (or shape) gets a fresh encoder pass, never
+            # stale codes (an in-place refill of the same buffer must go through a run without reuse_encoder first)
+            _, x, mu, sd_raw, _ = cache
         else:
-            cache = None
-        if cache is None:
             x = self._dev(x)
             mu, sd_raw = self.encoder.forward(x)
-            self._enc_cache = (self.ps.step["ae"], x, mu, sd_raw)
+            self._enc_cache = (self.ps.step["ae"], x, mu, sd_raw, tok)
         B = x.shape[0]
         self.x, self.B = x, B
         self.Bg = B * ctx.comm.world
@@ -1136,25 +1141,28 @@ class LadderEngine:
         if not self.use_graphs or noise is not None or self.ctx.comm.on:
             return fn(x, lr, noise, use_sg, use_mask, reuse_encoder)
         group = self._GROUP[kind]
+        tok = self._batch_token(x)
         xin = self._dev(x)
         cache = getattr(self, "_enc_cache", None)
-        reuse = bool(reuse_encoder and cache is not None and cache[0] == self.ps.step["ae"])
+        reuse = bool(reuse_encoder and cache is not None and cache[0] == self.ps.step["ae"] and cache[4] == tok)
         key = (kind, bool(use_sg), bool(use_mask), tuple(xin.shape), cache[2].data_ptr() if reuse else 0, self._gm_packed.data_ptr()
                if self._gm_packed is not None else 0, self.ctx.ws_generation)
         ent = self._graphs.get(key)
         if ent is None:
             if self._warm.get(key, 0) < 2:                         # eager warm-up: sizes the workspace and the allocator
                 self._warm[key] = self._warm.get(key, 0) + 1
+                self._x_token = tok
                 return fn(xin, lr, None, use_sg, use_mask, reuse_encoder)
             static_x = cache[1] if reuse else xin.clone()
             self.ps.set_lr(group, lr)
             steps, calls = dict(self.ps.step), self._run_calls
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
+            self._x_token = tok
             with torch.cuda.graph(graph):                          # records the launches; nothing executes, host counters restored
                 fn(static_x, lr, None, use_sg, use_mask, reuse_encoder)
             snap = {k: getattr(self, k, None) for k in self._SNAP}
-            enc = None if reuse else self._enc_cache[1:]
+            enc = None if reuse else self._enc_cache[1:4]
             self.ps.step, self._run_calls = steps, calls
             if self.ctx.ws_generation != key[-1]:                  # the workspace grew while recording: this graph is void
                 self._warm[key[:-1] + (self.ctx.ws_generation,)] = 2
@@ -1165,7 +1173,7 @@ class LadderEngine:
             static_x.copy_(xin)
         self.ps.set_lr(group, lr)
         if enc is not None:
-            self._enc_cache = (self.ps.step["ae"],) + tuple(enc)   # as the eager forward does (pre-update step)
+            self._enc_cache = (self.ps.step["ae"],) + tuple(enc) + (tok,)   # as the eager forward does (pre-update step)
         graph.replay()
         self.ps.step[group] += 1
         for k, v in snap.items():

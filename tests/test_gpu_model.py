@@ -157,6 +157,27 @@ def test_encoder_reuse_is_bit_identical(golden_dir):
     assert torch.equal(b, eng.scalars) and not torch.equal(a, b)
 
 
+def test_encoder_reuse_never_serves_another_batch(golden_dir):
+    """The encoder-output cache is keyed by the minibatch the caller holds (address + shape) and the AE step: asking for reuse with a
+    different batch -- e.g. train_step_prior(b) after a val_step(other) overwrote the cache -- must evaluate the encoder on THAT
+    batch; asking with the same device tensor must reuse (same tensors handed back)."""
+    d = np.load(os.path.join(golden_dir, "oracle_celeba.npz"))
+    cfg = json.loads(str(d["config"]))
+    eng = _engine(cfg)
+    eng.set_mixture(d["gm_w"], d["gm_m"], d["gm_c"])
+    nz = {k: d["it0_run3_%s" % k] for k in ("eps_z", "eps_t", "eps_mc")}
+    x1 = torch.as_tensor(d["x"]).cuda()
+    x2 = torch.rand_like(x1)
+    eng.forward(x2, nz, False, False, ("inner", "gmm"))
+    want = eng.scalars.clone()
+    eng.forward(x1, nz, False, False, ("inner", "gmm"))                         # the cache now holds x1's codes
+    mu1 = eng.lat_z[0]
+    eng.forward(x1, nz, False, False, ("inner", "gmm"), reuse_encoder=True)
+    assert eng.lat_z[0] is mu1                                                  # same batch: reused, not recomputed
+    eng.forward(x2, nz, False, False, ("inner", "gmm"), reuse_encoder=True)     # another batch: must NOT see x1's codes
+    assert torch.equal(eng.scalars, want) and eng.lat_z[0] is not mu1
+
+
 def test_sg_feed_identity(golden_dir):
     """With the SG-pretraining feed (K identical N(0,I) components) the MC cross-entropy equals the finite-sum
     closed form mean_{l,b}[-R/2 log 2pi - 1/2 |t_mc|^2]."""
