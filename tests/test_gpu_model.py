@@ -271,6 +271,63 @@ dist.destroy_process_group()
 '''
 
 
+RCCL_WORKER = r"""
+import json, os, sys
+import numpy as np, torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%(port)d", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from ladder_latent_data_distribution_modelling_amd.engine import LadderEngine, Comm
+from ladder_latent_data_distribution_modelling_amd import arch
+d = np.load(os.path.join(%(root)r, "tests", "golden", "oracle_celeba.npz"))
+cfg = json.loads(str(d["config"]))
+x = torch.as_tensor(d["x"]).cuda()
+vals = arch.init_values(cfg, seed=1)
+res = []
+for forced in (False, True):
+    comm = Comm()
+    assert comm.world == 1 and not comm.on
+    comm.on = forced                 # a 1-rank group never exchanges on its own: force every C1-C4 call through RCCL
+    eng = LadderEngine(cfg, "cuda:0", values=vals, comm=comm, noise_seed=77)
+    eng.set_mixture(d["gm_w"], d["gm_m"], d["gm_c"])
+    for it in range(2):
+        eng.run_ae(x, 1e-3, None, False, False)
+        eng.run_sigma(x, 1e-3, None, False, False, reuse_encoder=False)
+        eng.run_prior(x, 1e-3, None, False, False, reuse_encoder=True)
+        eng.run_inner_sigma(x, 1e-3, None, False, False, reuse_encoder=True)
+    torch.cuda.synchronize()
+    res.append((eng.fetch(), eng.ps.to_dict()))
+(fa, pa), (fb, pb) = res
+assert fa == fb, (fa, fb)
+for k in pa:
+    assert np.array_equal(pa[k], pb[k]), k
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_OK")
+"""
+
+
+def test_exchange_steps_through_rccl_single_rank(tmp_path):
+    """Every exchange step of the data-parallel scheme (C1 bucketed gradient all-reduce incl. the asynchronous decoder bucket, C2
+    batch-norm statistics, C3 scalar partials, C4 prior gradients) issued through the REAL RCCL backend ("nccl") on a 1-rank group:
+    a sum over one rank is the identity, so two iterations of the four runs must be bit-identical to the exchange-free engine.
+    (Multi-rank semantics are covered by the gloo tests; this pins that the tensors / streams / async handles the engine hands to
+    torch.distributed are accepted by RCCL on the device.)"""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER % dict(root=root, port=port))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and "RCCL_OK" in p.stdout, p.stdout[-3000:]
+
+
 def test_data_parallel_two_ranks_one_gpu(golden_dir, tmp_path):
     """The PRODUCT data-parallel path (HIP kernels + C1-C4 exchanges through engine.Comm) with 2 processes sharing cuda:0 over
     gloo (RCCL refuses two ranks on one device): one full 4-run iteration on half batches must reproduce the single-process
