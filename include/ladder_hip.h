@@ -89,6 +89,9 @@ int ladder_conv1x1_smallcout_eligible(long M, int Cin, int Cout);
 size_t ladder_conv1x1_smallcout_bwd_workspace_bytes(long M, int Cin, int Cout);
 int ladder_conv1x1_smallcout_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long M, int Cin,
                                  int Cout, int gate_act, void* ws, size_t ws_bytes, ladder_stream_t stream);
+/* ... additionally produces the absolute-maximum record of dx (LADDER_ABSMAX_FLOATS floats, see ladder_absmax; dx must not be NULL). */
+int ladder_conv1x1_smallcout_bwd_absmax(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long M, int Cin,
+                                        int Cout, int gate_act, void* ws, size_t ws_bytes, float* dx_absmax, ladder_stream_t stream);
 
 /* ---------------------------------------------------------------- N1s: the same convolutions on the 16-bit matrix cores
  * (operand splitting; csrc/convsplit.hip).  gfx950 has no TF32-class MFMA and its f32-input MFMA runs at the f32 vector rate;
@@ -103,7 +106,10 @@ int ladder_conv1x1_smallcout_bwd(const float* x, const float* dy, const float* w
  * H % 8 == 0, Cin % 16 == 0, Cout % 4 == 0, Cout >= 64 and >= 512 workgroups (codes/models.py:538-578: the decoder's
  * 32x32 ... 128x128 maps). */
 enum { LADDER_PREC_F32 = 0, LADDER_PREC_BF16X3 = 2, LADDER_PREC_BF16X6 = 3, LADDER_PREC_F16X3 = 4 };
-/* out[0] = max |x[i]| (device scalar; exact and order-independent). */
+/* Absolute-maximum RECORD of a tensor: LADDER_ABSMAX_FLOATS floats (16 slots, 128 bytes apart; max |x| = the maximum of the slots --
+ * exact and order-independent; producers fold block maxima into the slots with one atomic per workgroup).  ladder_absmax fills
+ * `out` from scratch; kernels with a `*_absmax` OUTPUT argument zero it and fill it for the tensor they write (NULL = skip). */
+#define LADDER_ABSMAX_FLOATS 512
 int ladder_absmax(const float* x, size_t n, float* out, ladder_stream_t stream);
 /* ladder_filter_pack_split: once per weight update, HWIO fp32 bank of ntaps = KH*KW taps -> split planes in the kernels' LDS layout
  * (Cin % 16 == 0; output channels zero-padded to a multiple of 128).
@@ -114,9 +120,10 @@ int ladder_filter_pack_split(const float* w, void* packed, int ntaps, int Cin, i
                              ladder_stream_t stream);
 int ladder_conv3x3_split_eligible(int N, int H, int W, int Cin, int Cout);
 /* y = act(conv3x3_same(x, F) + bias) with F as packed above (bias may be NULL; x_absmax is read only for LADDER_PREC_F16X3 and may
- * be any upper bound of max |x|: a looser bound only raises the absolute representation floor 2^-38 * bound). */
-int ladder_conv3x3_split(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, int N, int H, int W,
-                         int Cin, int Cout, int act, int prec, ladder_stream_t stream);
+ * hold any upper bound of max |x|: a looser bound only raises the absolute representation floor 2^-38 * bound).  y_absmax (may be
+ * NULL): record of the output, produced in the epilogue. */
+int ladder_conv3x3_split(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, float* y_absmax, int N,
+                         int H, int W, int Cin, int Cout, int act, int prec, ladder_stream_t stream);
 
 /* The gather kernel on split operands: every other large convolution (128x128 output tiles; gathered channels % 32 == 0; tap table
  * <= 28 taps), i.e. the strided encoder layers and the 8x8 / 16x16 decoder maps (codes/models.py:398-460, 522-547) and their
@@ -209,6 +216,12 @@ int ladder_in_style_fwd(const float* x, const float* style, float* y, float* mea
 int ladder_in_style_bwd(const float* dy, const float* x, const float* style, const float* mean_rstd,
                         float* dx, float* dstyle /*[N,2C]*/, int N, int HW, int C, int act,
                         void* ws, size_t ws_bytes, ladder_stream_t stream);
+/* The same two calls, additionally producing the absolute-maximum record (ladder_absmax) of the tensor they write -- y resp. dx --
+ * for the split-precision convolution that consumes it (C % 4 == 0, workspace supplied). */
+int ladder_in_style_fwd_absmax(const float* x, const float* style, float* y, float* mean_rstd, int N, int HW, int C, float eps, int act,
+                               void* ws, size_t ws_bytes, float* y_absmax, ladder_stream_t stream);
+int ladder_in_style_bwd_absmax(const float* dy, const float* x, const float* style, const float* mean_rstd, float* dx, float* dstyle,
+                               int N, int HW, int C, int act, void* ws, size_t ws_bytes, float* dx_absmax, ladder_stream_t stream);
 
 /* ---------------------------------------------------------------- N6: tf.image.resize_images (TF1 legacy bilinear)
  * codes/models.py:519,538,544,555,561,572,578.  align_corners=False, half_pixel_centers=False;

@@ -24,6 +24,7 @@ S_NAMES = ["sigma", "mean_pixel_error", "entropy_z", "crossEntropy_prior_sg", "c
            "_g_pix", "_g_sigma_var", "_g_code", "_g_inner_sigma_var", "_inv_B", "_inv_LB"]
 S_INDEX = {n: i for i, n in enumerate(S_NAMES)}
 S_COUNT = 32
+ABSMAX_FLOATS = 512      # LADDER_ABSMAX_FLOATS: size of an absolute-maximum record
 
 
 class LadderElboCfg(C.Structure):
@@ -106,7 +107,10 @@ PROTOTYPES = {
     "ladder_conv2d_bwd_data_split_workspace_bytes": (_z, [_i] * 12),
     "ladder_conv2d_bwd_data_split": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p, _i, _i, _p, _z, _p]),
     "ladder_conv3x3_split_eligible": (_i, [_i] * 5),
-    "ladder_conv3x3_split": (_i, [_p, _p, _p, _p, _p] + [_i] * 7 + [_p]),
+    "ladder_conv3x3_split": (_i, [_p, _p, _p, _p, _p, _p] + [_i] * 7 + [_p]),
+    "ladder_in_style_fwd_absmax": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _z, _p, _p]),
+    "ladder_in_style_bwd_absmax": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _z, _p, _p]),
+    "ladder_conv1x1_smallcout_bwd_absmax": (_i, [_p, _p, _p, _p, _p, _p, C.c_long, _i, _i, _i, _p, _z, _p, _p]),
     "ladder_absmax": (_i, [_p, _z, _p, _p]),
     "ladder_conv3x3_wgrad_split_eligible": (_i, [_i] * 6),
     "ladder_conv3x3_wgrad_split_workspace_bytes": (_z, [_i] * 5),

@@ -53,3 +53,33 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int xcd = bid & 7, local = bid >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
+
+// ---- absolute-maximum records ---------------------------------------------------------------------------------------------------
+// A tensor's max |x| travels as a RECORD of 16 slots, 128 bytes apart (LADDER_ABSMAX_FLOATS floats): every producing workgroup
+// folds its block maximum into slot (block id % 16) with one atomic max on the bit pattern (non-negative floats order like their
+// bit patterns: exact, order-independent), consumers take the maximum of the 16 slots.  One shared counter would serialise all
+// workgroups of a launch in the L2 (~12 ns per same-address atomic: 100 us for 8192 workgroups); 16 lines keep it under 2 us.
+constexpr int AMAX_SLOTS = 16, AMAX_STRIDE = 32;
+static_assert(AMAX_SLOTS * AMAX_STRIDE == LADDER_ABSMAX_FLOATS, "record size of include/ladder_hip.h");
+
+__device__ __forceinline__ float amax_load(const float* rec) {
+  float m = 0.f;
+#pragma unroll
+  for (int s = 0; s < AMAX_SLOTS; ++s) m = fmaxf(m, rec[s * AMAX_STRIDE]);
+  return m;
+}
+// Block-wide: EVERY thread of the workgroup must call it (contains a barrier); `m` = the thread's running max of |values written|.
+__device__ __forceinline__ void amax_commit_block(float m, float* rec) {
+  __shared__ float amax_red[16];
+  m = wave_max(m);
+  const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+  if ((tid & 63) == 0) amax_red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    const int nw = (blockDim.x * blockDim.y * blockDim.z + 63) >> 6;
+    float b = 0.f;
+    for (int w = 0; w < nw; ++w) b = fmaxf(b, amax_red[w]);
+    const unsigned slot = (blockIdx.x + 7u * blockIdx.y + 3u * blockIdx.z) % AMAX_SLOTS;
+    atomicMax(reinterpret_cast<unsigned*>(rec) + slot * AMAX_STRIDE, __builtin_bit_cast(unsigned, b));
+  }
+}

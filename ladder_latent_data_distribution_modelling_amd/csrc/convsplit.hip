@@ -34,10 +34,8 @@ __device__ __attribute__((aligned(16))) float gs_zero16[4] = {0.f, 0.f, 0.f, 0.f
 
 // ---- absolute maximum ------------------------------------------------------------------------------------------------------
 // Non-negative floats order like their bit patterns, so an unsigned atomic max is exact and order-independent (deterministic).
-// One atomic per WORKGROUP: same-address atomics serialise at ~12 ns each in the L2 (a per-wavefront atomic from 2048 blocks cost
-// 100 us, 4x the streaming time of a 1 GB tensor), so a launch is 512 blocks x 8 float4 loads in flight per thread.
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n4, size_t n, unsigned* __restrict__ out) {
-  __shared__ float red[4];
+// 512 workgroups x 8 float4 loads in flight per thread; block maxima are folded into the 16-slot record (split16.h).
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n4, size_t n, float* __restrict__ rec) {
   const float4* x4 = reinterpret_cast<const float4*>(x);
   float m = 0.f;
   const size_t stride = (size_t)gridDim.x * 256;
@@ -55,10 +53,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   }
   if (blockIdx.x == 0)
     for (size_t t = n4 * 4 + threadIdx.x; t < n; t += 256) m = fmaxf(m, fabsf(x[t]));
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicMax(out, __builtin_bit_cast(unsigned, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+  amax_commit_block(m, rec);
 }
 
 // ---- filter packing ----------------------------------------------------------------------------------------------------
@@ -77,7 +72,7 @@ __global__ __launch_bounds__(256) void filter_pack_kernel(const float* __restric
   constexpr bool F16 = Fmt<PREC>::F16;
   const int i = blockIdx.x * 256 + threadIdx.x;     // one thread per (tap, slab, cot, kg, co)
   if (i >= total) return;
-  const float c = F16 ? scale_from_absmax(*wamax) : 1.f;
+  const float c = F16 ? scale_from_absmax(amax_load(wamax)) : 1.f;
   const int cots = (Cout + SP_BN - 1) / SP_BN, nslabs = Cin / 16;
   const int col = i % SP_BN;
   int t = i / SP_BN;
@@ -122,7 +117,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void conv3x3_halo_split_kernel(const
                                                                           const int N, const int H, const int W, const int Cin,
                                                                           const int Cout, const int act, const int tiles_n,
                                                                           const float* __restrict__ xamax,
-                                                                          const float* __restrict__ wamax) {
+                                                                          const float* __restrict__ wamax, float* __restrict__ yamax) {
   constexpr int NS = Fmt<PREC>::NS;
   constexpr bool F16 = Fmt<PREC>::F16;
   constexpr int A_BUF = NS * SP_A_PLANE, B_BUF = NS * SP_B_PLANE;
@@ -144,8 +139,8 @@ __global__ __launch_bounds__(SP_THREADS, 2) void conv3x3_halo_split_kernel(const
   const int nslabs = Cin / 16;
   float cx = 1.f, unscale = 1.f;
   if (F16) {
-    cx = scale_from_absmax(*xamax);
-    unscale = 1.f / (cx * scale_from_absmax(*wamax));      // exact: powers of two
+    cx = scale_from_absmax(amax_load(xamax));
+    unscale = 1.f / (cx * scale_from_absmax(amax_load(wamax)));      // exact: powers of two
   }
 
   const float* hsrc[SP_AU];
@@ -241,6 +236,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void conv3x3_halo_split_kernel(const
     }
   }
 
+  float ymax = 0.f;
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int n = n0 + wn * 64 + ni * 32 + l31;
@@ -253,10 +249,15 @@ __global__ __launch_bounds__(SP_THREADS, 2) void conv3x3_halo_split_kernel(const
         const int px = (e & 3) + 8 * (e >> 2) + 4 * lh;
         float v = acc[mi][ni][e];
         if (F16) v *= unscale;
-        if (n < Cout) y[rowbase + (long)px * Cout + n] = ladder_act_fn(v + bv, act);
+        v = ladder_act_fn(v + bv, act);
+        if (n < Cout) {
+          y[rowbase + (long)px * Cout + n] = v;
+          ymax = fmaxf(ymax, fabsf(v));
+        }
       }
     }
   }
+  if (yamax != nullptr) amax_commit_block(ymax, yamax);     // the output's absolute maximum for the next split contraction
 }
 
 // ---- 3x3 filter gradient on split operands -----------------------------------------------------------------------------------
@@ -327,8 +328,8 @@ __global__ __launch_bounds__(WS_THREADS, 3) void wgrad3x3_split_kernel(const flo
   const int r = wv >> 2, cb = (wv >> 1) & 1, njp = wv & 1;
   float cx = 1.f, cd = 1.f;
   if (F16) {
-    cx = scale_from_absmax(*xamax);
-    cd = scale_from_absmax(*damax);
+    cx = scale_from_absmax(amax_load(xamax));
+    cd = scale_from_absmax(amax_load(damax));
   }
   // fragment addresses (bytes inside a buffer): pixel row of 64 B, this lane's 4-channel group inside its 16-lane block
   const int frag_lane = (8 * lh + (l15 >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (l15 & 3)) * 2;
@@ -499,18 +500,18 @@ extern "C" {
 int ladder_absmax(const float* x, size_t n, float* out, ladder_stream_t stream) {
   if (n == 0) return LADDER_E_SHAPE;
   if (!ladder_aligned16(x)) return LADDER_E_ALIGN;
-  if (hipMemsetAsync(out, 0, sizeof(float), stream) != hipSuccess) return LADDER_E_LAUNCH;
+  if (hipMemsetAsync(out, 0, LADDER_ABSMAX_FLOATS * sizeof(float), stream) != hipSuccess) return LADDER_E_LAUNCH;
   const size_t n4 = n / 4;
   size_t blocks = (n4 + 256 * 8 - 1) / (256 * 8);
   blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
-  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n4, n, (unsigned*)out);
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n4, n, out);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
 
 size_t ladder_filter_pack_split_bytes(int ntaps, int Cin, int Cout, int prec) {
   if (ntaps <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 16) != 0 || !prec_ok(prec)) return 0;
-  return pack_payload_bytes(ntaps, Cin, Cout, prec) + 16;
+  return pack_payload_bytes(ntaps, Cin, Cout, prec) + LADDER_ABSMAX_FLOATS * sizeof(float);
 }
 
 int ladder_filter_pack_split(const float* w, void* packed, int ntaps, int Cin, int Cout, int transpose_flip, int prec,
@@ -537,8 +538,8 @@ int ladder_filter_pack_split(const float* w, void* packed, int ntaps, int Cin, i
 
 int ladder_conv3x3_split_eligible(int N, int H, int W, int Cin, int Cout) { return split_halo_ok(N, H, W, Cin, Cout) ? 1 : 0; }
 
-int ladder_conv3x3_split(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, int N, int H, int W,
-                         int Cin, int Cout, int act, int prec, ladder_stream_t stream) {
+int ladder_conv3x3_split(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, float* y_absmax, int N,
+                         int H, int W, int Cin, int Cout, int act, int prec, ladder_stream_t stream) {
   if (!split_halo_ok(N, H, W, Cin, Cout) || !prec_ok(prec)) return LADDER_E_SHAPE;
   if (!ladder_aligned16(x) || !ladder_aligned16(packed) || !ladder_aligned16(y)) return LADDER_E_ALIGN;
   if (prec == LADDER_PREC_F16X3 && x_absmax == nullptr) return LADDER_E_SHAPE;
@@ -546,8 +547,9 @@ int ladder_conv3x3_split(const float* x, const float* x_absmax, const void* pack
   const int tiles_m = N * (H / SP_H) * (W / SP_W);
   const dim3 grid(tiles_m * tiles_n), block(SP_THREADS);
   const float* wamax = reinterpret_cast<const float*>(static_cast<const unsigned char*>(packed) + pack_payload_bytes(9, Cin, Cout, prec));
+  if (y_absmax != nullptr && hipMemsetAsync(y_absmax, 0, LADDER_ABSMAX_FLOATS * sizeof(float), stream) != hipSuccess) return LADDER_E_LAUNCH;
 #define LADDER_SPLIT_LAUNCH(P_) \
-  hipLaunchKernelGGL(conv3x3_halo_split_kernel<P_>, grid, block, 0, stream, x, (const uint4*)packed, bias, y, N, H, W, Cin, Cout, act, tiles_n, x_absmax, wamax)
+  hipLaunchKernelGGL(conv3x3_halo_split_kernel<P_>, grid, block, 0, stream, x, (const uint4*)packed, bias, y, N, H, W, Cin, Cout, act, tiles_n, x_absmax, wamax, y_absmax)
   if (prec == LADDER_PREC_F16X3) LADDER_SPLIT_LAUNCH(LADDER_PREC_F16X3);
   else if (prec == LADDER_PREC_BF16X6) LADDER_SPLIT_LAUNCH(LADDER_PREC_BF16X6);
   else LADDER_SPLIT_LAUNCH(LADDER_PREC_BF16X3);

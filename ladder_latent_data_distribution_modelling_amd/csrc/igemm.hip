@@ -359,8 +359,8 @@ __global__ __launch_bounds__(kThreads, 2) void igemm_fwd_split_kernel(const floa
   const int nslabs16 = d.Cin / 16;
   float cx = 1.f, unscale = 1.f;
   if (F16) {
-    cx = scale_from_absmax(*xamax);
-    unscale = 1.f / (cx * scale_from_absmax(*wamax));
+    cx = scale_from_absmax(amax_load(xamax));
+    unscale = 1.f / (cx * scale_from_absmax(amax_load(wamax)));
   }
 
   const float* a_ptr[AU];
@@ -735,8 +735,8 @@ __global__ __launch_bounds__(kThreads, 2) void igemm_wgrad_split_kernel(const fl
   const int tr = tap / d.KW, ts = tap - tr * d.KW;
   float cx = 1.f, cd = 1.f;
   if (F16) {
-    cx = scale_from_absmax(*xamax);
-    cd = scale_from_absmax(*damax);
+    cx = scale_from_absmax(amax_load(xamax));
+    cd = scale_from_absmax(amax_load(damax));
   }
   const bool do_bias = (bias_part != nullptr) && (tile / tiles_n == 0) && wm == 0;
   float bsum[2] = {0.f, 0.f};
@@ -1397,7 +1397,9 @@ template <int COUT, bool BWD>
 __global__ __launch_bounds__(256) void conv1x1_smallcout_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                 const float* __restrict__ bias, float* __restrict__ y,
                                                                 const float* __restrict__ dy, float* __restrict__ dx,
-                                                                float* __restrict__ part, int Cin, int act, int M) {
+                                                                float* __restrict__ part, int Cin, int act, int M,
+                                                                float* __restrict__ dxamax) {
+  float dmax = 0.f;                                 // max |dx| written by this thread (backward, optional absmax record)
   const int cq = Cin >> 2;                          // channel quads per pixel (power of two, 4..64)
   const int q = threadIdx.x & (cq - 1), pl = threadIdx.x / cq, ppb = 256 / cq;
   float4 wr[COUT];                                  // wr[o] = w[4q..4q+3][o]
@@ -1456,6 +1458,7 @@ __global__ __launch_bounds__(256) void conv1x1_smallcout_kernel(const float* __r
           d4.x *= ladder_act_grad_from_out(xv.x, act); d4.y *= ladder_act_grad_from_out(xv.y, act);
           d4.z *= ladder_act_grad_from_out(xv.z, act); d4.w *= ladder_act_grad_from_out(xv.w, act);
           *reinterpret_cast<float4*>(dx + (size_t)m * Cin + q * 4) = d4;
+          dmax = fmaxf(fmaxf(dmax, fmaxf(fabsf(d4.x), fabsf(d4.y))), fmaxf(fabsf(d4.z), fabsf(d4.w)));
         }
       }
     }
@@ -1484,6 +1487,7 @@ __global__ __launch_bounds__(256) void conv1x1_smallcout_kernel(const float* __r
       }
       __syncthreads();
     }
+    if (dxamax != nullptr) amax_commit_block(dmax, dxamax);
   }
 }
 
@@ -1817,7 +1821,7 @@ int ladder_conv2d_fwd(const float* x, const float* w, const float* bias, float* 
   if (smallcout_eligible(Cin, Cout, KH, KW, stride, (long)N * Ho * Wo) && ladder_aligned16(x)) {
     const int M = N * Ho * Wo, blocks = smallcout_blocks(M, Cin);
 #define LADDER_SCO_FWD(CO_) hipLaunchKernelGGL((conv1x1_smallcout_kernel<CO_, false>), dim3(blocks), dim3(256), 0, stream, x, w, bias, y, \
-                                               (const float*)nullptr, (float*)nullptr, (float*)nullptr, Cin, act, M)
+                                               (const float*)nullptr, (float*)nullptr, (float*)nullptr, Cin, act, M, (float*)nullptr)
     switch (Cout) { case 1: LADDER_SCO_FWD(1); break; case 2: LADDER_SCO_FWD(2); break; case 3: LADDER_SCO_FWD(3); break; default: LADDER_SCO_FWD(4); }
 #undef LADDER_SCO_FWD
     LADDER_CHECK_LAUNCH();
@@ -2079,13 +2083,20 @@ size_t ladder_conv1x1_smallcout_bwd_workspace_bytes(long M, int Cin, int Cout) {
 
 int ladder_conv1x1_smallcout_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long M, int Cin,
                                  int Cout, int gate_act, void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  return ladder_conv1x1_smallcout_bwd_absmax(x, dy, w, dx, dw, db, M, Cin, Cout, gate_act, ws, ws_bytes, nullptr, stream);
+}
+
+int ladder_conv1x1_smallcout_bwd_absmax(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long M, int Cin,
+                                        int Cout, int gate_act, void* ws, size_t ws_bytes, float* dx_absmax, ladder_stream_t stream) {
   if (!smallcout_eligible(Cin, Cout, 1, 1, 1, M)) return LADDER_E_SHAPE;
+  if (dx_absmax != nullptr && (dx == nullptr || hipMemsetAsync(dx_absmax, 0, LADDER_ABSMAX_FLOATS * sizeof(float), stream) != hipSuccess))
+    return LADDER_E_SHAPE;
   if (!ladder_aligned16(x) || (dx != nullptr && !ladder_aligned16(dx))) return LADDER_E_ALIGN;
   if (ws == nullptr || ws_bytes < ladder_conv1x1_smallcout_bwd_workspace_bytes(M, Cin, Cout)) return LADDER_E_WORKSPACE;
   const int blocks = smallcout_blocks(M, Cin), kn = Cin * Cout;
   float* part = (float*)ws;
 #define LADDER_SCO_BWD(CO_) hipLaunchKernelGGL((conv1x1_smallcout_kernel<CO_, true>), dim3(blocks), dim3(256), 0, stream, x, w, (const float*)nullptr, \
-                                               (float*)nullptr, dy, dx, part, Cin, gate_act, (int)M)
+                                               (float*)nullptr, dy, dx, part, Cin, gate_act, (int)M, dx_absmax)
   switch (Cout) { case 1: LADDER_SCO_BWD(1); break; case 2: LADDER_SCO_BWD(2); break; case 3: LADDER_SCO_BWD(3); break; default: LADDER_SCO_BWD(4); }
 #undef LADDER_SCO_BWD
   // partial layout per block: [Cin*Cout filter gradient | Cout bias gradient]

@@ -327,12 +327,18 @@ __global__ void in_finalize_kernel(const float* __restrict__ x, const float* __r
 
 __global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__ x, const float* __restrict__ style,
                                                        const float* __restrict__ mean_rstd, float* __restrict__ y, int HW, int C,
-                                                       int act, int split) {
+                                                       int act, int split, float* __restrict__ yamax) {
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int n = blockIdx.y, c = blockIdx.x * 64 + cq * 4, sp = blockIdx.z;
-  if (c >= C) return;
+  const int n = blockIdx.y, sp = blockIdx.z;
+  int c = blockIdx.x * 64 + cq * 4;
+  const bool live = c < C;
+  if (!live) {
+    if (yamax == nullptr) return;
+    c = 0;                                       // (keeps the loads in range; the thread stores nothing and contributes max 0)
+  }
+  float ymax = 0.f;
   const size_t base = (size_t)n * HW * C;
-  const int per = (HW + split - 1) / split, r0 = sp * per, r1 = min(HW, r0 + per);
+  const int per = (HW + split - 1) / split, r0 = sp * per, r1 = live ? min(HW, r0 + per) : r0;
   const float4 mu = *reinterpret_cast<const float4*>(mean_rstd + (size_t)n * 2 * C + c);
   const float4 rs = *reinterpret_cast<const float4*>(mean_rstd + (size_t)n * 2 * C + C + c);
   float4 s0 = *reinterpret_cast<const float4*>(style + (size_t)n * 2 * C + c);
@@ -347,7 +353,9 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__
     o.z = ladder_act_fn((v.z - mu.z) * rs.z * s0.z + s1.z, act);
     o.w = ladder_act_fn((v.w - mu.w) * rs.w * s0.w + s1.w, act);
     *reinterpret_cast<float4*>(y + i) = o;
+    ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
   }
+  if (yamax != nullptr) amax_commit_block(ymax, yamax);
 }
 
 // backward statistics: part[.,0] = sum dp*xhat, part[.,1] = sum dp
@@ -401,12 +409,18 @@ __global__ void in_bwd_finalize_kernel(const float* __restrict__ part, float* __
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ style, const float* __restrict__ mean_rstd,
                                                            const float* __restrict__ dstyle, float* __restrict__ dx, int HW, int C,
-                                                           int act, int split) {
+                                                           int act, int split, float* __restrict__ dxamax) {
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int n = blockIdx.y, c = blockIdx.x * 64 + cq * 4, sp = blockIdx.z;
-  if (c >= C) return;
+  const int n = blockIdx.y, sp = blockIdx.z;
+  int c = blockIdx.x * 64 + cq * 4;
+  const bool live = c < C;
+  if (!live) {
+    if (dxamax == nullptr) return;
+    c = 0;
+  }
+  float omax = 0.f;
   const size_t base = (size_t)n * HW * C;
-  const int per = (HW + split - 1) / split, r0 = sp * per, r1 = min(HW, r0 + per);
+  const int per = (HW + split - 1) / split, r0 = sp * per, r1 = live ? min(HW, r0 + per) : r0;
   const float inv = 1.f / (float)HW;
   float mu[4], rs[4], s0[4], s1[4], d0[4], d1[4];
 #pragma unroll
@@ -430,7 +444,9 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* __restri
       o[j] = rs[j] * s0[j] * (dp - d1[j] - xh * d0[j]);
     }
     *reinterpret_cast<float4*>(dx + i) = make_float4(o[0], o[1], o[2], o[3]);
+    omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
   }
+  if (dxamax != nullptr) amax_commit_block(omax, dxamax);
 }
 
 inline int in_split(int N, int HW, int C) {
@@ -720,13 +736,23 @@ size_t ladder_in_style_workspace_bytes(int N, int HW, int C) { return (size_t)N 
 
 int ladder_in_style_fwd(const float* x, const float* style, float* y, float* mean_rstd, int N, int HW, int C, float eps, int act,
                         void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  return ladder_in_style_fwd_absmax(x, style, y, mean_rstd, N, HW, C, eps, act, ws, ws_bytes, nullptr, stream);
+}
+
+int ladder_in_style_fwd_absmax(const float* x, const float* style, float* y, float* mean_rstd, int N, int HW, int C, float eps, int act,
+                               void* ws, size_t ws_bytes, float* y_absmax, ladder_stream_t stream) {
   if (N <= 0 || HW <= 0 || C <= 0) return LADDER_E_SHAPE;
+  if (y_absmax != nullptr) {
+    if (!(C % 4 == 0 && ws != nullptr && ws_bytes >= ladder_in_style_workspace_bytes(N, HW, C) && ladder_aligned16(x) && ladder_aligned16(y)))
+      return LADDER_E_SHAPE;                     // the record is produced by the vectorised three-kernel path only
+    if (hipMemsetAsync(y_absmax, 0, LADDER_ABSMAX_FLOATS * sizeof(float), stream) != hipSuccess) return LADDER_E_LAUNCH;
+  }
   if (C % 4 == 0 && ws != nullptr && ws_bytes >= ladder_in_style_workspace_bytes(N, HW, C) && ladder_aligned16(x) && ladder_aligned16(y)) {
     const int sp = in_split(N, HW, C);
     dim3 grid((C + 63) / 64, N, sp);
     hipLaunchKernelGGL(in_stats_kernel, grid, dim3(256), 0, stream, x, (float*)ws, HW, C, sp);
     hipLaunchKernelGGL(in_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, stream, x, (const float*)ws, mean_rstd, N, HW, C, sp, eps);
-    hipLaunchKernelGGL(in_apply_kernel, grid, dim3(256), 0, stream, x, style, (const float*)mean_rstd, y, HW, C, act, sp);
+    hipLaunchKernelGGL(in_apply_kernel, grid, dim3(256), 0, stream, x, style, (const float*)mean_rstd, y, HW, C, act, sp, y_absmax);
     LADDER_CHECK_LAUNCH();
     return LADDER_OK;
   }
@@ -737,14 +763,25 @@ int ladder_in_style_fwd(const float* x, const float* style, float* y, float* mea
 
 int ladder_in_style_bwd(const float* dy, const float* x, const float* style, const float* mean_rstd, float* dx, float* dstyle,
                         int N, int HW, int C, int act, void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  return ladder_in_style_bwd_absmax(dy, x, style, mean_rstd, dx, dstyle, N, HW, C, act, ws, ws_bytes, nullptr, stream);
+}
+
+int ladder_in_style_bwd_absmax(const float* dy, const float* x, const float* style, const float* mean_rstd, float* dx, float* dstyle,
+                               int N, int HW, int C, int act, void* ws, size_t ws_bytes, float* dx_absmax, ladder_stream_t stream) {
   if (N <= 0 || HW <= 0 || C <= 0) return LADDER_E_SHAPE;
+  if (dx_absmax != nullptr) {
+    if (!(C % 4 == 0 && ws != nullptr && ws_bytes >= ladder_in_style_workspace_bytes(N, HW, C) && ladder_aligned16(x) && ladder_aligned16(dy) &&
+          ladder_aligned16(dx)))
+      return LADDER_E_SHAPE;
+    if (hipMemsetAsync(dx_absmax, 0, LADDER_ABSMAX_FLOATS * sizeof(float), stream) != hipSuccess) return LADDER_E_LAUNCH;
+  }
   if (C % 4 == 0 && ws != nullptr && ws_bytes >= ladder_in_style_workspace_bytes(N, HW, C) && ladder_aligned16(x) && ladder_aligned16(dy) &&
       ladder_aligned16(dx)) {
     const int sp = in_split(N, HW, C);
     dim3 grid((C + 63) / 64, N, sp);
     hipLaunchKernelGGL(in_bwd_stats_kernel, grid, dim3(256), 0, stream, dy, x, style, mean_rstd, (float*)ws, HW, C, act, sp);
     hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dstyle, N, C, sp);
-    hipLaunchKernelGGL(in_bwd_apply_kernel, grid, dim3(256), 0, stream, dy, x, style, mean_rstd, (const float*)dstyle, dx, HW, C, act, sp);
+    hipLaunchKernelGGL(in_bwd_apply_kernel, grid, dim3(256), 0, stream, dy, x, style, mean_rstd, (const float*)dstyle, dx, HW, C, act, sp, dx_absmax);
     LADDER_CHECK_LAUNCH();
     return LADDER_OK;
   }

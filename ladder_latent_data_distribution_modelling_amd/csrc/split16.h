@@ -76,7 +76,7 @@ __device__ __forceinline__ f32x16 mfma16(const uint4 a, const uint4 b, const f32
 }
 
 // Bytes of the split filter image [tap][Cin/16][ceil(Cout/128)][plane][2][128][8 x 16 bit] (convsplit.hip: filter_pack_kernel); the
-// filter's absolute maximum (f16x3 scale) is stored in the 16 bytes behind it.
+// filter's absolute-maximum record (f16x3 scale; LADDER_ABSMAX_FLOATS floats) is stored behind it.
 inline size_t pack_payload_bytes(int ntaps, int Cin, int Cout, int prec) {
   return (size_t)ntaps * (Cin / 16) * ((Cout + 127) / 128) * prec_planes(prec) * 4096;
 }

@@ -161,6 +161,7 @@ class Ctx:
         self.comm = comm or Comm()
         self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
         self._ws_retired, self.ws_generation = [], 0
+        self._amax = {}      # id(tensor) -> (weakref, absolute-maximum record)
         self.ns = 0          # LADDER_PREC_* of the split-precision contraction kernels (0 = native f32 MFMA); set by the engine
 
     @property
@@ -180,13 +181,37 @@ class Ctx:
     def empty(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
 
+    # -- absolute-maximum records of the f16x3 split kernels (include/ladder_hip.h: ladder_absmax) --------------------------------
+    # Producers that can compute max|y| while they write y (split conv epilogue, instance-norm apply, ...) register the record
+    # for the tensor object; consumers look it up and fall back to a standalone pass over the tensor.  Entries are keyed by the
+    # tensor OBJECT (dropped when it is collected), never by address: a view / reshape is a different object and simply misses.
+    def new_amax(self):
+        return torch.empty(L.ABSMAX_FLOATS, dtype=torch.float32, device=self.device)
+
+    def set_amax(self, t, rec):
+        if self.ns == 4 and rec is not None:
+            import weakref
+            k, reg = id(t), self._amax
+            reg[k] = (weakref.ref(t, lambda _r, k=k, reg=reg: reg.pop(k, None)), rec)
+
+    def known_amax(self, t):
+        e = self._amax.get(id(t))
+        return e[1] if e is not None and e[0]() is t else None
+
+    def drop_amax(self, t):
+        self._amax.pop(id(t), None)
+
     def absmax(self, t):
-        """Device scalar max|t| (the per-tensor scale of the f16x3 split kernels); None when the precision mode needs none."""
+        """Absolute-maximum record of `t` (an upper bound is as good: it only moves the 2^-38 representation floor); None when
+        the precision mode needs none."""
         if self.ns != 4:
             return None
-        out = torch.empty(4, dtype=torch.float32, device=self.device)
-        L.call("ladder_absmax", _p(t), t.numel(), _p(out), self.stream)
-        return out
+        rec = self.known_amax(t)
+        if rec is None:
+            rec = self.new_amax()
+            L.call("ladder_absmax", _p(t), t.numel(), _p(rec), self.stream)
+            self.set_amax(t, rec)
+        return rec
 
     def zeros(self, *shape):
         return torch.zeros(*shape, dtype=torch.float32, device=self.device)
@@ -324,8 +349,10 @@ class Conv2D:
         self.x_amax = None
         if self._split_ok(N, H, W, self.cin, self.cout):
             self.x_amax = self.ctx.absmax(x)
-            args = (_p(x), _p(self.x_amax), _p(self._packed_filter(0)), _p(self.ps.w[self.name + "/bias"]), _p(y), N, H, W, self.cin,
-                    self.cout, L.ACT[self.act], self.ctx.ns, self.ctx.stream)
+            y_amax = self.ctx.new_amax() if self.ctx.ns == 4 else None
+            args = (_p(x), _p(self.x_amax), _p(self._packed_filter(0)), _p(self.ps.w[self.name + "/bias"]), _p(y), _p(y_amax), N, H, W,
+                    self.cin, self.cout, L.ACT[self.act], self.ctx.ns, self.ctx.stream)
+            self.ctx.set_amax(y, y_amax)
             _timed(256120 + self.ctx.ns, 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_split", args)
             self.x, self.y = x, y
             return y
@@ -364,9 +391,12 @@ class Conv2D:
             M = N * H * W
             wsp, wsn = self.ctx.ws(L.query("ladder_conv1x1_smallcout_bwd_workspace_bytes", M, self.cin, self.cout))
             dx = self.ctx.empty(N, H, W, self.cin) if need_dx else None
-            L.call("ladder_conv1x1_smallcout_bwd", _p(x), _p(dy), _p(self.ps.w[self.name + "/kernel"]), _p(dx),
+            dx_amax = self.ctx.new_amax() if (need_dx and self.ctx.ns == 4) else None
+            L.call("ladder_conv1x1_smallcout_bwd_absmax", _p(x), _p(dy), _p(self.ps.w[self.name + "/kernel"]), _p(dx),
                    _p(self.ps.g[self.name + "/kernel"]), _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, M, self.cin,
-                   self.cout, L.ACT[gate_prev] if gate_prev else 0, wsp, wsn, st)
+                   self.cout, L.ACT[gate_prev] if gate_prev else 0, wsp, wsn, _p(dx_amax), st)
+            if dx is not None:
+                self.ctx.set_amax(dx, dx_amax)
             self.x = self.y = None
             return dx
         dy_amax = None
@@ -409,8 +439,10 @@ class Conv2D:
         dx = None
         if split_d:
             dx = self.ctx.empty(N, H, W, self.cin)
-            args = (_p(dy), _p(dy_amax), _p(self._packed_filter(1)), None, _p(dx), N, H, W, self.cout, self.cin, 0,
+            dx_amax = self.ctx.new_amax() if self.ctx.ns == 4 else None
+            args = (_p(dy), _p(dy_amax), _p(self._packed_filter(1)), None, _p(dx), _p(dx_amax), N, H, W, self.cout, self.cin, 0,
                     self.ctx.ns, st)
+            self.ctx.set_amax(dx, dx_amax)
             _timed(256120 + self.ctx.ns, 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_split", args)
         elif need_dx and self.ctx.ns and L.query("ladder_conv2d_bwd_data_split_eligible", N, H, W, self.cin, Ho, Wo, self.cout, self.k,
                                                  self.k, self.stride, self.pt, self.pl, 1 if gate_prev else 0):
@@ -529,8 +561,10 @@ class InstanceNormStyleAct:
         y = torch.empty_like(x)
         self.mean_rstd = self.ctx.empty(N, 2 * C)
         wsp, wsn = self.ctx.ws(L.query("ladder_in_style_workspace_bytes", N, H * W, C))
-        L.call("ladder_in_style_fwd", _p(x), _p(style), _p(y), _p(self.mean_rstd), N, H * W, C, IN_EPS, L.ACT[self.act],
-               wsp, wsn, self.ctx.stream)
+        y_amax = self.ctx.new_amax() if (self.ctx.ns == 4 and C % 4 == 0) else None
+        L.call("ladder_in_style_fwd_absmax", _p(x), _p(style), _p(y), _p(self.mean_rstd), N, H * W, C, IN_EPS, L.ACT[self.act],
+               wsp, wsn, _p(y_amax), self.ctx.stream)
+        self.ctx.set_amax(y, y_amax)
         self.x, self.style = x, style
         return y
 
@@ -540,8 +574,10 @@ class InstanceNormStyleAct:
         dx = torch.empty_like(x)
         dstyle = self.ctx.empty(N, 2 * C)
         wsp, wsn = self.ctx.ws(L.query("ladder_in_style_workspace_bytes", N, H * W, C))
-        L.call("ladder_in_style_bwd", _p(dy), _p(x), _p(self.style), _p(self.mean_rstd), _p(dx), _p(dstyle), N, H * W, C,
-               L.ACT[self.act], wsp, wsn, self.ctx.stream)
+        dx_amax = self.ctx.new_amax() if (self.ctx.ns == 4 and C % 4 == 0) else None
+        L.call("ladder_in_style_bwd_absmax", _p(dy), _p(x), _p(self.style), _p(self.mean_rstd), _p(dx), _p(dstyle), N, H * W, C,
+               L.ACT[self.act], wsp, wsn, _p(dx_amax), self.ctx.stream)
+        self.ctx.set_amax(dx, dx_amax)
         self.x = self.style = None
         return dx, dstyle
 
@@ -559,6 +595,7 @@ class Resize:
             return x
         y = self.ctx.empty(N, self.oh, self.ow, C)
         L.call("ladder_resize_bilinear_fwd", _p(x), _p(y), N, H, W, C, self.oh, self.ow, self.ctx.stream)
+        self.ctx.set_amax(y, self.ctx.known_amax(x))        # bilinear interpolation is a convex combination: max|y| <= max|x|
         return y
 
     def backward(self, dy):
@@ -567,6 +604,9 @@ class Resize:
             return dy
         dx = self.ctx.empty(N, H, W, C)
         L.call("ladder_resize_bilinear_bwd", _p(dy), _p(dx), N, H, W, C, self.oh, self.ow, self.ctx.stream)
+        rec = self.ctx.known_amax(dy)
+        if rec is not None:      # the transpose sums interpolation weights: every column sum is <= (oh/H) * (ow/W)
+            self.ctx.set_amax(dx, rec * float((self.oh // H) * (self.ow // W)))
         return dx
 
 
@@ -598,6 +638,7 @@ def pad_symmetric(ctx, x, p):
 
 def add_(ctx, out, inp):
     L.call("ladder_axpy", _p(inp), _p(out), out.numel(), 1.0, 1, ctx.stream)
+    ctx.drop_amax(out)                       # values changed in place: a registered absolute-maximum record no longer bounds them
     return out
 
 

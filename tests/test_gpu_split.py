@@ -41,7 +41,8 @@ def close(got, ref, rtol, what=""):
 
 
 def absmax(L, t, st):
-    out = torch.empty(4, device="cuda")
+    """Absolute-maximum record (LADDER_ABSMAX_FLOATS floats; the value is the maximum over its slots)."""
+    out = torch.empty(L.ABSMAX_FLOATS, device="cuda")
     L.call("ladder_absmax", p(t), t.numel(), p(out), st)
     return out
 
@@ -55,10 +56,10 @@ def test_absmax_is_exact(gpu_ctx, n):
     if n % 2 == 0:
         x = (x * 1e-33).astype(np.float32)
     xd = dev(x)
-    got = absmax(L, xd, gpu_ctx.stream)[0].item()
+    got = absmax(L, xd, gpu_ctx.stream).max().item()
     assert got == float(np.abs(x).max())
     z = torch.zeros(n, device="cuda")
-    assert absmax(L, z, gpu_ctx.stream)[0].item() == 0.0
+    assert absmax(L, z, gpu_ctx.stream).max().item() == 0.0
 
 
 def _fill(rng, shape, kind):
@@ -109,12 +110,14 @@ def test_conv3x3_split_fwd_bwd(gpu_ctx, case, prec):
     L.call("ladder_filter_pack_split", p(wd), p(pk), 9, Cin, Cout, 0, P, st)
     xa = absmax(L, xd, st)
     y = torch.empty(N, H, W, Cout, device="cuda")
-    L.call("ladder_conv3x3_split", p(xd), p(xa), p(pk), p(bd), p(y), N, H, W, Cin, Cout, L.ACT[act], P, st)
+    ya = torch.full((L.ABSMAX_FLOATS,), 7.0, device="cuda")          # (the call zeroes the record before filling it)
+    L.call("ladder_conv3x3_split", p(xd), p(xa), p(pk), p(bd), p(y), p(ya), N, H, W, Cin, Cout, L.ACT[act], P, st)
     close(y, yr, tf, "fwd")
+    assert ya.max().item() == y.abs().max().item()                   # the fused output record is exact
     # a looser (x8) absmax bound only moves the representation floor
     if prec == "f16x3":
         y2 = torch.empty_like(y)
-        L.call("ladder_conv3x3_split", p(xd), p(xa * 8), p(pk), p(bd), p(y2), N, H, W, Cin, Cout, L.ACT[act], P, st)
+        L.call("ladder_conv3x3_split", p(xd), p(xa * 8), p(pk), p(bd), p(y2), None, N, H, W, Cin, Cout, L.ACT[act], P, st)
         close(y2, yr, tf, "fwd with a x8 absmax bound")
     dyd = dev(dy)
     if act is not None:
@@ -125,7 +128,7 @@ def test_conv3x3_split_fwd_bwd(gpu_ctx, case, prec):
         pkT = torch.empty(L.query("ladder_filter_pack_split_bytes", 9, Cout, Cin, P), dtype=torch.uint8, device="cuda")
         L.call("ladder_filter_pack_split", p(wd), p(pkT), 9, Cout, Cin, 1, P, st)
         dx = torch.empty_like(xd)
-        L.call("ladder_conv3x3_split", p(dyd), p(da), p(pkT), None, p(dx), N, H, W, Cout, Cin, 0, P, st)
+        L.call("ladder_conv3x3_split", p(dyd), p(da), p(pkT), None, p(dx), None, N, H, W, Cout, Cin, 0, P, st)
         close(dx, xt.grad, tb, "dx")
     if L.query("ladder_conv3x3_wgrad_split_eligible", N, H, W, Cin, Cout, P):
         wsp, wsn = gpu_ctx.ws(L.query("ladder_conv3x3_wgrad_split_workspace_bytes", N, H, W, Cin, Cout))
@@ -224,15 +227,15 @@ def test_split_abi_errors(gpu_ctx):
     x = torch.zeros(32 * 64 * 64 * 32 + 4, device="cuda")
     pk = torch.empty(L.query("ladder_filter_pack_split_bytes", 9, 32, 128, 4), dtype=torch.uint8, device="cuda")
     y = torch.empty(32 * 64 * 64 * 128, device="cuda")
-    am = torch.zeros(4, device="cuda")
+    am = torch.zeros(L.ABSMAX_FLOATS, device="cuda")
     assert L.query("ladder_filter_pack_split_bytes", 9, 24, 128, 4) == 0             # Cin % 16 != 0
     assert L.query("ladder_filter_pack_split_bytes", 9, 32, 128, 1) == 0             # unknown precision
     assert lib.ladder_filter_pack_split(p(x), p(pk), 9, 24, 128, 0, 4, st) == -1
-    assert lib.ladder_conv3x3_split(p(x), p(am), p(pk), None, p(y), 32, 64, 64, 32, 128, 0, 7, st) == -1      # precision
-    assert lib.ladder_conv3x3_split(p(x), p(am), p(pk), None, p(y), 32, 60, 64, 32, 128, 0, 4, st) == -1      # H % 8
-    assert lib.ladder_conv3x3_split(p(x), None, p(pk), None, p(y), 32, 64, 64, 32, 128, 0, 4, st) == -1       # f16x3 needs the scale
-    assert lib.ladder_conv3x3_split(p(x) + 4, p(am), p(pk), None, p(y), 32, 64, 64, 32, 128, 0, 4, st) == -2   # alignment
-    assert lib.ladder_conv3x3_split(p(x), None, p(pk), None, p(y), 32, 64, 64, 32, 128, 0, 3, st) == 0        # bf16 needs none
+    assert lib.ladder_conv3x3_split(p(x), p(am), p(pk), None, p(y), None, 32, 64, 64, 32, 128, 0, 7, st) == -1      # precision
+    assert lib.ladder_conv3x3_split(p(x), p(am), p(pk), None, p(y), None, 32, 60, 64, 32, 128, 0, 4, st) == -1      # H % 8
+    assert lib.ladder_conv3x3_split(p(x), None, p(pk), None, p(y), None, 32, 64, 64, 32, 128, 0, 4, st) == -1       # f16x3 needs the scale
+    assert lib.ladder_conv3x3_split(p(x) + 4, p(am), p(pk), None, p(y), None, 32, 64, 64, 32, 128, 0, 4, st) == -2   # alignment
+    assert lib.ladder_conv3x3_split(p(x), None, p(pk), None, p(y), None, 32, 64, 64, 32, 128, 0, 3, st) == 0        # bf16 needs none
     assert L.query("ladder_conv3x3_wgrad_split_eligible", 32, 64, 64, 64, 128, 3) == 0          # three planes do not fit LDS
     assert L.query("ladder_conv3x3_wgrad_split_eligible", 32, 64, 64, 64, 128, 4) == 1
     assert L.query("ladder_conv3x3_wgrad_split_eligible", 32, 63, 64, 64, 128, 4) == 0          # H % 2
@@ -243,3 +246,32 @@ def test_split_abi_errors(gpu_ctx):
     assert lib.ladder_conv2d_fwd_split_eligible(2, 16, 16, 64, 16, 16, 256, 3, 3, 1, 1, 1) == 0                # too few tiles for 128x128
     assert lib.ladder_conv2d_fwd_split_eligible(48, 16, 16, 48, 16, 16, 256, 3, 3, 1, 1, 1) == 0               # Cin % 32
     torch.cuda.synchronize()
+
+
+def test_fused_absmax_records_of_producers(gpu_ctx):
+    """The producers that hand an absolute-maximum record to the next split convolution -- instance-norm apply (forward and
+    backward) and the fused backward of the 1x1 output convolution -- must report exactly max |tensor written|."""
+    L = _lib()
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(5)
+    N, H, W, C = 3, 16, 16, 72                                   # C % 64 != 0: part of the last channel group is idle
+    x, style = dev(rng.standard_normal((N, H, W, C))), dev(rng.standard_normal((N, 2 * C)) * 0.3)
+    dy = dev(rng.standard_normal((N, H, W, C)) * 1e-3)
+    y, mr = torch.empty_like(x), torch.empty(N, 2 * C, device="cuda")
+    wsp, wsn = gpu_ctx.ws(L.query("ladder_in_style_workspace_bytes", N, H * W, C))
+    rec = torch.empty(L.ABSMAX_FLOATS, device="cuda")
+    L.call("ladder_in_style_fwd_absmax", p(x), p(style), p(y), p(mr), N, H * W, C, 1e-6, 1, wsp, wsn, p(rec), st)
+    y0 = torch.empty_like(x)
+    L.call("ladder_in_style_fwd", p(x), p(style), p(y0), p(mr), N, H * W, C, 1e-6, 1, wsp, wsn, st)
+    assert torch.equal(y, y0) and rec.max().item() == y.abs().max().item()
+    dx, dx0, ds = torch.empty_like(x), torch.empty_like(x), torch.empty(N, 2 * C, device="cuda")
+    L.call("ladder_in_style_bwd_absmax", p(dy), p(x), p(style), p(mr), p(dx), p(ds), N, H * W, C, 1, wsp, wsn, p(rec), st)
+    L.call("ladder_in_style_bwd", p(dy), p(x), p(style), p(mr), p(dx0), p(ds), N, H * W, C, 1, wsp, wsn, st)
+    assert torch.equal(dx, dx0) and rec.max().item() == dx.abs().max().item()
+    M, Cin, Cout = 8 * 128 * 128, 128, 3
+    xs, dys, w = dev(rng.standard_normal((M, Cin))), dev(rng.standard_normal((M, Cout))), dev(rng.standard_normal((Cin, Cout)) * 0.1)
+    dxs, dxs0, dw, db = torch.empty_like(xs), torch.empty_like(xs), torch.empty_like(w), torch.empty(Cout, device="cuda")
+    wsp, wsn = gpu_ctx.ws(L.query("ladder_conv1x1_smallcout_bwd_workspace_bytes", M, Cin, Cout))
+    L.call("ladder_conv1x1_smallcout_bwd_absmax", p(xs), p(dys), p(w), p(dxs), p(dw), p(db), M, Cin, Cout, 1, wsp, wsn, p(rec), st)
+    L.call("ladder_conv1x1_smallcout_bwd", p(xs), p(dys), p(w), p(dxs0), p(dw), p(db), M, Cin, Cout, 1, wsp, wsn, st)
+    assert torch.equal(dxs, dxs0) and rec.max().item() == dxs.abs().max().item()
