@@ -111,8 +111,10 @@ constexpr int SP_B_PLANE = 2 * SP_BN * 16;              // bytes per plane (4096
 constexpr int SP_HALO_UNITS = SP_NPIX * 4;              // float4 units per slab (1360)
 constexpr int SP_AU = (SP_HALO_UNITS + SP_THREADS - 1) / SP_THREADS;   // 3
 
+// (two-plane formats: 128 registers and < 80 KB of LDS, so that TWO workgroups share a CU and one's staging / barrier phase hides behind
+// the other's MFMAs; the 9 taps are fully unrolled: fragment addresses become immediates, ~4 VALU instructions per tap are left)
 template <int PREC>
-__global__ __launch_bounds__(SP_THREADS, 2) void conv3x3_halo_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
+__global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x3_halo_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                                           const int N, const int H, const int W, const int Cin,
                                                                           const int Cout, const int act, const int tiles_n,
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void conv3x3_halo_split_kernel(const
   int bbuf = 0;
   for (int slab = 0; slab < nslabs; ++slab) {
     const int hb = slab & 1;
-#pragma unroll 1
+#pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const bool last = (slab + 1 == nslabs) && (tap == 8);
       if (!last) load_b(tap == 8 ? slab + 1 : slab, tap == 8 ? 0 : tap + 1);
