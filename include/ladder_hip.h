@@ -125,6 +125,14 @@ int ladder_conv3x3_split_eligible(int N, int H, int W, int Cin, int Cout);
 int ladder_conv3x3_split(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, float* y_absmax, int N,
                          int H, int W, int Cin, int Cout, int act, int prec, ladder_stream_t stream);
 
+/* The same convolution with a FUSED 1x1 projection of its activated output to proj_cout <= 4 channels (Cout <= 128 so that a workgroup
+ * holds all channels of its pixels): proj_out[n,h,w,o] = proj_b[o] + sum_c y[n,h,w,c] * proj_w[c][o] -- the CelebA decoder's last 3x3
+ * conv + its 1x1 output conv (codes/models.py:573-586) in one launch.  y may be NULL: a forward-only evaluation (RUN#2, val_step)
+ * then never writes nor re-reads the 128-channel full-resolution activation. */
+int ladder_conv3x3_split_proj(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, const float* proj_w,
+                              const float* proj_b, float* proj_out, int proj_cout, int N, int H, int W, int Cin, int Cout, int act,
+                              int prec, ladder_stream_t stream);
+
 /* The gather kernel on split operands: every other large convolution (128x128 output tiles; gathered channels % 32 == 0; tap table
  * <= 28 taps), i.e. the strided encoder layers and the 8x8 / 16x16 decoder maps (codes/models.py:398-460, 522-547) and their
  * backward-data passes (stride 2: the four output-parity classes).  Same semantics as ladder_conv2d_fwd / ladder_conv2d_bwd_data with

@@ -119,7 +119,9 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
                                                                           const int N, const int H, const int W, const int Cin,
                                                                           const int Cout, const int act, const int tiles_n,
                                                                           const float* __restrict__ xamax,
-                                                                          const float* __restrict__ wamax, float* __restrict__ yamax) {
+                                                                          const float* __restrict__ wamax, float* __restrict__ yamax,
+                                                                          const float* __restrict__ pw, const float* __restrict__ pb,
+                                                                          float* __restrict__ pout, const int pco) {
   constexpr int NS = Fmt<PREC>::NS;
   constexpr bool F16 = Fmt<PREC>::F16;
   constexpr int A_BUF = NS * SP_A_PLANE, B_BUF = NS * SP_B_PLANE;
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma16<F16>(a[mi][pa], b[ni][pb], acc[mi][ni]);
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma16<F16>(b[ni][pb], a[mi][pa], acc[mi][ni]);   // D^T: lane = pixel, registers = channels
         }
       if (tap == 4 && slab + 1 < nslabs) store_halo(hb ^ 1);
       if (!last) store_b(bbuf ^ 1);
@@ -238,28 +240,77 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
     }
   }
 
+  // Transposed accumulators (the filter fragment is the MFMA's A operand): lane l31 = pixel of the patch row, register e -> channel
+  // (e & 3) + 8 (e >> 2) + 4 lh of the 32-channel tile, i.e. four consecutive channels per register quad = one 16-byte store, and the
+  // channel sum of the fused 1x1 projection below stays inside the lane.
   float ymax = 0.f;
+  float pacc[2][4];                                          // fused projection: partial sums of this lane's channels, per patch row
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int o = 0; o < 4; ++o) pacc[mi][o] = 0.f;
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
-    const int n = n0 + wn * 64 + ni * 32 + l31;
-    const float bv = (bias != nullptr && n < Cout) ? bias[n] : 0.f;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      const long rowbase = (((long)img * H + h0 + 2 * wm + mi) * W + w0) * Cout;
+      float* yp = y != nullptr ? y + (((long)img * H + h0 + 2 * wm + mi) * W + w0 + l31) * Cout : nullptr;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int px = (e & 3) + 8 * (e >> 2) + 4 * lh;
-        float v = acc[mi][ni][e];
-        if (F16) v *= unscale;
-        v = ladder_act_fn(v + bv, act);
-        if (n < Cout) {
-          y[rowbase + (long)px * Cout + n] = v;
-          ymax = fmaxf(ymax, fabsf(v));
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * lh;
+        if (n < Cout) {                                      // Cout % 4 == 0: a channel quad is inside or outside as a whole
+          float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (bias != nullptr) bv = *reinterpret_cast<const float4*>(bias + n);
+          float4 v = make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
+          if (F16) v = make_float4(v.x * unscale, v.y * unscale, v.z * unscale, v.w * unscale);
+          v = make_float4(ladder_act_fn(v.x + bv.x, act), ladder_act_fn(v.y + bv.y, act), ladder_act_fn(v.z + bv.z, act),
+                          ladder_act_fn(v.w + bv.w, act));
+          if (yp != nullptr) *reinterpret_cast<float4*>(yp + n) = v;
+          ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+          if (pout != nullptr) {                             // 1x1 projection: pw[Cout][pco], pco <= 4
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            if (pco == 3) {                                  // (the RGB output conv) rows n..n+3 = 12 consecutive floats, 16-byte aligned
+              const float4* q = reinterpret_cast<const float4*>(pw + (size_t)n * 3);
+              const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+              const float wq[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+              for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+                for (int o = 0; o < 3; ++o) pacc[mi][o] = fmaf(vv[c4], wq[c4 * 3 + o], pacc[mi][o]);
+            } else {
+#pragma unroll
+              for (int c4 = 0; c4 < 4; ++c4)
+                for (int o = 0; o < pco; ++o) pacc[mi][o] = fmaf(vv[c4], pw[(size_t)(n + c4) * pco + o], pacc[mi][o]);
+            }
+          }
         }
       }
     }
   }
   if (yamax != nullptr) amax_commit_block(ymax, yamax);     // the output's absolute maximum for the next split contraction
+  if (pout != nullptr) {
+    // combine the two half-waves (lh) in registers, the two channel halves (wn) through LDS (free after the main loop), fixed order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);             // [wm 4][mi 2][pixel 32][4]
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int o = 0; o < 4; ++o) pacc[mi][o] += __shfl_xor(pacc[mi][o], 32, 64);
+    if (wn == 1 && lh == 0) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        *reinterpret_cast<float4*>(red + (((wm * 2 + mi) * 32 + l31) * 4)) = make_float4(pacc[mi][0], pacc[mi][1], pacc[mi][2], pacc[mi][3]);
+    }
+    __syncthreads();
+    if (wn == 0 && lh == 0) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const float4 other = *reinterpret_cast<const float4*>(red + (((wm * 2 + mi) * 32 + l31) * 4));
+        const float t[4] = {pacc[mi][0] + other.x, pacc[mi][1] + other.y, pacc[mi][2] + other.z, pacc[mi][3] + other.w};
+        float* op = pout + (((long)img * H + h0 + 2 * wm + mi) * W + w0 + l31) * pco;
+        for (int o = 0; o < pco; ++o) op[o] = t[o] + (pb != nullptr ? pb[o] : 0.f);
+      }
+    }
+  }
 }
 
 // ---- 3x3 filter gradient on split operands -----------------------------------------------------------------------------------
@@ -540,10 +591,14 @@ int ladder_filter_pack_split(const float* w, void* packed, int ntaps, int Cin, i
 
 int ladder_conv3x3_split_eligible(int N, int H, int W, int Cin, int Cout) { return split_halo_ok(N, H, W, Cin, Cout) ? 1 : 0; }
 
-int ladder_conv3x3_split(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, float* y_absmax, int N,
-                         int H, int W, int Cin, int Cout, int act, int prec, ladder_stream_t stream) {
+static int conv3x3_split_launch(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, float* y_absmax,
+                                const float* pw, const float* pb, float* pout, int pco, int N, int H, int W, int Cin, int Cout, int act,
+                                int prec, ladder_stream_t stream) {
   if (!split_halo_ok(N, H, W, Cin, Cout) || !prec_ok(prec)) return LADDER_E_SHAPE;
-  if (!ladder_aligned16(x) || !ladder_aligned16(packed) || !ladder_aligned16(y)) return LADDER_E_ALIGN;
+  if (pout != nullptr && (pw == nullptr || pco < 1 || pco > 4 || Cout > SP_BN || !ladder_aligned16(pw))) return LADDER_E_SHAPE;
+  if (pout == nullptr && y == nullptr) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(x) || !ladder_aligned16(packed) || !ladder_aligned16(y) || (bias != nullptr && !ladder_aligned16(bias)))
+    return LADDER_E_ALIGN;
   if (prec == LADDER_PREC_F16X3 && x_absmax == nullptr) return LADDER_E_SHAPE;
   const int tiles_n = (Cout + SP_BN - 1) / SP_BN;
   const int tiles_m = N * (H / SP_H) * (W / SP_W);
@@ -551,13 +606,27 @@ int ladder_conv3x3_split(const float* x, const float* x_absmax, const void* pack
   const float* wamax = reinterpret_cast<const float*>(static_cast<const unsigned char*>(packed) + pack_payload_bytes(9, Cin, Cout, prec));
   if (y_absmax != nullptr && hipMemsetAsync(y_absmax, 0, LADDER_ABSMAX_FLOATS * sizeof(float), stream) != hipSuccess) return LADDER_E_LAUNCH;
 #define LADDER_SPLIT_LAUNCH(P_) \
-  hipLaunchKernelGGL(conv3x3_halo_split_kernel<P_>, grid, block, 0, stream, x, (const uint4*)packed, bias, y, N, H, W, Cin, Cout, act, tiles_n, x_absmax, wamax, y_absmax)
+  hipLaunchKernelGGL(conv3x3_halo_split_kernel<P_>, grid, block, 0, stream, x, (const uint4*)packed, bias, y, N, H, W, Cin, Cout, act, tiles_n, x_absmax, wamax, y_absmax, \
+                     pw, pb, pout, pco)
   if (prec == LADDER_PREC_F16X3) LADDER_SPLIT_LAUNCH(LADDER_PREC_F16X3);
   else if (prec == LADDER_PREC_BF16X6) LADDER_SPLIT_LAUNCH(LADDER_PREC_BF16X6);
   else LADDER_SPLIT_LAUNCH(LADDER_PREC_BF16X3);
 #undef LADDER_SPLIT_LAUNCH
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
+}
+
+int ladder_conv3x3_split(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, float* y_absmax, int N,
+                         int H, int W, int Cin, int Cout, int act, int prec, ladder_stream_t stream) {
+  return conv3x3_split_launch(x, x_absmax, packed, bias, y, y_absmax, nullptr, nullptr, nullptr, 0, N, H, W, Cin, Cout, act, prec, stream);
+}
+
+int ladder_conv3x3_split_proj(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, const float* proj_w,
+                              const float* proj_b, float* proj_out, int proj_cout, int N, int H, int W, int Cin, int Cout, int act,
+                              int prec, ladder_stream_t stream) {
+  if (proj_out == nullptr) return LADDER_E_SHAPE;
+  return conv3x3_split_launch(x, x_absmax, packed, bias, y, nullptr, proj_w, proj_b, proj_out, proj_cout, N, H, W, Cin, Cout, act, prec,
+                              stream);
 }
 
 // (two-plane formats only: the double-buffered 2x32-pixel patch images of a three-plane format exceed the 160 KB of LDS)

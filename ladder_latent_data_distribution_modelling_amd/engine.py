@@ -162,6 +162,7 @@ class Ctx:
         self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
         self._ws_retired, self.ws_generation = [], 0
         self._amax = {}      # id(tensor) -> (weakref, absolute-maximum record)
+        self.keep_activations = True   # False inside forward-only runs: fused kernels may skip writing tensors only a backward pass reads
         self.ns = 0          # LADDER_PREC_* of the split-precision contraction kernels (0 = native f32 MFMA); set by the engine
 
     @property
@@ -340,6 +341,28 @@ class Conv2D:
                    self.ctx.stream)
             ent[0] = ver
         return ent[1]
+
+    def forward_fused_proj(self, x, proj, keep_y):
+        """This 3x3 conv + activation followed by the 1x1 conv `proj` (<= 4 output channels, no activation) in ONE launch of the split
+        halo kernel (ladder_conv3x3_split_proj); returns proj's output or None when the pair is not eligible.  `keep_y` = the
+        activation is needed later (training forward: both layers' backward read it); a forward-only run never writes it."""
+        N, H, W, _ = x.shape
+        if not (self._split_ok(N, H, W, self.cin, self.cout) and self.cout <= 128 and proj.k == 1 and proj.stride == 1
+                and proj.cout <= 4 and proj.act is None and proj.cin == self.cout):
+            return None
+        self.pt, _ = arch.conv_out(H, self.k, self.stride, self.padding)
+        self.pl, _ = arch.conv_out(W, self.k, self.stride, self.padding)
+        proj.pt = proj.pl = 0
+        y = self.ctx.empty(N, H, W, self.cout) if keep_y else None
+        out = self.ctx.empty(N, H, W, proj.cout)
+        self.x_amax = self.ctx.absmax(x)
+        args = (_p(x), _p(self.x_amax), _p(self._packed_filter(0)), _p(self.ps.w[self.name + "/bias"]), _p(y),
+                _p(self.ps.w[proj.name + "/kernel"]), _p(self.ps.w[proj.name + "/bias"]), _p(out), proj.cout, N, H, W, self.cin, self.cout,
+                L.ACT[self.act], self.ctx.ns, self.ctx.stream)
+        _timed(256120 + self.ctx.ns, 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_split_proj", args)
+        self.x, self.y = x, y
+        proj.x, proj.y = y, out
+        return out
 
     def forward(self, x):
         N, H, W, _ = x.shape
@@ -751,7 +774,14 @@ class CelebADecoder:
             d = lyr.forward(d)
         dlatent = d
         h = self.up0.forward(self.conv0.forward(encoded.view(B, 1, 1, self.nh)))
-        for conv, sty, norm, rs in self.blocks:
+        for bi, (conv, sty, norm, rs) in enumerate(self.blocks):
+            if bi == len(self.blocks) - 1 and norm is None and (rs is None or (rs.oh, rs.ow) == tuple(h.shape[1:3])):
+                # the last 3x3 conv feeds the 1x1 output conv directly (its resize is the identity): one fused launch
+                out = conv.forward_fused_proj(h, self.conv_out, keep_y=self.ctx.keep_activations)
+                if out is not None:
+                    if rs is not None:
+                        rs.in_shape = tuple(h.shape[:3]) + (conv.cout,)
+                    return out
             h = conv.forward(h)
             if norm is not None:
                 h = norm.forward(h, sty.forward(dlatent))
@@ -928,13 +958,14 @@ class LadderEngine:
         self.set_mixture(np.full(K, 1.0 / K), np.zeros((K, R)), np.tile(np.eye(R), (K, 1, 1)))
 
     # -- forward --------------------------------------------------------------------------------
-    def forward(self, x, noise=None, use_sg=True, use_mask=False, parts=("dec", "inner", "gmm"), reuse_encoder=False):
+    def forward(self, x, noise=None, use_sg=True, use_mask=False, parts=("dec", "inner", "gmm"), reuse_encoder=False, keep_acts=True):
         """`reuse_encoder`: the caller asserts that this run evaluates the SAME minibatch as the previous run and that no
         encoder variable changed in between (RUN#2/#3/#4 after RUN#1: only sigma / prior variables are updated,
         codes/base.py:601-639).  The encoder output (code_mean, code_std_dev) of the previous run is then bit-identical to
         what a re-evaluation would give (deterministic kernels, batch statistics of the same batch) and is reused; the
         fresh noise of the run still produces a new code_sample.  Guarded by the AE optimiser step counter."""
         ctx, st = self.ctx, self.ctx.stream
+        ctx.keep_activations = bool(keep_acts)     # forward-only runs (RUN#2, val_step): fused kernels skip backward-only tensors
         Z, R = self.Z, self.R
         P = self.partials
         P.zero_()
@@ -1146,7 +1177,7 @@ class LadderEngine:
         self.ps.adam("ae", lr)
 
     def _sigma(self, x, lr, noise, use_sg, use_mask, reuse_encoder=False):
-        self.forward(x, noise, use_sg, use_mask, ("dec",), reuse_encoder)
+        self.forward(x, noise, use_sg, use_mask, ("dec",), reuse_encoder, keep_acts=False)
         self.ps.adam("sigma", lr, grad=self._sc("_g_sigma_var"), n=1)
 
     def _prior(self, x, lr, noise, use_sg, use_mask, reuse_encoder=False):
@@ -1234,12 +1265,16 @@ class LadderEngine:
 
     def evaluate(self, x, noise=None, use_sg=True, use_mask=False):
         parts = ("dec", "inner", "gmm") if (((self.has_inner or self.gmm_z) and self._gm_packed is not None) or self.vamp) else ("dec", "inner")
-        self.forward(x, noise, use_sg, use_mask, parts)
+        self.forward(x, noise, use_sg, use_mask, parts, keep_acts=False)
 
     # -- generation -----------------------------------------------------------------------------
     def decode(self, code):
         """decoded given code_input (is_code_input=True; models.py:107,265,500)."""
-        return self.decoder.forward(self._dev(code))
+        self.ctx.keep_activations = False
+        try:
+            return self.decoder.forward(self._dev(code))
+        finally:
+            self.ctx.keep_activations = True
 
     def decode_representation(self, t):
         """decoded_code given representation_input (base.py:171-186)."""

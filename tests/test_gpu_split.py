@@ -275,3 +275,37 @@ def test_fused_absmax_records_of_producers(gpu_ctx):
     L.call("ladder_conv1x1_smallcout_bwd_absmax", p(xs), p(dys), p(w), p(dxs), p(dw), p(db), M, Cin, Cout, 1, wsp, wsn, p(rec), st)
     L.call("ladder_conv1x1_smallcout_bwd", p(xs), p(dys), p(w), p(dxs0), p(dw), p(db), M, Cin, Cout, 1, wsp, wsn, st)
     assert torch.equal(dxs, dxs0) and rec.max().item() == dxs.abs().max().item()
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x6"])
+@pytest.mark.parametrize("keep_y", [True, False])
+def test_conv3x3_split_fused_projection(gpu_ctx, prec, keep_y):
+    """The last decoder conv (3x3, leaky) with the 1x1 output conv fused into its epilogue (codes/models.py:573-586): the projection
+    equals oracle conv1x1(leaky(conv3x3(x))) to the forward tolerance; with y == NULL (forward-only runs) only the projection is written."""
+    L = _lib()
+    P = PREC[prec]
+    N, H, W, Cin, Cout, Cp = 32, 64, 64, 32, 128, 3
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    pw = (rng.standard_normal((1, 1, Cout, Cp)) / np.sqrt(Cout)).astype(np.float32)
+    pb = rng.standard_normal(Cp).astype(np.float32)
+    td = lambda a: torch.tensor(a, dtype=torch.float64)
+    yr = O.act(O.conv2d_tf(td(x), td(w), td(b), 1, "same"), "leaky_relu")
+    outr = O.conv2d_tf(yr, td(pw), td(pb), 1, "same")
+    st = gpu_ctx.stream
+    xd, wd, bd, pwd, pbd = dev(x), dev(w), dev(b), dev(pw), dev(pb)
+    pk = torch.empty(L.query("ladder_filter_pack_split_bytes", 9, Cin, Cout, P), dtype=torch.uint8, device="cuda")
+    L.call("ladder_filter_pack_split", p(wd), p(pk), 9, Cin, Cout, 0, P, st)
+    xa = absmax(L, xd, st)
+    y = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    out = torch.empty(N, H, W, Cp, device="cuda")
+    L.call("ladder_conv3x3_split_proj", p(xd), p(xa), p(pk), p(bd), p(y) if keep_y else None, p(pwd), p(pbd), p(out), Cp, N, H, W, Cin, Cout,
+           1, P, st)
+    close(out, outr, TOL[prec][0], "fused projection")
+    if keep_y:
+        close(y, yr, TOL[prec][0], "activation")
+    lib = L.load()
+    assert lib.ladder_conv3x3_split_proj(p(xd), p(xa), p(pk), p(bd), None, p(pwd), p(pbd), p(out), 5, N, H, W, Cin, Cout, 1, P, st) == -1
+    assert lib.ladder_conv3x3_split_proj(p(xd), p(xa), p(pk), p(bd), None, p(pwd), p(pbd), None, 3, N, H, W, Cin, Cout, 1, P, st) == -1
