@@ -133,23 +133,29 @@ int ladder_conv3x3_split_proj(const float* x, const float* x_absmax, const void*
                               const float* proj_b, float* proj_out, int proj_cout, int N, int H, int W, int Cin, int Cout, int act,
                               int prec, ladder_stream_t stream);
 
+/* planes[p][i] = 16-bit plane p of x[i] (scaled by the power of two derived from x_absmax for LADDER_PREC_F16X3), plane-major,
+ * n % 8 == 0; ladder_presplit_bytes = planes * n * 2. */
+size_t ladder_presplit_bytes(size_t n, int prec);
+int ladder_presplit(const float* x, const float* x_absmax, void* planes, size_t n, int prec, ladder_stream_t stream);
 /* The gather kernel on split operands: every other large convolution (128x128 output tiles; gathered channels % 32 == 0; tap table
  * <= 28 taps), i.e. the strided encoder layers and the 8x8 / 16x16 decoder maps (codes/models.py:398-460, 522-547) and their
  * backward-data passes (stride 2: the four output-parity classes).  Same semantics as ladder_conv2d_fwd / ladder_conv2d_bwd_data with
- * `packed` from ladder_filter_pack_split (transpose_flip = 1 for backward-data) and the gathered tensor's absolute maximum.
+ * `packed` from ladder_filter_pack_split (transpose_flip = 1 for backward-data), the gathered tensor's absolute maximum and the gathered
+ * tensor given as its PRE-SPLIT planes (ladder_presplit: these kernels re-read every input element once per tap and per output-channel
+ * tile, so the fp32 -> 16-bit split is done once per tensor, not 18-36 times).
  * *_eligible: 1 when EVERY launch of the call runs on the split kernel (call the fp32 entry point otherwise). */
 int ladder_conv2d_fwd_split_eligible(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t,
                                      int pad_l);
 size_t ladder_conv2d_fwd_split_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
                                                int pad_t, int pad_l);
-int ladder_conv2d_fwd_split(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, int N, int H, int W,
+int ladder_conv2d_fwd_split(const void* x_planes, const float* x_absmax, const void* packed, const float* bias, float* y, int N, int H, int W,
                             int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int act, int prec,
                             void* ws, size_t ws_bytes, ladder_stream_t stream);
 int ladder_conv2d_bwd_data_split_eligible(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t,
                                           int pad_l, int gated);
 size_t ladder_conv2d_bwd_data_split_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
                                                     int pad_t, int pad_l);
-int ladder_conv2d_bwd_data_split(const float* dy, const float* dy_absmax, const void* packed_T, float* dx, int N, int H, int W, int Cin,
+int ladder_conv2d_bwd_data_split(const void* dy_planes, const float* dy_absmax, const void* packed_T, float* dx, int N, int H, int W, int Cin,
                                  int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, const float* gate_y,
                                  int gate_act, int prec, void* ws, size_t ws_bytes, ladder_stream_t stream);
 /* Filter gradient of the same layers on split operands (Cin % 64 == 0, W % 32 == 0, >= 4096 row patches): dw[3][3][Cin][Cout] =
@@ -166,7 +172,7 @@ int ladder_conv3x3_wgrad_split(const float* x, const float* x_absmax, const floa
 int ladder_conv2d_bwd_filter_split_eligible(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t,
                                             int pad_l);
 size_t ladder_conv2d_bwd_filter_split_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW);
-int ladder_conv2d_bwd_filter_split(const float* x, const float* x_absmax, const float* dy, const float* dy_absmax, float* dw, float* db,
+int ladder_conv2d_bwd_filter_split(const void* x_planes, const float* x_absmax, const void* dy_planes, const float* dy_absmax, float* dw, float* db,
                                    int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l,
                                    int prec, void* ws, size_t ws_bytes, ladder_stream_t stream);
 /* out[i] = sum_s ws[s*n + i] in the fixed order s = 0..splits-1 (second stage of every split reduction). */

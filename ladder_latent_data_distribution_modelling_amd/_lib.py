@@ -108,6 +108,8 @@ PROTOTYPES = {
     "ladder_conv2d_bwd_data_split": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p, _i, _i, _p, _z, _p]),
     "ladder_conv3x3_split_eligible": (_i, [_i] * 5),
     "ladder_conv3x3_split": (_i, [_p, _p, _p, _p, _p, _p] + [_i] * 7 + [_p]),
+    "ladder_presplit_bytes": (_z, [_z, _i]),
+    "ladder_presplit": (_i, [_p, _p, _p, _z, _i, _p]),
     "ladder_conv3x3_split_proj": (_i, [_p, _p, _p, _p, _p, _p, _p, _p] + [_i] * 8 + [_p]),
     "ladder_in_style_fwd_absmax": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _z, _p, _p]),
     "ladder_in_style_bwd_absmax": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _z, _p, _p]),

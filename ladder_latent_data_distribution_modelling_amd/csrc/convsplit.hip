@@ -56,6 +56,30 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   amax_commit_block(m, rec);
 }
 
+// ---- operand pre-splitting ------------------------------------------------------------------------------------------------------
+// planes[p][i] = plane p of x[i] (16-bit, scaled for the fp16 format), plane-major.  The gather kernels re-read every input element
+// once per filter tap and per output-channel tile (18-36 times): splitting it there each time cost 38 % of the kernel (VALU + LDS
+// stores); one elementwise pass per tensor (4 B read + 4 B written per element) lets them stage planes with plain 16-byte copies.
+template <int PREC>
+__global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__ x, const float* __restrict__ xamax,
+                                                       uint4* __restrict__ planes, size_t n8) {
+  constexpr int NS = Fmt<PREC>::NS;
+  constexpr bool F16 = Fmt<PREC>::F16;
+  const float c = F16 ? scale_from_absmax(amax_load(xamax)) : 1.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+    if (F16) {
+      a = make_float4(a.x * c, a.y * c, a.z * c, a.w * c);
+      b = make_float4(b.x * c, b.y * c, b.z * c, b.w * c);
+    }
+    uint2 lo[NS], hi[NS];
+    split4<NS, F16>(a, lo);
+    split4<NS, F16>(b, hi);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) planes[(size_t)p * n8 + i] = make_uint4(lo[p].x, lo[p].y, hi[p].x, hi[p].y);
+  }
+}
+
 // ---- filter packing ----------------------------------------------------------------------------------------------------
 // Logical filter F[tap][ci][co] (tap = r*KW+s < ntaps, ci < Cin, co < Cout):
 //   transpose_flip = 0:  F[tap][ci][co] = w[tap][ci][co]               (w is the HWIO bank [ntaps][Cin][Cout])              forward
@@ -558,6 +582,23 @@ int ladder_absmax(const float* x, size_t n, float* out, ladder_stream_t stream) 
   size_t blocks = (n4 + 256 * 8 - 1) / (256 * 8);
   blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n4, n, out);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+size_t ladder_presplit_bytes(size_t n, int prec) { return (prec_ok(prec) && n % 8 == 0) ? (size_t)prec_planes(prec) * n * 2 : 0; }
+
+int ladder_presplit(const float* x, const float* x_absmax, void* planes, size_t n, int prec, ladder_stream_t stream) {
+  if (n == 0 || (n % 8) != 0 || !prec_ok(prec)) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(x) || !ladder_aligned16(planes)) return LADDER_E_ALIGN;
+  if (prec == LADDER_PREC_F16X3 && x_absmax == nullptr) return LADDER_E_SHAPE;
+  const size_t n8 = n / 8;
+  size_t blocks = (n8 + 255) / 256;
+  blocks = blocks > 4096 ? 4096 : blocks;
+  const dim3 grid((unsigned)blocks), block(256);
+  if (prec == LADDER_PREC_F16X3) hipLaunchKernelGGL(presplit_kernel<LADDER_PREC_F16X3>, grid, block, 0, stream, x, x_absmax, (uint4*)planes, n8);
+  else if (prec == LADDER_PREC_BF16X6) hipLaunchKernelGGL(presplit_kernel<LADDER_PREC_BF16X6>, grid, block, 0, stream, x, x_absmax, (uint4*)planes, n8);
+  else hipLaunchKernelGGL(presplit_kernel<LADDER_PREC_BF16X3>, grid, block, 0, stream, x, x_absmax, (uint4*)planes, n8);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

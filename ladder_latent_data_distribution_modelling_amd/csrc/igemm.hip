@@ -328,14 +328,16 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? IGEMM_FWD_MINW :
 
 // ---------------------------------------------------------------------------------------------------------------
 // The gather kernel on split operands (precision formats of split16.h / convsplit.hip): 128x128 tile, 4 wavefronts of 64x64, 32-channel
-// K chunks = two 32x32x16 MFMA K-steps.  A is gathered as fp32 exactly like igemm_fwd_kernel's fast path (tap table + validity mask)
-// and split into 16-bit planes while it is written to LDS ([plane][k-step][channel octet][row][8 x 16 bit]: a fragment = 32 consecutive
-// 16-byte slots); B comes pre-split from ladder_filter_pack_split, whose blocks already have that layout, by plain 16-byte copies.
+// K chunks = two 32x32x16 MFMA K-steps.  A is gathered exactly like igemm_fwd_kernel's fast path (tap table + validity mask) but from the
+// PRE-SPLIT 16-bit planes of the input (ladder_presplit: an element is re-read once per tap and per output-channel tile, 18-36 times;
+// splitting it in this kernel each time cost 38 % of its run time) straight into LDS ([plane][k-step][channel octet][row][8 x 16 bit]:
+// a fragment = 32 consecutive 16-byte slots); B comes pre-split from ladder_filter_pack_split, whose blocks already have that layout.
 constexpr int GS_BM = 128, GS_BN = 128, GS_BK = 32;
 constexpr int GS_PLANE = 2 * 2 * 128 * 16;      // bytes per plane of either operand tile (8192)
 
 template <int PREC>
-__global__ __launch_bounds__(kThreads, 2) void igemm_fwd_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
+__global__ __launch_bounds__(kThreads, 2) void igemm_fwd_split_kernel(const uint16_t* __restrict__ xp, const size_t plane_elems,
+                                                                     const uint4* __restrict__ wp,
                                                                      const float* __restrict__ bias, float* __restrict__ y,
                                                                      const IgemmDesc d, const int tiles_n, float* __restrict__ part,
                                                                      const int chunks_per_split, const float* __restrict__ gate,
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(kThreads, 2) void igemm_fwd_split_kernel(const floa
   constexpr int NS = Fmt<PREC>::NS;
   constexpr bool F16 = Fmt<PREC>::F16;
   constexpr int OPB = NS * GS_PLANE;                       // bytes of one operand tile
-  constexpr int AU = GS_BM * (GS_BK / 4) / kThreads;       // 4 float4 gathers per thread
+  constexpr int AU = GS_BM * (GS_BK / 8) / kThreads;       // 2 (row, channel octet) units per thread, NS 16-byte loads each
   constexpr int B_CHUNKS = 2 * NS * 256;                   // 16-byte chunks of the B tile (two packed blocks)
   constexpr int BU = B_CHUNKS / kThreads;                  // 4 (NS=2) / 6 (NS=3)
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * OPB];   // [buffer][A | B]
@@ -363,20 +365,20 @@ __global__ __launch_bounds__(kThreads, 2) void igemm_fwd_split_kernel(const floa
     unscale = 1.f / (cx * scale_from_absmax(amax_load(wamax)));
   }
 
-  const float* a_ptr[AU];
+  long a_off[AU];                                          // element offset of the unit at tap (0,0), channel slab 0
   uint32_t a_mask[AU];
   int a_dst[AU];
 #pragma unroll
   for (int i = 0; i < AU; ++i) {
     const int u = tid + i * kThreads;
-    const int row = u >> 3, kq = u & 7;
+    const int row = u >> 2, oct = u & 3;                   // oct = k-step * 2 + channel octet of the 32-channel chunk
     const int m = m0 + row;
     const bool ok = m < d.M;
     const uint32_t mm = ok ? m : 0;
     const uint32_t n_img = fdiv(mm, d.div_howo), rem = mm - n_img * HoWo;
     const uint32_t ho = fdiv(rem, d.div_wo), wo = rem - ho * d.Wo;
     const int bh = (int)ho * d.stride - d.pad_t, bw = (int)wo * d.stride - d.pad_l;
-    a_ptr[i] = x + (long)n_img * d.H * d.W * d.Cin + ((long)bh * d.W + bw) * d.Cin + kq * 4;
+    a_off[i] = (long)n_img * d.H * d.W * d.Cin + ((long)bh * d.W + bw) * d.Cin + oct * 8;
     uint32_t msk = 0;
     if (ok)
       for (int t = 0; t < d.ntaps; ++t) {
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(kThreads, 2) void igemm_fwd_split_kernel(const floa
         if (nh >= 0 && nh < d.H && nw >= 0 && nw < d.W) msk |= 1u << t;
       }
     a_mask[i] = msk;
-    a_dst[i] = (((kq >> 2) * 2 + ((kq >> 1) & 1)) * 128 + row) * 16 + (kq & 1) * 8;
+    a_dst[i] = (oct * 128 + row) * 16;
   }
 
   f32x16 acc[2][2];
@@ -395,14 +397,18 @@ __global__ __launch_bounds__(kThreads, 2) void igemm_fwd_split_kernel(const floa
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-  float4 ra[AU];
-  uint4 rb0, rb1, rb2, rb3, rb4, rb5;                      // (named: hipcc demotes a uint4 array captured by two lambdas to LDS)
+  static_assert(AU == 2, "two A units per thread");
+  uint4 ra00, ra01, ra02, ra10, ra11, ra12;                // [unit][plane]  (named: hipcc demotes a uint4 array captured by two
+  uint4 rb0, rb1, rb2, rb3, rb4, rb5;                      //  lambdas to LDS)
   static_assert(BU == 4 || BU == 6, "B staging rounds");
   auto load_chunk = [&](int c) {
     const int t = c % d.ntaps, ci0 = (c / d.ntaps) * GS_BK;
     const long coff = ((long)d.tap_dh[t] * d.W + d.tap_dw[t]) * d.Cin + ci0;
-#pragma unroll
-    for (int i = 0; i < AU; ++i) ra[i] = ld4(((a_mask[i] >> t) & 1u) ? a_ptr[i] + coff : g_zero16);
+#define GS_ASRC(i_, p_) *reinterpret_cast<const uint4*>(((a_mask[i_] >> t) & 1u) ? (const void*)(xp + (size_t)(p_) * plane_elems + a_off[i_] + coff) \
+                                                                             : (const void*)g_zero16)
+    ra00 = GS_ASRC(0, 0); ra01 = GS_ASRC(0, 1); ra10 = GS_ASRC(1, 0); ra11 = GS_ASRC(1, 1);
+    if (NS > 2) { ra02 = GS_ASRC(0, 2); ra12 = GS_ASRC(1, 2); }
+#undef GS_ASRC
     const uint4* bs = wp + (((size_t)d.tap_w[t] * nslabs16 + ci0 / 16) * tiles_n + cot) * (NS * 256);
     // unit i = (k-step i / NS, plane i % NS), 256 threads x 16 B each
 #define GS_BSRC(i_) bs[(size_t)((i_) / NS) * tiles_n * (NS * 256) + ((i_) % NS) * 256 + tid]
@@ -412,15 +418,10 @@ __global__ __launch_bounds__(kThreads, 2) void igemm_fwd_split_kernel(const floa
   };
   auto store_chunk = [&](int buf) {
     unsigned char* Ab = lds + buf * 2 * OPB;
-#pragma unroll
-    for (int i = 0; i < AU; ++i) {
-      float4 v = ra[i];
-      if (F16) v = make_float4(v.x * cx, v.y * cx, v.z * cx, v.w * cx);
-      uint2 pl[NS];
-      split4<NS, F16>(v, pl);
-#pragma unroll
-      for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(Ab + p * GS_PLANE + a_dst[i]) = pl[p];
-    }
+#define GS_ADST(i_, p_) *reinterpret_cast<uint4*>(Ab + (p_) * GS_PLANE + a_dst[i_])
+    GS_ADST(0, 0) = ra00; GS_ADST(0, 1) = ra01; GS_ADST(1, 0) = ra10; GS_ADST(1, 1) = ra11;
+    if (NS > 2) { GS_ADST(0, 2) = ra02; GS_ADST(1, 2) = ra12; }
+#undef GS_ADST
 #define GS_BDST(i_) *reinterpret_cast<uint4*>(Ab + OPB + ((i_) % NS) * GS_PLANE + (((i_) / NS) * 256 + tid) * 16)
     GS_BDST(0) = rb0; GS_BDST(1) = rb1; GS_BDST(2) = rb2; GS_BDST(3) = rb3;
     if (BU > 4) { GS_BDST(4) = rb4; GS_BDST(5) = rb5; }
@@ -713,7 +714,8 @@ __device__ __forceinline__ float gw_frag_sum(const uint4 f) {
 }
 
 template <int PREC>
-__global__ __launch_bounds__(kThreads, 2) void igemm_wgrad_split_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ __launch_bounds__(kThreads, 2) void igemm_wgrad_split_kernel(const uint16_t* __restrict__ xp, const size_t x_plane_elems,
+                                                                       const uint16_t* __restrict__ dyp, const size_t dy_plane_elems,
                                                                        float* __restrict__ out, float* __restrict__ bias_part,
                                                                        const IgemmDesc d, const int tiles_n, const int m_per_split,
                                                                        const float* __restrict__ xamax, const float* __restrict__ damax) {
@@ -741,10 +743,11 @@ __global__ __launch_bounds__(kThreads, 2) void igemm_wgrad_split_kernel(const fl
   const bool do_bias = (bias_part != nullptr) && (tile / tiles_n == 0) && wm == 0;
   float bsum[2] = {0.f, 0.f};
 
-  // staging units: 32 pixels x 32 float4 per operand = 1024 units = 4 per thread; unit u -> pixel u >> 5, channel quad u & 31
-  const int s_pix = tid >> 5, s_q4 = tid & 31;                // + 8 pixels per round
-  const int s_dst = (s_q4 >> 3) * GW_BLK + s_pix * 64 + (s_q4 & 7) * 8;     // + round * 8 * 64
-  const bool n_ok = (n0 + s_q4 * 4) < d.Cout;
+  // staging units: 32 pixels x 16 channel octets per operand = 512 units = 2 per thread and operand, NS 16-byte plane loads each;
+  // unit u -> pixel u >> 4, octet u & 15 (both operands arrive pre-split: ladder_presplit)
+  const int s_pix = tid >> 4, s_oct = tid & 15;              // + 16 pixels for the second round
+  const int s_dst = (s_oct >> 2) * GW_BLK + s_pix * 64 + (s_oct & 3) * 16;   // + round * 16 * 64
+  const bool n_ok = (n0 + s_oct * 8) < d.Cout;
   const int frag_lane = (8 * lh + (l15 >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (l15 & 3)) * 2;
 
   f32x16 acc[2][2];
@@ -755,38 +758,40 @@ __global__ __launch_bounds__(kThreads, 2) void igemm_wgrad_split_kernel(const fl
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-  float4 ra0, ra1, ra2, ra3, rd0, rd1, rd2, rd3;
-  auto load_a = [&](int pc, int round) -> float4 {
-    const int p = pc + s_pix + round * 8;
-    const float* src = g_zero16;
+  uint4 ra00, ra01, ra02, ra10, ra11, ra12, rd00, rd01, rd02, rd10, rd11, rd12;     // [round][plane] (named: see igemm_fwd_split_kernel)
+  auto unit_offsets = [&](int pc, int round, long& ao, long& dof) {
+    const int p = pc + s_pix + round * 16;
+    ao = dof = -1;
     if (p < p_end) {
       const uint32_t n_img = fdiv((uint32_t)p, d.div_howo), rem = (uint32_t)p - n_img * HoWo;
       const int ho = (int)fdiv(rem, d.div_wo), wo = (int)rem - ho * d.Wo;
       const int hi = ho * d.stride - d.pad_t + tr, wi = wo * d.stride - d.pad_l + ts;
-      if (hi >= 0 && hi < d.H && wi >= 0 && wi < d.W) src = x + (((long)n_img * d.H + hi) * d.W + wi) * d.Cin + ci0 + s_q4 * 4;
+      if (hi >= 0 && hi < d.H && wi >= 0 && wi < d.W) ao = (((long)n_img * d.H + hi) * d.W + wi) * d.Cin + ci0 + s_oct * 8;
+      if (n_ok) dof = (long)p * d.Cout + n0 + s_oct * 8;
     }
-    return ld4(src);
   };
-  auto load_d = [&](int pc, int round) -> float4 {
-    const int p = pc + s_pix + round * 8;
-    return ld4((p < p_end && n_ok) ? dy + (long)p * d.Cout + n0 + s_q4 * 4 : g_zero16);
-  };
-  auto store_op = [&](unsigned char* base, int round, float4 v, float c) {
-    if (F16) v = make_float4(v.x * c, v.y * c, v.z * c, v.w * c);
-    uint2 pl[NS];
-    split4<NS, F16>(v, pl);
-#pragma unroll
-    for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(base + p * GW_PLANE + s_dst + round * 8 * 64) = pl[p];
-  };
+#define GW_LD(base_, elems_, off_, p_) *reinterpret_cast<const uint4*>((off_) >= 0 ? (const void*)((base_) + (size_t)(p_) * (elems_) + (off_)) \
+                                                                                : (const void*)g_zero16)
   auto load_chunk = [&](int c) {
     const int pc = p_begin + c * 32;
-    ra0 = load_a(pc, 0); ra1 = load_a(pc, 1); ra2 = load_a(pc, 2); ra3 = load_a(pc, 3);
-    rd0 = load_d(pc, 0); rd1 = load_d(pc, 1); rd2 = load_d(pc, 2); rd3 = load_d(pc, 3);
+    long ao, dof;
+    unit_offsets(pc, 0, ao, dof);
+    ra00 = GW_LD(xp, x_plane_elems, ao, 0); ra01 = GW_LD(xp, x_plane_elems, ao, 1);
+    rd00 = GW_LD(dyp, dy_plane_elems, dof, 0); rd01 = GW_LD(dyp, dy_plane_elems, dof, 1);
+    if (NS > 2) { ra02 = GW_LD(xp, x_plane_elems, ao, 2); rd02 = GW_LD(dyp, dy_plane_elems, dof, 2); }
+    unit_offsets(pc, 1, ao, dof);
+    ra10 = GW_LD(xp, x_plane_elems, ao, 0); ra11 = GW_LD(xp, x_plane_elems, ao, 1);
+    rd10 = GW_LD(dyp, dy_plane_elems, dof, 0); rd11 = GW_LD(dyp, dy_plane_elems, dof, 1);
+    if (NS > 2) { ra12 = GW_LD(xp, x_plane_elems, ao, 2); rd12 = GW_LD(dyp, dy_plane_elems, dof, 2); }
   };
+#undef GW_LD
   auto store_chunk = [&](int buf) {
     unsigned char* Ab = lds + buf * 2 * OPB;
-    store_op(Ab, 0, ra0, cx); store_op(Ab, 1, ra1, cx); store_op(Ab, 2, ra2, cx); store_op(Ab, 3, ra3, cx);
-    store_op(Ab + OPB, 0, rd0, cd); store_op(Ab + OPB, 1, rd1, cd); store_op(Ab + OPB, 2, rd2, cd); store_op(Ab + OPB, 3, rd3, cd);
+#define GW_ST(op_, round_, p_) *reinterpret_cast<uint4*>(Ab + (op_) * OPB + (p_) * GW_PLANE + s_dst + (round_) * 16 * 64)
+    GW_ST(0, 0, 0) = ra00; GW_ST(0, 0, 1) = ra01; GW_ST(0, 1, 0) = ra10; GW_ST(0, 1, 1) = ra11;
+    GW_ST(1, 0, 0) = rd00; GW_ST(1, 0, 1) = rd01; GW_ST(1, 1, 0) = rd10; GW_ST(1, 1, 1) = rd11;
+    if (NS > 2) { GW_ST(0, 0, 2) = ra02; GW_ST(0, 1, 2) = ra12; GW_ST(1, 0, 2) = rd02; GW_ST(1, 1, 2) = rd12; }
+#undef GW_ST
   };
   auto mma_chunk = [&](int buf) {
     const unsigned char* Ab = lds + buf * 2 * OPB + frag_lane + wm * 2 * GW_BLK;
@@ -1172,10 +1177,12 @@ size_t fwd_split_ws_bytes(const IgemmDesc& d) {
   return sp.splits > 1 ? (size_t)sp.splits * d.M * d.Cout * sizeof(float) : 0;
 }
 
-int launch_fwd_split(const float* x, const float* xamax, const void* packed, const float* bias, float* y, const IgemmDesc& d, int prec,
+int launch_fwd_split(const void* x, const float* xamax, const void* packed, const float* bias, float* y, const IgemmDesc& d, int prec,
                      void* ws, size_t ws_bytes, hipStream_t st, const float* gate, int gate_act) {
+  // `x` = the pre-split planes of the gathered tensor (ladder_presplit), plane-major, d.N*d.H*d.W*d.Cin elements per plane
   if (!split_gather_ok(d) || !prec_ok(prec)) return LADDER_E_SHAPE;
   if (!ladder_aligned16(x) || !ladder_aligned16(packed) || !ladder_aligned16(y)) return LADDER_E_ALIGN;
+  const size_t plane_elems = (size_t)d.N * d.H * d.W * d.Cin;
   if (prec == LADDER_PREC_F16X3 && xamax == nullptr) return LADDER_E_SHAPE;
   const int tiles_m = (d.M + GS_BM - 1) / GS_BM, tiles_n = (d.Cout + GS_BN - 1) / GS_BN;
   const bool dense_out = d.out_sh == 1 && d.out_sw == 1 && d.OH == d.Ho && d.OW == d.Wo;
@@ -1186,7 +1193,7 @@ int launch_fwd_split(const float* x, const float* xamax, const void* packed, con
   const float* wamax = reinterpret_cast<const float*>(static_cast<const unsigned char*>(packed) + pack_payload_bytes(d.KH * d.KW, d.Cin, d.Cout, prec));
   const dim3 grid(tiles_m * tiles_n, sp.splits), block(kThreads);
 #define LADDER_GS_LAUNCH(P_) \
-  hipLaunchKernelGGL(igemm_fwd_split_kernel<P_>, grid, block, 0, st, x, (const uint4*)packed, bias, y, d, tiles_n, part, sp.cps, \
+  hipLaunchKernelGGL(igemm_fwd_split_kernel<P_>, grid, block, 0, st, (const uint16_t*)x, plane_elems, (const uint4*)packed, bias, y, d, tiles_n, part, sp.cps, \
                      part ? nullptr : gate, gate_act, xamax, wamax)
   if (prec == LADDER_PREC_F16X3) LADDER_GS_LAUNCH(LADDER_PREC_F16X3);
   else if (prec == LADDER_PREC_BF16X6) LADDER_GS_LAUNCH(LADDER_PREC_BF16X6);
@@ -1761,7 +1768,7 @@ int run_wgrad(const float* x, const float* dy, float* dw, float* db, const Igemm
 
 // ---- split filter gradient: planning shared by the workspace query and the launcher
 bool wgrad_split_ok(const IgemmDesc& d) {
-  if (d.ups != 1 || (d.Cin % 128) != 0 || d.Cout <= 64 || d.M < 4096) return false;
+  if (d.ups != 1 || (d.Cin % 128) != 0 || d.Cout <= 64 || (d.Cout % 8) != 0 || d.M < 4096) return false;
   const WgradPlan p = plan_wgrad(d.M, d.K, d.Cout);
   return p.bm == 128 && p.bn == 128;
 }
@@ -1776,8 +1783,9 @@ size_t wgrad_split_ws_bytes(const IgemmDesc& d) {
   const WgradPlan p = plan_wgrad_split32(d);
   return ((size_t)p.splits * d.K * d.Cout + (size_t)p.splits * d.Cout) * sizeof(float);
 }
-int run_wgrad_split(const float* x, const float* xamax, const float* dy, const float* damax, float* dw, float* db, const IgemmDesc& d,
+int run_wgrad_split(const void* x, const float* xamax, const void* dy, const float* damax, float* dw, float* db, const IgemmDesc& d,
                     int prec, void* ws, size_t ws_bytes, hipStream_t st) {
+  // x, dy = pre-split planes (ladder_presplit) of the layer input [N,H,W,Cin] and of the output gradient [N,Ho,Wo,Cout]
   if (!wgrad_split_ok(d) || !prec_ok(prec)) return LADDER_E_SHAPE;
   if (!ladder_aligned16(x) || !ladder_aligned16(dy) || !ladder_aligned16(dw)) return LADDER_E_ALIGN;
   if (prec == LADDER_PREC_F16X3 && (xamax == nullptr || damax == nullptr)) return LADDER_E_SHAPE;
@@ -1788,7 +1796,8 @@ int run_wgrad_split(const float* x, const float* xamax, const float* dy, const f
   float* bias_part = db != nullptr ? part + (size_t)p.splits * kn : nullptr;
   const dim3 grid(p.tiles_k * p.tiles_n, p.splits), block(kThreads);
 #define LADDER_GW_LAUNCH(P_) \
-  hipLaunchKernelGGL(igemm_wgrad_split_kernel<P_>, grid, block, 0, st, x, dy, part, bias_part, d, p.tiles_n, p.m_per_split, xamax, damax)
+  hipLaunchKernelGGL(igemm_wgrad_split_kernel<P_>, grid, block, 0, st, (const uint16_t*)x, (size_t)d.N * d.H * d.W * d.Cin, (const uint16_t*)dy, \
+                     (size_t)d.M * d.Cout, part, bias_part, d, p.tiles_n, p.m_per_split, xamax, damax)
   if (prec == LADDER_PREC_F16X3) LADDER_GW_LAUNCH(LADDER_PREC_F16X3);
   else if (prec == LADDER_PREC_BF16X6) LADDER_GW_LAUNCH(LADDER_PREC_BF16X6);
   else LADDER_GW_LAUNCH(LADDER_PREC_BF16X3);
@@ -1914,7 +1923,7 @@ int ladder_conv2d_bwd_data(const float* dy, const float* wT, float* dx, int N, i
 
 // ---- split-precision variants of the forward-type convolution calls (gather kernel; the 3x3 halo layers have their own entry points
 // in convsplit.hip).  `dry` = only report whether every launch of the call would run on the split kernel.
-static int conv2d_fwd_split_impl(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, int N, int H,
+static int conv2d_fwd_split_impl(const void* x, const float* x_absmax, const void* packed, const float* bias, float* y, int N, int H,
                                  int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int act,
                                  int prec, void* ws, size_t ws_bytes, ladder_stream_t stream, bool dry, size_t* ws_need) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return LADDER_E_SHAPE;
@@ -1926,7 +1935,7 @@ static int conv2d_fwd_split_impl(const float* x, const float* x_absmax, const vo
   return launch_fwd_split(x, x_absmax, packed, bias, y, d, prec, ws, ws_bytes, stream, nullptr, 0);
 }
 
-static int conv2d_bwd_data_split_impl(const float* dy, const float* dy_absmax, const void* packed, float* dx, int N, int H, int W, int Cin,
+static int conv2d_bwd_data_split_impl(const void* dy, const float* dy_absmax, const void* packed, float* dx, int N, int H, int W, int Cin,
                                       int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, const float* gate_y,
                                       int gate_act, int prec, void* ws, size_t ws_bytes, ladder_stream_t stream, bool dry, size_t* ws_need) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return LADDER_E_SHAPE;
@@ -1990,10 +1999,10 @@ size_t ladder_conv2d_fwd_split_workspace_bytes(int N, int H, int W, int Cin, int
   return need;
 }
 
-int ladder_conv2d_fwd_split(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, int N, int H, int W,
+int ladder_conv2d_fwd_split(const void* x_planes, const float* x_absmax, const void* packed, const float* bias, float* y, int N, int H, int W,
                             int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int act, int prec,
                             void* ws, size_t ws_bytes, ladder_stream_t stream) {
-  return conv2d_fwd_split_impl(x, x_absmax, packed, bias, y, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_t, pad_l, act, prec, ws,
+  return conv2d_fwd_split_impl(x_planes, x_absmax, packed, bias, y, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_t, pad_l, act, prec, ws,
                                ws_bytes, stream, false, nullptr);
 }
 
@@ -2013,10 +2022,10 @@ size_t ladder_conv2d_bwd_data_split_workspace_bytes(int N, int H, int W, int Cin
   return need;
 }
 
-int ladder_conv2d_bwd_data_split(const float* dy, const float* dy_absmax, const void* packed_T, float* dx, int N, int H, int W, int Cin,
+int ladder_conv2d_bwd_data_split(const void* dy_planes, const float* dy_absmax, const void* packed_T, float* dx, int N, int H, int W, int Cin,
                                  int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, const float* gate_y,
                                  int gate_act, int prec, void* ws, size_t ws_bytes, ladder_stream_t stream) {
-  return conv2d_bwd_data_split_impl(dy, dy_absmax, packed_T, dx, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_t, pad_l, gate_y, gate_act,
+  return conv2d_bwd_data_split_impl(dy_planes, dy_absmax, packed_T, dx, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_t, pad_l, gate_y, gate_act,
                                     prec, ws, ws_bytes, stream, false, nullptr);
 }
 
@@ -2067,12 +2076,12 @@ size_t ladder_conv2d_bwd_filter_split_workspace_bytes(int N, int H, int W, int C
   return wgrad_split_ws_bytes(d);
 }
 
-int ladder_conv2d_bwd_filter_split(const float* x, const float* x_absmax, const float* dy, const float* dy_absmax, float* dw, float* db,
+int ladder_conv2d_bwd_filter_split(const void* x_planes, const float* x_absmax, const void* dy_planes, const float* dy_absmax, float* dw, float* db,
                                    int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l,
                                    int prec, void* ws, size_t ws_bytes, ladder_stream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return LADDER_E_SHAPE;
   IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, 1, pad_t, pad_l, N * Ho * Wo, KH * KW * Cin, LADDER_ACT_NONE, make_fastdiv(Ho * Wo), make_fastdiv(Wo)};
-  return run_wgrad_split(x, x_absmax, dy, dy_absmax, dw, db, d, prec, ws, ws_bytes, stream);
+  return run_wgrad_split(x_planes, x_absmax, dy_planes, dy_absmax, dw, db, d, prec, ws, ws_bytes, stream);
 }
 
 int ladder_conv1x1_smallcout_eligible(long M, int Cin, int Cout) { return smallcout_eligible(Cin, Cout, 1, 1, 1, M) ? 1 : 0; }

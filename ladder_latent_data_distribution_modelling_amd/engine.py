@@ -162,6 +162,7 @@ class Ctx:
         self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
         self._ws_retired, self.ws_generation = [], 0
         self._amax = {}      # id(tensor) -> (weakref, absolute-maximum record)
+        self._planes = {}    # id(tensor) -> (weakref, pre-split planes)
         self.keep_activations = True   # False inside forward-only runs: fused kernels may skip writing tensors only a backward pass reads
         self.ns = 0          # LADDER_PREC_* of the split-precision contraction kernels (0 = native f32 MFMA); set by the engine
 
@@ -201,6 +202,7 @@ class Ctx:
 
     def drop_amax(self, t):
         self._amax.pop(id(t), None)
+        self._planes.pop(id(t), None)
 
     def absmax(self, t):
         """Absolute-maximum record of `t` (an upper bound is as good: it only moves the 2^-38 representation floor); None when
@@ -213,6 +215,20 @@ class Ctx:
             L.call("ladder_absmax", _p(t), t.numel(), _p(rec), self.stream)
             self.set_amax(t, rec)
         return rec
+
+    def planes(self, t):
+        """Pre-split 16-bit planes of `t` (ladder_presplit) for the gather kernels, cached per tensor object like the absmax records:
+        a layer input is split once and serves the forward call and the filter gradient, an output gradient the backward-data call
+        and the filter gradient."""
+        e = self._planes.get(id(t))
+        if e is not None and e[0]() is t:
+            return e[1]
+        import weakref
+        buf = torch.empty(L.query("ladder_presplit_bytes", t.numel(), self.ns), dtype=torch.uint8, device=self.device)
+        L.call("ladder_presplit", _p(t), _p(self.absmax(t)), _p(buf), t.numel(), self.ns, self.stream)
+        k, reg = id(t), self._planes
+        reg[k] = (weakref.ref(t, lambda _r, k=k, reg=reg: reg.pop(k, None)), buf)
+        return buf
 
     def zeros(self, *shape):
         return torch.zeros(*shape, dtype=torch.float32, device=self.device)
@@ -384,7 +400,7 @@ class Conv2D:
             self.x_amax = self.ctx.absmax(x)
             nb = L.query("ladder_conv2d_fwd_split_workspace_bytes", *geo)
             wsp, wsn = self.ctx.ws(nb)
-            args = (_p(x), _p(self.x_amax), _p(self._packed_filter(0)), _p(self.ps.w[self.name + "/bias"]), _p(y)) + geo + (
+            args = (_p(self.ctx.planes(x)), _p(self.x_amax), _p(self._packed_filter(0)), _p(self.ps.w[self.name + "/bias"]), _p(y)) + geo + (
                 L.ACT[self.act], self.ctx.ns, wsp, wsn, self.ctx.stream)
             if nb:                                       # split-K launch: two kernels, not attributed by the profiler
                 L.call("ladder_conv2d_fwd_split", *args)
@@ -442,7 +458,8 @@ class Conv2D:
                     self.x_amax = self.ctx.absmax(x)
                 dy_amax = self.ctx.absmax(dy)
             wsp, wsn = self.ctx.ws(L.query("ladder_conv2d_bwd_filter_split_workspace_bytes", N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k))
-            L.call("ladder_conv2d_bwd_filter_split", _p(x), _p(self.x_amax), _p(dy), _p(dy_amax), _p(self.ps.g[self.name + "/kernel"]),
+            L.call("ladder_conv2d_bwd_filter_split", _p(self.ctx.planes(x)), _p(self.x_amax), _p(self.ctx.planes(dy)), _p(dy_amax),
+                   _p(self.ps.g[self.name + "/kernel"]),
                    _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k,
                    self.stride, self.pt, self.pl, self.ctx.ns, wsp, wsn, st)
         elif wgrad:
@@ -474,7 +491,7 @@ class Conv2D:
                 dy_amax = self.ctx.absmax(dy)
             wsp, wsn = self.ctx.ws(L.query("ladder_conv2d_bwd_data_split_workspace_bytes", *geo))
             dx = self.ctx.empty(N, H, W, self.cin)
-            L.call("ladder_conv2d_bwd_data_split", _p(dy), _p(dy_amax), _p(self._packed_filter(1)), _p(dx), *geo,
+            L.call("ladder_conv2d_bwd_data_split", _p(self.ctx.planes(dy)), _p(dy_amax), _p(self._packed_filter(1)), _p(dx), *geo,
                    _p(x) if gate_prev else None, L.ACT[gate_prev] if gate_prev else 0, self.ctx.ns, wsp, wsn, st)
         elif need_dx:
             w = self.ps.w[self.name + "/kernel"]

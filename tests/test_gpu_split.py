@@ -62,6 +62,13 @@ def test_absmax_is_exact(gpu_ctx, n):
     assert absmax(L, z, gpu_ctx.stream).max().item() == 0.0
 
 
+def presplit(L, t, rec, P, st):
+    """Pre-split planes of a tensor (ladder_presplit): what the gather kernels consume."""
+    buf = torch.empty(L.query("ladder_presplit_bytes", t.numel(), P), dtype=torch.uint8, device="cuda")
+    L.call("ladder_presplit", p(t), p(rec), p(buf), t.numel(), P, st)
+    return buf
+
+
 def _fill(rng, shape, kind):
     x = rng.standard_normal(shape).astype(np.float32)
     if kind == "heavy":            # heavy tail: a handful of elements 4 decades above the bulk
@@ -184,23 +191,25 @@ def test_conv2d_split_gather_fwd_bwd(gpu_ctx, case, prec):
     L.call("ladder_filter_pack_split", p(wd), p(pk), k * k, Cin, Cout, 0, P, st)
     y = torch.empty(N, Ho, Wo, Cout, device="cuda")
     wsp, wsn = gpu_ctx.ws(max(L.query("ladder_conv2d_fwd_split_workspace_bytes", *geo), 16))
-    L.call("ladder_conv2d_fwd_split", p(xd), p(xa), p(pk), p(bd), p(y), *geo, L.ACT[act], P, wsp, wsn, st)
+    xpl = presplit(L, xd, xa, P, st)
+    L.call("ladder_conv2d_fwd_split", p(xpl), p(xa), p(pk), p(bd), p(y), *geo, L.ACT[act], P, wsp, wsn, st)
     close(y, yr, tf, "fwd (split-K allowed)")
-    L.call("ladder_conv2d_fwd_split", p(xd), p(xa), p(pk), p(bd), p(y), *geo, L.ACT[act], P, None, 0, st)
+    L.call("ladder_conv2d_fwd_split", p(xpl), p(xa), p(pk), p(bd), p(y), *geo, L.ACT[act], P, None, 0, st)
     close(y, yr, tf, "fwd")
     dyd = dev(dy)
     if act is not None:
         L.call("ladder_act_bwd", p(dyd), p(dev(yr.detach().numpy())), p(dyd), dyd.numel(), L.ACT[act], st)
     da = absmax(L, dyd, st)
+    dypl = presplit(L, dyd, da, P, st)
     if L.query("ladder_conv2d_bwd_data_split_eligible", *geo, 0):
         pkT = torch.empty(L.query("ladder_filter_pack_split_bytes", k * k, Cout, Cin, P), dtype=torch.uint8, device="cuda")
         L.call("ladder_filter_pack_split", p(wd), p(pkT), k * k, Cout, Cin, 1, P, st)
         wsp, wsn = gpu_ctx.ws(max(L.query("ladder_conv2d_bwd_data_split_workspace_bytes", *geo), 16))
         dx = torch.empty_like(xd)
-        L.call("ladder_conv2d_bwd_data_split", p(dyd), p(da), p(pkT), p(dx), *geo, None, 0, P, wsp, wsn, st)
+        L.call("ladder_conv2d_bwd_data_split", p(dypl), p(da), p(pkT), p(dx), *geo, None, 0, P, wsp, wsn, st)
         close(dx, xt.grad, tb, "dx")
         dxg = torch.empty_like(xd)
-        L.call("ladder_conv2d_bwd_data_split", p(dyd), p(da), p(pkT), p(dxg), *geo, p(xd), 1, P, wsp, wsn, st)
+        L.call("ladder_conv2d_bwd_data_split", p(dypl), p(da), p(pkT), p(dxg), *geo, p(xd), 1, P, wsp, wsn, st)
         assert torch.equal(dxg, dx * torch.where(xd > 0, 1.0, 0.2))
         checked_dx = True
     else:
@@ -208,7 +217,7 @@ def test_conv2d_split_gather_fwd_bwd(gpu_ctx, case, prec):
     if L.query("ladder_conv2d_bwd_filter_split_eligible", *geo):
         wsp, wsn = gpu_ctx.ws(L.query("ladder_conv2d_bwd_filter_split_workspace_bytes", *geo[:9]))
         dw, db = torch.empty_like(wd), torch.empty_like(bd)
-        L.call("ladder_conv2d_bwd_filter_split", p(xd), p(xa), p(dyd), p(da), p(dw), p(db), *geo, P, wsp, wsn, st)
+        L.call("ladder_conv2d_bwd_filter_split", p(xpl), p(xa), p(dypl), p(da), p(dw), p(db), *geo, P, wsp, wsn, st)
         close(dw, wt.grad, tb, "dw")
         close(db, bt.grad, tb, "db")
         checked_dw = True
