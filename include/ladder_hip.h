@@ -134,7 +134,7 @@ int ladder_conv3x3_split_proj(const float* x, const float* x_absmax, const void*
                               int prec, ladder_stream_t stream);
 
 /* planes[p][i] = 16-bit plane p of x[i] (scaled by the power of two derived from x_absmax for LADDER_PREC_F16X3), plane-major,
- * n % 8 == 0; ladder_presplit_bytes = planes * n * 2. */
+ * n % 8 == 0, followed by 16 zero bytes (the source of out-of-image taps); ladder_presplit_bytes = planes * n * 2 + 16. */
 size_t ladder_presplit_bytes(size_t n, int prec);
 int ladder_presplit(const float* x, const float* x_absmax, void* planes, size_t n, int prec, ladder_stream_t stream);
 /* The gather kernel on split operands: every other large convolution (128x128 output tiles; gathered channels % 32 == 0; tap table

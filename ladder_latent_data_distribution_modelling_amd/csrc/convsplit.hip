@@ -59,13 +59,17 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
 // ---- operand pre-splitting ------------------------------------------------------------------------------------------------------
 // planes[p][i] = plane p of x[i] (16-bit, scaled for the fp16 format), plane-major.  The gather kernels re-read every input element
 // once per filter tap and per output-channel tile (18-36 times): splitting it there each time cost 38 % of the kernel (VALU + LDS
-// stores); one elementwise pass per tensor (4 B read + 4 B written per element) lets them stage planes with plain 16-byte copies.
+// stores); one elementwise pass per tensor (4 B read + 4 B written per element) lets them stage planes by LDS-DMA.  16 zero bytes
+// follow the last plane: the source of out-of-image taps (an offset INTO THE SAME BUFFER, so that the DMA source is selected by a
+// conditional move on an integer -- a pointer select against another object compiles to exec-masked branches, and a partially
+// masked global_load_lds takes its LDS base from the first ACTIVE lane).
 template <int PREC>
 __global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__ x, const float* __restrict__ xamax,
                                                        uint4* __restrict__ planes, size_t n8) {
   constexpr int NS = Fmt<PREC>::NS;
   constexpr bool F16 = Fmt<PREC>::F16;
   const float c = F16 ? scale_from_absmax(amax_load(xamax)) : 1.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) planes[(size_t)NS * n8] = make_uint4(0u, 0u, 0u, 0u);   // the 16 zero bytes behind the planes
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
     float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
     if (F16) {
@@ -586,7 +590,7 @@ int ladder_absmax(const float* x, size_t n, float* out, ladder_stream_t stream) 
   return LADDER_OK;
 }
 
-size_t ladder_presplit_bytes(size_t n, int prec) { return (prec_ok(prec) && n % 8 == 0) ? (size_t)prec_planes(prec) * n * 2 : 0; }
+size_t ladder_presplit_bytes(size_t n, int prec) { return (prec_ok(prec) && n % 8 == 0) ? (size_t)prec_planes(prec) * n * 2 + 16 : 0; }
 
 int ladder_presplit(const float* x, const float* x_absmax, void* planes, size_t n, int prec, ladder_stream_t stream) {
   if (n == 0 || (n % 8) != 0 || !prec_ok(prec)) return LADDER_E_SHAPE;
