@@ -189,6 +189,16 @@ int ladder_dense_bwd_data(const float* dy, const float* wT, float* dx, int M, in
 size_t ladder_dense_bwd_weight_workspace_bytes(int M, int K, int N);
 int ladder_dense_bwd_weight(const float* x, const float* dy, float* dw, float* db,
                             int M, int K, int N, void* ws, size_t ws_bytes, ladder_stream_t stream);
+/* The same three calls for BATCH-SIZED layers (M <= 512 rows, M*N <= 2^20: the mapping MLP, style projections, inner VAE and encoder
+ * heads, codes/models.py:478-510, codes/base.py:145-186) on the bf16 matrix cores in the fp32-class bf16x6 format (csrc/densesplit.hip):
+ * ONE launch per call -- a 32x32 output tile per workgroup, operand fragments loaded straight from global memory in MFMA layout and
+ * split in registers, no split-K pass, no workspace, no transposed weight copy (bwd_data takes w itself, [K,N]). */
+int ladder_dense_small_eligible(int M, int K, int N);
+int ladder_dense_fwd_small(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act, ladder_stream_t stream);
+int ladder_dense_bwd_data_small(const float* dy, const float* w, float* dx, int M, int K, int N, const float* gate_y, int gate_act,
+                                ladder_stream_t stream);
+int ladder_dense_bwd_weight_small(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, ladder_stream_t stream);
+
 
 /* ---------------------------------------------------------------- N12: activations (backward)
  * dx = dy * act'(y) evaluated from the activation OUTPUT y (leaky/relu/tanh).  In-place (dx==dy) allowed. */

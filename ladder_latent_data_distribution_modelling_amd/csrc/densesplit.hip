@@ -1,0 +1,141 @@
+// Small dense layers (batch-sized GEMMs: M = minibatch <= a few hundred rows) on the bf16 matrix cores, fp32-class (bf16x6: three bf16
+// planes per fp32 operand, six plane products, fp32 accumulation -- split16.h; no tensor scale needed, so no absmax pass).
+//
+// The mapping MLP, the style projections, the inner VAE and the encoder heads are ~110 dependent GEMMs of 128 x 512 x 512 per
+// iteration.  On the fp32 MFMA path each was two launches (split-K gather kernel + reduction pass, ~18 + 6 us) because a 32x32 tile
+// over K = 512 alone is 256 fp32 MFMAs x 64 cycles = 7 us for one wavefront.  With the bf16 MFMA the same tile is 32 K-steps x 6 MFMAs x
+// 32 cycles = 2.6 us, so ONE launch without split-K suffices: one workgroup per 32x32 output tile, its 4 wavefronts take every 4th
+// K-step, load BOTH operand fragments straight from global memory in MFMA layout (8 consecutive reduction elements per lane: two
+// 16-byte loads when the reduction index is contiguous in memory, 8 coalesced 4-byte loads when it is strided), split them in
+// registers, and combine their partial tiles through LDS in a fixed order.  One generic kernel serves the three calls of a dense layer:
+//     C[i][j] = sum_r A(i, r) * B(r, j),   A(i, r) at a + i * a_is + r * a_rs,   B(r, j) at b + r * b_rs + j * b_js
+//   forward        y  = x w        : i = m, j = n, r = k    A = x  (a_is = K, a_rs = 1)   B = w  (b_rs = N, b_js = 1)
+//   backward-data  dx = dy w^T     : i = m, j = k, r = n    A = dy (a_is = N, a_rs = 1)   B = w  (b_rs = 1, b_js = N)  -- no transposed copy
+//   backward-weight dw = x^T dy    : i = k, j = n, r = m    A = x  (a_is = 1, a_rs = K)   B = dy (b_rs = N, b_js = 1), db = column sums of dy
+#include "split16.h"
+
+namespace {
+
+struct GemmSmall {
+  int I, J, R;
+  long a_is, a_rs, b_rs, b_js;
+  int act, gate_act;
+};
+
+// 8 consecutive reduction elements r0..r0+7 of one operand row/column, zero beyond R
+__device__ __forceinline__ void load8(const float* __restrict__ p, long rs, int r0, int R, bool live, float (&v)[8]) {
+  if (live && rs == 1 && r0 + 8 <= R && ((reinterpret_cast<uintptr_t>(p + r0) & 15u) == 0)) {
+    const float4 a = *reinterpret_cast<const float4*>(p + r0), b = *reinterpret_cast<const float4*>(p + r0 + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (live && r0 + e < R) ? p[(long)(r0 + e) * rs] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm_small_split_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                               const float* __restrict__ bias, float* __restrict__ c,
+                                                               const float* __restrict__ gate, float* __restrict__ colsum,
+                                                               const GemmSmall g) {
+  __shared__ float red[4][32 * 33];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  const int i = i0 + l31, j = j0 + l31;
+  const bool i_ok = i < g.I, j_ok = j < g.J;
+  const float* ap = a + (long)(i_ok ? i : 0) * g.a_is;
+  const float* bp = b + (long)(j_ok ? j : 0) * g.b_js;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  float csum = 0.f;                                           // column sum of B (bias gradient), this lane's column and r-octets
+  const int nsteps = (g.R + 15) / 16;
+  for (int ks = wv; ks < nsteps; ks += 4) {
+    const int r0 = ks * 16 + 8 * lh;
+    float av[8], bv[8];
+    load8(ap, g.a_rs, r0, g.R, i_ok, av);
+    load8(bp, g.b_rs, r0, g.R, j_ok, bv);
+    if (colsum != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) csum += bv[e];
+    }
+    uint2 alo[3], ahi[3], blo[3], bhi[3];
+    split4<3, false>(make_float4(av[0], av[1], av[2], av[3]), alo);
+    split4<3, false>(make_float4(av[4], av[5], av[6], av[7]), ahi);
+    split4<3, false>(make_float4(bv[0], bv[1], bv[2], bv[3]), blo);
+    split4<3, false>(make_float4(bv[4], bv[5], bv[6], bv[7]), bhi);
+    uint4 af[3], bf[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      af[p] = make_uint4(alo[p].x, alo[p].y, ahi[p].x, ahi[p].y);
+      bf[p] = make_uint4(blo[p].x, blo[p].y, bhi[p].x, bhi[p].y);
+    }
+#pragma unroll
+    for (int sum = 2; sum >= 0; --sum)
+#pragma unroll
+      for (int pa = 0; pa <= sum; ++pa) acc = mfma16<false>(af[pa], bf[sum - pa], acc);
+  }
+  // partial tiles of the 4 wavefronts -> LDS (row-major 32 x 33), fixed-order sum, epilogue with 128-byte row segments
+#pragma unroll
+  for (int e = 0; e < 16; ++e) red[wv][((e & 3) + 8 * (e >> 2) + 4 * lh) * 33 + l31] = acc[e];
+  __syncthreads();
+  const int col = tid & 31, rq = tid >> 5;                   // 8 row groups x 32 columns
+  const int jj = j0 + col;
+  const float bval = (bias != nullptr && jj < g.J) ? bias[jj] : 0.f;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int row = rq + 8 * rr, ii = i0 + row;
+    if (ii < g.I && jj < g.J) {
+      float v = ((red[0][row * 33 + col] + red[1][row * 33 + col]) + red[2][row * 33 + col]) + red[3][row * 33 + col];
+      v = ladder_act_fn(v + bval, g.act);
+      const long o = (long)ii * g.J + jj;
+      if (gate != nullptr) v *= ladder_act_grad_from_out(gate[o], g.gate_act);
+      c[o] = v;
+    }
+  }
+  if (colsum != nullptr && blockIdx.y == 0) {                 // db[j] = sum_r B(r, j): lanes (l31, lh) x 4 wavefronts, fixed order
+    __syncthreads();
+    csum += __shfl_xor(csum, 32, 64);
+    if (lh == 0) red[wv][l31] = csum;
+    __syncthreads();
+    if (tid < 32 && j0 + tid < g.J) colsum[j0 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+  }
+}
+
+int launch_gemm_small(const float* a, const float* b, const float* bias, float* c, const float* gate, float* colsum, const GemmSmall& g,
+                      hipStream_t st) {
+  if (g.I <= 0 || g.J <= 0 || g.R <= 0) return LADDER_E_SHAPE;
+  const dim3 grid((g.J + 31) / 32, (g.I + 31) / 32), block(256);
+  hipLaunchKernelGGL(gemm_small_split_kernel, grid, block, 0, st, a, b, bias, c, gate, colsum, g);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Worth it while the whole output is a few hundred tiles of 32x32 (batch-sized M): beyond that the tiled fp32 / split gather kernels win.
+int ladder_dense_small_eligible(int M, int K, int N) { return (M > 0 && K > 0 && N > 0 && M <= 512 && (long)M * N <= (1L << 20)) ? 1 : 0; }
+
+int ladder_dense_fwd_small(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act,
+                           ladder_stream_t stream) {
+  if (!ladder_dense_small_eligible(M, K, N)) return LADDER_E_SHAPE;
+  const GemmSmall g{M, N, K, K, 1, N, 1, act, 0};
+  return launch_gemm_small(x, w, bias, y, nullptr, nullptr, g, stream);
+}
+
+int ladder_dense_bwd_data_small(const float* dy, const float* w, float* dx, int M, int K, int N, const float* gate_y, int gate_act,
+                                ladder_stream_t stream) {
+  if (!ladder_dense_small_eligible(M, K, N)) return LADDER_E_SHAPE;
+  const GemmSmall g{M, K, N, N, 1, 1, N, LADDER_ACT_NONE, gate_act};
+  return launch_gemm_small(dy, w, nullptr, dx, gate_y, nullptr, g, stream);
+}
+
+int ladder_dense_bwd_weight_small(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, ladder_stream_t stream) {
+  if (!ladder_dense_small_eligible(M, K, N)) return LADDER_E_SHAPE;
+  const GemmSmall g{K, N, M, 1, K, N, 1, LADDER_ACT_NONE, 0};
+  return launch_gemm_small(x, dy, nullptr, dw, nullptr, db, g, stream);
+}
+
+}  // extern "C"

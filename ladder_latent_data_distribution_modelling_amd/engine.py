@@ -514,9 +514,18 @@ class Dense:
     def __init__(self, ctx, ps, name, cin, cout, act=None):
         self.ctx, self.ps, self.name, self.cin, self.cout, self.act = ctx, ps, name, cin, cout, act
 
+    def _small(self, M):
+        """Batch-sized layer in a split-precision mode: the one-launch bf16x6 kernels of csrc/densesplit.hip."""
+        return bool(self.ctx.ns and L.query("ladder_dense_small_eligible", M, self.cin, self.cout))
+
     def forward(self, x):
         M = x.shape[0]
         y = self.ctx.empty(M, self.cout)
+        if self._small(M):
+            L.call("ladder_dense_fwd_small", _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y),
+                   M, self.cin, self.cout, L.ACT[self.act], self.ctx.stream)
+            self.x, self.y = x, y
+            return y
         _igemm(self.ctx, "ladder_dense_fwd", M, self.cin, self.cout, self.cin,
                _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y),
                M, self.cin, self.cout, L.ACT[self.act])
@@ -528,6 +537,17 @@ class Dense:
         M = x.shape[0]
         if self.act is not None and not act_done:
             L.call("ladder_act_bwd", _p(dy), _p(y), _p(dy), dy.numel(), L.ACT[self.act], st)
+        if self._small(M):
+            if wgrad:
+                L.call("ladder_dense_bwd_weight_small", _p(x), _p(dy), _p(self.ps.g[self.name + "/kernel"]),
+                       _p(self.ps.g[self.name + "/bias"]), M, self.cin, self.cout, st)
+            dx = None
+            if need_dx:
+                dx = self.ctx.empty(M, self.cin)
+                L.call("ladder_dense_bwd_data_small", _p(dy), _p(self.ps.w[self.name + "/kernel"]), _p(dx), M, self.cin, self.cout,
+                       _p(x) if gate_prev else None, L.ACT[gate_prev] if gate_prev else 0, st)
+            self.x = self.y = None
+            return dx
         if wgrad:
             nb = L.query("ladder_dense_bwd_weight_workspace_bytes", M, self.cin, self.cout)
             wsp, wsn = self.ctx.ws(nb)

@@ -318,3 +318,38 @@ def test_conv3x3_split_fused_projection(gpu_ctx, prec, keep_y):
     lib = L.load()
     assert lib.ladder_conv3x3_split_proj(p(xd), p(xa), p(pk), p(bd), None, p(pwd), p(pbd), p(out), 5, N, H, W, Cin, Cout, 1, P, st) == -1
     assert lib.ladder_conv3x3_split_proj(p(xd), p(xa), p(pk), p(bd), None, p(pwd), p(pbd), None, 3, N, H, W, Cin, Cout, 1, P, st) == -1
+
+
+@pytest.mark.parametrize("M,K,N,act", [(128, 512, 512, "leaky_relu"), (128, 2048, 64, "relu"), (128, 2, 512, None), (128, 64, 512, "leaky_relu"),
+                                       (7, 20, 36, "relu"), (256, 512, 1024, None), (33, 100, 70, "tanh"), (128, 512, 2, None)])
+def test_dense_small_bf16x6(gpu_ctx, M, K, N, act):
+    """Batch-sized dense layers on the bf16 matrix cores (bf16x6, one launch, csrc/densesplit.hip): forward, backward-data from the
+    UN-transposed weights (with and without the fused activation gate) and backward-weight + bias, at the fp32 kernels' tolerances."""
+    L = _lib()
+    rng = np.random.default_rng(M * 7 + K)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    x.reshape(-1)[rng.integers(0, x.size, 4)] *= 1e3                      # heavy tail: bf16x6 needs no tensor scale
+    w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    xt, wt, bt = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (x, w, b))
+    yr = O.act(xt @ wt + bt, act)
+    dy = (rng.standard_normal((M, N)) * 1e-2).astype(np.float32)
+    yr.backward(torch.tensor(dy, dtype=torch.float64))
+    st = gpu_ctx.stream
+    assert L.query("ladder_dense_small_eligible", M, K, N) == 1
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    y = torch.empty(M, N, device="cuda")
+    L.call("ladder_dense_fwd_small", p(xd), p(wd), p(bd), p(y), M, K, N, L.ACT[act], st)
+    close(y, yr, 2e-5, "fwd")
+    dyd = dev(dy)
+    if act is not None:
+        L.call("ladder_act_bwd", p(dyd), p(dev(yr.detach().numpy())), p(dyd), dyd.numel(), L.ACT[act], st)
+    dw, db, dx, dxg = torch.empty_like(wd), torch.empty_like(bd), torch.empty_like(xd), torch.empty_like(xd)
+    L.call("ladder_dense_bwd_weight_small", p(xd), p(dyd), p(dw), p(db), M, K, N, st)
+    close(dw, wt.grad, 3e-5, "dw")
+    close(db, bt.grad, 3e-5, "db")
+    L.call("ladder_dense_bwd_data_small", p(dyd), p(wd), p(dx), M, K, N, None, 0, st)
+    close(dx, xt.grad, 3e-5, "dx")
+    L.call("ladder_dense_bwd_data_small", p(dyd), p(wd), p(dxg), M, K, N, p(xd), 1, st)
+    assert torch.equal(dxg, dx * torch.where(xd > 0, 1.0, 0.2))
+    assert L.query("ladder_dense_small_eligible", 4096, 512, 512) == 0
