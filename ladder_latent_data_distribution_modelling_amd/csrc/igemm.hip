@@ -1156,8 +1156,12 @@ int select_fwd_tile(long M, int Cout) {
 }
 
 
-bool split_gather_ok(const IgemmDesc& d) {
-  return d.ntaps > 0 && d.ntaps <= 28 && d.ups == 1 && (d.Cin % GS_BK) == 0 && d.M > 0 && select_fwd_tile(d.M, d.Cout) == 128128;
+// `small_ok`: the call writes a dense output, so a few 128x128 tiles can still fill the chip through split-K (the 8x8 ... 1x1 ends of the
+// CelebA encoder / decoder: M = 128 ... 8192 pixels, K = 1152 ... 8192)
+bool split_gather_ok(const IgemmDesc& d, bool small_ok = false) {
+  if (!(d.ntaps > 0 && d.ntaps <= 28 && d.ups == 1 && (d.Cin % GS_BK) == 0 && d.M > 0)) return false;
+  if (select_fwd_tile(d.M, d.Cout) == 128128) return true;
+  return small_ok && d.M >= 128 && d.Cout >= 128 && (long)d.ntaps * d.Cin >= 1024;
 }
 
 // the split-K plan of the fp32 kernel (16-deep chunks) re-expressed in this kernel's 32-deep chunks
@@ -1180,12 +1184,12 @@ size_t fwd_split_ws_bytes(const IgemmDesc& d) {
 int launch_fwd_split(const void* x, const float* xamax, const void* packed, const float* bias, float* y, const IgemmDesc& d, int prec,
                      void* ws, size_t ws_bytes, hipStream_t st, const float* gate, int gate_act) {
   // `x` = the pre-split planes of the gathered tensor (ladder_presplit), plane-major, d.N*d.H*d.W*d.Cin elements per plane
-  if (!split_gather_ok(d) || !prec_ok(prec)) return LADDER_E_SHAPE;
+  const bool dense_out = d.out_sh == 1 && d.out_sw == 1 && d.OH == d.Ho && d.OW == d.Wo;
+  if (!split_gather_ok(d, dense_out) || !prec_ok(prec)) return LADDER_E_SHAPE;
   if (!ladder_aligned16(x) || !ladder_aligned16(packed) || !ladder_aligned16(y)) return LADDER_E_ALIGN;
   const size_t plane_elems = (size_t)d.N * d.H * d.W * d.Cin;
   if (prec == LADDER_PREC_F16X3 && xamax == nullptr) return LADDER_E_SHAPE;
   const int tiles_m = (d.M + GS_BM - 1) / GS_BM, tiles_n = (d.Cout + GS_BN - 1) / GS_BN;
-  const bool dense_out = d.out_sh == 1 && d.out_sw == 1 && d.OH == d.Ho && d.OW == d.Wo;
   SplitPlan sp = plan_splitk32(d, dense_out);
   const size_t need = (size_t)sp.splits * d.M * d.Cout * sizeof(float);
   if (sp.splits > 1 && (ws == nullptr || ws_bytes < need)) sp = SplitPlan{1, d.ntaps * (d.Cin / GS_BK)};
@@ -1929,7 +1933,7 @@ static int conv2d_fwd_split_impl(const void* x, const float* x_absmax, const voi
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return LADDER_E_SHAPE;
   IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, 1, pad_t, pad_l, N * Ho * Wo, KH * KW * Cin, act, make_fastdiv(Ho * Wo), make_fastdiv(Wo)};
   set_conv_taps(d);
-  if (!split_gather_ok(d) || halo_eligible(d)) return LADDER_E_SHAPE;
+  if (!split_gather_ok(d, true) || halo_eligible(d)) return LADDER_E_SHAPE;
   if (ws_need != nullptr) *ws_need = fwd_split_ws_bytes(d);
   if (dry) return LADDER_OK;
   return launch_fwd_split(x, x_absmax, packed, bias, y, d, prec, ws, ws_bytes, stream, nullptr, 0);
@@ -1943,7 +1947,7 @@ static int conv2d_bwd_data_split_impl(const void* dy, const float* dy_absmax, co
   set_conv_taps(d);
   if (ws_need != nullptr) *ws_need = 0;
   if (stride == 1) {
-    if (!split_gather_ok(d) || (gate_y == nullptr && halo_eligible(d))) return LADDER_E_SHAPE;
+    if (!split_gather_ok(d, true) || (gate_y == nullptr && halo_eligible(d))) return LADDER_E_SHAPE;
     if (ws_need != nullptr) *ws_need = fwd_split_ws_bytes(d);
     if (dry) return LADDER_OK;
     return launch_fwd_split(dy, dy_absmax, packed, nullptr, dx, d, prec, ws, ws_bytes, stream, gate_y, gate_act);

@@ -342,6 +342,10 @@ class Conv2D:
         return bool(self.ctx.ns and self.k == 3 and self.stride == 1 and self.padding == "same"
                     and L.query("ladder_conv3x3_split_eligible", N, H, W, cin, cout))
 
+    def _as_dense(self, M):
+        return bool(self.ctx.ns and self.k == 1 and self.stride == 1 and M <= 512 and self.cin >= 16
+                    and L.query("ladder_dense_small_eligible", M, self.cin, self.cout))
+
     def _packed_filter(self, transpose_flip):
         """Split bf16 planes of the filter bank in the kernel's LDS layout, re-packed when the weights changed (always while a
         hipGraph is being captured, so that a replay re-packs the then-current weights)."""
@@ -408,6 +412,11 @@ class Conv2D:
                 _timed(128120 + self.ctx.ns, 2.0 * N * Ho * Wo * self.k * self.k * self.cin * self.cout, "ladder_conv2d_fwd_split", args)
             self.x, self.y = x, y
             return y
+        if self._as_dense(N * H * W):                   # 1x1 conv over a tiny map (decoder conv0 on the 1x1 map) = a batch-sized dense layer
+            L.call("ladder_dense_fwd_small", _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y), N * H * W,
+                   self.cin, self.cout, L.ACT[self.act], self.ctx.stream)
+            self.x, self.y = x, y
+            return y
         _igemm(self.ctx, "ladder_conv2d_fwd", N * Ho * Wo, self.cin, self.cout, self.k * self.k * self.cin,
                _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y),
                N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl, L.ACT[self.act],
@@ -436,6 +445,18 @@ class Conv2D:
                    self.cout, L.ACT[gate_prev] if gate_prev else 0, wsp, wsn, _p(dx_amax), st)
             if dx is not None:
                 self.ctx.set_amax(dx, dx_amax)
+            self.x = self.y = None
+            return dx
+        if self._as_dense(N * H * W):
+            M = N * H * W
+            if wgrad:
+                L.call("ladder_dense_bwd_weight_small", _p(x), _p(dy), _p(self.ps.g[self.name + "/kernel"]),
+                       _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, M, self.cin, self.cout, st)
+            dx = None
+            if need_dx:
+                dx = self.ctx.empty(N, H, W, self.cin)
+                L.call("ladder_dense_bwd_data_small", _p(dy), _p(self.ps.w[self.name + "/kernel"]), _p(dx), M, self.cin, self.cout,
+                       _p(x) if gate_prev else None, L.ACT[gate_prev] if gate_prev else 0, st)
             self.x = self.y = None
             return dx
         dy_amax = None

@@ -159,6 +159,11 @@ GATHER_CASES = [
     (96, 32, 32, 128, 128, 3, 2, "same", None),            # strided encoder layer: forward + 4 parity classes of backward-data
     (160, 32, 32, 128, 160, 3, 2, "valid", "leaky_relu"),  # stride 2 VALID (15x15 output), Cout tile edge
     (13, 24, 40, 32, 192, 5, 1, "same", None),             # 5x5, ragged M (13*24*40 not a multiple of 128)
+    # small maps: a handful of 128x128 tiles, the chip is filled through split-K (dense outputs only: forward and stride-1 backward-data)
+    (128, 2, 2, 512, 512, 3, 1, "same", "leaky_relu"),     # decoder conv1 / conv2: M = 512, K = 4608
+    (128, 4, 4, 512, 512, 4, 1, "valid", "leaky_relu"),    # encoder conv6: 4x4 VALID -> 1x1, M = 128, K = 8192
+    (128, 8, 8, 256, 512, 3, 2, "same", "leaky_relu"),     # encoder conv5: M = 2048, K = 2304, stride 2
+    (37, 3, 5, 128, 160, 3, 1, "same", None),              # ragged: M = 555, Cout = 128 + 32, K = 1152
 ]
 
 
@@ -224,8 +229,9 @@ def test_conv2d_split_gather_fwd_bwd(gpu_ctx, case, prec):
     else:
         checked_dw = False
     # the cases are chosen so that every entry point is exercised by at least one of them
-    assert checked_dx == (case in (GATHER_CASES[1], GATHER_CASES[2])), case
-    assert checked_dw == (Cin % 128 == 0), case
+    small = N * Ho * Wo < 8192
+    assert checked_dx == (case in (GATHER_CASES[1], GATHER_CASES[2]) or (small and s == 1)), case
+    assert small or checked_dw == (Cin % 128 == 0), case
 
 
 def test_split_abi_errors(gpu_ctx):
