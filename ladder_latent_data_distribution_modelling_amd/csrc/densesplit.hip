@@ -33,11 +33,32 @@ __device__ __forceinline__ void load8(const float* __restrict__ p, long rs, int 
   }
 }
 
-__global__ __launch_bounds__(256) void gemm_small_split_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                               const float* __restrict__ bias, float* __restrict__ c,
-                                                               const float* __restrict__ gate, float* __restrict__ colsum,
-                                                               const GemmSmall g) {
-  __shared__ float red[4][32 * 33];
+__device__ __forceinline__ void mma_step(const float (&av)[8], const float (&bv)[8], f32x16& acc) {
+  uint2 alo[3], ahi[3], blo[3], bhi[3];
+  split4<3, false>(make_float4(av[0], av[1], av[2], av[3]), alo);
+  split4<3, false>(make_float4(av[4], av[5], av[6], av[7]), ahi);
+  split4<3, false>(make_float4(bv[0], bv[1], bv[2], bv[3]), blo);
+  split4<3, false>(make_float4(bv[4], bv[5], bv[6], bv[7]), bhi);
+  uint4 af[3], bf[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    af[p] = make_uint4(alo[p].x, alo[p].y, ahi[p].x, ahi[p].y);
+    bf[p] = make_uint4(blo[p].x, blo[p].y, bhi[p].x, bhi[p].y);
+  }
+#pragma unroll
+  for (int sum = 2; sum >= 0; --sum)
+#pragma unroll
+    for (int pa = 0; pa <= sum; ++pa) acc = mfma16<false>(af[pa], bf[sum - pa], acc);
+}
+
+// NW wavefronts per 32x32 tile; wavefront w takes K-steps w, w + NW, ... two at a time (both steps' loads are issued before the first
+// split: the kernel is bound by the load -> split -> MFMA latency chain, ~0.8 us per round, not by throughput)
+template <int NW, bool PAIR>
+__global__ __launch_bounds__(NW * 64) void gemm_small_split_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                   const float* __restrict__ bias, float* __restrict__ c,
+                                                                   const float* __restrict__ gate, float* __restrict__ colsum,
+                                                                   const GemmSmall g) {
+  __shared__ float red[NW][32 * 33];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
@@ -50,63 +71,65 @@ __global__ __launch_bounds__(256) void gemm_small_split_kernel(const float* __re
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   float csum = 0.f;                                           // column sum of B (bias gradient), this lane's column and r-octets
   const int nsteps = (g.R + 15) / 16;
-  for (int ks = wv; ks < nsteps; ks += 4) {
-    const int r0 = ks * 16 + 8 * lh;
-    float av[8], bv[8];
-    load8(ap, g.a_rs, r0, g.R, i_ok, av);
-    load8(bp, g.b_rs, r0, g.R, j_ok, bv);
+  for (int ks = wv; ks < nsteps; ks += (PAIR ? 2 : 1) * NW) {
+    const bool two = PAIR && ks + NW < nsteps;                // (wave-uniform; the 1024-thread variant is held to 128 VGPRs: one step)
+    float a0[8], b0[8], a1[8], b1[8];
+    load8(ap, g.a_rs, ks * 16 + 8 * lh, g.R, i_ok, a0);
+    load8(bp, g.b_rs, ks * 16 + 8 * lh, g.R, j_ok, b0);
+    load8(ap, g.a_rs, (ks + NW) * 16 + 8 * lh, g.R, i_ok && two, a1);
+    load8(bp, g.b_rs, (ks + NW) * 16 + 8 * lh, g.R, j_ok && two, b1);
     if (colsum != nullptr) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) csum += bv[e];
+      for (int e = 0; e < 8; ++e) csum += b0[e] + b1[e];
     }
-    uint2 alo[3], ahi[3], blo[3], bhi[3];
-    split4<3, false>(make_float4(av[0], av[1], av[2], av[3]), alo);
-    split4<3, false>(make_float4(av[4], av[5], av[6], av[7]), ahi);
-    split4<3, false>(make_float4(bv[0], bv[1], bv[2], bv[3]), blo);
-    split4<3, false>(make_float4(bv[4], bv[5], bv[6], bv[7]), bhi);
-    uint4 af[3], bf[3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      af[p] = make_uint4(alo[p].x, alo[p].y, ahi[p].x, ahi[p].y);
-      bf[p] = make_uint4(blo[p].x, blo[p].y, bhi[p].x, bhi[p].y);
-    }
-#pragma unroll
-    for (int sum = 2; sum >= 0; --sum)
-#pragma unroll
-      for (int pa = 0; pa <= sum; ++pa) acc = mfma16<false>(af[pa], bf[sum - pa], acc);
+    mma_step(a0, b0, acc);
+    if (two) mma_step(a1, b1, acc);
   }
-  // partial tiles of the 4 wavefronts -> LDS (row-major 32 x 33), fixed-order sum, epilogue with 128-byte row segments
+  // partial tiles of the NW wavefronts -> LDS (row-major 32 x 33), fixed-order sum, epilogue with 128-byte row segments
 #pragma unroll
   for (int e = 0; e < 16; ++e) red[wv][((e & 3) + 8 * (e >> 2) + 4 * lh) * 33 + l31] = acc[e];
   __syncthreads();
-  const int col = tid & 31, rq = tid >> 5;                   // 8 row groups x 32 columns
-  const int jj = j0 + col;
-  const float bval = (bias != nullptr && jj < g.J) ? bias[jj] : 0.f;
+  if (tid < 256) {
+    const int col = tid & 31, rq = tid >> 5;                 // 8 row groups x 32 columns
+    const int jj = j0 + col;
+    const float bval = (bias != nullptr && jj < g.J) ? bias[jj] : 0.f;
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int row = rq + 8 * rr, ii = i0 + row;
-    if (ii < g.I && jj < g.J) {
-      float v = ((red[0][row * 33 + col] + red[1][row * 33 + col]) + red[2][row * 33 + col]) + red[3][row * 33 + col];
-      v = ladder_act_fn(v + bval, g.act);
-      const long o = (long)ii * g.J + jj;
-      if (gate != nullptr) v *= ladder_act_grad_from_out(gate[o], g.gate_act);
-      c[o] = v;
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = rq + 8 * rr, ii = i0 + row;
+      if (ii < g.I && jj < g.J) {
+        float v = red[0][row * 33 + col];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += red[w][row * 33 + col];
+        v = ladder_act_fn(v + bval, g.act);
+        const long o = (long)ii * g.J + jj;
+        if (gate != nullptr) v *= ladder_act_grad_from_out(gate[o], g.gate_act);
+        c[o] = v;
+      }
     }
   }
-  if (colsum != nullptr && blockIdx.y == 0) {                 // db[j] = sum_r B(r, j): lanes (l31, lh) x 4 wavefronts, fixed order
+  if (colsum != nullptr && blockIdx.y == 0) {                 // db[j] = sum_r B(r, j): lanes (l31, lh) x NW wavefronts, fixed order
     __syncthreads();
     csum += __shfl_xor(csum, 32, 64);
     if (lh == 0) red[wv][l31] = csum;
     __syncthreads();
-    if (tid < 32 && j0 + tid < g.J) colsum[j0 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+    if (tid < 32 && j0 + tid < g.J) {
+      float v = red[0][tid];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) v += red[w][tid];
+      colsum[j0 + tid] = v;
+    }
   }
 }
 
 int launch_gemm_small(const float* a, const float* b, const float* bias, float* c, const float* gate, float* colsum, const GemmSmall& g,
                       hipStream_t st) {
   if (g.I <= 0 || g.J <= 0 || g.R <= 0) return LADDER_E_SHAPE;
-  const dim3 grid((g.J + 31) / 32, (g.I + 31) / 32), block(256);
-  hipLaunchKernelGGL(gemm_small_split_kernel, grid, block, 0, st, a, b, bias, c, gate, colsum, g);
+  const dim3 grid((g.J + 31) / 32, (g.I + 31) / 32);
+  // fewer tiles than compute units and a reduction of >= 32 steps: 16 wavefronts per tile (a fixed 16-way K split inside the workgroup)
+  const long tiles = (long)grid.x * grid.y;
+  const int nsteps = (g.R + 15) / 16;
+  if (tiles <= 128 && nsteps >= 32) hipLaunchKernelGGL((gemm_small_split_kernel<16, false>), grid, dim3(1024), 0, st, a, b, bias, c, gate, colsum, g);
+  else hipLaunchKernelGGL((gemm_small_split_kernel<4, true>), grid, dim3(256), 0, st, a, b, bias, c, gate, colsum, g);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
