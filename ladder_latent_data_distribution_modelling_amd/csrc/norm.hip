@@ -552,6 +552,41 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict
   reinterpret_cast<T*>(dx)[((size_t)row * W + ix) * CV + cv] = acc;
 }
 
+// The factor-2 case of the transpose (every resize of the CelebA decoder but one): output row 2i carries weight 1 to input row i, rows
+// 2i-1 and 2i+1 weight 1/2 (row 2H-1 weight 1: its upper neighbour is clamped to H-1) -- a 3x3 footprint with constant weights.  All
+// nine loads are issued before the first add (the generic kernel walks a 4x4 window behind integer divisions, one load at a time),
+// the sum runs in the same (oy, ox) order.
+template <int V>
+__global__ __launch_bounds__(256) void resize_bwd_x2_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int CV,
+                                                            int bpr) {
+  using T = typename ResizeVec<V>::T;
+  const int row = blockIdx.x / bpr;
+  const int j = (blockIdx.x - row * bpr) * blockDim.x + threadIdx.x;
+  if (j >= W * CV) return;
+  const int n = row / H, iy = row - n * H;
+  const int ix = j / CV, cv = j - ix * CV;
+  const int OW = 2 * W;
+  const T* base = reinterpret_cast<const T*>(dy) + (size_t)n * (2 * H) * OW * CV + cv;
+  const float wy[3] = {iy > 0 ? 0.5f : 0.f, 1.f, iy == H - 1 ? 1.f : 0.5f};
+  const float wx[3] = {ix > 0 ? 0.5f : 0.f, 1.f, ix == W - 1 ? 1.f : 0.5f};
+  T v[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const int oy = max(2 * iy - 1 + a, 0), ox = max(2 * ix - 1 + b, 0);        // (clamped taps carry weight 0)
+      v[a][b] = base[((size_t)oy * OW + ox) * CV];
+    }
+  T acc;
+  rz_zero(acc);
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      if (wy[a] != 0.f && wx[b] != 0.f) rz_fma(acc, wy[a] * wx[b], v[a][b]);
+  reinterpret_cast<T*>(dx)[((size_t)row * W + ix) * CV + cv] = acc;
+}
+
 // ----------------------------------------------------------------------------- minibatch assembly from an HBM-resident data set
 // out[b, :] = scale * float(src[idx[b], :]): the reference's input pipeline (uint8 CelebA pixels * 1/255, models.py:354-371;
 // MNIST floats, data_loader.py:19-33) for a data set that lives in device memory (CelebA train split as uint8 = 8.8 GB of the
@@ -820,7 +855,10 @@ static int resize_launch(bool fwd, const float* a, float* b, int N, int H, int W
     if (v4) hipLaunchKernelGGL(resize_fwd_kernel<4>, grid, block, 0, stream, a, b, H, W, CV, fy, fx, bpr);
     else hipLaunchKernelGGL(resize_fwd_kernel<1>, grid, block, 0, stream, a, b, H, W, CV, fy, fx, bpr);
   } else {
-    if (v4) hipLaunchKernelGGL(resize_bwd_kernel<4>, grid, block, 0, stream, a, b, H, W, CV, fy, fx, bpr);
+    if (fy == 2 && fx == 2) {
+      if (v4) hipLaunchKernelGGL(resize_bwd_x2_kernel<4>, grid, block, 0, stream, a, b, H, W, CV, bpr);
+      else hipLaunchKernelGGL(resize_bwd_x2_kernel<1>, grid, block, 0, stream, a, b, H, W, CV, bpr);
+    } else if (v4) hipLaunchKernelGGL(resize_bwd_kernel<4>, grid, block, 0, stream, a, b, H, W, CV, fy, fx, bpr);
     else hipLaunchKernelGGL(resize_bwd_kernel<1>, grid, block, 0, stream, a, b, H, W, CV, fy, fx, bpr);
   }
   LADDER_CHECK_LAUNCH();

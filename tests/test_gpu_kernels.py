@@ -228,7 +228,8 @@ def test_instance_norm_style(gpu_ctx, shape):
     close(dx, xt.grad, 1e-3 if H * W <= 4 else 5e-5, "dx")
 
 
-@pytest.mark.parametrize("shape,out", [((2, 1, 1, 8), 2), ((2, 2, 2, 16), 8), ((1, 8, 8, 4), 16), ((2, 5, 5, 3), 10), ((2, 4, 4, 4), 4)])
+@pytest.mark.parametrize("shape,out", [((2, 1, 1, 8), 2), ((2, 2, 2, 16), 8), ((1, 8, 8, 4), 16), ((2, 5, 5, 3), 10), ((2, 4, 4, 4), 4),
+                                       ((3, 16, 16, 32), 32), ((2, 3, 3, 8), 12)])
 def test_resize_legacy_bilinear(gpu_ctx, shape, out):
     L = _lib()
     rng = np.random.default_rng(out)
