@@ -226,6 +226,13 @@ int ladder_bn_bwd_stats(const float* dy, const float* x, const float* mean_rstd,
 int ladder_bn_bwd_apply(const float* dy, const float* x, const float* mean_rstd, const float* gamma,
                         const float* beta, const float* dsums, double count, float* dx,
                         float* dgamma, float* dbeta, size_t rows, int C, int act, ladder_stream_t stream);
+/* The two apply calls, additionally producing the absolute-maximum record (ladder_absmax, section N1s) of the tensor they write --
+ * y resp. dx -- for the split-precision convolution that consumes it (C % 4 == 0, 16-byte aligned tensors; dx not NULL). */
+int ladder_bn_fwd_apply_absmax(const float* x, const float* sums, double count, const float* gamma, const float* beta, float* y,
+                               float* mean_rstd, size_t rows, int C, float eps, int act, float* y_absmax, ladder_stream_t stream);
+int ladder_bn_bwd_apply_absmax(const float* dy, const float* x, const float* mean_rstd, const float* gamma, const float* beta,
+                               const float* dsums, double count, float* dx, float* dgamma, float* dbeta, size_t rows, int C, int act,
+                               float* dx_absmax, ladder_stream_t stream);
 
 /* ---------------------------------------------------------------- N4+N5+N12: instance_norm + style_mod + leaky
  * codes/models.py:522-528,531-537,547-554,564-571; codes/modules.py:6-10.

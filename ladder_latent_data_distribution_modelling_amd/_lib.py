@@ -115,6 +115,8 @@ PROTOTYPES = {
     "ladder_presplit_bytes": (_z, [_z, _i]),
     "ladder_presplit": (_i, [_p, _p, _p, _z, _i, _p]),
     "ladder_conv3x3_split_proj": (_i, [_p, _p, _p, _p, _p, _p, _p, _p] + [_i] * 8 + [_p]),
+    "ladder_bn_fwd_apply_absmax": (_i, [_p, _p, _d, _p, _p, _p, _p, _z, _i, _f, _i, _p, _p]),
+    "ladder_bn_bwd_apply_absmax": (_i, [_p, _p, _p, _p, _p, _p, _d, _p, _p, _p, _z, _i, _i, _p, _p]),
     "ladder_in_style_fwd_absmax": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _z, _p, _p]),
     "ladder_in_style_bwd_absmax": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _z, _p, _p]),
     "ladder_conv1x1_smallcout_bwd_absmax": (_i, [_p, _p, _p, _p, _p, _p, C.c_long, _i, _i, _i, _p, _z, _p, _p]),

@@ -123,7 +123,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, double count,
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean_rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       float* __restrict__ y, size_t n, int C, int act) {
+                                                       float* __restrict__ y, size_t n, int C, int act, float* __restrict__ yamax) {
   // C % 4 == 0 path: float4 per thread, grid-stride; the 4 channels' coefficients are loaded once when the stride is a multiple of C
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   int c = (int)((i0 * 4) % C);
   float4 mu = *reinterpret_cast<const float4*>(mean_rstd + c), rs = *reinterpret_cast<const float4*>(mean_rstd + C + c);
   float4 g = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+  float ymax = 0.f;
   for (size_t i = i0; i < n / 4; i += stride) {
     if (!fixed) {
       c = (int)((i * 4) % C);
@@ -144,7 +145,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     o.z = ladder_act_fn(g.z * ((v.z - mu.z) * rs.z) + be.z, act);
     o.w = ladder_act_fn(g.w * ((v.w - mu.w) * rs.w) + be.w, act);
     reinterpret_cast<float4*>(y)[i] = o;
+    ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
   }
+  if (yamax != nullptr) amax_commit_block(ymax, yamax);     // max|y| for the split contraction that consumes y
 }
 __global__ void bn_apply_scalar_kernel(const float* __restrict__ x, const float* __restrict__ mean_rstd,
                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -175,10 +178,12 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
 __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                               const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ dsums,
-                                                              float inv_count, float* __restrict__ dx, size_t n, int C, int act) {
+                                                              float inv_count, float* __restrict__ dx, size_t n, int C, int act,
+                                                              float* __restrict__ dxamax) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool fixed = ((stride * 4) % (size_t)C) == 0;
+  float dmax = 0.f;
   float mu[4], rs[4], g[4], be[4], s1[4], s2[4];
   auto coeffs = [&](int c) {
 #pragma unroll
@@ -200,7 +205,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
       o[j] = g[j] * rs[j] * (dp - s1[j] - xh * s2[j]);
     }
     reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    dmax = fmaxf(fmaxf(dmax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
   }
+  if (dxamax != nullptr) amax_commit_block(dmax, dxamax);
 }
 __global__ void bn_param_grad_kernel(const float* __restrict__ dsums, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -735,11 +742,20 @@ int ladder_bn_fwd_stats(const float* x, float* sums, size_t rows, int C, void* w
 
 int ladder_bn_fwd_apply(const float* x, const float* sums, double count, const float* gamma, const float* beta, float* y,
                         float* mean_rstd, size_t rows, int C, float eps, int act, ladder_stream_t stream) {
+  return ladder_bn_fwd_apply_absmax(x, sums, count, gamma, beta, y, mean_rstd, rows, C, eps, act, nullptr, stream);
+}
+
+int ladder_bn_fwd_apply_absmax(const float* x, const float* sums, double count, const float* gamma, const float* beta, float* y,
+                               float* mean_rstd, size_t rows, int C, float eps, int act, float* y_absmax, ladder_stream_t stream) {
   if (rows == 0 || C <= 0 || count <= 0) return LADDER_E_SHAPE;
+  if (y_absmax != nullptr) {                     // the record is produced by the vectorised kernel only
+    if (!(C % 4 == 0 && ladder_aligned16(x) && ladder_aligned16(y))) return LADDER_E_SHAPE;
+    if (hipMemsetAsync(y_absmax, 0, LADDER_ABSMAX_FLOATS * sizeof(float), stream) != hipSuccess) return LADDER_E_LAUNCH;
+  }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sums, count, eps, mean_rstd, C);
   const size_t n = rows * (size_t)C;
   if (C % 4 == 0 && ladder_aligned16(x) && ladder_aligned16(y))
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, stream, x, mean_rstd, gamma, beta, y, n, C, act);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, stream, x, mean_rstd, gamma, beta, y, n, C, act, y_absmax);
   else
     hipLaunchKernelGGL(bn_apply_scalar_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, x, mean_rstd, gamma, beta, y, n, C, act);
   LADDER_CHECK_LAUNCH();
@@ -766,12 +782,22 @@ int ladder_bn_bwd_stats(const float* dy, const float* x, const float* mean_rstd,
 int ladder_bn_bwd_apply(const float* dy, const float* x, const float* mean_rstd, const float* gamma, const float* beta,
                         const float* dsums, double count, float* dx, float* dgamma, float* dbeta, size_t rows, int C, int act,
                         ladder_stream_t stream) {
+  return ladder_bn_bwd_apply_absmax(dy, x, mean_rstd, gamma, beta, dsums, count, dx, dgamma, dbeta, rows, C, act, nullptr, stream);
+}
+
+int ladder_bn_bwd_apply_absmax(const float* dy, const float* x, const float* mean_rstd, const float* gamma, const float* beta,
+                               const float* dsums, double count, float* dx, float* dgamma, float* dbeta, size_t rows, int C, int act,
+                               float* dx_absmax, ladder_stream_t stream) {
   if (rows == 0 || C <= 0 || count <= 0) return LADDER_E_SHAPE;
   const size_t n = rows * (size_t)C;
+  if (dx_absmax != nullptr) {
+    if (!(dx != nullptr && C % 4 == 0 && ladder_aligned16(x) && ladder_aligned16(dy) && ladder_aligned16(dx))) return LADDER_E_SHAPE;
+    if (hipMemsetAsync(dx_absmax, 0, LADDER_ABSMAX_FLOATS * sizeof(float), stream) != hipSuccess) return LADDER_E_LAUNCH;
+  }
   if (dx != nullptr) {
     if (C % 4 == 0 && ladder_aligned16(x) && ladder_aligned16(dy) && ladder_aligned16(dx))
       hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, stream, dy, x, mean_rstd, gamma, beta, dsums,
-                         (float)(1.0 / count), dx, n, C, act);
+                         (float)(1.0 / count), dx, n, C, act, dx_absmax);
     else
       hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, dy, x, mean_rstd, gamma, beta, dsums,
                          (float)(1.0 / count), dx, n, C, act);

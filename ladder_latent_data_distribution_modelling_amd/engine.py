@@ -603,8 +603,10 @@ class BatchNormAct:
         self.count = float(rows) * ctx.comm.world
         y = torch.empty_like(x)
         self.mean_rstd = ctx.empty(2 * C)
-        L.call("ladder_bn_fwd_apply", _p(x), _p(sums), self.count, _p(self.ps.w[self.name + "/gamma"]),
-               _p(self.ps.w[self.name + "/beta"]), _p(y), _p(self.mean_rstd), rows, C, BN_EPS, L.ACT[self.act], ctx.stream)
+        y_amax = ctx.new_amax() if (ctx.ns == 4 and C % 4 == 0) else None
+        L.call("ladder_bn_fwd_apply_absmax", _p(x), _p(sums), self.count, _p(self.ps.w[self.name + "/gamma"]),
+               _p(self.ps.w[self.name + "/beta"]), _p(y), _p(self.mean_rstd), rows, C, BN_EPS, L.ACT[self.act], _p(y_amax), ctx.stream)
+        ctx.set_amax(y, y_amax)
         self.x = x
         return y
 
@@ -621,9 +623,12 @@ class BatchNormAct:
         dx = torch.empty_like(x) if need_dx else None
         # dgamma/dbeta are global sums already: written on every rank, the group all-reduce must not re-sum
         # them -> the engine divides BN parameter grads by world size before the flat all-reduce.
-        L.call("ladder_bn_bwd_apply", _p(dy), _p(x), _p(self.mean_rstd), _p(gam), _p(bet), _p(dsums), self.count, _p(dx),
+        dx_amax = ctx.new_amax() if (need_dx and ctx.ns == 4 and C % 4 == 0) else None
+        L.call("ladder_bn_bwd_apply_absmax", _p(dy), _p(x), _p(self.mean_rstd), _p(gam), _p(bet), _p(dsums), self.count, _p(dx),
                _p(self.ps.g[self.name + "/gamma"]) if wgrad else None, _p(self.ps.g[self.name + "/beta"]) if wgrad else None,
-               rows, C, L.ACT[self.act], ctx.stream)
+               rows, C, L.ACT[self.act], _p(dx_amax), ctx.stream)
+        if dx is not None:
+            ctx.set_amax(dx, dx_amax)
         if wgrad and ctx.comm.world > 1:
             self.ps.g[self.name + "/gamma"].mul_(1.0 / ctx.comm.world)
             self.ps.g[self.name + "/beta"].mul_(1.0 / ctx.comm.world)

@@ -290,6 +290,25 @@ def test_fused_absmax_records_of_producers(gpu_ctx):
     L.call("ladder_conv1x1_smallcout_bwd_absmax", p(xs), p(dys), p(w), p(dxs), p(dw), p(db), M, Cin, Cout, 1, wsp, wsn, p(rec), st)
     L.call("ladder_conv1x1_smallcout_bwd", p(xs), p(dys), p(w), p(dxs0), p(dw), p(db), M, Cin, Cout, 1, wsp, wsn, st)
     assert torch.equal(dxs, dxs0) and rec.max().item() == dxs.abs().max().item()
+    # batch-norm apply, forward and backward (encoder layers): big enough for the grid-stride loop to iterate (> 2048 x 256 float4)
+    rows, C = 128 * 70 * 70, 32
+    xb, dyb = dev(rng.standard_normal((rows, C)) * 3 + 1), dev(rng.standard_normal((rows, C)) * 1e-3)
+    gam, bet = dev(rng.standard_normal(C)), dev(rng.standard_normal(C))
+    wsp, wsn = gpu_ctx.ws(L.query("ladder_bn_workspace_bytes", rows, C))
+    sums, mrb, dsums = torch.empty(2 * C, device="cuda"), torch.empty(2 * C, device="cuda"), torch.empty(2 * C, device="cuda")
+    L.call("ladder_bn_fwd_stats", p(xb), p(sums), rows, C, wsp, wsn, st)
+    yb, yb0 = torch.empty_like(xb), torch.empty_like(xb)
+    L.call("ladder_bn_fwd_apply_absmax", p(xb), p(sums), float(rows), p(gam), p(bet), p(yb), p(mrb), rows, C, 1e-3, 1, p(rec), st)
+    L.call("ladder_bn_fwd_apply", p(xb), p(sums), float(rows), p(gam), p(bet), p(yb0), p(mrb), rows, C, 1e-3, 1, st)
+    assert torch.equal(yb, yb0) and rec.max().item() == yb.abs().max().item()
+    L.call("ladder_bn_bwd_stats", p(dyb), p(xb), p(mrb), p(gam), p(bet), p(dsums), rows, C, 1, wsp, wsn, st)
+    dxb, dxb0, dg, dbt = torch.empty_like(xb), torch.empty_like(xb), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    L.call("ladder_bn_bwd_apply_absmax", p(dyb), p(xb), p(mrb), p(gam), p(bet), p(dsums), float(rows), p(dxb), p(dg), p(dbt), rows, C, 1,
+           p(rec), st)
+    L.call("ladder_bn_bwd_apply", p(dyb), p(xb), p(mrb), p(gam), p(bet), p(dsums), float(rows), p(dxb0), p(dg), p(dbt), rows, C, 1, st)
+    assert torch.equal(dxb, dxb0) and rec.max().item() == dxb.abs().max().item()
+    assert L.query("ladder_bn_bwd_apply_absmax", p(dyb), p(xb), p(mrb), p(gam), p(bet), p(dsums), float(rows), None, p(dg), p(dbt), rows, C,
+                   1, p(rec), st) != 0                            # a record of a tensor that is not written
 
 
 @pytest.mark.parametrize("prec", ["f16x3", "bf16x6"])
