@@ -349,18 +349,25 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
 //   * the LDS images stay [32-channel block][pixel][32 channels x 16 bit] (64-byte pixel rows: the 4 rows x 64 B a half-wave
 //     touches are one contiguous 256-byte bank row -> conflict-free), written by plain 8-byte stores of split float4s;
 //   * a filter tap is a whole-pixel address offset into the halo image (no misaligned or shifted copies).
-// Work decomposition as wgrad3x3_halo_kernel (igemm.hip): one workgroup = 12 wavefronts owns a 64 ci x 128 co slab of dW for all 9
-// taps (72 MFMA tiles), wavefront -> (filter row r, ci half cb, co pair njp) with 6 tiles; it walks 2x32-pixel patches
-// (K = 4 x 16 pixels; 4x34 halo), double-buffered in LDS; partial sums over the patch split are reduced in a fixed order by the caller.
+// One workgroup = 8 wavefronts owns a 64 ci x 128 co slab of dW for all 9 taps (72 MFMA tiles); wavefront (cb, nq) owns ALL 9 taps
+// of a 32 ci x 32 co block (9 tiles, 144 accumulator registers): per 16-pixel K-step one dy fragment serves 27 MFMAs and the three
+// shifted x fragments of a filter row 9 -- 20 fragment reads per 27 MFMAs (the first version, 12 wavefronts x 6 tiles as in
+// wgrad3x3_halo_kernel of igemm.hip, needed 20 per 18: 983 KB of LDS reads per patch against 6912 MFMA cycles).  2 wavefronts per SIMD
+// leave 256 registers per lane.  The workgroup walks 2x32-pixel patches (K = 4 x 16 pixels; 4x34 halo) DOWN a 32-pixel column of an
+// image, double-buffered in LDS; partial sums over the patch split are reduced in a fixed order by the caller.
+// Memory side (measured, conv7 at batch 64): walking along W with the slabs of one pixel split on different XCDs read 2.14 GB from HBM
+// per launch (8 % L2 hits); the column walk (consecutive patches share two of four halo rows) + placing the slabs of a split on one
+// XCD brought that to 1.10 GB = the operands once.  Time barely moved -- the kernel is bound by the per-unit ISSUE cost of staging
+// (address arithmetic, split, LDS stores: no-staging ablation 433 TF), which the per-thread offset tables below cut by a third.
 constexpr int WS_CI = 64, WS_CO = 128, WS_PH = 2, WS_PW = 32, WS_HW = WS_PW + 2, WS_HH = WS_PH + 2;
-constexpr int WS_THREADS = 768;
+constexpr int WS_THREADS = 512;
 constexpr int WS_XPIX = WS_HH * WS_HW, WS_DPIX = WS_PH * WS_PW;      // 136 halo pixels, 64 output pixels per patch
 constexpr int WS_XBLK = WS_XPIX * 64 + 64, WS_DBLK = WS_DPIX * 64 + 64;   // bytes per 32-channel block (+64: blocks land on different banks)
 constexpr int WS_XPLANE = 2 * WS_XBLK, WS_DPLANE = 4 * WS_DBLK;
 constexpr int WS_XU = WS_XPIX * (WS_CI / 4), WS_DU = WS_DPIX * (WS_CO / 4);                     // float4 units per patch: 2176, 2048
-constexpr int WS_ROUNDS = (WS_XU + WS_DU + WS_THREADS - 1) / WS_THREADS;                        // 6 staging rounds
+constexpr int WS_ROUNDS = (WS_XU + WS_DU + WS_THREADS - 1) / WS_THREADS;                        // 9 staging rounds (the last one 1/4 full)
 constexpr int WS_KSTEPS = WS_DPIX / 16;                                                          // 4 MFMA K-steps per patch
-static_assert(WS_ROUNDS == 6 && WS_KSTEPS == 4, "staging schedule below is written for 2x32 patches");
+static_assert(WS_ROUNDS == 9 && WS_KSTEPS == 4, "staging schedule below is written for 2x32 patches");
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 lds_tr_frag(const unsigned char* p) {
@@ -389,128 +396,153 @@ __device__ __forceinline__ float frag_sum(const uint4 f) {
 }
 
 template <int PREC>
-__global__ __launch_bounds__(WS_THREADS, 3) void wgrad3x3_split_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                                      float* __restrict__ out, float* __restrict__ bias_part,
-                                                                      const int N, const int H, const int W, const int Cin,
-                                                                      const int Cout, const int tiles_co, const int patches_per_split,
-                                                                      const float* __restrict__ xamax, const float* __restrict__ damax) {
+__global__ __launch_bounds__(WS_THREADS, 2) void wgrad3x3_split_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                       float* __restrict__ out, float* __restrict__ bias_part,
+                                                                       const int N, const int H, const int W, const int Cin,
+                                                                       const int Cout, const int tiles_ci, const int tiles_co,
+                                                                       const int nsplits, const int patches_per_split,
+                                                                       const float* __restrict__ xamax, const float* __restrict__ damax) {
   constexpr int NS = Fmt<PREC>::NS;
   constexpr bool F16 = Fmt<PREC>::F16;
   constexpr int BUF = NS * (WS_XPLANE + WS_DPLANE);
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wv = tid >> 6;            // 12 wavefronts
+  const int lane = tid & 63, wv = tid >> 6;            // 8 wavefronts
   const int l31 = lane & 31, lh = lane >> 5, l15 = lane & 15;
-  const int ci0 = (blockIdx.x / tiles_co) * WS_CI, co0 = (blockIdx.x % tiles_co) * WS_CO;
+  // 1-D grid: the workgroups that walk the SAME pixel split (one per ci x co slab) get linear ids 8 apart -- same XCD, dispatched
+  // together -- so that the x / dy rows they share are fetched from HBM once and hit in that XCD's L2 for the others
+  const int slabs = tiles_ci * tiles_co;
+  const int grp = blockIdx.x / (8 * slabs), within = blockIdx.x - grp * (8 * slabs);
+  const int slab = within >> 3, split = grp * 8 + (within & 7);
+  if (split >= nsplits) return;
+  const int ci0 = (slab / tiles_co) * WS_CI, co0 = (slab % tiles_co) * WS_CO;
   const int WP = W / WS_PW, HP = H / WS_PH;
   const int q_total = N * HP * WP;
-  const int q0 = blockIdx.y * patches_per_split, q1 = min(q_total, q0 + patches_per_split);
-  const int r = wv >> 2, cb = (wv >> 1) & 1, njp = wv & 1;
+  const int q0 = split * patches_per_split, q1 = min(q_total, q0 + patches_per_split);
+  const int cb = wv >> 2, nq = wv & 3;                 // ci half, co quarter
   float cx = 1.f, cd = 1.f;
   if (F16) {
     cx = scale_from_absmax(amax_load(xamax));
     cd = scale_from_absmax(amax_load(damax));
   }
-  // fragment addresses (bytes inside a buffer): pixel row of 64 B, this lane's 4-channel group inside its 16-lane block
   const int frag_lane = (8 * lh + (l15 >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (l15 & 3)) * 2;
-  const int a_off = cb * WS_XBLK + r * WS_HW * 64 + frag_lane;                        // + plane*WS_XPLANE + (halo pixel of the k-step + s) * 64
-  const int b_off = NS * WS_XPLANE + (njp * 2) * WS_DBLK + frag_lane;                 // + plane*WS_DPLANE + j*WS_DBLK + (pixel of the k-step) * 64
-  // bias gradient = column sums of dy, read off the centre-row B fragments (every output channel is covered exactly once by the
-  // r = 1, cb = 0 wavefronts): the two planes of a fragment add up to dy * cd to 2^-23 relative.
-  const bool do_bias = (bias_part != nullptr) && (ci0 == 0) && r == 1 && cb == 0;
+  const int a_off = cb * WS_XBLK + frag_lane;                             // + plane*WS_XPLANE + (halo pixel of the k-step and tap) * 64
+  const int b_off = NS * WS_XPLANE + nq * WS_DBLK + frag_lane;            // + plane*WS_DPLANE + (pixel of the k-step) * 64
+  const bool do_bias = (bias_part != nullptr) && (ci0 == 0) && cb == 0;   // every output channel once: the cb = 0 wavefronts
 
-  f32x16 acc[6];                                       // [j][s]
+  f32x16 acc[9];                                       // [tap]
 #pragma unroll
-  for (int i = 0; i < 6; ++i)
+  for (int i = 0; i < 9; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-  float bsum[2] = {0.f, 0.f};
+  float bsum = 0.f;
 
-  // staging: the 2176 halo units and the 2048 dy units of a patch form ONE list of float4 units, 6 rounds of 768 threads; two rounds
-  // are in flight across each of the first three MFMA blocks of a patch (8 staging registers)
-  float4 r0, r1;
-  // coordinates of the patch being staged (the next one), advanced incrementally: no divisions in the loop
-  int pn = q0 / (HP * WP), ph0, pw0;
-  {
-    const int rem = q0 - pn * (HP * WP), hp = rem / WP;
-    ph0 = hp * WS_PH;
-    pw0 = (rem - hp * WP) * WS_PW;
+  float4 r0, r1, r2;                                   // one batch = three staging rounds, in flight across one K-step
+  // Staging units: everything that does not depend on the patch is computed ONCE per thread -- the element offset of the unit from the
+  // patch's origin pixel, its LDS offset, and which image borders would invalidate it (bit 0 top, 1 bottom, 2 left, 3 right halo).  Per
+  // patch a unit costs: border test, one load off a wave-uniform base, four selects (the per-patch address arithmetic -- a division,
+  // bounds tests and a 64-bit multiply-add chain per unit -- was a quarter of the kernel's time).
+  int goff[WS_ROUNDS], loff[WS_ROUNDS];
+  uint64_t bmask = 0;                                  // 4 bits per round
+#pragma unroll
+  for (int i = 0; i < WS_ROUNDS; ++i) {
+    const int u = tid + i * WS_THREADS;
+    if (u < WS_XU) {
+      const int pix = u >> 4, q4 = u & 15;
+      const int hr = pix / WS_HW, hc = pix - hr * WS_HW;
+      goff[i] = ((hr - 1) * W + (hc - 1)) * Cin + q4 * 4;
+      loff[i] = (q4 >> 3) * WS_XBLK + pix * 64 + (q4 & 7) * 8;
+      bmask |= (uint64_t)((hr == 0 ? 1 : 0) | (hr == WS_HH - 1 ? 2 : 0) | (hc == 0 ? 4 : 0) | (hc == WS_HW - 1 ? 8 : 0)) << (4 * i);
+    } else if (u < WS_XU + WS_DU) {
+      const int v = u - WS_XU, pp = v >> 5, q4 = v & 31;
+      goff[i] = ((pp >> 5) * W + (pp & 31)) * Cout + q4 * 4;
+      loff[i] = NS * WS_XPLANE + (q4 >> 3) * WS_DBLK + pp * 64 + (q4 & 7) * 8;
+      if (co0 + q4 * 4 >= Cout) bmask |= (uint64_t)15 << (4 * i);            // channel tail of the last co slab: never valid
+    } else {
+      goff[i] = 0;
+      loff[i] = -1;                                    // idle slot of the last round
+    }
   }
+  int pn = q0 / (HP * WP), ph0, pw0;                   // the patch being staged (the next one), advanced incrementally
+  {
+    const int rem = q0 - pn * (HP * WP), wp = rem / HP;
+    pw0 = wp * WS_PW;
+    ph0 = (rem - wp * HP) * WS_PH;
+  }
+  // (patches are walked DOWN a 32-pixel column of an image: consecutive patches share two of their four halo rows -> L2 hits)
   auto next_patch = [&]() {
-    pw0 += WS_PW;
-    if (pw0 >= W) {
-      pw0 = 0;
-      ph0 += WS_PH;
-      if (ph0 >= H) {
-        ph0 = 0;
+    ph0 += WS_PH;
+    if (ph0 >= H) {
+      ph0 = 0;
+      pw0 += WS_PW;
+      if (pw0 >= W) {
+        pw0 = 0;
         ++pn;
       }
     }
   };
+  const float* xb = x;                                  // wave-uniform bases of the staged patch: its origin pixel, first channel of the slab
+  const float* db = dy;
+  unsigned pmask = 0;
+  auto set_patch = [&]() {
+    const long pix0 = ((long)pn * H + ph0) * W + pw0;
+    xb = x + pix0 * Cin + ci0;
+    db = dy + pix0 * Cout + co0;
+    pmask = (ph0 == 0 ? 1u : 0u) | (ph0 + WS_PH >= H ? 2u : 0u) | (pw0 == 0 ? 4u : 0u) | (pw0 + WS_PW >= W ? 8u : 0u);
+  };
   auto load_unit = [&](int i) -> float4 {
     const int u = tid + i * WS_THREADS;
-    const int n = pn, h0 = ph0, w0 = pw0;
-    const float* src = gs_zero16;
-    if (u < WS_XU) {
-      const int pix = u >> 4, q4 = u & 15;
-      const int hr = pix / WS_HW, hc = pix - hr * WS_HW;
-      const int hi = h0 - 1 + hr, wi = w0 - 1 + hc;
-      if (hi >= 0 && hi < H && wi >= 0 && wi < W) src = x + (((long)n * H + hi) * W + wi) * Cin + ci0 + q4 * 4;
-    } else if (u < WS_XU + WS_DU) {
-      const int v = u - WS_XU, p = v >> 5, q4 = v & 31;
-      if ((co0 + q4 * 4) < Cout) src = dy + (((long)n * H + h0 + (p >> 5)) * W + w0 + (p & 31)) * Cout + co0 + q4 * 4;
-    }
-    return *reinterpret_cast<const float4*>(src);
+    const bool isx = u < WS_XU;                          // (compile-time for all rounds but the mixed one)
+    // x units: invalid when one of their border bits meets the patch's; dy units carry 0 (valid) or 15 (channel tail)
+    const unsigned m = (unsigned)(bmask >> (4 * i)) & 15u;
+    const bool bad = isx ? ((m & pmask) != 0u) : (m == 15u);
+    const int off = bad ? 0 : goff[i];
+    float4 v = *reinterpret_cast<const float4*>((isx ? xb : db) + off);
+    if (bad) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    return v;
   };
   auto store_unit = [&](int buf, int i, float4 v) {
-    const int u = tid + i * WS_THREADS;
-    if (u >= WS_XU + WS_DU) return;
-    const bool isx = u < WS_XU;
-    const int w = isx ? u : u - WS_XU;
-    const int pix = isx ? (w >> 4) : (w >> 5), q4 = isx ? (w & 15) : (w & 31);
+    if (loff[i] < 0) return;
+    const bool isx = (tid + i * WS_THREADS) < WS_XU;
     const float c = isx ? cx : cd;
     if (F16) v = make_float4(v.x * c, v.y * c, v.z * c, v.w * c);
     uint2 pl[NS];
     split4<NS, F16>(v, pl);
-    const int off = (isx ? (q4 >> 3) * WS_XBLK : NS * WS_XPLANE + (q4 >> 3) * WS_DBLK) + pix * 64 + (q4 & 7) * 8;
 #pragma unroll
-    for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(lds + buf * BUF + off + p * (isx ? WS_XPLANE : WS_DPLANE)) = pl[p];
+    for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(lds + buf * BUF + loff[i] + p * (isx ? WS_XPLANE : WS_DPLANE)) = pl[p];
   };
   auto mma_step = [&](int buf, int ks) {
     const int prow = ks >> 1, pcol = (ks & 1) * 16;                                   // 16 pixels of patch row prow starting at pcol
     const unsigned char* base = lds + buf * BUF;
-    uint4 a[3][NS], b[2][NS];
+    uint4 b0 = lds_tr_frag(base + b_off + (prow * WS_PW + pcol) * 64);
+    uint4 b1 = lds_tr_frag(base + b_off + WS_DPLANE + (prow * WS_PW + pcol) * 64);
 #pragma unroll
-    for (int p = 0; p < NS; ++p) {
+    for (int r = 0; r < 3; ++r) {
+      uint4 a0[3], a1[3];
 #pragma unroll
-      for (int s = 0; s < 3; ++s) a[s][p] = lds_tr_frag(base + a_off + p * WS_XPLANE + (prow * WS_HW + pcol + s) * 64);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) b[j][p] = lds_tr_frag(base + b_off + p * WS_DPLANE + j * WS_DBLK + (prow * WS_PW + pcol) * 64);
-    }
-#pragma unroll
-    for (int sum = NS - 1; sum >= 0; --sum)
-#pragma unroll
-      for (int pa = 0; pa <= sum; ++pa) {
-        const int pb = sum - pa;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int s = 0; s < 3; ++s) acc[j * 3 + s] = mfma16<F16>(a[s][pa], b[j][pb], acc[j * 3 + s]);
+      for (int s = 0; s < 3; ++s) {
+        a0[s] = lds_tr_frag(base + a_off + ((prow + r) * WS_HW + pcol + s) * 64);
+        a1[s] = lds_tr_frag(base + a_off + WS_XPLANE + ((prow + r) * WS_HW + pcol + s) * 64);
       }
-    if (do_bias) {
+      // plane products, smallest weights first: lo x hi, hi x lo, hi x hi
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int s = 0; s < 3; ++s) acc[r * 3 + s] = mfma16<F16>(a1[s], b0, acc[r * 3 + s]);
 #pragma unroll
-        for (int p = NS - 1; p >= 0; --p) bsum[j] += frag_sum<F16>(b[j][p]);
+      for (int s = 0; s < 3; ++s) acc[r * 3 + s] = mfma16<F16>(a0[s], b1, acc[r * 3 + s]);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) acc[r * 3 + s] = mfma16<F16>(a0[s], b0, acc[r * 3 + s]);
     }
+    if (do_bias) bsum += frag_sum<F16>(b1) + frag_sum<F16>(b0);
   };
+  static_assert(NS == 2, "two-plane formats only");
 
+  set_patch();
   if (q0 < q1) {
 #pragma unroll
-    for (int i = 0; i < WS_ROUNDS; i += 2) {
-      r0 = load_unit(i); r1 = load_unit(i + 1);
-      store_unit(0, i, r0); store_unit(0, i + 1, r1);
+    for (int i = 0; i < WS_ROUNDS; i += 3) {
+      r0 = load_unit(i); r1 = load_unit(i + 1); r2 = load_unit(i + 2);
+      store_unit(0, i, r0); store_unit(0, i + 1, r1); store_unit(0, i + 2, r2);
     }
   }
   __syncthreads();
@@ -518,36 +550,35 @@ __global__ __launch_bounds__(WS_THREADS, 3) void wgrad3x3_split_kernel(const flo
     const int buf = (q - q0) & 1;
     const bool more = q + 1 < q1;
     next_patch();
-#pragma unroll 1
-    for (int ks = 0; ks < WS_KSTEPS; ++ks) {
-      if (more && ks < 3) { r0 = load_unit(2 * ks); r1 = load_unit(2 * ks + 1); }
-      mma_step(buf, ks);
-      if (more && ks < 3) { store_unit(buf ^ 1, 2 * ks, r0); store_unit(buf ^ 1, 2 * ks + 1, r1); }
-    }
+    if (more) set_patch();
+    // (K-steps unrolled by hand: the staging rounds must be compile-time indices into the per-thread offset tables)
+    if (more) { r0 = load_unit(0); r1 = load_unit(1); r2 = load_unit(2); }
+    mma_step(buf, 0);
+    if (more) { store_unit(buf ^ 1, 0, r0); store_unit(buf ^ 1, 1, r1); store_unit(buf ^ 1, 2, r2); }
+    if (more) { r0 = load_unit(3); r1 = load_unit(4); r2 = load_unit(5); }
+    mma_step(buf, 1);
+    if (more) { store_unit(buf ^ 1, 3, r0); store_unit(buf ^ 1, 4, r1); store_unit(buf ^ 1, 5, r2); }
+    if (more) { r0 = load_unit(6); r1 = load_unit(7); r2 = load_unit(8); }
+    mma_step(buf, 2);
+    if (more) { store_unit(buf ^ 1, 6, r0); store_unit(buf ^ 1, 7, r1); store_unit(buf ^ 1, 8, r2); }
+    mma_step(buf, 3);
     __syncthreads();
   }
 
   const float unscale = F16 ? 1.f / (cx * cd) : 1.f;
+  const int n = co0 + nq * 32 + l31;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = co0 + njp * 64 + j * 32 + l31;
+  for (int t = 0; t < 9; ++t) {
+    float* o = out + ((size_t)split * 9 + t) * Cin * Cout;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      float* o = out + ((size_t)blockIdx.y * 9 + (3 * r + s)) * Cin * Cout;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int ci = ci0 + cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (n < Cout) o[(size_t)ci * Cout + n] = acc[j * 3 + s][e] * unscale;
-      }
+    for (int e = 0; e < 16; ++e) {
+      const int ci = ci0 + cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      if (n < Cout) o[(size_t)ci * Cout + n] = acc[t][e] * unscale;
     }
   }
   if (do_bias) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = co0 + njp * 64 + j * 32 + l31;
-      const float v = (bsum[j] + __shfl_down(bsum[j], 32, 64)) * (F16 ? 1.f / cd : 1.f);   // pixels 0-7 + 8-15 of every k-step
-      if (lh == 0 && n < Cout) bias_part[(size_t)blockIdx.y * Cout + n] = v;
-    }
+    const float v = (bsum + __shfl_down(bsum, 32, 64)) * (F16 ? 1.f / cd : 1.f);   // pixels 0-7 + 8-15 of every k-step
+    if (lh == 0 && n < Cout) bias_part[(size_t)split * Cout + n] = v;
   }
 }
 
@@ -560,7 +591,7 @@ WgradSplitPlan plan_wgrad_split(int N, int H, int W, int Cin, int Cout) {
   p.tiles_ci = Cin / WS_CI;
   p.tiles_co = (Cout + WS_CO - 1) / WS_CO;
   const long pairs = (long)p.tiles_ci * p.tiles_co;
-  long s = (2 * 256L) / pairs;                                 // two whole rounds of the chip (one 12-wave workgroup per CU)
+  long s = (2 * 256L) / pairs;                                 // two whole rounds of the chip (one workgroup per CU)
   if (s > q_total / 16) s = q_total / 16;
   if (s < 1) s = 1;
   p.pps = (int)((q_total + s - 1) / s);
@@ -695,9 +726,9 @@ int ladder_conv3x3_wgrad_split(const float* x, const float* x_absmax, const floa
   const size_t kn = (size_t)9 * Cin * Cout;
   float* part = (float*)ws;
   float* bias_part = db != nullptr ? part + (size_t)p.splits * kn : nullptr;
-  const dim3 grid(p.tiles_ci * p.tiles_co, p.splits), block(WS_THREADS);
+  const dim3 grid(p.tiles_ci * p.tiles_co * ((p.splits + 7) / 8) * 8), block(WS_THREADS);
 #define LADDER_WS_LAUNCH(P_) \
-  hipLaunchKernelGGL(wgrad3x3_split_kernel<P_>, grid, block, 0, stream, x, dy, part, bias_part, N, H, W, Cin, Cout, p.tiles_co, p.pps, x_absmax, dy_absmax)
+  hipLaunchKernelGGL(wgrad3x3_split_kernel<P_>, grid, block, 0, stream, x, dy, part, bias_part, N, H, W, Cin, Cout, p.tiles_ci, p.tiles_co, p.splits, p.pps, x_absmax, dy_absmax)
   if (prec == LADDER_PREC_F16X3) LADDER_WS_LAUNCH(LADDER_PREC_F16X3);
   else LADDER_WS_LAUNCH(LADDER_PREC_BF16X3);
 #undef LADDER_WS_LAUNCH
