@@ -341,6 +341,226 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
   }
 }
 
+// ---- the same kernel with a 16x32-pixel patch per workgroup (two-plane formats) ----------------------------------------------------
+// 16 wavefronts (one workgroup per CU instead of two of 8): the filter block a tap needs is fetched ONCE for 512 pixels instead of once
+// per 256 -- the L2 -> LDS filter traffic (590 KB per workgroup at 128 -> 128 channels, 4.8 GB per launch) was the largest single item
+// of the 8-wave kernel's non-MFMA time (ablation: +13..15 % without it) -- and the halo overhead drops from 340/256 to 612/512.  The
+// filter blocks of a whole filter ROW (3 taps, 24 KB) are staged at once: one barrier per 3 taps instead of one per tap.
+constexpr int F_H = 16, F_PH = F_H + 2, F_NPIX = F_PH * SP_PW;                 // 612 halo pixels
+constexpr int F_THREADS = 1024;
+constexpr int F_A_PLANE = 2 * F_NPIX * 16;                                     // bytes per plane (19584)
+constexpr int F_HALO_UNITS = F_NPIX * 4;                                       // float4 units per slab (2448)
+constexpr int F_AU = (F_HALO_UNITS + F_THREADS - 1) / F_THREADS;               // 3
+template <int PREC>
+__global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
+                                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                                          const int N, const int H, const int W, const int Cin,
+                                                                          const int Cout, const int act, const int tiles_n,
+                                                                          const float* __restrict__ xamax,
+                                                                          const float* __restrict__ wamax, float* __restrict__ yamax,
+                                                                          const float* __restrict__ pw, const float* __restrict__ pb,
+                                                                          float* __restrict__ pout, const int pco) {
+  constexpr int NS = Fmt<PREC>::NS;
+  constexpr bool F16 = Fmt<PREC>::F16;
+  static_assert(NS == 2, "two-plane formats only");
+  constexpr int A_BUF = NS * F_A_PLANE, B_BUF = NS * SP_B_PLANE, B_STAGE = 3 * B_BUF;
+  constexpr int B_CHUNKS = NS * 256;                                       // 16-byte chunks per filter block
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * A_BUF + 2 * B_STAGE];
+  unsigned char* const Abase = lds;
+  unsigned char* const Bbase = lds + 2 * A_BUF;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = tile / tiles_n, cot = tile % tiles_n, n0 = cot * SP_BN;
+  const int tw_n = W / SP_W, th_n = H / F_H;
+  const int img = mt / (tw_n * th_n), rem = mt - img * (tw_n * th_n);
+  const int h0 = (rem / tw_n) * F_H, w0 = (rem % tw_n) * SP_W;
+  const int nslabs = Cin / 16;
+  float cx = 1.f, unscale = 1.f;
+  if (F16) {
+    cx = scale_from_absmax(amax_load(xamax));
+    unscale = 1.f / (cx * scale_from_absmax(amax_load(wamax)));      // exact: powers of two
+  }
+
+  const float* hsrc[F_AU];
+  int hdst[F_AU];
+#pragma unroll
+  for (int i = 0; i < F_AU; ++i) {
+    const int u = tid + i * F_THREADS;
+    const int pix = u >> 2, kq = u & 3;
+    const int hr = pix / SP_PW, hc = pix - hr * SP_PW;
+    const int hi = h0 - 1 + hr, wi = w0 - 1 + hc;
+    const bool ok = (u < F_HALO_UNITS) && hi >= 0 && hi < H && wi >= 0 && wi < W;
+    hsrc[i] = ok ? x + (((long)img * H + hi) * W + wi) * Cin + kq * 4 : nullptr;
+    hdst[i] = ((kq >> 1) * F_NPIX + pix) * 16 + (kq & 1) * 8;
+  }
+  // filter stage = the blocks of taps 3r .. 3r+2: 1536 chunks of 16 bytes, thread tid takes chunk tid (tap 3r + tid/512) and, the first
+  // half of the workgroup, chunk 1024 + tid (tap 3r + 2)
+  const size_t tap_stride = (size_t)nslabs * tiles_n * B_CHUNKS;
+  const uint4* const bsrc = wp + (size_t)cot * B_CHUNKS + (tid & 511) + (size_t)(tid >> 9) * tap_stride;   // + (3r*nslabs + slab) * tiles_n * B_CHUNKS
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  // staging registers are the scarce resource (128 per lane at 16 wavefronts): ONE halo unit and ONE filter chunk are in flight at a
+  // time -- halo round i of the next slab rides on filter row i of this one, the second filter chunk re-uses the first one's register
+  float4 ha;
+  uint4 rb0;
+  const bool b_second = tid < 512;
+  auto load_halo = [&](int slab, int i) {
+    ha = *reinterpret_cast<const float4*>(hsrc[i] != nullptr ? hsrc[i] + slab * 16 : gs_zero16);
+  };
+  auto store_halo = [&](int buf, int i) {
+    if (tid + i * F_THREADS < F_HALO_UNITS) {
+      uint2 pl[NS];
+      float4 v = ha;
+      if (F16) v = make_float4(v.x * cx, v.y * cx, v.z * cx, v.w * cx);
+      split4<NS, F16>(v, pl);
+#pragma unroll
+      for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(Abase + buf * A_BUF + p * F_A_PLANE + hdst[i]) = pl[p];
+    }
+  };
+  auto load_b = [&](int slab, int r, int part) {                          // part 0: chunk tid, part 1: chunk 1024 + tid (first half only)
+    const uint4* s = bsrc + (size_t)(3 * r * nslabs + slab) * tiles_n * B_CHUNKS;
+    if (part == 0) rb0 = s[0];
+    else if (b_second) rb0 = s[2 * tap_stride];
+  };
+  auto store_b = [&](int buf, int part) {
+    if (part == 0) *reinterpret_cast<uint4*>(Bbase + buf * B_STAGE + tid * 16) = rb0;
+    else if (b_second) *reinterpret_cast<uint4*>(Bbase + buf * B_STAGE + (tid + F_THREADS) * 16) = rb0;
+  };
+
+#pragma unroll
+  for (int i = 0; i < F_AU; ++i) {
+    load_halo(0, i);
+    store_halo(0, i);
+  }
+  load_b(0, 0, 0);
+  store_b(0, 0);
+  load_b(0, 0, 1);
+  store_b(0, 1);
+  __syncthreads();
+  int bbuf = 0;
+  for (int slab = 0; slab < nslabs; ++slab) {
+    const int hb = slab & 1;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const bool last = (slab + 1 == nslabs) && (r == 2);
+      const int nslab = r == 2 ? slab + 1 : slab, nr = r == 2 ? 0 : r + 1;   // the filter stage being fetched
+      if (slab + 1 < nslabs) load_halo(slab + 1, r);
+#pragma unroll
+      for (int sft = 0; sft < 3; ++sft) {
+        if (!last && sft < 2) load_b(nslab, nr, sft);
+        const unsigned char* Ab = Abase + hb * A_BUF + (lh * F_NPIX + (2 * wm + r) * SP_PW + sft + l31) * 16;
+        const unsigned char* Bb = Bbase + bbuf * B_STAGE + sft * B_BUF + (lh * SP_BN + wn * 64 + l31) * 16;
+        uint4 a[2][NS], b[2][NS];
+#pragma unroll
+        for (int p = 0; p < NS; ++p) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) a[mi][p] = *reinterpret_cast<const uint4*>(Ab + p * F_A_PLANE + mi * SP_PW * 16);
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) b[ni][p] = *reinterpret_cast<const uint4*>(Bb + p * SP_B_PLANE + ni * 32 * 16);
+        }
+        // plane products, smallest weights first: (pa, pb) with pa + pb < NS
+#pragma unroll
+        for (int sum = NS - 1; sum >= 0; --sum)
+#pragma unroll
+          for (int pa = 0; pa <= sum; ++pa) {
+            const int pb = sum - pa;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma16<F16>(b[ni][pb], a[mi][pa], acc[mi][ni]);   // D^T: lane = pixel, registers = channels
+          }
+        if (!last && sft < 2) store_b(bbuf ^ 1, sft);
+      }
+      if (slab + 1 < nslabs) store_halo(hb ^ 1, r);
+      __syncthreads();
+      bbuf ^= 1;
+    }
+  }
+
+  // Transposed accumulators (the filter fragment is the MFMA's A operand): lane l31 = pixel of the patch row, register e -> channel
+  // (e & 3) + 8 (e >> 2) + 4 lh of the 32-channel tile, i.e. four consecutive channels per register quad = one 16-byte store, and the
+  // channel sum of the fused 1x1 projection below stays inside the lane.
+  float ymax = 0.f;
+  float pacc[2][4];                                          // fused projection: partial sums of this lane's channels, per patch row
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int o = 0; o < 4; ++o) pacc[mi][o] = 0.f;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      float* yp = y != nullptr ? y + (((long)img * H + h0 + 2 * wm + mi) * W + w0 + l31) * Cout : nullptr;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * lh;
+        if (n < Cout) {                                      // Cout % 4 == 0: a channel quad is inside or outside as a whole
+          float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (bias != nullptr) bv = *reinterpret_cast<const float4*>(bias + n);
+          float4 v = make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
+          if (F16) v = make_float4(v.x * unscale, v.y * unscale, v.z * unscale, v.w * unscale);
+          v = make_float4(ladder_act_fn(v.x + bv.x, act), ladder_act_fn(v.y + bv.y, act), ladder_act_fn(v.z + bv.z, act),
+                          ladder_act_fn(v.w + bv.w, act));
+          if (yp != nullptr) *reinterpret_cast<float4*>(yp + n) = v;
+          ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+          if (pout != nullptr) {                             // 1x1 projection: pw[Cout][pco], pco <= 4
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            if (pco == 3) {                                  // (the RGB output conv) rows n..n+3 = 12 consecutive floats, 16-byte aligned
+              const float4* q = reinterpret_cast<const float4*>(pw + (size_t)n * 3);
+              const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+              const float wq[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+              for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+                for (int o = 0; o < 3; ++o) pacc[mi][o] = fmaf(vv[c4], wq[c4 * 3 + o], pacc[mi][o]);
+            } else {
+#pragma unroll
+              for (int c4 = 0; c4 < 4; ++c4)
+                for (int o = 0; o < pco; ++o) pacc[mi][o] = fmaf(vv[c4], pw[(size_t)(n + c4) * pco + o], pacc[mi][o]);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (yamax != nullptr) amax_commit_block(ymax, yamax);     // the output's absolute maximum for the next split contraction
+  if (pout != nullptr) {
+    // combine the two half-waves (lh) in registers, the two channel halves (wn) through LDS (free after the main loop), fixed order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);             // [wm 8][mi 2][pixel 32][4]
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int o = 0; o < 4; ++o) pacc[mi][o] += __shfl_xor(pacc[mi][o], 32, 64);
+    if (wn == 1 && lh == 0) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        *reinterpret_cast<float4*>(red + (((wm * 2 + mi) * 32 + l31) * 4)) = make_float4(pacc[mi][0], pacc[mi][1], pacc[mi][2], pacc[mi][3]);
+    }
+    __syncthreads();
+    if (wn == 0 && lh == 0) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const float4 other = *reinterpret_cast<const float4*>(red + (((wm * 2 + mi) * 32 + l31) * 4));
+        const float t[4] = {pacc[mi][0] + other.x, pacc[mi][1] + other.y, pacc[mi][2] + other.z, pacc[mi][3] + other.w};
+        float* op = pout + (((long)img * H + h0 + 2 * wm + mi) * W + w0 + l31) * pco;
+        for (int o = 0; o < pco; ++o) op[o] = t[o] + (pb != nullptr ? pb[o] : 0.f);
+      }
+    }
+  }
+}
+
 // ---- 3x3 filter gradient on split operands -----------------------------------------------------------------------------------
 // dW[tap][ci][co] = sum_pixels x[pix + tap][ci] * dy[pix][co]: the reduction index of the MFMA is the PIXEL, so both fragments need
 // 8 consecutive pixels of one channel per lane while NHWC memory (and the LDS image a coalesced staging pass writes) has the
@@ -600,6 +820,12 @@ WgradSplitPlan plan_wgrad_split(int N, int H, int W, int Cin, int Cout) {
   return p;
 }
 
+// the 16-row patch variant: two-plane formats, enough patches for two rounds of the chip
+bool split_halo16_ok(int N, int H, int W, int Cin, int Cout, int prec) {
+  static const bool off = getenv("LADDER_DISABLE_HALO16") != nullptr;
+  return !off && prec_planes(prec) == 2 && (H % F_H) == 0 && (long)N * (H / F_H) * (W / SP_W) * ((Cout + SP_BN - 1) / SP_BN) >= 512;
+}
+
 bool split_halo_ok(int N, int H, int W, int Cin, int Cout) {
   return N > 0 && (Cin % 16) == 0 && (Cout % 4) == 0 && Cout >= 64 && (W % SP_W) == 0 && (H % SP_H) == 0 &&
          (long)N * (H / SP_H) * (W / SP_W) * ((Cout + SP_BN - 1) / SP_BN) >= 512;
@@ -684,10 +910,16 @@ static int conv3x3_split_launch(const float* x, const float* x_absmax, const voi
 #define LADDER_SPLIT_LAUNCH(P_) \
   hipLaunchKernelGGL(conv3x3_halo_split_kernel<P_>, grid, block, 0, stream, x, (const uint4*)packed, bias, y, N, H, W, Cin, Cout, act, tiles_n, x_absmax, wamax, y_absmax, \
                      pw, pb, pout, pco)
-  if (prec == LADDER_PREC_F16X3) LADDER_SPLIT_LAUNCH(LADDER_PREC_F16X3);
+#define LADDER_SPLIT16_LAUNCH(P_) \
+  hipLaunchKernelGGL(conv3x3_halo_split16_kernel<P_>, dim3(N * (H / F_H) * (W / SP_W) * tiles_n), dim3(F_THREADS), 0, stream, x, (const uint4*)packed, bias, y, N, H, W, Cin, Cout, act, tiles_n, x_absmax, wamax, y_absmax, \
+                     pw, pb, pout, pco)
+  if (split_halo16_ok(N, H, W, Cin, Cout, prec)) {
+    if (prec == LADDER_PREC_F16X3) LADDER_SPLIT16_LAUNCH(LADDER_PREC_F16X3); else LADDER_SPLIT16_LAUNCH(LADDER_PREC_BF16X3);
+  } else if (prec == LADDER_PREC_F16X3) LADDER_SPLIT_LAUNCH(LADDER_PREC_F16X3);
   else if (prec == LADDER_PREC_BF16X6) LADDER_SPLIT_LAUNCH(LADDER_PREC_BF16X6);
   else LADDER_SPLIT_LAUNCH(LADDER_PREC_BF16X3);
 #undef LADDER_SPLIT_LAUNCH
+#undef LADDER_SPLIT16_LAUNCH
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

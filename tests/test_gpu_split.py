@@ -90,6 +90,7 @@ HALO_CASES = [
     (32, 64, 64, 64, 128, None, "tiny", "huge"),               # filter-gradient split kernel (>= 4096 row patches, Cin % 64 == 0)
     (32, 64, 64, 128, 64, "leaky_relu", "normal", "heavy"),    # 2 ci slabs, Cout = 64
     (32, 64, 64, 32, 128, None, "zero", "normal"),             # all-zero input: absmax 0 -> scale 1, output = bias
+    (64, 32, 64, 64, 160, "leaky_relu", "heavy", "normal"),    # >= 512 patches of 16x32 pixels: the 16-wavefront forward kernel
 ]
 
 
