@@ -26,13 +26,13 @@ class KernelProfiler:
 
     NAMES = {256128: "conv3x3_halo_kernel (8x32 px x 128 ch LDS-halo tile, 8 waves, fp32 MFMA 32x32x2)",
              256123: "conv3x3_halo_split_kernel<bf16x6> (8x32 px x 128 ch LDS-halo tile, 8 waves, fp32 operands as 3 bf16 planes, 6 x MFMA 32x32x16 bf16)",
-             256122: "conv3x3_halo_split_kernel<bf16x3> (8x32 px x 128 ch LDS-halo tile, 8 waves, fp32 operands as 2 bf16 planes, 3 x MFMA 32x32x16 bf16)",
-             256124: "conv3x3_halo_split_kernel<f16x3> (8x32 px x 128 ch LDS-halo tile, 8 waves, fp32 operands as 2 scaled fp16 planes, 3 x MFMA 32x32x16 f16)",
+             256122: "conv3x3_halo_split16_kernel / conv3x3_halo_split_kernel<bf16x3> (16x32 px x 128 ch LDS-halo tile, 16 waves -- 8x32, 8 waves below 512 tiles; fp32 operands as 2 bf16 planes, 3 x MFMA 32x32x16 bf16)",
+             256124: "conv3x3_halo_split16_kernel / conv3x3_halo_split_kernel<f16x3> (16x32 px x 128 ch LDS-halo tile, 16 waves -- 8x32, 8 waves below 512 tiles; fp32 operands as 2 scaled fp16 planes, 3 x MFMA 32x32x16 f16)",
              128128: "igemm_fwd_kernel<128,128,2,2,true,true> (gather implicit GEMM, fp32 MFMA 32x32x2)",
              128124: "igemm_fwd_split_kernel<f16x3> (gather implicit GEMM, 128x128 tile, 3 x MFMA 32x32x16 f16)",
              128122: "igemm_fwd_split_kernel<bf16x3>", 128123: "igemm_fwd_split_kernel<bf16x6>",
              9003: "conv_smallcin_kernel (direct 1x1 from 3 channels, HBM-bound)",
-             9124: "wgrad3x3_split_kernel<f16x3> (64ci x 128co slab x 9 taps, 12 waves, transposing LDS reads, 3 x MFMA 32x32x16 f16; incl. its split reduction)",
+             9124: "wgrad3x3_split_kernel<f16x3> (64ci x 128co slab x 9 taps, 8 waves x 9 tiles, transposing LDS reads, 3 x MFMA 32x32x16 f16; incl. its split reduction)",
              9122: "wgrad3x3_split_kernel<bf16x3>", 9123: "wgrad3x3_split_kernel<bf16x6>",
              9128: "wgrad3x3_halo_kernel (64ci x 128co slab x 9 taps, 12 waves, LDS-DMA staged 1x32-pixel patches, fp32 MFMA 32x32x2)"}
 

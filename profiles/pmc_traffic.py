@@ -12,7 +12,7 @@ import json
 import sqlite3
 import sys
 
-KERNELS = ("conv3x3_halo_split_kernel", "wgrad3x3_split_kernel", "igemm_fwd_split_kernel", "igemm_wgrad_split_kernel")
+KERNELS = ("conv3x3_halo_split", "wgrad3x3_split_kernel", "igemm_fwd_split_kernel", "igemm_wgrad_split_kernel")   # [0] matches both tile variants
 
 
 def per_kernel(dbpath, counter):
