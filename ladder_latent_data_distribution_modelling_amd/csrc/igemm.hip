@@ -871,6 +871,24 @@ __global__ void splitk_epilogue_kernel(const float* __restrict__ part, const flo
   y[i] = s;
 }
 
+// The same second pass for a call whose M space is a strided subset of the output map (one parity class of a stride-2 backward-data):
+// partials are dense in the class-local pixel index m, the result goes to y[n, out_h0 + ho*out_sh, out_w0 + wo*out_sw, :].
+__global__ void splitk_epilogue_strided_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ y,
+                                               int S, size_t MN, int act, const float* __restrict__ gate, int gate_act, const IgemmDesc d) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= MN) return;
+  float s = 0.f;
+  for (int z = 0; z < S; ++z) s += part[(size_t)z * MN + i];   // fixed order
+  const uint32_t m = (uint32_t)(i / d.Cout), n = (uint32_t)(i - (size_t)m * d.Cout);
+  const uint32_t n_img = fdiv(m, d.div_howo), rem = m - n_img * (uint32_t)(d.Ho * d.Wo);
+  const uint32_t ho = fdiv(rem, d.div_wo), wo = rem - ho * d.Wo;
+  const size_t o = ((((size_t)n_img * d.OH + d.out_h0 + (size_t)ho * d.out_sh) * d.OW + d.out_w0 + (size_t)wo * d.out_sw)) * d.Cout + n;
+  if (bias != nullptr) s += bias[n];
+  s = ladder_act_fn(s, act);
+  if (gate != nullptr) s *= ladder_act_grad_from_out(gate[o], gate_act);
+  y[o] = s;
+}
+
 __global__ void reduce_splits_kernel(const float* __restrict__ ws, float* __restrict__ out, int S, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1156,28 +1174,35 @@ int select_fwd_tile(long M, int Cout) {
 }
 
 
-// `small_ok`: the call writes a dense output, so a few 128x128 tiles can still fill the chip through split-K (the 8x8 ... 1x1 ends of the
-// CelebA encoder / decoder: M = 128 ... 8192 pixels, K = 1152 ... 8192)
+// `small_ok`: a few 128x128 tiles can still fill the chip through split-K (the 8x8 ... 1x1 ends of the CelebA encoder / decoder:
+// M = 128 ... 8192 pixels, K = 256 ... 8192; strided outputs -- the parity classes of a stride-2 backward-data -- go through
+// splitk_epilogue_strided_kernel)
 bool split_gather_ok(const IgemmDesc& d, bool small_ok = false) {
   if (!(d.ntaps > 0 && d.ntaps <= 28 && d.ups == 1 && (d.Cin % GS_BK) == 0 && d.M > 0)) return false;
   if (select_fwd_tile(d.M, d.Cout) == 128128) return true;
-  return small_ok && d.M >= 128 && d.Cout >= 128 && (long)d.ntaps * d.Cin >= 1024;
+  return small_ok && d.M >= 128 && d.Cout >= 128;
 }
 
-// the split-K plan of the fp32 kernel (16-deep chunks) re-expressed in this kernel's 32-deep chunks
-SplitPlan plan_splitk32(const IgemmDesc& d, bool dense_out) {
+// Split-K plan of the split gather kernel (32-deep chunks).  Measured at B = 128: with >= 384 tiles (two workgroups per CU, 75 % full)
+// the partial traffic costs more than the idle CUs (dec.conv4, 512 tiles: 252 TF with 2 splits, 267 without; the stride-2 encoder layer
+// 172 vs 218); around 256 tiles a LONG reduction still gains from 4 splits (dec.conv3, K = 4608: 237 vs 189 TF) while a short one (a
+// parity class of a stride-2 backward-data, K <= 1024) does not; a split keeps at least 8 chunks (K = 256).
+SplitPlan plan_splitk32(const IgemmDesc& d) {
   const int nchunks = d.ntaps * (d.Cin / GS_BK);
-  if (!dense_out) return SplitPlan{1, nchunks};
-  const SplitPlan p16 = plan_splitk(d.M, d.ntaps * d.Cin, d.Cout, GS_BM, GS_BN);
-  if (p16.splits <= 1) return SplitPlan{1, nchunks};
-  SplitPlan p;
-  p.cps = (p16.cps + 1) / 2;
+  const long tiles = (long)((d.M + GS_BM - 1) / GS_BM) * ((d.Cout + GS_BN - 1) / GS_BN);
+  SplitPlan p{1, nchunks};
+  if (tiles >= 384 || nchunks < 16 || (tiles >= 192 && nchunks < 64)) return p;
+  long s = (1024 + tiles - 1) / tiles;
+  if (s > nchunks / 8) s = nchunks / 8;
+  if (s > 32) s = 32;
+  if (s < 2) return p;
+  p.cps = (int)((nchunks + s - 1) / s);
   p.splits = (nchunks + p.cps - 1) / p.cps;
   return p;
 }
 
 size_t fwd_split_ws_bytes(const IgemmDesc& d) {
-  const SplitPlan sp = plan_splitk32(d, true);
+  const SplitPlan sp = plan_splitk32(d);
   return sp.splits > 1 ? (size_t)sp.splits * d.M * d.Cout * sizeof(float) : 0;
 }
 
@@ -1185,12 +1210,12 @@ int launch_fwd_split(const void* x, const float* xamax, const void* packed, cons
                      void* ws, size_t ws_bytes, hipStream_t st, const float* gate, int gate_act) {
   // `x` = the pre-split planes of the gathered tensor (ladder_presplit), plane-major, d.N*d.H*d.W*d.Cin elements per plane
   const bool dense_out = d.out_sh == 1 && d.out_sw == 1 && d.OH == d.Ho && d.OW == d.Wo;
-  if (!split_gather_ok(d, dense_out) || !prec_ok(prec)) return LADDER_E_SHAPE;
+  if (!split_gather_ok(d, true) || !prec_ok(prec)) return LADDER_E_SHAPE;
   if (!ladder_aligned16(x) || !ladder_aligned16(packed) || !ladder_aligned16(y)) return LADDER_E_ALIGN;
   const size_t plane_elems = (size_t)d.N * d.H * d.W * d.Cin;
   if (prec == LADDER_PREC_F16X3 && xamax == nullptr) return LADDER_E_SHAPE;
   const int tiles_m = (d.M + GS_BM - 1) / GS_BM, tiles_n = (d.Cout + GS_BN - 1) / GS_BN;
-  SplitPlan sp = plan_splitk32(d, dense_out);
+  SplitPlan sp = plan_splitk32(d);
   const size_t need = (size_t)sp.splits * d.M * d.Cout * sizeof(float);
   if (sp.splits > 1 && (ws == nullptr || ws_bytes < need)) sp = SplitPlan{1, d.ntaps * (d.Cin / GS_BK)};
   float* part = sp.splits > 1 ? (float*)ws : nullptr;
@@ -1205,8 +1230,12 @@ int launch_fwd_split(const void* x, const float* xamax, const void* packed, cons
 #undef LADDER_GS_LAUNCH
   if (part != nullptr) {
     const size_t mn = (size_t)d.M * d.Cout;
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, (const float*)part, bias, y,
-                       sp.splits, mn, d.Cout, d.act, gate, gate_act);
+    if (dense_out)
+      hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, (const float*)part, bias, y,
+                         sp.splits, mn, d.Cout, d.act, gate, gate_act);
+    else
+      hipLaunchKernelGGL(splitk_epilogue_strided_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, (const float*)part, bias, y,
+                         sp.splits, mn, d.act, gate, gate_act, d);
   }
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
@@ -1978,9 +2007,10 @@ static int conv2d_bwd_data_split_impl(const void* dy, const float* dy_absmax, co
         }
         c.K = c.ntaps * Cout;
         if (pass == 0) {
-          if (c.ntaps == 0 || !split_gather_ok(c)) return LADDER_E_SHAPE;
+          if (c.ntaps == 0 || !split_gather_ok(c, true)) return LADDER_E_SHAPE;
+          if (ws_need != nullptr && fwd_split_ws_bytes(c) > *ws_need) *ws_need = fwd_split_ws_bytes(c);   // (classes run one after another)
         } else {
-          const int rc = launch_fwd_split(dy, dy_absmax, packed, nullptr, dx, c, prec, nullptr, 0, stream, gate_y, gate_act);
+          const int rc = launch_fwd_split(dy, dy_absmax, packed, nullptr, dx, c, prec, ws, ws_bytes, stream, gate_y, gate_act);
           if (rc != LADDER_OK) return rc;
         }
       }

@@ -399,6 +399,11 @@ class Conv2D:
             _timed(256120 + self.ctx.ns, 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_split", args)
             self.x, self.y = x, y
             return y
+        if self._as_dense(N * H * W):                   # 1x1 conv over a tiny map (decoder conv0 on the 1x1 map) = a batch-sized dense layer
+            L.call("ladder_dense_fwd_small", _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y), N * H * W,
+                   self.cin, self.cout, L.ACT[self.act], self.ctx.stream)
+            self.x, self.y = x, y
+            return y
         geo = (N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl)
         if self.ctx.ns and L.query("ladder_conv2d_fwd_split_eligible", *geo):
             self.x_amax = self.ctx.absmax(x)
@@ -410,11 +415,6 @@ class Conv2D:
                 L.call("ladder_conv2d_fwd_split", *args)
             else:
                 _timed(128120 + self.ctx.ns, 2.0 * N * Ho * Wo * self.k * self.k * self.cin * self.cout, "ladder_conv2d_fwd_split", args)
-            self.x, self.y = x, y
-            return y
-        if self._as_dense(N * H * W):                   # 1x1 conv over a tiny map (decoder conv0 on the 1x1 map) = a batch-sized dense layer
-            L.call("ladder_dense_fwd_small", _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y), N * H * W,
-                   self.cin, self.cout, L.ACT[self.act], self.ctx.stream)
             self.x, self.y = x, y
             return y
         _igemm(self.ctx, "ladder_conv2d_fwd", N * Ho * Wo, self.cin, self.cout, self.k * self.k * self.cin,
