@@ -68,6 +68,13 @@ __device__ __forceinline__ float amax_load(const float* rec) {
   for (int s = 0; s < AMAX_SLOTS; ++s) m = fmaxf(m, rec[s * AMAX_STRIDE]);
   return m;
 }
+
+// Clears a record from inside a kernel that runs BEFORE the record's producer on the same stream (the finalize kernels of the norm
+// layers): block 0 writes the LADDER_ABSMAX_FLOATS zeros, which saves the separate memset launch per record.
+__device__ __forceinline__ void amax_clear_by_block0(float* __restrict__ rec) {
+  if (rec != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    for (int i = threadIdx.x; i < AMAX_SLOTS * AMAX_STRIDE; i += blockDim.x) rec[i] = 0.f;
+}
 // Block-wide: EVERY thread of the workgroup must call it (contains a barrier); `m` = the thread's running max of |values written|.
 __device__ __forceinline__ void amax_commit_block(float m, float* rec) {
   __shared__ float amax_red[16];

@@ -111,7 +111,9 @@ size_t stats_nblk(size_t rows) {
   return nblk;
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ sums, double count, float eps, float* __restrict__ mean_rstd, int C) {
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, double count, float eps, float* __restrict__ mean_rstd, int C,
+                                   float* __restrict__ clear_rec) {
+  amax_clear_by_block0(clear_rec);
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double mean = (double)sums[c] / count;
@@ -209,7 +211,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
   }
   if (dxamax != nullptr) amax_commit_block(dmax, dxamax);
 }
-__global__ void bn_param_grad_kernel(const float* __restrict__ dsums, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+__global__ void bn_param_grad_kernel(const float* __restrict__ dsums, float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
+                                     float* __restrict__ clear_rec) {
+  amax_clear_by_block0(clear_rec);
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   dbeta[c] = dsums[c];
@@ -332,7 +336,8 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const float* __restrict__
 }
 
 __global__ void in_finalize_kernel(const float* __restrict__ x, const float* __restrict__ part, float* __restrict__ mean_rstd,
-                                   int N, int HW, int C, int split, float eps) {
+                                   int N, int HW, int C, int split, float eps, float* __restrict__ clear_rec) {
+  amax_clear_by_block0(clear_rec);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * C) return;
   const int n = i / C, c = i - n * C;
@@ -418,7 +423,9 @@ __global__ __launch_bounds__(256) void in_bwd_stats_kernel(const float* __restri
     *reinterpret_cast<float4*>(part + (((size_t)n * split + sp) * 2 + rl) * C + c) = t;
   }
 }
-__global__ void in_bwd_finalize_kernel(const float* __restrict__ part, float* __restrict__ dstyle, int N, int C, int split) {
+__global__ void in_bwd_finalize_kernel(const float* __restrict__ part, float* __restrict__ dstyle, int N, int C, int split,
+                                       float* __restrict__ clear_rec) {
+  amax_clear_by_block0(clear_rec);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * C) return;
   const int n = i / C, c = i - n * C;
@@ -750,9 +757,9 @@ int ladder_bn_fwd_apply_absmax(const float* x, const float* sums, double count, 
   if (rows == 0 || C <= 0 || count <= 0) return LADDER_E_SHAPE;
   if (y_absmax != nullptr) {                     // the record is produced by the vectorised kernel only
     if (!(C % 4 == 0 && ladder_aligned16(x) && ladder_aligned16(y))) return LADDER_E_SHAPE;
-    if (hipMemsetAsync(y_absmax, 0, LADDER_ABSMAX_FLOATS * sizeof(float), stream) != hipSuccess) return LADDER_E_LAUNCH;
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sums, count, eps, mean_rstd, C);
+  // (the finalize kernel clears the record: no separate memset launch)
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sums, count, eps, mean_rstd, C, y_absmax);
   const size_t n = rows * (size_t)C;
   if (C % 4 == 0 && ladder_aligned16(x) && ladder_aligned16(y))
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, stream, x, mean_rstd, gamma, beta, y, n, C, act, y_absmax);
@@ -792,8 +799,13 @@ int ladder_bn_bwd_apply_absmax(const float* dy, const float* x, const float* mea
   const size_t n = rows * (size_t)C;
   if (dx_absmax != nullptr) {
     if (!(dx != nullptr && C % 4 == 0 && ladder_aligned16(x) && ladder_aligned16(dy) && ladder_aligned16(dx))) return LADDER_E_SHAPE;
-    if (hipMemsetAsync(dx_absmax, 0, LADDER_ABSMAX_FLOATS * sizeof(float), stream) != hipSuccess) return LADDER_E_LAUNCH;
   }
+  // the parameter-gradient kernel runs first and clears the record on its way (no memset launch); without parameter gradients: memset
+  const bool pgrad = dgamma != nullptr && dbeta != nullptr;
+  if (pgrad)
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, dsums, dgamma, dbeta, C, dx_absmax);
+  else if (dx_absmax != nullptr && hipMemsetAsync(dx_absmax, 0, LADDER_ABSMAX_FLOATS * sizeof(float), stream) != hipSuccess)
+    return LADDER_E_LAUNCH;
   if (dx != nullptr) {
     if (C % 4 == 0 && ladder_aligned16(x) && ladder_aligned16(dy) && ladder_aligned16(dx))
       hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, stream, dy, x, mean_rstd, gamma, beta, dsums,
@@ -802,8 +814,6 @@ int ladder_bn_bwd_apply_absmax(const float* dy, const float* x, const float* mea
       hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, dy, x, mean_rstd, gamma, beta, dsums,
                          (float)(1.0 / count), dx, n, C, act);
   }
-  if (dgamma != nullptr && dbeta != nullptr)
-    hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, dsums, dgamma, dbeta, C);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
@@ -822,14 +832,13 @@ int ladder_in_style_fwd_absmax(const float* x, const float* style, float* y, flo
   if (N <= 0 || HW <= 0 || C <= 0) return LADDER_E_SHAPE;
   if (y_absmax != nullptr) {
     if (!(C % 4 == 0 && ws != nullptr && ws_bytes >= ladder_in_style_workspace_bytes(N, HW, C) && ladder_aligned16(x) && ladder_aligned16(y)))
-      return LADDER_E_SHAPE;                     // the record is produced by the vectorised three-kernel path only
-    if (hipMemsetAsync(y_absmax, 0, LADDER_ABSMAX_FLOATS * sizeof(float), stream) != hipSuccess) return LADDER_E_LAUNCH;
+      return LADDER_E_SHAPE;                     // the record is produced by the vectorised three-kernel path only (its finalize kernel clears it)
   }
   if (C % 4 == 0 && ws != nullptr && ws_bytes >= ladder_in_style_workspace_bytes(N, HW, C) && ladder_aligned16(x) && ladder_aligned16(y)) {
     const int sp = in_split(N, HW, C);
     dim3 grid((C + 63) / 64, N, sp);
     hipLaunchKernelGGL(in_stats_kernel, grid, dim3(256), 0, stream, x, (float*)ws, HW, C, sp);
-    hipLaunchKernelGGL(in_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, stream, x, (const float*)ws, mean_rstd, N, HW, C, sp, eps);
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, stream, x, (const float*)ws, mean_rstd, N, HW, C, sp, eps, y_absmax);
     hipLaunchKernelGGL(in_apply_kernel, grid, dim3(256), 0, stream, x, style, (const float*)mean_rstd, y, HW, C, act, sp, y_absmax);
     LADDER_CHECK_LAUNCH();
     return LADDER_OK;
@@ -851,14 +860,13 @@ int ladder_in_style_bwd_absmax(const float* dy, const float* x, const float* sty
     if (!(C % 4 == 0 && ws != nullptr && ws_bytes >= ladder_in_style_workspace_bytes(N, HW, C) && ladder_aligned16(x) && ladder_aligned16(dy) &&
           ladder_aligned16(dx)))
       return LADDER_E_SHAPE;
-    if (hipMemsetAsync(dx_absmax, 0, LADDER_ABSMAX_FLOATS * sizeof(float), stream) != hipSuccess) return LADDER_E_LAUNCH;
   }
   if (C % 4 == 0 && ws != nullptr && ws_bytes >= ladder_in_style_workspace_bytes(N, HW, C) && ladder_aligned16(x) && ladder_aligned16(dy) &&
       ladder_aligned16(dx)) {
     const int sp = in_split(N, HW, C);
     dim3 grid((C + 63) / 64, N, sp);
     hipLaunchKernelGGL(in_bwd_stats_kernel, grid, dim3(256), 0, stream, dy, x, style, mean_rstd, (float*)ws, HW, C, act, sp);
-    hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dstyle, N, C, sp);
+    hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dstyle, N, C, sp, dx_absmax);
     hipLaunchKernelGGL(in_bwd_apply_kernel, grid, dim3(256), 0, stream, dy, x, style, mean_rstd, (const float*)dstyle, dx, HW, C, act, sp, dx_absmax);
     LADDER_CHECK_LAUNCH();
     return LADDER_OK;
