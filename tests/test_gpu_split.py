@@ -262,7 +262,9 @@ def test_split_abi_errors(gpu_ctx):
     dyw = torch.zeros(32 * 64 * 64 * 128, device="cuda")
     dw = torch.empty(9 * 64 * 128, device="cuda")
     assert lib.ladder_conv3x3_wgrad_split(p(xw), p(am), p(dyw), p(am), p(dw), None, 32, 64, 64, 64, 128, 4, None, 0, st) == -3   # workspace
-    assert lib.ladder_conv2d_fwd_split_eligible(2, 16, 16, 64, 16, 16, 256, 3, 3, 1, 1, 1) == 0                # too few tiles for 128x128
+    assert lib.ladder_conv2d_fwd_split_eligible(1, 8, 8, 64, 8, 8, 256, 3, 3, 1, 1, 1) == 0                    # fewer pixels than one 128-row tile
+    assert lib.ladder_conv2d_fwd_split_eligible(2, 16, 16, 64, 16, 16, 64, 3, 3, 1, 1, 1) == 0                 # small map and half a channel tile
+    assert lib.ladder_conv2d_fwd_split_eligible(2, 16, 16, 64, 16, 16, 256, 3, 3, 1, 1, 1) == 1                # small map: split-K fills the chip
     assert lib.ladder_conv2d_fwd_split_eligible(48, 16, 16, 48, 16, 16, 256, 3, 3, 1, 1, 1) == 0               # Cin % 32
     torch.cuda.synchronize()
 
