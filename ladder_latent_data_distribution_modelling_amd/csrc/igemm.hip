@@ -1801,7 +1801,7 @@ int run_wgrad(const float* x, const float* dy, float* dw, float* db, const Igemm
 
 // ---- split filter gradient: planning shared by the workspace query and the launcher
 bool wgrad_split_ok(const IgemmDesc& d) {
-  if (d.ups != 1 || (d.Cin % 128) != 0 || d.Cout <= 64 || (d.Cout % 8) != 0 || d.M < 4096) return false;
+  if (d.ups != 1 || (d.Cin % 128) != 0 || d.Cout <= 64 || (d.Cout % 8) != 0 || d.M < 128) return false;
   const WgradPlan p = plan_wgrad(d.M, d.K, d.Cout);
   return p.bm == 128 && p.bn == 128;
 }
