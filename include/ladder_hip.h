@@ -200,6 +200,18 @@ int ladder_dense_bwd_data_small(const float* dy, const float* w, float* dx, int 
 int ladder_dense_bwd_weight_small(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, ladder_stream_t stream);
 
 
+/* The image-side convolution of the CelebA encoder (codes/models.py:398-405: 3x3, stride 2, SAME, 3 -> Cout channels over even-sized RGB
+ * maps; pad_t == pad_l == 0, i.e. the SAME padding is the bottom row / right column) on the fp16 matrix cores in the fp32-class f16x3
+ * format with per-workgroup scales (csrc/convrgb.hip): forward writes y = act(conv(x, w) + bias); the filter gradient reduces over pixel
+ * runs into `ws` and sums them in a fixed order (db = column sums of dy, may be NULL).  (H/2) % 8 == 0, (W/2) % 32 == 0, Cout % 4 == 0. */
+int ladder_conv_rgb_s2_eligible(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l);
+int ladder_conv_rgb_s2_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act,
+                           ladder_stream_t stream);
+/* dw [3,3,3,Cout], db [Cout] (may be NULL); x_absmax / dy_absmax = the tensors' absolute-maximum records (ladder_absmax or a producer's). */
+size_t ladder_conv_rgb_s2_bwd_filter_workspace_bytes(int N, int H, int W, int Cout);
+int ladder_conv_rgb_s2_bwd_filter(const float* x, const float* x_absmax, const float* dy, const float* dy_absmax, float* dw, float* db,
+                                  int N, int H, int W, int Cout, void* ws, size_t ws_bytes, ladder_stream_t stream);
+
 /* ---------------------------------------------------------------- N12: activations (backward)
  * dx = dy * act'(y) evaluated from the activation OUTPUT y (leaky/relu/tanh).  In-place (dx==dy) allowed. */
 int ladder_act_bwd(const float* dy, const float* y, float* dx, size_t n, int act, ladder_stream_t stream);

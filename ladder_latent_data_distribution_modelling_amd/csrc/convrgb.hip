@@ -1,0 +1,357 @@
+// The image-side convolution of the CelebA encoder: 3x3, stride 2, SAME, 3 -> Cout channels over a 128x128 RGB batch (codes/models.py:398-405).
+// K = 27 is far too short for the generic gather kernels (they pad it to 32 fp32 MFMA K-steps and spend their time on address
+// arithmetic: 140 us forward, 143 us filter gradient at batch 128 -- the call is bound by WRITING the 268 MB activation, ~60 us).
+//
+// Forward (conv_rgb_s2_fwd_kernel): one workgroup = an 8x32 output patch x 128 channels.
+//   1. the 17 x 65 x 3 input patch goes to LDS as fp32 (coalesced row segments; 13 KB);
+//   2. the im2col matrix A[256 pixels][32] (27 taps + zero padding) and the filter B[32][128] are built in LDS as TWO fp16 planes
+//      (split16.h: f16x3, three MFMAs per product, fp32-class) with a PER-WORKGROUP power-of-two scale from the patch's / the filter's
+//      own absolute maximum -- the scale only has to be constant inside one accumulation, so no tensor-wide absmax pass is needed;
+//   3. 2 K-steps x 3 plane products of v_mfma_f32_32x32x16_f16 per 32x32 tile (lane = channel, registers = pixels), un-scale + bias +
+//      activation, stores of whole 128-byte lines.
+// Filter gradient (conv_rgb_s2_wgrad_kernel): dW[27][Cout] = sum_pixels A[pixel][27] * dY[pixel][Cout]; the reduction index is the
+// pixel, so both operands are read with the transposing LDS read (ds_read_b64_tr_b16) from pixel-major fp16 plane images exactly as in
+// wgrad3x3_split_kernel; each workgroup reduces a run of patches, partials are summed in a fixed order by ladder_reduce_splits.
+#include "split16.h"
+
+namespace {
+
+constexpr int RGB_TH = 8, RGB_TW = 32, RGB_PIX = RGB_TH * RGB_TW;                 // output patch
+constexpr int RGB_PH = 2 * RGB_TH + 1, RGB_PW = 2 * RGB_TW + 1;                   // input patch 17 x 65 (x 3 channels)
+constexpr int RGB_PATCH = RGB_PH * RGB_PW * 3;                                    // 3315 floats
+constexpr int RGB_THREADS = 512;
+constexpr int RGB_A_PLANE = 2 * 2 * RGB_PIX * 16;                                 // [k-step][channel octet][pixel][8 x 16 bit] = 16 KB
+constexpr int RGB_B_PLANE = 2 * 2 * 128 * 16;                                     // 8 KB
+
+__device__ __forceinline__ float block_max_512(float m, float* red) {             // all 512 threads; red = 8 floats of LDS
+  m = wave_max(m);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  float b = red[0];
+#pragma unroll
+  for (int w = 1; w < 8; ++w) b = fmaxf(b, red[w]);
+  return b;
+}
+
+// element k (0..26) of a pixel's im2col row, taken from the fp32 patch in LDS: k = (r*3 + s)*3 + ci
+__device__ __forceinline__ float rgb_tap(const float* __restrict__ patch, int pr, int pc, int k) {
+  const int tap = k / 3, ci = k - tap * 3, r = tap / 3, s = tap - r * 3;
+  return patch[((2 * pr + r) * RGB_PW + 2 * pc + s) * 3 + ci];
+}
+
+__global__ __launch_bounds__(RGB_THREADS, 4) void conv_rgb_s2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                                        const int N, const int H, const int W, const int Cout,
+                                                                        const int act, const int tiles_n) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * RGB_A_PLANE + 2 * RGB_B_PLANE];   // 48 KB; the fp32 patch aliases the B region + tail
+  __shared__ __attribute__((aligned(16))) float patch[RGB_PATCH + 5];
+  __shared__ float red[8];
+  unsigned char* const Ab = lds;
+  unsigned char* const Bb = lds + 2 * RGB_A_PLANE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5, wm = wid >> 1, wn = wid & 1;
+  const int Ho = H / 2, Wo = W / 2;
+  const int tile = blockIdx.x, mt = tile / tiles_n, cot = tile - mt * tiles_n, n0 = cot * 128;
+  const int tw_n = Wo / RGB_TW, th_n = Ho / RGB_TH;
+  const int img = mt / (tw_n * th_n), rem = mt - img * (tw_n * th_n);
+  const int h0 = (rem / tw_n) * RGB_TH, w0 = (rem % tw_n) * RGB_TW;
+
+  // 1. input patch -> LDS (rows of 195 consecutive floats; the bottom row / right column of the image border are the SAME padding)
+  float xmax = 0.f;
+  for (int u = tid; u < RGB_PATCH; u += RGB_THREADS) {
+    const int r = u / (RGB_PW * 3), c3 = u - r * (RGB_PW * 3);
+    const int hi = 2 * h0 + r, wi3 = 2 * w0 * 3 + c3;
+    float v = 0.f;
+    if (hi < H && wi3 < W * 3) v = x[((long)img * H + hi) * W * 3 + wi3];
+    patch[u] = v;
+    xmax = fmaxf(xmax, fabsf(v));
+  }
+  // 2. filter block -> registers (thread = channel co, K octet kq), its maximum
+  const int co = tid & 127, kq = tid >> 7;
+  float wv[8], wmax = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = kq * 8 + j;
+    wv[j] = (k < 27 && n0 + co < Cout) ? w[(long)k * Cout + n0 + co] : 0.f;
+    wmax = fmaxf(wmax, fabsf(wv[j]));
+  }
+  const float cx = scale_from_absmax(block_max_512(xmax, red));
+  const float cw = scale_from_absmax(block_max_512(wmax, red));     // (also orders the patch writes before the reads below)
+  {
+    uint2 lo[2], hi[2];
+    split4<2, true>(make_float4(wv[0] * cw, wv[1] * cw, wv[2] * cw, wv[3] * cw), lo);
+    split4<2, true>(make_float4(wv[4] * cw, wv[5] * cw, wv[6] * cw, wv[7] * cw), hi);
+#pragma unroll
+    for (int p = 0; p < 2; ++p)   // [plane][k-step kq >> 1][octet kq & 1][co][8 x 16 bit]
+      *reinterpret_cast<uint4*>(Bb + p * RGB_B_PLANE + (((kq >> 1) * 2 + (kq & 1)) * 128 + co) * 16) = make_uint4(lo[p].x, lo[p].y, hi[p].x, hi[p].y);
+  }
+  // 3. im2col rows: thread = (pixel, K half)
+  {
+    const int p = tid & 255, kh = tid >> 8, pr = p >> 5, pc = p & 31;
+    float av[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int k = kh * 16 + j;
+      av[j] = k < 27 ? rgb_tap(patch, pr, pc, k) * cx : 0.f;
+    }
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      uint2 lo[2], hi[2];
+      split4<2, true>(make_float4(av[8 * o], av[8 * o + 1], av[8 * o + 2], av[8 * o + 3]), lo);
+      split4<2, true>(make_float4(av[8 * o + 4], av[8 * o + 5], av[8 * o + 6], av[8 * o + 7]), hi);
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        *reinterpret_cast<uint4*>(Ab + pl * RGB_A_PLANE + ((kh * 2 + o) * RGB_PIX + p) * 16) = make_uint4(lo[pl].x, lo[pl].y, hi[pl].x, hi[pl].y);
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    uint4 a[2][2], b[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        a[mi][p] = *reinterpret_cast<const uint4*>(Ab + p * RGB_A_PLANE + ((ks * 2 + lh) * RGB_PIX + wm * 64 + mi * 32 + l31) * 16);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+        b[ni][p] = *reinterpret_cast<const uint4*>(Bb + p * RGB_B_PLANE + ((ks * 2 + lh) * 128 + wn * 64 + ni * 32 + l31) * 16);
+    }
+#pragma unroll
+    for (int sum = 1; sum >= 0; --sum)
+#pragma unroll
+      for (int pa = 0; pa <= sum; ++pa)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma16<true>(a[mi][pa], b[ni][sum - pa], acc[mi][ni]);   // lane = channel, registers = pixels
+  }
+
+  // lane = channel: every store instruction writes whole 128-byte lines (32 consecutive channels of one pixel per half-wave) -- the call
+  // is bound by writing y, and 16-byte pieces of four different lines per lane (the transposed layout of the halo kernels) ran at 2 TB/s
+  const float unscale = 1.f / (cx * cw);                             // exact: powers of two
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int n = n0 + wn * 64 + ni * 32 + l31;
+    const float bv = (bias != nullptr && n < Cout) ? bias[n] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      float* yp = y + (((long)img * Ho + h0 + 2 * wm + mi) * Wo + w0) * Cout + n;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int px = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (n < Cout) yp[(long)px * Cout] = ladder_act_fn(acc[mi][ni][e] * unscale + bv, act);
+      }
+    }
+  }
+}
+
+// ---- filter gradient ------------------------------------------------------------------------------------------------------------
+// Workgroup = 4 wavefronts, walks a run of 2x32-pixel output patches (64 pixels = 4 MFMA K-steps of 16); wavefront w owns the 32 output
+// channels [32w, 32w + 32) of the 128-channel slab (one accumulator tile, no cross-wavefront reduction).  Per patch:
+// the 5 x 65 x 3 input patch and the 64 x 128 dY tile (prefetched into registers during the previous patch) are written to LDS -- dY as
+// two fp16 planes in [32-channel block][pixel][32 ch x 16 bit] rows of 64 bytes, the im2col matrix [pixel][32 taps x 16 bit] likewise
+// -- and every wavefront multiplies A = im2col^T (rows = tap index k) with its B = dY block, fragments through the transposing LDS
+// read.  The scales are TENSOR-wide here (absmax records of x and dy): one accumulator sums over many patches.
+constexpr int RW_PH = 2, RW_PW = 32, RW_PIX = RW_PH * RW_PW;
+constexpr int RW_XH = 2 * RW_PH + 1, RW_XW = 2 * RW_PW + 1, RW_PATCH = RW_XH * RW_XW * 3;       // 5 x 65 x 3 = 975 floats
+constexpr int RW_THREADS = 256;
+constexpr int RW_ABLK = RW_PIX * 64 + 64, RW_DBLK = RW_PIX * 64 + 64;                          // bytes per 32-channel block image
+constexpr int RW_APLANE = RW_ABLK, RW_DPLANE = 4 * RW_DBLK;
+constexpr int RW_XU = (RW_PATCH + RW_THREADS - 1) / RW_THREADS;                                // 4 patch floats per thread
+constexpr int RW_DU = RW_PIX * 32 / RW_THREADS;                                                // 8 dY float4 units per thread
+
+typedef short rgb_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 rgb_tr_frag(const unsigned char* p) {
+  const rgb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rgb_s16x4*)(p));
+  const rgb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rgb_s16x4*)(p + 4 * 64));
+  const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+  return make_uint4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ float rgb_frag_sum(const uint4 f) {      // sum of the 8 fp16 values of a fragment, in fp32
+  const uint32_t w[4] = {f.x, f.y, f.z, f.w};
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x2 v = __builtin_convertvector(__builtin_bit_cast(f16x2, w[i]), f32x2);
+    s += v.x + v.y;
+  }
+  return s;
+}
+
+__global__ __launch_bounds__(RW_THREADS, 3) void conv_rgb_s2_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                         float* __restrict__ part, float* __restrict__ bias_part,
+                                                                         const int N, const int H, const int W, const int Cout,
+                                                                         const int tiles_co, const int patches_per_split,
+                                                                         const float* __restrict__ xamax, const float* __restrict__ damax) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * RW_APLANE + 2 * RW_DPLANE];
+  __shared__ __attribute__((aligned(16))) float patch[RW_PATCH + 1];
+  unsigned char* const Ab = lds;
+  unsigned char* const Db = lds + 2 * RW_APLANE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5, l15 = lane & 15;
+  const int split = blockIdx.x / tiles_co, co0 = (blockIdx.x - split * tiles_co) * 128;
+  const int Ho = H / 2, Wo = W / 2, WP = Wo / RW_PW, HP = Ho / RW_PH;
+  const int q_total = N * HP * WP;
+  const int q0 = split * patches_per_split, q1 = min(q_total, q0 + patches_per_split);
+  const float cx = scale_from_absmax(amax_load(xamax)), cd = scale_from_absmax(amax_load(damax));
+  const int frag_lane = (8 * lh + (l15 >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (l15 & 3)) * 2;
+
+  f32x16 acc;                                                  // wavefront wv owns output channels [32 wv, 32 wv + 32) for all 4 K-steps
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  float bsum = 0.f;
+
+  float xr[RW_XU];
+  float4 d0, d1, d2, d3, d4, d5, d6, d7;                       // (named: see convsplit.hip on arrays of vectors captured by lambdas)
+  auto load_patch = [&](int q) {
+    const int img = q / (HP * WP), rem = q - img * (HP * WP), hp = rem / WP;
+    const int h0 = hp * RW_PH, w0 = (rem - hp * WP) * RW_PW;
+#pragma unroll
+    for (int i = 0; i < RW_XU; ++i) {
+      const int v = tid + i * RW_THREADS;
+      const int r = v / (RW_XW * 3), c3 = v - r * (RW_XW * 3);
+      const int hi = 2 * h0 + r, wi3 = 2 * w0 * 3 + c3;
+      xr[i] = (v < RW_PATCH && hi < H && wi3 < W * 3) ? x[((long)img * H + hi) * W * 3 + wi3] : 0.f;
+    }
+    const float* dbase = dy + (((long)img * Ho + h0) * Wo + w0) * Cout + co0;
+#define RW_DSRC(i_) [&]() -> float4 {                                                                                       \
+      const int u = tid + (i_) * RW_THREADS, px = u >> 5, q4 = u & 31;                                                        \
+      if (co0 + q4 * 4 >= Cout) return make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
+      return *reinterpret_cast<const float4*>(dbase + ((long)(px >> 5) * Wo + (px & 31)) * Cout + q4 * 4); }()
+    d0 = RW_DSRC(0); d1 = RW_DSRC(1); d2 = RW_DSRC(2); d3 = RW_DSRC(3); d4 = RW_DSRC(4); d5 = RW_DSRC(5); d6 = RW_DSRC(6); d7 = RW_DSRC(7);
+#undef RW_DSRC
+  };
+  auto store_d = [&](int i, float4 v) {
+    const int u = tid + i * RW_THREADS, px = u >> 5, q4 = u & 31;
+    uint2 pl[2];
+    split4<2, true>(make_float4(v.x * cd, v.y * cd, v.z * cd, v.w * cd), pl);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) *reinterpret_cast<uint2*>(Db + p * RW_DPLANE + (q4 >> 3) * RW_DBLK + px * 64 + (q4 & 7) * 8) = pl[p];
+  };
+
+  if (q0 < q1) load_patch(q0);
+  for (int q = q0; q < q1; ++q) {
+    // registers -> LDS: fp32 input patch, dY planes
+#pragma unroll
+    for (int i = 0; i < RW_XU; ++i)
+      if (tid + i * RW_THREADS < RW_PATCH) patch[tid + i * RW_THREADS] = xr[i];
+    store_d(0, d0); store_d(1, d1); store_d(2, d2); store_d(3, d3); store_d(4, d4); store_d(5, d5); store_d(6, d6); store_d(7, d7);
+    __syncthreads();
+    if (tid < 2 * RW_PIX) {                                     // im2col rows: thread = (pixel, K half)
+      const int p = tid & (RW_PIX - 1), kh = tid >> 6, pr = p >> 5, pc = p & 31;
+      float av[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int k = kh * 16 + j;
+        const int tap = k / 3, ci = k - tap * 3, r = tap / 3, s = tap - r * 3;
+        av[j] = k < 27 ? patch[((2 * pr + r) * RW_XW + 2 * pc + s) * 3 + ci] * cx : 0.f;
+      }
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        uint2 pl[2];
+        split4<2, true>(make_float4(av[4 * o], av[4 * o + 1], av[4 * o + 2], av[4 * o + 3]), pl);
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) *reinterpret_cast<uint2*>(Ab + pp * RW_APLANE + p * 64 + kh * 32 + o * 8) = pl[pp];
+      }
+    }
+    __syncthreads();
+    if (q + 1 < q1) load_patch(q + 1);                          // in flight across the MFMAs and the next patch's barriers
+#pragma unroll
+    for (int ks = 0; ks < RW_PIX / 16; ++ks) {
+      const int pb = ks * 16;
+      const uint4 a0 = rgb_tr_frag(Ab + pb * 64 + frag_lane), a1 = rgb_tr_frag(Ab + RW_APLANE + pb * 64 + frag_lane);
+      const uint4 b0 = rgb_tr_frag(Db + wv * RW_DBLK + pb * 64 + frag_lane), b1 = rgb_tr_frag(Db + RW_DPLANE + wv * RW_DBLK + pb * 64 + frag_lane);
+      acc = mfma16<true>(a1, b0, acc);
+      acc = mfma16<true>(a0, b1, acc);
+      acc = mfma16<true>(a0, b0, acc);
+      bsum += rgb_frag_sum(b1) + rgb_frag_sum(b0);
+    }
+    __syncthreads();
+  }
+
+  const float unscale = 1.f / (cx * cd);
+  float* o = part + (size_t)split * 27 * Cout;
+  const int n = co0 + wv * 32 + l31;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int k = (e & 3) + 8 * (e >> 2) + 4 * lh;
+    if (k < 27 && n < Cout) o[(size_t)k * Cout + n] = acc[e] * unscale;
+  }
+  bsum += __shfl_down(bsum, 32, 64);                           // pixels 0-7 + 8-15 of every K-step
+  if (bias_part != nullptr && lh == 0 && n < Cout) bias_part[(size_t)split * Cout + n] = bsum * (1.f / cd);
+}
+
+struct RgbWgradPlan { int tiles_co, splits, pps; };
+RgbWgradPlan plan_rgb_wgrad(int N, int H, int W, int Cout) {
+  RgbWgradPlan p;
+  p.tiles_co = (Cout + 127) / 128;
+  const long q_total = (long)N * (H / 2 / RW_PH) * (W / 2 / RW_PW);
+  long s = (3 * 256L) / p.tiles_co;                            // three workgroups per CU
+  if (s > q_total / 4) s = q_total / 4;
+  if (s < 1) s = 1;
+  p.pps = (int)((q_total + s - 1) / s);
+  p.splits = (int)((q_total + p.pps - 1) / p.pps);
+  return p;
+}
+
+bool rgb_s2_ok(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l) {
+  return N > 0 && Cin == 3 && KH == 3 && KW == 3 && stride == 2 && pad_t == 0 && pad_l == 0 && (H % 2) == 0 && (W % 2) == 0 &&
+         ((H / 2) % RGB_TH) == 0 && ((W / 2) % RGB_TW) == 0 && Cout >= 32 && (Cout % 4) == 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ladder_conv_rgb_s2_eligible(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l) {
+  return rgb_s2_ok(N, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l) ? 1 : 0;
+}
+
+int ladder_conv_rgb_s2_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act,
+                           ladder_stream_t stream) {
+  if (!rgb_s2_ok(N, H, W, 3, Cout, 3, 3, 2, 0, 0)) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(y) || (bias != nullptr && !ladder_aligned16(bias))) return LADDER_E_ALIGN;
+  const int tiles_n = (Cout + 127) / 128;
+  const long tiles = (long)N * (H / 2 / RGB_TH) * (W / 2 / RGB_TW) * tiles_n;
+  if (tiles >= (1L << 31)) return LADDER_E_SHAPE;
+  hipLaunchKernelGGL(conv_rgb_s2_fwd_kernel, dim3((unsigned)tiles), dim3(RGB_THREADS), 0, stream, x, w, bias, y, N, H, W, Cout, act, tiles_n);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+size_t ladder_conv_rgb_s2_bwd_filter_workspace_bytes(int N, int H, int W, int Cout) {
+  if (!rgb_s2_ok(N, H, W, 3, Cout, 3, 3, 2, 0, 0)) return 0;
+  const RgbWgradPlan p = plan_rgb_wgrad(N, H, W, Cout);
+  return (size_t)p.splits * (27 * (size_t)Cout + Cout) * sizeof(float);
+}
+
+int ladder_conv_rgb_s2_bwd_filter(const float* x, const float* x_absmax, const float* dy, const float* dy_absmax, float* dw, float* db, int N,
+                                  int H, int W, int Cout, void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  if (!rgb_s2_ok(N, H, W, 3, Cout, 3, 3, 2, 0, 0) || x_absmax == nullptr || dy_absmax == nullptr) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(dy) || !ladder_aligned16(dw)) return LADDER_E_ALIGN;
+  if (ws == nullptr || ws_bytes < ladder_conv_rgb_s2_bwd_filter_workspace_bytes(N, H, W, Cout)) return LADDER_E_WORKSPACE;
+  const RgbWgradPlan p = plan_rgb_wgrad(N, H, W, Cout);
+  float* part = (float*)ws;
+  float* bias_part = db != nullptr ? part + (size_t)p.splits * 27 * Cout : nullptr;
+  hipLaunchKernelGGL(conv_rgb_s2_wgrad_kernel, dim3(p.tiles_co * p.splits), dim3(RW_THREADS), 0, stream, x, dy, part, bias_part, N, H, W, Cout,
+                     p.tiles_co, p.pps, x_absmax, dy_absmax);
+  LADDER_CHECK_LAUNCH();
+  int rc = ladder_reduce_splits(part, dw, p.splits, (size_t)27 * Cout, stream);
+  if (rc != LADDER_OK) return rc;
+  if (db != nullptr) rc = ladder_reduce_splits(bias_part, db, p.splits, (size_t)Cout, stream);
+  return rc;
+}
+
+}  // extern "C"

@@ -346,6 +346,11 @@ class Conv2D:
         return bool(self.ctx.ns and self.k == 1 and self.stride == 1 and M <= 512 and self.cin >= 16
                     and L.query("ladder_dense_small_eligible", M, self.cin, self.cout))
 
+    def _rgb(self, N, H, W):
+        # (the kernels are f16x3 inside -- the filter gradient takes tensor-wide absmax records -- so they belong to that precision mode)
+        return bool(self.ctx.ns == 4 and self.cin == 3 and L.query("ladder_conv_rgb_s2_eligible", N, H, W, self.cin, self.cout, self.k, self.k,
+                                                               self.stride, self.pt, self.pl))
+
     def _packed_filter(self, transpose_flip):
         """Split bf16 planes of the filter bank in the kernel's LDS layout, re-packed when the weights changed (always while a
         hipGraph is being captured, so that a replay re-packs the then-current weights)."""
@@ -405,6 +410,11 @@ class Conv2D:
             self.x, self.y = x, y
             return y
         geo = (N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl)
+        if self._rgb(N, H, W):                           # the image-side encoder conv (3 -> Cout channels, stride 2): csrc/convrgb.hip
+            L.call("ladder_conv_rgb_s2_fwd", _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y), N, H, W,
+                   self.cout, L.ACT[self.act], self.ctx.stream)
+            self.x, self.y = x, y
+            return y
         if self.ctx.ns and L.query("ladder_conv2d_fwd_split_eligible", *geo):
             self.x_amax = self.ctx.absmax(x)
             nb = L.query("ladder_conv2d_fwd_split_workspace_bytes", *geo)
@@ -459,6 +469,12 @@ class Conv2D:
                        _p(x) if gate_prev else None, L.ACT[gate_prev] if gate_prev else 0, st)
             self.x = self.y = None
             return dx
+        if wgrad and self._rgb(N, H, W):
+            wsp, wsn = self.ctx.ws(L.query("ladder_conv_rgb_s2_bwd_filter_workspace_bytes", N, H, W, self.cout))
+            L.call("ladder_conv_rgb_s2_bwd_filter", _p(x), _p(self.ctx.absmax(x)), _p(dy), _p(self.ctx.absmax(dy)),
+                   _p(self.ps.g[self.name + "/kernel"]), _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, N, H, W, self.cout,
+                   wsp, wsn, st)
+            wgrad = False
         dy_amax = None
         split_w = bool(wgrad and self._split_ok(N, H, W, self.cin, self.cout)
                        and L.query("ladder_conv3x3_wgrad_split_eligible", N, H, W, self.cin, self.cout, self.ctx.ns))

@@ -384,3 +384,49 @@ def test_dense_small_bf16x6(gpu_ctx, M, K, N, act):
     L.call("ladder_dense_bwd_data_small", p(dyd), p(wd), p(dxg), M, K, N, p(xd), 1, st)
     assert torch.equal(dxg, dx * torch.where(xd > 0, 1.0, 0.2))
     assert L.query("ladder_dense_small_eligible", 4096, 512, 512) == 0
+
+
+@pytest.mark.parametrize("case", [(4, 128, 128, 128, "leaky_relu"), (3, 32, 64, 160, None), (2, 16, 64, 32, "tanh")],
+                         ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_rgb_stride2(gpu_ctx, case):
+    """The encoder's image-side convolution (3x3, stride 2, SAME, 3 input channels; codes/models.py:398-405) on csrc/convrgb.hip:
+    forward and filter gradient (+ bias gradient) against the float64 oracle at the fp32 kernels' tolerances, images scaled like the
+    data ([0, 1]) with one heavy-tailed tile."""
+    L = _lib()
+    from ladder_latent_data_distribution_modelling_amd import arch
+    N, H, W, Cout, act = case
+    rng = np.random.default_rng(N * 131 + Cout)
+    x = rng.random((N, H, W, 3)).astype(np.float32)
+    x[0, :5, :7] *= 300.0                                                # one tile with a very different scale (per-workgroup scales)
+    x[-1, -1, -1] = 0.0
+    w = (rng.standard_normal((3, 3, 3, Cout)) / np.sqrt(27)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    xt, wt, bt = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (x, w, b))
+    yr = O.act(O.conv2d_tf(xt, wt, bt, 2, "same"), act)
+    pt, Ho = arch.conv_out(H, 3, 2, "same")
+    pl, Wo = arch.conv_out(W, 3, 2, "same")
+    assert (pt, pl) == (0, 0) and L.query("ladder_conv_rgb_s2_eligible", N, H, W, 3, Cout, 3, 3, 2, pt, pl) == 1
+    st = gpu_ctx.stream
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    y = torch.empty(N, Ho, Wo, Cout, device="cuda")
+    L.call("ladder_conv_rgb_s2_fwd", p(xd), p(wd), p(bd), p(y), N, H, W, Cout, L.ACT[act], st)
+    close(y, yr, 2e-5, "fwd")
+    dy = (rng.standard_normal(tuple(yr.shape)) * 1e-3).astype(np.float32)
+    dy[0, 0, 0, :] *= 50.0
+    yr.backward(torch.tensor(dy, dtype=torch.float64))
+    dyd = dev(dy)
+    if act is not None:
+        L.call("ladder_act_bwd", p(dyd), p(dev(yr.detach().numpy())), p(dyd), dyd.numel(), L.ACT[act], st)
+    xa, da = absmax(L, xd, st), absmax(L, dyd, st)
+    wsp, wsn = gpu_ctx.ws(L.query("ladder_conv_rgb_s2_bwd_filter_workspace_bytes", N, H, W, Cout))
+    dw, db = torch.empty_like(wd), torch.empty_like(bd)
+    L.call("ladder_conv_rgb_s2_bwd_filter", p(xd), p(xa), p(dyd), p(da), p(dw), p(db), N, H, W, Cout, wsp, wsn, st)
+    close(dw, wt.grad, 3e-5, "dw")
+    close(db, bt.grad, 3e-5, "db")
+    dw2 = torch.full_like(wd, 7.0)
+    L.call("ladder_conv_rgb_s2_bwd_filter", p(xd), p(xa), p(dyd), p(da), p(dw2), None, N, H, W, Cout, wsp, wsn, st)
+    assert torch.equal(dw2, dw)                                           # bit-reproducible, db == NULL leaves dw untouched
+    assert L.query("ladder_conv_rgb_s2_bwd_filter", p(xd), p(xa), p(dyd), p(da), p(dw), p(db), N, H, W, Cout, None, 0, st) == -3
+    assert L.query("ladder_conv_rgb_s2_eligible", N, H, W, 4, Cout, 3, 3, 2, 0, 0) == 0
+    assert L.query("ladder_conv_rgb_s2_eligible", N, H + 2, W, 3, Cout, 3, 3, 2, 0, 0) == 0      # (H/2) % 8
+    assert L.query("ladder_conv_rgb_s2_eligible", N, H, W, 3, Cout, 3, 3, 1, 1, 1) == 0
