@@ -839,7 +839,8 @@ WgradSplitPlan plan_wgrad_split(int N, int H, int W, int Cin, int Cout) {
   p.tiles_ci = Cin / WS_CI;
   p.tiles_co = (Cout + WS_CO - 1) / WS_CO;
   const long pairs = (long)p.tiles_ci * p.tiles_co;
-  long s = (2 * 256L) / pairs;                                 // two whole rounds of the chip (one workgroup per CU)
+  long s = 256L / pairs;                                       // ONE round of the chip (one workgroup per CU): every further round doubles the
+                                                               // partial-sum traffic for nothing (conv5: 360 / 340 / 309 / 292 TF at 1 / 2 / 3 / 4 rounds)
   if (s > q_total / 16) s = q_total / 16;
   if (s < 1) s = 1;
   p.pps = (int)((q_total + s - 1) / s);
