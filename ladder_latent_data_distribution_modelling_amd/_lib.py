@@ -117,6 +117,9 @@ PROTOTYPES = {
     "ladder_conv3x3_split_proj": (_i, [_p, _p, _p, _p, _p, _p, _p, _p] + [_i] * 8 + [_p]),
     "ladder_conv_rgb_s2_eligible": (_i, [_i] * 10),
     "ladder_conv_rgb_s2_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "ladder_conv_rgb_s2_fwd_bnstats_workspace_bytes": (_z, [_i] * 4),
+    "ladder_conv_rgb_s2_fwd_bnstats": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _z, _p]),
+    "ladder_bn_stats_from_partials": (_i, [_p, _i, _p, _i, _p]),
     "ladder_conv_rgb_s2_bwd_filter_workspace_bytes": (_z, [_i] * 4),
     "ladder_conv_rgb_s2_bwd_filter": (_i, [_p] * 6 + [_i] * 4 + [_p, _z, _p]),
     "ladder_bn_fwd_apply_absmax": (_i, [_p, _p, _d, _p, _p, _p, _p, _z, _i, _f, _i, _p, _p]),

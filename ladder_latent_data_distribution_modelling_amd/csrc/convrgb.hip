@@ -43,7 +43,7 @@ __device__ __forceinline__ float rgb_tap(const float* __restrict__ patch, int pr
 __global__ __launch_bounds__(RGB_THREADS, 4) void conv_rgb_s2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                         const float* __restrict__ bias, float* __restrict__ y,
                                                                         const int N, const int H, const int W, const int Cout,
-                                                                        const int act, const int tiles_n) {
+                                                                        const int act, const int tiles_n, float* __restrict__ stats_part) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * RGB_A_PLANE + 2 * RGB_B_PLANE];   // 48 KB; the fp32 patch aliases the B region + tail
   __shared__ __attribute__((aligned(16))) float patch[RGB_PATCH + 5];
   __shared__ float red[8];
@@ -140,6 +140,7 @@ __global__ __launch_bounds__(RGB_THREADS, 4) void conv_rgb_s2_fwd_kernel(const f
   // lane = channel: every store instruction writes whole 128-byte lines (32 consecutive channels of one pixel per half-wave) -- the call
   // is bound by writing y, and 16-byte pieces of four different lines per lane (the transposed layout of the halo kernels) ran at 2 TB/s
   const float unscale = 1.f / (cx * cw);                             // exact: powers of two
+  float st0[2] = {0.f, 0.f}, st1[2] = {0.f, 0.f};                    // per-channel sum / sum of squares of what is written (batch-norm statistics)
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int n = n0 + wn * 64 + ni * 32 + l31;
@@ -150,8 +151,31 @@ __global__ __launch_bounds__(RGB_THREADS, 4) void conv_rgb_s2_fwd_kernel(const f
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int px = (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (n < Cout) yp[(long)px * Cout] = ladder_act_fn(acc[mi][ni][e] * unscale + bv, act);
+        const float v = ladder_act_fn(acc[mi][ni][e] * unscale + bv, act);
+        if (n < Cout) yp[(long)px * Cout] = v;
+        st0[ni] += v;
+        st1[ni] += v * v;
       }
+    }
+  }
+  if (stats_part != nullptr) {
+    // lane = channel makes the column sums local: 32 pixels per lane, the other half-wave holds the other 32 of this wavefront's 64,
+    // the four wm wavefronts the rest of the patch; fixed order throughout.  partials[tile_m][2][Cout]
+    float* sred = reinterpret_cast<float*>(lds);                     // [which 2][wm 4][128 channels] (the plane images are dead)
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const float a0 = st0[ni] + __shfl_xor(st0[ni], 32, 64), a1 = st1[ni] + __shfl_xor(st1[ni], 32, 64);
+      if (lh == 0) {
+        sred[(0 * 4 + wm) * 128 + wn * 64 + ni * 32 + l31] = a0;
+        sred[(1 * 4 + wm) * 128 + wn * 64 + ni * 32 + l31] = a1;
+      }
+    }
+    __syncthreads();
+    if (tid < 256) {
+      const int which = tid >> 7, c = tid & 127;
+      const float t = (sred[(which * 4 + 0) * 128 + c] + sred[(which * 4 + 1) * 128 + c]) + (sred[(which * 4 + 2) * 128 + c] + sred[(which * 4 + 3) * 128 + c]);
+      if (n0 + c < Cout) stats_part[((size_t)mt * 2 + which) * Cout + n0 + c] = t;
     }
   }
 }
@@ -319,16 +343,39 @@ int ladder_conv_rgb_s2_eligible(int N, int H, int W, int Cin, int Cout, int KH, 
   return rgb_s2_ok(N, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l) ? 1 : 0;
 }
 
-int ladder_conv_rgb_s2_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act,
-                           ladder_stream_t stream) {
+static int rgb_fwd_launch(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act, float* stats_part,
+                          ladder_stream_t stream) {
   if (!rgb_s2_ok(N, H, W, 3, Cout, 3, 3, 2, 0, 0)) return LADDER_E_SHAPE;
   if (!ladder_aligned16(y) || (bias != nullptr && !ladder_aligned16(bias))) return LADDER_E_ALIGN;
   const int tiles_n = (Cout + 127) / 128;
   const long tiles = (long)N * (H / 2 / RGB_TH) * (W / 2 / RGB_TW) * tiles_n;
   if (tiles >= (1L << 31)) return LADDER_E_SHAPE;
-  hipLaunchKernelGGL(conv_rgb_s2_fwd_kernel, dim3((unsigned)tiles), dim3(RGB_THREADS), 0, stream, x, w, bias, y, N, H, W, Cout, act, tiles_n);
+  hipLaunchKernelGGL(conv_rgb_s2_fwd_kernel, dim3((unsigned)tiles), dim3(RGB_THREADS), 0, stream, x, w, bias, y, N, H, W, Cout, act, tiles_n,
+                     stats_part);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
+}
+
+int ladder_conv_rgb_s2_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act,
+                           ladder_stream_t stream) {
+  return rgb_fwd_launch(x, w, bias, y, N, H, W, Cout, act, nullptr, stream);
+}
+
+size_t ladder_conv_rgb_s2_fwd_bnstats_workspace_bytes(int N, int H, int W, int Cout) {
+  if (!rgb_s2_ok(N, H, W, 3, Cout, 3, 3, 2, 0, 0)) return 0;
+  return (size_t)N * (H / 2 / RGB_TH) * (W / 2 / RGB_TW) * 2 * Cout * sizeof(float);
+}
+
+// The forward call + the batch-norm statistics of its output (sums[0:Cout] = sum over all pixels of y, sums[Cout:2Cout] = sum of y^2:
+// what ladder_bn_fwd_stats would compute from a second pass over y), from per-patch column sums of the epilogue.
+int ladder_conv_rgb_s2_fwd_bnstats(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act,
+                                   float* sums, void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  const size_t need = ladder_conv_rgb_s2_fwd_bnstats_workspace_bytes(N, H, W, Cout);
+  if (need == 0 || sums == nullptr) return LADDER_E_SHAPE;
+  if (ws == nullptr || ws_bytes < need) return LADDER_E_WORKSPACE;
+  const int rc = rgb_fwd_launch(x, w, bias, y, N, H, W, Cout, act, (float*)ws, stream);
+  if (rc != LADDER_OK) return rc;
+  return ladder_bn_stats_from_partials((const float*)ws, N * (H / 2 / RGB_TH) * (W / 2 / RGB_TW), sums, Cout, stream);
 }
 
 size_t ladder_conv_rgb_s2_bwd_filter_workspace_bytes(int N, int H, int W, int Cout) {

@@ -104,6 +104,27 @@ __global__ __launch_bounds__(256) void colstats_stage2(const float* __restrict__
   if (rl == 0 && i < 2 * C) out[i] = (float)((sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]));
 }
 
+// stage 2 for MANY partials (the per-tile column sums a convolution epilogue emits: thousands of blocks): 16 columns x 16 row lanes per
+// workgroup, every lane sums each 16th partial in fp64, fixed-order LDS tree.
+__global__ __launch_bounds__(256) void colstats_stage2_wide(const float* __restrict__ ws, float* __restrict__ out, int nblk, int C) {
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + cl;   // over 2C
+  double s = 0.0;
+  if (i < 2 * C) {
+    const int which = i / C, c = i - which * C;
+    for (int b = rl; b < nblk; b += 16) s += (double)ws[((size_t)b * 2 + which) * C + c];
+  }
+  __shared__ double sm[16][17];
+  sm[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && i < 2 * C) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sm[k][cl];
+    out[i] = (float)t;
+  }
+}
+
 size_t stats_nblk(size_t rows) {
   size_t nblk = (rows + 1023) / 1024;
   if (nblk > 512) nblk = 512;
@@ -743,6 +764,14 @@ int ladder_bn_fwd_stats(const float* x, float* sums, size_t rows, int C, void* w
     hipLaunchKernelGGL(colstats_stage1<1>, dim3((C + 63) / 64, (unsigned)nblk), dim3(256), 0, stream, x, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)ws, rows, C, rpb, 0);
   hipLaunchKernelGGL(colstats_stage2, dim3((2 * C + 63) / 64), dim3(256), 0, stream, (const float*)ws, sums, (int)nblk, C);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+// sums[0:C] = sum over blocks of partials[b][0][:], sums[C:2C] = ... of partials[b][1][:]  (partials [nblk][2][C]; fixed order, fp64)
+int ladder_bn_stats_from_partials(const float* partials, int nblk, float* sums, int C, ladder_stream_t stream) {
+  if (nblk <= 0 || C <= 0) return LADDER_E_SHAPE;
+  hipLaunchKernelGGL(colstats_stage2_wide, dim3((2 * C + 15) / 16), dim3(256), 0, stream, partials, sums, nblk, C);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

@@ -336,6 +336,7 @@ class Conv2D:
         # it is not computed and stays 0 in the flat gradient buffer
         self.bias_grad = bias_grad
         self._packed = {}      # (transpose_flip, ns) -> [weight version, packed bf16 planes]
+        self.want_bn_sums, self.bn_sums = False, None          # batch-norm statistics of the output from the conv epilogue (RGB conv)
 
     def _split_ok(self, N, H, W, cin, cout):
         """The layer runs on the split-bf16 halo kernel (csrc/convsplit.hip) in the configured precision mode."""
@@ -411,8 +412,14 @@ class Conv2D:
             return y
         geo = (N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl)
         if self._rgb(N, H, W):                           # the image-side encoder conv (3 -> Cout channels, stride 2): csrc/convrgb.hip
-            L.call("ladder_conv_rgb_s2_fwd", _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y), N, H, W,
-                   self.cout, L.ACT[self.act], self.ctx.stream)
+            if self.want_bn_sums and self.act is None:
+                wsp, wsn = self.ctx.ws(L.query("ladder_conv_rgb_s2_fwd_bnstats_workspace_bytes", N, H, W, self.cout))
+                self.bn_sums = self.ctx.empty(2 * self.cout)
+                L.call("ladder_conv_rgb_s2_fwd_bnstats", _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y),
+                       N, H, W, self.cout, 0, _p(self.bn_sums), wsp, wsn, self.ctx.stream)
+            else:
+                L.call("ladder_conv_rgb_s2_fwd", _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y), N, H,
+                       W, self.cout, L.ACT[self.act], self.ctx.stream)
             self.x, self.y = x, y
             return y
         if self.ctx.ns and L.query("ladder_conv2d_fwd_split_eligible", *geo):
@@ -608,13 +615,15 @@ class BatchNormAct:
     def __init__(self, ctx, ps, name, C, act):
         self.ctx, self.ps, self.name, self.C, self.act = ctx, ps, name, C, act
 
-    def forward(self, x):
+    def forward(self, x, sums=None):
+        """`sums`: the [2C] statistics of x when its producer already computed them (conv epilogue), else a pass over x."""
         C, ctx = self.C, self.ctx
         rows = x.numel() // C
-        nb = L.query("ladder_bn_workspace_bytes", rows, C)
-        wsp, wsn = ctx.ws(nb)
-        sums = ctx.empty(2 * C)
-        L.call("ladder_bn_fwd_stats", _p(x), _p(sums), rows, C, wsp, wsn, ctx.stream)
+        if sums is None:
+            nb = L.query("ladder_bn_workspace_bytes", rows, C)
+            wsp, wsn = ctx.ws(nb)
+            sums = ctx.empty(2 * C)
+            L.call("ladder_bn_fwd_stats", _p(x), _p(sums), rows, C, wsp, wsn, ctx.stream)
         ctx.comm.allreduce_(sums)
         self.count = float(rows) * ctx.comm.world
         y = torch.empty_like(x)
@@ -763,9 +772,11 @@ class Encoder:
     def forward(self, x):
         h = pad_symmetric(self.ctx, x, 2) if self.exp != "celeba" else x
         for conv, bn in zip(self.convs, self.bns):
+            conv.want_bn_sums = bn is not None                  # a conv that can emit the statistics of its output does (conv.bn_sums)
             h = conv.forward(h)
             if bn is not None:
-                h = bn.forward(h)
+                h = bn.forward(h, sums=conv.bn_sums)
+            conv.bn_sums = None
         self.conv_shape = h.shape
         h = h.reshape(h.shape[0], -1)
         if self.hidden is not None:

@@ -411,6 +411,16 @@ def test_conv_rgb_stride2(gpu_ctx, case):
     y = torch.empty(N, Ho, Wo, Cout, device="cuda")
     L.call("ladder_conv_rgb_s2_fwd", p(xd), p(wd), p(bd), p(y), N, H, W, Cout, L.ACT[act], st)
     close(y, yr, 2e-5, "fwd")
+    # the same call emitting the batch-norm statistics of its output: identical y, sums as the two-pass kernels compute them
+    wsp, wsn = gpu_ctx.ws(L.query("ladder_conv_rgb_s2_fwd_bnstats_workspace_bytes", N, H, W, Cout))
+    y2, sums, sums0 = torch.empty_like(y), torch.empty(2 * Cout, device="cuda"), torch.empty(2 * Cout, device="cuda")
+    L.call("ladder_conv_rgb_s2_fwd_bnstats", p(xd), p(wd), p(bd), p(y2), N, H, W, Cout, L.ACT[act], p(sums), wsp, wsn, st)
+    assert torch.equal(y2, y)
+    wsp2, wsn2 = gpu_ctx.ws(L.query("ladder_bn_workspace_bytes", N * Ho * Wo, Cout))
+    L.call("ladder_bn_fwd_stats", p(y), p(sums0), N * Ho * Wo, Cout, wsp2, wsn2, st)
+    y64 = y.double().reshape(-1, Cout)
+    ref = torch.cat([y64.sum(0), (y64 * y64).sum(0)])
+    assert ((sums.double() - ref).abs() <= 2e-6 * ref.abs().max()).all() and ((sums0.double() - ref).abs() <= 2e-6 * ref.abs().max()).all()
     dy = (rng.standard_normal(tuple(yr.shape)) * 1e-3).astype(np.float32)
     dy[0, 0, 0, :] *= 50.0
     yr.backward(torch.tensor(dy, dtype=torch.float64))
