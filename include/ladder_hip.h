@@ -272,6 +272,11 @@ int ladder_in_style_fwd_absmax(const float* x, const float* style, float* y, flo
                                void* ws, size_t ws_bytes, float* y_absmax, ladder_stream_t stream);
 int ladder_in_style_bwd_absmax(const float* dy, const float* x, const float* style, const float* mean_rstd, float* dx, float* dstyle,
                                int N, int HW, int C, int act, void* ws, size_t ws_bytes, float* dx_absmax, ladder_stream_t stream);
+/* Forward fused with the factor-2 tf.image.resize_images that follows it in the CelebA decoder (models.py:528-538, 554-561, 571-578):
+ * up [N,2H,2W,C] = resize(act(style_mod(instance_norm(x)))), bit-identical to ladder_in_style_fwd + ladder_resize_bilinear_fwd; the
+ * normalised tensor is never written.  C % 4 == 0, workspace required; up_absmax (may be NULL) receives the record of max|up|. */
+int ladder_in_style_fwd_resize2x(const float* x, const float* style, float* up, float* mean_rstd, int N, int H, int W, int C, float eps,
+                                 int act, void* ws, size_t ws_bytes, float* up_absmax, ladder_stream_t stream);
 
 /* ---------------------------------------------------------------- N6: tf.image.resize_images (TF1 legacy bilinear)
  * codes/models.py:519,538,544,555,561,572,578.  align_corners=False, half_pixel_centers=False;

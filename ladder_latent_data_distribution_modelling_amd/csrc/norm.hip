@@ -554,6 +554,52 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(const float* __restrict
   }
 }
 
+// instance-norm apply FUSED with the factor-2 legacy-bilinear resize that follows it in the decoder (models.py:528-538, 554-561, 571-578):
+// up[n, 2i + a, 2j + b, :] = mean over the (1 + a) x (1 + b) block of y[n, i.., j.., :] with the neighbour indices clamped to the map, y the
+// normalised, styled, activated tensor -- which is never written.  One thread = one low-resolution pixel x 4 channels: it normalises its
+// own value and its right / lower / diagonal neighbours (re-read through L1) and writes the 2x2 output block; the call is bound by
+// writing `up` (4x the input).  The record receives max|y| (a bilinear interpolation is a convex combination).
+__global__ __launch_bounds__(256) void in_apply_resize2x_kernel(const float* __restrict__ x, const float* __restrict__ style,
+                                                                const float* __restrict__ mean_rstd, float* __restrict__ up, int H, int W,
+                                                                int C, int act, float* __restrict__ yamax) {
+  const int CV = C >> 2;
+  const int n = blockIdx.y;
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;          // over H * W * CV
+  float ymax = 0.f;
+  if (j < (long)H * W * CV) {
+    const int cv = (int)(j % CV);
+    const int pix = (int)(j / CV), iy = pix / W, ix = pix - iy * W;
+    const int c = cv * 4;
+    const float4 mu = *reinterpret_cast<const float4*>(mean_rstd + (size_t)n * 2 * C + c);
+    const float4 rs = *reinterpret_cast<const float4*>(mean_rstd + (size_t)n * 2 * C + C + c);
+    float4 s0 = *reinterpret_cast<const float4*>(style + (size_t)n * 2 * C + c);
+    const float4 s1 = *reinterpret_cast<const float4*>(style + (size_t)n * 2 * C + C + c);
+    s0.x += 1.f; s0.y += 1.f; s0.z += 1.f; s0.w += 1.f;
+    const int yh = min(iy + 1, H - 1), xh = min(ix + 1, W - 1);
+    const float* xb = x + (size_t)n * H * W * C + c;
+    auto norm = [&](int r, int q) -> float4 {
+      const float4 v = *reinterpret_cast<const float4*>(xb + ((size_t)r * W + q) * C);
+      float4 o;
+      o.x = ladder_act_fn((v.x - mu.x) * rs.x * s0.x + s1.x, act);
+      o.y = ladder_act_fn((v.y - mu.y) * rs.y * s0.y + s1.y, act);
+      o.z = ladder_act_fn((v.z - mu.z) * rs.z * s0.z + s1.z, act);
+      o.w = ladder_act_fn((v.w - mu.w) * rs.w * s0.w + s1.w, act);
+      return o;
+    };
+    const float4 tl = norm(iy, ix), tr = norm(iy, xh), bl = norm(yh, ix), br = norm(yh, xh);
+    ymax = fmaxf(fmaxf(fabsf(tl.x), fabsf(tl.y)), fmaxf(fabsf(tl.z), fabsf(tl.w)));
+    // the same arithmetic as resize_fwd_kernel (lerp along x, then along y, weights 0 and 1/2)
+    const float4 top = rz_lerp(tl, tr, 0.5f), bot = rz_lerp(bl, br, 0.5f);
+    const int OW = 2 * W;
+    float* o = up + (((size_t)n * 2 * H + 2 * iy) * OW + 2 * ix) * C + c;
+    *reinterpret_cast<float4*>(o) = tl;
+    *reinterpret_cast<float4*>(o + C) = top;
+    *reinterpret_cast<float4*>(o + (size_t)OW * C) = rz_lerp(tl, bl, 0.5f);
+    *reinterpret_cast<float4*>(o + (size_t)OW * C + C) = rz_lerp(top, bot, 0.5f);
+  }
+  if (yamax != nullptr) amax_commit_block(ymax, yamax);
+}
+
 // transpose of the map above in gather form (no atomics): input pixel (iy,ix) collects every output
 // pixel whose lo or hi index equals it, in (oy, ox) order.
 template <int V>
@@ -873,6 +919,25 @@ int ladder_in_style_fwd_absmax(const float* x, const float* style, float* y, flo
     return LADDER_OK;
   }
   hipLaunchKernelGGL(in_style_fwd_kernel, dim3((C + 63) / 64, N), dim3(256), 0, stream, x, style, y, mean_rstd, HW, C, eps, act);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+// Forward + the factor-2 bilinear resize of the decoder in one pass over x: `up` [N, 2H, 2W, C]; the normalised tensor itself is not
+// written.  Needs the vectorised path (C % 4 == 0, workspace, 16-byte alignment).
+int ladder_in_style_fwd_resize2x(const float* x, const float* style, float* up, float* mean_rstd, int N, int H, int W, int C, float eps,
+                                 int act, void* ws, size_t ws_bytes, float* up_absmax, ladder_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return LADDER_E_SHAPE;
+  const int HW = H * W;
+  if (!(C % 4 == 0 && ws != nullptr && ws_bytes >= ladder_in_style_workspace_bytes(N, HW, C) && ladder_aligned16(x) && ladder_aligned16(up)))
+    return LADDER_E_SHAPE;
+  const int sp = in_split(N, HW, C);
+  dim3 grid((C + 63) / 64, N, sp);
+  hipLaunchKernelGGL(in_stats_kernel, grid, dim3(256), 0, stream, x, (float*)ws, HW, C, sp);
+  hipLaunchKernelGGL(in_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, stream, x, (const float*)ws, mean_rstd, N, HW, C, sp, eps, up_absmax);
+  const long units = (long)HW * (C / 4);
+  hipLaunchKernelGGL(in_apply_resize2x_kernel, dim3((unsigned)((units + 255) / 256), N), dim3(256), 0, stream, x, style,
+                     (const float*)mean_rstd, up, H, W, C, act, up_absmax);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

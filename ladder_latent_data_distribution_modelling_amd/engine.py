@@ -679,6 +679,23 @@ class InstanceNormStyleAct:
         self.x, self.style = x, style
         return y
 
+    def forward_resized(self, x, style, rs):
+        """forward() followed by the factor-2 resize `rs` in ONE pass over x (ladder_in_style_fwd_resize2x): the normalised tensor is
+        never written; returns None when the pair is not eligible.  The backward passes are those of the two separate layers."""
+        N, H, W, C = x.shape
+        if not (C % 4 == 0 and (rs.oh, rs.ow) == (2 * H, 2 * W)):
+            return None
+        up = self.ctx.empty(N, 2 * H, 2 * W, C)
+        self.mean_rstd = self.ctx.empty(N, 2 * C)
+        wsp, wsn = self.ctx.ws(L.query("ladder_in_style_workspace_bytes", N, H * W, C))
+        up_amax = self.ctx.new_amax() if self.ctx.ns == 4 else None
+        L.call("ladder_in_style_fwd_resize2x", _p(x), _p(style), _p(up), _p(self.mean_rstd), N, H, W, C, IN_EPS, L.ACT[self.act], wsp, wsn,
+               _p(up_amax), self.ctx.stream)
+        self.ctx.set_amax(up, up_amax)
+        self.x, self.style = x, style
+        rs.in_shape = (N, H, W, C)
+        return up
+
     def backward(self, dy):
         x = self.x
         N, H, W, C = x.shape
@@ -874,7 +891,12 @@ class CelebADecoder:
                     return out
             h = conv.forward(h)
             if norm is not None:
-                h = norm.forward(h, sty.forward(dlatent))
+                style = sty.forward(dlatent)
+                up = norm.forward_resized(h, style, rs) if rs is not None else None
+                if up is not None:
+                    h = up
+                    continue
+                h = norm.forward(h, style)
             if rs is not None:
                 h = rs.forward(h)
         return self.conv_out.forward(h)

@@ -440,3 +440,24 @@ def test_conv_rgb_stride2(gpu_ctx, case):
     assert L.query("ladder_conv_rgb_s2_eligible", N, H, W, 4, Cout, 3, 3, 2, 0, 0) == 0
     assert L.query("ladder_conv_rgb_s2_eligible", N, H + 2, W, 3, Cout, 3, 3, 2, 0, 0) == 0      # (H/2) % 8
     assert L.query("ladder_conv_rgb_s2_eligible", N, H, W, 3, Cout, 3, 3, 1, 1, 1) == 0
+
+
+@pytest.mark.parametrize("shape", [(3, 16, 16, 72), (2, 5, 7, 8), (4, 1, 1, 16)], ids=lambda c: "x".join(str(v) for v in c))
+def test_instance_norm_fused_with_resize(gpu_ctx, shape):
+    """ladder_in_style_fwd_resize2x = ladder_in_style_fwd + ladder_resize_bilinear_fwd (factor 2) bit for bit, with the record of the
+    normalised tensor's maximum (the interpolation is a convex combination)."""
+    L = _lib()
+    st = gpu_ctx.stream
+    N, H, W, C = shape
+    rng = np.random.default_rng(H * 31 + C)
+    x, style = dev(rng.standard_normal((N, H, W, C)) * 2 + 0.5), dev(rng.standard_normal((N, 2 * C)) * 0.3)
+    wsp, wsn = gpu_ctx.ws(L.query("ladder_in_style_workspace_bytes", N, H * W, C))
+    y, mr = torch.empty_like(x), torch.empty(N, 2 * C, device="cuda")
+    L.call("ladder_in_style_fwd", p(x), p(style), p(y), p(mr), N, H * W, C, 1e-6, 1, wsp, wsn, st)
+    up0 = torch.empty(N, 2 * H, 2 * W, C, device="cuda")
+    L.call("ladder_resize_bilinear_fwd", p(y), p(up0), N, H, W, C, 2 * H, 2 * W, st)
+    up, mr2, rec = torch.empty_like(up0), torch.empty_like(mr), torch.empty(L.ABSMAX_FLOATS, device="cuda")
+    L.call("ladder_in_style_fwd_resize2x", p(x), p(style), p(up), p(mr2), N, H, W, C, 1e-6, 1, wsp, wsn, p(rec), st)
+    assert torch.equal(up, up0) and torch.equal(mr2, mr)
+    assert rec.max().item() == y.abs().max().item()
+    assert L.query("ladder_in_style_fwd_resize2x", p(x), p(style), p(up), p(mr2), N, H, W, C, 1e-6, 1, None, 0, p(rec), st) != 0
