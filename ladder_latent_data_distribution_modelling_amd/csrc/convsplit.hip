@@ -141,7 +141,8 @@ constexpr int SP_AU = (SP_HALO_UNITS + SP_THREADS - 1) / SP_THREADS;   // 3
 
 // (two-plane formats: 128 registers and < 80 KB of LDS, so that TWO workgroups share a CU and one's staging / barrier phase hides behind
 // the other's MFMAs; the 9 taps are fully unrolled: fragment addresses become immediates, ~4 VALU instructions per tap are left)
-template <int PREC>
+// PROJ: transposed accumulators (lane = pixel) for the fused projection; otherwise lane = channel and whole-line stores (see the 16-wave kernel)
+template <int PREC, bool PROJ>
 __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x3_halo_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                                           const int N, const int H, const int W, const int Cin,
@@ -259,7 +260,9 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma16<F16>(b[ni][pb], a[mi][pa], acc[mi][ni]);   // D^T: lane = pixel, registers = channels
+            for (int ni = 0; ni < 2; ++ni)
+              acc[mi][ni] = PROJ ? mfma16<F16>(b[ni][pb], a[mi][pa], acc[mi][ni])       // D^T: lane = pixel, registers = channels
+                                 : mfma16<F16>(a[mi][pa], b[ni][pb], acc[mi][ni]);      // lane = channel, registers = pixels
         }
       if (tap == 4 && slab + 1 < nslabs) store_halo(hb ^ 1);
       if (!last) store_b(bbuf ^ 1);
@@ -268,6 +271,29 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
     }
   }
 
+  if (!PROJ) {
+    float ymax = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = n0 + wn * 64 + ni * 32 + l31;
+      const float bv = (bias != nullptr && n < Cout) ? bias[n] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        float* yp = y + (((long)img * H + h0 + 2 * wm + mi) * W + w0) * Cout + n;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int px = (e & 3) + 8 * (e >> 2) + 4 * lh;
+          float v = acc[mi][ni][e];
+          if (F16) v *= unscale;
+          v = ladder_act_fn(v + bv, act);
+          if (n < Cout) yp[(long)px * Cout] = v;
+          ymax = fmaxf(ymax, n < Cout ? fabsf(v) : 0.f);
+        }
+      }
+    }
+    if (yamax != nullptr) amax_commit_block(ymax, yamax);
+    return;
+  }
   // Transposed accumulators (the filter fragment is the MFMA's A operand): lane l31 = pixel of the patch row, register e -> channel
   // (e & 3) + 8 (e >> 2) + 4 lh of the 32-channel tile, i.e. four consecutive channels per register quad = one 16-byte store, and the
   // channel sum of the fused 1x1 projection below stays inside the lane.
@@ -936,9 +962,10 @@ static int conv3x3_split_launch(const float* x, const float* x_absmax, const voi
   const dim3 grid(tiles_m * tiles_n), block(SP_THREADS);
   const float* wamax = reinterpret_cast<const float*>(static_cast<const unsigned char*>(packed) + pack_payload_bytes(9, Cin, Cout, prec));
   if (y_absmax != nullptr && hipMemsetAsync(y_absmax, 0, LADDER_ABSMAX_FLOATS * sizeof(float), stream) != hipSuccess) return LADDER_E_LAUNCH;
-#define LADDER_SPLIT_LAUNCH(P_) \
-  hipLaunchKernelGGL(conv3x3_halo_split_kernel<P_>, grid, block, 0, stream, x, (const uint4*)packed, bias, y, N, H, W, Cin, Cout, act, tiles_n, x_absmax, wamax, y_absmax, \
+#define LADDER_SPLIT_LAUNCH_(P_, PROJ_) \
+  hipLaunchKernelGGL((conv3x3_halo_split_kernel<P_, PROJ_>), grid, block, 0, stream, x, (const uint4*)packed, bias, y, N, H, W, Cin, Cout, act, tiles_n, x_absmax, wamax, y_absmax, \
                      pw, pb, pout, pco)
+#define LADDER_SPLIT_LAUNCH(P_) do { if (pout != nullptr) LADDER_SPLIT_LAUNCH_(P_, true); else LADDER_SPLIT_LAUNCH_(P_, false); } while (0)
 #define LADDER_SPLIT16_LAUNCH(P_, PROJ_) \
   hipLaunchKernelGGL((conv3x3_halo_split16_kernel<P_, PROJ_>), dim3(N * (H / F_H) * (W / SP_W) * tiles_n), dim3(F_THREADS), 0, stream, x, (const uint4*)packed, bias, y, N, H, W, Cin, Cout, act, tiles_n, x_absmax, wamax, y_absmax, \
                      pw, pb, pout, pco)
@@ -952,6 +979,7 @@ static int conv3x3_split_launch(const float* x, const float* x_absmax, const voi
   else if (prec == LADDER_PREC_BF16X6) LADDER_SPLIT_LAUNCH(LADDER_PREC_BF16X6);
   else LADDER_SPLIT_LAUNCH(LADDER_PREC_BF16X3);
 #undef LADDER_SPLIT_LAUNCH
+#undef LADDER_SPLIT_LAUNCH_
 #undef LADDER_SPLIT16_LAUNCH
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
