@@ -461,3 +461,52 @@ def test_instance_norm_fused_with_resize(gpu_ctx, shape):
     assert torch.equal(up, up0) and torch.equal(mr2, mr)
     assert rec.max().item() == y.abs().max().item()
     assert L.query("ladder_in_style_fwd_resize2x", p(x), p(style), p(up), p(mr2), N, H, W, C, 1e-6, 1, None, 0, p(rec), st) != 0
+
+
+def test_full_size_power_of_two_homogeneity(gpu_ctx):
+    """Size-independent property at BASELINE's largest layer (dec.conv7: 128 x 128x128 x 128 -> 128 channels, the 16-wave kernel, both
+    accumulator layouts) and its filter gradient: the f16x3 format scales each operand tensor by a power of two derived from its
+    absolute maximum, so multiplying the input by 2^k must multiply the output by exactly 2^k -- bit for bit -- for k = -7 and +9."""
+    L = _lib()
+    st = gpu_ctx.stream
+    N, H, W, Ci, Co, P = 128, 128, 128, 128, 128, 4
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(N, H, W, Ci, device="cuda", generator=g)
+    w = torch.randn(3, 3, Ci, Co, device="cuda", generator=g) * 0.03
+    b = torch.zeros(Co, device="cuda")
+    pk = torch.empty(L.query("ladder_filter_pack_split_bytes", 9, Ci, Co, P), dtype=torch.uint8, device="cuda")
+    L.call("ladder_filter_pack_split", p(w), p(pk), 9, Ci, Co, 0, P, st)
+    pw, pb = torch.randn(Co, 3, device="cuda", generator=g) * 0.1, torch.zeros(3, device="cuda")
+
+    def fwd(xs):
+        xa = absmax(L, xs, st)
+        y, yp, out = torch.empty(N, H, W, Co, device="cuda"), torch.empty(N, H, W, Co, device="cuda"), torch.empty(N, H, W, 3, device="cuda")
+        L.call("ladder_conv3x3_split", p(xs), p(xa), p(pk), p(b), p(y), None, N, H, W, Ci, Co, 0, P, st)
+        L.call("ladder_conv3x3_split_proj", p(xs), p(xa), p(pk), p(b), p(yp), p(pw), p(pb), p(out), 3, N, H, W, Ci, Co, 0, P, st)
+        return y, yp, out
+
+    y0, yp0, out0 = fwd(x)
+    assert torch.equal(y0, yp0)                                       # lane = channel and lane = pixel layouts: the same sums
+    assert torch.isfinite(y0).all() and y0.abs().max().item() > 1.0
+    for k in (-7, 9):
+        f = 2.0 ** k
+        xs = x * f
+        y1, yp1, out1 = fwd(xs)
+        assert torch.equal(y1, y0 * f) and torch.equal(yp1, y0 * f) and torch.equal(out1, out0 * f), k
+        del xs, y1, yp1, out1
+    # filter gradient: scale dy by 2^k
+    dy = torch.randn(N, H, W, Co, device="cuda", generator=g) * 1e-3
+    wsp, wsn = gpu_ctx.ws(L.query("ladder_conv3x3_wgrad_split_workspace_bytes", N, H, W, Ci, Co))
+    xa = absmax(L, x, st)
+
+    def wgrad(d):
+        da = absmax(L, d, st)
+        dw, db = torch.empty_like(w), torch.empty(Co, device="cuda")
+        L.call("ladder_conv3x3_wgrad_split", p(x), p(xa), p(d), p(da), p(dw), p(db), N, H, W, Ci, Co, P, wsp, wsn, st)
+        return dw, db
+
+    dw0, db0 = wgrad(dy)
+    for k in (-7, 9):
+        f = 2.0 ** k
+        dw1, db1 = wgrad(dy * f)
+        assert torch.equal(dw1, dw0 * f) and torch.equal(db1, db0 * f), k
