@@ -207,11 +207,12 @@ int ladder_dense_bwd_weight_small(const float* x, const float* dy, float* dw, fl
 int ladder_conv_rgb_s2_eligible(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l);
 int ladder_conv_rgb_s2_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act,
                            ladder_stream_t stream);
-/* The forward call + the batch-norm statistics of its output in the same launch (per-patch column sums from the epilogue, reduced in a
- * fixed order): sums as ladder_bn_fwd_stats would produce them from a second pass over y. */
+/* The forward call + the batch-norm statistics of its output in the same launch (per-patch column statistics from the epilogue, reduced in
+ * a fixed order): sums4 as ladder_bn_fwd_stats_minmax would produce them from a second pass over y. */
 size_t ladder_conv_rgb_s2_fwd_bnstats_workspace_bytes(int N, int H, int W, int Cout);
 int ladder_conv_rgb_s2_fwd_bnstats(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act,
-                                   float* sums /*[2 Cout]*/, void* ws, size_t ws_bytes, ladder_stream_t stream);
+                                   float* sums4 /*[4 Cout]: sum | sum of squares | min | max*/, void* ws, size_t ws_bytes,
+                                   ladder_stream_t stream);
 /* dw [3,3,3,Cout], db [Cout] (may be NULL); x_absmax / dy_absmax = the tensors' absolute-maximum records (ladder_absmax or a producer's). */
 size_t ladder_conv_rgb_s2_bwd_filter_workspace_bytes(int N, int H, int W, int Cout);
 int ladder_conv_rgb_s2_bwd_filter(const float* x, const float* x_absmax, const float* dy, const float* dy_absmax, float* dw, float* db,
@@ -233,6 +234,16 @@ int ladder_bn_fwd_stats(const float* x, float* sums /*[2C]*/, size_t rows, int C
  * Writes mean_rstd[0:C]=mean, [C:2C]=rstd.  `count` = GLOBAL row count (after the all-reduce). */
 /* Second stage alone: sums from per-block partials [nblk][2][C] (what a convolution epilogue emits), fixed order, fp64. */
 int ladder_bn_stats_from_partials(const float* partials, int nblk, float* sums /*[2C]*/, int C, ladder_stream_t stream);
+/* Statistics with the per-channel extremes: sums4 [4C] = sum x | sum x^2 | min x | max x (the first 2C floats are what ladder_bn_fwd_stats
+ * writes; only they are summed across ranks).  Workspace: 2 x ladder_bn_workspace_bytes.  C % 4 == 0. */
+int ladder_bn_fwd_stats_minmax(const float* x, float* sums4, size_t rows, int C, void* ws, size_t ws_bytes, ladder_stream_t stream);
+int ladder_bn_stats_minmax_from_partials(const float* partials /*[nblk][4][C]*/, int nblk, float* sums4, int C, ladder_stream_t stream);
+/* ladder_bn_fwd_apply that writes y as the two fp16 PLANES the split gather kernels read (ladder_presplit layout for LADDER_PREC_F16X3) and
+ * the record of max|y| it scaled them with -- known in advance because y is monotone in x per channel, so max|y| sits at a channel's min or
+ * max.  y (fp32) is optional: NULL = never written (the consumer convolutions read only the planes).  rows*C % 8 == 0, C % 4 == 0. */
+int ladder_bn_fwd_apply_planes(const float* x, const float* sums4, double count, const float* gamma, const float* beta, float* y,
+                               void* y_planes, float* mean_rstd, size_t rows, int C, float eps, int act, float* y_absmax,
+                               ladder_stream_t stream);
 int ladder_bn_fwd_apply(const float* x, const float* sums, double count,
                         const float* gamma, const float* beta, float* y, float* mean_rstd,
                         size_t rows, int C, float eps, int act, ladder_stream_t stream);

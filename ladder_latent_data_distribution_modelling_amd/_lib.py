@@ -120,6 +120,9 @@ PROTOTYPES = {
     "ladder_conv_rgb_s2_fwd_bnstats_workspace_bytes": (_z, [_i] * 4),
     "ladder_conv_rgb_s2_fwd_bnstats": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _z, _p]),
     "ladder_bn_stats_from_partials": (_i, [_p, _i, _p, _i, _p]),
+    "ladder_bn_stats_minmax_from_partials": (_i, [_p, _i, _p, _i, _p]),
+    "ladder_bn_fwd_stats_minmax": (_i, [_p, _p, _z, _i, _p, _z, _p]),
+    "ladder_bn_fwd_apply_planes": (_i, [_p, _p, _d, _p, _p, _p, _p, _p, _z, _i, _f, _i, _p, _p]),
     "ladder_conv_rgb_s2_bwd_filter_workspace_bytes": (_z, [_i] * 4),
     "ladder_conv_rgb_s2_bwd_filter": (_i, [_p] * 6 + [_i] * 4 + [_p, _z, _p]),
     "ladder_bn_fwd_apply_absmax": (_i, [_p, _p, _d, _p, _p, _p, _p, _z, _i, _f, _i, _p, _p]),

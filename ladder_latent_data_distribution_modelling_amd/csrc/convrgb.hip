@@ -140,7 +140,8 @@ __global__ __launch_bounds__(RGB_THREADS, 4) void conv_rgb_s2_fwd_kernel(const f
   // lane = channel: every store instruction writes whole 128-byte lines (32 consecutive channels of one pixel per half-wave) -- the call
   // is bound by writing y, and 16-byte pieces of four different lines per lane (the transposed layout of the halo kernels) ran at 2 TB/s
   const float unscale = 1.f / (cx * cw);                             // exact: powers of two
-  float st0[2] = {0.f, 0.f}, st1[2] = {0.f, 0.f};                    // per-channel sum / sum of squares of what is written (batch-norm statistics)
+  float st0[2] = {0.f, 0.f}, st1[2] = {0.f, 0.f};                    // per-channel sum / sum of squares / extremes of what is written
+  float smn[2] = {INFINITY, INFINITY}, smx[2] = {-INFINITY, -INFINITY};   // (batch-norm statistics; the extremes give max|BN(y)| in advance)
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int n = n0 + wn * 64 + ni * 32 + l31;
@@ -155,27 +156,35 @@ __global__ __launch_bounds__(RGB_THREADS, 4) void conv_rgb_s2_fwd_kernel(const f
         if (n < Cout) yp[(long)px * Cout] = v;
         st0[ni] += v;
         st1[ni] += v * v;
+        smn[ni] = fminf(smn[ni], v);
+        smx[ni] = fmaxf(smx[ni], v);
       }
     }
   }
   if (stats_part != nullptr) {
     // lane = channel makes the column sums local: 32 pixels per lane, the other half-wave holds the other 32 of this wavefront's 64,
-    // the four wm wavefronts the rest of the patch; fixed order throughout.  partials[tile_m][2][Cout]
-    float* sred = reinterpret_cast<float*>(lds);                     // [which 2][wm 4][128 channels] (the plane images are dead)
+    // the four wm wavefronts the rest of the patch; fixed order throughout.  partials[tile_m][4][Cout] = sum | sum of squares | min | max
+    float* sred = reinterpret_cast<float*>(lds);                     // [which 4][wm 4][128 channels] (the plane images are dead)
     __syncthreads();
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const float a0 = st0[ni] + __shfl_xor(st0[ni], 32, 64), a1 = st1[ni] + __shfl_xor(st1[ni], 32, 64);
+      const float a2 = fminf(smn[ni], __shfl_xor(smn[ni], 32, 64)), a3 = fmaxf(smx[ni], __shfl_xor(smx[ni], 32, 64));
       if (lh == 0) {
-        sred[(0 * 4 + wm) * 128 + wn * 64 + ni * 32 + l31] = a0;
-        sred[(1 * 4 + wm) * 128 + wn * 64 + ni * 32 + l31] = a1;
+        const int cc = wn * 64 + ni * 32 + l31;
+        sred[(0 * 4 + wm) * 128 + cc] = a0;
+        sred[(1 * 4 + wm) * 128 + cc] = a1;
+        sred[(2 * 4 + wm) * 128 + cc] = a2;
+        sred[(3 * 4 + wm) * 128 + cc] = a3;
       }
     }
     __syncthreads();
-    if (tid < 256) {
-      const int which = tid >> 7, c = tid & 127;
-      const float t = (sred[(which * 4 + 0) * 128 + c] + sred[(which * 4 + 1) * 128 + c]) + (sred[(which * 4 + 2) * 128 + c] + sred[(which * 4 + 3) * 128 + c]);
-      if (n0 + c < Cout) stats_part[((size_t)mt * 2 + which) * Cout + n0 + c] = t;
+    {
+      const int which = tid >> 7, c = tid & 127;                    // 512 threads = 4 statistics x 128 channels
+      const float v0 = sred[(which * 4 + 0) * 128 + c], v1 = sred[(which * 4 + 1) * 128 + c], v2 = sred[(which * 4 + 2) * 128 + c],
+                  v3 = sred[(which * 4 + 3) * 128 + c];
+      const float t = which < 2 ? (v0 + v1) + (v2 + v3) : (which == 2 ? fminf(fminf(v0, v1), fminf(v2, v3)) : fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)));
+      if (n0 + c < Cout) stats_part[((size_t)mt * 4 + which) * Cout + n0 + c] = t;
     }
   }
 }
@@ -363,11 +372,11 @@ int ladder_conv_rgb_s2_fwd(const float* x, const float* w, const float* bias, fl
 
 size_t ladder_conv_rgb_s2_fwd_bnstats_workspace_bytes(int N, int H, int W, int Cout) {
   if (!rgb_s2_ok(N, H, W, 3, Cout, 3, 3, 2, 0, 0)) return 0;
-  return (size_t)N * (H / 2 / RGB_TH) * (W / 2 / RGB_TW) * 2 * Cout * sizeof(float);
+  return (size_t)N * (H / 2 / RGB_TH) * (W / 2 / RGB_TW) * 4 * Cout * sizeof(float);
 }
 
-// The forward call + the batch-norm statistics of its output (sums[0:Cout] = sum over all pixels of y, sums[Cout:2Cout] = sum of y^2:
-// what ladder_bn_fwd_stats would compute from a second pass over y), from per-patch column sums of the epilogue.
+// The forward call + the batch-norm statistics of its output (sums4 [4 Cout] = per-channel sum | sum of squares | min | max of y: what
+// ladder_bn_fwd_stats_minmax would compute from a second pass over y), from per-patch column statistics of the epilogue.
 int ladder_conv_rgb_s2_fwd_bnstats(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act,
                                    float* sums, void* ws, size_t ws_bytes, ladder_stream_t stream) {
   const size_t need = ladder_conv_rgb_s2_fwd_bnstats_workspace_bytes(N, H, W, Cout);
@@ -375,7 +384,7 @@ int ladder_conv_rgb_s2_fwd_bnstats(const float* x, const float* w, const float* 
   if (ws == nullptr || ws_bytes < need) return LADDER_E_WORKSPACE;
   const int rc = rgb_fwd_launch(x, w, bias, y, N, H, W, Cout, act, (float*)ws, stream);
   if (rc != LADDER_OK) return rc;
-  return ladder_bn_stats_from_partials((const float*)ws, N * (H / 2 / RGB_TH) * (W / 2 / RGB_TW), sums, Cout, stream);
+  return ladder_bn_stats_minmax_from_partials((const float*)ws, N * (H / 2 / RGB_TH) * (W / 2 / RGB_TW), sums, Cout, stream);
 }
 
 size_t ladder_conv_rgb_s2_bwd_filter_workspace_bytes(int N, int H, int W, int Cout) {

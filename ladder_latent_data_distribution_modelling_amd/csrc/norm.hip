@@ -2,7 +2,7 @@
 // all-reduce the 2C statistics), instance-norm + style modulation + leaky-ReLU, TF1-legacy bilinear
 // resize, depth-to-space, symmetric pad, activation backward.  All tensors NHWC fp32: the channel
 // axis is contiguous, so a wavefront always touches >=256 contiguous bytes per row.
-#include "common.h"
+#include "split16.h"
 
 namespace {
 
@@ -85,6 +85,65 @@ __global__ __launch_bounds__(256) void colstats_stage1_v4(const float* __restric
       t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
     }
     *reinterpret_cast<float4*>(ws + ((size_t)blockIdx.y * 2 + rl) * C + c) = t;
+  }
+}
+
+// MODE 1 plus the per-channel minimum and maximum (ws [nblk][4][C]: sum, sum of squares, min, max): the extremes let the batch-norm
+// apply know max|y| BEFORE it writes y (y is monotone in x per channel), i.e. it can emit fp16 planes directly (bn_apply_planes_kernel).
+__global__ __launch_bounds__(256) void colstats_minmax_stage1_v4(const float* __restrict__ a, float* __restrict__ ws, size_t rows, int C,
+                                                                 size_t rows_per_blk) {
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;       // 16 float4 channel groups x 16 row lanes
+  const int c = blockIdx.x * 64 + cq * 4;
+  const size_t r0 = (size_t)blockIdx.y * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  float4 mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY), mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  if (c < C) {
+    for (size_t r = r0 + rl; r < r1; r += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(a + r * C + c);
+      s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+      s1.x += v.x * v.x; s1.y += v.y * v.y; s1.z += v.z * v.z; s1.w += v.w * v.w;
+      mn.x = fminf(mn.x, v.x); mn.y = fminf(mn.y, v.y); mn.z = fminf(mn.z, v.z); mn.w = fminf(mn.w, v.w);
+      mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
+    }
+  }
+  __shared__ float4 sm[4][16][16];
+  sm[0][rl][cq] = s0;
+  sm[1][rl][cq] = s1;
+  sm[2][rl][cq] = mn;
+  sm[3][rl][cq] = mx;
+  __syncthreads();
+  if (rl < 4 && c < C) {        // rl = which statistic; fixed-order combination of the 16 row lanes
+    float4 t = sm[rl][0][cq];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      const float4 v = sm[rl][k][cq];
+      if (rl < 2) { t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+      else if (rl == 2) { t.x = fminf(t.x, v.x); t.y = fminf(t.y, v.y); t.z = fminf(t.z, v.z); t.w = fminf(t.w, v.w); }
+      else { t.x = fmaxf(t.x, v.x); t.y = fmaxf(t.y, v.y); t.z = fmaxf(t.z, v.z); t.w = fmaxf(t.w, v.w); }
+    }
+    *reinterpret_cast<float4*>(ws + ((size_t)blockIdx.y * 4 + rl) * C + c) = t;
+  }
+}
+
+// second stage for [nblk][4][C] partials: sums in fp64 (fixed order), extremes exactly; out [4C] = sum | sum of squares | min | max
+__global__ __launch_bounds__(256) void colstats_minmax_stage2(const float* __restrict__ ws, float* __restrict__ out, int nblk, int C) {
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + cl;   // over 4C
+  const int which = i < 4 * C ? i / C : 0, c = i < 4 * C ? i - which * C : 0;
+  double s = which == 2 ? (double)INFINITY : (which == 3 ? -(double)INFINITY : 0.0);
+  if (i < 4 * C)
+    for (int b = rl; b < nblk; b += 16) {
+      const double v = (double)ws[((size_t)b * 4 + which) * C + c];
+      s = which < 2 ? s + v : (which == 2 ? fmin(s, v) : fmax(s, v));
+    }
+  __shared__ double sm[16][17];
+  sm[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && i < 4 * C) {
+    double t = sm[0][cl];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t = which < 2 ? t + sm[k][cl] : (which == 2 ? fmin(t, sm[k][cl]) : fmax(t, sm[k][cl]));
+    out[i] = (float)t;
   }
 }
 
@@ -179,6 +238,66 @@ __global__ void bn_apply_scalar_kernel(const float* __restrict__ x, const float*
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int c = (int)(i % C);
     y[i] = ladder_act_fn(gamma[c] * ((x[i] - mean_rstd[c]) * mean_rstd[C + c]) + beta[c], act);
+  }
+}
+
+// ---- batch-norm apply that emits the fp16 PLANES of y (the operand images of the split gather kernels, ladder_presplit layout) ----------
+// max|y| must be known before y is split (the f16x3 scale); per channel y = act(gamma * xhat + beta) is monotone in x, so it is attained
+// at the channel's minimum or maximum: the finalize kernel evaluates those 2C values with the apply kernel's own expression and writes
+// the record.  One workgroup (C <= a few thousand channels).
+__global__ __launch_bounds__(256) void bn_finalize_minmax_kernel(const float* __restrict__ sums4, double count, float eps,
+                                                                 float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int C, int act, float* __restrict__ rec) {
+  float bmax = 0.f;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const double mean = (double)sums4[c] / count;
+    double var = (double)sums4[C + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float mu = (float)mean, rs = (float)(1.0 / sqrt(var + (double)eps));
+    mean_rstd[c] = mu;
+    mean_rstd[C + c] = rs;
+    const float g = gamma[c], be = beta[c];
+    const float ylo = ladder_act_fn(g * ((sums4[2 * C + c] - mu) * rs) + be, act), yhi = ladder_act_fn(g * ((sums4[3 * C + c] - mu) * rs) + be, act);
+    bmax = fmaxf(bmax, fmaxf(fabsf(ylo), fabsf(yhi)));
+  }
+  __shared__ float red[4];
+  bmax = wave_max(bmax);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bmax;
+  __syncthreads();
+  for (int i = threadIdx.x; i < AMAX_SLOTS * AMAX_STRIDE; i += blockDim.x) rec[i] = 0.f;
+  __syncthreads();
+  if (threadIdx.x == 0) rec[0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(256) void bn_apply_planes_kernel(const float* __restrict__ x, const float* __restrict__ mean_rstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ y, uint16_t* __restrict__ planes, size_t n, int C, int act,
+                                                              const float* __restrict__ rec) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool fixed = ((stride * 4) % (size_t)C) == 0;
+  const float cs = scale_from_absmax(amax_load(rec));
+  int c = (int)((i0 * 4) % C);
+  float4 mu = *reinterpret_cast<const float4*>(mean_rstd + c), rs = *reinterpret_cast<const float4*>(mean_rstd + C + c);
+  float4 g = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+  if (i0 == 0) *reinterpret_cast<uint4*>(planes + 2 * n) = make_uint4(0u, 0u, 0u, 0u);      // the zero pad behind the last plane
+  for (size_t i = i0; i < n / 4; i += stride) {
+    if (!fixed) {
+      c = (int)((i * 4) % C);
+      mu = *reinterpret_cast<const float4*>(mean_rstd + c); rs = *reinterpret_cast<const float4*>(mean_rstd + C + c);
+      g = *reinterpret_cast<const float4*>(gamma + c); be = *reinterpret_cast<const float4*>(beta + c);
+    }
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    float4 o;
+    o.x = ladder_act_fn(g.x * ((v.x - mu.x) * rs.x) + be.x, act);
+    o.y = ladder_act_fn(g.y * ((v.y - mu.y) * rs.y) + be.y, act);
+    o.z = ladder_act_fn(g.z * ((v.z - mu.z) * rs.z) + be.z, act);
+    o.w = ladder_act_fn(g.w * ((v.w - mu.w) * rs.w) + be.w, act);
+    if (y != nullptr) reinterpret_cast<float4*>(y)[i] = o;
+    uint2 pl[2];
+    split4<2, true>(make_float4(o.x * cs, o.y * cs, o.z * cs, o.w * cs), pl);
+    reinterpret_cast<uint2*>(planes)[i] = pl[0];
+    reinterpret_cast<uint2*>(planes + n)[i] = pl[1];
   }
 }
 
@@ -840,6 +959,42 @@ int ladder_bn_fwd_apply_absmax(const float* x, const float* sums, double count, 
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, stream, x, mean_rstd, gamma, beta, y, n, C, act, y_absmax);
   else
     hipLaunchKernelGGL(bn_apply_scalar_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, x, mean_rstd, gamma, beta, y, n, C, act);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+// sums4 [4C] = sum x | sum x^2 | min x | max x over the rows (per channel); workspace: 2 x ladder_bn_workspace_bytes
+int ladder_bn_fwd_stats_minmax(const float* x, float* sums4, size_t rows, int C, void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  if (rows == 0 || C <= 0 || (C % 4) != 0) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(x)) return LADDER_E_ALIGN;
+  const size_t nblk = stats_nblk(rows);
+  if (ws_bytes < nblk * 4 * (size_t)C * sizeof(float)) return LADDER_E_WORKSPACE;
+  const size_t rpb = (rows + nblk - 1) / nblk;
+  hipLaunchKernelGGL(colstats_minmax_stage1_v4, dim3((C + 63) / 64, (unsigned)nblk), dim3(256), 0, stream, x, (float*)ws, rows, C, rpb);
+  hipLaunchKernelGGL(colstats_minmax_stage2, dim3((4 * C + 15) / 16), dim3(256), 0, stream, (const float*)ws, sums4, (int)nblk, C);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+// the second stage alone, for [nblk][4][C] partials emitted by a convolution epilogue
+int ladder_bn_stats_minmax_from_partials(const float* partials, int nblk, float* sums4, int C, ladder_stream_t stream) {
+  if (nblk <= 0 || C <= 0) return LADDER_E_SHAPE;
+  hipLaunchKernelGGL(colstats_minmax_stage2, dim3((4 * C + 15) / 16), dim3(256), 0, stream, partials, sums4, nblk, C);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+// Apply that writes the two fp16 planes of y (ladder_presplit layout for LADDER_PREC_F16X3: plane-major, 16 zero bytes behind) and the
+// record of max|y| it scaled them with; the fp32 tensor itself is optional (y == NULL: never written).
+int ladder_bn_fwd_apply_planes(const float* x, const float* sums4, double count, const float* gamma, const float* beta, float* y, void* y_planes,
+                               float* mean_rstd, size_t rows, int C, float eps, int act, float* y_absmax, ladder_stream_t stream) {
+  if (rows == 0 || C <= 0 || count <= 0 || (C % 4) != 0 || y_planes == nullptr || y_absmax == nullptr) return LADDER_E_SHAPE;
+  const size_t n = rows * (size_t)C;
+  if ((n % 8) != 0) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(x) || !ladder_aligned16(y_planes) || (y != nullptr && !ladder_aligned16(y))) return LADDER_E_ALIGN;
+  hipLaunchKernelGGL(bn_finalize_minmax_kernel, dim3(1), dim3(256), 0, stream, sums4, count, eps, mean_rstd, gamma, beta, C, act, y_absmax);
+  hipLaunchKernelGGL(bn_apply_planes_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, stream, x, (const float*)mean_rstd, gamma, beta, y,
+                     (uint16_t*)y_planes, n, C, act, (const float*)y_absmax);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

@@ -150,6 +150,23 @@ class _NoComm:
         return t
 
 
+class PlanesOnly:
+    """Stand-in for an activation that exists ONLY as its fp16 plane images (registered with Ctx.set_planes / set_amax): the batch-norm
+    apply of an encoder layer whose consumer is a split gather convolution never writes the fp32 tensor.  Any fp32 use raises."""
+
+    def __init__(self, shape):
+        self.shape = torch.Size(shape)
+
+    def numel(self):
+        n = 1
+        for d in self.shape:
+            n *= int(d)
+        return n
+
+    def data_ptr(self):
+        raise RuntimeError("this activation exists only as fp16 planes (PlanesOnly): an fp32 kernel was routed to it")
+
+
 class Ctx:
     """Device context shared by all layers: stream handle, grow-only workspace, communicator."""
 
@@ -215,6 +232,12 @@ class Ctx:
             L.call("ladder_absmax", _p(t), t.numel(), _p(rec), self.stream)
             self.set_amax(t, rec)
         return rec
+
+    def set_planes(self, t, buf):
+        """Registers plane images a producer wrote for `t` itself (ladder_bn_fwd_apply_planes)."""
+        import weakref
+        k, reg = id(t), self._planes
+        reg[k] = (weakref.ref(t, lambda _r, k=k, reg=reg: reg.pop(k, None)), buf)
 
     def planes(self, t):
         """Pre-split 16-bit planes of `t` (ladder_presplit) for the gather kernels, cached per tensor object like the absmax records:
@@ -352,6 +375,20 @@ class Conv2D:
         return bool(self.ctx.ns == 4 and self.cin == 3 and L.query("ladder_conv_rgb_s2_eligible", N, H, W, self.cin, self.cout, self.k, self.k,
                                                                self.stride, self.pt, self.pl))
 
+    def planes_demand(self, in_shape):
+        """(wants_planes, needs_fp32) for an input of `in_shape`: whether this layer's forward reads the fp16 plane images of its input
+        (split gather kernel) and whether anything of it still needs the fp32 tensor (a filter gradient outside the split kernel)."""
+        ctx = self.ctx
+        N, H, W, _ = in_shape
+        if ctx.ns != 4 or self.cin == 3 or self._split_ok(N, H, W, self.cin, self.cout):
+            return False, True
+        pt, Ho = arch.conv_out(H, self.k, self.stride, self.padding)
+        pl, Wo = arch.conv_out(W, self.k, self.stride, self.padding)
+        geo = (N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride, pt, pl)
+        if self._as_dense(N * H * W) or not L.query("ladder_conv2d_fwd_split_eligible", *geo):
+            return False, True
+        return True, bool(ctx.keep_activations and not L.query("ladder_conv2d_bwd_filter_split_eligible", *geo))
+
     def _packed_filter(self, transpose_flip):
         """Split bf16 planes of the filter bank in the kernel's LDS layout, re-packed when the weights changed (always while a
         hipGraph is being captured, so that a replay re-packs the then-current weights)."""
@@ -414,7 +451,7 @@ class Conv2D:
         if self._rgb(N, H, W):                           # the image-side encoder conv (3 -> Cout channels, stride 2): csrc/convrgb.hip
             if self.want_bn_sums and self.act is None:
                 wsp, wsn = self.ctx.ws(L.query("ladder_conv_rgb_s2_fwd_bnstats_workspace_bytes", N, H, W, self.cout))
-                self.bn_sums = self.ctx.empty(2 * self.cout)
+                self.bn_sums = self.ctx.empty(4 * self.cout)       # sum | sum of squares | min | max per channel
                 L.call("ladder_conv_rgb_s2_fwd_bnstats", _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y),
                        N, H, W, self.cout, 0, _p(self.bn_sums), wsp, wsn, self.ctx.stream)
             else:
@@ -615,22 +652,45 @@ class BatchNormAct:
     def __init__(self, ctx, ps, name, C, act):
         self.ctx, self.ps, self.name, self.C, self.act = ctx, ps, name, C, act
 
-    def forward(self, x, sums=None):
-        """`sums`: the [2C] statistics of x when its producer already computed them (conv epilogue), else a pass over x."""
+    def forward(self, x, sums=None, planes=(False, True)):
+        """`sums`: the statistics of x when its producer already computed them (conv epilogue: [4C] = sum | sum of squares | min | max),
+        else a pass over x.  `planes` = (emit the fp16 plane images of y, also keep y in fp32): with the per-channel extremes max|y| is
+        known before y is written, so the apply kernel can split it on the fly -- and when nothing needs the fp32 tensor it is never
+        written (returns a PlanesOnly stand-in)."""
         C, ctx = self.C, self.ctx
         rows = x.numel() // C
+        want_planes, need_fp32 = planes
+        want_planes = bool(want_planes and ctx.ns == 4 and C % 4 == 0 and x.numel() % 8 == 0)
         if sums is None:
             nb = L.query("ladder_bn_workspace_bytes", rows, C)
-            wsp, wsn = ctx.ws(nb)
-            sums = ctx.empty(2 * C)
-            L.call("ladder_bn_fwd_stats", _p(x), _p(sums), rows, C, wsp, wsn, ctx.stream)
-        ctx.comm.allreduce_(sums)
+            if want_planes:
+                wsp, wsn = ctx.ws(2 * nb)
+                sums = ctx.empty(4 * C)
+                L.call("ladder_bn_fwd_stats_minmax", _p(x), _p(sums), rows, C, wsp, wsn, ctx.stream)
+            else:
+                wsp, wsn = ctx.ws(nb)
+                sums = ctx.empty(2 * C)
+                L.call("ladder_bn_fwd_stats", _p(x), _p(sums), rows, C, wsp, wsn, ctx.stream)
+        want_planes = want_planes and sums.numel() == 4 * C
+        ctx.comm.allreduce_(sums[:2 * C])                       # (the extremes stay local: they bound THIS rank's tensor)
         self.count = float(rows) * ctx.comm.world
-        y = torch.empty_like(x)
         self.mean_rstd = ctx.empty(2 * C)
+        gam, bet = self.ps.w[self.name + "/gamma"], self.ps.w[self.name + "/beta"]
+        if want_planes:
+            y = torch.empty_like(x) if need_fp32 else None
+            out = y if need_fp32 else PlanesOnly(x.shape)
+            buf = torch.empty(L.query("ladder_presplit_bytes", x.numel(), ctx.ns), dtype=torch.uint8, device=ctx.device)
+            y_amax = ctx.new_amax()
+            L.call("ladder_bn_fwd_apply_planes", _p(x), _p(sums), self.count, _p(gam), _p(bet), _p(y), _p(buf), _p(self.mean_rstd), rows, C,
+                   BN_EPS, L.ACT[self.act], _p(y_amax), ctx.stream)
+            ctx.set_amax(out, y_amax)
+            ctx.set_planes(out, buf)
+            self.x = x
+            return out
+        y = torch.empty_like(x)
         y_amax = ctx.new_amax() if (ctx.ns == 4 and C % 4 == 0) else None
-        L.call("ladder_bn_fwd_apply_absmax", _p(x), _p(sums), self.count, _p(self.ps.w[self.name + "/gamma"]),
-               _p(self.ps.w[self.name + "/beta"]), _p(y), _p(self.mean_rstd), rows, C, BN_EPS, L.ACT[self.act], _p(y_amax), ctx.stream)
+        L.call("ladder_bn_fwd_apply_absmax", _p(x), _p(sums), self.count, _p(gam), _p(bet), _p(y), _p(self.mean_rstd), rows, C, BN_EPS,
+               L.ACT[self.act], _p(y_amax), ctx.stream)
         ctx.set_amax(y, y_amax)
         self.x = x
         return y
@@ -788,11 +848,12 @@ class Encoder:
 
     def forward(self, x):
         h = pad_symmetric(self.ctx, x, 2) if self.exp != "celeba" else x
-        for conv, bn in zip(self.convs, self.bns):
+        for i, (conv, bn) in enumerate(zip(self.convs, self.bns)):
             conv.want_bn_sums = bn is not None                  # a conv that can emit the statistics of its output does (conv.bn_sums)
             h = conv.forward(h)
             if bn is not None:
-                h = bn.forward(h, sums=conv.bn_sums)
+                nxt = self.convs[i + 1] if i + 1 < len(self.convs) else None
+                h = bn.forward(h, sums=conv.bn_sums, planes=nxt.planes_demand(h.shape) if nxt is not None else (False, True))
             conv.bn_sums = None
         self.conv_shape = h.shape
         h = h.reshape(h.shape[0], -1)

@@ -411,16 +411,18 @@ def test_conv_rgb_stride2(gpu_ctx, case):
     y = torch.empty(N, Ho, Wo, Cout, device="cuda")
     L.call("ladder_conv_rgb_s2_fwd", p(xd), p(wd), p(bd), p(y), N, H, W, Cout, L.ACT[act], st)
     close(y, yr, 2e-5, "fwd")
-    # the same call emitting the batch-norm statistics of its output: identical y, sums as the two-pass kernels compute them
+    # the same call emitting the batch-norm statistics of its output (sum | sum of squares | min | max per channel): identical y
     wsp, wsn = gpu_ctx.ws(L.query("ladder_conv_rgb_s2_fwd_bnstats_workspace_bytes", N, H, W, Cout))
-    y2, sums, sums0 = torch.empty_like(y), torch.empty(2 * Cout, device="cuda"), torch.empty(2 * Cout, device="cuda")
+    y2, sums, sums0 = torch.empty_like(y), torch.empty(4 * Cout, device="cuda"), torch.empty(2 * Cout, device="cuda")
     L.call("ladder_conv_rgb_s2_fwd_bnstats", p(xd), p(wd), p(bd), p(y2), N, H, W, Cout, L.ACT[act], p(sums), wsp, wsn, st)
     assert torch.equal(y2, y)
     wsp2, wsn2 = gpu_ctx.ws(L.query("ladder_bn_workspace_bytes", N * Ho * Wo, Cout))
     L.call("ladder_bn_fwd_stats", p(y), p(sums0), N * Ho * Wo, Cout, wsp2, wsn2, st)
     y64 = y.double().reshape(-1, Cout)
     ref = torch.cat([y64.sum(0), (y64 * y64).sum(0)])
-    assert ((sums.double() - ref).abs() <= 2e-6 * ref.abs().max()).all() and ((sums0.double() - ref).abs() <= 2e-6 * ref.abs().max()).all()
+    assert ((sums[:2 * Cout].double() - ref).abs() <= 2e-6 * ref.abs().max()).all() and ((sums0.double() - ref).abs() <= 2e-6 * ref.abs().max()).all()
+    yf = y.reshape(-1, Cout)
+    assert torch.equal(sums[2 * Cout:3 * Cout], yf.min(0).values) and torch.equal(sums[3 * Cout:], yf.max(0).values)
     dy = (rng.standard_normal(tuple(yr.shape)) * 1e-3).astype(np.float32)
     dy[0, 0, 0, :] *= 50.0
     yr.backward(torch.tensor(dy, dtype=torch.float64))
@@ -510,3 +512,39 @@ def test_full_size_power_of_two_homogeneity(gpu_ctx):
         f = 2.0 ** k
         dw1, db1 = wgrad(dy * f)
         assert torch.equal(dw1, dw0 * f) and torch.equal(db1, db0 * f), k
+
+
+@pytest.mark.parametrize("rows,C", [(128 * 70 * 70, 32), (4096, 256), (1000, 12)])
+def test_bn_apply_emits_planes(gpu_ctx, rows, C):
+    """ladder_bn_fwd_stats_minmax + ladder_bn_fwd_apply_planes: the statistics with the per-channel extremes, the record of max|y| derived
+    from them BEFORE y is written, and y as fp16 planes -- bit-identical to ladder_presplit of the fp32 y with the same record; the fp32
+    tensor itself optional."""
+    L = _lib()
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(rows % 97 + C)
+    x = dev(rng.standard_normal((rows, C)) * 3 + rng.standard_normal(C) * 2)
+    x[rng.integers(0, rows, 5), rng.integers(0, C, 5)] *= 40.0                     # heavy tail: the extremes matter
+    gam, bet = dev(rng.standard_normal(C)), dev(rng.standard_normal(C))              # negative gammas: max|y| at the channel MINIMUM
+    wsp, wsn = gpu_ctx.ws(2 * L.query("ladder_bn_workspace_bytes", rows, C))
+    s4, s2 = torch.empty(4 * C, device="cuda"), torch.empty(2 * C, device="cuda")
+    L.call("ladder_bn_fwd_stats_minmax", p(x), p(s4), rows, C, wsp, wsn, st)
+    L.call("ladder_bn_fwd_stats", p(x), p(s2), rows, C, wsp, wsn, st)
+    x64 = x.double()
+    assert ((s4[:2 * C].double() - torch.cat([x64.sum(0), (x64 * x64).sum(0)])).abs() <= 2e-6 * (x64 * x64).sum(0).max()).all()
+    assert torch.allclose(s4[:2 * C], s2, rtol=2e-6, atol=0) or ((s4[:2 * C] - s2).abs() <= 2e-6 * s2.abs().max()).all()
+    assert torch.equal(s4[2 * C:3 * C], x.min(0).values) and torch.equal(s4[3 * C:], x.max(0).values)
+    for act in (1, 0):
+        y0, mr0 = torch.empty_like(x), torch.empty(2 * C, device="cuda")
+        L.call("ladder_bn_fwd_apply", p(x), p(s4), float(rows), p(gam), p(bet), p(y0), p(mr0), rows, C, 1e-3, act, st)
+        n = rows * C
+        planes = torch.empty(L.query("ladder_presplit_bytes", n, 4), dtype=torch.uint8, device="cuda")
+        y, mr, rec = torch.empty_like(x), torch.empty(2 * C, device="cuda"), torch.empty(L.ABSMAX_FLOATS, device="cuda")
+        L.call("ladder_bn_fwd_apply_planes", p(x), p(s4), float(rows), p(gam), p(bet), p(y), p(planes), p(mr), rows, C, 1e-3, act, p(rec), st)
+        assert torch.equal(y, y0) and torch.equal(mr, mr0)
+        assert rec.max().item() == y0.abs().max().item()                              # the exact maximum, known before y was written
+        ref = presplit(L, y0, rec, 4, st)
+        assert torch.equal(planes, ref)
+        planes2 = torch.zeros_like(planes)
+        L.call("ladder_bn_fwd_apply_planes", p(x), p(s4), float(rows), p(gam), p(bet), None, p(planes2), p(mr), rows, C, 1e-3, act, p(rec), st)
+        assert torch.equal(planes2, ref)                                              # fp32 y never written
+    assert L.query("ladder_bn_fwd_apply_planes", p(x), p(s4), float(rows), p(gam), p(bet), None, None, p(mr), rows, C, 1e-3, 1, p(rec), st) != 0
