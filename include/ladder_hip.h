@@ -294,6 +294,10 @@ int ladder_in_style_fwd_resize2x(const float* x, const float* style, float* up, 
  * OH/H and OW/W must be integers (1->2, 2->8, 8->16, ... in the reference). */
 int ladder_resize_bilinear_fwd(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, ladder_stream_t stream);
 int ladder_resize_bilinear_bwd(const float* dy, float* dx, int N, int H, int W, int C, int OH, int OW, ladder_stream_t stream);
+/* The factor-2 transpose with the activation backward of the producing layer fused in: dx *= act'(gate_y), gate_y = that layer's output
+ * [N,H,W,C] (codes/models.py:538-545, 561-568: leaky conv -> resize). */
+int ladder_resize_bilinear_bwd_gated(const float* dy, float* dx, int N, int H, int W, int C, int OH, int OW, const float* gate_y,
+                                     int gate_act, ladder_stream_t stream);
 
 /* ---------------------------------------------------------------- N7: depth_to_space (DCR) / tf.pad SYMMETRIC
  * codes/models.py:48-50,113,122,131,140,200-202,271,...,307.  inverse!=0 gives space_to_depth (the backward). */

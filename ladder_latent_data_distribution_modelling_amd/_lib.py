@@ -63,6 +63,7 @@ PROTOTYPES = {
     "ladder_in_style_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
     "ladder_resize_bilinear_fwd": (_i, [_p, _p] + [_i] * 6 + [_p]),
     "ladder_resize_bilinear_bwd": (_i, [_p, _p] + [_i] * 6 + [_p]),
+    "ladder_resize_bilinear_bwd_gated": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
     "ladder_depth_to_space": (_i, [_p, _p] + [_i] * 6 + [_p]),
     "ladder_pad_symmetric": (_i, [_p, _p] + [_i] * 5 + [_p]),
     "ladder_randn": (_i, [_p, _z, _u64, _u64, _p]),

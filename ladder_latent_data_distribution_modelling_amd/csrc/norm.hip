@@ -647,6 +647,11 @@ __device__ __forceinline__ void rz_fma(float4& acc, float w, const float4& q) {
 __device__ __forceinline__ void rz_fma(float& acc, float w, float q) { acc += w * q; }
 __device__ __forceinline__ void rz_zero(float4& a) { a = make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ void rz_zero(float& a) { a = 0.f; }
+__device__ __forceinline__ void rz_gate(float4& a, const float4& y, int act) {
+  a.x *= ladder_act_grad_from_out(y.x, act); a.y *= ladder_act_grad_from_out(y.y, act);
+  a.z *= ladder_act_grad_from_out(y.z, act); a.w *= ladder_act_grad_from_out(y.w, act);
+}
+__device__ __forceinline__ void rz_gate(float& a, float y, int act) { a *= ladder_act_grad_from_out(y, act); }
 
 template <int V>
 __global__ __launch_bounds__(256) void resize_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int CV,
@@ -758,7 +763,7 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict
 // the sum runs in the same (oy, ox) order.
 template <int V>
 __global__ __launch_bounds__(256) void resize_bwd_x2_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int CV,
-                                                            int bpr) {
+                                                            int bpr, const float* __restrict__ gate_y, int gate_act) {
   using T = typename ResizeVec<V>::T;
   const int row = blockIdx.x / bpr;
   const int j = (blockIdx.x - row * bpr) * blockDim.x + threadIdx.x;
@@ -784,7 +789,9 @@ __global__ __launch_bounds__(256) void resize_bwd_x2_kernel(const float* __restr
 #pragma unroll
     for (int b = 0; b < 3; ++b)
       if (wy[a] != 0.f && wx[b] != 0.f) rz_fma(acc, wy[a] * wx[b], v[a][b]);
-  reinterpret_cast<T*>(dx)[((size_t)row * W + ix) * CV + cv] = acc;
+  const size_t o = ((size_t)row * W + ix) * CV + cv;
+  if (gate_y != nullptr) rz_gate(acc, reinterpret_cast<const T*>(gate_y)[o], gate_act);   // the producer's activation backward, fused
+  reinterpret_cast<T*>(dx)[o] = acc;
 }
 
 // ----------------------------------------------------------------------------- minibatch assembly from an HBM-resident data set
@@ -1125,9 +1132,11 @@ int ladder_in_style_bwd_absmax(const float* dy, const float* x, const float* sty
   return LADDER_OK;
 }
 
-static int resize_launch(bool fwd, const float* a, float* b, int N, int H, int W, int C, int OH, int OW, hipStream_t stream) {
+static int resize_launch(bool fwd, const float* a, float* b, int N, int H, int W, int C, int OH, int OW, hipStream_t stream,
+                         const float* gate_y = nullptr, int gate_act = 0) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH < H || OW < W || OH % H || OW % W) return LADDER_E_SHAPE;
-  const bool v4 = (C % 4 == 0) && ladder_aligned16(a) && ladder_aligned16(b);
+  if (gate_y != nullptr && (fwd || OH != 2 * H || OW != 2 * W)) return LADDER_E_SHAPE;      // the fused gate exists for the factor-2 transpose
+  const bool v4 = (C % 4 == 0) && ladder_aligned16(a) && ladder_aligned16(b) && (gate_y == nullptr || ladder_aligned16(gate_y));
   const int CV = v4 ? C / 4 : C;
   const long bprl = ((long)W * CV + 255) / 256;
   if (bprl * N * H >= (1L << 31)) return LADDER_E_SHAPE;
@@ -1139,8 +1148,8 @@ static int resize_launch(bool fwd, const float* a, float* b, int N, int H, int W
     else hipLaunchKernelGGL(resize_fwd_kernel<1>, grid, block, 0, stream, a, b, H, W, CV, fy, fx, bpr);
   } else {
     if (fy == 2 && fx == 2) {
-      if (v4) hipLaunchKernelGGL(resize_bwd_x2_kernel<4>, grid, block, 0, stream, a, b, H, W, CV, bpr);
-      else hipLaunchKernelGGL(resize_bwd_x2_kernel<1>, grid, block, 0, stream, a, b, H, W, CV, bpr);
+      if (v4) hipLaunchKernelGGL(resize_bwd_x2_kernel<4>, grid, block, 0, stream, a, b, H, W, CV, bpr, gate_y, gate_act);
+      else hipLaunchKernelGGL(resize_bwd_x2_kernel<1>, grid, block, 0, stream, a, b, H, W, CV, bpr, gate_y, gate_act);
     } else if (v4) hipLaunchKernelGGL(resize_bwd_kernel<4>, grid, block, 0, stream, a, b, H, W, CV, fy, fx, bpr);
     else hipLaunchKernelGGL(resize_bwd_kernel<1>, grid, block, 0, stream, a, b, H, W, CV, fy, fx, bpr);
   }
@@ -1154,6 +1163,14 @@ int ladder_resize_bilinear_fwd(const float* x, float* y, int N, int H, int W, in
 
 int ladder_resize_bilinear_bwd(const float* dy, float* dx, int N, int H, int W, int C, int OH, int OW, ladder_stream_t stream) {
   return resize_launch(false, dy, dx, N, H, W, C, OH, OW, stream);
+}
+
+// factor-2 transpose with the activation backward of the layer that produced the resized tensor fused in: dx *= act'(gate_y), gate_y = that
+// layer's OUTPUT [N,H,W,C] (saves the separate read-modify-write pass of ladder_act_bwd)
+int ladder_resize_bilinear_bwd_gated(const float* dy, float* dx, int N, int H, int W, int C, int OH, int OW, const float* gate_y, int gate_act,
+                                     ladder_stream_t stream) {
+  if (gate_y == nullptr) return LADDER_E_SHAPE;
+  return resize_launch(false, dy, dx, N, H, W, C, OH, OW, stream, gate_y, gate_act);
 }
 
 int ladder_gather_rows(const void* src, int src_is_u8, const int64_t* idx, float* out, int B, int64_t D, float scale,

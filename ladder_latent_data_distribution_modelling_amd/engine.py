@@ -786,16 +786,22 @@ class Resize:
         self.ctx.set_amax(y, self.ctx.known_amax(x))        # bilinear interpolation is a convex combination: max|y| <= max|x|
         return y
 
-    def backward(self, dy):
+    def backward(self, dy, gate=None):
+        """`gate` = (y, act) of the layer that produced the resized tensor: its activation backward is applied to dx in the same pass
+        (factor-2 resizes; returns (dx, True) then, so that the caller skips that layer's own activation backward)."""
         N, H, W, C = self.in_shape
         if (H, W) == (self.oh, self.ow):
-            return dy
+            return (dy, False) if gate is not None else dy
         dx = self.ctx.empty(N, H, W, C)
+        if gate is not None and (self.oh, self.ow) == (2 * H, 2 * W) and gate[1] is not None:
+            L.call("ladder_resize_bilinear_bwd_gated", _p(dy), _p(dx), N, H, W, C, self.oh, self.ow, _p(gate[0]), L.ACT[gate[1]],
+                   self.ctx.stream)
+            return dx, True                                     # (no absmax record: the gate rescales elements)
         L.call("ladder_resize_bilinear_bwd", _p(dy), _p(dx), N, H, W, C, self.oh, self.ow, self.ctx.stream)
         rec = self.ctx.known_amax(dy)
         if rec is not None:      # the transpose sums interpolation weights: every column sum is <= (oh/H) * (ow/W)
             self.ctx.set_amax(dx, rec * float((self.oh // H) * (self.ow // W)))
-        return dx
+        return (dx, False) if gate is not None else dx
 
 
 class DepthToSpace:
@@ -972,13 +978,17 @@ class CelebADecoder:
         dh = self.conv_out.backward(dxhat, gate_prev=last_conv.act if fuse_last else None)
         ddlat = None
         for bi, (conv, sty, norm, rs) in enumerate(reversed(self.blocks)):
+            gated = False
             if rs is not None:
-                dh = rs.backward(dh)
+                if norm is None and conv.act is not None and not (bi == 0 and fuse_last):
+                    dh, gated = rs.backward(dh, gate=(conv.y, conv.act))   # leaky conv -> resize: its activation backward rides on the transpose
+                else:
+                    dh = rs.backward(dh)
             if norm is not None:
                 dh, dstyle = norm.backward(dh)
                 g = sty.backward(dstyle)
                 ddlat = g if ddlat is None else add_(ctx, ddlat, g)
-            dh = conv.backward(dh, act_done=(bi == 0 and fuse_last))
+            dh = conv.backward(dh, act_done=(bi == 0 and fuse_last) or gated)
         dh = self.conv0.backward(self.up0.backward(dh))
         denc = dh.reshape(dh.shape[0], self.nh)
         # mapping MLP: each layer's backward-data epilogue applies the previous layer's leaky-ReLU derivative

@@ -246,6 +246,13 @@ def test_resize_legacy_bilinear(gpu_ctx, shape, out):
     L.call("ladder_resize_bilinear_bwd", p(dyd), p(dx), N, H, W, C, out, out, st)
     close(y, yr, 1e-6, "y")
     close(dx, xt.grad, 1e-6, "dx")
+    if out == 2 * H:                       # the gated form: dx * leaky'(gate) in the same pass, bit-identical to the two separate kernels
+        gate = dev(rng.standard_normal(shape).astype(np.float32))
+        dxg = torch.empty_like(xd)
+        L.call("ladder_resize_bilinear_bwd_gated", p(dyd), p(dxg), N, H, W, C, out, out, p(gate), 1, st)
+        assert torch.equal(dxg, dx * torch.where(gate > 0, 1.0, 0.2))
+    else:
+        assert L.query("ladder_resize_bilinear_bwd_gated", p(dyd), p(dx), N, H, W, C, out, out, p(xd), 1, st) != 0
 
 
 def test_depth_to_space_and_pad(gpu_ctx):
