@@ -118,6 +118,20 @@ int ladder_absmax(const float* x, size_t n, float* out, ladder_stream_t stream);
 size_t ladder_filter_pack_split_bytes(int ntaps, int Cin, int Cout, int prec);
 int ladder_filter_pack_split(const float* w, void* packed, int ntaps, int Cin, int Cout, int transpose_flip, int prec,
                              ladder_stream_t stream);
+/* All filter banks of a model in TWO launches (after an optimiser step: forward orientation and the flipped / transposed one of every
+ * convolution; the per-bank call above is memset + absmax + pack = three launches each).  `jobs_dev` = job table in DEVICE memory, sorted
+ * by block_begin (block_begin = running sum of ladder_filter_pack_job_blocks over the preceding jobs, total_blocks = the sum over all);
+ * every job's `packed` buffer has ladder_filter_pack_split_bytes bytes.  Scratch: ladder_filter_pack_split_multi_scratch_bytes(njobs). */
+typedef struct ladder_pack_job_t {
+  const float* w; /* HWIO fp32 bank */
+  void* packed;   /* destination image (+ absmax record behind the payload) */
+  int ntaps, Cin, Cout, transpose_flip;
+  int block_begin, reserved;
+} ladder_pack_job_t;
+int ladder_filter_pack_job_blocks(int ntaps, int Cin, int Cout);
+size_t ladder_filter_pack_split_multi_scratch_bytes(int njobs);
+int ladder_filter_pack_split_multi(const ladder_pack_job_t* jobs_dev, int njobs, int total_blocks, int prec, void* scratch,
+                                   size_t scratch_bytes, ladder_stream_t stream);
 int ladder_conv3x3_split_eligible(int N, int H, int W, int Cin, int Cout);
 /* y = act(conv3x3_same(x, F) + bias) with F as packed above (bias may be NULL; x_absmax is read only for LADDER_PREC_F16X3 and may
  * hold any upper bound of max |x|: a looser bound only raises the absolute representation floor 2^-38 * bound).  y_absmax (may be

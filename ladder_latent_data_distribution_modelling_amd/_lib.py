@@ -101,6 +101,9 @@ PROTOTYPES = {
     "ladder_axpy": (_i, [_p, _p, _z, _f, _i, _p]),
     "ladder_filter_pack_split_bytes": (_z, [_i, _i, _i, _i]),
     "ladder_filter_pack_split": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "ladder_filter_pack_job_blocks": (_i, [_i, _i, _i]),
+    "ladder_filter_pack_split_multi_scratch_bytes": (_z, [_i]),
+    "ladder_filter_pack_split_multi": (_i, [_p, _i, _i, _i, _p, _z, _p]),
     "ladder_conv2d_fwd_split_eligible": (_i, [_i] * 12),
     "ladder_conv2d_fwd_split_workspace_bytes": (_z, [_i] * 12),
     "ladder_conv2d_fwd_split": (_i, [_p, _p, _p, _p, _p] + [_i] * 14 + [_p, _z, _p]),

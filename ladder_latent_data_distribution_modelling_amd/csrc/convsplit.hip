@@ -94,13 +94,10 @@ __global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__
 constexpr int SP_BN = 128;
 
 template <int PREC>
-__global__ __launch_bounds__(256) void filter_pack_kernel(const float* __restrict__ w, uint4* __restrict__ out, int ntaps, int Cin,
-                                                          int Cout, int transpose_flip, int total, const float* __restrict__ wamax) {
+__device__ __forceinline__ void filter_pack_element(const float* __restrict__ w, uint4* __restrict__ out, int ntaps, int Cin, int Cout,
+                                                    int transpose_flip, int i, float c) {
   constexpr int NS = Fmt<PREC>::NS;
   constexpr bool F16 = Fmt<PREC>::F16;
-  const int i = blockIdx.x * 256 + threadIdx.x;     // one thread per (tap, slab, cot, kg, co)
-  if (i >= total) return;
-  const float c = F16 ? scale_from_absmax(amax_load(wamax)) : 1.f;
   const int cots = (Cout + SP_BN - 1) / SP_BN, nslabs = Cin / 16;
   const int col = i % SP_BN;
   int t = i / SP_BN;
@@ -123,6 +120,66 @@ __global__ __launch_bounds__(256) void filter_pack_kernel(const float* __restric
   const size_t blk = ((size_t)(tap * nslabs + slab) * cots + cot) * (NS * 256);   // uint4 units
 #pragma unroll
   for (int p = 0; p < NS; ++p) out[blk + (size_t)p * 256 + kg * 128 + col] = make_uint4(lo[p].x, lo[p].y, hi[p].x, hi[p].y);
+}
+
+template <int PREC>
+__global__ __launch_bounds__(256) void filter_pack_kernel(const float* __restrict__ w, uint4* __restrict__ out, int ntaps, int Cin,
+                                                          int Cout, int transpose_flip, int total, const float* __restrict__ wamax) {
+  const int i = blockIdx.x * 256 + threadIdx.x;     // one thread per (tap, slab, cot, kg, co)
+  if (i >= total) return;
+  const float c = Fmt<PREC>::F16 ? scale_from_absmax(amax_load(wamax)) : 1.f;
+  filter_pack_element<PREC>(w, out, ntaps, Cin, Cout, transpose_flip, i, c);
+}
+
+// ---- all filter banks of a model in two launches -----------------------------------------------------------------------------------------
+// After an optimiser step every convolution needs its split image again (forward orientation and the flipped / transposed one for
+// backward-data): ~25 banks on the CelebA nets, each of them memset + absmax + pack = three 5 us launches on the lazy path.  Here a job
+// table in device memory describes all of them: kernel A leaves 64 partial maxima per job in a scratch array (plain stores: nothing to
+// clear; 64 blocks per bank, 16-byte loads), kernel B derives each job's scale from them, packs, and writes the bank's absmax record behind its payload.
+constexpr int PK_PARTS = 64;
+__global__ __launch_bounds__(256) void filter_absmax_multi_kernel(const ladder_pack_job_t* __restrict__ jobs, float* __restrict__ partial) {
+  const ladder_pack_job_t j = jobs[blockIdx.y];
+  const size_t n = (size_t)j.ntaps * j.Cin * j.Cout;            // Cin % 16 == 0: a multiple of 4; banks are 16-byte aligned views of the flat store
+  float m = 0.f;
+  if ((reinterpret_cast<uintptr_t>(j.w) & 15u) == 0) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (size_t)PK_PARTS * 256) {
+      const float4 v = reinterpret_cast<const float4*>(j.w)[i];
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+  } else {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)PK_PARTS * 256) m = fmaxf(m, fabsf(j.w[i]));
+  }
+  __shared__ float red[4];
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.y * PK_PARTS + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+template <int PREC>
+__global__ __launch_bounds__(256) void filter_pack_multi_kernel(const ladder_pack_job_t* __restrict__ jobs, int njobs,
+                                                                const float* __restrict__ partial) {
+  // job of this block: block_begin is ascending
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const ladder_pack_job_t j = jobs[lo];
+  const int total = j.ntaps * (j.Cin / 16) * ((j.Cout + SP_BN - 1) / SP_BN) * 2 * SP_BN;
+  const int i = ((int)blockIdx.x - j.block_begin) * 256 + threadIdx.x;
+  __shared__ float amax_s;
+  if (threadIdx.x < 64) {                                            // PK_PARTS = 64 partial maxima of this bank: one per lane of wavefront 0
+    const float m = wave_max(partial[lo * PK_PARTS + threadIdx.x]);
+    if (threadIdx.x == 0) amax_s = m;
+  }
+  __syncthreads();
+  const float amax = amax_s;
+  float* rec = reinterpret_cast<float*>(static_cast<unsigned char*>(j.packed) + pack_payload_bytes_dev(j.ntaps, j.Cin, j.Cout, Fmt<PREC>::NS));
+  if ((int)blockIdx.x == j.block_begin)                              // the bank's absmax record: slot 0 = the maximum, the rest 0
+    for (int k = threadIdx.x; k < AMAX_SLOTS * AMAX_STRIDE; k += 256) rec[k] = k == 0 ? amax : 0.f;
+  if (i >= total) return;
+  filter_pack_element<PREC>(j.w, (uint4*)j.packed, j.ntaps, j.Cin, j.Cout, j.transpose_flip, i, Fmt<PREC>::F16 ? scale_from_absmax(amax) : 1.f);
 }
 
 // ---- 3x3 halo convolution on split operands -------------------------------------------------------------------------------
@@ -942,6 +999,27 @@ int ladder_filter_pack_split(const float* w, void* packed, int ntaps, int Cin, i
   } else {
     hipLaunchKernelGGL(filter_pack_kernel<LADDER_PREC_BF16X3>, grid, block, 0, stream, w, (uint4*)packed, ntaps, Cin, Cout, transpose_flip, total, wamax);
   }
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_filter_pack_job_blocks(int ntaps, int Cin, int Cout) {
+  if (ntaps <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 16) != 0) return 0;
+  const long total = (long)ntaps * (Cin / 16) * ((Cout + SP_BN - 1) / SP_BN) * 2 * SP_BN;
+  return total >= (1L << 31) ? 0 : (int)((total + 255) / 256);
+}
+
+size_t ladder_filter_pack_split_multi_scratch_bytes(int njobs) { return njobs > 0 ? (size_t)njobs * PK_PARTS * sizeof(float) : 0; }
+
+int ladder_filter_pack_split_multi(const ladder_pack_job_t* jobs_dev, int njobs, int total_blocks, int prec, void* scratch, size_t scratch_bytes,
+                                   ladder_stream_t stream) {
+  if (jobs_dev == nullptr || njobs <= 0 || total_blocks <= 0 || !prec_ok(prec)) return LADDER_E_SHAPE;
+  if (scratch == nullptr || scratch_bytes < ladder_filter_pack_split_multi_scratch_bytes(njobs)) return LADDER_E_WORKSPACE;
+  hipLaunchKernelGGL(filter_absmax_multi_kernel, dim3(PK_PARTS, njobs), dim3(256), 0, stream, jobs_dev, (float*)scratch);
+  const dim3 grid(total_blocks), block(256);
+  if (prec == LADDER_PREC_F16X3) hipLaunchKernelGGL(filter_pack_multi_kernel<LADDER_PREC_F16X3>, grid, block, 0, stream, jobs_dev, njobs, (const float*)scratch);
+  else if (prec == LADDER_PREC_BF16X6) hipLaunchKernelGGL(filter_pack_multi_kernel<LADDER_PREC_BF16X6>, grid, block, 0, stream, jobs_dev, njobs, (const float*)scratch);
+  else hipLaunchKernelGGL(filter_pack_multi_kernel<LADDER_PREC_BF16X3>, grid, block, 0, stream, jobs_dev, njobs, (const float*)scratch);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

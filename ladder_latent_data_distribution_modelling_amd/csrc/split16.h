@@ -80,5 +80,8 @@ __device__ __forceinline__ f32x16 mfma16(const uint4 a, const uint4 b, const f32
 inline size_t pack_payload_bytes(int ntaps, int Cin, int Cout, int prec) {
   return (size_t)ntaps * (Cin / 16) * ((Cout + 127) / 128) * prec_planes(prec) * 4096;
 }
+__device__ __forceinline__ size_t pack_payload_bytes_dev(int ntaps, int Cin, int Cout, int planes) {
+  return (size_t)ntaps * (Cin / 16) * ((Cout + 127) / 128) * planes * 4096;
+}
 
 }  // namespace

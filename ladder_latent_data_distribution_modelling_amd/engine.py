@@ -180,6 +180,7 @@ class Ctx:
         self._ws_retired, self.ws_generation = [], 0
         self._amax = {}      # id(tensor) -> (weakref, absolute-maximum record)
         self._planes = {}    # id(tensor) -> (weakref, pre-split planes)
+        self.pack_banks, self._pack_table = [], None              # split filter images known so far; their device job table
         self.keep_activations = True   # False inside forward-only runs: fused kernels may skip writing tensors only a backward pass reads
         self.ns = 0          # LADDER_PREC_* of the split-precision contraction kernels (0 = native f32 MFMA); set by the engine
 
@@ -398,6 +399,8 @@ class Conv2D:
         if ent is None:
             nb = L.query("ladder_filter_pack_split_bytes", self.k * self.k, cin, cout, ns)
             ent = self._packed[(transpose_flip, ns)] = [-1, torch.empty(nb, dtype=torch.uint8, device=self.ctx.device)]
+            # known to the batched re-pack after an optimiser step (LadderEngine._repack_filters): (entry, bank, taps, cin, cout, flip, ns)
+            self.ctx.pack_banks.append((ent, ps.w[self.name + "/kernel"], self.k * self.k, cin, cout, transpose_flip, ns))
         ver = ps.version["ae"]
         if ent[0] != ver or torch.cuda.is_current_stream_capturing():
             L.call("ladder_filter_pack_split", _p(ps.w[self.name + "/kernel"]), _p(ent[1]), self.k * self.k, cin, cout, transpose_flip, ns,
@@ -1358,6 +1361,33 @@ class LadderEngine:
         else:
             self.ctx.comm.allreduce_(g)
         self.ps.adam("ae", lr)
+        self._repack_filters()
+
+    def _repack_filters(self):
+        """Every split filter image the convolutions have asked for so far, re-packed from the just-updated weights in TWO launches
+        (ladder_filter_pack_split_multi) instead of memset + absmax + pack per bank on first use (~25 banks on the CelebA nets).  Eager
+        mode only: a hipGraph capture keeps the lazy per-bank path (it re-packs inside the graph)."""
+        ctx = self.ctx
+        banks = ctx.pack_banks
+        if not banks or not ctx.ns or self.use_graphs or torch.cuda.is_current_stream_capturing():
+            return
+        tab = ctx._pack_table
+        if tab is None or tab[0] != len(banks):
+            import numpy as np
+            dt = np.dtype([("w", "<u8"), ("packed", "<u8"), ("ntaps", "<i4"), ("cin", "<i4"), ("cout", "<i4"), ("flip", "<i4"),
+                           ("block_begin", "<i4"), ("reserved", "<i4")])
+            rows, blk = np.zeros(len(banks), dtype=dt), 0
+            for r, (ent, w, taps, cin, cout, flip, ns) in zip(rows, banks):
+                assert ns == ctx.ns
+                r["w"], r["packed"], r["ntaps"], r["cin"], r["cout"], r["flip"], r["block_begin"] = w.data_ptr(), ent[1].data_ptr(), taps, cin, cout, flip, blk
+                blk += L.query("ladder_filter_pack_job_blocks", taps, cin, cout)
+            dev = torch.from_numpy(rows.view(np.uint8).copy()).to(ctx.device)
+            scratch = torch.empty(L.query("ladder_filter_pack_split_multi_scratch_bytes", len(banks)), dtype=torch.uint8, device=ctx.device)
+            tab = ctx._pack_table = (len(banks), dev, blk, scratch)
+        L.call("ladder_filter_pack_split_multi", _p(tab[1]), tab[0], tab[2], ctx.ns, _p(tab[3]), tab[3].numel(), ctx.stream)
+        ver = self.ps.version["ae"]
+        for ent, *_ in banks:
+            ent[0] = ver
 
     def _sigma(self, x, lr, noise, use_sg, use_mask, reuse_encoder=False):
         self.forward(x, noise, use_sg, use_mask, ("dec",), reuse_encoder, keep_acts=False)

@@ -548,3 +548,40 @@ def test_bn_apply_emits_planes(gpu_ctx, rows, C):
         L.call("ladder_bn_fwd_apply_planes", p(x), p(s4), float(rows), p(gam), p(bet), None, p(planes2), p(mr), rows, C, 1e-3, act, p(rec), st)
         assert torch.equal(planes2, ref)                                              # fp32 y never written
     assert L.query("ladder_bn_fwd_apply_planes", p(x), p(s4), float(rows), p(gam), p(bet), None, None, p(mr), rows, C, 1e-3, 1, p(rec), st) != 0
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x6"])
+def test_filter_pack_multi_equals_single(gpu_ctx, prec):
+    """ladder_filter_pack_split_multi (all banks of a model in two launches, job table in device memory) writes, bank for bank, what the
+    per-bank ladder_filter_pack_split writes -- payload bit for bit, and an absmax record that selects the same scale."""
+    L = _lib()
+    st = gpu_ctx.stream
+    P = PREC[prec]
+    rng = np.random.default_rng(3)
+    banks = [(9, 32, 128, 0), (9, 128, 32, 1), (9, 64, 160, 0), (1, 512, 512, 0), (16, 16, 96, 1), (25, 48, 64, 0)]
+    dt = np.dtype([("w", "<u8"), ("packed", "<u8"), ("ntaps", "<i4"), ("cin", "<i4"), ("cout", "<i4"), ("flip", "<i4"), ("block_begin", "<i4"),
+                   ("reserved", "<i4")])
+    rows, blk, keep = np.zeros(len(banks), dtype=dt), 0, []
+    for r, (taps, cin, cout, flip) in zip(rows, banks):
+        ci, co = (cout, cin) if flip else (cin, cout)                  # w is the layer's HWIO bank [taps, ci, co]
+        w = dev((rng.standard_normal((taps, ci, co)) * 10.0 ** rng.integers(-3, 2)).astype(np.float32))
+        nb = L.query("ladder_filter_pack_split_bytes", taps, cin, cout, P)
+        single = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+        L.call("ladder_filter_pack_split", p(w), p(single), taps, cin, cout, flip, P, st)
+        multi = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+        r["w"], r["packed"], r["ntaps"], r["cin"], r["cout"], r["flip"], r["block_begin"] = w.data_ptr(), multi.data_ptr(), taps, cin, cout, flip, blk
+        nblk = L.query("ladder_filter_pack_job_blocks", taps, cin, cout)
+        assert nblk > 0
+        blk += nblk
+        keep.append((w, single, multi, nb))
+    tab = torch.from_numpy(rows.view(np.uint8).copy()).to("cuda")
+    scratch = torch.empty(L.query("ladder_filter_pack_split_multi_scratch_bytes", len(banks)), dtype=torch.uint8, device="cuda")
+    L.call("ladder_filter_pack_split_multi", p(tab), len(banks), blk, P, p(scratch), scratch.numel(), st)
+    for w, single, multi, nb in keep:
+        pay = nb - 4 * L.ABSMAX_FLOATS
+        assert torch.equal(multi[:pay], single[:pay])
+        if prec == "f16x3":
+            rs, rm = single[pay:].view(torch.float32), multi[pay:].view(torch.float32)
+            assert rs.max().item() == rm.max().item() == w.abs().max().item()
+    assert L.query("ladder_filter_pack_split_multi", p(tab), len(banks), blk, P, None, 0, st) == -3
+    assert L.query("ladder_filter_pack_job_blocks", 9, 24, 128) == 0
