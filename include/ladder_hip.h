@@ -212,6 +212,9 @@ int ladder_dense_fwd_small(const float* x, const float* w, const float* bias, fl
 int ladder_dense_bwd_data_small(const float* dy, const float* w, float* dx, int M, int K, int N, const float* gate_y, int gate_act,
                                 ladder_stream_t stream);
 int ladder_dense_bwd_weight_small(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, ladder_stream_t stream);
+/* Both gradient calls of a layer in ONE launch (a launch costs as much as the arithmetic of one of them): dx and dw must not be NULL. */
+int ladder_dense_bwd_small(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int M, int K, int N,
+                           const float* gate_y, int gate_act, ladder_stream_t stream);
 
 
 /* The image-side convolution of the CelebA encoder (codes/models.py:398-405: 3x3, stride 2, SAME, 3 -> Cout channels over even-sized RGB

@@ -116,6 +116,7 @@ PROTOTYPES = {
     "ladder_dense_fwd_small": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "ladder_dense_bwd_data_small": (_i, [_p, _p, _p, _i, _i, _i, _p, _i, _p]),
     "ladder_dense_bwd_weight_small": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "ladder_dense_bwd_small": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _p]),
     "ladder_presplit_bytes": (_z, [_z, _i]),
     "ladder_presplit": (_i, [_p, _p, _p, _z, _i, _p]),
     "ladder_conv3x3_split_proj": (_i, [_p, _p, _p, _p, _p, _p, _p, _p] + [_i] * 8 + [_p]),

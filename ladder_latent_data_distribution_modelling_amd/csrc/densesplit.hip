@@ -53,15 +53,34 @@ __device__ __forceinline__ void mma_step(const float (&av)[8], const float (&bv)
 
 // NW wavefronts per 32x32 tile; wavefront w takes K-steps w, w + NW, ... two at a time (both steps' loads are issued before the first
 // split: the kernel is bound by the load -> split -> MFMA latency chain, ~0.8 us per round, not by throughput)
+// One problem of a launch (blockIdx.z selects; up to two independent GEMMs share a launch: the backward-data and backward-weight
+// calls of a dense layer -- a launch costs as much as the arithmetic of one of these)
+struct GemmProb {
+  const float* a;
+  const float* b;
+  const float* bias;
+  float* c;
+  const float* gate;
+  float* colsum;
+  GemmSmall g;
+};
+
 template <int NW, bool PAIR>
-__global__ __launch_bounds__(NW * 64) void gemm_small_split_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                                   const float* __restrict__ bias, float* __restrict__ c,
-                                                                   const float* __restrict__ gate, float* __restrict__ colsum,
-                                                                   const GemmSmall g) {
+__global__ __launch_bounds__(NW * 64) void gemm_small_split_kernel(const GemmProb p0, const GemmProb p1) {
+  const GemmProb& pr = blockIdx.z ? p1 : p0;
+  const GemmSmall& g = pr.g;
+  const int tiles_j = (g.J + 31) / 32, tile_i = (int)blockIdx.x / tiles_j, tile_j = (int)blockIdx.x - tile_i * tiles_j;
+  if (tile_i * 32 >= g.I) return;                             // (the grid has as many workgroups as the larger problem has tiles)
+  const float* __restrict__ a = pr.a;
+  const float* __restrict__ b = pr.b;
+  const float* __restrict__ bias = pr.bias;
+  float* __restrict__ c = pr.c;
+  const float* __restrict__ gate = pr.gate;
+  float* __restrict__ colsum = pr.colsum;
   __shared__ float red[NW][32 * 33];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  const int i0 = tile_i * 32, j0 = tile_j * 32;
   const int i = i0 + l31, j = j0 + l31;
   const bool i_ok = i < g.I, j_ok = j < g.J;
   const float* ap = a + (long)(i_ok ? i : 0) * g.a_is;
@@ -107,7 +126,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_split_kernel(const float* 
       }
     }
   }
-  if (colsum != nullptr && blockIdx.y == 0) {                 // db[j] = sum_r B(r, j): lanes (l31, lh) x NW wavefronts, fixed order
+  if (colsum != nullptr && tile_i == 0) {                 // db[j] = sum_r B(r, j): lanes (l31, lh) x NW wavefronts, fixed order
     __syncthreads();
     csum += __shfl_xor(csum, 32, 64);
     if (lh == 0) red[wv][l31] = csum;
@@ -121,17 +140,32 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_split_kernel(const float* 
   }
 }
 
-int launch_gemm_small(const float* a, const float* b, const float* bias, float* c, const float* gate, float* colsum, const GemmSmall& g,
-                      hipStream_t st) {
+int launch_gemm_probs(const GemmProb& p0, const GemmProb* p1, hipStream_t st) {
+  const GemmSmall& g = p0.g;
   if (g.I <= 0 || g.J <= 0 || g.R <= 0) return LADDER_E_SHAPE;
-  const dim3 grid((g.J + 31) / 32, (g.I + 31) / 32);
+  long tiles = (long)((g.J + 31) / 32) * ((g.I + 31) / 32);
   // fewer tiles than compute units and a reduction of >= 32 steps: 16 wavefronts per tile (a fixed 16-way K split inside the workgroup)
-  const long tiles = (long)grid.x * grid.y;
-  const int nsteps = (g.R + 15) / 16;
-  if (tiles <= 128 && nsteps >= 32) hipLaunchKernelGGL((gemm_small_split_kernel<16, false>), grid, dim3(1024), 0, st, a, b, bias, c, gate, colsum, g);
-  else hipLaunchKernelGGL((gemm_small_split_kernel<4, true>), grid, dim3(256), 0, st, a, b, bias, c, gate, colsum, g);
+  bool wide = tiles <= 128 && (g.R + 15) / 16 >= 32;
+  dim3 grid(1, 1, 1);
+  if (p1 != nullptr) {
+    const GemmSmall& h = p1->g;
+    if (h.I <= 0 || h.J <= 0 || h.R <= 0) return LADDER_E_SHAPE;
+    tiles = max(tiles, (long)((h.J + 31) / 32) * ((h.I + 31) / 32));
+    grid.z = 2;
+    wide = true;                                            // (a short reduction just leaves the upper wavefronts idle)
+  }
+  grid.x = (unsigned)tiles;
+  const GemmProb& q = p1 != nullptr ? *p1 : p0;
+  if (wide) hipLaunchKernelGGL((gemm_small_split_kernel<16, false>), grid, dim3(1024), 0, st, p0, q);
+  else hipLaunchKernelGGL((gemm_small_split_kernel<4, true>), grid, dim3(256), 0, st, p0, q);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
+}
+
+int launch_gemm_small(const float* a, const float* b, const float* bias, float* c, const float* gate, float* colsum, const GemmSmall& g,
+                      hipStream_t st) {
+  const GemmProb p{a, b, bias, c, gate, colsum, g};
+  return launch_gemm_probs(p, nullptr, st);
 }
 
 }  // namespace
@@ -159,6 +193,15 @@ int ladder_dense_bwd_weight_small(const float* x, const float* dy, float* dw, fl
   if (!ladder_dense_small_eligible(M, K, N)) return LADDER_E_SHAPE;
   const GemmSmall g{K, N, M, 1, K, N, 1, LADDER_ACT_NONE, 0};
   return launch_gemm_small(x, dy, nullptr, dw, nullptr, db, g, stream);
+}
+
+// Both gradient GEMMs of a dense layer in ONE launch (dx = dy w^T with the optional activation gate, dw = x^T dy, db = column sums of dy).
+int ladder_dense_bwd_small(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int M, int K, int N,
+                           const float* gate_y, int gate_act, ladder_stream_t stream) {
+  if (!ladder_dense_small_eligible(M, K, N) || dx == nullptr || dw == nullptr) return LADDER_E_SHAPE;
+  const GemmProb pd{dy, w, nullptr, dx, gate_y, nullptr, GemmSmall{M, K, N, N, 1, 1, N, LADDER_ACT_NONE, gate_act}};
+  const GemmProb pw{x, dy, nullptr, dw, nullptr, db, GemmSmall{K, N, M, 1, K, N, 1, LADDER_ACT_NONE, 0}};
+  return launch_gemm_probs(pd, &pw, stream);
 }
 
 }  // extern "C"

@@ -622,6 +622,13 @@ class Dense:
         if self.act is not None and not act_done:
             L.call("ladder_act_bwd", _p(dy), _p(y), _p(dy), dy.numel(), L.ACT[self.act], st)
         if self._small(M):
+            if wgrad and need_dx:                               # both gradient GEMMs in one launch
+                dx = self.ctx.empty(M, self.cin)
+                L.call("ladder_dense_bwd_small", _p(x), _p(dy), _p(self.ps.w[self.name + "/kernel"]), _p(dx),
+                       _p(self.ps.g[self.name + "/kernel"]), _p(self.ps.g[self.name + "/bias"]), M, self.cin, self.cout,
+                       _p(x) if gate_prev else None, L.ACT[gate_prev] if gate_prev else 0, st)
+                self.x = self.y = None
+                return dx
             if wgrad:
                 L.call("ladder_dense_bwd_weight_small", _p(x), _p(dy), _p(self.ps.g[self.name + "/kernel"]),
                        _p(self.ps.g[self.name + "/bias"]), M, self.cin, self.cout, st)

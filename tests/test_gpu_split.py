@@ -383,6 +383,12 @@ def test_dense_small_bf16x6(gpu_ctx, M, K, N, act):
     close(dx, xt.grad, 3e-5, "dx")
     L.call("ladder_dense_bwd_data_small", p(dyd), p(wd), p(dxg), M, K, N, p(xd), 1, st)
     assert torch.equal(dxg, dx * torch.where(xd > 0, 1.0, 0.2))
+    # both gradient GEMMs in one launch: the same sums in the same order when the variant (wavefronts per tile) coincides, else to tolerance
+    dw2, db2, dx2 = torch.empty_like(wd), torch.empty_like(bd), torch.empty_like(xd)
+    L.call("ladder_dense_bwd_small", p(xd), p(dyd), p(wd), p(dx2), p(dw2), p(db2), M, K, N, p(xd), 1, st)
+    close(dw2, wt.grad, 3e-5, "dw (fused)")
+    close(db2, bt.grad, 3e-5, "db (fused)")
+    close(dx2, xt.grad * torch.where(xt.detach() > 0, 1.0, 0.2), 3e-5, "dx (fused, gated)")
     assert L.query("ladder_dense_small_eligible", 4096, 512, 512) == 0
 
 
