@@ -431,8 +431,9 @@ def test_celeba_full_size_halo_kernels_in_situ(tmp_path):
     device noise in four builds of the contraction path:
       f32 generic   every convolution on the fp32 gather kernels (LADDER_DISABLE_HALO=1)          -- the yardstick
       f32 halo      fp32 LDS-halo conv / filter-gradient kernels (engaged only at this scale)
-      f16x3         the default: split-precision kernels, 2 scaled fp16 planes, 3 MFMAs per product
+      f16x3         the default: split-precision kernels, 2 scaled fp16 planes, 3 MFMAs per product (16-wave halo kernel at this batch)
       bf16x6        split-precision kernels, 3 bf16 planes, 6 MFMAs per product
+      f16x3-8wave   f16x3 with the 16x32-pixel halo kernel switched off (LADDER_DISABLE_HALO16=1): the 8-wave kernel at full size
     Every build must reproduce the yardstick: fetched ELBO terms of RUN#1 to 2e-6 relative, selected gradient tensors to 1e-4 of
     their scale, finite everywhere (the fp32-class split formats get the SAME bars as the fp32 halo kernels)."""
     import subprocess
@@ -442,14 +443,15 @@ def test_celeba_full_size_halo_kernels_in_situ(tmp_path):
     script.write_text(HALO_WORKER % dict(root=root))
     res = {}
     for tag, env in (("generic", {"LADDER_DISABLE_HALO": "1", "LADDER_TEST_PRECISION": "f32"}), ("halo", {"LADDER_TEST_PRECISION": "f32"}),
-                     ("f16x3", {"LADDER_TEST_PRECISION": "f16x3"}), ("bf16x6", {"LADDER_TEST_PRECISION": "bf16x6"})):
+                     ("f16x3", {"LADDER_TEST_PRECISION": "f16x3"}), ("bf16x6", {"LADDER_TEST_PRECISION": "bf16x6"}),
+                     ("f16x3-8wave", {"LADDER_TEST_PRECISION": "f16x3", "LADDER_DISABLE_HALO16": "1"})):
         outp = str(tmp_path / (tag + ".npz"))
         e = dict(os.environ, **env)
         p = subprocess.run([sys.executable, str(script), outp], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
         assert p.returncode == 0, p.stdout[-2000:]
         res[tag] = np.load(outp)
     fb = json.loads(str(res["generic"]["fetch"]))
-    for tag in ("halo", "f16x3", "bf16x6"):
+    for tag in ("halo", "f16x3", "bf16x6", "f16x3-8wave"):
         fa = json.loads(str(res[tag]["fetch"]))
         split = tag != "halo"
         for k in SCALARS_RUN1:
