@@ -12,6 +12,7 @@
 //   forward        y  = x w        : i = m, j = n, r = k    A = x  (a_is = K, a_rs = 1)   B = w  (b_rs = N, b_js = 1)
 //   backward-data  dx = dy w^T     : i = m, j = k, r = n    A = dy (a_is = N, a_rs = 1)   B = w  (b_rs = 1, b_js = N)  -- no transposed copy
 //   backward-weight dw = x^T dy    : i = k, j = n, r = m    A = x  (a_is = 1, a_rs = K)   B = dy (b_rs = N, b_js = 1), db = column sums of dy
+#include <cstdlib>
 #include "split16.h"
 
 namespace {
@@ -140,10 +141,91 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_split_kernel(const GemmPro
   }
 }
 
+// ---- 16x16 tiles (v_mfma_f32_16x16x32_bf16) for launches that would leave most of the chip idle -------------------------------------------
+// A 128 x 512 output is only 64 tiles of 32x32 on 256 CUs; with 16x16 tiles it is 256 workgroups, each with a quarter of the work on its
+// latency chain (load -> split -> MFMA -> reduce).  Fragment layout of the 16x16x32 instruction: lane l holds row / column l % 16 and the
+// K-octet l / 16 (4 octets = 32); the accumulator (4 registers) holds column l % 16, rows 4 (l / 16) + 0..3.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mma_step16(const float (&av)[8], const float (&bv)[8], f32x4v& acc) {
+  uint2 alo[3], ahi[3], blo[3], bhi[3];
+  split4<3, false>(make_float4(av[0], av[1], av[2], av[3]), alo);
+  split4<3, false>(make_float4(av[4], av[5], av[6], av[7]), ahi);
+  split4<3, false>(make_float4(bv[0], bv[1], bv[2], bv[3]), blo);
+  split4<3, false>(make_float4(bv[4], bv[5], bv[6], bv[7]), bhi);
+#pragma unroll
+  for (int sum = 2; sum >= 0; --sum)
+#pragma unroll
+    for (int pa = 0; pa <= sum; ++pa) {
+      const int pb = sum - pa;
+      const uint4 af = make_uint4(alo[pa].x, alo[pa].y, ahi[pa].x, ahi[pa].y), bf = make_uint4(blo[pb].x, blo[pb].y, bhi[pb].x, bhi[pb].y);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), acc, 0, 0, 0);
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_small16_split_kernel(const GemmProb p0, const GemmProb p1) {
+  const GemmProb& pr = blockIdx.z ? p1 : p0;
+  const GemmSmall& g = pr.g;
+  const int tiles_j = (g.J + 15) / 16, tile_i = (int)blockIdx.x / tiles_j, tile_j = (int)blockIdx.x - tile_i * tiles_j;
+  if (tile_i * 16 >= g.I) return;
+  __shared__ float red[NW][16 * 17];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int i0 = tile_i * 16, j0 = tile_j * 16;
+  const int i = i0 + l15, j = j0 + l15;
+  const bool i_ok = i < g.I, j_ok = j < g.J;
+  const float* ap = pr.a + (long)(i_ok ? i : 0) * g.a_is;
+  const float* bp = pr.b + (long)(j_ok ? j : 0) * g.b_js;
+  f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+  float csum = 0.f;
+  const int nsteps = (g.R + 31) / 32;
+  for (int ks = wv; ks < nsteps; ks += NW) {
+    float av[8], bv[8];
+    load8(ap, g.a_rs, ks * 32 + 8 * lq, g.R, i_ok, av);
+    load8(bp, g.b_rs, ks * 32 + 8 * lq, g.R, j_ok, bv);
+    if (pr.colsum != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) csum += bv[e];
+    }
+    mma_step16(av, bv, acc);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[wv][(4 * lq + e) * 17 + l15] = acc[e];
+  __syncthreads();
+  for (int t = tid; t < 256; t += NW * 64) {                  // (NW = 2: two outputs per thread)
+    const int col = t & 15, row = t >> 4;
+    const int ii = i0 + row, jj = j0 + col;
+    if (ii < g.I && jj < g.J) {
+      float v = red[0][row * 17 + col];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) v += red[w][row * 17 + col];
+      v = ladder_act_fn(v + (pr.bias != nullptr ? pr.bias[jj] : 0.f), g.act);
+      const long o = (long)ii * g.J + jj;
+      if (pr.gate != nullptr) v *= ladder_act_grad_from_out(pr.gate[o], g.gate_act);
+      pr.c[o] = v;
+    }
+  }
+  if (pr.colsum != nullptr && tile_i == 0) {                  // db[j]: 4 K-octet lanes x NW wavefronts per column, fixed order
+    __syncthreads();
+    csum += __shfl_xor(csum, 16, 64);
+    csum += __shfl_xor(csum, 32, 64);
+    if (lq == 0) red[wv][l15] = csum;
+    __syncthreads();
+    if (tid < 16 && j0 + tid < g.J) {
+      float v = red[0][tid];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) v += red[w][tid];
+      pr.colsum[j0 + tid] = v;
+    }
+  }
+}
+
 int launch_gemm_probs(const GemmProb& p0, const GemmProb* p1, hipStream_t st) {
   const GemmSmall& g = p0.g;
   if (g.I <= 0 || g.J <= 0 || g.R <= 0) return LADDER_E_SHAPE;
   long tiles = (long)((g.J + 31) / 32) * ((g.I + 31) / 32);
+  long tiles16 = (long)((g.J + 15) / 16) * ((g.I + 15) / 16);
+  int steps32 = (g.R + 31) / 32;
   // fewer tiles than compute units and a reduction of >= 32 steps: 16 wavefronts per tile (a fixed 16-way K split inside the workgroup)
   bool wide = tiles <= 128 && (g.R + 15) / 16 >= 32;
   dim3 grid(1, 1, 1);
@@ -151,11 +233,22 @@ int launch_gemm_probs(const GemmProb& p0, const GemmProb* p1, hipStream_t st) {
     const GemmSmall& h = p1->g;
     if (h.I <= 0 || h.J <= 0 || h.R <= 0) return LADDER_E_SHAPE;
     tiles = max(tiles, (long)((h.J + 31) / 32) * ((h.I + 31) / 32));
+    tiles16 = max(tiles16, (long)((h.J + 15) / 16) * ((h.I + 15) / 16));
+    steps32 = max(steps32, (h.R + 31) / 32);
     grid.z = 2;
     wide = true;                                            // (a short reduction just leaves the upper wavefronts idle)
   }
-  grid.x = (unsigned)tiles;
   const GemmProb& q = p1 != nullptr ? *p1 : p0;
+  static const bool no16 = getenv("LADDER_DISABLE_GEMM16") != nullptr;
+  if (!no16 && tiles * grid.z < 256 && tiles16 <= 4096) {   // the chip would be under-filled by 32x32 tiles: 16x16 tiles, K split over <= 8 wavefronts
+    grid.x = (unsigned)tiles16;
+    if (steps32 >= 8) hipLaunchKernelGGL((gemm_small16_split_kernel<8>), grid, dim3(512), 0, st, p0, q);
+    else if (steps32 >= 4) hipLaunchKernelGGL((gemm_small16_split_kernel<4>), grid, dim3(256), 0, st, p0, q);
+    else hipLaunchKernelGGL((gemm_small16_split_kernel<2>), grid, dim3(128), 0, st, p0, q);
+    LADDER_CHECK_LAUNCH();
+    return LADDER_OK;
+  }
+  grid.x = (unsigned)tiles;
   if (wide) hipLaunchKernelGGL((gemm_small_split_kernel<16, false>), grid, dim3(1024), 0, st, p0, q);
   else hipLaunchKernelGGL((gemm_small_split_kernel<4, true>), grid, dim3(256), 0, st, p0, q);
   LADDER_CHECK_LAUNCH();
