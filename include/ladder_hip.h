@@ -165,6 +165,13 @@ size_t ladder_conv2d_fwd_split_workspace_bytes(int N, int H, int W, int Cin, int
 int ladder_conv2d_fwd_split(const void* x_planes, const float* x_absmax, const void* packed, const float* bias, float* y, int N, int H, int W,
                             int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int act, int prec,
                             void* ws, size_t ws_bytes, ladder_stream_t stream);
+/* The forward call + the batch-norm statistics of its output from the epilogue (sums4 [4 Cout] = sum | sum of squares | min | max per
+ * channel, as ladder_bn_fwd_stats_minmax); only for calls that run without split-K: the workspace query returns 0 otherwise. */
+size_t ladder_conv2d_fwd_split_bnstats_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                                                       int pad_t, int pad_l);
+int ladder_conv2d_fwd_split_bnstats(const void* x_planes, const float* x_absmax, const void* packed, const float* bias, float* y, int N,
+                                    int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l,
+                                    int act, int prec, float* sums4, void* stats_ws, size_t stats_ws_bytes, ladder_stream_t stream);
 int ladder_conv2d_bwd_data_split_eligible(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t,
                                           int pad_l, int gated);
 size_t ladder_conv2d_bwd_data_split_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(kThreads, 2) void igemm_fwd_split_kernel(const uint
                                                                      const IgemmDesc d, const int tiles_n, float* __restrict__ part,
                                                                      const int chunks_per_split, const float* __restrict__ gate,
                                                                      const int gate_act, const float* __restrict__ xamax,
-                                                                     const float* __restrict__ wamax) {
+                                                                     const float* __restrict__ wamax, float* __restrict__ stats_part) {
   constexpr int NS = Fmt<PREC>::NS;
   constexpr bool F16 = Fmt<PREC>::F16;
   constexpr int OPB = NS * GS_PLANE;                       // bytes of one operand tile
@@ -482,6 +482,9 @@ __global__ __launch_bounds__(kThreads, 2) void igemm_fwd_split_kernel(const uint
     return;
   }
   const bool dense_out = d.out_sh == 1 && d.out_sw == 1 && d.OH == d.Ho && d.OW == d.Wo;
+  // batch-norm statistics of what is written (lane = output channel: the column sums are local), stats_part [tile_m][4][Cout] =
+  // sum | sum of squares | min | max per tile, reduced by ladder_bn_stats_minmax_from_partials
+  float st0[2] = {0.f, 0.f}, st1[2] = {0.f, 0.f}, smn[2] = {INFINITY, INFINITY}, smx[2] = {-INFINITY, -INFINITY};
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int n = n0 + wn * 64 + ni * 32 + l31;
@@ -501,8 +504,35 @@ __global__ __launch_bounds__(kThreads, 2) void igemm_fwd_split_kernel(const uint
           float v = ladder_act_fn(acc[mi][ni][e] * unscale + bv, d.act);
           if (gate != nullptr) v *= ladder_act_grad_from_out(gate[row * d.Cout + n], gate_act);
           y[row * d.Cout + n] = v;
+          st0[ni] += v;
+          st1[ni] += v * v;
+          smn[ni] = fminf(smn[ni], v);
+          smx[ni] = fmaxf(smx[ni], v);
         }
       }
+    }
+  }
+  if (stats_part != nullptr) {
+    float* sred = reinterpret_cast<float*>(lds);             // [which 4][wm 2][128 channels] (the operand tiles are dead)
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const float a0 = st0[ni] + __shfl_xor(st0[ni], 32, 64), a1 = st1[ni] + __shfl_xor(st1[ni], 32, 64);
+      const float a2 = fminf(smn[ni], __shfl_xor(smn[ni], 32, 64)), a3 = fmaxf(smx[ni], __shfl_xor(smx[ni], 32, 64));
+      if (lh == 0) {
+        const int cc = wn * 64 + ni * 32 + l31;
+        sred[(0 * 2 + wm) * 128 + cc] = a0;
+        sred[(1 * 2 + wm) * 128 + cc] = a1;
+        sred[(2 * 2 + wm) * 128 + cc] = a2;
+        sred[(3 * 2 + wm) * 128 + cc] = a3;
+      }
+    }
+    __syncthreads();
+    for (int t = tid; t < 4 * 128; t += kThreads) {
+      const int which = t >> 7, c = t & 127;
+      const float v0 = sred[(which * 2 + 0) * 128 + c], v1 = sred[(which * 2 + 1) * 128 + c];
+      const float r = which < 2 ? v0 + v1 : (which == 2 ? fminf(v0, v1) : fmaxf(v0, v1));
+      if (n0 + c < d.Cout) stats_part[((size_t)(tile / tiles_n) * 4 + which) * d.Cout + n0 + c] = r;
     }
   }
 }
@@ -1207,7 +1237,7 @@ size_t fwd_split_ws_bytes(const IgemmDesc& d) {
 }
 
 int launch_fwd_split(const void* x, const float* xamax, const void* packed, const float* bias, float* y, const IgemmDesc& d, int prec,
-                     void* ws, size_t ws_bytes, hipStream_t st, const float* gate, int gate_act) {
+                     void* ws, size_t ws_bytes, hipStream_t st, const float* gate, int gate_act, float* stats_part = nullptr) {
   // `x` = the pre-split planes of the gathered tensor (ladder_presplit), plane-major, d.N*d.H*d.W*d.Cin elements per plane
   const bool dense_out = d.out_sh == 1 && d.out_sw == 1 && d.OH == d.Ho && d.OW == d.Wo;
   if (!split_gather_ok(d, true) || !prec_ok(prec)) return LADDER_E_SHAPE;
@@ -1219,11 +1249,12 @@ int launch_fwd_split(const void* x, const float* xamax, const void* packed, cons
   const size_t need = (size_t)sp.splits * d.M * d.Cout * sizeof(float);
   if (sp.splits > 1 && (ws == nullptr || ws_bytes < need)) sp = SplitPlan{1, d.ntaps * (d.Cin / GS_BK)};
   float* part = sp.splits > 1 ? (float*)ws : nullptr;
+  if (stats_part != nullptr && (part != nullptr || !dense_out)) return LADDER_E_SHAPE;   // statistics come from the single-pass epilogue
   const float* wamax = reinterpret_cast<const float*>(static_cast<const unsigned char*>(packed) + pack_payload_bytes(d.KH * d.KW, d.Cin, d.Cout, prec));
   const dim3 grid(tiles_m * tiles_n, sp.splits), block(kThreads);
 #define LADDER_GS_LAUNCH(P_) \
   hipLaunchKernelGGL(igemm_fwd_split_kernel<P_>, grid, block, 0, st, (const uint16_t*)x, plane_elems, (const uint4*)packed, bias, y, d, tiles_n, part, sp.cps, \
-                     part ? nullptr : gate, gate_act, xamax, wamax)
+                     part ? nullptr : gate, gate_act, xamax, wamax, stats_part)
   if (prec == LADDER_PREC_F16X3) LADDER_GS_LAUNCH(LADDER_PREC_F16X3);
   else if (prec == LADDER_PREC_BF16X6) LADDER_GS_LAUNCH(LADDER_PREC_BF16X6);
   else LADDER_GS_LAUNCH(LADDER_PREC_BF16X3);
@@ -2048,6 +2079,30 @@ int ladder_conv2d_fwd_split(const void* x_planes, const float* x_absmax, const v
                             void* ws, size_t ws_bytes, ladder_stream_t stream) {
   return conv2d_fwd_split_impl(x_planes, x_absmax, packed, bias, y, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_t, pad_l, act, prec, ws,
                                ws_bytes, stream, false, nullptr);
+}
+
+// Forward + the batch-norm statistics of its output (sums4 [4 Cout] = sum | sum of squares | min | max per channel, as
+// ladder_bn_fwd_stats_minmax computes them from a second pass over y) from the epilogue's per-tile column statistics.  Available when the
+// call runs without split-K (workspace query > 0): the partial sums of a split reduction never see the finished values.
+size_t ladder_conv2d_fwd_split_bnstats_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                                                       int pad_t, int pad_l) {
+  if (!ladder_conv2d_fwd_split_eligible(N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_t, pad_l)) return 0;
+  if (ladder_conv2d_fwd_split_workspace_bytes(N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_t, pad_l) != 0) return 0;
+  const size_t tiles_m = ((size_t)N * Ho * Wo + GS_BM - 1) / GS_BM;
+  return tiles_m * 4 * (size_t)Cout * sizeof(float);
+}
+
+int ladder_conv2d_fwd_split_bnstats(const void* x_planes, const float* x_absmax, const void* packed, const float* bias, float* y, int N, int H,
+                                    int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int act,
+                                    int prec, float* sums4, void* stats_ws, size_t stats_ws_bytes, ladder_stream_t stream) {
+  const size_t need = ladder_conv2d_fwd_split_bnstats_workspace_bytes(N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_t, pad_l);
+  if (need == 0 || sums4 == nullptr) return LADDER_E_SHAPE;
+  if (stats_ws == nullptr || stats_ws_bytes < need) return LADDER_E_WORKSPACE;
+  IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, 1, pad_t, pad_l, N * Ho * Wo, KH * KW * Cin, act, make_fastdiv(Ho * Wo), make_fastdiv(Wo)};
+  set_conv_taps(d);
+  const int rc = launch_fwd_split(x_planes, x_absmax, packed, bias, y, d, prec, nullptr, 0, stream, nullptr, 0, (float*)stats_ws);
+  if (rc != LADDER_OK) return rc;
+  return ladder_bn_stats_minmax_from_partials((const float*)stats_ws, (int)(((size_t)N * Ho * Wo + GS_BM - 1) / GS_BM), sums4, Cout, stream);
 }
 
 int ladder_conv2d_bwd_data_split_eligible(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t,

@@ -466,6 +466,15 @@ class Conv2D:
             self.x_amax = self.ctx.absmax(x)
             nb = L.query("ladder_conv2d_fwd_split_workspace_bytes", *geo)
             wsp, wsn = self.ctx.ws(nb)
+            if self.want_bn_sums and self.act is None and not nb:
+                snb = L.query("ladder_conv2d_fwd_split_bnstats_workspace_bytes", *geo)
+                if snb:                                  # the epilogue also emits the batch-norm statistics of y (no second pass over it)
+                    swp, swn = self.ctx.ws(snb)
+                    self.bn_sums = self.ctx.empty(4 * self.cout)
+                    L.call("ladder_conv2d_fwd_split_bnstats", _p(self.ctx.planes(x)), _p(self.x_amax), _p(self._packed_filter(0)),
+                           _p(self.ps.w[self.name + "/bias"]), _p(y), *geo, 0, self.ctx.ns, _p(self.bn_sums), swp, swn, self.ctx.stream)
+                    self.x, self.y = x, y
+                    return y
             args = (_p(self.ctx.planes(x)), _p(self.x_amax), _p(self._packed_filter(0)), _p(self.ps.w[self.name + "/bias"]), _p(y)) + geo + (
                 L.ACT[self.act], self.ctx.ns, wsp, wsn, self.ctx.stream)
             if nb:                                       # split-K launch: two kernels, not attributed by the profiler

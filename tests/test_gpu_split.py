@@ -204,6 +204,17 @@ def test_conv2d_split_gather_fwd_bwd(gpu_ctx, case, prec):
     close(y, yr, tf, "fwd (split-K allowed)")
     L.call("ladder_conv2d_fwd_split", p(xpl), p(xa), p(pk), p(bd), p(y), *geo, L.ACT[act], P, None, 0, st)
     close(y, yr, tf, "fwd")
+    snb = L.query("ladder_conv2d_fwd_split_bnstats_workspace_bytes", *geo)
+    assert (snb > 0) == (L.query("ladder_conv2d_fwd_split_workspace_bytes", *geo) == 0)       # statistics only without split-K
+    if snb:                                     # the same launch emitting the batch-norm statistics of y
+        swp, swn = gpu_ctx.ws(snb)
+        y2, s4 = torch.empty_like(y), torch.empty(4 * Cout, device="cuda")
+        L.call("ladder_conv2d_fwd_split_bnstats", p(xpl), p(xa), p(pk), p(bd), p(y2), *geo, L.ACT[act], P, p(s4), swp, swn, st)
+        assert torch.equal(y2, y)
+        yf = y.double().reshape(-1, Cout)
+        ref = torch.cat([yf.sum(0), (yf * yf).sum(0)])
+        assert ((s4[:2 * Cout].double() - ref).abs() <= 2e-6 * ref.abs().max() + 1e-30).all()
+        assert torch.equal(s4[2 * Cout:3 * Cout], y.reshape(-1, Cout).min(0).values) and torch.equal(s4[3 * Cout:], y.reshape(-1, Cout).max(0).values)
     dyd = dev(dy)
     if act is not None:
         L.call("ladder_act_bwd", p(dyd), p(dev(yr.detach().numpy())), p(dyd), dyd.numel(), L.ACT[act], st)
