@@ -6,6 +6,8 @@ every arithmetic op below is a call into libladder_hip.so (see _lib.py) -- there
 import math
 
 import numpy as np
+import os
+
 import torch
 
 from . import _lib as L
@@ -181,6 +183,11 @@ class Ctx:
         self._amax = {}      # id(tensor) -> (weakref, absolute-maximum record)
         self._planes = {}    # id(tensor) -> (weakref, pre-split planes)
         self.pack_banks, self._pack_table = [], None              # split filter images known so far; their device job table
+        # second HIP stream for the filter gradients (MFMA-bound, needed only by the optimiser step): they run beside the backward-data /
+        # resize / norm backward kernels of the layers below, which are HBM-bound and fit on the same CUs (Conv2D.backward, join_side)
+        self.side, self._side_active, self._side_refs = None, False, []
+        self._ws_side = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
+        self._ws_side_retired = []
         self.keep_activations = True   # False inside forward-only runs: fused kernels may skip writing tensors only a backward pass reads
         self.ns = 0          # LADDER_PREC_* of the split-precision contraction kernels (0 = native f32 MFMA); set by the engine
 
@@ -188,7 +195,38 @@ class Ctx:
     def stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def fork_side(self, *keep):
+        """Context manager: what is launched inside runs on the side stream, ordered after everything enqueued on the main stream so
+        far.  `keep`: tensors the side stream reads -- referenced until join_side() so that the caching allocator (which only knows the
+        main stream) does not hand their memory out again."""
+        ev = torch.cuda.Event()
+        ev.record()
+        self.side.wait_event(ev)
+        self._side_refs.extend(k for k in keep if k is not None)
+        self._side_active = True
+        return torch.cuda.stream(self.side)
+
+    def side_or_main(self, *keep):
+        """fork_side() when the side stream is enabled (eager mode, not inside a hipGraph capture), else a no-op context."""
+        if self.side is None or torch.cuda.is_current_stream_capturing():
+            import contextlib
+            return contextlib.nullcontext()
+        return self.fork_side(*keep)
+
+    def join_side(self):
+        """The main stream waits for the side stream (before anything reads the filter gradients)."""
+        if self._side_active:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+            self._side_active = False
+            self._side_refs.clear()
+            self._ws_side_retired.clear()
+
     def ws(self, nbytes):
+        if self.side is not None and torch.cuda.current_stream(self.device) == self.side:      # the side stream has its own scratch
+            if self._ws_side.numel() < nbytes:
+                self._ws_side_retired.append(self._ws_side)
+                self._ws_side = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+            return self._ws_side.data_ptr(), self._ws_side.numel()
         if self._ws.numel() < nbytes:
             # a captured hipGraph has the pointer of the workspace it was recorded with baked in: superseded buffers stay alive (the
             # caching allocator must never hand their memory to a live tensor) and every graph recorded so far is dropped, so the
@@ -340,6 +378,7 @@ class ParamStore:
         """clip to [-1,1] + TF-form Adam on the whole group (codes/base.py:459-517); lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is
         evaluated on the device from the device step counter.  `grad` may be a device pointer into the scalars vector
         (n = 1) for the two scalar optimisers."""
+        self.ctx.join_side()                                    # filter gradients computed on the side stream
         self.set_lr(group, lr)
         self.step[group] += 1
         self.version[group] += 1
@@ -526,10 +565,11 @@ class Conv2D:
             self.x = self.y = None
             return dx
         if wgrad and self._rgb(N, H, W):
-            wsp, wsn = self.ctx.ws(L.query("ladder_conv_rgb_s2_bwd_filter_workspace_bytes", N, H, W, self.cout))
-            L.call("ladder_conv_rgb_s2_bwd_filter", _p(x), _p(self.ctx.absmax(x)), _p(dy), _p(self.ctx.absmax(dy)),
-                   _p(self.ps.g[self.name + "/kernel"]), _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, N, H, W, self.cout,
-                   wsp, wsn, st)
+            xa, da = self.ctx.absmax(x), self.ctx.absmax(dy)
+            with self.ctx.side_or_main(x, dy, xa, da):
+                wsp, wsn = self.ctx.ws(L.query("ladder_conv_rgb_s2_bwd_filter_workspace_bytes", N, H, W, self.cout))
+                L.call("ladder_conv_rgb_s2_bwd_filter", _p(x), _p(xa), _p(dy), _p(da), _p(self.ps.g[self.name + "/kernel"]),
+                       _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, N, H, W, self.cout, wsp, wsn, self.ctx.stream)
             wgrad = False
         dy_amax = None
         split_w = bool(wgrad and self._split_ok(N, H, W, self.cin, self.cout)
@@ -540,21 +580,27 @@ class Conv2D:
         if split_w or split_d:
             dy_amax = self.ctx.absmax(dy)               # one pass serves the filter gradient and the backward-data call
         if split_w:
-            wsp, wsn = self.ctx.ws(L.query("ladder_conv3x3_wgrad_split_workspace_bytes", N, H, W, self.cin, self.cout))
-            args = (_p(x), _p(self.x_amax), _p(dy), _p(dy_amax), _p(self.ps.g[self.name + "/kernel"]),
-                    _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, N, H, W, self.cin, self.cout, self.ctx.ns, wsp, wsn, st)
-            _timed(9120 + self.ctx.ns, 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_wgrad_split", args)
+            # (on the side stream: the filter gradient is MFMA-bound and only the optimiser step needs it; the backward-data call below
+            # and the HBM-bound resize / norm backward kernels of the layers underneath run beside it)
+            with self.ctx.side_or_main(x, dy, self.x_amax, dy_amax):
+                wsp, wsn = self.ctx.ws(L.query("ladder_conv3x3_wgrad_split_workspace_bytes", N, H, W, self.cin, self.cout))
+                args = (_p(x), _p(self.x_amax), _p(dy), _p(dy_amax), _p(self.ps.g[self.name + "/kernel"]),
+                        _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, N, H, W, self.cin, self.cout, self.ctx.ns, wsp, wsn,
+                        self.ctx.stream)
+                _timed(9120 + self.ctx.ns, 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_wgrad_split", args)
         elif wgrad and self.ctx.ns and L.query("ladder_conv2d_bwd_filter_split_eligible", N, H, W, self.cin, Ho, Wo, self.cout, self.k,
                                                self.k, self.stride, self.pt, self.pl):
             if self.ctx.ns == 4:
                 if getattr(self, "x_amax", None) is None:
                     self.x_amax = self.ctx.absmax(x)
                 dy_amax = self.ctx.absmax(dy)
-            wsp, wsn = self.ctx.ws(L.query("ladder_conv2d_bwd_filter_split_workspace_bytes", N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k))
-            L.call("ladder_conv2d_bwd_filter_split", _p(self.ctx.planes(x)), _p(self.x_amax), _p(self.ctx.planes(dy)), _p(dy_amax),
-                   _p(self.ps.g[self.name + "/kernel"]),
-                   _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k,
-                   self.stride, self.pt, self.pl, self.ctx.ns, wsp, wsn, st)
+            xpl, dpl = self.ctx.planes(x), self.ctx.planes(dy)          # (split on the main stream: backward-data reads dy's planes too)
+            with self.ctx.side_or_main(x, dy, xpl, dpl, self.x_amax, dy_amax):
+                wsp, wsn = self.ctx.ws(L.query("ladder_conv2d_bwd_filter_split_workspace_bytes", N, H, W, self.cin, Ho, Wo, self.cout, self.k,
+                                               self.k))
+                L.call("ladder_conv2d_bwd_filter_split", _p(xpl), _p(self.x_amax), _p(dpl), _p(dy_amax), _p(self.ps.g[self.name + "/kernel"]),
+                       _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k,
+                       self.stride, self.pt, self.pl, self.ctx.ns, wsp, wsn, self.ctx.stream)
         elif wgrad:
             nb = L.query("ladder_conv2d_bwd_filter_workspace_bytes", N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k)
             wsp, wsn = self.ctx.ws(nb)
@@ -1108,6 +1154,9 @@ class LadderEngine:
         self._run_calls = 0
         self._gm_packed = None
         self.use_graphs = False
+        # filter gradients on a second stream beside the backward chain (config key `overlap_filter_gradients`, default on)
+        if bool(int(cfg.get("overlap_filter_gradients", os.environ.get("LADDER_OVERLAP_FILTER_GRADIENTS", 1)))):
+            self.ctx.side = torch.cuda.Stream(device=self.ctx.device)
         self._graphs, self._warm = {}, {}
         self._dec_range = self.ps.prefix_range("ae", "decoder/")   # C1 bucket boundary (data parallel)
 
@@ -1307,6 +1356,7 @@ class LadderEngine:
             # the encoder weights receive two gradient contributions (data pass + pseudo-input pass); the filter-gradient kernels
             # overwrite, so the pseudo-pass result is parked and added back after the data pass
             self._vamp_backward(wgrad=True, need_input_dx=False)
+            ctx.join_side()
             lo, hi = self._enc_range
             saved_enc = self.ps.grad["ae"][lo:hi].clone()
         dxhat = torch.empty_like(self.xhat)
@@ -1317,6 +1367,7 @@ class LadderEngine:
             # C1, first bucket: every decoder gradient is final here (~3/4 of the 72 MB); its all-reduce runs over xGMI
             # while the inner-VAE and encoder backward kernels keep the CUs busy.  The rest follows in _ae.
             lo, hi = self._dec_range
+            ctx.join_side()                                       # the decoder's filter gradients are final only after the side stream
             self._c1_pending = ctx.comm.allreduce_async_(self.ps.grad["ae"][lo:hi])
         mode = 1
         if self.has_inner and not self.use_sg:
@@ -1338,6 +1389,7 @@ class LadderEngine:
         L.call("ladder_latent_bwd", _p(dz), _p(mu), _p(sd), _p(sd_raw), _p(eps_z), _p(ex_mu), _p(ex_sd), -1.0, _p(self.scalars), mode,
                _p(dmu), _p(dsdraw), B, Z, st)
         self.encoder.backward(dmu, dsdraw)
+        ctx.join_side()
         if saved_enc is not None:
             lo, hi = self._enc_range
             add_(ctx, self.ps.grad["ae"][lo:hi], saved_enc)
@@ -1440,7 +1492,10 @@ class LadderEngine:
         lr_t, noise stream position) lives in device memory, so a replay is exactly the eager run."""
         fn = getattr(self, "_" + kind)
         if not self.use_graphs or noise is not None or self.ctx.comm.on:
-            return fn(x, lr, noise, use_sg, use_mask, reuse_encoder)
+            try:
+                return fn(x, lr, noise, use_sg, use_mask, reuse_encoder)
+            finally:
+                self.ctx.join_side()
         group = self._GROUP[kind]
         tok = self._batch_token(x)
         xin = self._dev(x)
