@@ -1154,8 +1154,10 @@ class LadderEngine:
         self._run_calls = 0
         self._gm_packed = None
         self.use_graphs = False
-        # filter gradients on a second stream beside the backward chain (config key `overlap_filter_gradients`, default on)
-        if bool(int(cfg.get("overlap_filter_gradients", os.environ.get("LADDER_OVERLAP_FILTER_GRADIENTS", 1)))):
+        # filter gradients on a second stream beside the backward chain (config key `overlap_filter_gradients` / environment variable
+        # LADDER_OVERLAP_FILTER_GRADIENTS): +0.7-1 % per iteration, bit-identical results -- OFF by default because kernels that share the
+        # chip stretch each other, so the per-kernel HIP-event durations bench.py reports (roofline.achieved) stop describing the kernels
+        if bool(int(cfg.get("overlap_filter_gradients", os.environ.get("LADDER_OVERLAP_FILTER_GRADIENTS", 0)))):
             self.ctx.side = torch.cuda.Stream(device=self.ctx.device)
         self._graphs, self._warm = {}, {}
         self._dec_range = self.ps.prefix_range("ae", "decoder/")   # C1 bucket boundary (data parallel)

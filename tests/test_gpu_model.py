@@ -897,3 +897,11 @@ def test_celeba_iteration_is_bit_reproducible(tmp_path):
     assert len(r["a"]) == len(r["b"]) == 11
     for i, (u, v) in enumerate(zip(r["a"], r["b"])):
         assert u == v, (i, u, v)
+    # the same two iterations with the filter gradients on the second HIP stream (overlap_filter_gradients): bit-identical again
+    outp2 = str(tmp_path / "repro_side.json")
+    p = subprocess.run([sys.executable, str(script), outp2], env=dict(os.environ, LADDER_OVERLAP_FILTER_GRADIENTS="1"), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:]
+    r2 = json.load(open(outp2))
+    for i, (u, v) in enumerate(zip(r["a"], r2["a"])):
+        assert u == v, ("side stream", i, u, v)
