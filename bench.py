@@ -1,29 +1,40 @@
 """bench.py -- the reference's headline workload on MI355X: LaDDer training iterations, CelebA 128x128.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1 without a launcher: spawns the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" = one pass of the hot path over one minibatch = the reference's four sess.run's (codes/base.py:583-641) in
 the post-pretraining regime (fitted-GM feed, prior + inner-sigma training on), through the trainer's own step functions.
 Workload at N=1: BASELINE.json configs[2] (codes/celeba_config.json: CelebA 128x128, nh=512, z=64, R=2, K=30, B=128);
-N>1: the same per-GPU batch on every rank (weak scaling, global batch N*128) with RCCL all-reduces C1-C4.
+N>1: the same per-GPU batch on every rank (weak scaling, global batch N*128 = configs[3] at N=8) with RCCL all-reduces C1-C4;
+`--config codes/celeba_r8k50_config.json` is the per-GPU leg of configs[4] (2-rung ladder, R=8, K=50).
 Inputs are synthetic (x ~ U[0,1), seeded Glorot weights) and resident in HBM before the timed region starts.
-Prints ONE JSON line on rank 0.
+
+Timing: W warm-up steps, then `--repeats` (5) timed regions of EXACTLY K steps each, every region bracketed by
+barrier + torch.cuda.synchronize() on both sides and reduced with MAX over ranks; `value` is the MEDIAN region (all regions are
+listed in `repeats_images_per_sec`).  A `sustained` leg of >= 30 s of back-to-back steps follows (clock / power settle there).
+Prints ONE JSON line on rank 0.  Exits non-zero when the number of ranks actually running differs from --gpus.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FWD_FLOP_PER_IMG = {"celeba": 41.4e9}   # RUN#1 30.1 + RUN#2 10.0 + RUN#3 0.63 + RUN#4 0.62 GFLOP / image / iteration
+# SURVEY 8(d), CelebA nh=512 z=64: forward 10.04 GFLOP / image (encoder 0.614 + decoder 9.420 + inner VAE 0.0044)
+#   algorithmic: RUN#1 30.1 + RUN#2 10.0 + RUN#3 0.63 + RUN#4 0.62 = 41.4 GFLOP / image / iteration (what the reference's four sess.run evaluate)
+#   executed:    RUN#3 and RUN#4 reuse RUN#2's encoder output (same minibatch, unchanged encoder weights: bit-identical):
+#                2 x 0.614 GFLOP of the 41.4 are never issued -> 40.17
+FLOP_PER_IMG = {"celeba": {"algorithmic": 41.4e9, "executed": 41.4e9 - 2 * 0.614e9}}
 FP32_PEAK_TFLOPS = 157.3                # MI355X_MICROARCH.md: fp32 MFMA (= vector) dense peak
 F16_PEAK_TFLOPS = 2516.6                # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak (256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz)
 # matrix instructions issued per algorithmic fp32 multiply-add by each matmul_precision (csrc/convsplit.hip)
 MFMA_PER_PRODUCT = {"f32": 1, "f16x3": 3, "bf16x3": 3, "bf16x6": 6}
+TRAFFIC_FILES = {"f16x3": ("r03_pmc_traffic.json", "r02_pmc_traffic.json"), "f32": ("r01_pmc_traffic.json",)}
 
 
 def cpu_baseline(cfg, gm, seconds_budget=20.0, threads=None):
@@ -54,27 +65,96 @@ def cpu_baseline(cfg, gm, seconds_budget=20.0, threads=None):
         t_tot += one(x)
         n_it += 1
     return dict(value=round(Bc * n_it / t_tot, 3), unit="images/sec", cores=cores, kind="port",
-                sample="%d full 4-run iterations at batch %d of the same CelebA 128x128 nh=512 z=64 K=30 network "
-                       "(oracle/ladder_oracle.py, torch-CPU fp32, %d threads)" % (n_it, Bc, cores))
+                sample="%d full 4-run iterations at batch %d of the same %s %dx%d nh=%d z=%d R=%d K=%d network "
+                       "(oracle/ladder_oracle.py, torch-CPU fp32, %d threads)" % (
+                           n_it, Bc, cfg["exp_name"], cfg["dim_input_x"], cfg["dim_input_y"], cfg["num_hidden_units"], cfg["code_size"],
+                           cfg["representation_size"], cfg["n_mixtures"], cores))
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks as fresh child processes through
+    torch.distributed.run.  This parent has not touched the GPU (torch.cuda.device_count() does not initialise it on this image), and it
+    never re-executes itself: it waits for the children and exits with their status."""
+    import socket
+    import torch
+    one_dev = os.environ.get("LADDER_BENCH_SINGLE_DEVICE") == "1"
+    have = torch.cuda.device_count()
+    if have < args.gpus and not one_dev:
+        sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) are visible: refusing to print a %d-GPU number under an "
+                         "%d-GPU label\n" % (args.gpus, have, have, args.gpus))
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def workload_index(cfg, world):
+    if cfg["exp_name"] == "mnist_digit":
+        return "0"
+    if cfg["exp_name"] == "mnist_fashion":
+        return "1"
+    if int(cfg["representation_size"]) == 8 and int(cfg["n_mixtures"]) == 50:
+        return "4" if world == 8 else "4, per-GPU leg at %d GPU(s)" % world
+    return "2" if world == 1 else ("3" if world == 8 else "3, per-GPU leg at %d GPUs" % world)
+
+
+def roofline_of(prof, precision, step_seconds, traffic_for=None):
+    """The dominant contraction kernel (largest share of GPU time) of a profiled leg against its MFMA peak."""
+    dom = max((r for r in prof.values() if r.get("bound", "mfma") == "mfma"), key=lambda r: r["total_ms"])
+    split = "split" in dom["kernel"]
+    nm = MFMA_PER_PRODUCT[precision] if split else 1
+    # peak for the ALGORITHMIC (fp32) flops of the kernel: the dense MFMA peak of the instruction it issues divided by the number of
+    # matrix instructions it needs per fp32 product (f16x3: 2516.6 / 3); native fp32 kernels: the fp32 MFMA peak
+    peak = (F16_PEAK_TFLOPS / nm) if split else FP32_PEAK_TFLOPS
+    traffic, tsrc = None, None
+    if traffic_for:
+        for fn in TRAFFIC_FILES.get(precision, ()):
+            tpath = os.path.join(ROOT, "profiles", fn)
+            if os.path.isfile(tpath):
+                tj = json.load(open(tpath))
+                if tj.get("kernel", "") in dom["kernel"]:
+                    traffic = tj["hbm_bytes_per_launch"]
+                    tsrc = ("static: profiles/%s -- two separate `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE; gfx950 corrections per "
+                            "MI355X_MICROARCH.md) over this same command and launch mix; not re-measured in this run" % fn)
+                break
+    return {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2), "peak": round(peak, 1),
+            "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": traffic, "traffic_source": tsrc,
+            "peak_basis": ("dense %s MFMA peak %.1f TFLOP/s / %d matrix instructions per fp32 product" % (
+                "fp16" if precision == "f16x3" else "bf16", F16_PEAK_TFLOPS, nm)) if split else "fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
+            "mfma_issued_tflops": round(dom["tflops"] * nm, 1),
+            "launches": dom["launches"], "avg_launch_ms": round(dom["avg_ms"], 4),
+            "flop_per_launch": dom["flops_per_launch"],
+            "share_of_step_time": round(dom["total_ms"] / (1e3 * step_seconds), 3),
+            "other_kernels": [{"kernel": r["kernel"], "achieved": round(r["tflops"], 2), "launches": r["launches"],
+                               "avg_launch_ms": round(r["avg_ms"], 4)} for r in prof.values() if r is not dom and r.get("bound", "mfma") == "mfma"]}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; `value` is their median")
+    ap.add_argument("--sustained-seconds", type=float, default=30.0, help="length of the sustained-throughput leg (0: skip)")
     ap.add_argument("--config", default=os.path.join(ROOT, "codes", "celeba_config.json"))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (default: config batch_size)")
     ap.add_argument("--precision", default="", help="matmul_precision override: f32 | bf16x6 | bf16x3 (default: the engine's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--no-compare", action="store_true", help="skip the native-fp32 comparison run after the timed region")
+    ap.add_argument("--no-compare", action="store_true", help="skip the native-fp32 leg after the timed region")
     ap.add_argument("--graphs", type=int, default=-1,
                     help="0: eager launches, the dominant kernel is timed with HIP events INSIDE the timed region (default for "
                          "CelebA, where replay changes nothing); 1: replay each run as a captured hipGraph (default for the MNIST "
                          "configs, whose ~350 short launches per iteration are host-bound in eager mode: 2.87 -> 2.49 ms on digit); "
                          "the per-kernel profile then comes from a second, eager pass after the timed region")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)                                       # never returns
 
     import numpy as np
     import torch
@@ -83,6 +163,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d rank(s) are running: refusing to report under the wrong label\n"
+                             % (args.gpus, world))
+        sys.exit(2)
     # test hook (tests/test_gpu_model.py): all ranks on cuda:0 over gloo, to exercise the multi-rank path of this script on a
     # 1-GPU box (RCCL refuses two ranks on one device).  Never set by the driver.
     one_dev = os.environ.get("LADDER_BENCH_SINGLE_DEVICE") == "1"
@@ -94,6 +179,13 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    ones = torch.ones(1, device="cuda")
+    if world > 1:
+        dist.all_reduce(ones)
+    ranks_seen = int(ones.item())
+    if ranks_seen != args.gpus:
+        sys.stderr.write("bench.py: all-reduce of ones saw %d ranks, --gpus %d\n" % (ranks_seen, args.gpus))
+        sys.exit(2)
 
     from ladder_latent_data_distribution_modelling_amd import engine as E
     from ladder_latent_data_distribution_modelling_amd.codes.models import CelebAModel_densenet, MNISTModel_digit, MNISTModel_fashion
@@ -122,7 +214,7 @@ def main():
     if R == 2 and K <= 50:
         w = fix["w_full"][:K] / fix["w_full"][:K].sum()
         gm = dict(weights=w, means=fix["m_full"][:K], covs=fix["K_full"][:K])
-    else:
+    else:                                                       # m ~ N(0, 1.5^2), Sigma = A A^T / R + 0.05 I, w ~ Dirichlet(1)
         rng = np.random.default_rng(3)
         A = rng.normal(0, 0.3, (K, R, R))
         gm = dict(weights=rng.dirichlet(np.ones(K)), means=rng.normal(0, 1.5, (K, R)),
@@ -141,6 +233,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(fn, n):
+        """EXACTLY n calls bracketed by barrier + synchronize on both sides; seconds, MAX over ranks."""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     if graphs:                                                  # set-up, not warm-up: capture the four run graphs first
         for _ in range(8):
             step()
@@ -148,93 +252,92 @@ def main():
     for _ in range(args.warmup):
         step()
     if not args.no_profile and not graphs:
-        E.PROF = E.KernelProfiler()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+        E.PROF = E.KernelProfiler()                             # HIP events around the contraction launches INSIDE the timed regions
+    dts = [timed(step, args.steps) for _ in range(max(1, args.repeats))]
+    prof_seconds = sum(dts)
     if graphs and not args.no_profile:                         # per-kernel HIP events need individual launches: eager pass, untimed
         trainer.engine.use_graphs = False
         E.PROF = E.KernelProfiler()
-        for _ in range(args.steps):
-            step()
-        barrier()
+        prof_seconds = timed(step, args.steps)
     prof = E.PROF.summary() if E.PROF is not None else None
     E.PROF = None
-    tdt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
-    dt = float(tdt.item())
+    dt = sorted(dts)[len(dts) // 2]                              # the median region
     value = B * world * args.steps / dt
     f = trainer.last_fetch_ae
+    exp_label = {"celeba": "CelebA", "mnist_digit": "MNIST-digit", "mnist_fashion": "MNIST-fashion"}[cfg["exp_name"]]
     out = {
-        "metric": "training images/sec (full 4-run LaDDer iteration, %s %dx%d)" % (
-            {"celeba": "CelebA", "mnist_digit": "MNIST-digit", "mnist_fashion": "MNIST-fashion"}[cfg["exp_name"]],
-            cfg["dim_input_x"], cfg["dim_input_y"]), "value": round(value, 2), "unit": "images/sec",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+        "metric": "training images/sec (full 4-run LaDDer iteration, %s %dx%d)" % (exp_label, cfg["dim_input_x"], cfg["dim_input_y"]),
+        "value": round(value, 2), "unit": "images/sec",
+        "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if precision == "f32" else "f32 (%s split MFMA)" % precision,
         "data": "synthetic",
-        "config": {"workload": "BASELINE configs[" + {"mnist_digit": "0", "mnist_fashion": "1", "celeba": "2"}[cfg["exp_name"]] + "]: %s %dx%dx%d nh=%d z=%d R=%d K=%d L=%d per-GPU batch=%d, 4 runs/iteration "
+        "config": {"workload": "BASELINE configs[%s]: %s %dx%dx%d nh=%d z=%d R=%d K=%d L=%d per-GPU batch=%d, 4 runs/iteration "
                                "(AE step, sigma step, prior step, inner-sigma step), fitted-GM regime" % (
-                                   cfg["exp_name"], cfg["dim_input_x"], cfg["dim_input_y"], cfg["dim_input_channel"],
+                                   workload_index(cfg, world), cfg["exp_name"], cfg["dim_input_x"], cfg["dim_input_y"], cfg["dim_input_channel"],
                                    cfg["num_hidden_units"], cfg["code_size"], R, K, cfg["n_MC_samples"], B),
                    "global_batch": B * world, "parallelism": "dp%d" % world},
+        "timing": "median of %d timed regions of exactly %d steps (each: barrier + synchronize on both sides, MAX over ranks)" % (len(dts), args.steps),
+        "repeats_images_per_sec": [round(B * world * args.steps / t, 2) for t in dts],
         "launch": "hipGraph replay (4 graphs/iteration)" if graphs else "eager", "matmul_precision": precision,
         "elbo": f["elbo"], "elbo_prior": trainer.last_fetch_prior["elbo_prior"],
     }
     if prof:
-        dom = max(prof.values(), key=lambda r: r["total_ms"])       # the dominant kernel = largest share of GPU time
-        traffic = None      # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json), same launch mix
-        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json" if precision == "f16x3" else "r01_pmc_traffic.json")
-        if os.path.isfile(tpath) and cfg["exp_name"] == "celeba" and B == 128:
-            tj = json.load(open(tpath))
-            if tj.get("kernel", "") in dom["kernel"]:
-                traffic = tj["hbm_bytes_per_launch"]
-        split = "split" in dom["kernel"]
-        nm = MFMA_PER_PRODUCT[precision] if split else 1
-        # peak for the ALGORITHMIC (fp32) flops of the dominant kernel: the dense MFMA peak of the instruction it issues divided by
-        # the number of matrix instructions it needs per fp32 product (f16x3: 2516.6 / 3); native fp32 kernels: the fp32 MFMA peak
-        peak = (F16_PEAK_TFLOPS / nm) if split else FP32_PEAK_TFLOPS
-        out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2), "peak": round(peak, 1),
-                           "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": traffic,
-                           "peak_basis": ("dense %s MFMA peak %.1f TFLOP/s / %d matrix instructions per fp32 product" % (
-                               "fp16" if precision == "f16x3" else "bf16", F16_PEAK_TFLOPS, nm)) if split else "fp32 MFMA peak",
-                           "mfma_issued_tflops": round(dom["tflops"] * nm, 1),
-                           "launches": dom["launches"], "avg_launch_ms": round(dom["avg_ms"], 4),
-                           "flop_per_launch": dom["flops_per_launch"],
-                           "share_of_step_time": round(dom["total_ms"] / (1e3 * dt), 3),
-                           "other_kernels": [{"kernel": r["kernel"], "achieved": round(r["tflops"], 2), "launches": r["launches"],
-                                              "avg_launch_ms": round(r["avg_ms"], 4)} for r in prof.values() if r is not dom]}
+        out["roofline"] = roofline_of(prof, precision, prof_seconds, traffic_for=(cfg["exp_name"] == "celeba" and B == 128))
+        mix = [r for r in prof.values() if r.get("bound") == "latency"]
+        if mix:                                                 # the hyper-prior ELBO kernel (configs[4] stresses it): lane = component
+            r = mix[0]
+            out["mixture_kernel"] = {"kernel": r["kernel"], "launches": r["launches"], "avg_launch_us": round(1e3 * r["avg_ms"], 2),
+                                     "component_evals_per_launch": int(cfg["n_MC_samples"]) * B * K,
+                                     "component_gevals_per_sec": round(int(cfg["n_MC_samples"]) * B * K / (r["avg_ms"] * 1e-3) / 1e9, 2),
+                                     "share_of_step_time": round(r["total_ms"] / (1e3 * prof_seconds), 5)}
+    # sustained leg: >= `--sustained-seconds` of back-to-back steps (the short regions above run before clocks / power settle)
+    if args.sustained_seconds > 0:
+        n_s = max(args.steps, int(args.sustained_seconds / (dt / args.steps)) + 1)
+        t_s = timed(step, n_s)
+        out["sustained"] = {"seconds": round(t_s, 2), "steps": n_s, "images_per_sec": round(B * world * n_s / t_s, 2),
+                            "ms_per_step": round(1e3 * t_s / n_s, 3)}
     # also the AE-step-only (RUN#1) and forward-only (val_step, VAE fetches) rates; untimed extras after the metric
-    def rate(fn, n=max(3, args.steps // 2)):
-        fn()
-        barrier()
-        t = time.perf_counter()
-        for _ in range(n):
-            fn()
-        barrier()
-        t = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device="cuda")
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return round(B * world * n / float(t.item()), 2)
+    n_x = max(3, args.steps // 2)
     use_sg, use_mask = trainer.compute_feeddict(x, "VAE")
-    out["ae_step_only_images_per_sec"] = rate(lambda: (trainer.engine.run_ae(x, lr, None, use_sg, use_mask), trainer.engine.fetch()))
-    out["forward_only_images_per_sec"] = rate(lambda: trainer.val_step("VAE", x))
+    ae_only = lambda: (trainer.engine.run_ae(x, lr, None, use_sg, use_mask), trainer.engine.fetch())
+    ae_only()
+    out["ae_step_only_images_per_sec"] = round(B * world * n_x / timed(ae_only, n_x), 2)
+    fwd_only = lambda: trainer.val_step("VAE", x)
+    fwd_only()
+    out["forward_only_images_per_sec"] = round(B * world * n_x / timed(fwd_only, n_x), 2)
     if precision != "f32" and cfg["exp_name"] == "celeba" and not args.no_compare:
-        # the same iteration with every contraction on the native fp32 MFMA kernels (round-1 path), untimed extra for comparison
+        # the SAME iteration with every contraction on the native fp32 MFMA kernels (v_mfma_f32_32x32x2_f32: bit-exact fp32 FMA
+        # chains, the round-1 path): first-class second number with its own roofline against the fp32 peak
         cfg32 = dict(cfg, matmul_precision="f32")
         with contextlib.redirect_stdout(io.StringIO()):
             model32 = Model(cfg32, device="cuda:%d" % local, seed=1)
         tr32 = BaseTrain_joint(None, model32, None, cfg32)
         tr32.cur_epoch, tr32.gm_params = trainer.cur_epoch, trainer.gm_params
-        out["native_f32_images_per_sec"] = rate(lambda: (tr32.train_step_ae(cur_lr=lr, batch_data=x), tr32.train_step_prior(batch_data=x)))
+        step32 = lambda: (tr32.train_step_ae(cur_lr=lr, batch_data=x), tr32.train_step_prior(batch_data=x))
+        for _ in range(3):
+            step32()
+        if not args.no_profile:
+            E.PROF = E.KernelProfiler()
+        t32 = timed(step32, n_x)
+        p32 = E.PROF.summary() if E.PROF is not None else None
+        E.PROF = None
+        v32 = B * world * n_x / t32
+        out["native_f32"] = {"images_per_sec": round(v32, 2), "ms_per_step": round(1e3 * t32 / n_x, 3), "steps": n_x, "dtype": "f32",
+                             "elbo": tr32.last_fetch_ae["elbo"]}
+        out["native_f32_images_per_sec"] = round(v32, 2)
+        if p32:
+            out["native_f32"]["roofline"] = roofline_of(p32, "f32", t32)
+            out["roofline_native_f32"] = out["native_f32"]["roofline"]
         del tr32, model32
-    whole = FWD_FLOP_PER_IMG.get(cfg["exp_name"])
-    if whole and int(cfg["num_hidden_units"]) == 512 and int(cfg["code_size"]) == 64:
-        out["whole_step_tflops_per_gpu"] = round(whole * value / world / 1e12, 2)
+    fl = FLOP_PER_IMG.get(cfg["exp_name"])
+    if fl and int(cfg["num_hidden_units"]) == 512 and int(cfg["code_size"]) == 64:
+        out["flop_per_image"] = dict(fl, note="RUN#3/#4 reuse RUN#2's encoder output (bit-identical): 1.23 GFLOP of the algorithmic "
+                                              "41.4 are not executed")
+        out["whole_step_tflops_per_gpu"] = round(fl["executed"] * value / world / 1e12, 2)
+        if "native_f32" in out:
+            out["native_f32"]["whole_step_tflops_per_gpu"] = round(fl["executed"] * out["native_f32"]["images_per_sec"] / world / 1e12, 2)
+            out["native_f32"]["whole_step_frac_of_fp32_peak"] = round(out["native_f32"]["whole_step_tflops_per_gpu"] / FP32_PEAK_TFLOPS, 4)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, gm)
     if rank == 0:

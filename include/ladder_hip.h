@@ -350,6 +350,10 @@ int ladder_gmm_logprob_fwd_bwd(const float* mu, const float* sd, const float* ep
                                int L, int B, int R, int K, float* sum_logp, float* dmu, float* dsd,
                                void* ws, size_t ws_bytes, ladder_stream_t stream);
 
+/* log p(t_i) of n separate points t [n,R] under the prepared mixture (R in 1..8), one wavefront per point.  Replaces
+ * `sess.run(prior.prob(pos))` / `prior.log_prob` on the tfd.Mixture the reference's demo builds (demo/demo_tools.py:88-99, 265). */
+int ladder_gmm_logprob_rows(const float* t, const float* packed, int n, int R, int K, float* logp, ladder_stream_t stream);
+
 /* ---------------------------------------------------------------- N10: ELBO reductions + scalar algebra
  * codes/base.py:262-305,374-402; codes/models.py:152-159,319-326,591-597.
  *
@@ -438,6 +442,10 @@ size_t ladder_gmm_dense_workspace_bytes(int L, int B, int R, int K);
 int ladder_gmm_dense_logprob_fwd_bwd(const float* mu, const float* sd, const float* eps, const float* params, int L, int B, int R,
                                      int K, float* sum_logp, float* dmu, float* dsd, void* ws, size_t ws_bytes,
                                      ladder_stream_t stream);
+
+/* per-point log p(t_i), t [n,R], on the wide-latent path (same workspace size as the training call with L = 1, B = n). */
+int ladder_gmm_dense_logprob_rows(const float* t, const float* params, int n, int R, int K, float* logp, void* ws, size_t ws_bytes,
+                                  ladder_stream_t stream);
 
 /* ---- VampPrior (codes/base.py:216-254, 361-370): equally weighted mixture of K DIAGONAL Gaussians on z (Z <= 64) whose
  * components (comp_mean, comp_sd [K,Z]) are the encoder's outputs on the trainable pseudo-inputs.  sum_logp = sum over the L*B MC

@@ -71,6 +71,8 @@ PROTOTYPES = {
     "ladder_gmm_prepare": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "ladder_gmm_workspace_bytes": (_z, [_i, _i]),
     "ladder_gmm_logprob_fwd_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _z, _p]),
+    "ladder_gmm_logprob_rows": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "ladder_gmm_dense_logprob_rows": (_i, [_p, _p, _i, _i, _i, _p, _p, _z, _p]),
     "ladder_pixel_partials_workspace_bytes": (_z, [_z]),
     "ladder_pixel_partials": (_i, [_p, _p, _z, _p, _p, _z, _p]),
     "ladder_pixel_grad": (_i, [_p, _p, _p, _p, _z, _p]),

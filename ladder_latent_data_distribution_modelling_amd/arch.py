@@ -23,6 +23,28 @@ def conv_out(n_in, k, s, padding):
     return 0, (n_in - k) // s + 1
 
 
+_RESIZE_GAIN = {}
+
+
+def resize_transpose_gain(n_in, n_out):
+    """Largest column sum of the 1-D TF1-legacy bilinear interpolation matrix n_in -> n_out (tf.image.resize_images without
+    half-pixel centres: src = y * n_in / n_out, neighbours floor(src) and min(floor(src) + 1, n_in - 1)).  The transpose of the resize
+    multiplies max|dy| by at most this factor per axis; the LAST source row also collects the clamped outputs, so for an integer
+    factor f the maximum is 1.5 f - 0.5 (2.5 for f = 2), not f."""
+    key = (int(n_in), int(n_out))
+    g = _RESIZE_GAIN.get(key)
+    if g is None:
+        col = np.zeros(key[0])
+        src = np.arange(key[1], dtype=np.float64) * (key[0] / key[1])
+        i0 = np.floor(src).astype(np.int64)
+        i1 = np.minimum(i0 + 1, key[0] - 1)
+        fr = src - i0
+        np.add.at(col, i0, 1.0 - fr)
+        np.add.at(col, i1, fr)
+        g = _RESIZE_GAIN[key] = float(col.max())
+    return g
+
+
 def tfname(base, i):
     return base if i == 0 else "%s_%d" % (base, i)
 

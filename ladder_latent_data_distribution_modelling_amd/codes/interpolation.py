@@ -59,6 +59,8 @@ class SLPInterpolator:
         """Notebook cells 18-21.  Returns (pts [n_step, R], record dict of the per-iteration loss terms)."""
         start, end = np.asarray(start, np.float64), np.asarray(end, np.float64)
         pts = np.asarray(init, np.float64).copy() if init is not None else np.linspace(start, end, n_step + 1, endpoint=False)[1:]
+        from .utils import register_trainable_scope
+        register_trainable_scope("interpolation", pts.size)      # notebook cell 19: count_trainable_variables('interpolation')
         m, v = np.zeros_like(pts), np.zeros_like(pts)
         rec = dict(loss=[], path_length=[], step_var=[], neg_ll=[])
         for t in range(1, n_iter + 1):

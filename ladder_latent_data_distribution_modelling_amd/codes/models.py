@@ -21,10 +21,14 @@ class BaseModel:
             device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
         self.engine = LadderEngine(config, device, values, seed, comm)
         self.define_GM_prior()
-        ps = self.engine.ps
-        self.num_encoder, self.num_decoder = ps.num_params("encoder/"), ps.num_params("decoder/")
-        self.num_sigma = ps.num_params("sigma/")
-        self.num_prior_ae, self.num_prior_sigma = ps.num_params("prior/"), ps.num_params("inner_sigma/")
+        # codes/base.py:437-451: per-scope counts through the single-argument helper (this model becomes the default "graph")
+        from .utils import count_trainable_variables, set_default_model
+        set_default_model(self)
+        self.num_encoder = count_trainable_variables("encoder")
+        self.num_decoder = count_trainable_variables("decoder")
+        self.num_sigma = count_trainable_variables("sigma")
+        self.num_prior_ae = count_trainable_variables("prior") if config["prior"] in ("ours", "hierarchical", "vampPrior") else 0
+        self.num_prior_sigma = count_trainable_variables("inner_sigma") if config["prior"] in ("ours", "hierarchical") else 0
         self.num_para_list = [self.num_encoder, self.num_decoder, self.num_sigma, self.num_prior_ae, self.num_prior_sigma]
         print("Total number of trainable parameters in VAE network is:\n{}k\n".format(np.around(sum(self.num_para_list) / 1000, 2)))
         self.init_saver()

@@ -23,7 +23,8 @@ PLACEHOLDERS = ("original_signal", "seed", "data_file", "code_input", "is_code_i
                 "is_representation_input", "is_outer_VAE_input", "customised_inner_VAE_input", "prior_mean", "prior_cov",
                 "prior_weight", "use_standard_gaussian_prior", "use_mask", "lr_ae", "lr_sigma", "lr_prior", "lr_inner_sigma")
 TENSORS = ("input_image", "code_mean", "code_std_dev", "code_sample", "decoded", "representation_mean",
-           "representation_std_dev", "representation_sample", "decoded_code", "std_dev_code", "std_dev_representation")
+           "representation_std_dev", "representation_sample", "decoded_code", "std_dev_code", "std_dev_representation",
+           "psedeu_input")        # (sic: the reference's spelling of the VampPrior pseudo-inputs, base.py:219)
 SCALARS = ("sigma", "mean_pixel_error", "inner_sigma", "mean_code_error", "entropy_z", "crossEntropy_prior",
            "crossEntropy_prior_sg", "code_reconstruction_likelihood", "code_l1_reconstruction_error",
            "representation_regularisor", "entropy_t", "crossEntropy_representation", "elbo_prior", "l1_reconstruction_error",
@@ -43,6 +44,15 @@ class Handle:
 
     def __repr__(self):
         return "<ladder.%s %r>" % (self.kind, self.name)
+
+
+class Deferred:
+    """A value that exists once `Session.run` evaluates it -- what a TFP distribution method returns in graph mode
+    (`prior.sample(n)`, `prior.prob(pos)`: demo/demo_tools.py:120, 265 of the reference)."""
+    __slots__ = ("thunk",)
+
+    def __init__(self, thunk):
+        self.thunk = thunk
 
 
 def attach_handles(model):
@@ -74,8 +84,13 @@ class Session:
 
     # ------------------------------------------------------------------------------------------------------------
     def run(self, fetches, feed_dict=None):
+        if isinstance(fetches, Deferred):
+            return fetches.thunk()
         single = isinstance(fetches, Handle)
         flist = [fetches] if single else list(fetches)
+        if flist and all(isinstance(h, Deferred) for h in flist):
+            out = [h.thunk() for h in flist]
+            return tuple(out) if isinstance(fetches, tuple) else out
         for h in flist:
             if not isinstance(h, Handle):
                 raise TypeError("fetch %r is not a model attribute handle" % (h,))
@@ -115,6 +130,13 @@ class Session:
         outer_in = flag("is_outer_VAE_input", True)
         rep_in = flag("is_representation_input", False)
         vals = {}
+        if "psedeu_input" in want:
+            if not eng.vamp:
+                raise ValueError("prior %r has no pseudo-inputs" % eng.cfg["prior"])
+            vals["psedeu_input"] = eng.ps.w["prior/Variable"].detach().cpu().numpy()
+            want = want - {"psedeu_input"}
+            if not want:
+                return vals
 
         ops = [n for n in want if n in TRAIN_OPS]
         if ops:
@@ -185,7 +207,7 @@ class Session:
         if "decoded_code" in want:
             t = eng._dev(need("representation_input")) if rep_in else vals["representation_sample"]
             vals["decoded_code"] = eng.decode_representation(t)
-        return {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in vals.items() if k in want}
+        return {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in vals.items() if k in want or k == "psedeu_input"}
 
     @staticmethod
     def _collect(vals, want, eng, x):

@@ -61,9 +61,38 @@ def create_dirs(dirs):
     return 0
 
 
-def count_trainable_variables(model, scope_name):
-    """Trainable parameter count under a variable scope ("encoder", "decoder", "prior", ...)."""
-    n = model.engine.ps.num_params(scope_name + "/")
+# The reference counts `tf.trainable_variables(scope_name)` of the process-wide DEFAULT GRAPH (utils.py:96-113; called with the scope
+# name only by base.py:438-444 and by the notebook, cell 19: `count_trainable_variables('interpolation')`).  The equivalent here: the
+# most recently constructed model registers its parameter store as the default "graph", and other owners of trainable variables
+# (codes/interpolation.py: the path points of the SLP optimisation) register their scope the same way.
+_DEFAULT_GRAPH = {"model": None, "scopes": {}}
+
+
+def set_default_model(model):
+    """Called by BaseModel.__init__ (the analogue of building the model in TF's default graph)."""
+    import weakref
+    _DEFAULT_GRAPH["model"] = weakref.ref(model)
+
+
+def register_trainable_scope(scope_name, n_parameters):
+    """Trainable variables that live outside a model's parameter store (e.g. scope "interpolation")."""
+    _DEFAULT_GRAPH["scopes"][str(scope_name)] = int(n_parameters)
+
+
+def count_trainable_variables(scope_name, model=None):
+    """Trainable parameter count under a variable scope ("encoder", "decoder", "sigma", "prior", "inner_sigma", "interpolation");
+    same signature, printed line and return value as the reference (utils.py:96-113).  `model` (keyword, optional) selects a model other
+    than the most recently constructed one.  Like tf.trainable_variables, the scope is a name PREFIX ("prior" also matches nothing
+    else here because every scope is followed by "/")."""
+    if not isinstance(scope_name, str):
+        raise TypeError("count_trainable_variables(scope_name): scope_name must be a str (got %r)" % type(scope_name).__name__)
+    m = model
+    if m is None:
+        ref = _DEFAULT_GRAPH["model"]
+        m = ref() if ref is not None else None
+    n = _DEFAULT_GRAPH["scopes"].get(scope_name, 0)
+    if m is not None:
+        n += m.engine.ps.num_params(scope_name + "/")
     print("The total number of trainable parameters in the {} model is: {}k.".format(scope_name, round(n / 1000, 2)))
     return n
 

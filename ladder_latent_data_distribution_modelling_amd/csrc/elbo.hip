@@ -422,6 +422,42 @@ __global__ __launch_bounds__(256) void gmm_logprob_kernel(const float* __restric
   }
   if (threadIdx.x == 0) ws_logp[b] = (sm_lp[0] + sm_lp[1]) + (sm_lp[2] + sm_lp[3]);
 }
+// log p(t_i) of n separate points (density of the fitted mixture on a grid / at embeddings: demo/demo_tools.py prior.prob, log_prob):
+// one wavefront per point, lane = component, same per-component arithmetic as gmm_logprob_kernel.
+template <int R>
+__global__ __launch_bounds__(256) void gmm_rows_kernel(const float* __restrict__ t, const float* __restrict__ packed, int n, int K,
+                                                       float* __restrict__ logp) {
+  constexpr int STRIDE = 1 + R + R * (R + 1) / 2;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  float t_[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) t_[j] = t[(size_t)i * R + j];
+  float mx = -INFINITY, se = 0.f;                 // online logsumexp over this lane's components, then across lanes
+  for (int k = lane; k < K; k += 64) {
+    const float* prm = packed + (size_t)k * STRIDE;
+    float maha = 0.f;
+    int q = 1 + R;
+#pragma unroll
+    for (int a = 0; a < R; ++a) {
+      float ya = 0.f;
+#pragma unroll
+      for (int j = 0; j < R; ++j)
+        if (j <= a) ya += prm[q++] * (t_[j] - prm[1 + j]);
+      maha += ya * ya;
+    }
+    const float lp = prm[0] - 0.5f * maha;
+    const float m2 = fmaxf(mx, lp);
+    se = se * __expf(mx - m2) + __expf(lp - m2);
+    mx = m2;
+  }
+  const float gm = wave_max(mx);
+  se = (mx == -INFINITY) ? 0.f : se * __expf(mx - gm);
+  se = wave_sum(se);
+  if (lane == 0) logp[i] = gm + logf(se);
+}
+
 __global__ __launch_bounds__(64) void gmm_sum_kernel(const double* __restrict__ ws, int B, float* __restrict__ out) {
   double s = 0.0;                                    // one wavefront: lane-strided partial sums, then a fixed-order shuffle tree
   for (int b = threadIdx.x; b < B; b += 64) s += ws[b];
@@ -502,7 +538,8 @@ __global__ void mc_samples_kernel(const float* __restrict__ mu, const float* __r
 
 // one wavefront per MC sample: lp_k = logc_k - 0.5 |Y_k|^2, logsumexp over k, responsibilities; Y <- dlogp/dY = -resp_k * Y_k.
 __global__ __launch_bounds__(256) void gmm_dense_resp_kernel(float* __restrict__ Y, const float* __restrict__ logc, int S, int K, int R,
-                                                             int write_dy, double* __restrict__ ws_lse) {
+                                                             int write_dy, double* __restrict__ ws_lse,
+                                                             float* __restrict__ row_lse = nullptr) {
   extern __shared__ float lp_sh[];               // [4 waves][K]
   __shared__ double blk[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -528,6 +565,7 @@ __global__ __launch_bounds__(256) void gmm_dense_resp_kernel(float* __restrict__
     se = wave_sum(se);
     const float lse = mx + __logf(se);
     lse_d = (double)lse;
+    if (row_lse != nullptr && lane == 0) row_lse[s] = lse;
     if (write_dy)
       for (int k = 0; k < K; ++k) {
         const float r = __expf(lp[k] - lse);
@@ -828,6 +866,13 @@ int ladder_gmm_logprob_fwd_bwd(const float* mu, const float* sd, const float* ep
   return LADDER_OK;
 }
 
+int ladder_gmm_logprob_rows(const float* t, const float* packed, int n, int R, int K, float* logp, ladder_stream_t stream) {
+  if (n <= 0 || K <= 0 || K > 1024) return LADDER_E_SHAPE;
+  LADDER_R_SWITCH(R, hipLaunchKernelGGL(gmm_rows_kernel<RR>, dim3((n + 3) / 4), dim3(256), 0, stream, t, packed, n, K, logp));
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
 size_t ladder_gmm_dense_param_floats(int K, int R) { return (size_t)2 * K * R * R + (size_t)K * R + K; }
 
 int ladder_gmm_prepare_dense(const float* weights, const float* means, const float* covs, int K, int R, float* params,
@@ -881,6 +926,28 @@ int ladder_gmm_dense_logprob_fwd_bwd(const float* mu, const float* sd, const flo
     if (rc != LADDER_OK) return rc;
     hipLaunchKernelGGL(gmm_dense_reduce_kernel, dim3((B * R + 255) / 256), dim3(256), 0, stream, dT, eps, dmu, dsd, L, B * R);
   }
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_gmm_dense_logprob_rows(const float* t, const float* params, int n, int R, int K, float* logp, void* ws, size_t ws_bytes,
+                                  ladder_stream_t stream) {
+  if (n <= 0 || K <= 0 || K > 1024 || R <= 0 || R > GD_MAXR || (R % 4) != 0) return LADDER_E_SHAPE;
+  if (ws == nullptr || ws_bytes < ladder_gmm_dense_workspace_bytes(1, n, R, K)) return LADDER_E_WORKSPACE;
+  const size_t S = (size_t)n;
+  char* p = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  p += 2 * gd_align(S * R * 4);                                  // (T, dT of the training entry point: unused here)
+  float* Y = (float*)p;               p += gd_align(S * K * R * 4);
+  double* lse = (double*)p;           p += gd_align(((S + 3) / 4) * 8);
+  void* gws = p;
+  const size_t gws_bytes = ws_bytes - (size_t)(p - (char*)ws);
+  const float* Bmat = params;
+  const float* bias = Bmat + (size_t)2 * K * R * R;
+  const float* logc = bias + (size_t)K * R;
+  int rc = ladder_dense_fwd(t, Bmat, bias, Y, (int)S, R, K * R, LADDER_ACT_NONE, gws, gws_bytes, stream);
+  if (rc != LADDER_OK) return rc;
+  hipLaunchKernelGGL(gmm_dense_resp_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 4 * (size_t)K * sizeof(float), stream, Y, logc, (int)S,
+                     K, R, 0, lse, logp);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

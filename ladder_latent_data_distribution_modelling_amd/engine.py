@@ -36,7 +36,9 @@ class KernelProfiler:
              9003: "conv_smallcin_kernel (direct 1x1 from 3 channels, HBM-bound)",
              9124: "wgrad3x3_split_kernel<f16x3> (64ci x 128co slab x 9 taps, 8 waves x 9 tiles, transposing LDS reads, 3 x MFMA 32x32x16 f16; incl. its split reduction)",
              9122: "wgrad3x3_split_kernel<bf16x3>", 9123: "wgrad3x3_split_kernel<bf16x6>",
-             9128: "wgrad3x3_halo_kernel (64ci x 128co slab x 9 taps, 12 waves, LDS-DMA staged 1x32-pixel patches, fp32 MFMA 32x32x2)"}
+             9128: "wgrad3x3_halo_kernel (64ci x 128co slab x 9 taps, 12 waves, LDS-DMA staged 1x32-pixel patches, fp32 MFMA 32x32x2)",
+             7700: "gmm_logprob_kernel<R> + gmm_sum_kernel (mixture log-prob / responsibilities, lane = component, wave-shuffle logsumexp)"}
+    LATENCY_BOUND = (7700,)          # not contraction kernels: reported beside the roofline, never as the dominant MFMA kernel
 
     def __init__(self):
         self.records = {}
@@ -52,7 +54,8 @@ class KernelProfiler:
             fl = sum(f for _, _, f in recs)
             n = len(recs)
             out[kid] = dict(kernel=self.NAMES.get(kid, "igemm tile %d" % kid), launches=n, total_ms=ms, avg_ms=ms / n,
-                            flops_per_launch=fl / n, tflops=(fl / (ms * 1e-3) / 1e12) if ms > 0 else 0.0)
+                            flops_per_launch=fl / n, tflops=(fl / (ms * 1e-3) / 1e12) if ms > 0 else 0.0,
+                            bound="latency" if kid in self.LATENCY_BOUND else "mfma")
         return out
 
 
@@ -64,6 +67,13 @@ class KernelProfiler:
 #   "bf16x3"  2 bf16 planes (16 bits), 3 products (error ~1e-5 relative per product: between TF32 and fp32)
 PRECISIONS = {"f32": 0, "bf16x3": 2, "bf16x6": 3, "f16x3": 4}
 DEFAULT_PRECISION = "f16x3"
+
+PRECISION_NOTES = {
+    "f32": "native fp32 MFMA (v_mfma_f32_32x32x2_f32), bit-exact fp32 FMA chains",
+    "f16x3": "fp32-class EMULATION: fp32 operands as 2 scaled fp16 planes (22 significand bits, one power-of-two scale per tensor, "
+             "see DESIGN 4a), 3 fp16 MFMAs per product, fp32 accumulation; set \"matmul_precision\": \"f32\" for strict fp32",
+    "bf16x6": "fp32-class EMULATION: 3 bf16 planes (24 bits), 6 bf16 MFMAs per product, fp32 accumulation",
+    "bf16x3": "REDUCED precision: 2 bf16 planes (16 bits), 3 bf16 MFMAs per product (between TF32 and fp32)"}
 
 PROF = None   # set to a KernelProfiler by bench.py
 _WS_NEED, _KID = {}, {}
@@ -399,6 +409,7 @@ class Conv2D:
         # it is not computed and stays 0 in the flat gradient buffer
         self.bias_grad = bias_grad
         self._packed = {}      # (transpose_flip, ns) -> [weight version, packed bf16 planes]
+        self.group = arch.group_of(name + "/kernel")           # optimiser group whose version stamps the packed images
         self.want_bn_sums, self.bn_sums = False, None          # batch-norm statistics of the output from the conv epilogue (RGB conv)
 
     def _split_ok(self, N, H, W, cin, cout):
@@ -439,8 +450,8 @@ class Conv2D:
             nb = L.query("ladder_filter_pack_split_bytes", self.k * self.k, cin, cout, ns)
             ent = self._packed[(transpose_flip, ns)] = [-1, torch.empty(nb, dtype=torch.uint8, device=self.ctx.device)]
             # known to the batched re-pack after an optimiser step (LadderEngine._repack_filters): (entry, bank, taps, cin, cout, flip, ns)
-            self.ctx.pack_banks.append((ent, ps.w[self.name + "/kernel"], self.k * self.k, cin, cout, transpose_flip, ns))
-        ver = ps.version["ae"]
+            self.ctx.pack_banks.append((ent, ps.w[self.name + "/kernel"], self.k * self.k, cin, cout, transpose_flip, ns, self.group))
+        ver = ps.version[self.group]
         if ent[0] != ver or torch.cuda.is_current_stream_capturing():
             L.call("ladder_filter_pack_split", _p(ps.w[self.name + "/kernel"]), _p(ent[1]), self.k * self.k, cin, cout, transpose_flip, ns,
                    self.ctx.stream)
@@ -864,8 +875,8 @@ class Resize:
             return dx, True                                     # (no absmax record: the gate rescales elements)
         L.call("ladder_resize_bilinear_bwd", _p(dy), _p(dx), N, H, W, C, self.oh, self.ow, self.ctx.stream)
         rec = self.ctx.known_amax(dy)
-        if rec is not None:      # the transpose sums interpolation weights: every column sum is <= (oh/H) * (ow/W)
-            self.ctx.set_amax(dx, rec * float((self.oh // H) * (self.ow // W)))
+        if rec is not None:      # the transpose sums interpolation weights: column sums are bounded per axis (arch.resize_transpose_gain)
+            self.ctx.set_amax(dx, rec * float(arch.resize_transpose_gain(H, self.oh) * arch.resize_transpose_gain(W, self.ow)))
         return (dx, False) if gate is not None else dx
 
 
@@ -1125,7 +1136,13 @@ class LadderEngine:
     def __init__(self, cfg, device="cuda:0", values=None, seed=1, comm=None, noise_seed=1234):
         self.cfg = cfg
         self.ctx = Ctx(device, comm)
-        self.ctx.ns = PRECISIONS[str(cfg.get("matmul_precision", DEFAULT_PRECISION))]
+        prec = str(cfg.get("matmul_precision", DEFAULT_PRECISION))
+        if prec not in PRECISIONS:
+            raise ValueError("matmul_precision %r: expected one of %s" % (prec, sorted(PRECISIONS)))
+        self.ctx.ns = PRECISIONS[prec]
+        self.precision = prec
+        if self.ctx.comm.rank == 0:
+            print("Contraction precision (config key matmul_precision): {} -- {}".format(prec, PRECISION_NOTES[prec]))
         self.ps = ParamStore(cfg, self.ctx, values, seed)
         self.encoder = Encoder(self.ctx, self.ps, cfg)
         self.decoder = (CelebADecoder if cfg["exp_name"] == "celeba" else MnistDecoder)(self.ctx, self.ps, cfg)
@@ -1301,8 +1318,9 @@ class LadderEngine:
             if dmu is None:
                 dmu, dsd = ctx.empty(B, R), ctx.empty(B, R)
             wsp, wsn = ctx.ws(L.query("ladder_gmm_workspace_bytes", self.Lmc, B))
-            L.call("ladder_gmm_logprob_fwd_bwd", _p(mu), _p(sd), _p(eps_mc), _p(self._gm_packed), self.Lmc, B, R, self.K,
-                   _p(P[L.P_LOGP:]), _p(dmu), _p(dsd), wsp, wsn, st)
+            # (flop count of the profiler entry: two Mahalanobis passes + the gradient accumulation per component evaluation)
+            _timed(7700, float(self.Lmc) * B * self.K * (3.0 * R * (R + 1) + 4.0 * R + 8.0), "ladder_gmm_logprob_fwd_bwd",
+                   (_p(mu), _p(sd), _p(eps_mc), _p(self._gm_packed), self.Lmc, B, R, self.K, _p(P[L.P_LOGP:]), _p(dmu), _p(dsd), wsp, wsn, st))
         return dmu, dsd
 
     def _vamp_term(self, mu, sd, noise, B):
@@ -1447,7 +1465,7 @@ class LadderEngine:
             dt = np.dtype([("w", "<u8"), ("packed", "<u8"), ("ntaps", "<i4"), ("cin", "<i4"), ("cout", "<i4"), ("flip", "<i4"),
                            ("block_begin", "<i4"), ("reserved", "<i4")])
             rows, blk = np.zeros(len(banks), dtype=dt), 0
-            for r, (ent, w, taps, cin, cout, flip, ns) in zip(rows, banks):
+            for r, (ent, w, taps, cin, cout, flip, ns, _grp) in zip(rows, banks):
                 assert ns == ctx.ns
                 r["w"], r["packed"], r["ntaps"], r["cin"], r["cout"], r["flip"], r["block_begin"] = w.data_ptr(), ent[1].data_ptr(), taps, cin, cout, flip, blk
                 blk += L.query("ladder_filter_pack_job_blocks", taps, cin, cout)
@@ -1455,9 +1473,8 @@ class LadderEngine:
             scratch = torch.empty(L.query("ladder_filter_pack_split_multi_scratch_bytes", len(banks)), dtype=torch.uint8, device=ctx.device)
             tab = ctx._pack_table = (len(banks), dev, blk, scratch)
         L.call("ladder_filter_pack_split_multi", _p(tab[1]), tab[0], tab[2], ctx.ns, _p(tab[3]), tab[3].numel(), ctx.stream)
-        ver = self.ps.version["ae"]
-        for ent, *_ in banks:
-            ent[0] = ver
+        for ent, *_, grp in banks:
+            ent[0] = self.ps.version[grp]
 
     def _sigma(self, x, lr, noise, use_sg, use_mask, reuse_encoder=False):
         self.forward(x, noise, use_sg, use_mask, ("dec",), reuse_encoder, keep_acts=False)
@@ -1534,6 +1551,9 @@ class LadderEngine:
             self._enc_cache = (self.ps.step["ae"],) + tuple(enc) + (tok,)   # as the eager forward does (pre-update step)
         graph.replay()
         self.ps.step[group] += 1
+        # the replay changed the group's weights on the device: packed split-filter images stamped with the old version are stale
+        # for any EAGER forward that follows (val_step, fit_GMM_VI, decode, Session) -- graphs re-pack inside their own capture
+        self.ps.version[group] += 1
         for k, v in snap.items():
             setattr(self, k, v)
 

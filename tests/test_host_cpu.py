@@ -282,3 +282,19 @@ def test_tf_bundle_checkpoint_roundtrip_and_corruption(tmp_path, monkeypatch):
     with pytest.raises(T.BundleError, match="magic"):
         open(str(tmp_path / "junk.index"), "wb").write(b"x" * 100)
         T.read_index(str(tmp_path / "junk.index"))
+
+
+@pytest.mark.parametrize("h,oh", [(1, 2), (2, 8), (4, 8), (8, 16), (64, 128), (3, 7), (16, 16)])
+def test_resize_transpose_absmax_bound(h, oh):
+    """engine.Resize.backward registers max|dx| <= max|dy| * gain_h * gain_w for the f16x3 scale records (the last source
+    row / column of the TF1-legacy bilinear resize also collects the clamped outputs -- 2.5 per axis for factor 2, not 2).  The bound
+    is checked against the transpose of the oracle's resize on an all-ones dy (the worst case: all weights are non-negative)."""
+    import torch
+    from oracle import ladder_oracle as O
+    from ladder_latent_data_distribution_modelling_amd import arch
+    x = torch.zeros(1, h, h, 1, dtype=torch.float64, requires_grad=True)
+    O.resize_bilinear_legacy(x, oh, oh).sum().backward()
+    g = arch.resize_transpose_gain(h, oh)
+    assert abs(float(x.grad.max()) - g * g) < 1e-9, (float(x.grad.max()), g)
+    if oh == 2 * h and h > 1:
+        assert g == 2.5
