@@ -10,6 +10,10 @@
  * Conventions (all exports):
  *   - extern "C", returns int: 0 = LADDER_OK, <0 = LADDER_E_*.  Never throws, never
  *     allocates, never synchronises the device, keeps no global mutable state.
+ *     (Test-only exception: six environment variables, read ONCE per process on first use, switch a specialised kernel family off so that
+ *     tests can compare it with the generic path in situ -- LADDER_DISABLE_HALO, LADDER_DISABLE_HALO16, LADDER_DISABLE_GEMM16,
+ *     LADDER_DISABLE_SMALLCIN, LADDER_DISABLE_COUT1, LADDER_DISABLE_SMALLCOUT.  They select between kernels with identical
+ *     semantics, are never written by the library, and nothing in the product path sets them.)
  *   - every pointer is CALLER-OWNED DEVICE memory, fp32 unless stated, dense row-major,
  *     activations NHWC, conv filters HWIO, dense weights [in,out] (the reference's
  *     checkpoint layouts).  16-byte alignment of tensor base pointers is required.
@@ -89,28 +93,41 @@ int ladder_conv1x1_smallcout_eligible(long M, int Cin, int Cout);
 size_t ladder_conv1x1_smallcout_bwd_workspace_bytes(long M, int Cin, int Cout);
 int ladder_conv1x1_smallcout_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long M, int Cin,
                                  int Cout, int gate_act, void* ws, size_t ws_bytes, ladder_stream_t stream);
-/* ... additionally produces the absolute-maximum record of dx (LADDER_ABSMAX_FLOATS floats, see ladder_absmax; dx must not be NULL). */
+/* ... additionally produces the absolute-maximum record of dx (LADDER_ABSMAX_FLOATS floats, see ladder_absmax; dx must not be NULL):
+ * per sample (mode 1) when rows_per_sample = H*W > 0 divides M and is a multiple of 256 / (Cin / 4), else one bound for the tensor. */
 int ladder_conv1x1_smallcout_bwd_absmax(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long M, int Cin,
-                                        int Cout, int gate_act, void* ws, size_t ws_bytes, float* dx_absmax, ladder_stream_t stream);
+                                        int Cout, int gate_act, void* ws, size_t ws_bytes, float* dx_absmax, long rows_per_sample,
+                                        ladder_stream_t stream);
 
 /* ---------------------------------------------------------------- N1s: the same convolutions on the 16-bit matrix cores
  * (operand splitting; csrc/convsplit.hip).  gfx950 has no TF32-class MFMA and its f32-input MFMA runs at the f32 vector rate;
  * v_mfma_f32_32x32x16_{f16,bf16} are 16x faster.  Each fp32 operand is split into 16-bit planes whose cross products are
  * accumulated in fp32 (`prec`):
- *   LADDER_PREC_F16X3   2 fp16 planes = 22 bits, 3 products, dropped term <= 2^-22 relative (fp32 class); operands are scaled per
- *                       tensor by a power of two derived from their absolute maximum (x_absmax, a device scalar from ladder_absmax;
- *                       the filter's is taken by the pack call).
+ *   LADDER_PREC_F16X3   2 fp16 planes = 22 bits, 3 products, dropped term <= 2^-22 relative (fp32 class); operands are scaled by a
+ *                       power of two derived from their absolute maximum -- per SAMPLE where the record carries per-sample bounds,
+ *                       else per tensor (x_absmax: see the record layouts below; the filter's is taken by the pack call).
  *   LADDER_PREC_BF16X6  3 bf16 planes = 24 bits, 6 products, dropped terms <= 2^-23 relative (fp32 class); no scaling.
  *   LADDER_PREC_BF16X3  2 bf16 planes = 16 bits, 3 products, <= 3 * 2^-17 relative.
  * Replaces the same call sites as ladder_conv2d_fwd / ladder_conv2d_bwd_data for 3x3 / stride 1 / SAME layers with W % 32 == 0,
  * H % 8 == 0, Cin % 16 == 0, Cout % 4 == 0, Cout >= 64 and >= 512 workgroups (codes/models.py:538-578: the decoder's
  * 32x32 ... 128x128 maps). */
 enum { LADDER_PREC_F32 = 0, LADDER_PREC_BF16X3 = 2, LADDER_PREC_BF16X6 = 3, LADDER_PREC_F16X3 = 4 };
-/* Absolute-maximum RECORD of a tensor: LADDER_ABSMAX_FLOATS floats (16 slots, 128 bytes apart; max |x| = the maximum of the slots --
- * exact and order-independent; producers fold block maxima into the slots with one atomic per workgroup).  ladder_absmax fills
- * `out` from scratch; kernels with a `*_absmax` OUTPUT argument zero it and fill it for the tensor they write (NULL = skip). */
+/* Absolute-maximum RECORD of a tensor: LADDER_ABSMAX_FLOATS floats = 16 lines of 128 bytes, exact and order-independent (producers fold
+ * block maxima into it with one atomic max per workgroup), in one of two layouts (csrc/common.h):
+ *   mode 0 (float 1 == 0): ONE bound for the tensor = the maximum of float 0 of each line.  ladder_absmax; batch-norm producers.
+ *   mode 1 (float 1 != 0): one bound PER SAMPLE of an [N, ...] tensor: sample n in float 2 + (n/16) % 30 of line n % 16 (480 distinct
+ *                          samples; larger batches share slots).  ladder_absmax_samples; the split conv epilogue, instance-norm
+ *                          forward / backward, the fused instance-norm + resize.  Round 3: the f16x3 kernels whose accumulations stay
+ *                          inside one sample (3x3 halo conv forward / backward-data, gather conv forward / backward-data) scale every
+ *                          sample by ITS OWN maximum (capped at 2^24 above the tensor-wide scale), so the format's fp32-like relative
+ *                          precision holds per sample; reductions over all samples (filter gradients) use the tensor-wide bound or
+ *                          re-scale their accumulators at sample boundaries.
+ * Every entry is an UPPER bound (a looser one only raises the representation floor 2^-38 * bound).  ladder_absmax* fill `out` from
+ * scratch; kernels with a `*_absmax` OUTPUT argument zero it and fill it for the tensor they write (NULL = skip). */
 #define LADDER_ABSMAX_FLOATS 512
 int ladder_absmax(const float* x, size_t n, float* out, ladder_stream_t stream);
+/* per-sample record of x [n_samples, per_sample] (per_sample % 4 == 0). */
+int ladder_absmax_samples(const float* x, int n_samples, size_t per_sample, float* out, ladder_stream_t stream);
 /* ladder_filter_pack_split: once per weight update, HWIO fp32 bank of ntaps = KH*KW taps -> split planes in the kernels' LDS layout
  * (Cin % 16 == 0; output channels zero-padded to a multiple of 128).
  *   transpose_flip = 0: `w` = [KH][KW][Cin][Cout] (forward).  transpose_flip = 1: `w` = the layer's bank [KH][KW][Cout][Cin] read as
@@ -147,10 +164,14 @@ int ladder_conv3x3_split_proj(const float* x, const float* x_absmax, const void*
                               const float* proj_b, float* proj_out, int proj_cout, int N, int H, int W, int Cin, int Cout, int act,
                               int prec, ladder_stream_t stream);
 
-/* planes[p][i] = 16-bit plane p of x[i] (scaled by the power of two derived from x_absmax for LADDER_PREC_F16X3), plane-major,
- * n % 8 == 0, followed by 16 zero bytes (the source of out-of-image taps); ladder_presplit_bytes = planes * n * 2 + 16. */
+/* planes[p][i] = 16-bit plane p of x[i] (scaled by a power of two derived from x_absmax for LADDER_PREC_F16X3), plane-major,
+ * n % 8 == 0, followed by 16 zero bytes (the source of out-of-image taps) and a 16-byte header; ladder_presplit_bytes = planes * n * 2 + 32.
+ * n_samples > 0 (x is [n_samples, ...], (n / n_samples) % 8 == 0) AND a per-sample record (ladder_absmax_samples, or a producer that
+ * emits one): every sample is scaled by ITS OWN maximum and header word 0 is set to 1 -- the gather kernels below read the header and
+ * un-scale per output row (forward / backward-data) or re-scale their accumulators at sample boundaries (filter gradient; the caller
+ * must then request per-sample planes only where a sample's output pixels are a multiple of 32).  n_samples = 0: one scale. */
 size_t ladder_presplit_bytes(size_t n, int prec);
-int ladder_presplit(const float* x, const float* x_absmax, void* planes, size_t n, int prec, ladder_stream_t stream);
+int ladder_presplit(const float* x, const float* x_absmax, void* planes, size_t n, int n_samples, int prec, ladder_stream_t stream);
 /* The gather kernel on split operands: every other large convolution (128x128 output tiles; gathered channels % 32 == 0; tap table
  * <= 28 taps), i.e. the strided encoder layers and the 8x8 / 16x16 decoder maps (codes/models.py:398-460, 522-547) and their
  * backward-data passes (stride 2: the four output-parity classes).  Same semantics as ladder_conv2d_fwd / ladder_conv2d_bwd_data with

@@ -122,7 +122,8 @@ PROTOTYPES = {
     "ladder_dense_bwd_weight_small": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "ladder_dense_bwd_small": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _p]),
     "ladder_presplit_bytes": (_z, [_z, _i]),
-    "ladder_presplit": (_i, [_p, _p, _p, _z, _i, _p]),
+    "ladder_presplit": (_i, [_p, _p, _p, _z, _i, _i, _p]),
+    "ladder_absmax_samples": (_i, [_p, _i, _z, _p, _p]),
     "ladder_conv3x3_split_proj": (_i, [_p, _p, _p, _p, _p, _p, _p, _p] + [_i] * 8 + [_p]),
     "ladder_conv_rgb_s2_eligible": (_i, [_i] * 10),
     "ladder_conv_rgb_s2_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
@@ -139,7 +140,7 @@ PROTOTYPES = {
     "ladder_in_style_fwd_absmax": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _z, _p, _p]),
     "ladder_in_style_fwd_resize2x": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _z, _p, _p]),
     "ladder_in_style_bwd_absmax": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _z, _p, _p]),
-    "ladder_conv1x1_smallcout_bwd_absmax": (_i, [_p, _p, _p, _p, _p, _p, C.c_long, _i, _i, _i, _p, _z, _p, _p]),
+    "ladder_conv1x1_smallcout_bwd_absmax": (_i, [_p, _p, _p, _p, _p, _p, C.c_long, _i, _i, _i, _p, _z, _p, C.c_long, _p]),
     "ladder_absmax": (_i, [_p, _z, _p, _p]),
     "ladder_conv3x3_wgrad_split_eligible": (_i, [_i] * 6),
     "ladder_conv3x3_wgrad_split_workspace_bytes": (_z, [_i] * 5),

@@ -55,19 +55,45 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // ---- absolute-maximum records ---------------------------------------------------------------------------------------------------
-// A tensor's max |x| travels as a RECORD of 16 slots, 128 bytes apart (LADDER_ABSMAX_FLOATS floats): every producing workgroup
-// folds its block maximum into slot (block id % 16) with one atomic max on the bit pattern (non-negative floats order like their
-// bit patterns: exact, order-independent), consumers take the maximum of the 16 slots.  One shared counter would serialise all
-// workgroups of a launch in the L2 (~12 ns per same-address atomic: 100 us for 8192 workgroups); 16 lines keep it under 2 us.
-constexpr int AMAX_SLOTS = 16, AMAX_STRIDE = 32;
+// A tensor's max |x| travels as a RECORD of LADDER_ABSMAX_FLOATS = 512 floats = 16 lines of 128 bytes, in one of two layouts:
+//   mode 0 (rec[1] == 0)  ONE bound for the whole tensor: every producing workgroup folds its block maximum into slot (block id % 16) =
+//                         float 0 of line (block id % 16) with one atomic max on the bit pattern (non-negative floats order like their
+//                         bit patterns: exact, order-independent); the bound is the maximum of the 16 slots.  One shared counter would
+//                         serialise all workgroups of a launch in the L2 (~12 ns per same-address atomic: 100 us for 8192 workgroups).
+//   mode 1 (rec[1] != 0)  one bound PER SAMPLE (NHWC tensors; round 3): sample n folds into float 2 + (n / 16) % 30 of line n % 16
+//                         (480 distinct samples, larger batches share slots -- still valid bounds).  Consumers whose accumulations stay
+//                         inside one sample (convolution forward / backward-data) scale each sample by ITS OWN maximum: the fp32-like
+//                         relative precision of the f16x3 format then holds per sample, not only within 2^16 of the tensor's largest
+//                         element.  The tensor-wide bound is the maximum over all floats but the flag.
+// Every value in a record is an UPPER bound: a producer that cannot attribute its maxima to samples writes a mode-0 record.
+constexpr int AMAX_SLOTS = 16, AMAX_STRIDE = 32, AMAX_MODE_IDX = 1, AMAX_PS_FIRST = 2, AMAX_PS_PER_LINE = 30;
 static_assert(AMAX_SLOTS * AMAX_STRIDE == LADDER_ABSMAX_FLOATS, "record size of include/ladder_hip.h");
+// per-sample scales are capped at 2^AMAX_PS_CAP above the tensor-wide scale (filter-gradient kernels re-scale their accumulators when
+// the reduction crosses into another sample: the ratio of two scale products stays below 2^(2 * cap), far inside the fp32 range)
+constexpr int AMAX_PS_CAP = 24;
 
+__device__ __forceinline__ int amax_ps_index(int n) { return (n & (AMAX_SLOTS - 1)) * AMAX_STRIDE + AMAX_PS_FIRST + ((n >> 4) % AMAX_PS_PER_LINE); }
+
+// Tensor-wide bound of a record in either mode.  COOPERATIVE: all 64 lanes of the calling wavefront must be active (call it at kernel
+// start, before any divergent exit); each lane reads 8 of the 512 floats.
 __device__ __forceinline__ float amax_load(const float* rec) {
-  float m = 0.f;
-#pragma unroll
-  for (int s = 0; s < AMAX_SLOTS; ++s) m = fmaxf(m, rec[s * AMAX_STRIDE]);
-  return m;
+  const int lane = threadIdx.x & 63;
+  const float4 a = reinterpret_cast<const float4*>(rec)[2 * lane], b = reinterpret_cast<const float4*>(rec)[2 * lane + 1];
+  float m = fmaxf(fmaxf(a.x, lane == 0 ? 0.f : a.y), fmaxf(a.z, a.w));          // (float 1 = the mode flag)
+  m = fmaxf(m, fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
+  // (every lane holds the maximum: hand it to the scalar unit, so that the scales derived from it live in SGPRs like the 16 scalar
+  // loads of the round-2 record did -- two more VGPRs spill in the 128-register halo kernels)
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wave_max(m))));
 }
+__device__ __forceinline__ bool amax_per_sample(const float* rec) { return rec[AMAX_MODE_IDX] != 0.f; }
+// Bound for sample n: its own slot of a mode-1 record when `per_sample`, else the tensor-wide bound `tmax` (= amax_load(rec)).
+__device__ __forceinline__ float amax_sample(const float* rec, int n, bool per_sample, float tmax) {
+  return per_sample ? rec[amax_ps_index(n)] : tmax;
+}
+
+// One slot update: fire-and-forget (no returned value: the wavefront does not wait for the L2).  A read-before-update filter was tried
+// and was slower: the workgroup then waits a full L2 round trip for the value before it can retire.
+__device__ __forceinline__ void amax_fold(unsigned* slot, float b) { atomicMax(slot, __builtin_bit_cast(unsigned, b)); }
 
 // Clears a record from inside a kernel that runs BEFORE the record's producer on the same stream (the finalize kernels of the norm
 // layers): block 0 writes the LADDER_ABSMAX_FLOATS zeros, which saves the separate memset launch per record.
@@ -87,6 +113,25 @@ __device__ __forceinline__ void amax_commit_block(float m, float* rec) {
     float b = 0.f;
     for (int w = 0; w < nw; ++w) b = fmaxf(b, amax_red[w]);
     const unsigned slot = (blockIdx.x + 7u * blockIdx.y + 3u * blockIdx.z) % AMAX_SLOTS;
-    atomicMax(reinterpret_cast<unsigned*>(rec) + slot * AMAX_STRIDE, __builtin_bit_cast(unsigned, b));
+    amax_fold(reinterpret_cast<unsigned*>(rec) + slot * AMAX_STRIDE, b);
   }
+}
+// The per-sample form (mode 1): the whole workgroup's values belong to sample n.  EVERY thread must call it.  The record must have been
+// cleared before the launch; workgroup (0,0,0) sets the mode flag (65536 workgroups storing to that one address stretched the fused
+// instance-norm + resize kernel by 40 %).  RESYNC: the workgroup commits more than once (the reduction array is reused).
+template <bool RESYNC = false>
+__device__ __forceinline__ void amax_commit_block_sample(float m, float* rec, int n) {
+  __shared__ float amax_red_ps[16];
+  m = wave_max(m);
+  const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+  if ((tid & 63) == 0) amax_red_ps[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    const int nw = (blockDim.x * blockDim.y * blockDim.z + 63) >> 6;
+    float b = 0.f;
+    for (int w = 0; w < nw; ++w) b = fmaxf(b, amax_red_ps[w]);
+    amax_fold(reinterpret_cast<unsigned*>(rec) + amax_ps_index(n), b);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) rec[AMAX_MODE_IDX] = 1.f;
+  }
+  if (RESYNC) __syncthreads();
 }

@@ -56,22 +56,52 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   amax_commit_block(m, rec);
 }
 
+// The per-sample form (mode-1 record, common.h): blockIdx.y = sample, its blocks stride over the sample's elements.
+__global__ __launch_bounds__(256) void absmax_samples_kernel(const float* __restrict__ x, size_t per_sample, float* __restrict__ rec) {
+  const float* xs = x + (size_t)blockIdx.y * per_sample;
+  const size_t n4 = per_sample / 4;                             // (per_sample % 4 == 0 and x 16-byte aligned: checked by the launcher)
+  const float4* x4 = reinterpret_cast<const float4*>(xs);
+  float m = 0.f;
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = x4[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+  }
+  for (; i < n4; i += stride) {
+    const float4 v = x4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  amax_commit_block_sample(m, rec, blockIdx.y);
+}
+
 // ---- operand pre-splitting ------------------------------------------------------------------------------------------------------
 // planes[p][i] = plane p of x[i] (16-bit, scaled for the fp16 format), plane-major.  The gather kernels re-read every input element
 // once per filter tap and per output-channel tile (18-36 times): splitting it there each time cost 38 % of the kernel (VALU + LDS
 // stores); one elementwise pass per tensor (4 B read + 4 B written per element) lets them stage planes by LDS-DMA.  16 zero bytes
+// (+ a 16-byte header: word 0 != 0 when the planes carry one f16x3 scale per SAMPLE instead of one for the tensor)
 // follow the last plane: the source of out-of-image taps (an offset INTO THE SAME BUFFER, so that the DMA source is selected by a
 // conditional move on an integer -- a pointer select against another object compiles to exec-masked branches, and a partially
 // masked global_load_lds takes its LDS base from the first ACTIVE lane).
 template <int PREC>
 __global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__ x, const float* __restrict__ xamax,
-                                                       uint4* __restrict__ planes, size_t n8) {
+                                                       uint4* __restrict__ planes, size_t n8, unsigned sample8) {
   constexpr int NS = Fmt<PREC>::NS;
   constexpr bool F16 = Fmt<PREC>::F16;
-  const float c = F16 ? scale_from_absmax(amax_load(xamax)) : 1.f;
-  if (blockIdx.x == 0 && threadIdx.x == 0) planes[(size_t)NS * n8] = make_uint4(0u, 0u, 0u, 0u);   // the 16 zero bytes behind the planes
+  // sample8 = 16-byte units (8 elements) per sample when the consumer scales per sample (and the record carries per-sample bounds), else 0
+  const float tmax = F16 ? amax_load(xamax) : 0.f;
+  const bool ps = F16 && sample8 != 0u && amax_per_sample(xamax);
+  float c = F16 ? scale_from_absmax(tmax) : 1.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    planes[(size_t)NS * n8] = make_uint4(0u, 0u, 0u, 0u);               // the 16 zero bytes behind the planes
+    planes[(size_t)NS * n8 + 1] = make_uint4(ps ? 1u : 0u, 0u, 0u, 0u);  // header: one scale per sample / one for the tensor
+  }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
     float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+    if (ps) c = scale_for_sample(xamax, (int)(i / sample8), true, tmax);
     if (F16) {
       a = make_float4(a.x * c, a.y * c, a.z * c, a.w * c);
       b = make_float4(b.x * c, b.y * c, b.z * c, b.w * c);
@@ -126,8 +156,8 @@ template <int PREC>
 __global__ __launch_bounds__(256) void filter_pack_kernel(const float* __restrict__ w, uint4* __restrict__ out, int ntaps, int Cin,
                                                           int Cout, int transpose_flip, int total, const float* __restrict__ wamax) {
   const int i = blockIdx.x * 256 + threadIdx.x;     // one thread per (tap, slab, cot, kg, co)
+  const float c = Fmt<PREC>::F16 ? scale_from_absmax(amax_load(wamax)) : 1.f;   // (cooperative load: before the divergent exit)
   if (i >= total) return;
-  const float c = Fmt<PREC>::F16 ? scale_from_absmax(amax_load(wamax)) : 1.f;
   filter_pack_element<PREC>(w, out, ntaps, Cin, Cout, transpose_flip, i, c);
 }
 
@@ -228,9 +258,9 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
   const int h0 = (rem / tw_n) * SP_H, w0 = (rem % tw_n) * SP_W;
   const int nslabs = Cin / 16;
   float cx = 1.f, unscale = 1.f;
-  if (F16) {
-    cx = scale_from_absmax(amax_load(xamax));
-    unscale = 1.f / (cx * scale_from_absmax(amax_load(wamax)));      // exact: powers of two
+  if (F16) {                                                           // the patch lies inside ONE image: that sample's own scale
+    cx = uniform_f(scale_for_sample(xamax, img, amax_per_sample(xamax), amax_load(xamax)));
+    unscale = uniform_f(1.f / (cx * scale_from_absmax(amax_load(wamax))));      // exact: powers of two
   }
 
   const float* hsrc[SP_AU];
@@ -348,7 +378,7 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
         }
       }
     }
-    if (yamax != nullptr) amax_commit_block(ymax, yamax);
+    if (yamax != nullptr) amax_commit_block_sample(ymax, yamax, img);
     return;
   }
   // Transposed accumulators (the filter fragment is the MFMA's A operand): lane l31 = pixel of the patch row, register e -> channel
@@ -397,7 +427,7 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
       }
     }
   }
-  if (yamax != nullptr) amax_commit_block(ymax, yamax);     // the output's absolute maximum for the next split contraction
+  if (yamax != nullptr) amax_commit_block_sample(ymax, yamax, img);     // the output's absolute maximum for the next split contraction
   if (pout != nullptr) {
     // combine the two half-waves (lh) in registers, the two channel halves (wn) through LDS (free after the main loop), fixed order
     __syncthreads();
@@ -466,9 +496,9 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
   const int h0 = (rem / tw_n) * F_H, w0 = (rem % tw_n) * SP_W;
   const int nslabs = Cin / 16;
   float cx = 1.f, unscale = 1.f;
-  if (F16) {
-    cx = scale_from_absmax(amax_load(xamax));
-    unscale = 1.f / (cx * scale_from_absmax(amax_load(wamax)));      // exact: powers of two
+  if (F16) {                                                           // the patch lies inside ONE image: that sample's own scale
+    cx = uniform_f(scale_for_sample(xamax, img, amax_per_sample(xamax), amax_load(xamax)));
+    unscale = uniform_f(1.f / (cx * scale_from_absmax(amax_load(wamax))));      // exact: powers of two
   }
 
   const float* hsrc[F_AU];
@@ -596,7 +626,7 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
         }
       }
     }
-    if (yamax != nullptr) amax_commit_block(ymax, yamax);
+    if (yamax != nullptr) amax_commit_block_sample(ymax, yamax, img);
     return;
   }
   // Transposed accumulators (the filter fragment is the MFMA's A operand): lane l31 = pixel of the patch row, register e -> channel
@@ -645,7 +675,7 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
       }
     }
   }
-  if (yamax != nullptr) amax_commit_block(ymax, yamax);     // the output's absolute maximum for the next split contraction
+  if (yamax != nullptr) amax_commit_block_sample(ymax, yamax, img);     // the output's absolute maximum for the next split contraction
   if (pout != nullptr) {
     // combine the two half-waves (lh) in registers, the two channel halves (wn) through LDS (free after the main loop), fixed order
     __syncthreads();
@@ -959,19 +989,36 @@ int ladder_absmax(const float* x, size_t n, float* out, ladder_stream_t stream) 
   return LADDER_OK;
 }
 
-size_t ladder_presplit_bytes(size_t n, int prec) { return (prec_ok(prec) && n % 8 == 0) ? (size_t)prec_planes(prec) * n * 2 + 16 : 0; }
+int ladder_absmax_samples(const float* x, int n_samples, size_t per_sample, float* out, ladder_stream_t stream) {
+  if (n_samples <= 0 || per_sample == 0 || (per_sample % 4) != 0) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(x) || !ladder_aligned16(out)) return LADDER_E_ALIGN;
+  if (hipMemsetAsync(out, 0, LADDER_ABSMAX_FLOATS * sizeof(float), stream) != hipSuccess) return LADDER_E_LAUNCH;
+  size_t bx = (per_sample / 4 + 256 * 4 - 1) / (256 * 4);
+  const size_t cap = (size_t)(2048 / n_samples) > 0 ? (size_t)(2048 / n_samples) : 1;          // ~2048 workgroups in total
+  bx = bx < 1 ? 1 : (bx > cap ? cap : bx);
+  hipLaunchKernelGGL(absmax_samples_kernel, dim3((unsigned)bx, (unsigned)n_samples), dim3(256), 0, stream, x, per_sample, out);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
 
-int ladder_presplit(const float* x, const float* x_absmax, void* planes, size_t n, int prec, ladder_stream_t stream) {
-  if (n == 0 || (n % 8) != 0 || !prec_ok(prec)) return LADDER_E_SHAPE;
+size_t ladder_presplit_bytes(size_t n, int prec) { return (prec_ok(prec) && n % 8 == 0) ? (size_t)prec_planes(prec) * n * 2 + 32 : 0; }
+
+int ladder_presplit(const float* x, const float* x_absmax, void* planes, size_t n, int n_samples, int prec, ladder_stream_t stream) {
+  if (n == 0 || (n % 8) != 0 || !prec_ok(prec) || n_samples < 0) return LADDER_E_SHAPE;
+  unsigned sample8 = 0;                                          // per-sample scales: n_samples > 0 and whole 16-byte units per sample
+  if (n_samples > 0) {
+    if ((n % (size_t)n_samples) != 0 || ((n / (size_t)n_samples) % 8) != 0 || (n / (size_t)n_samples) / 8 > 0xffffffffull) return LADDER_E_SHAPE;
+    sample8 = (unsigned)((n / (size_t)n_samples) / 8);
+  }
   if (!ladder_aligned16(x) || !ladder_aligned16(planes)) return LADDER_E_ALIGN;
   if (prec == LADDER_PREC_F16X3 && x_absmax == nullptr) return LADDER_E_SHAPE;
   const size_t n8 = n / 8;
   size_t blocks = (n8 + 255) / 256;
   blocks = blocks > 4096 ? 4096 : blocks;
   const dim3 grid((unsigned)blocks), block(256);
-  if (prec == LADDER_PREC_F16X3) hipLaunchKernelGGL(presplit_kernel<LADDER_PREC_F16X3>, grid, block, 0, stream, x, x_absmax, (uint4*)planes, n8);
-  else if (prec == LADDER_PREC_BF16X6) hipLaunchKernelGGL(presplit_kernel<LADDER_PREC_BF16X6>, grid, block, 0, stream, x, x_absmax, (uint4*)planes, n8);
-  else hipLaunchKernelGGL(presplit_kernel<LADDER_PREC_BF16X3>, grid, block, 0, stream, x, x_absmax, (uint4*)planes, n8);
+  if (prec == LADDER_PREC_F16X3) hipLaunchKernelGGL(presplit_kernel<LADDER_PREC_F16X3>, grid, block, 0, stream, x, x_absmax, (uint4*)planes, n8, sample8);
+  else if (prec == LADDER_PREC_BF16X6) hipLaunchKernelGGL(presplit_kernel<LADDER_PREC_BF16X6>, grid, block, 0, stream, x, x_absmax, (uint4*)planes, n8, sample8);
+  else hipLaunchKernelGGL(presplit_kernel<LADDER_PREC_BF16X3>, grid, block, 0, stream, x, x_absmax, (uint4*)planes, n8, sample8);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

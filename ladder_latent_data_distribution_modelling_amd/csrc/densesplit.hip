@@ -265,8 +265,13 @@ int launch_gemm_small(const float* a, const float* b, const float* bias, float* 
 
 extern "C" {
 
-// Worth it while the whole output is a few hundred tiles of 32x32 (batch-sized M): beyond that the tiled fp32 / split gather kernels win.
-int ladder_dense_small_eligible(int M, int K, int N) { return (M > 0 && K > 0 && N > 0 && M <= 512 && (long)M * N <= (1L << 20)) ? 1 : 0; }
+// Worth it while every output of the layer's three GEMMs is at most a few thousand 32x32 tiles: the forward / backward-data outputs are
+// M x N and M x K (batch-sized M), the backward-weight output is K x N with the reduction over M -- a wide layer (K * N beyond 2 M
+// elements, e.g. a 16 K-feature flatten into 512 units) would launch thousands of tiles of M / 16 strided 4-byte-load steps each and is
+// better served by the split-K gather filter-gradient kernel, so such layers stay on the tiled path as a whole.
+int ladder_dense_small_eligible(int M, int K, int N) {
+  return (M > 0 && K > 0 && N > 0 && M <= 512 && (long)M * N <= (1L << 20) && (long)M * K <= (1L << 21) && (long)K * N <= (1L << 21)) ? 1 : 0;
+}
 
 int ladder_dense_fwd_small(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act,
                            ladder_stream_t stream) {

@@ -333,6 +333,12 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? IGEMM_FWD_MINW :
 // splitting it in this kernel each time cost 38 % of its run time) straight into LDS ([plane][k-step][channel octet][row][8 x 16 bit]:
 // a fragment = 32 consecutive 16-byte slots); B comes pre-split from ladder_filter_pack_split, whose blocks already have that layout.
 constexpr int GS_BM = 128, GS_BN = 128, GS_BK = 32;
+
+// ladder_presplit leaves behind the planes: 16 zero bytes (the source of padding taps), then a 16-byte header whose first word says
+// whether the planes carry one scale per SAMPLE (f16x3, mode-1 absmax record) or one for the tensor.
+__device__ __forceinline__ bool planes_per_sample(const uint16_t* planes, size_t plane_elems, int ns) {
+  return reinterpret_cast<const uint32_t*>(planes + (size_t)ns * plane_elems)[4] != 0u;
+}
 constexpr int GS_PLANE = 2 * 2 * 128 * 16;      // bytes per plane of either operand tile (8192)
 
 template <int PREC>
@@ -359,11 +365,18 @@ __global__ __launch_bounds__(kThreads, 2) void igemm_fwd_split_kernel(const uint
   const int m0 = (tile / tiles_n) * GS_BM, cot = tile % tiles_n, n0 = cot * GS_BN;
   const int HoWo = d.Ho * d.Wo;
   const int nslabs16 = d.Cin / 16;
-  float cx = 1.f, unscale = 1.f;
+  // f16x3: the planes were scaled by ladder_presplit -- with ONE scale for the tensor or with one per sample (flag word behind the
+  // planes); a GEMM row is one output pixel = one sample, so the un-scale factor is a per-row constant (table in LDS for the epilogue)
+  float tmax = 0.f, cw = 1.f;
+  bool x_ps = false;
   if (F16) {
-    cx = scale_from_absmax(amax_load(xamax));
-    unscale = 1.f / (cx * scale_from_absmax(amax_load(wamax)));
+    tmax = amax_load(xamax);
+    cw = scale_from_absmax(amax_load(wamax));
+    x_ps = planes_per_sample(xp, plane_elems, NS);
   }
+  // (thread r < 128 fetches the scale of tile row r now: the load has the whole main loop to arrive)
+  float my_row_scale = 1.f;
+  if (F16 && tid < GS_BM) my_row_scale = scale_for_sample(xamax, (int)fdiv((uint32_t)min(m0 + tid, d.M - 1), d.div_howo), x_ps, tmax);
 
   long a_off[AU];                                          // element offset of the unit at tap (0,0), channel slab 0
   uint32_t a_mask[AU];
@@ -466,6 +479,11 @@ __global__ __launch_bounds__(kThreads, 2) void igemm_fwd_split_kernel(const uint
     __syncthreads();
   }
 
+  float* const row_unscale = reinterpret_cast<float*>(lds);   // (the operand tiles are dead after the last barrier of the main loop)
+  if (F16) {
+    if (tid < GS_BM) row_unscale[tid] = 1.f / (my_row_scale * cw);       // exact: powers of two
+    __syncthreads();
+  }
   if (part != nullptr) {   // split-K partial: un-scaled accumulators, bias/activation applied by splitk_epilogue_kernel
     float* o = part + (size_t)blockIdx.y * d.M * d.Cout;
 #pragma unroll
@@ -476,7 +494,7 @@ __global__ __launch_bounds__(kThreads, 2) void igemm_fwd_split_kernel(const uint
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int m = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-          if (m < d.M && n < d.Cout) o[(long)m * d.Cout + n] = acc[mi][ni][e] * unscale;
+          if (m < d.M && n < d.Cout) o[(long)m * d.Cout + n] = F16 ? acc[mi][ni][e] * row_unscale[m - m0] : acc[mi][ni][e];
         }
     }
     return;
@@ -501,7 +519,7 @@ __global__ __launch_bounds__(kThreads, 2) void igemm_fwd_split_kernel(const uint
             const uint32_t ho = fdiv(rem, d.div_wo), wo = rem - ho * d.Wo;
             row = ((long)n_img * d.OH + d.out_h0 + (long)ho * d.out_sh) * d.OW + d.out_w0 + (long)wo * d.out_sw;
           }
-          float v = ladder_act_fn(acc[mi][ni][e] * unscale + bv, d.act);
+          float v = ladder_act_fn((F16 ? acc[mi][ni][e] * row_unscale[m - m0] : acc[mi][ni][e]) + bv, d.act);
           if (gate != nullptr) v *= ladder_act_grad_from_out(gate[row * d.Cout + n], gate_act);
           y[row * d.Cout + n] = v;
           st0[ni] += v;
@@ -765,10 +783,30 @@ __global__ __launch_bounds__(kThreads, 2) void igemm_wgrad_split_kernel(const ui
   const int p_end = min(d.M, p_begin + m_per_split);
   const int tap = k0t / d.Cin, ci0 = k0t - tap * d.Cin;       // the tile lies inside one tap (Cin % 128 == 0)
   const int tr = tap / d.KW, ts = tap - tr * d.KW;
-  float cx = 1.f, cd = 1.f;
+  // f16x3 scales: either operand's planes may carry one scale per sample (ladder_presplit).  The reduction runs over the pixels of ALL
+  // samples, so the accumulators hold s * (partial sum) with s = cx(n) * cd(n) of the sample being reduced and are multiplied by
+  // s_new / s_old (a power of two: exact) whenever a 32-pixel chunk starts in another sample.  Needs chunks inside one sample.
+  // The scales of the samples this workgroup reduces over are gathered ONCE into an LDS table (vector loads, counted by vmcnt like the chunk
+  // loads they precede): scalar loads between the segments made the first LDS wait of every segment stall on them (lgkmcnt counts both).
+  constexpr int GW_NSC = 256;
+  __shared__ float2 seg_scale[GW_NSC];                       // [sample - n_first] = {cx * cd, cd}
+  float xt = 0.f, dt = 0.f, s_cur = 1.f, cd_cur = 1.f;
+  bool x_ps = false, d_ps = false;
+  int n_cur = 0, n_first = 0;
   if (F16) {
-    cx = scale_from_absmax(amax_load(xamax));
-    cd = scale_from_absmax(amax_load(damax));
+    xt = amax_load(xamax);
+    dt = amax_load(damax);
+    x_ps = planes_per_sample(xp, x_plane_elems, NS);
+    d_ps = planes_per_sample(dyp, dy_plane_elems, NS);
+    if ((x_ps || d_ps) && ((HoWo % 32) != 0 || (p_begin % 32) != 0)) __builtin_trap();     // the caller asked for per-sample planes on a map it must not
+    n_first = n_cur = (int)fdiv((uint32_t)min(p_begin, d.M - 1), d.div_howo);
+    // (one entry when both operands carry a single scale; else m_per_split / HoWo + 1 samples per workgroup: far below the table size)
+    const int n_tab = (x_ps || d_ps) ? (int)fdiv((uint32_t)(max(p_end, p_begin + 1) - 1), d.div_howo) - n_first : 0;
+    if (n_tab >= GW_NSC) __builtin_trap();
+    if (tid <= n_tab) {
+      const float cdn = scale_for_sample(damax, n_first + tid, d_ps, dt);
+      seg_scale[tid] = make_float2(scale_for_sample(xamax, n_first + tid, x_ps, xt) * cdn, cdn);
+    }
   }
   const bool do_bias = (bias_part != nullptr) && (tile / tiles_n == 0) && wm == 0;
   float bsum[2] = {0.f, 0.f};
@@ -861,15 +899,50 @@ __global__ __launch_bounds__(kThreads, 2) void igemm_wgrad_split_kernel(const ui
     store_chunk(0);
   }
   __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
-    const int buf = c & 1;
-    if (c + 1 < nchunks) load_chunk(c + 1);
-    mma_chunk(buf);
-    if (c + 1 < nchunks) store_chunk(buf ^ 1);
-    __syncthreads();
+  // chunk loop in SEGMENTS of chunks that share their scales (per-sample planes: the chunks of one sample; else one segment): the inner
+  // loop is the plain pipelined loop, all re-scaling sits between segments (a test inside the chunk loop cost the kernel 19 %)
+  if (F16) {                                                 // (after the barrier above: the table is complete)
+    s_cur = seg_scale[0].x;
+    cd_cur = seg_scale[0].y;
+  }
+  const bool any_ps = F16 && (x_ps || d_ps);
+  const int cps = any_ps ? HoWo / 32 : nchunks;             // chunks per sample (HoWo % 32 == 0 and p_begin % 32 == 0 were checked)
+  int c = 0;
+  int seg_end = any_ps ? min(nchunks, cps - (int)((uint32_t)(p_begin / 32) - (uint32_t)n_cur * (uint32_t)cps)) : nchunks;
+  while (c < nchunks) {
+    // the NEXT segment's scales are fetched now and used after this segment's chunks
+    float s_nxt = s_cur, cd_nxt = cd_cur;
+    if (any_ps && seg_end < nchunks) {
+      const float2 e = seg_scale[n_cur + 1 - n_first];
+      s_nxt = e.x;
+      cd_nxt = e.y;
+    }
+    for (; c < seg_end; ++c) {
+      const int buf = c & 1;
+      if (c + 1 < nchunks) load_chunk(c + 1);
+      mma_chunk(buf);
+      if (c + 1 < nchunks) store_chunk(buf ^ 1);
+      __syncthreads();
+    }
+    if (c < nchunks) {                                       // entering the next sample: re-scale the accumulators (powers of two: exact)
+      if (s_nxt != s_cur || cd_nxt != cd_cur) {
+        const float ratio = s_nxt / s_cur, bratio = cd_nxt / cd_cur;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= ratio;
+        bsum[0] *= bratio;
+        bsum[1] *= bratio;
+      }
+      ++n_cur; s_cur = s_nxt; cd_cur = cd_nxt;
+      seg_end = min(nchunks, seg_end + cps);
+    }
   }
 
-  const float unscale = F16 ? 1.f / (cx * cd) : 1.f;
+  const float unscale = F16 ? 1.f / s_cur : 1.f;
+  const float cd = cd_cur;
   float* o = out + (size_t)blockIdx.y * d.K * d.Cout;
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
@@ -1469,8 +1542,12 @@ __global__ __launch_bounds__(256) void conv1x1_smallcout_kernel(const float* __r
                                                                 const float* __restrict__ bias, float* __restrict__ y,
                                                                 const float* __restrict__ dy, float* __restrict__ dx,
                                                                 float* __restrict__ part, int Cin, int act, int M,
-                                                                float* __restrict__ dxamax) {
+                                                                float* __restrict__ dxamax, int rows_per_sample) {
   float dmax = 0.f;                                 // max |dx| written by this thread (backward, optional absmax record)
+  // per-sample record of dx (rows_per_sample > 0): a workgroup then walks a CONTIGUOUS run of pixels (grid-stride otherwise), i.e. one or
+  // two samples, and commits its maximum whenever the run enters another sample
+  const bool ps_rec = BWD && dxamax != nullptr && rows_per_sample > 0;
+  int n_cur = -1;
   const int cq = Cin >> 2;                          // channel quads per pixel (power of two, 4..64)
   const int q = threadIdx.x & (cq - 1), pl = threadIdx.x / cq, ppb = 256 / cq;
   float4 wr[COUT];                                  // wr[o] = w[4q..4q+3][o]
@@ -1491,9 +1568,17 @@ __global__ __launch_bounds__(256) void conv1x1_smallcout_kernel(const float* __r
   for (int it = 0; it < steps; ++it) {              // uniform trip count: the shuffles below need whole wavefronts
     int mm[U];
     float4 xu[U];
+    if (ps_rec) {                                   // (block-uniform: the ppb pixels of a step lie in one sample, rows_per_sample % ppb == 0)
+      const int n_it = min((blockIdx.x * steps + it) * ppb, M - 1) / rows_per_sample;
+      if (n_it != n_cur) {
+        if (n_cur >= 0) amax_commit_block_sample<true>(dmax, dxamax, n_cur);
+        dmax = 0.f;
+        n_cur = n_it;
+      }
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      mm[u] = ((it * U + u) * gridDim.x + blockIdx.x) * ppb + pl;
+      mm[u] = ps_rec ? (blockIdx.x * steps + it) * ppb + pl : ((it * U + u) * gridDim.x + blockIdx.x) * ppb + pl;
       xu[u] = mm[u] < M ? *reinterpret_cast<const float4*>(x + (size_t)mm[u] * Cin + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
@@ -1558,7 +1643,8 @@ __global__ __launch_bounds__(256) void conv1x1_smallcout_kernel(const float* __r
       }
       __syncthreads();
     }
-    if (dxamax != nullptr) amax_commit_block(dmax, dxamax);
+    if (ps_rec) amax_commit_block_sample<true>(dmax, dxamax, n_cur < 0 ? 0 : n_cur);
+    else if (dxamax != nullptr) amax_commit_block(dmax, dxamax);
   }
 }
 
@@ -1904,7 +1990,7 @@ int ladder_conv2d_fwd(const float* x, const float* w, const float* bias, float* 
   if (smallcout_eligible(Cin, Cout, KH, KW, stride, (long)N * Ho * Wo) && ladder_aligned16(x)) {
     const int M = N * Ho * Wo, blocks = smallcout_blocks(M, Cin);
 #define LADDER_SCO_FWD(CO_) hipLaunchKernelGGL((conv1x1_smallcout_kernel<CO_, false>), dim3(blocks), dim3(256), 0, stream, x, w, bias, y, \
-                                               (const float*)nullptr, (float*)nullptr, (float*)nullptr, Cin, act, M, (float*)nullptr)
+                                               (const float*)nullptr, (float*)nullptr, (float*)nullptr, Cin, act, M, (float*)nullptr, 0)
     switch (Cout) { case 1: LADDER_SCO_FWD(1); break; case 2: LADDER_SCO_FWD(2); break; case 3: LADDER_SCO_FWD(3); break; default: LADDER_SCO_FWD(4); }
 #undef LADDER_SCO_FWD
     LADDER_CHECK_LAUNCH();
@@ -2191,12 +2277,16 @@ size_t ladder_conv1x1_smallcout_bwd_workspace_bytes(long M, int Cin, int Cout) {
 
 int ladder_conv1x1_smallcout_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long M, int Cin,
                                  int Cout, int gate_act, void* ws, size_t ws_bytes, ladder_stream_t stream) {
-  return ladder_conv1x1_smallcout_bwd_absmax(x, dy, w, dx, dw, db, M, Cin, Cout, gate_act, ws, ws_bytes, nullptr, stream);
+  return ladder_conv1x1_smallcout_bwd_absmax(x, dy, w, dx, dw, db, M, Cin, Cout, gate_act, ws, ws_bytes, nullptr, 0, stream);
 }
 
 int ladder_conv1x1_smallcout_bwd_absmax(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long M, int Cin,
-                                        int Cout, int gate_act, void* ws, size_t ws_bytes, float* dx_absmax, ladder_stream_t stream) {
+                                        int Cout, int gate_act, void* ws, size_t ws_bytes, float* dx_absmax, long rows_per_sample,
+                                        ladder_stream_t stream) {
   if (!smallcout_eligible(Cin, Cout, 1, 1, 1, M)) return LADDER_E_SHAPE;
+  // per-sample record only where a step's pixels (256 / (Cin / 4) of them) never straddle two samples
+  const int rps = (rows_per_sample > 0 && rows_per_sample < (1L << 30) && (M % rows_per_sample) == 0 &&
+                   (rows_per_sample % (256 / (Cin >> 2))) == 0) ? (int)rows_per_sample : 0;
   if (dx_absmax != nullptr && (dx == nullptr || hipMemsetAsync(dx_absmax, 0, LADDER_ABSMAX_FLOATS * sizeof(float), stream) != hipSuccess))
     return LADDER_E_SHAPE;
   if (!ladder_aligned16(x) || (dx != nullptr && !ladder_aligned16(dx))) return LADDER_E_ALIGN;
@@ -2204,7 +2294,7 @@ int ladder_conv1x1_smallcout_bwd_absmax(const float* x, const float* dy, const f
   const int blocks = smallcout_blocks(M, Cin), kn = Cin * Cout;
   float* part = (float*)ws;
 #define LADDER_SCO_BWD(CO_) hipLaunchKernelGGL((conv1x1_smallcout_kernel<CO_, true>), dim3(blocks), dim3(256), 0, stream, x, w, (const float*)nullptr, \
-                                               (float*)nullptr, dy, dx, part, Cin, gate_act, (int)M, dx_absmax)
+                                               (float*)nullptr, dy, dx, part, Cin, gate_act, (int)M, dx_absmax, rps)
   switch (Cout) { case 1: LADDER_SCO_BWD(1); break; case 2: LADDER_SCO_BWD(2); break; case 3: LADDER_SCO_BWD(3); break; default: LADDER_SCO_BWD(4); }
 #undef LADDER_SCO_BWD
   // partial layout per block: [Cin*Cout filter gradient | Cout bias gradient]

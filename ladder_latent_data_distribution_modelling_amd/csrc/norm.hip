@@ -280,7 +280,10 @@ __global__ __launch_bounds__(256) void bn_apply_planes_kernel(const float* __res
   int c = (int)((i0 * 4) % C);
   float4 mu = *reinterpret_cast<const float4*>(mean_rstd + c), rs = *reinterpret_cast<const float4*>(mean_rstd + C + c);
   float4 g = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
-  if (i0 == 0) *reinterpret_cast<uint4*>(planes + 2 * n) = make_uint4(0u, 0u, 0u, 0u);      // the zero pad behind the last plane
+  if (i0 == 0) {
+    *reinterpret_cast<uint4*>(planes + 2 * n) = make_uint4(0u, 0u, 0u, 0u);      // the zero pad behind the last plane
+    *reinterpret_cast<uint4*>(planes + 2 * n + 8) = make_uint4(0u, 0u, 0u, 0u);  // header (ladder_presplit): ONE scale for the tensor
+  }
   for (size_t i = i0; i < n / 4; i += stride) {
     if (!fixed) {
       c = (int)((i * 4) % C);
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__
     *reinterpret_cast<float4*>(y + i) = o;
     ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
   }
-  if (yamax != nullptr) amax_commit_block(ymax, yamax);
+  if (yamax != nullptr) amax_commit_block_sample(ymax, yamax, n);      // (blockIdx.y = sample: a per-sample record)
 }
 
 // backward statistics: part[.,0] = sum dp*xhat, part[.,1] = sum dp
@@ -617,7 +620,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* __restri
     *reinterpret_cast<float4*>(dx + i) = make_float4(o[0], o[1], o[2], o[3]);
     omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
   }
-  if (dxamax != nullptr) amax_commit_block(omax, dxamax);
+  if (dxamax != nullptr) amax_commit_block_sample(omax, dxamax, n);
 }
 
 inline int in_split(int N, int HW, int C) {
@@ -721,7 +724,7 @@ __global__ __launch_bounds__(256) void in_apply_resize2x_kernel(const float* __r
     *reinterpret_cast<float4*>(o + (size_t)OW * C) = rz_lerp(tl, bl, 0.5f);
     *reinterpret_cast<float4*>(o + (size_t)OW * C + C) = rz_lerp(top, bot, 0.5f);
   }
-  if (yamax != nullptr) amax_commit_block(ymax, yamax);
+  if (yamax != nullptr) amax_commit_block_sample(ymax, yamax, n);
 }
 
 // transpose of the map above in gather form (no atomics): input pixel (iy,ix) collects every output

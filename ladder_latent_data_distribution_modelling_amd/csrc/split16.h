@@ -69,6 +69,18 @@ __device__ __forceinline__ float scale_from_absmax(float amax) {
   return __builtin_bit_cast(float, (uint32_t)se << 23);
 }
 
+// a wave-uniform float back into a scalar register (float arithmetic runs on the vector unit even on uniform operands)
+__device__ __forceinline__ float uniform_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+
+// Scale of sample n (see the record layouts in common.h): its own power-of-two scale when the record carries per-sample bounds, capped at
+// 2^AMAX_PS_CAP above the tensor-wide scale ct = scale_from_absmax(tmax) (an all-zero sample takes ct), else ct.
+__device__ __forceinline__ float scale_for_sample(const float* rec, int n, bool per_sample, float tmax) {
+  const float ct = scale_from_absmax(tmax);
+  if (!per_sample) return ct;
+  const float bn = rec[amax_ps_index(n)];
+  return bn > 0.f ? fminf(scale_from_absmax(bn), ct * (float)(1 << AMAX_PS_CAP)) : ct;
+}
+
 template <bool F16>
 __device__ __forceinline__ f32x16 mfma16(const uint4 a, const uint4 b, const f32x16 c) {
   if (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);

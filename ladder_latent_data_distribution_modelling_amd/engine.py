@@ -272,13 +272,17 @@ class Ctx:
 
     def absmax(self, t):
         """Absolute-maximum record of `t` (an upper bound is as good: it only moves the 2^-38 representation floor); None when
-        the precision mode needs none."""
+        the precision mode needs none.  A standalone pass writes a PER-SAMPLE record for [N, ...] tensors (include/ladder_hip.h)."""
         if self.ns != 4:
             return None
         rec = self.known_amax(t)
         if rec is None:
             rec = self.new_amax()
-            L.call("ladder_absmax", _p(t), t.numel(), _p(rec), self.stream)
+            per = t.numel() // int(t.shape[0]) if t.dim() >= 2 else 0
+            if per and per % 4 == 0 and int(t.shape[0]) > 1:
+                L.call("ladder_absmax_samples", _p(t), int(t.shape[0]), per, _p(rec), self.stream)
+            else:
+                L.call("ladder_absmax", _p(t), t.numel(), _p(rec), self.stream)
             self.set_amax(t, rec)
         return rec
 
@@ -288,16 +292,19 @@ class Ctx:
         k, reg = id(t), self._planes
         reg[k] = (weakref.ref(t, lambda _r, k=k, reg=reg: reg.pop(k, None)), buf)
 
-    def planes(self, t):
+    def planes(self, t, per_sample=False):
         """Pre-split 16-bit planes of `t` (ladder_presplit) for the gather kernels, cached per tensor object like the absmax records:
         a layer input is split once and serves the forward call and the filter gradient, an output gradient the backward-data call
-        and the filter gradient."""
+        and the filter gradient.  `per_sample`: scale every sample by its own maximum (when the record carries per-sample bounds; the
+        planes' header tells the consumer) -- the caller asks for it only where the filter-gradient kernel can follow (a sample's output
+        pixels a multiple of its 32-pixel chunks)."""
         e = self._planes.get(id(t))
         if e is not None and e[0]() is t:
             return e[1]
         import weakref
         buf = torch.empty(L.query("ladder_presplit_bytes", t.numel(), self.ns), dtype=torch.uint8, device=self.device)
-        L.call("ladder_presplit", _p(t), _p(self.absmax(t)), _p(buf), t.numel(), self.ns, self.stream)
+        ns = int(t.shape[0]) if (per_sample and t.dim() == 4 and (t.numel() // int(t.shape[0])) % 8 == 0) else 0
+        L.call("ladder_presplit", _p(t), _p(self.absmax(t)), _p(buf), t.numel(), ns, self.ns, self.stream)
         k, reg = id(t), self._planes
         reg[k] = (weakref.ref(t, lambda _r, k=k, reg=reg: reg.pop(k, None)), buf)
         return buf
@@ -421,6 +428,12 @@ class Conv2D:
         return bool(self.ctx.ns and self.k == 1 and self.stride == 1 and M <= 512 and self.cin >= 16
                     and L.query("ladder_dense_small_eligible", M, self.cin, self.cout))
 
+    @staticmethod
+    def _ps(Ho, Wo):
+        """Per-sample f16x3 scales for the planes of this layer's operands: where the split filter-gradient kernel, which shares them,
+        can re-scale at sample boundaries (a sample's output pixels = whole 32-pixel chunks)."""
+        return (Ho * Wo) % 32 == 0
+
     def _rgb(self, N, H, W):
         # (the kernels are f16x3 inside -- the filter gradient takes tensor-wide absmax records -- so they belong to that precision mode)
         return bool(self.ctx.ns == 4 and self.cin == 3 and L.query("ladder_conv_rgb_s2_eligible", N, H, W, self.cin, self.cout, self.k, self.k,
@@ -521,11 +534,11 @@ class Conv2D:
                 if snb:                                  # the epilogue also emits the batch-norm statistics of y (no second pass over it)
                     swp, swn = self.ctx.ws(snb)
                     self.bn_sums = self.ctx.empty(4 * self.cout)
-                    L.call("ladder_conv2d_fwd_split_bnstats", _p(self.ctx.planes(x)), _p(self.x_amax), _p(self._packed_filter(0)),
+                    L.call("ladder_conv2d_fwd_split_bnstats", _p(self.ctx.planes(x, self._ps(Ho, Wo))), _p(self.x_amax), _p(self._packed_filter(0)),
                            _p(self.ps.w[self.name + "/bias"]), _p(y), *geo, 0, self.ctx.ns, _p(self.bn_sums), swp, swn, self.ctx.stream)
                     self.x, self.y = x, y
                     return y
-            args = (_p(self.ctx.planes(x)), _p(self.x_amax), _p(self._packed_filter(0)), _p(self.ps.w[self.name + "/bias"]), _p(y)) + geo + (
+            args = (_p(self.ctx.planes(x, self._ps(Ho, Wo))), _p(self.x_amax), _p(self._packed_filter(0)), _p(self.ps.w[self.name + "/bias"]), _p(y)) + geo + (
                 L.ACT[self.act], self.ctx.ns, wsp, wsn, self.ctx.stream)
             if nb:                                       # split-K launch: two kernels, not attributed by the profiler
                 L.call("ladder_conv2d_fwd_split", *args)
@@ -558,7 +571,7 @@ class Conv2D:
             dx_amax = self.ctx.new_amax() if (need_dx and self.ctx.ns == 4) else None
             L.call("ladder_conv1x1_smallcout_bwd_absmax", _p(x), _p(dy), _p(self.ps.w[self.name + "/kernel"]), _p(dx),
                    _p(self.ps.g[self.name + "/kernel"]), _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, M, self.cin,
-                   self.cout, L.ACT[gate_prev] if gate_prev else 0, wsp, wsn, _p(dx_amax), st)
+                   self.cout, L.ACT[gate_prev] if gate_prev else 0, wsp, wsn, _p(dx_amax), H * W, st)
             if dx is not None:
                 self.ctx.set_amax(dx, dx_amax)
             self.x = self.y = None
@@ -605,7 +618,8 @@ class Conv2D:
                 if getattr(self, "x_amax", None) is None:
                     self.x_amax = self.ctx.absmax(x)
                 dy_amax = self.ctx.absmax(dy)
-            xpl, dpl = self.ctx.planes(x), self.ctx.planes(dy)          # (split on the main stream: backward-data reads dy's planes too)
+            ps_ = self._ps(Ho, Wo)
+            xpl, dpl = self.ctx.planes(x, ps_), self.ctx.planes(dy, ps_)          # (split on the main stream: backward-data reads dy's planes too)
             with self.ctx.side_or_main(x, dy, xpl, dpl, self.x_amax, dy_amax):
                 wsp, wsn = self.ctx.ws(L.query("ladder_conv2d_bwd_filter_split_workspace_bytes", N, H, W, self.cin, Ho, Wo, self.cout, self.k,
                                                self.k))
@@ -641,7 +655,7 @@ class Conv2D:
                 dy_amax = self.ctx.absmax(dy)
             wsp, wsn = self.ctx.ws(L.query("ladder_conv2d_bwd_data_split_workspace_bytes", *geo))
             dx = self.ctx.empty(N, H, W, self.cin)
-            L.call("ladder_conv2d_bwd_data_split", _p(self.ctx.planes(dy)), _p(dy_amax), _p(self._packed_filter(1)), _p(dx), *geo,
+            L.call("ladder_conv2d_bwd_data_split", _p(self.ctx.planes(dy, self._ps(Ho, Wo))), _p(dy_amax), _p(self._packed_filter(1)), _p(dx), *geo,
                    _p(x) if gate_prev else None, L.ACT[gate_prev] if gate_prev else 0, self.ctx.ns, wsp, wsn, st)
         elif need_dx:
             w = self.ps.w[self.name + "/kernel"]

@@ -1,0 +1,145 @@
+"""Long-horizon numerics of the default f16x3 contraction mode (round 3, VERDICT r2 items 2c / "what's missing" 5):
+no test before this one ran more than 2 iterations in f16x3.
+
+  * five complete 4-run iterations of the full-resolution CelebA network (batch 8) against the float64 oracle with explicit noise, in
+    f16x3 AND in native fp32: every iteration's ELBO / elbo_prior within the BASELINE bar, and f16x3 no further from the oracle than
+    the fp32 build is (up to a small factor);
+  * a 200-iteration full-size trajectory (batch 128, device noise, four alternating minibatches) in f16x3, bf16x6 and native fp32 from the
+    same seeds.  Training dynamics amplify ANY rounding difference (Adam's first steps are sign-like; leaky-ReLU masks flip): two fp32-class
+    builds decorrelate after ~20 iterations -- measured on MI355X (profiles/r03_traj_*.json): |ELBO_f16x3 - ELBO_f32| / |ELBO_f32| up to
+    1.4e-3 over iterations 0-4, 6e-3 over 5-19, then 2-10 % like any pair of differently rounded runs (fp32 halo kernels vs fp32 generic
+    kernels: 5 %).  So the test pins (i) the early window, where deviations are still rounding-sized, against the bf16x6 build as the
+    yardstick of "another fp32-class rounding", and (ii) the statistics of the late window (mean ELBO of the last 50 iterations, that
+    training made the same progress, nothing non-finite)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import ladder_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_five_iterations_fullres_vs_oracle_f16x3_and_f32():
+    from ladder_latent_data_distribution_modelling_amd.engine import LadderEngine
+    cfg0 = json.load(open(os.path.join(ROOT, "codes", "celeba_config.json")))
+    cfg0["batch_size"] = B = 8
+    rng = np.random.default_rng(31)
+    x = rng.random((B, 128, 128, 3)).astype(np.float32)
+    P = O.init_params(cfg0, seed=9)
+    K = int(cfg0["n_mixtures"])
+    fix = np.load(os.path.join(ROOT, "tests", "golden", "GM_prior_info.npz"))
+    gm = dict(weights=(fix["w_full"][:K] / fix["w_full"][:K].sum()).astype(np.float32), means=fix["m_full"][:K].astype(np.float32),
+              covs=fix["K_full"][:K].astype(np.float32))
+    n_it = 5
+    noises = [[O.make_noise(cfg0, B, rng, np.float32) for _ in range(4)] for _ in range(n_it)]
+    epoch = int(cfg0["sg_pretraining"]) + 1
+    lr_ae = float(cfg0["learning_rate_ae"])
+    lr_s = float(cfg0["learning_rate_sigma"]) * 0.99 ** (epoch - 1)
+    lr_p = float(cfg0["learning_rate_prior"]) * 1.01 ** (epoch - 1)
+    lr_i = float(cfg0["learning_rate_inner_sigma"]) * 1.01 ** (epoch - 1)
+    st = O.OracleState(cfg0, P, np.float64)
+    ref = [O.train_iteration(st, x, noises[i], gm, cur_epoch=epoch, lr_ae=lr_ae) for i in range(n_it)]
+    dev = {}
+    for prec in ("f32", "f16x3"):
+        cfg = dict(cfg0, matmul_precision=prec)
+        eng = LadderEngine(cfg, "cuda:0", values=P, seed=1)
+        eng.set_mixture(gm["weights"], gm["means"], gm["covs"])
+        d = []
+        for i in range(n_it):
+            eng.run_ae(x, lr_ae, noises[i][0], False, False)
+            f1 = eng.fetch()
+            eng.run_sigma(x, lr_s, noises[i][1], False, False)
+            sg = eng.fetch(["sigma"])["sigma"]
+            eng.run_prior(x, lr_p, noises[i][2], False, False)
+            f3 = eng.fetch()
+            eng.run_inner_sigma(x, lr_i, noises[i][3], False, False)
+            r = ref[i]
+            d.append(dict(elbo=abs(f1["elbo"] - float(r["run1"]["elbo"])) / abs(float(r["run1"]["elbo"])),
+                          l1=abs(f1["l1_reconstruction_error"] - float(r["run1"]["l1_reconstruction_error"])) / abs(float(r["run1"]["l1_reconstruction_error"])),
+                          sigma=abs(sg - float(r["run2"]["sigma"])) / abs(float(r["run2"]["sigma"])),
+                          elbo_prior=abs(f3["elbo_prior"] - float(r["run3"]["elbo_prior"])) / max(abs(float(r["run3"]["elbo_prior"])), 1.0)))
+        dev[prec] = d
+        print(prec, [{k: "%.1e" % v for k, v in e.items()} for e in d])
+    for i in range(n_it):
+        # iteration 0 sees identical parameters: kernel accuracy alone (2e-5).  Later iterations start from parameters that went through
+        # Adam's sign-like first steps, where an element whose gradient is within rounding of zero moves by +-lr either way -- in ANY fp32
+        # build: the bar is BASELINE's 1e-3 on the ELBO, and f16x3 may not be further from float64 than 3x the native-fp32 build + 1e-4
+        bar = 2e-5 if i == 0 else 1e-3
+        for prec in ("f32", "f16x3"):
+            assert dev[prec][i]["elbo"] < bar and dev[prec][i]["l1"] < bar and dev[prec][i]["sigma"] < bar, (prec, i, dev[prec][i])
+            assert dev[prec][i]["elbo_prior"] < (2e-4 if i == 0 else 2e-2), (prec, i, dev[prec][i])
+        for k in ("elbo", "l1", "sigma"):
+            assert dev["f16x3"][i][k] <= 3 * dev["f32"][i][k] + 1e-4, (i, k, dev["f16x3"][i][k], dev["f32"][i][k])
+
+
+TRAJ_WORKER = r'''
+import json, os, sys
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+from ladder_latent_data_distribution_modelling_amd import engine as E
+prec, steps, outp = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+cfg = json.load(open(os.path.join(%(root)r, "codes", "celeba_config.json")))
+cfg["matmul_precision"] = prec
+B = cfg["batch_size"]
+eng = E.LadderEngine(cfg, "cuda:0", seed=1, noise_seed=99)
+fix = np.load(os.path.join(%(root)r, "tests", "golden", "GM_prior_info.npz"))
+K = cfg["n_mixtures"]
+eng.set_mixture(fix["w_full"][:K] / fix["w_full"][:K].sum(), fix["m_full"][:K], fix["K_full"][:K])
+xs = [torch.rand(B, 128, 128, 3, generator=torch.Generator().manual_seed(5 + i)).cuda() for i in range(4)]
+rec = dict(elbo=[], elbo_prior=[], grad_norm=[], sigma=[])
+for it in range(steps):
+    x = xs[it %% 4]
+    eng.run_ae(x, 2.5e-4, None, False, False)
+    rec["elbo"].append(eng.fetch()["elbo"])
+    rec["grad_norm"].append(float(eng.ps.grad["ae"].double().norm()))
+    eng.run_sigma(x, 2.5e-4, None, False, False, reuse_encoder=False)
+    rec["sigma"].append(eng.fetch(["sigma"])["sigma"])
+    eng.run_prior(x, 1.25e-4, None, False, False, reuse_encoder=True)
+    rec["elbo_prior"].append(eng.fetch()["elbo_prior"])
+    eng.run_inner_sigma(x, 2e-4, None, False, False, reuse_encoder=True)
+json.dump(rec, open(outp, "w"))
+'''
+
+
+def test_200_iteration_trajectory_f16x3_vs_f32_full_size(tmp_path):
+    steps = 200
+    script = tmp_path / "traj_worker.py"
+    script.write_text(TRAJ_WORKER % dict(root=ROOT))
+    T = {}
+    for prec in ("f32", "f16x3", "bf16x6"):
+        outp = str(tmp_path / (prec + ".json"))
+        p = subprocess.run([sys.executable, str(script), prec, str(steps), outp], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
+        assert p.returncode == 0, p.stdout[-2000:]
+        T[prec] = {k: np.asarray(v, np.float64) for k, v in json.load(open(outp)).items()}
+    for prec, t in T.items():
+        for k, v in t.items():
+            assert np.isfinite(v).all() and len(v) == steps, (prec, k)
+    rel = lambda a, b: np.abs(a - b) / np.abs(b)
+    e32 = T["f32"]["elbo"]
+    d16, dbf = rel(T["f16x3"]["elbo"], e32), rel(T["bf16x6"]["elbo"], e32)
+    g16, gbf = rel(T["f16x3"]["grad_norm"], T["f32"]["grad_norm"]), rel(T["bf16x6"]["grad_norm"], T["f32"]["grad_norm"])
+    print("ELBO deviation from f32, max over iterations 0-4 / 5-19 / 20-199: f16x3 %.1e %.1e %.1e | bf16x6 %.1e %.1e %.1e" % (
+        d16[:5].max(), d16[5:20].max(), d16[20:].max(), dbf[:5].max(), dbf[5:20].max(), dbf[20:].max()))
+    print("gradient-norm deviation, iteration 0 / max 0-4: f16x3 %.1e %.1e | bf16x6 %.1e %.1e" % (g16[0], g16[:5].max(), gbf[0], gbf[:5].max()))
+    # iteration 0: identical parameters -- kernel rounding only
+    assert d16[0] < 2e-6 and g16[0] < 1e-4
+    # early window: still rounding-sized, and f16x3 behaves like the other fp32-class split format (same planes-and-products scheme
+    # with 24-bit operands): within 4x of its deviation (+ a floor), and small in absolute terms
+    assert d16[:5].max() < 5e-3 and d16[:5].max() <= 4 * dbf[:5].max() + 5e-4, (d16[:5].max(), dbf[:5].max())
+    assert d16[5:20].max() < 3e-2 and d16[5:20].max() <= 4 * dbf[5:20].max() + 3e-3, (d16[5:20].max(), dbf[5:20].max())
+    # late window: decorrelated trajectories of the same training run -- the statistics agree
+    m32, m16, mbf = e32[-50:].mean(), T["f16x3"]["elbo"][-50:].mean(), T["bf16x6"]["elbo"][-50:].mean()
+    assert abs(m16 - m32) / abs(m32) < 0.05 and abs(mbf - m32) / abs(m32) < 0.05, (m32, m16, mbf)
+    for prec in T:
+        e = T[prec]["elbo"]
+        assert e[-50:].mean() > e[1:11].mean(), prec                       # the ELBO of the 4 minibatches improved in every build
+        assert e[-50:].mean() > 0.5 * e[0], prec                           # ... by a lot (it starts at -7.4e4 and reaches ~-2.3e4)
+    s32, s16 = T["f32"]["sigma"], T["f16x3"]["sigma"]
+    assert rel(s16, s32)[:20].max() < 2e-2

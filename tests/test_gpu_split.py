@@ -56,17 +56,38 @@ def test_absmax_is_exact(gpu_ctx, n):
     if n % 2 == 0:
         x = (x * 1e-33).astype(np.float32)
     xd = dev(x)
-    got = absmax(L, xd, gpu_ctx.stream).max().item()
+    got = recmax(absmax(L, xd, gpu_ctx.stream))
     assert got == float(np.abs(x).max())
     z = torch.zeros(n, device="cuda")
-    assert absmax(L, z, gpu_ctx.stream).max().item() == 0.0
+    assert recmax(absmax(L, z, gpu_ctx.stream)) == 0.0
 
 
-def presplit(L, t, rec, P, st):
-    """Pre-split planes of a tensor (ladder_presplit): what the gather kernels consume."""
+def presplit(L, t, rec, P, st, n_samples=0):
+    """Pre-split planes of a tensor (ladder_presplit): what the gather kernels consume.  n_samples > 0 + a per-sample record: every
+    sample scaled by its own maximum (the planes' header tells the consumer)."""
     buf = torch.empty(L.query("ladder_presplit_bytes", t.numel(), P), dtype=torch.uint8, device="cuda")
-    L.call("ladder_presplit", p(t), p(rec), p(buf), t.numel(), P, st)
+    L.call("ladder_presplit", p(t), p(rec), p(buf), t.numel(), n_samples, P, st)
     return buf
+
+
+def recmax(rec):
+    """Tensor-wide bound of an absolute-maximum record in either layout (float 1 is the mode flag, include/ladder_hip.h)."""
+    r = rec.clone()
+    r[1] = 0
+    return r.max().item()
+
+
+def rec_sample(rec, n):
+    """Bound of sample n in a per-sample (mode 1) record."""
+    assert rec[1].item() != 0, "not a per-sample record"
+    return rec[(n & 15) * 32 + 2 + ((n >> 4) % 30)].item()
+
+
+def absmax_samples(L, t, st):
+    """Per-sample record of an [N, ...] tensor (ladder_absmax_samples)."""
+    out = torch.empty(L.ABSMAX_FLOATS, device="cuda")
+    L.call("ladder_absmax_samples", p(t), t.shape[0], t.numel() // t.shape[0], p(out), st)
+    return out
 
 
 def _fill(rng, shape, kind):
@@ -121,7 +142,9 @@ def test_conv3x3_split_fwd_bwd(gpu_ctx, case, prec):
     ya = torch.full((L.ABSMAX_FLOATS,), 7.0, device="cuda")          # (the call zeroes the record before filling it)
     L.call("ladder_conv3x3_split", p(xd), p(xa), p(pk), p(bd), p(y), p(ya), N, H, W, Cin, Cout, L.ACT[act], P, st)
     close(y, yr, tf, "fwd")
-    assert ya.max().item() == y.abs().max().item()                   # the fused output record is exact
+    assert recmax(ya) == y.abs().max().item()                        # the fused output record is exact ...
+    for n in (0, N // 2, N - 1):                                      # ... and per sample (mode 1)
+        assert rec_sample(ya, n) == y[n].abs().max().item()
     # a looser (x8) absmax bound only moves the representation floor
     if prec == "f16x3":
         y2 = torch.empty_like(y)
@@ -295,18 +318,26 @@ def test_fused_absmax_records_of_producers(gpu_ctx):
     L.call("ladder_in_style_fwd_absmax", p(x), p(style), p(y), p(mr), N, H * W, C, 1e-6, 1, wsp, wsn, p(rec), st)
     y0 = torch.empty_like(x)
     L.call("ladder_in_style_fwd", p(x), p(style), p(y0), p(mr), N, H * W, C, 1e-6, 1, wsp, wsn, st)
-    assert torch.equal(y, y0) and rec.max().item() == y.abs().max().item()
+    assert torch.equal(y, y0) and recmax(rec) == y.abs().max().item()
+    assert all(rec_sample(rec, n) == y[n].abs().max().item() for n in range(N))       # instance-norm works per sample: a per-sample record
     dx, dx0, ds = torch.empty_like(x), torch.empty_like(x), torch.empty(N, 2 * C, device="cuda")
     L.call("ladder_in_style_bwd_absmax", p(dy), p(x), p(style), p(mr), p(dx), p(ds), N, H * W, C, 1, wsp, wsn, p(rec), st)
     L.call("ladder_in_style_bwd", p(dy), p(x), p(style), p(mr), p(dx0), p(ds), N, H * W, C, 1, wsp, wsn, st)
-    assert torch.equal(dx, dx0) and rec.max().item() == dx.abs().max().item()
+    assert torch.equal(dx, dx0) and recmax(rec) == dx.abs().max().item()
+    assert all(rec_sample(rec, n) == dx[n].abs().max().item() for n in range(N))
     M, Cin, Cout = 8 * 128 * 128, 128, 3
     xs, dys, w = dev(rng.standard_normal((M, Cin))), dev(rng.standard_normal((M, Cout))), dev(rng.standard_normal((Cin, Cout)) * 0.1)
     dxs, dxs0, dw, db = torch.empty_like(xs), torch.empty_like(xs), torch.empty_like(w), torch.empty(Cout, device="cuda")
     wsp, wsn = gpu_ctx.ws(L.query("ladder_conv1x1_smallcout_bwd_workspace_bytes", M, Cin, Cout))
-    L.call("ladder_conv1x1_smallcout_bwd_absmax", p(xs), p(dys), p(w), p(dxs), p(dw), p(db), M, Cin, Cout, 1, wsp, wsn, p(rec), st)
+    L.call("ladder_conv1x1_smallcout_bwd_absmax", p(xs), p(dys), p(w), p(dxs), p(dw), p(db), M, Cin, Cout, 1, wsp, wsn, p(rec), 0, st)
+    dw0, db0 = dw.clone(), db.clone()
     L.call("ladder_conv1x1_smallcout_bwd", p(xs), p(dys), p(w), p(dxs0), p(dw), p(db), M, Cin, Cout, 1, wsp, wsn, st)
-    assert torch.equal(dxs, dxs0) and rec.max().item() == dxs.abs().max().item()
+    assert torch.equal(dxs, dxs0) and recmax(rec) == dxs.abs().max().item() and rec[1].item() == 0      # one bound for the tensor
+    # per-sample record (rows_per_sample = H*W): the workgroups walk contiguous pixel runs; dx identical, dw / db up to summation order
+    L.call("ladder_conv1x1_smallcout_bwd_absmax", p(xs), p(dys), p(w), p(dxs), p(dw), p(db), M, Cin, Cout, 1, wsp, wsn, p(rec), 128 * 128, st)
+    assert torch.equal(dxs, dxs0) and recmax(rec) == dxs.abs().max().item()
+    assert all(rec_sample(rec, n) == dxs.reshape(8, -1)[n].abs().max().item() for n in range(8))
+    assert (dw - dw0).abs().max().item() <= 1e-5 * dw0.abs().max().item() and (db - db0).abs().max().item() <= 1e-5 * db0.abs().max().item()
     # batch-norm apply, forward and backward (encoder layers): big enough for the grid-stride loop to iterate (> 2048 x 256 float4)
     rows, C = 128 * 70 * 70, 32
     xb, dyb = dev(rng.standard_normal((rows, C)) * 3 + 1), dev(rng.standard_normal((rows, C)) * 1e-3)
@@ -317,13 +348,13 @@ def test_fused_absmax_records_of_producers(gpu_ctx):
     yb, yb0 = torch.empty_like(xb), torch.empty_like(xb)
     L.call("ladder_bn_fwd_apply_absmax", p(xb), p(sums), float(rows), p(gam), p(bet), p(yb), p(mrb), rows, C, 1e-3, 1, p(rec), st)
     L.call("ladder_bn_fwd_apply", p(xb), p(sums), float(rows), p(gam), p(bet), p(yb0), p(mrb), rows, C, 1e-3, 1, st)
-    assert torch.equal(yb, yb0) and rec.max().item() == yb.abs().max().item()
+    assert torch.equal(yb, yb0) and recmax(rec) == yb.abs().max().item()
     L.call("ladder_bn_bwd_stats", p(dyb), p(xb), p(mrb), p(gam), p(bet), p(dsums), rows, C, 1, wsp, wsn, st)
     dxb, dxb0, dg, dbt = torch.empty_like(xb), torch.empty_like(xb), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
     L.call("ladder_bn_bwd_apply_absmax", p(dyb), p(xb), p(mrb), p(gam), p(bet), p(dsums), float(rows), p(dxb), p(dg), p(dbt), rows, C, 1,
            p(rec), st)
     L.call("ladder_bn_bwd_apply", p(dyb), p(xb), p(mrb), p(gam), p(bet), p(dsums), float(rows), p(dxb0), p(dg), p(dbt), rows, C, 1, st)
-    assert torch.equal(dxb, dxb0) and rec.max().item() == dxb.abs().max().item()
+    assert torch.equal(dxb, dxb0) and recmax(rec) == dxb.abs().max().item()
     assert L.query("ladder_bn_bwd_apply_absmax", p(dyb), p(xb), p(mrb), p(gam), p(bet), p(dsums), float(rows), None, p(dg), p(dbt), rows, C,
                    1, p(rec), st) != 0                            # a record of a tensor that is not written
 
@@ -478,7 +509,7 @@ def test_instance_norm_fused_with_resize(gpu_ctx, shape):
     up, mr2, rec = torch.empty_like(up0), torch.empty_like(mr), torch.empty(L.ABSMAX_FLOATS, device="cuda")
     L.call("ladder_in_style_fwd_resize2x", p(x), p(style), p(up), p(mr2), N, H, W, C, 1e-6, 1, wsp, wsn, p(rec), st)
     assert torch.equal(up, up0) and torch.equal(mr2, mr)
-    assert rec.max().item() == y.abs().max().item()
+    assert recmax(rec) == y.abs().max().item()
     assert L.query("ladder_in_style_fwd_resize2x", p(x), p(style), p(up), p(mr2), N, H, W, C, 1e-6, 1, None, 0, p(rec), st) != 0
 
 
@@ -558,7 +589,7 @@ def test_bn_apply_emits_planes(gpu_ctx, rows, C):
         y, mr, rec = torch.empty_like(x), torch.empty(2 * C, device="cuda"), torch.empty(L.ABSMAX_FLOATS, device="cuda")
         L.call("ladder_bn_fwd_apply_planes", p(x), p(s4), float(rows), p(gam), p(bet), p(y), p(planes), p(mr), rows, C, 1e-3, act, p(rec), st)
         assert torch.equal(y, y0) and torch.equal(mr, mr0)
-        assert rec.max().item() == y0.abs().max().item()                              # the exact maximum, known before y was written
+        assert recmax(rec) == y0.abs().max().item()                              # the exact maximum, known before y was written
         ref = presplit(L, y0, rec, 4, st)
         assert torch.equal(planes, ref)
         planes2 = torch.zeros_like(planes)
@@ -602,3 +633,186 @@ def test_filter_pack_multi_equals_single(gpu_ctx, prec):
             assert rs.max().item() == rm.max().item() == w.abs().max().item()
     assert L.query("ladder_filter_pack_split_multi", p(tab), len(banks), blk, P, None, 0, st) == -3
     assert L.query("ladder_filter_pack_job_blocks", 9, 24, 128) == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 3 (VERDICT r2 item 2a): the f16x3 hazard probed with a PER-OUTPUT error metric.  `close()` above divides the largest error by the
+# tensor-wide max|ref|, which hides a bulk output that is off by 20 % beside a few huge ones.  Here every output element is held to
+#     |got - ref| <= tol * sum_k |a_k| |b_k|          (the form of the fp32 dot-product bound gamma_K * sum |a||b|)
+# on operands with (i) a per-SAMPLE scale disparity of 2^30 across the batch and (ii) an in-tensor dynamic range of 2^20 .. 2^30.  A
+# per-tensor f16x3 scale represents an element only to 2^-38 of the TENSOR maximum: samples 2^-16 below it lose relative precision
+# (the round-2 format failed (i) by four orders of magnitude); with per-sample scales (mode-1 records) the fp32-class bound holds
+# for every sample.  tol = 6 * 2^-22 = 1.4e-6 = twice the format's worst case PER PRODUCT, 3 * 2^-22 = 7.2e-7 (two 11-bit fp16 planes leave a
+# representation error <= 2^-22 |a| per operand, the dropped a1*b1 term <= 2^-22 |ab|), reached only when one product carries the whole sum
+# (measured 6.6e-7 on the 2^24 log-uniform operands); fp32's own worst case gamma_K = K * 2^-24 is 1.7e-5 ... 1.4e-4 for the K = 288 ...
+# 2304 of these layers; the native fp32 kernels measure ~1e-7 on the same metric, f16x3 1e-7 ... 7e-7.
+PER_OUTPUT_TOL = 6 * 2.0 ** -22
+
+
+def _per_output_err(got, ref, mag):
+    got = got.detach().cpu().numpy().astype(np.float64) if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    ref, mag = np.asarray(ref, np.float64), np.asarray(mag, np.float64)
+    assert np.isfinite(got).all()
+    ok = mag > 0
+    return float((np.abs(got - ref)[ok] / mag[ok]).max()), float(np.abs(got - ref)[~ok].max()) if (~ok).any() else 0.0
+
+
+def _disparity_fill(rng, shape, kind):
+    """[N, ...] operand: 'samples' -- sample n scaled by 2^(-30 n / (N-1)), elements log-uniform over 2^12 inside a sample;
+    'range' -- every element log-uniform over 2^24 (no sample structure); 'both' -- samples + a log-uniform factor over 2^8 (2^20 inside
+    a sample, 2^50 across the tensor)."""
+    N = shape[0]
+    x = rng.standard_normal(shape)
+    if kind in ("samples", "both"):
+        x = x * np.exp2(-12.0 * rng.random(shape))
+        x = x * np.exp2(-30.0 * np.arange(N) / (N - 1)).reshape((N,) + (1,) * (len(shape) - 1))
+    if kind in ("range", "both"):          # ('both': 2^20 inside a sample; at 2^36 the floor of the SAMPLE maximum shows: 1.2e-6 measured)
+        x = x * np.exp2((-24.0 if kind == "range" else -8.0) * rng.random(shape))
+    return x.astype(np.float32)
+
+
+@pytest.mark.parametrize("kind", ["samples", "range", "both"])
+@pytest.mark.parametrize("geom", [(64, 32, 64, 32, 128), (64, 64, 64, 32, 128)], ids=["8wave", "16wave"])
+def test_halo_conv_per_output_error_under_scale_disparity(gpu_ctx, geom, kind):
+    """3x3 halo convolution forward and backward-data (both tile variants), f16x3: per-output fp32-class bound on operands whose samples
+    differ in scale by up to 2^30 -- with the per-sample record of ladder_absmax_samples; the same launch with a per-TENSOR record is
+    shown to violate the bound on the 'samples' operands (that is the hazard the per-sample scales remove)."""
+    L = _lib()
+    N, H, W, Cin, Cout = geom
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(7)
+    x = _disparity_fill(rng, (N, H, W, Cin), kind)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    xt, wt = torch.tensor(x, dtype=torch.float64), torch.tensor(w, dtype=torch.float64)
+    yr = O.conv2d_tf(xt, wt, None, 1, "same").numpy()
+    mag = O.conv2d_tf(xt.abs(), wt.abs(), None, 1, "same").numpy()
+    xd, wd = dev(x), dev(w)
+    pk = torch.empty(L.query("ladder_filter_pack_split_bytes", 9, Cin, Cout, 4), dtype=torch.uint8, device="cuda")
+    L.call("ladder_filter_pack_split", p(wd), p(pk), 9, Cin, Cout, 0, 4, st)
+    y = torch.empty(N, H, W, Cout, device="cuda")
+    ya = torch.empty(L.ABSMAX_FLOATS, device="cuda")
+    L.call("ladder_conv3x3_split", p(xd), p(absmax_samples(L, xd, st)), p(pk), None, p(y), p(ya), N, H, W, Cin, Cout, 0, 4, st)
+    e_ps, _ = _per_output_err(y, yr, mag)
+    L.call("ladder_conv3x3_split", p(xd), p(absmax(L, xd, st)), p(pk), None, p(y), None, N, H, W, Cin, Cout, 0, 4, st)
+    e_pt, _ = _per_output_err(y, yr, mag)
+    print("halo conv fwd %s %s: per-output error / sum|a||b|: per-sample scales %.2e, per-tensor scale %.2e (bound %.2e)" % (geom, kind, e_ps, e_pt, PER_OUTPUT_TOL))
+    assert e_ps < PER_OUTPUT_TOL, (kind, e_ps)
+    if kind == "samples":
+        assert e_pt > 100 * PER_OUTPUT_TOL, e_pt            # the round-2 per-tensor format on the same operands: far outside
+    # backward-data = the same kernel on dy with the flipped / transposed bank; dy carries the disparity
+    dy = _disparity_fill(rng, (N, H, W, Cout), kind)
+    dyt = torch.tensor(dy, dtype=torch.float64)
+    wT = torch.flip(wt, (0, 1)).permute(0, 1, 3, 2).contiguous()
+    dxr = O.conv2d_tf(dyt, wT, None, 1, "same").numpy()
+    dmag = O.conv2d_tf(dyt.abs(), wT.abs(), None, 1, "same").numpy()
+    if L.query("ladder_conv3x3_split_eligible", N, H, W, Cout, Cin):
+        pkT = torch.empty(L.query("ladder_filter_pack_split_bytes", 9, Cout, Cin, 4), dtype=torch.uint8, device="cuda")
+        L.call("ladder_filter_pack_split", p(wd), p(pkT), 9, Cout, Cin, 1, 4, st)
+        dyd, dx = dev(dy), torch.empty(N, H, W, Cin, device="cuda")
+        L.call("ladder_conv3x3_split", p(dyd), p(absmax_samples(L, dyd, st)), p(pkT), None, p(dx), None, N, H, W, Cout, Cin, 0, 4, st)
+        e_bd, _ = _per_output_err(dx, dxr, dmag)
+        print("halo conv bwd-data %s %s: %.2e" % (geom, kind, e_bd))
+        assert e_bd < PER_OUTPUT_TOL, (kind, e_bd)
+
+
+@pytest.mark.parametrize("kind", ["samples", "both"])
+@pytest.mark.parametrize("case", [(48, 16, 16, 64, 256, 3, 1, "same"), (64, 16, 16, 256, 256, 3, 2, "same"), (96, 32, 32, 128, 128, 3, 2, "same")],
+                         ids=lambda c: "x".join(str(v) for v in c))
+def test_gather_conv_per_output_error_under_scale_disparity(gpu_ctx, case, kind):
+    """The gather kernels (forward, backward-data incl. the stride-2 parity classes, filter gradient) on planes pre-split with
+    per-sample scales: forward / backward-data meet the per-output fp32-class bound for every sample; the filter gradient, whose
+    reduction runs over all samples (accumulators re-scaled at sample boundaries), meets it against sum over samples of |x||dy|."""
+    L = _lib()
+    from ladder_latent_data_distribution_modelling_amd import arch
+    N, H, W, Cin, Cout, k, s_, pad = case
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(11)
+    x = _disparity_fill(rng, (N, H, W, Cin), kind)
+    w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    yr = O.conv2d_tf(xt, wt, None, s_, pad)
+    pt, Ho = arch.conv_out(H, k, s_, pad)
+    pl, Wo = arch.conv_out(W, k, s_, pad)
+    assert (Ho * Wo) % 32 == 0                               # the engine's rule for per-sample planes (Conv2D._ps)
+    geo = (N, H, W, Cin, Ho, Wo, Cout, k, k, s_, pt, pl)
+    dy = _disparity_fill(rng, tuple(yr.shape), kind)
+    dyt = torch.tensor(dy, dtype=torch.float64)
+    yr.backward(dyt)
+    xa_, wa_ = xt.detach().abs().requires_grad_(True), wt.detach().abs().requires_grad_(True)
+    ymag = O.conv2d_tf(xa_, wa_, None, s_, pad)
+    ymag.backward(dyt.abs())                                 # magnitudes of the gradient sums: sum |dy||w| and sum |x||dy|
+    xd, wd, dyd = dev(x), dev(w), dev(dy)
+    xa, da = absmax_samples(L, xd, st), absmax_samples(L, dyd, st)
+    xpl, dpl = presplit(L, xd, xa, 4, st, n_samples=N), presplit(L, dyd, da, 4, st, n_samples=N)
+    pk = torch.empty(L.query("ladder_filter_pack_split_bytes", k * k, Cin, Cout, 4), dtype=torch.uint8, device="cuda")
+    L.call("ladder_filter_pack_split", p(wd), p(pk), k * k, Cin, Cout, 0, 4, st)
+    y = torch.empty(N, Ho, Wo, Cout, device="cuda")
+    wsp, wsn = gpu_ctx.ws(max(L.query("ladder_conv2d_fwd_split_workspace_bytes", *geo), 16))
+    L.call("ladder_conv2d_fwd_split", p(xpl), p(xa), p(pk), None, p(y), *geo, 0, 4, wsp, wsn, st)
+    e_f, _ = _per_output_err(y, yr.detach().numpy(), ymag.detach().numpy())
+    # the same call on per-TENSOR planes: what round 2 did
+    xa0 = absmax(L, xd, st)
+    L.call("ladder_conv2d_fwd_split", p(presplit(L, xd, xa0, 4, st)), p(xa0), p(pk), None, p(y), *geo, 0, 4, wsp, wsn, st)
+    e_f0, _ = _per_output_err(y, yr.detach().numpy(), ymag.detach().numpy())
+    print("gather fwd %s %s: per-sample %.2e, per-tensor %.2e" % (case, kind, e_f, e_f0))
+    assert e_f < PER_OUTPUT_TOL and e_f0 > 100 * PER_OUTPUT_TOL, (e_f, e_f0)
+    if L.query("ladder_conv2d_bwd_data_split_eligible", *geo, 0):
+        pkT = torch.empty(L.query("ladder_filter_pack_split_bytes", k * k, Cout, Cin, 4), dtype=torch.uint8, device="cuda")
+        L.call("ladder_filter_pack_split", p(wd), p(pkT), k * k, Cout, Cin, 1, 4, st)
+        wsp, wsn = gpu_ctx.ws(max(L.query("ladder_conv2d_bwd_data_split_workspace_bytes", *geo), 16))
+        dx = torch.empty_like(xd)
+        L.call("ladder_conv2d_bwd_data_split", p(dpl), p(da), p(pkT), p(dx), *geo, None, 0, 4, wsp, wsn, st)
+        e_d, _ = _per_output_err(dx, xt.grad.numpy(), xa_.grad.numpy())
+        print("gather bwd-data %s %s: %.2e" % (case, kind, e_d))
+        assert e_d < PER_OUTPUT_TOL, e_d
+    if L.query("ladder_conv2d_bwd_filter_split_eligible", *geo):
+        wsp, wsn = gpu_ctx.ws(L.query("ladder_conv2d_bwd_filter_split_workspace_bytes", *geo[:9]))
+        dw, db = torch.empty_like(wd), torch.empty(Cout, device="cuda")
+        L.call("ladder_conv2d_bwd_filter_split", p(xpl), p(xa), p(dpl), p(da), p(dw), p(db), *geo, 4, wsp, wsn, st)
+        e_w, _ = _per_output_err(dw, wt.grad.numpy(), wa_.grad.numpy())
+        e_b, _ = _per_output_err(db, dyt.sum((0, 1, 2)).numpy(), dyt.abs().sum((0, 1, 2)).numpy())
+        print("gather filter gradient %s %s: dw %.2e db %.2e" % (case, kind, e_w, e_b))
+        assert e_w < PER_OUTPUT_TOL and e_b < PER_OUTPUT_TOL, (e_w, e_b)
+
+
+@pytest.mark.parametrize("kind", ["samples", "both"])
+def test_wgrad3x3_per_output_error_under_scale_disparity(gpu_ctx, kind):
+    """The 3x3 filter-gradient kernel keeps ONE scale per tensor: its reduction runs over every sample, so each output's sum |x||dy| is
+    carried by the large samples and the 2^-38 * max floor of the small ones is far below the bound -- checked, not assumed."""
+    L = _lib()
+    N, H, W, Cin, Cout = 32, 64, 64, 64, 128
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(13)
+    x, dy = _disparity_fill(rng, (N, H, W, Cin), kind), _disparity_fill(rng, (N, H, W, Cout), kind)
+    w = np.zeros((3, 3, Cin, Cout), np.float32)
+    xt, dyt = torch.tensor(x, dtype=torch.float64), torch.tensor(dy, dtype=torch.float64)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    O.conv2d_tf(xt, wt, None, 1, "same").backward(dyt)
+    wm = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    O.conv2d_tf(xt.abs(), wm, None, 1, "same").backward(dyt.abs())
+    xd, dyd = dev(x), dev(dy)
+    assert L.query("ladder_conv3x3_wgrad_split_eligible", N, H, W, Cin, Cout, 4) == 1
+    wsp, wsn = gpu_ctx.ws(L.query("ladder_conv3x3_wgrad_split_workspace_bytes", N, H, W, Cin, Cout))
+    dw, db = torch.empty(3, 3, Cin, Cout, device="cuda"), torch.empty(Cout, device="cuda")
+    for recs in ((absmax_samples(L, xd, st), absmax_samples(L, dyd, st)), (absmax(L, xd, st), absmax(L, dyd, st))):   # either record layout
+        L.call("ladder_conv3x3_wgrad_split", p(xd), p(recs[0]), p(dyd), p(recs[1]), p(dw), p(db), N, H, W, Cin, Cout, 4, wsp, wsn, st)
+        e_w, _ = _per_output_err(dw, wt.grad.numpy(), wm.grad.numpy())
+        e_b, _ = _per_output_err(db, dyt.sum((0, 1, 2)).numpy(), dyt.abs().sum((0, 1, 2)).numpy())
+        print("wgrad3x3 %s: dw %.2e db %.2e" % (kind, e_w, e_b))
+        assert e_w < PER_OUTPUT_TOL and e_b < PER_OUTPUT_TOL, (e_w, e_b)
+
+
+def test_absmax_samples_record(gpu_ctx):
+    """ladder_absmax_samples: exact per-sample maxima in the mode-1 slots, the tensor-wide bound as their maximum; batches beyond the 480
+    distinct slots share slots (still upper bounds)."""
+    L = _lib()
+    rng = np.random.default_rng(3)
+    for N, per in ((128, 2 * 2 * 512), (7, 128 * 128 * 12), (600, 64)):
+        x = (rng.standard_normal((N, per)) * np.exp2(-20 * rng.random((N, 1)))).astype(np.float32)
+        rec = absmax_samples(L, dev(x), gpu_ctx.stream)
+        assert recmax(rec) == float(np.abs(x).max())
+        sm = np.abs(x).max(1)
+        for n in range(N):
+            shared = [m for m in range(N) if (m & 15) == (n & 15) and ((m >> 4) % 30) == ((n >> 4) % 30)]
+            assert rec_sample(rec, n) == float(sm[shared].max()), (N, n)
