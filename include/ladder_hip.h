@@ -364,8 +364,10 @@ int ladder_gmm_prepare(const float* weights, const float* means, const float* co
                        float* packed, ladder_stream_t stream);
 /* R in 1..8.  t[l,b,:] = mu[b,:] + sd[b,:]*eps[l,b,:];  lp = logsumexp_k(...).  Outputs: sum_logp[0] = sum_{l,b} lp;
  * dmu[b,:] = sum_l dlp/dt ; dsd[b,:] = sum_l dlp/dt * eps   (un-normalised; host scales by 1/(L*B_global)).
- * One workgroup per batch row, wavefronts stride over l, lane = component; logsumexp / responsibilities
- * reduced with wave shuffles. */
+ * lane = mixture component; K <= 64: every lane keeps its component's parameters in registers, the L samples of a batch row are
+ * spread over ~2048 / B wavefronts, a sample costs two wave-shuffle reductions (max, sum of exponentials), the gradient terms
+ * accumulate per lane and are reduced once per wavefront; partials in `ws` are summed in a fixed order.  K > 64: one workgroup per
+ * batch row, components in chunks of 64. */
 size_t ladder_gmm_workspace_bytes(int L, int B);
 int ladder_gmm_logprob_fwd_bwd(const float* mu, const float* sd, const float* eps, const float* packed,
                                int L, int B, int R, int K, float* sum_logp, float* dmu, float* dsd,

@@ -422,6 +422,118 @@ __global__ __launch_bounds__(256) void gmm_logprob_kernel(const float* __restric
   }
   if (threadIdx.x == 0) ws_logp[b] = (sm_lp[0] + sm_lp[1]) + (sm_lp[2] + sm_lp[3]);
 }
+// ---- the same reduction with the mixture held in REGISTERS (K <= 64; round 3) ------------------------------------------------------
+// The kernel above re-reads the 1 + R + R(R+1)/2 packed floats of its component from global memory for every MC sample, twice (it makes
+// two passes: maximum, then exponentials), and runs 4 wavefronts on each of only B workgroups -- half the chip idle at B = 128, every
+// wavefront a serial chain of L1 round trips: 116 us for L*B*K = 640 000 evaluations at R = 8 (BASELINE configs[4]).  Here lane k loads
+// its component ONCE (45 registers at R = 8), keeps the whitened residual y = Linv (t - m_k) of the single pass for the gradient
+// (d lp / d t = -sum_k r_k Linv_k^T y_k), and accumulates r_k-weighted gradient terms PER LANE across its samples, so that a sample costs
+// two wave reductions (max, sum of exponentials) instead of 2 + R; the R + R gradient reductions happen once per wavefront.  The L
+// samples of a batch row are spread over S = 4 gridDim.y wavefronts (workgroup (b, g), wavefront w takes l = 4g + w, + S, ...): B * S
+// ~ 2048 wavefronts fill the chip; their partials are summed in a fixed order by gmm_finish_kernel.
+template <int R>
+__global__ __launch_bounds__(256) void gmm_logprob_reg_kernel(const float* __restrict__ mu, const float* __restrict__ sd,
+                                                              const float* __restrict__ eps, const float* __restrict__ packed, int L,
+                                                              int B, int K, double* __restrict__ ws_lp, float* __restrict__ ws_g) {
+  constexpr int NT = R * (R + 1) / 2, STRIDE = 1 + R + NT;
+  const int b = blockIdx.x, lane = threadIdx.x & 63;
+  const int S = 4 * gridDim.y, sidx = 4 * blockIdx.y + (threadIdx.x >> 6);
+  float c0 = -INFINITY, mk[R], Li[NT];
+#pragma unroll
+  for (int j = 0; j < R; ++j) mk[j] = 0.f;
+#pragma unroll
+  for (int q = 0; q < NT; ++q) Li[q] = 0.f;
+  if (lane < K) {
+    const float* prm = packed + (size_t)lane * STRIDE;
+    c0 = prm[0];
+#pragma unroll
+    for (int j = 0; j < R; ++j) mk[j] = prm[1 + j];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) Li[q] = prm[1 + R + q];
+  }
+  float m_[R], s_[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    m_[j] = mu[(size_t)b * R + j];
+    s_[j] = sd[(size_t)b * R + j];
+  }
+  double acc_lp = 0.0;
+  float gm[R], gs[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) gm[j] = gs[j] = 0.f;
+  for (int l = sidx; l < L; l += S) {
+    float e_[R], d_[R], y_[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      e_[j] = eps[((size_t)l * B + b) * R + j];
+      d_[j] = (m_[j] + s_[j] * e_[j]) - mk[j];
+    }
+    float maha = 0.f;
+    int q = 0;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      float yi = 0.f;
+#pragma unroll
+      for (int j = 0; j < R; ++j)
+        if (j <= i) yi += Li[q++] * d_[j];
+      y_[i] = yi;
+      maha += yi * yi;
+    }
+    const float lp = c0 - 0.5f * maha;                      // -inf on the idle lanes (K < 64)
+    const float mx = wave_max(lp);
+    const float ex = __expf(lp - mx);
+    const float se = wave_sum(ex);
+    acc_lp += (double)(mx + logf(se));
+    const float r = ex / se;
+    q = 0;
+    float v_[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) v_[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+      for (int j = 0; j < R; ++j)
+        if (j <= i) v_[j] += Li[q++] * y_[i];               // (Linv^T y)_j
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const float g = r * v_[j];
+      gm[j] -= g;
+      gs[j] -= g * e_[j];
+    }
+  }
+  float* o = ws_g + ((size_t)b * S + sidx) * (2 * R);
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const float a = wave_sum(gm[j]), c = wave_sum(gs[j]);
+    if (lane == 0) {
+      o[j] = a;
+      o[R + j] = c;
+    }
+  }
+  if (lane == 0) ws_lp[(size_t)b * S + sidx] = acc_lp;
+}
+
+// dmu[b,j] / dsd[b,j] = sum over the S wavefront partials of row b (fixed order); the last workgroup sums the B * S log-prob partials.
+__global__ __launch_bounds__(256) void gmm_finish_kernel(const double* __restrict__ ws_lp, const float* __restrict__ ws_g, int B, int S,
+                                                         int R, float* __restrict__ dmu, float* __restrict__ dsd,
+                                                         float* __restrict__ out) {
+  if (blockIdx.x == gridDim.x - 1) {
+    if (threadIdx.x < 64) {
+      double s = 0.0;
+      for (int i = threadIdx.x; i < B * S; i += 64) s += ws_lp[i];
+      s = wave_sum_d(s);
+      if (threadIdx.x == 0) out[0] = (float)s;
+    }
+    return;
+  }
+  const int i = blockIdx.x * 256 + threadIdx.x;              // (b, jj) with jj in [0, 2R)
+  if (i >= B * 2 * R) return;
+  const int b = i / (2 * R), jj = i - b * 2 * R;
+  float a = 0.f;
+  for (int s = 0; s < S; ++s) a += ws_g[((size_t)b * S + s) * (2 * R) + jj];
+  if (jj < R) dmu[(size_t)b * R + jj] = a; else dsd[(size_t)b * R + jj - R] = a;
+}
+
 // log p(t_i) of n separate points (density of the fitted mixture on a grid / at embeddings: demo/demo_tools.py prior.prob, log_prob):
 // one wavefront per point, lane = component, same per-component arithmetic as gmm_logprob_kernel.
 template <int R>
@@ -854,12 +966,33 @@ int ladder_gmm_prepare(const float* weights, const float* means, const float* co
   return LADDER_OK;
 }
 
-size_t ladder_gmm_workspace_bytes(int L, int B) { (void)L; return (size_t)B * sizeof(double); }
+// wavefront groups per batch row of the register kernel: ~2048 wavefronts in total, at most one per MC sample
+static int gmm_row_groups(int L, int B) {
+  int g = 512 / (B > 0 ? B : 1);
+  const int gmax = (L + 3) / 4;
+  g = g > gmax ? gmax : g;
+  return g < 1 ? 1 : g;
+}
+
+size_t ladder_gmm_workspace_bytes(int L, int B) {
+  const size_t S = (size_t)4 * gmm_row_groups(L, B);
+  return (size_t)B * S * sizeof(double) + (size_t)B * S * 16 * sizeof(float);     // log-prob partials + [2R <= 16] gradient partials
+}
 
 int ladder_gmm_logprob_fwd_bwd(const float* mu, const float* sd, const float* eps, const float* packed, int L, int B, int R, int K,
                                float* sum_logp, float* dmu, float* dsd, void* ws, size_t ws_bytes, ladder_stream_t stream) {
   if (L <= 0 || B <= 0 || K <= 0 || K > 1024) return LADDER_E_SHAPE;
-  if (ws_bytes < (size_t)B * sizeof(double)) return LADDER_E_WORKSPACE;
+  if (ws == nullptr || ws_bytes < ladder_gmm_workspace_bytes(L, B)) return LADDER_E_WORKSPACE;
+  if (K <= 64) {                                            // the mixture in registers, lane = component
+    const int G = gmm_row_groups(L, B), S = 4 * G;
+    double* ws_lp = (double*)ws;
+    float* ws_g = (float*)(ws_lp + (size_t)B * S);
+    LADDER_R_SWITCH(R, hipLaunchKernelGGL(gmm_logprob_reg_kernel<RR>, dim3(B, G), dim3(256), 0, stream, mu, sd, eps, packed, L, B, K, ws_lp, ws_g));
+    hipLaunchKernelGGL(gmm_finish_kernel, dim3((B * 2 * R + 255) / 256 + 1), dim3(256), 0, stream, (const double*)ws_lp, (const float*)ws_g, B, S, R,
+                       dmu, dsd, sum_logp);
+    LADDER_CHECK_LAUNCH();
+    return LADDER_OK;
+  }
   LADDER_R_SWITCH(R, hipLaunchKernelGGL(gmm_logprob_kernel<RR>, dim3(B), dim3(256), 0, stream, mu, sd, eps, packed, L, B, K, dmu, dsd, (double*)ws));
   hipLaunchKernelGGL(gmm_sum_kernel, dim3(1), dim3(64), 0, stream, (const double*)ws, B, sum_logp);
   LADDER_CHECK_LAUNCH();
