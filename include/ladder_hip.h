@@ -491,8 +491,9 @@ int ladder_gather_rows(const void* src, int src_is_u8, const int64_t* idx, float
  * warm_start=True).fit(samples) of codes/base.py:93-99 (per-epoch "fast" fit, 681-721) and 723-789 ("accurate" fit), as ONE
  * persistent-workgroup launch running the whole variational loop in float64 (csrc/vbgmm.hip).
  *   X [N,R] fp32 samples (R <= 8, K <= 64, N >= K); labels [N] int32 = hard initial assignment (k-means labels) or NULL to
- *   warm-start from `state` (ladder_vbgmm_state_doubles(K,R) doubles, caller-owned, persists between fits; its last three
- *   entries are lower_bound_, n_iter_, converged_ (-1 = ill-defined covariance, sklearn raises ValueError there)).
+ *   warm-start from `state` (ladder_vbgmm_state_doubles(K,R) doubles, caller-owned, persists between fits; its last four
+ *   entries are lower_bound_, n_iter_, converged_ (-1 = ill-defined covariance, sklearn raises ValueError there) and the `done` flag of the
+ *   sharded fit below).
  *   prior_type 0 = dirichlet_distribution, 1 = dirichlet_process.  mean/covariance priors are taken from X as sklearn does.
  *   Outputs weights [K], means [K,R], covs [K,R,R] fp32 = weights_, means_, covariances_ (float64 copies live in `state`). */
 size_t ladder_vbgmm_state_doubles(int K, int R);
@@ -500,6 +501,24 @@ size_t ladder_vbgmm_workspace_bytes(int N, int K);
 int ladder_vbgmm_fit(const float* X, int N, int K, int R, const int* labels, double* state, int prior_type, double wc_prior,
                      double mean_prec_prior, double reg_covar, double tol, int max_iter, float* weights, float* means,
                      float* covs, void* ws, size_t ws_bytes, ladder_stream_t stream);
+
+/* The same fit SHARDED over data-parallel ranks (exchange step C5: "mixture sufficient statistics all-reduce"): every rank holds only its
+ * samples X [N_local, R].  Per variational iteration `it` (0 = the M-step on the hard initial labels, then 1 .. max_iter):
+ *     ladder_vbgmm_shard_estep(...)  ->  stats [ladder_vbgmm_shard_stats_doubles] = local sufficient statistics
+ *     all-reduce(stats, SUM)             (the caller: torch.distributed over RCCL)
+ *     ladder_vbgmm_shard_mstep(...)  ->  M-step from the global statistics, lower bound, convergence test into `state`
+ * with the data-derived priors from ladder_vbgmm_shard_moments (all-reduced once).  state[-1] != 0 marks the end of the fit (converged,
+ * max_iter reached or state[-2] = -1: ill-defined covariance); both step kernels are no-ops from then on, so the caller may enqueue
+ * iterations ahead and read the flag every few iterations.  The caller clears state[-2] and state[-1] before a (warm-started) fit.
+ * labels: hard assignment of the LOCAL samples for it = 0, NULL afterwards. */
+size_t ladder_vbgmm_shard_stats_doubles(int K, int R);
+size_t ladder_vbgmm_shard_moments_doubles(int R);
+int ladder_vbgmm_shard_moments(const float* X, int N, int R, double* moments, ladder_stream_t stream);
+int ladder_vbgmm_shard_estep(const float* X, int N, int K, int R, const int* labels, const double* state, int prior_type, double* stats,
+                             void* ws, size_t ws_bytes, ladder_stream_t stream);
+int ladder_vbgmm_shard_mstep(const double* stats, const double* moments, int K, int R, double* state, int prior_type, double wc_prior,
+                             double mean_prec_prior, double reg_covar, double tol, int max_iter, int it, float* weights, float* means,
+                             float* covs, ladder_stream_t stream);
 
 /* ---------------------------------------------------------------- helpers */
 /* HOST function (no device work): CRC-32C (Castagnoli) of host memory, crc = 0 to start, chainable.  Used by the

@@ -100,6 +100,11 @@ PROTOTYPES = {
     "ladder_vbgmm_state_doubles": (_z, [_i, _i]),
     "ladder_vbgmm_workspace_bytes": (_z, [_i, _i]),
     "ladder_vbgmm_fit": (_i, [_p, _i, _i, _i, _p, _p, _i, _d, _d, _d, _d, _i, _p, _p, _p, _p, _z, _p]),
+    "ladder_vbgmm_shard_stats_doubles": (_z, [_i, _i]),
+    "ladder_vbgmm_shard_moments_doubles": (_z, [_i]),
+    "ladder_vbgmm_shard_moments": (_i, [_p, _i, _i, _p, _p]),
+    "ladder_vbgmm_shard_estep": (_i, [_p, _i, _i, _i, _p, _p, _i, _p, _p, _z, _p]),
+    "ladder_vbgmm_shard_mstep": (_i, [_p, _p, _i, _i, _p, _i, _d, _d, _d, _d, _i, _i, _p, _p, _p, _p]),
     "ladder_axpy": (_i, [_p, _p, _z, _f, _i, _p]),
     "ladder_filter_pack_split_bytes": (_z, [_i, _i, _i, _i]),
     "ladder_filter_pack_split": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),

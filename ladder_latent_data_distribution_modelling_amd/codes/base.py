@@ -30,6 +30,29 @@ class BaseTrain:
         self.n_train_iter, self.n_val_iter = 0, 0
         self.gm_params = None          # (weights, means, covs) currently fed as the GM hyper-prior
         self.GM_prior_final = None
+        # config key `async_fetch` (default 1): the train steps read the fetched scalars of a run through pinned-memory copies AFTER the
+        # next run has been enqueued, so the GPU never idles while the host reads (engine.fetch_async).  The record lists of RUN#2 / RUN#3
+        # (sigma_train, code_elbo_train, ...) are then completed one call later; flush() -- called by every evaluation / fit / save /
+        # epoch-end path and by the last_fetch_* properties -- completes them at once.  0 restores a blocking fetch after every run.
+        self.async_fetch = bool(int(config.get("async_fetch", 1)))
+        self._pending = []             # [(fetch handle, callback)] in enqueue order
+        self._last_fetch_sigma, self._last_fetch_prior = None, None
+
+    def flush(self):
+        """Complete the record lists from every fetch still in flight (in order)."""
+        pend, self._pending = self._pending, []
+        for h, cb in pend:
+            cb(h.get())
+
+    @property
+    def last_fetch_prior(self):
+        self.flush()
+        return self._last_fetch_prior
+
+    @property
+    def last_fetch_sigma(self):
+        self.flush()
+        return self._last_fetch_sigma
 
     def compute_execution_time(self, cur_epoch, total_epoch):
         self.current_time = time.time()
@@ -73,20 +96,39 @@ class BaseTrain:
         eng, cfg = self.engine, self.config
         use_sg, use_mask = self.compute_feeddict(batch_data, "VAE")
         eng.run_ae(batch_data, cur_lr, noise[0] if noise else None, use_sg, use_mask)
-        f = eng.fetch()
+        h1 = eng.fetch_async()
+        if int(cfg["TRAIN_sigma"]) == 1:                # enqueued BEFORE RUN#1's values are read: the GPU works on it meanwhile
+            lr_s = float(cfg["learning_rate_sigma"]) * (0.99 ** (self.cur_epoch - 1))
+            eng.run_sigma(batch_data, lr_s, noise[1] if noise else None, use_sg, use_mask)
+            self._enc_batch = batch_data      # RUN#2 evaluated the encoder with the post-RUN#1 weights on this batch
+            self._pending.append((eng.fetch_async(["sigma"]), self._record_sigma))
+        f = h1.get()
         self.recons_error_train.append(f["l1_reconstruction_error"])
         self.entropy_z_train.append(f["entropy_z"])
         self.crossEntropy_prior_train.append(f["crossEntropy_prior"])
         self.sigma_reguarisor_train.append(f["sigma_regularisor"])
         self.elbo_train.append(f["elbo"])
         self.last_fetch_ae = f
-        if int(cfg["TRAIN_sigma"]) == 1:
-            lr_s = float(cfg["learning_rate_sigma"]) * (0.99 ** (self.cur_epoch - 1))
-            eng.run_sigma(batch_data, lr_s, noise[1] if noise else None, use_sg, use_mask)
-            self._enc_batch = batch_data      # RUN#2 evaluated the encoder with the post-RUN#1 weights on this batch
-            self.last_fetch_sigma = eng.fetch(["sigma"])
-            self.sigma_train.append(self.last_fetch_sigma["sigma"])
+        if not self.async_fetch:
+            self.flush()
         return f["loss_ae"]
+
+    def _record_sigma(self, f):
+        self._last_fetch_sigma = f
+        self.sigma_train.append(f["sigma"])
+
+    def _record_prior(self, f):
+        self._last_fetch_prior = f
+        if self.config["prior"] == "vampPrior":               # base.py:629-634: loss_prior = -elbo, crossEntropy_prior
+            self.train_loss_prior.append(f["loss_ae"])
+            self.vampPrior_crossEntropy_prior_train.append(f["crossEntropy_prior"])
+            return
+        self.code_recons_error_train.append(f["code_l1_reconstruction_error"])
+        self.code_recons_likelihood_train.append(f["code_reconstruction_likelihood"])
+        self.entropy_t_train.append(f["entropy_t"])
+        self.crossEntropy_t_train.append(f["crossEntropy_representation"])
+        self.code_elbo_train.append(f["elbo_prior"])
+        self.code_inner_sigma_train.append(f["inner_sigma"])
 
     def train_step_prior(self, batch_data, noise=None):
         """RUN#3 (+ RUN#4 if TRAIN_inner_sigma): codes/base.py:610-641."""
@@ -97,25 +139,18 @@ class BaseTrain:
         reuse = getattr(self, "_enc_batch", None) is batch_data
         eng.run_prior(batch_data, lr_p, noise[0] if noise else None, use_sg, use_mask, reuse_encoder=reuse)
         self._enc_batch = batch_data
-        f = eng.fetch()
-        self.last_fetch_prior = f
-        if cfg["prior"] == "vampPrior":               # base.py:629-634: loss_prior = -elbo, crossEntropy_prior
-            self.train_loss_prior.append(f["loss_ae"])
-            self.vampPrior_crossEntropy_prior_train.append(f["crossEntropy_prior"])
-            return
-        self.code_recons_error_train.append(f["code_l1_reconstruction_error"])
-        self.code_recons_likelihood_train.append(f["code_reconstruction_likelihood"])
-        self.entropy_t_train.append(f["entropy_t"])
-        self.crossEntropy_t_train.append(f["crossEntropy_representation"])
-        self.code_elbo_train.append(f["elbo_prior"])
-        self.code_inner_sigma_train.append(f["inner_sigma"])
-        self.last_fetch_prior = f
-        if int(cfg["TRAIN_inner_sigma"]) == 1:
+        h3 = eng.fetch_async()
+        if cfg["prior"] != "vampPrior" and int(cfg["TRAIN_inner_sigma"]) == 1:
             lr_i = float(cfg["learning_rate_inner_sigma"]) * (1.01 ** (self.cur_epoch - 1))
             eng.run_inner_sigma(batch_data, lr_i, noise[1] if noise else None, use_sg, use_mask, reuse_encoder=True)
+        self.flush()                          # RUN#2's sigma (finished before RUN#3 started: no wait), earlier iterations' values
+        self._pending.append((h3, self._record_prior))
+        if not self.async_fetch:
+            self.flush()
 
     def val_step(self, model_to_train, batch_data, noise=None):
         """codes/base.py:643-679."""
+        self.flush()
         self._enc_batch = None          # this call overwrites the engine's encoder cache with another batch
         use_sg, use_mask = self.compute_feeddict(batch_data, model_to_train)
         self.engine.evaluate(batch_data, noise, use_sg, use_mask)
@@ -139,14 +174,21 @@ class BaseTrain:
         return f["loss_prior"]
 
     # ------------------------------------------------------------------ GM fit (base.py:681-789)
-    def _draw_t_samples(self, iterator, n_batch, space="t"):
+    def _sharded_fit(self, gm):
+        """C5 as an all-reduce of the mixture's sufficient statistics (default under data parallelism with the device fit; config key
+        `gm_fit_mode`: "allreduce_stats" | "replicated" = all-gather the samples and run the same deterministic fit on every rank)."""
+        from .vbgmm import DeviceBayesianGaussianMixture
+        return (self.engine.ctx.comm.on and isinstance(gm, DeviceBayesianGaussianMixture)
+                and self.config.get("gm_fit_mode", "allreduce_stats") == "allreduce_stats")
+
+    def _draw_t_samples(self, iterator, n_batch, space="t", gather=True):
         """t- (or z-) samples of n_batch minibatches as ONE device tensor [n, R] (every rank's, in rank order, under data
-        parallelism)."""
+        parallelism -- or, gather=False, this rank's only: the sharded fit exchanges statistics, not samples)."""
         eng = self.engine
         chunks = []
         for _ in range(n_batch):
             t = eng.sample_representation(iterator.next()) if space == "t" else eng.sample_code(iterator.next())
-            if eng.ctx.comm.on:   # C5: gather every rank's samples
+            if eng.ctx.comm.on and gather:   # C5 ("replicated" mode): gather every rank's samples
                 parts = [torch.empty_like(t) for _ in range(eng.ctx.comm.world)]
                 eng.ctx.comm.dist.all_gather(parts, t.contiguous(), group=eng.ctx.comm.group)
                 t = torch.cat(parts, 0)
@@ -171,13 +213,17 @@ class BaseTrain:
         rank 0 fits on a host copy and broadcasts."""
         from .vbgmm import DeviceBayesianGaussianMixture
         if isinstance(gm, DeviceBayesianGaussianMixture):
-            gm.fit(samples)
+            if self._sharded_fit(gm):
+                gm.fit_sharded(samples, self.engine.ctx.comm)      # `samples` = this rank's: statistics are all-reduced per iteration
+            else:
+                gm.fit(samples)
             return gm.weights_dev, gm.means_dev, gm.covariances_dev
         if self.engine.ctx.comm.rank == 0:
             gm.fit(samples.cpu().numpy().astype(np.float64))
         return self._share_gm(gm)
 
     def fit_GMM_VI(self, iterator, mode="fast", space="t"):
+        self.flush()
         self._enc_batch = None          # this call overwrites the engine's encoder cache with another batch
         if space == "z":
             return self._fit_GMM_z(iterator, mode)
@@ -185,11 +231,10 @@ class BaseTrain:
         bs_global = int(self.config["batch_size"]) * comm.world
         rank0 = comm.rank == 0
         if mode == "fast":
-            samples = self._draw_t_samples(iterator, 2000 // bs_global + 1)
+            samples = self._draw_t_samples(iterator, 2000 // bs_global + 1, gather=not self._sharded_fit(self.model.GM_prior_training))
             self.gm_params = self._fit(self.model.GM_prior_training, samples)
             w = self.gm_params[0]
         else:
-            samples = self._draw_t_samples(iterator, 20000 // bs_global + 1)
             kw = dict(n_components=int(self.config["n_mixtures"]), covariance_type="full", max_iter=2000,
                       n_init=int(self.config["GM_fit_restart"]), weight_concentration_prior_type="dirichlet_process",
                       weight_concentration_prior=0.1, warm_start=False)
@@ -200,6 +245,7 @@ class BaseTrain:
             else:
                 from sklearn.mixture import BayesianGaussianMixture
                 self.GM_prior_final = BayesianGaussianMixture(**kw)
+            samples = self._draw_t_samples(iterator, 20000 // bs_global + 1, gather=not self._sharded_fit(self.GM_prior_final))
             self.gm_final_params = self._fit(self.GM_prior_final, samples)
             gmf = self.GM_prior_final
             if rank0 or hasattr(gmf, "weights_dev"):
@@ -250,6 +296,7 @@ class BaseTrain:
 
     def save_variables_VAE(self):
         """<result_dir>/<exp_name>-result.npz with the reference's keys (codes/base.py:791-823)."""
+        self.flush()
         if self.engine.ctx.comm.rank != 0:
             return
         file_name = "{}{}-result.npz".format(self.config["result_dir"], self.config["exp_name"])
@@ -280,6 +327,7 @@ class BaseTrain_joint(BaseTrain):
 
     def test_step(self, batch_data, print_result=False, noise=None):
         """codes/base.py:944-986."""
+        self.flush()
         self._enc_batch = None          # this call overwrites the engine's encoder cache with another batch
         use_sg, use_mask = self.compute_feeddict(batch_data)
         eng = self.engine

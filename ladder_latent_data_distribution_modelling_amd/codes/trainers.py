@@ -53,6 +53,7 @@ class _JointEpochMixin:
                 train_loss_cur_epoch += loss
             if self._prior_training_on():
                 self.train_step_prior(batch_data=batch)
+        self.flush()                                                        # record lists of the last iteration (async_fetch)
         if int(cfg["TRAIN_VAE"]) == 1:
             self.train_loss_ave_epoch.append(train_loss_cur_epoch / max(self.n_train_iter, 1))
             self.iter_epochs_list.append(len(self.train_loss) - 1)

@@ -68,7 +68,7 @@ class DeviceBayesianGaussianMixture:
             L.call("ladder_vbgmm_fit", Xd.data_ptr(), N, K, R, labels.data_ptr() if labels is not None else None, state.data_ptr(),
                    ptype, wc, mp, float(self.reg_covar), float(self.tol), self.max_iter, w.data_ptr(), m.data_ptr(), c.data_ptr(),
                    ws.data_ptr(), ws.numel(), st)
-            tail = state[-3:].cpu().numpy()                # the one host sync of the fit: lower_bound_, n_iter_, converged_
+            tail = state[-4:-1].cpu().numpy()              # the one host sync of the fit: lower_bound_, n_iter_, converged_
             if tail[2] < 0:
                 raise ValueError("Fitting the mixture model failed because some components have ill-defined empirical covariance "
                                  "(for instance caused by singleton or collapsed samples). Try to decrease the number of "
@@ -81,6 +81,88 @@ class DeviceBayesianGaussianMixture:
             warnings.warn("Best performing initialization did not converge. Try different init parameters, or increase max_iter, "
                           "tol, or check for degenerate data.", ConvergenceWarning)
         return self
+
+    # -------------------------------------------------------------------------------------------------------------
+    def fit_sharded(self, X_local, comm, check_every=8):
+        """The same fit with the samples SHARDED over the data-parallel ranks (exchange step C5 of SURVEY 2.3 as north_star words it:
+        an all-reduce of the mixture's sufficient statistics): `X_local` [N_local, R] are THIS rank's samples, `comm` the engine's
+        communicator (all-reduce over RCCL / xGMI).  Per variational iteration: E-step + local statistics (one launch), all-reduce of
+        1 + K + K R + K R^2 doubles, M-step + lower bound + convergence test (one launch, identical on every rank).  The `done` flag
+        lives in device memory and is read every `check_every` iterations; iterations enqueued past the end are no-ops, so the result
+        does not depend on `check_every`.  A cold start takes its k-means labels from rank 0 (sklearn.cluster.KMeans on the gathered
+        samples, as BaseMixture._initialize_parameters does) -- once; warm starts exchange statistics only."""
+        from sklearn.utils import check_random_state
+        K = self.n_components
+        Xd = X_local if isinstance(X_local, torch.Tensor) else torch.as_tensor(np.asarray(X_local, dtype=np.float32))
+        Xd = Xd.to(device=self.device, dtype=torch.float32).contiguous()
+        Nl, R = Xd.shape
+        wc = 1.0 / K if self.weight_concentration_prior is None else float(self.weight_concentration_prior)
+        mp = 1.0 if self.mean_precision_prior is None else float(self.mean_precision_prior)
+        ptype = 0 if self.weight_concentration_prior_type == "dirichlet_distribution" else 1
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        f64 = lambda n: torch.zeros(n, dtype=torch.float64, device=self.device)
+        mom = f64(L.query("ladder_vbgmm_shard_moments_doubles", R))
+        L.call("ladder_vbgmm_shard_moments", Xd.data_ptr(), Nl, R, mom.data_ptr(), st)
+        comm.allreduce_(mom)
+        stats = f64(L.query("ladder_vbgmm_shard_stats_doubles", K, R))
+        ws = torch.empty(L.query("ladder_vbgmm_workspace_bytes", Nl, K), dtype=torch.uint8, device=self.device)
+        do_init = not (self.warm_start and self._state is not None and hasattr(self, "converged_"))
+        rs = check_random_state(self.random_state)
+        best = None
+        for _ in range(self.n_init if do_init else 1):
+            state = f64(L.query("ladder_vbgmm_state_doubles", K, R)) if do_init else self._state
+            state[-2:] = 0.0                                                   # converged_, done
+            labels = None
+            if do_init:
+                # k-means needs every sample: gathered once (rank order), labelled on rank 0, this rank keeps its slice
+                if comm.on:
+                    counts = torch.zeros(comm.world, dtype=torch.int64, device=self.device)
+                    counts[comm.rank] = Nl
+                    comm.allreduce_(counts)
+                    cl = [int(c) for c in counts.cpu()]
+                    parts = [torch.empty(c, R, device=self.device) for c in cl]
+                    comm.dist.all_gather(parts, Xd, group=comm.group) if len(set(cl)) == 1 else self._gather_ragged(parts, Xd, comm)
+                    allx, off = torch.cat(parts, 0), sum(cl[:comm.rank])
+                else:
+                    allx, off = Xd, 0
+                lab = torch.empty(allx.shape[0], dtype=torch.int32, device=self.device)
+                if comm.rank == 0:
+                    lab.copy_(torch.as_tensor(self._kmeans_labels(allx.cpu().numpy().astype(np.float64), rs)))
+                comm.broadcast_(lab, 0)
+                labels = lab[off:off + Nl].contiguous()
+            w, m, c = (torch.empty(K, device=self.device), torch.empty(K, R, device=self.device), torch.empty(K, R, R, device=self.device))
+            it, done = (0 if do_init else 1), False
+            while not done:
+                for _i in range(check_every):
+                    L.call("ladder_vbgmm_shard_estep", Xd.data_ptr(), Nl, K, R, labels.data_ptr() if (labels is not None and it == 0) else None,
+                           state.data_ptr(), ptype, stats.data_ptr(), ws.data_ptr(), ws.numel(), st)
+                    comm.allreduce_(stats)
+                    L.call("ladder_vbgmm_shard_mstep", stats.data_ptr(), mom.data_ptr(), K, R, state.data_ptr(), ptype, wc, mp,
+                           float(self.reg_covar), float(self.tol), self.max_iter, it, w.data_ptr(), m.data_ptr(), c.data_ptr(), st)
+                    it += 1
+                    if it > self.max_iter:
+                        break
+                done = bool(state[-1].item() != 0) or it > self.max_iter     # (identical on every rank: same all-reduced statistics)
+            tail = state[-4:-1].cpu().numpy()
+            if tail[2] < 0:
+                raise ValueError("Fitting the mixture model failed because some components have ill-defined empirical covariance "
+                                 "(for instance caused by singleton or collapsed samples). Try to decrease the number of "
+                                 "components, increase reg_covar, or scale the input data.")
+            if best is None or tail[0] > best[0]:
+                best = (float(tail[0]), int(tail[1]), bool(tail[2] > 0), state, w, m, c)
+        self.lower_bound_, self.n_iter_, self.converged_, self._state, self.weights_dev, self.means_dev, self.covariances_dev = best
+        if not self.converged_ and self.max_iter > 0:
+            from sklearn.exceptions import ConvergenceWarning
+            warnings.warn("Best performing initialization did not converge. Try different init parameters, or increase max_iter, "
+                          "tol, or check for degenerate data.", ConvergenceWarning)
+        return self
+
+    @staticmethod
+    def _gather_ragged(parts, x, comm):
+        for r, p_ in enumerate(parts):                                           # ranks with different sample counts: one broadcast each
+            if r == comm.rank:
+                p_.copy_(x)
+            comm.broadcast_(p_, r)
 
     # float64 views of the fitted parameters, as sklearn exposes them
     def _unpack(self):

@@ -312,11 +312,282 @@ __global__ __launch_bounds__(VB_THREADS) void vbgmm_fit_kernel(const float* __re
   for (int i = tid; i < K * R * R; i += VB_THREADS) c_out[i] = (float)S.cov[i];
 }
 
+// ==================================================================================================================================
+// The SHARDED fit (data-parallel exchange step C5, round 3): every rank keeps only ITS samples.  One variational iteration =
+//   vbgmm_shard_estep_kernel   E-step on the local samples with the (replicated) current parameters + the local SUFFICIENT STATISTICS
+//                              stats = [ sum r log r | n_k | sum_n r_nk x_n | sum_n r_nk x_n x_n^T ]   (1 + K + K R + K R R doubles)
+//   all-reduce(stats)          over RCCL / xGMI by the host (torch.distributed; a few KB)
+//   vbgmm_shard_mstep_kernel   M-step from the GLOBAL statistics, lower bound, convergence test -- identical on every rank
+// The priors sklearn takes from the data (mean_prior_ = X.mean(0), covariance_prior_ = cov(X.T)) come from all-reduced raw moments
+// (vbgmm_moments_kernel).  Both kernels return at once when the state's `done` flag (tail[3]) is set, so the host may enqueue
+// iterations ahead and look at the flag only every few iterations without changing the result.  Second moments are accumulated raw
+// (sum r x x^T) and centred in the M-step, where sklearn (and the persistent kernel above) centre before summing: float64 on O(1..10)
+// latent coordinates -- the two forms agree to ~1e-13, tests/test_gpu_vbgmm.py holds the sharded fit to sklearn at 1e-7.
+__global__ __launch_bounds__(VB_THREADS) void vbgmm_moments_kernel(const float* __restrict__ X, int N, int R, double* __restrict__ out) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) out[0] = (double)N;
+  for (int p = wave; p < R + R * R; p += VB_WAVES) {
+    double a = 0.0;
+    if (p < R) {
+      for (int n = lane; n < N; n += 64) a += (double)X[(size_t)n * R + p];
+    } else {
+      const int i = (p - R) / R, j = (p - R) - i * R;
+      for (int n = lane; n < N; n += 64) a += (double)X[(size_t)n * R + i] * (double)X[(size_t)n * R + j];
+    }
+    a = wave_sum(a);
+    if (lane == 0) out[1 + p] = a;
+  }
+}
+
+__global__ __launch_bounds__(VB_THREADS) void vbgmm_shard_estep_kernel(const float* __restrict__ X, const int* __restrict__ labels,
+                                                                       const double* __restrict__ state, VbCfg c,
+                                                                       double* __restrict__ resp, double* __restrict__ stats) {
+  const int N = c.N, K = c.K, R = c.R, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  VbState S(const_cast<double*>(state), K, R);
+  if (S.tail[3] != 0.0) return;                                  // the fit is over: later (speculatively enqueued) iterations are no-ops
+  __shared__ double s_ck[VB_MAXK], s_mu[VB_MAXK * VB_MAXR], s_pc[VB_MAXK * VB_MAXR * VB_MAXR], s_red[VB_WAVES], s_scal[1];
+  double entropy = 0.0;
+  if (c.init_from_labels) {
+    for (size_t i = tid; i < (size_t)N * K; i += VB_THREADS) resp[i] = (labels[i / K] == (int)(i % K)) ? 1.0 : 0.0;
+  } else {
+    if (tid == 0 && c.prior_type == 0) {
+      double sw = 0.0;
+      for (int k = 0; k < K; ++k) sw += S.wa[k];
+      s_scal[0] = vb_digamma(sw);
+    }
+    for (int i = tid; i < K * R; i += VB_THREADS) s_mu[i] = S.means[i];
+    for (int i = tid; i < K * R * R; i += VB_THREADS) s_pc[i] = S.pchol[i];
+    __syncthreads();
+    if (tid < K) {
+      const int k = tid;
+      double log_det = 0.0, log_lambda = R * log(2.0);
+      for (int j = 0; j < R; ++j) {
+        log_det += log(s_pc[(k * R + j) * R + j]);
+        log_lambda += vb_digamma(0.5 * (S.dof[k] - j));
+      }
+      double lw;
+      if (c.prior_type == 0) {
+        lw = vb_digamma(S.wa[k]) - s_scal[0];
+      } else {
+        lw = vb_digamma(S.wa[k]) - vb_digamma(S.wa[k] + S.wb[k]);
+        for (int j = 0; j < k; ++j) lw += vb_digamma(S.wb[j]) - vb_digamma(S.wa[j] + S.wb[j]);
+      }
+      s_ck[k] = -0.5 * R * log(2.0 * M_PI) + log_det - 0.5 * R * log(S.dof[k]) + 0.5 * (log_lambda - R / S.mprec[k]) + lw;
+    }
+    __syncthreads();
+    double ent = 0.0;
+    for (int n = tid; n < N; n += VB_THREADS) {
+      double x[VB_MAXR];
+      for (int i = 0; i < R; ++i) x[i] = (double)X[(size_t)n * R + i];
+      double* wr = resp + (size_t)n * K;
+      double mx = -INFINITY;
+      for (int k = 0; k < K; ++k) {
+        const double* P = s_pc + (size_t)k * R * R;
+        const double* mu = s_mu + k * R;
+        double q = 0.0;
+        for (int j = 0; j < R; ++j) {
+          double xy = 0.0, my = 0.0;
+          for (int i = 0; i <= j; ++i) {
+            xy += x[i] * P[i * R + j];
+            my += mu[i] * P[i * R + j];
+          }
+          const double y = xy - my;
+          q += y * y;
+        }
+        const double w = s_ck[k] - 0.5 * q;
+        wr[k] = w;
+        mx = fmax(mx, w);
+      }
+      double se = 0.0;
+      for (int k = 0; k < K; ++k) se += exp(wr[k] - mx);
+      const double lse = mx + log(se);
+      for (int k = 0; k < K; ++k) {
+        const double lr = wr[k] - lse, r = exp(lr);
+        wr[k] = r;
+        ent += r * lr;
+      }
+    }
+    ent = wave_sum(ent);
+    if (lane == 0) s_red[wave] = ent;
+    __syncthreads();
+    if (tid == 0)
+      for (int w = 0; w < VB_WAVES; ++w) entropy += s_red[w];
+  }
+  __syncthreads();
+  // local sufficient statistics (fixed order: lane-strided partial sums, then the shuffle tree)
+  if (tid == 0) stats[0] = entropy;
+  double* st_nk = stats + 1;
+  double* st_x = st_nk + K;
+  double* st_xx = st_x + (size_t)K * R;
+  for (int p = wave; p < K * (1 + R + R * R); p += VB_WAVES) {
+    double a = 0.0;
+    if (p < K) {
+      for (int n = lane; n < N; n += 64) a += resp[(size_t)n * K + p];
+    } else if (p < K + K * R) {
+      const int k = (p - K) / R, r = (p - K) - k * R;
+      for (int n = lane; n < N; n += 64) a += resp[(size_t)n * K + k] * (double)X[(size_t)n * R + r];
+    } else {
+      const int q = p - K - K * R, k = q / (R * R), ij = q - k * R * R, i = ij / R, j = ij - i * R;
+      if (j < i) continue;                                        // (upper triangle; mirrored below)
+      for (int n = lane; n < N; n += 64) a += resp[(size_t)n * K + k] * (double)X[(size_t)n * R + i] * (double)X[(size_t)n * R + j];
+    }
+    a = wave_sum(a);
+    if (lane == 0) {
+      if (p < K) st_nk[p] = a;
+      else if (p < K + K * R) st_x[p - K] = a;
+      else {
+        const int q = p - K - K * R, k = q / (R * R), ij = q - k * R * R, i = ij / R, j = ij - i * R;
+        st_xx[(size_t)k * R * R + i * R + j] = a;
+        st_xx[(size_t)k * R * R + j * R + i] = a;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void vbgmm_shard_mstep_kernel(const double* __restrict__ stats, const double* __restrict__ moments,
+                                                                double* __restrict__ state, VbCfg c, int it,
+                                                                float* __restrict__ w_out, float* __restrict__ m_out,
+                                                                float* __restrict__ c_out) {
+  const int K = c.K, R = c.R, tid = threadIdx.x;
+  VbState S(state, K, R);
+  if (S.tail[3] != 0.0) return;
+  __shared__ double s_nk[VB_MAXK], s_xk[VB_MAXK * VB_MAXR], s_sk[VB_MAXK * VB_MAXR * VB_MAXR], s_ck[VB_MAXK];
+  __shared__ double s_prior_mean[VB_MAXR], s_prior_cov[VB_MAXR * VB_MAXR];
+  __shared__ int s_flag, s_done;
+  const double Ntot = moments[0];
+  if (tid < R) s_prior_mean[tid] = moments[1 + tid] / Ntot;
+  if (tid == 0) { s_flag = 0; s_done = 0; }
+  __syncthreads();
+  if (tid < R * R) {
+    const int i = tid / R, j = tid - i * R;
+    s_prior_cov[tid] = (moments[1 + R + tid] - Ntot * s_prior_mean[i] * s_prior_mean[j]) / (Ntot - 1.0);
+  }
+  const double* st_nk = stats + 1;
+  const double* st_x = st_nk + K;
+  const double* st_xx = st_x + (size_t)K * R;
+  if (tid < K) s_nk[tid] = st_nk[tid] + 10.0 * 2.220446049250313e-16;
+  __syncthreads();
+  for (int p = tid; p < K * R; p += 256) s_xk[p] = st_x[p] / s_nk[p / R];
+  __syncthreads();
+  for (int p = tid; p < K * R * R; p += 256) {
+    const int k = p / (R * R), ij = p - k * R * R, i = ij / R, j = ij - i * R;
+    s_sk[p] = st_xx[p] / s_nk[k] - s_xk[k * R + i] * s_xk[k * R + j] + (i == j ? c.reg_covar : 0.0);
+  }
+  __syncthreads();
+  if (tid < K) {
+    const int k = tid;
+    const double nk = s_nk[k];
+    if (c.prior_type == 0) {
+      S.wa[k] = c.wc_prior + nk;
+      S.wb[k] = 0.0;
+    } else {
+      double tail = 0.0;
+      for (int j = K - 1; j > k; --j) tail += s_nk[j];
+      S.wa[k] = 1.0 + nk;
+      S.wb[k] = c.wc_prior + tail;
+    }
+    const double mp = c.mean_prec_prior + nk;
+    S.mprec[k] = mp;
+    for (int r = 0; r < R; ++r) S.means[k * R + r] = (c.mean_prec_prior * s_prior_mean[r] + nk * s_xk[k * R + r]) / mp;
+    const double dof = (double)R + nk;
+    S.dof[k] = dof;
+    double* C = S.cov + (size_t)k * R * R;
+    for (int i = 0; i < R; ++i)
+      for (int j = 0; j < R; ++j) {
+        const double di = s_xk[k * R + i] - s_prior_mean[i], dj = s_xk[k * R + j] - s_prior_mean[j];
+        C[i * R + j] = (s_prior_cov[i * R + j] + nk * s_sk[(k * R + i) * R + j] + nk * c.mean_prec_prior / mp * (di * dj)) / dof;
+      }
+    double* Lm = s_sk + (size_t)k * R * R;
+    bool ok = true;
+    for (int j = 0; j < R; ++j) {
+      double d = C[j * R + j];
+      for (int p = 0; p < j; ++p) d -= Lm[j * R + p] * Lm[j * R + p];
+      if (!(d > 0.0)) { ok = false; d = 1.0; }
+      const double ljj = sqrt(d);
+      Lm[j * R + j] = ljj;
+      for (int i = j + 1; i < R; ++i) {
+        double v = C[i * R + j];
+        for (int p = 0; p < j; ++p) v -= Lm[i * R + p] * Lm[j * R + p];
+        Lm[i * R + j] = v / ljj;
+      }
+    }
+    if (!ok) atomicExch(&s_flag, 1);
+    double* Pk = S.pchol + (size_t)k * R * R;
+    for (int col = 0; col < R; ++col)
+      for (int i = 0; i < R; ++i) {
+        double v = (i == col) ? 1.0 : 0.0;
+        for (int p = col; p < i; ++p) v -= Lm[i * R + p] * Pk[col * R + p];
+        Pk[col * R + i] = (i < col) ? 0.0 : v / Lm[i * R + i];
+      }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (s_flag) {                                                  // ill-defined empirical covariance (sklearn raises)
+      S.tail[2] = -1.0;
+      S.tail[3] = 1.0;
+      s_done = 2;
+    } else if (it == 0) {
+      S.tail[0] = -INFINITY;                                       // _initialize: no lower bound yet
+      S.tail[1] = 0.0;
+      if (c.max_iter == 0) { S.tail[3] = 1.0; s_done = 1; }
+    } else {
+      double log_wishart = 0.0, sum_log_mp = 0.0, log_norm_weight;
+      for (int k = 0; k < K; ++k) {
+        const double* Pk = S.pchol + (size_t)k * R * R;
+        double ld = 0.0, lg = 0.0;
+        for (int j = 0; j < R; ++j) {
+          ld += log(Pk[j * R + j]);
+          lg += lgamma(0.5 * (S.dof[k] - j));
+        }
+        ld -= 0.5 * R * log(S.dof[k]);
+        log_wishart += -(S.dof[k] * ld + S.dof[k] * R * 0.5 * log(2.0) + lg);
+        sum_log_mp += log(S.mprec[k]);
+      }
+      if (c.prior_type == 0) {
+        double sw = 0.0, sl = 0.0;
+        for (int k = 0; k < K; ++k) { sw += S.wa[k]; sl += lgamma(S.wa[k]); }
+        log_norm_weight = lgamma(sw) - sl;
+      } else {
+        double sb = 0.0;
+        for (int k = 0; k < K; ++k) sb += lgamma(S.wa[k]) + lgamma(S.wb[k]) - lgamma(S.wa[k] + S.wb[k]);
+        log_norm_weight = -sb;
+      }
+      const double lb = -stats[0] - log_wishart - log_norm_weight - 0.5 * R * sum_log_mp;
+      const bool conv = fabs(lb - S.tail[0]) < c.tol;
+      S.tail[0] = lb;
+      S.tail[1] = (double)it;
+      if (conv) { S.tail[2] = 1.0; S.tail[3] = 1.0; s_done = 1; }
+      else if (it >= c.max_iter) { S.tail[3] = 1.0; s_done = 1; }
+    }
+  }
+  __syncthreads();
+  if (s_done != 1) return;
+  // _set_parameters: the float32 copies for the mixture feed
+  if (tid == 0) {
+    double tot = 0.0;
+    if (c.prior_type == 0) {
+      for (int k = 0; k < K; ++k) tot += S.wa[k];
+      for (int k = 0; k < K; ++k) w_out[k] = (float)(S.wa[k] / tot);
+    } else {
+      double prod = 1.0;
+      for (int k = 0; k < K; ++k) {
+        const double sm = S.wa[k] + S.wb[k];
+        s_ck[k] = S.wa[k] / sm * prod;
+        prod *= S.wb[k] / sm;
+        tot += s_ck[k];
+      }
+      for (int k = 0; k < K; ++k) w_out[k] = (float)(s_ck[k] / tot);
+    }
+  }
+  for (int i = tid; i < K * R; i += 256) m_out[i] = (float)S.means[i];
+  for (int i = tid; i < K * R * R; i += 256) c_out[i] = (float)S.cov[i];
+}
+
 }  // namespace
 
 extern "C" {
 
-size_t ladder_vbgmm_state_doubles(int K, int R) { return (size_t)K * (4 + R + 2 * R * R) + 3; }
+size_t ladder_vbgmm_state_doubles(int K, int R) { return (size_t)K * (4 + R + 2 * R * R) + 4; }
 
 size_t ladder_vbgmm_workspace_bytes(int N, int K) { return (size_t)N * K * sizeof(double); }
 
@@ -328,6 +599,38 @@ int ladder_vbgmm_fit(const float* X, int N, int K, int R, const int* labels, dou
   if (ws == nullptr || ws_bytes < ladder_vbgmm_workspace_bytes(N, K)) return LADDER_E_WORKSPACE;
   VbCfg c{N, K, R, prior_type, max_iter, labels != nullptr ? 1 : 0, wc_prior, mean_prec_prior, reg_covar, tol};
   hipLaunchKernelGGL(vbgmm_fit_kernel, dim3(1), dim3(VB_THREADS), 0, stream, X, labels, state, c, (double*)ws, weights, means, covs);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+// ---- the sharded fit: see the kernels above.  All vectors are device doubles; the host all-reduces `moments` once and `stats` once per
+// iteration (SUM over ranks) between the two launches.
+size_t ladder_vbgmm_shard_stats_doubles(int K, int R) { return (size_t)1 + K + (size_t)K * R + (size_t)K * R * R; }
+size_t ladder_vbgmm_shard_moments_doubles(int R) { return (size_t)1 + R + (size_t)R * R; }
+
+int ladder_vbgmm_shard_moments(const float* X, int N, int R, double* moments, ladder_stream_t stream) {
+  if (N < 1 || R < 1 || R > VB_MAXR) return LADDER_E_SHAPE;
+  hipLaunchKernelGGL(vbgmm_moments_kernel, dim3(1), dim3(VB_THREADS), 0, stream, X, N, R, moments);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_vbgmm_shard_estep(const float* X, int N, int K, int R, const int* labels, const double* state, int prior_type, double* stats,
+                             void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  if (N < 1 || K < 1 || K > VB_MAXK || R < 1 || R > VB_MAXR || (prior_type != 0 && prior_type != 1)) return LADDER_E_SHAPE;
+  if (ws == nullptr || ws_bytes < ladder_vbgmm_workspace_bytes(N, K)) return LADDER_E_WORKSPACE;
+  VbCfg c{N, K, R, prior_type, 0, labels != nullptr ? 1 : 0, 0.0, 0.0, 0.0, 0.0};
+  hipLaunchKernelGGL(vbgmm_shard_estep_kernel, dim3(1), dim3(VB_THREADS), 0, stream, X, labels, state, c, (double*)ws, stats);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_vbgmm_shard_mstep(const double* stats, const double* moments, int K, int R, double* state, int prior_type, double wc_prior,
+                             double mean_prec_prior, double reg_covar, double tol, int max_iter, int it, float* weights, float* means,
+                             float* covs, ladder_stream_t stream) {
+  if (K < 1 || K > VB_MAXK || R < 1 || R > VB_MAXR || max_iter < 0 || it < 0 || (prior_type != 0 && prior_type != 1)) return LADDER_E_SHAPE;
+  VbCfg c{0, K, R, prior_type, max_iter, 0, wc_prior, mean_prec_prior, reg_covar, tol};
+  hipLaunchKernelGGL(vbgmm_shard_mstep_kernel, dim3(1), dim3(256), 0, stream, stats, moments, state, c, it, weights, means, covs);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

@@ -1136,6 +1136,22 @@ class InnerVAE:
         return dh
 
 
+class _AsyncFetch:
+    """Handle of LadderEngine.fetch_async()."""
+
+    def __init__(self, host, event, names, pool):
+        self._host, self._event, self._names, self._pool, self._val = host, event, names, pool, None
+
+    def get(self):
+        if self._val is None:
+            self._event.synchronize()
+            s = self._host.numpy()
+            self._val = {n: float(s[L.S_INDEX[n]]) for n in self._names}
+            self._pool.append(self._host)          # the pinned buffer goes back to the engine's pool
+            self._host = None
+        return self._val
+
+
 # ------------------------------------------------------------------------------------------ engine
 class LadderEngine:
     """Owns parameters + optimiser state and evaluates the reference's four per-minibatch runs.
@@ -1370,6 +1386,18 @@ class LadderEngine:
         s = self.scalars.detach().cpu().numpy()
         names = names or [n for n in L.S_NAMES if not n.startswith("_")]
         return {n: float(s[L.S_INDEX[n]]) for n in names}
+
+    def fetch_async(self, names=None):
+        """fetch() without stalling the host: the scalars are copied into pinned host memory behind the kernels enqueued so far and an
+        event marks the copy; `.get()` on the returned handle waits for THAT event only.  A caller that enqueues the next run before it
+        reads the values keeps the GPU busy across the read (a synchronous fetch after every run left ~0.35 ms of bubbles per CelebA
+        iteration: the device drains, then waits for the host to enqueue the next run's first kernels)."""
+        pool = self.__dict__.setdefault("_pinned_pool", [])
+        host = pool.pop() if pool else torch.empty(L.S_COUNT, dtype=torch.float32, pin_memory=True)
+        host.copy_(self.scalars, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.ctx.device))
+        return _AsyncFetch(host, ev, names or [n for n in L.S_NAMES if not n.startswith("_")], pool)
 
     def std_dev_code(self):
         return (self.partials[L.P_FIXED:L.P_FIXED + self.Z] / self.Bg).cpu().numpy()

@@ -905,3 +905,32 @@ def test_celeba_iteration_is_bit_reproducible(tmp_path):
     r2 = json.load(open(outp2))
     for i, (u, v) in enumerate(zip(r["a"], r2["a"])):
         assert u == v, ("side stream", i, u, v)
+
+
+def test_async_fetch_equals_blocking_fetch(golden_dir):
+    """config key `async_fetch` (default 1): the trainer reads a run's scalars through pinned-memory copies AFTER the next run has been
+    enqueued (engine.fetch_async; no host-side bubble between the four runs) and completes the RUN#2 / RUN#3 record lists one call
+    later.  Same kernels in the same order: after flush() every record list must be bit-identical to the blocking mode, the returned
+    RUN#1 losses identical call by call, and flush() must leave nothing pending."""
+    from ladder_latent_data_distribution_modelling_amd.codes.models import CelebAModel_densenet
+    from ladder_latent_data_distribution_modelling_amd.codes.base import BaseTrain_joint
+    d = np.load(os.path.join(golden_dir, "oracle_celeba.npz"))
+    base = json.loads(str(d["config"]))
+    base.update(checkpoint_dir="/tmp/", result_dir="/tmp/", use_hip_graphs=0)
+    x = torch.as_tensor(d["x"]).cuda()
+    outs = []
+    for mode in (0, 1):
+        cfg = dict(base, async_fetch=mode)
+        tr = BaseTrain_joint(None, CelebAModel_densenet(cfg, device="cuda:0", seed=1), None, cfg)
+        tr.cur_epoch = int(cfg["sg_pretraining"]) + 1
+        tr.gm_params = (d["gm_w"], d["gm_m"], d["gm_c"])
+        losses = []
+        for it in range(4):
+            losses.append(tr.train_step_ae(cur_lr=1e-3, batch_data=x))
+            tr.train_step_prior(batch_data=x)
+            if mode == 1 and it == 1:
+                assert len(tr.code_elbo_train) == 1 and len(tr._pending) == 1      # RUN#3 of this iteration is still in flight
+        lp = tr.last_fetch_prior                                                  # (property: flushes)
+        assert not tr._pending and len(tr.code_elbo_train) == 4 and len(tr.sigma_train) == 4
+        outs.append((losses, list(tr.elbo_train), list(tr.sigma_train), list(tr.code_elbo_train), list(tr.code_inner_sigma_train), lp))
+    assert outs[0] == outs[1]

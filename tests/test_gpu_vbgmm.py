@@ -59,3 +59,105 @@ def test_vbgmm_restarts_determinism_and_errors():
         DeviceBayesianGaussianMixture(n_components=12).fit(X[:5])
     with pytest.raises(NotImplementedError):
         DeviceBayesianGaussianMixture(n_components=3, covariance_type="diag")
+
+
+@pytest.mark.parametrize("R,K,ptype,max_iter", [(2, 30, "dirichlet_distribution", 1000), (8, 50, "dirichlet_distribution", 300),
+                                                (2, 30, "dirichlet_process", 2000), (3, 7, "dirichlet_process", 5)])
+def test_vbgmm_sharded_statistics_fit_matches_sklearn_one_rank(R, K, ptype, max_iter):
+    """The sharded fit (E-step + local sufficient statistics / all-reduce / M-step per iteration: csrc/vbgmm.hip, exchange step C5) on ONE
+    rank, where the all-reduce is the identity: cold fit and warm-started refit against sklearn -- same iteration count, lower bound
+    to 1e-8, parameters to 1e-7 (second moments are accumulated raw and centred in the M-step; sklearn centres first) -- and the
+    result must not depend on how often the host looks at the `done` flag (iterations enqueued past the end are no-ops)."""
+    import warnings
+    from sklearn.mixture import BayesianGaussianMixture
+    from ladder_latent_data_distribution_modelling_amd.codes.vbgmm import DeviceBayesianGaussianMixture
+    from ladder_latent_data_distribution_modelling_amd.engine import Comm
+    rng = np.random.default_rng(R * 100 + K)
+    X1, X2 = _samples(rng, 2048, R), _samples(rng, 2048, R)
+    kw = dict(n_components=K, covariance_type="full", max_iter=max_iter, n_init=1, weight_concentration_prior_type=ptype,
+              weight_concentration_prior=0.1, warm_start=True, random_state=7)
+    ref, dev, dev1 = BayesianGaussianMixture(**kw), DeviceBayesianGaussianMixture(**kw), DeviceBayesianGaussianMixture(**kw)
+    comm = Comm()
+    assert not comm.on
+    for X in (X1, X2):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref.fit(X.astype(np.float64))
+            dev.fit_sharded(torch.as_tensor(X).cuda(), comm)
+            dev1.fit_sharded(torch.as_tensor(X).cuda(), comm, check_every=1)
+        assert dev.n_iter_ == ref.n_iter_ and dev.converged_ == ref.converged_
+        assert abs(dev.lower_bound_ - ref.lower_bound_) <= 1e-8 * abs(ref.lower_bound_)
+        np.testing.assert_allclose(dev.weights_, ref.weights_, rtol=1e-7, atol=1e-11)
+        np.testing.assert_allclose(dev.means_, ref.means_, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(dev.covariances_, ref.covariances_, rtol=1e-6, atol=1e-9)
+        assert dev1.n_iter_ == dev.n_iter_ and dev1.lower_bound_ == dev.lower_bound_ and np.array_equal(dev1.covariances_, dev.covariances_)
+        np.testing.assert_array_equal(dev.weights_dev.cpu().numpy(), dev.weights_.astype(np.float32))
+
+
+SHARD_WORKER = r'''
+import os, sys, warnings
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+if world > 1:
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=world)
+from ladder_latent_data_distribution_modelling_amd.codes.vbgmm import DeviceBayesianGaussianMixture
+from ladder_latent_data_distribution_modelling_amd.engine import Comm
+d = np.load(sys.argv[3])
+comm = Comm()
+assert comm.world == world
+kw = dict(n_components=int(d["K"]), covariance_type="full", max_iter=1000, n_init=1, weight_concentration_prior_type="dirichlet_distribution",
+          weight_concentration_prior=0.1, warm_start=True, random_state=7)
+gm = DeviceBayesianGaussianMixture(device="cuda:0", **kw)
+out = {}
+for i, key in enumerate(("X1", "X2")):
+    X = d[key]
+    n = X.shape[0] // world
+    Xl = X[rank * n:(rank + 1) * n] if rank < world - 1 else X[rank * n:]          # contiguous shards in rank order (ragged tail on the last)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gm.fit_sharded(torch.as_tensor(Xl).cuda(), comm)
+    out["n_iter%%d" %% i], out["lb%%d" %% i] = gm.n_iter_, gm.lower_bound_
+    out["w%%d" %% i], out["m%%d" %% i], out["c%%d" %% i] = gm.weights_, gm.means_, gm.covariances_
+if rank == 0:
+    np.savez(sys.argv[4], **out)
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+'''
+
+
+def test_vbgmm_sharded_fit_two_ranks_equals_sklearn(tmp_path):
+    """C5 with a real exchange: two processes (sharing cuda:0 over gloo; RCCL refuses two ranks on one device) hold 1024 + 1027 samples each
+    and all-reduce the sufficient statistics every variational iteration; cold fit + warm-started refit must reproduce sklearn's fit of
+    the 2051 samples (same iteration count, lower bound 1e-8, parameters 1e-7)."""
+    import os
+    import subprocess
+    import sys
+    import warnings
+    from sklearn.mixture import BayesianGaussianMixture
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(77)
+    R, K = 2, 20
+    X1, X2 = _samples(rng, 2051, R), _samples(rng, 2051, R)
+    inp, outp = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
+    np.savez(inp, X1=X1, X2=X2, K=K)
+    script = tmp_path / "shard_worker.py"
+    script.write_text(SHARD_WORKER % dict(root=root, port=32500 + os.getpid() % 2000))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", inp, outp], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[-2500:] for o in outs]
+    got = np.load(outp)
+    ref = BayesianGaussianMixture(n_components=K, covariance_type="full", max_iter=1000, n_init=1,
+                                  weight_concentration_prior_type="dirichlet_distribution", weight_concentration_prior=0.1, warm_start=True,
+                                  random_state=7)
+    for i, X in enumerate((X1, X2)):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref.fit(X.astype(np.float64))
+        assert int(got["n_iter%d" % i]) == ref.n_iter_, (i, int(got["n_iter%d" % i]), ref.n_iter_)
+        assert abs(float(got["lb%d" % i]) - ref.lower_bound_) <= 1e-8 * abs(ref.lower_bound_)
+        np.testing.assert_allclose(got["w%d" % i], ref.weights_, rtol=1e-7, atol=1e-11)
+        np.testing.assert_allclose(got["m%d" % i], ref.means_, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(got["c%d" % i], ref.covariances_, rtol=1e-6, atol=1e-9)
