@@ -182,18 +182,19 @@ class BaseTrain:
                 and self.config.get("gm_fit_mode", "allreduce_stats") == "allreduce_stats")
 
     def _draw_t_samples(self, iterator, n_batch, space="t", gather=True):
-        """t- (or z-) samples of n_batch minibatches as ONE device tensor [n, R] (every rank's, in rank order, under data
-        parallelism -- or, gather=False, this rank's only: the sharded fit exchanges statistics, not samples)."""
+        """t- (or z-) samples of n_batch minibatches as ONE device tensor [n, R]: every rank's, rank-major (rank 0's samples first), from
+        ONE all-gather under data parallelism -- or, gather=False, this rank's only: the sharded fit exchanges statistics, not samples."""
         eng = self.engine
         chunks = []
         for _ in range(n_batch):
             t = eng.sample_representation(iterator.next()) if space == "t" else eng.sample_code(iterator.next())
-            if eng.ctx.comm.on and gather:   # C5 ("replicated" mode): gather every rank's samples
-                parts = [torch.empty_like(t) for _ in range(eng.ctx.comm.world)]
-                eng.ctx.comm.dist.all_gather(parts, t.contiguous(), group=eng.ctx.comm.group)
-                t = torch.cat(parts, 0)
             chunks.append(t.clone())
-        return torch.cat(chunks, 0)
+        t = torch.cat(chunks, 0)
+        if eng.ctx.comm.on and gather:   # C5 ("replicated" mode): gather every rank's samples
+            parts = [torch.empty_like(t) for _ in range(eng.ctx.comm.world)]
+            eng.ctx.comm.dist.all_gather(parts, t.contiguous(), group=eng.ctx.comm.group)
+            t = torch.cat(parts, 0)
+        return t
 
     def _share_gm(self, gm):
         """sklearn backend: rank 0 fits on the host, every rank receives (weights, means, covs)."""
@@ -237,7 +238,7 @@ class BaseTrain:
         else:
             kw = dict(n_components=int(self.config["n_mixtures"]), covariance_type="full", max_iter=2000,
                       n_init=int(self.config["GM_fit_restart"]), weight_concentration_prior_type="dirichlet_process",
-                      weight_concentration_prior=0.1, warm_start=False)
+                      weight_concentration_prior=0.1, warm_start=False, random_state=self.config.get("gm_random_state"))
             if self.config.get("gm_fit_backend", "hip") == "hip":
                 from .vbgmm import DeviceBayesianGaussianMixture
                 self.GM_prior_final = DeviceBayesianGaussianMixture(

@@ -41,8 +41,10 @@ class BaseModel:
     def define_GM_prior(self):
         self.GM_prior_training = None
         if self.config["prior"] == "ours":
+            # (config key `gm_random_state`, optional: seeds the k-means initialisation of a cold fit; None = sklearn's default, as the reference)
             kw = dict(n_components=int(self.config["n_mixtures"]), covariance_type="full", max_iter=1000, n_init=1,
-                      weight_concentration_prior_type="dirichlet_distribution", weight_concentration_prior=0.1, warm_start=True)
+                      weight_concentration_prior_type="dirichlet_distribution", weight_concentration_prior=0.1, warm_start=True,
+                      random_state=self.config.get("gm_random_state"))
             if self.config.get("gm_fit_backend", "hip") == "hip":
                 from .vbgmm import DeviceBayesianGaussianMixture
                 comm = self.engine.ctx.comm
