@@ -94,7 +94,7 @@ size_t ladder_conv1x1_smallcout_bwd_workspace_bytes(long M, int Cin, int Cout);
 int ladder_conv1x1_smallcout_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long M, int Cin,
                                  int Cout, int gate_act, void* ws, size_t ws_bytes, ladder_stream_t stream);
 /* ... additionally produces the absolute-maximum record of dx (LADDER_ABSMAX_FLOATS floats, see ladder_absmax; dx must not be NULL):
- * per sample (mode 1) when rows_per_sample = H*W > 0 divides M and is a multiple of 256 / (Cin / 4), else one bound for the tensor. */
+ * per sample (mode 1) when rows_per_sample = H*W > 0 divides M (the workgroups of a sample then sweep its pixels), else one bound for the tensor. */
 int ladder_conv1x1_smallcout_bwd_absmax(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long M, int Cin,
                                         int Cout, int gate_act, void* ws, size_t ws_bytes, float* dx_absmax, long rows_per_sample,
                                         ladder_stream_t stream);
