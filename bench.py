@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--config", default=os.path.join(ROOT, "codes", "celeba_config.json"))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (default: config batch_size)")
     ap.add_argument("--precision", default="", help="matmul_precision override: f32 | bf16x6 | bf16x3 (default: the engine's)")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="override a config key (JSON value), repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-compare", action="store_true", help="skip the native-fp32 leg after the timed region")
@@ -199,6 +200,12 @@ def main():
         cfg["batch_size"] = args.batch
     if args.precision:
         cfg["matmul_precision"] = args.precision
+    for kv in args.set:
+        k, _, v = kv.partition("=")
+        try:
+            cfg[k] = json.loads(v)
+        except ValueError:
+            cfg[k] = v
     precision = str(cfg.get("matmul_precision", E.DEFAULT_PRECISION))
     cfg.setdefault("checkpoint_dir", "/tmp/ladder_bench/")
     cfg.setdefault("result_dir", "/tmp/ladder_bench/")

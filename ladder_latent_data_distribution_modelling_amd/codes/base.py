@@ -16,7 +16,12 @@ class BaseTrain:
         self.model, self.config, self.sess, self.data = model, config, sess, data
         self.engine = model.engine
         # replay each run as one captured hipGraph after two eager warm-ups (config key `use_hip_graphs`, default on)
-        self.engine.use_graphs = bool(int(config.get("use_hip_graphs", 1)))
+        # (default: on for the MNIST nets, whose ~350 short launches per iteration are host-bound in eager mode; off for CelebA, where
+        # replay measured SLOWER than eager launches -- 21.6 against 21.0 ms per iteration -- and would rule out the stream overlap below)
+        self.engine.use_graphs = bool(int(config.get("use_hip_graphs", 0 if config.get("exp_name") == "celeba" else 1)))
+        # config key `overlap_prior_runs` (default 1): RUN#3 / RUN#4 on a second HIP stream beside RUN#2's decoder forward
+        # (engine.enable_prior_overlap; bit-identical results; eager launches, one rank)
+        self.engine.enable_prior_overlap(bool(int(config.get("overlap_prior_runs", 1))) and not self.engine.use_graphs)
         self.cur_epoch = 0
         # same record lists as codes/base.py:531-570
         for name in ("train_loss train_loss_prior val_loss val_loss_prior train_loss_ave_epoch val_loss_ave_epoch elbo_train "

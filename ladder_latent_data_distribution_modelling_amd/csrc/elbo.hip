@@ -836,7 +836,7 @@ __global__ void adam_clip_dev_kernel(float* __restrict__ theta, const float* __r
   }
 }
 __global__ void u64_add_kernel(unsigned long long* __restrict__ p, unsigned long long inc) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *p += inc;
+  if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(p, inc);      // (atomic: two streams may advance the noise position concurrently)
 }
 
 // ----------------------------------------------------------------------------- Philox4x32-10 normals

@@ -198,6 +198,8 @@ class Ctx:
         self.side, self._side_active, self._side_refs = None, False, []
         self._ws_side = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
         self._ws_side_retired = []
+        self.aux = None      # third HIP stream: RUN#3 / RUN#4 beside RUN#2's decoder forward (LadderEngine.enable_prior_overlap)
+        self._ws_aux = None
         self.keep_activations = True   # False inside forward-only runs: fused kernels may skip writing tensors only a backward pass reads
         self.ns = 0          # LADDER_PREC_* of the split-precision contraction kernels (0 = native f32 MFMA); set by the engine
 
@@ -232,6 +234,11 @@ class Ctx:
             self._ws_side_retired.clear()
 
     def ws(self, nbytes):
+        if self.aux is not None and torch.cuda.current_stream(self.device) == self.aux:        # ... and so has the prior-run stream
+            if self._ws_aux is None or self._ws_aux.numel() < nbytes:
+                # (stream-ordered: the old buffer belongs to this stream's allocator pool, kernels already enqueued on it run first)
+                self._ws_aux = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+            return self._ws_aux.data_ptr(), self._ws_aux.numel()
         if self.side is not None and torch.cuda.current_stream(self.device) == self.side:      # the side stream has its own scratch
             if self._ws_side.numel() < nbytes:
                 self._ws_side_retired.append(self._ws_side)
@@ -369,6 +376,7 @@ class ParamStore:
         return lo, hi
 
     def load_dict(self, values, strict=True):
+        getattr(self, "before_read", lambda: None)()
         for name in self.specs:
             if name not in values:
                 if strict:
@@ -379,6 +387,7 @@ class ParamStore:
             self.version[arch.group_of(name)] += 1
 
     def to_dict(self, groups=None):
+        getattr(self, "before_read", lambda: None)()           # (the engine: wait for runs in flight on the aux stream)
         return {n: self.w[n].detach().cpu().numpy().reshape(self.specs[n]) for n in self.specs
                 if groups is None or arch.group_of(n) in groups}
 
@@ -1208,6 +1217,37 @@ class LadderEngine:
             self.ctx.side = torch.cuda.Stream(device=self.ctx.device)
         self._graphs, self._warm = {}, {}
         self._dec_range = self.ps.prefix_range("ae", "decoder/")   # C1 bucket boundary (data parallel)
+        # RUN#3 / RUN#4 on their own HIP stream beside RUN#2's decoder forward (enable_prior_overlap; the trainer turns it on)
+        self.ps.before_read = self._join_aux
+        self._aux_on = False
+        self._enc_event, self._aux_event = None, None              # "z of the last main-stream forward exists" / "the aux runs are done"
+        self._main_calls, self._aux_calls = 0, 0                    # noise calls of the last main forward / of the aux runs since
+        self._on_aux = False
+        self._fetch_src = None                                      # (scalars buffer, stream) of the last run
+
+    def enable_prior_overlap(self, on=True):
+        """RUN#3 and RUN#4 (inner VAE forward / backward, mixture term, Adam on prior/* and inner_sigma: ~150 launches of a few
+        microseconds, 0.9 ms of latency-bound chain on CelebA) read only the encoder output that RUN#2 computes FIRST and write only the
+        prior variables, which RUN#2 never touches: with this on, run_prior / run_inner_sigma called with reuse_encoder=True are
+        enqueued on a second HIP stream behind an event recorded right after RUN#2's code sample, and run beside RUN#2's decoder
+        forward (big MFMA-bound kernels).  Separate partials / scalars buffers and scratch; the noise positions are those of the
+        sequential order (snapshot of the device counter + host-known call counts), so results are bit-identical to the sequential
+        schedule.  The next main-stream run waits for the aux stream first.  Off under data parallelism (collectives stay on one
+        stream) and with hipGraph replay."""
+        on = bool(on) and not self.ctx.comm.on
+        self._aux_on = on
+        if on and self.ctx.aux is None:
+            # (high priority: its few-microsecond kernels should not queue behind the thousands of workgroups of a decoder conv)
+            self.ctx.aux = torch.cuda.Stream(device=self.ctx.device, priority=int(os.environ.get("LADDER_AUX_PRIORITY", -1)))
+            self.partials_aux, self.scalars_aux = torch.zeros_like(self.partials), torch.zeros_like(self.scalars)
+            self.rng_counter_aux = torch.zeros_like(self.rng_counter)
+
+    def _join_aux(self):
+        """The main stream waits for the runs enqueued on the aux stream (no-op when none are pending)."""
+        if self._aux_event is not None:
+            torch.cuda.current_stream(self.ctx.device).wait_event(self._aux_event)
+            self._aux_event = None
+            self._aux_calls = 0
 
     # -- inputs ---------------------------------------------------------------------------------
     def _dev(self, a):
@@ -1227,7 +1267,11 @@ class LadderEngine:
 
     def _randn(self, *shape):
         t = self.ctx.empty(*shape)
-        L.call("ladder_randn_dev", _p(t), t.numel(), self.noise_seed, _p(self.rng_counter), self._run_calls, self.ctx.stream)
+        if self._on_aux:      # sequential position: the counter as RUN#2 saw it + RUN#2's calls + the earlier aux runs' calls + this run's
+            L.call("ladder_randn_dev", _p(t), t.numel(), self.noise_seed, _p(self.rng_counter_aux),
+                   self._main_calls + self._aux_calls + self._run_calls, self.ctx.stream)
+        else:
+            L.call("ladder_randn_dev", _p(t), t.numel(), self.noise_seed, _p(self.rng_counter), self._run_calls, self.ctx.stream)
         self._run_calls += 1
         return t
 
@@ -1265,6 +1309,8 @@ class LadderEngine:
         what a re-evaluation would give (deterministic kernels, batch statistics of the same batch) and is reused; the
         fresh noise of the run still produces a new code_sample.  Guarded by the AE optimiser step counter."""
         ctx, st = self.ctx, self.ctx.stream
+        if not self._on_aux:
+            self._join_aux()                       # (prior variables / noise position: the aux runs of the last iteration come first)
         ctx.keep_activations = bool(keep_acts)     # forward-only runs (RUN#2, val_step): fused kernels skip backward-only tensors
         Z, R = self.Z, self.R
         P = self.partials
@@ -1291,6 +1337,11 @@ class LadderEngine:
         L.call("ladder_latent_fwd", _p(mu), _p(sd_raw), _p(eps_z), self.lvp, _p(z), _p(sd), _p(P[L.P_LOG_SDZ:]),
                _p(P[L.P_MU2SD2_Z:]), _p(P[L.P_FIXED:]), B, Z, st)
         self.lat_z = (mu, sd, sd_raw, eps_z, z)
+        # everything a following aux run reads from this forward exists now (the encoder output).  If this forward draws no further noise
+        # (RUN#2: decoder only) the aux stream may start here, beside the decoder; else only after the last draw (end of the forward)
+        early_aux = "inner" not in parts and "gmm" not in parts
+        if early_aux:
+            self._mark_for_aux()
         self.xhat = None
         if "dec" in parts:
             xhat = self.decoder.forward(z)
@@ -1328,9 +1379,22 @@ class LadderEngine:
                                1 if self.hier else 0, 1 if (self.gmm_z or vamp_on) else 0)
         L.call("ladder_elbo_finalize", _p(P), _p(self.ps.w["sigma/Variable"]),
                _p(self.ps.w["inner_sigma/Variable"]) if self.has_inner else None, ecfg, _p(self.scalars), st)
+        if not early_aux:
+            self._mark_for_aux()
         if self._run_calls:
-            L.call("ladder_u64_add", _p(self.rng_counter), self._run_calls, st)      # advance the device noise stream
+            L.call("ladder_u64_add", _p(self.rng_counter), self._run_calls, st)      # advance the device noise stream (atomic add)
+        if self._on_aux:
+            self._aux_calls += self._run_calls
+        else:
+            self._main_calls = self._run_calls
         self.use_sg, self.use_mask = use_sg, use_mask
+
+    def _mark_for_aux(self):
+        """Main-stream forward: snapshot of the noise position (before this run's advance) + the event an aux run waits for."""
+        if self._aux_on and not self._on_aux and not torch.cuda.is_current_stream_capturing():
+            self.rng_counter_aux.copy_(self.rng_counter, non_blocking=True)
+            self._enc_event = torch.cuda.Event()
+            self._enc_event.record(torch.cuda.current_stream(self.ctx.device))
 
     def _mixture_term(self, mu, sd, noise, B, need_grad=True):
         """MC estimate of E_q[log p_GM] over L samples of N(mu, sd^2) (base.py:308-313 on t, 322-329 on z): writes the sum of
@@ -1383,7 +1447,9 @@ class LadderEngine:
 
     def fetch(self, names=None):
         """Host copy of the fetched scalars (ONE device->host sync)."""
-        s = self.scalars.detach().cpu().numpy()
+        self._join_aux()
+        src = self._fetch_src[0] if self._fetch_src is not None else self.scalars
+        s = src.detach().cpu().numpy()
         names = names or [n for n in L.S_NAMES if not n.startswith("_")]
         return {n: float(s[L.S_INDEX[n]]) for n in names}
 
@@ -1394,9 +1460,11 @@ class LadderEngine:
         iteration: the device drains, then waits for the host to enqueue the next run's first kernels)."""
         pool = self.__dict__.setdefault("_pinned_pool", [])
         host = pool.pop() if pool else torch.empty(L.S_COUNT, dtype=torch.float32, pin_memory=True)
-        host.copy_(self.scalars, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.ctx.device))
+        src, stream = self._fetch_src if self._fetch_src is not None else (self.scalars, torch.cuda.current_stream(self.ctx.device))
+        with torch.cuda.stream(stream):                  # (the stream the run was enqueued on: its scalars buffer, its order)
+            host.copy_(src, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
         return _AsyncFetch(host, ev, names or [n for n in L.S_NAMES if not n.startswith("_")], pool)
 
     def std_dev_code(self):
@@ -1553,10 +1621,19 @@ class LadderEngine:
         lr_t, noise stream position) lives in device memory, so a replay is exactly the eager run."""
         fn = getattr(self, "_" + kind)
         if not self.use_graphs or noise is not None or self.ctx.comm.on:
+            cache = getattr(self, "_enc_cache", None)
+            if (self._aux_on and not self.use_graphs and kind in ("prior", "inner_sigma") and reuse_encoder and not self.vamp
+                    and self._enc_event is not None and cache is not None and cache[0] == self.ps.step["ae"]
+                    and cache[4] == self._batch_token(x)):
+                return self._run_on_aux(fn, x, lr, noise, use_sg, use_mask)
+            self._join_aux()
+            self._fetch_src = (self.scalars, torch.cuda.current_stream(self.ctx.device))
             try:
                 return fn(x, lr, noise, use_sg, use_mask, reuse_encoder)
             finally:
                 self.ctx.join_side()
+        self._join_aux()
+        self._fetch_src = (self.scalars, torch.cuda.current_stream(self.ctx.device))
         group = self._GROUP[kind]
         tok = self._batch_token(x)
         xin = self._dev(x)
@@ -1599,6 +1676,22 @@ class LadderEngine:
         for k, v in snap.items():
             setattr(self, k, v)
 
+    def _run_on_aux(self, fn, x, lr, noise, use_sg, use_mask):
+        """One of RUN#3 / RUN#4 on the aux stream (see enable_prior_overlap)."""
+        aux = self.ctx.aux
+        aux.wait_event(self._enc_event)
+        main_bufs = (self.partials, self.scalars)
+        self.partials, self.scalars, self._on_aux = self.partials_aux, self.scalars_aux, True
+        try:
+            with torch.cuda.stream(aux):
+                fn(x, lr, noise, use_sg, use_mask, True)
+                self._aux_event = torch.cuda.Event()
+                self._aux_event.record(aux)
+        finally:
+            self.partials, self.scalars = main_bufs
+            self._on_aux = False
+        self._fetch_src = (self.scalars_aux, aux)
+
     def run_ae(self, x, lr, noise=None, use_sg=True, use_mask=False):
         self._run("ae", x, lr, noise, use_sg, use_mask, False)
 
@@ -1618,6 +1711,7 @@ class LadderEngine:
     # -- generation -----------------------------------------------------------------------------
     def decode(self, code):
         """decoded given code_input (is_code_input=True; models.py:107,265,500)."""
+        self._join_aux()
         self.ctx.keep_activations = False
         try:
             return self.decoder.forward(self._dev(code))
@@ -1626,6 +1720,7 @@ class LadderEngine:
 
     def decode_representation(self, t):
         """decoded_code given representation_input (base.py:171-186)."""
+        self._join_aux()
         return self.inner.decode(self._dev(t))
 
     def sample_code(self, x, noise=None):

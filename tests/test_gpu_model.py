@@ -919,9 +919,12 @@ def test_async_fetch_equals_blocking_fetch(golden_dir):
     base.update(checkpoint_dir="/tmp/", result_dir="/tmp/", use_hip_graphs=0)
     x = torch.as_tensor(d["x"]).cuda()
     outs = []
-    for mode in (0, 1):
-        cfg = dict(base, async_fetch=mode)
+    # ... and `overlap_prior_runs` (default 1): RUN#3 / RUN#4 on a second HIP stream beside RUN#2's decoder forward, with their own
+    # partials / scalars / scratch and the noise positions of the sequential order -- every combination must give the same bits
+    for mode, overlap in ((0, 0), (1, 0), (1, 1), (0, 1)):
+        cfg = dict(base, async_fetch=mode, overlap_prior_runs=overlap)
         tr = BaseTrain_joint(None, CelebAModel_densenet(cfg, device="cuda:0", seed=1), None, cfg)
+        assert tr.engine._aux_on == bool(overlap)
         tr.cur_epoch = int(cfg["sg_pretraining"]) + 1
         tr.gm_params = (d["gm_w"], d["gm_m"], d["gm_c"])
         losses = []
@@ -932,5 +935,7 @@ def test_async_fetch_equals_blocking_fetch(golden_dir):
                 assert len(tr.code_elbo_train) == 1 and len(tr._pending) == 1      # RUN#3 of this iteration is still in flight
         lp = tr.last_fetch_prior                                                  # (property: flushes)
         assert not tr._pending and len(tr.code_elbo_train) == 4 and len(tr.sigma_train) == 4
-        outs.append((losses, list(tr.elbo_train), list(tr.sigma_train), list(tr.code_elbo_train), list(tr.code_inner_sigma_train), lp))
-    assert outs[0] == outs[1]
+        outs.append((losses, list(tr.elbo_train), list(tr.sigma_train), list(tr.code_elbo_train), list(tr.code_inner_sigma_train), lp,
+                     {k: v.tobytes() for k, v in tr.engine.ps.to_dict().items()}))
+    for o in outs[1:]:
+        assert o == outs[0]
