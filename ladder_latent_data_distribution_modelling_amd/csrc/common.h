@@ -91,6 +91,19 @@ __device__ __forceinline__ float amax_sample(const float* rec, int n, bool per_s
   return per_sample ? rec[amax_ps_index(n)] : tmax;
 }
 
+// wave_max for kernel EPILOGUES: the lane id is re-derived from an opaque copy of the thread id at the point of use, so that the shuffle
+// addresses ((lane ^ o) * 4 for ds_bpermute) are computed here and not hoisted above a register-starved main loop (they were parked in
+// scratch across the loop of the 128-register halo convolution kernels).
+__device__ __forceinline__ float wave_max_late(float v) {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  const int lane = t & 63;                                         // (1-D workgroups of whole wavefronts)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ o) << 2, __builtin_bit_cast(int, v))));
+  return v;
+}
+
 // One slot update: fire-and-forget (no returned value: the wavefront does not wait for the L2).  A read-before-update filter was tried
 // and was slower: the workgroup then waits a full L2 round trip for the value before it can retire.
 __device__ __forceinline__ void amax_fold(unsigned* slot, float b) { atomicMax(slot, __builtin_bit_cast(unsigned, b)); }
@@ -122,12 +135,13 @@ __device__ __forceinline__ void amax_commit_block(float m, float* rec) {
 template <bool RESYNC = false>
 __device__ __forceinline__ void amax_commit_block_sample(float m, float* rec, int n) {
   __shared__ float amax_red_ps[16];
-  m = wave_max(m);
-  const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+  m = wave_max_late(m);                              // (1-D workgroups: every caller)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
   if ((tid & 63) == 0) amax_red_ps[tid >> 6] = m;
   __syncthreads();
   if (tid == 0) {
-    const int nw = (blockDim.x * blockDim.y * blockDim.z + 63) >> 6;
+    const int nw = (blockDim.x + 63) >> 6;
     float b = 0.f;
     for (int w = 0; w < nw; ++w) b = fmaxf(b, amax_red_ps[w]);
     amax_fold(reinterpret_cast<unsigned*>(rec) + amax_ps_index(n), b);

@@ -358,6 +358,19 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
     }
   }
 
+  {  // ---- epilogue scope
+  // Epilogue coordinates are RE-DERIVED from opaque copies of the thread / workgroup ids: computed before the main loop they were live
+  // across it, and at 128 registers the compiler parked them in scratch (12-56 bytes per lane).
+  int e_tid = threadIdx.x, e_bid = blockIdx.x;
+  asm volatile("" : "+v"(e_tid));
+  asm volatile("" : "+s"(e_bid));
+  const int e_lane = e_tid & 63, e_wid = e_tid >> 6;
+  const int l31 = e_lane & 31, lh = e_lane >> 5, wm = e_wid >> 1, wn = e_wid & 1;
+  const int e_tile = xcd_remap(e_bid, gridDim.x);
+  const int e_mt = e_tile / tiles_n, n0 = (e_tile % tiles_n) * SP_BN;
+  const int e_twn = W / SP_W, e_thn = H / SP_H;
+  const int img = e_mt / (e_twn * e_thn), e_rem = e_mt - img * (e_twn * e_thn);
+  const int h0 = (e_rem / e_twn) * SP_H, w0 = (e_rem % e_twn) * SP_W;
   if (!PROJ) {
     float ymax = 0.f;
 #pragma unroll
@@ -452,6 +465,7 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
       }
     }
   }
+  }  // epilogue scope
 }
 
 // ---- the same kernel with a 16x32-pixel patch per workgroup (two-plane formats) ----------------------------------------------------
@@ -606,6 +620,19 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
     }
   }
 
+  {  // ---- epilogue scope
+  // Epilogue coordinates are RE-DERIVED from opaque copies of the thread / workgroup ids: computed before the main loop they were live
+  // across it, and at 128 registers the compiler parked them in scratch (12-56 bytes per lane).
+  int e_tid = threadIdx.x, e_bid = blockIdx.x;
+  asm volatile("" : "+v"(e_tid));
+  asm volatile("" : "+s"(e_bid));
+  const int e_lane = e_tid & 63, e_wid = e_tid >> 6;
+  const int l31 = e_lane & 31, lh = e_lane >> 5, wm = e_wid >> 1, wn = e_wid & 1;
+  const int e_tile = xcd_remap(e_bid, gridDim.x);
+  const int e_mt = e_tile / tiles_n, n0 = (e_tile % tiles_n) * SP_BN;
+  const int e_twn = W / SP_W, e_thn = H / F_H;
+  const int img = e_mt / (e_twn * e_thn), e_rem = e_mt - img * (e_twn * e_thn);
+  const int h0 = (e_rem / e_twn) * F_H, w0 = (e_rem % e_twn) * SP_W;
   if (!PROJ) {
     float ymax = 0.f;
 #pragma unroll
@@ -700,6 +727,7 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
       }
     }
   }
+  }  // epilogue scope
 }
 
 // ---- 3x3 filter gradient on split operands -----------------------------------------------------------------------------------
