@@ -123,21 +123,25 @@ def test_200_iteration_trajectory_f16x3_vs_f32_full_size(tmp_path):
     steps = 200
     script = tmp_path / "traj_worker.py"
     script.write_text(TRAJ_WORKER % dict(root=ROOT))
+    import time
     T = {}
     for prec in ("f32", "f16x3", "bf16x6"):
         outp = str(tmp_path / (prec + ".json"))
-        p = subprocess.run([sys.executable, str(script), prec, str(steps), outp], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
+        t0 = time.time()
+        n = steps if prec != "bf16x6" else 24           # (the bf16x6 leg is the yardstick of the EARLY windows only)
+        p = subprocess.run([sys.executable, str(script), prec, str(n), outp], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
         assert p.returncode == 0, p.stdout[-2000:]
+        print("trajectory %s: %.1f s" % (prec, time.time() - t0))
         T[prec] = {k: np.asarray(v, np.float64) for k, v in json.load(open(outp)).items()}
     for prec, t in T.items():
         for k, v in t.items():
-            assert np.isfinite(v).all() and len(v) == steps, (prec, k)
+            assert np.isfinite(v).all() and len(v) == (steps if prec != "bf16x6" else 24), (prec, k)
     rel = lambda a, b: np.abs(a - b) / np.abs(b)
     e32 = T["f32"]["elbo"]
-    d16, dbf = rel(T["f16x3"]["elbo"], e32), rel(T["bf16x6"]["elbo"], e32)
-    g16, gbf = rel(T["f16x3"]["grad_norm"], T["f32"]["grad_norm"]), rel(T["bf16x6"]["grad_norm"], T["f32"]["grad_norm"])
-    print("ELBO deviation from f32, max over iterations 0-4 / 5-19 / 20-199: f16x3 %.1e %.1e %.1e | bf16x6 %.1e %.1e %.1e" % (
-        d16[:5].max(), d16[5:20].max(), d16[20:].max(), dbf[:5].max(), dbf[5:20].max(), dbf[20:].max()))
+    d16, dbf = rel(T["f16x3"]["elbo"], e32), rel(T["bf16x6"]["elbo"], e32[:24])
+    g16, gbf = rel(T["f16x3"]["grad_norm"], T["f32"]["grad_norm"]), rel(T["bf16x6"]["grad_norm"], T["f32"]["grad_norm"][:24])
+    print("ELBO deviation from f32, max over iterations 0-4 / 5-19 / 20-199: f16x3 %.1e %.1e %.1e | bf16x6 %.1e %.1e (24 iterations)" % (
+        d16[:5].max(), d16[5:20].max(), d16[20:].max(), dbf[:5].max(), dbf[5:20].max()))
     print("gradient-norm deviation, iteration 0 / max 0-4: f16x3 %.1e %.1e | bf16x6 %.1e %.1e" % (g16[0], g16[:5].max(), gbf[0], gbf[:5].max()))
     # iteration 0: identical parameters -- kernel rounding only
     assert d16[0] < 2e-6 and g16[0] < 1e-4
@@ -149,10 +153,10 @@ def test_200_iteration_trajectory_f16x3_vs_f32_full_size(tmp_path):
     assert d16[:5].max() < 5e-3 and d16[:5].max() <= 8 * dbf[:5].max() + 5e-4, (d16[:5].max(), dbf[:5].max())
     assert d16[5:20].max() < 3e-2 and d16[5:20].max() <= 4 * dbf[5:20].max() + 3e-3, (d16[5:20].max(), dbf[5:20].max())
     # late window: decorrelated trajectories of the same training run -- the statistics agree
-    m32, m16, mbf = e32[-50:].mean(), T["f16x3"]["elbo"][-50:].mean(), T["bf16x6"]["elbo"][-50:].mean()
-    print("mean ELBO of the last 50 iterations: f32 %.1f f16x3 %.1f bf16x6 %.1f" % (m32, m16, mbf))
-    assert abs(m16 - m32) / abs(m32) < 0.05 and abs(mbf - m32) / abs(m32) < 0.05, (m32, m16, mbf)
-    for prec in T:
+    m32, m16 = e32[-50:].mean(), T["f16x3"]["elbo"][-50:].mean()
+    print("mean ELBO of the last 50 iterations: f32 %.1f f16x3 %.1f" % (m32, m16))
+    assert abs(m16 - m32) / abs(m32) < 0.05, (m32, m16)
+    for prec in ("f32", "f16x3"):
         e = T[prec]["elbo"]
         assert e[-50:].mean() > e[1:11].mean(), prec                       # the ELBO of the 4 minibatches improved in every build
         assert e[-50:].mean() > 0.5 * e[0], prec                           # ... by a lot (it starts at -7.4e4 and reaches ~-2.3e4)

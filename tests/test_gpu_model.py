@@ -628,15 +628,27 @@ def test_bench_script_two_ranks_one_gpu(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, LADDER_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29731", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--config", os.path.join(root, "codes", "mnist_fashion_config.json")]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    # round 3: `python bench.py --gpus 2` WITHOUT a launcher spawns its two ranks itself (through the same torch.distributed.run)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--repeats", "2",
+           "--sustained-seconds", "0", "--config", os.path.join(root, "codes", "mnist_fashion_config.json")]
+    out = subprocess.run(cmd, env={k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}, capture_output=True,
+                         text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["config"]["global_batch"] == 512
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["config"]["global_batch"] == 512
+    assert len(j["repeats_images_per_sec"]) == 2
+    # ... and refuses to print a number under a label it cannot honour: 8 ranks requested, one GPU visible, no test hook
+    env8 = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LADDER_BENCH_SINGLE_DEVICE")}
+    if torch.cuda.device_count() < 8:
+        bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1"], env=env8, capture_output=True,
+                             text=True, timeout=300)
+        assert bad.returncode == 2 and not [l for l in bad.stdout.splitlines() if l.startswith("{")] and "refusing" in bad.stderr
+    # a launcher whose world size disagrees with --gpus is refused as well
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=dict(env8, WORLD_SIZE="1", RANK="0",
+                         LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode == 2 and "refusing" in bad.stderr
     assert j["config"]["parallelism"] == "dp2" and j["value"] > 0 and np.isfinite(j["elbo"]) and "cpu_baseline" not in j
 
 
