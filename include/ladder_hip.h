@@ -164,6 +164,16 @@ int ladder_conv3x3_split_proj(const float* x, const float* x_absmax, const void*
                               const float* proj_b, float* proj_out, int proj_cout, int N, int H, int W, int Cin, int Cout, int act,
                               int prec, ladder_stream_t stream);
 
+/* Backward-data of a 3x3 / stride-2 / SAME convolution over even maps (codes/models.py:398-460: the encoder layers; pad_t = pad_l = 0,
+ * Cin = 128, dy map eligible for the halo kernel: Wo % 32 == 0, Ho % 8 == 0) as ONE launch of the 3x3 halo kernel over dy: the four
+ * output-parity classes are the four 128-channel output tiles, each issues only its 4 / 2 / 2 / 1 taps and writes the interleaved pixels of
+ * dx [N, H, W, 128].  packed_s2 = ladder_filter_pack_split(w, ., 9, Cout, 4 * Cin, transpose_flip = 2, prec) from the layer's HWIO bank
+ * [3][3][Cin][Cout].  dy_absmax / dx_absmax as for ladder_conv3x3_split (per-sample records). */
+int ladder_conv3x3_s2_bwd_data_split_eligible(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t,
+                                              int pad_l);
+int ladder_conv3x3_s2_bwd_data_split(const float* dy, const float* dy_absmax, const void* packed_s2, float* dx, float* dx_absmax, int N, int H,
+                                     int W, int Cin, int Ho, int Wo, int Cout, int prec, ladder_stream_t stream);
+
 /* planes[p][i] = 16-bit plane p of x[i] (scaled by a power of two derived from x_absmax for LADDER_PREC_F16X3), plane-major,
  * n % 8 == 0, followed by 16 zero bytes (the source of out-of-image taps) and a 16-byte header; ladder_presplit_bytes = planes * n * 2 + 32.
  * n_samples > 0 (x is [n_samples, ...], (n / n_samples) % 8 == 0) AND a per-sample record (ladder_absmax_samples, or a producer that

@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__
 // Logical filter F[tap][ci][co] (tap = r*KW+s < ntaps, ci < Cin, co < Cout):
 //   transpose_flip = 0:  F[tap][ci][co] = w[tap][ci][co]               (w is the HWIO bank [ntaps][Cin][Cout])              forward
 //   transpose_flip = 1:  F[tap][ci][co] = w[ntaps - 1 - tap][co][ci]   (w is the HWIO bank [ntaps][Cout][Cin] of the layer)  backward-data
+//   transpose_flip = 2:  the four parity classes of a 3x3 / stride-2 backward-data as output-channel blocks (see filter_pack_element)
 // Packed image (16-bit elements): P[tap][slab = ci/16][cot = co/128][plane][kg = (ci%16)/8][co % 128][ci % 8]; one (tap, slab, cot)
 // block is the contiguous NS * 4096 bytes a workgroup stages per K-step.  The last 16 bytes of the buffer hold the filter's
 // absolute maximum (f16x3 only; the kernels derive the power-of-two scale from it).
@@ -141,7 +142,21 @@ __device__ __forceinline__ void filter_pack_element(const float* __restrict__ w,
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     float f = 0.f;
-    if (co < Cout) f = transpose_flip ? w[((size_t)(ntaps - 1 - tap) * Cout + co) * Cin + ci0 + j] : w[((size_t)tap * Cin + ci0 + j) * Cout + co];
+    if (co < Cout) {
+      if (transpose_flip == 2) {
+        // stride-2 parity bank (ladder_conv3x3_s2_bwd_data_split): w = the layer's HWIO bank [3][3][C][Cin] with C = Cout / 4 its INPUT channels;
+        // output column co = class * C + c, class = (ph, pw); tap (a, b) of the 3x3 / stride-1 correlation over dy carries w[r][s][c][ci]
+        // with r = (a == 1 ? ph : 2) for a in A(ph) = {1} u {0 if ph == 0}, s likewise -- zero elsewhere (those taps are never issued)
+        const int C = Cout >> 2, cls = co / C, cc = co - cls * C, ph = cls >> 1, pw = cls & 1, a = tap / 3, b = tap - 3 * a;
+        const bool va = a == 1 || (a == 0 && ph == 0), vb = b == 1 || (b == 0 && pw == 0);
+        if (va && vb) {
+          const int r = a == 1 ? ph : 2, sx = b == 1 ? pw : 2;
+          f = w[(((size_t)r * 3 + sx) * C + cc) * Cin + ci0 + j];
+        }
+      } else {
+        f = transpose_flip ? w[((size_t)(ntaps - 1 - tap) * Cout + co) * Cin + ci0 + j] : w[((size_t)tap * Cin + ci0 + j) * Cout + co];
+      }
+    }
     v[j] = f * c;
   }
   uint2 lo[NS], hi[NS];
@@ -169,7 +184,7 @@ __global__ __launch_bounds__(256) void filter_pack_kernel(const float* __restric
 constexpr int PK_PARTS = 64;
 __global__ __launch_bounds__(256) void filter_absmax_multi_kernel(const ladder_pack_job_t* __restrict__ jobs, float* __restrict__ partial) {
   const ladder_pack_job_t j = jobs[blockIdx.y];
-  const size_t n = (size_t)j.ntaps * j.Cin * j.Cout;            // Cin % 16 == 0: a multiple of 4; banks are 16-byte aligned views of the flat store
+  const size_t n = (size_t)j.ntaps * j.Cin * (j.transpose_flip == 2 ? j.Cout / 4 : j.Cout);   // Cin % 16 == 0: a multiple of 4; banks are 16-byte aligned views of the flat store
   float m = 0.f;
   if ((reinterpret_cast<uintptr_t>(j.w) & 15u) == 0) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (size_t)PK_PARTS * 256) {
@@ -237,7 +252,8 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
                                                                           const float* __restrict__ xamax,
                                                                           const float* __restrict__ wamax, float* __restrict__ yamax,
                                                                           const float* __restrict__ pw, const float* __restrict__ pb,
-                                                                          float* __restrict__ pout, const int pco) {
+                                                                          float* __restrict__ pout, const int pco,
+                                                                          const unsigned long long tap_masks, const int s2_out) {
   constexpr int NS = Fmt<PREC>::NS;
   constexpr bool F16 = Fmt<PREC>::F16;
   constexpr int A_BUF = NS * SP_A_PLANE, B_BUF = NS * SP_B_PLANE;
@@ -314,10 +330,13 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
     if (b_second) *reinterpret_cast<uint4*>(Bbase + buf * B_BUF + (tid + SP_THREADS) * 16) = rb1;
   };
 
+  // taps this output-channel tile uses (all 9 for a convolution; the parity classes of a stride-2 backward-data bank use 1, 2 or 4:
+  // ladder_conv3x3_s2_bwd_data_split) -- a masked tap costs its barrier, nothing else: no filter block staged, no fragment read, no MFMA
+  const unsigned tmask = (unsigned)(tap_masks >> (9 * cot)) & 0x1ffu;
   load_halo(0);
-  load_b(0, 0);
+  if (tmask & 1u) load_b(0, 0);
   store_halo(0);
-  store_b(0);
+  if (tmask & 1u) store_b(0);
   __syncthreads();
   int bbuf = 0;
   for (int slab = 0; slab < nslabs; ++slab) {
@@ -325,8 +344,10 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const bool last = (slab + 1 == nslabs) && (tap == 8);
-      if (!last) load_b(tap == 8 ? slab + 1 : slab, tap == 8 ? 0 : tap + 1);
+      const bool next_used = !last && ((tmask >> (tap == 8 ? 0 : tap + 1)) & 1u);
+      if (next_used) load_b(tap == 8 ? slab + 1 : slab, tap == 8 ? 0 : tap + 1);
       if (tap == 0 && slab + 1 < nslabs) load_halo(slab + 1);
+      if ((tmask >> tap) & 1u) {
       const int r = tap / 3, sft = tap - 3 * r;
       const unsigned char* Ab = Abase + hb * A_BUF + (lh * SP_NPIX + (2 * wm + r) * SP_PW + sft + l31) * 16;
       const unsigned char* Bb = Bbase + bbuf * B_BUF + (lh * SP_BN + wn * 64 + l31) * 16;
@@ -351,8 +372,9 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
               acc[mi][ni] = PROJ ? mfma16<F16>(b[ni][pb], a[mi][pa], acc[mi][ni])       // D^T: lane = pixel, registers = channels
                                  : mfma16<F16>(a[mi][pa], b[ni][pb], acc[mi][ni]);      // lane = channel, registers = pixels
         }
+      }
       if (tap == 4 && slab + 1 < nslabs) store_halo(hb ^ 1);
-      if (!last) store_b(bbuf ^ 1);
+      if (next_used) store_b(bbuf ^ 1);
       __syncthreads();
       bbuf ^= 1;
     }
@@ -379,14 +401,18 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
       const float bv = (bias != nullptr && n < Cout) ? bias[n] : 0.f;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        float* yp = y + (((long)img * H + h0 + 2 * wm + mi) * W + w0) * Cout + n;
+        // s2_out: this output-channel tile is one PARITY CLASS (ph, pw) = (cot >> 1, cot & 1) of a stride-2 backward-data result: pixel
+        // (h, w) of the class is dx[2h + ph, 2w + pw], channels = the tile's 128 (the 4 class tiles interleave into [N, 2H, 2W, 128])
+        float* yp = s2_out ? y + (((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_tile % tiles_n >> 1)) * 2 * W + 2 * w0 + (e_tile % tiles_n & 1)) * SP_BN + (n - n0)
+                           : y + (((long)img * H + h0 + 2 * wm + mi) * W + w0) * Cout + n;
+        const long pstride = s2_out ? 2 * SP_BN : Cout;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int px = (e & 3) + 8 * (e >> 2) + 4 * lh;
           float v = acc[mi][ni][e];
           if (F16) v *= unscale;
           v = ladder_act_fn(v + bv, act);
-          if (n < Cout) yp[(long)px * Cout] = v;
+          if (n < Cout) yp[(long)px * pstride] = v;
           ymax = fmaxf(ymax, n < Cout ? fabsf(v) : 0.f);
         }
       }
@@ -489,7 +515,8 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
                                                                           const float* __restrict__ xamax,
                                                                           const float* __restrict__ wamax, float* __restrict__ yamax,
                                                                           const float* __restrict__ pw, const float* __restrict__ pb,
-                                                                          float* __restrict__ pout, const int pco) {
+                                                                          float* __restrict__ pout, const int pco,
+                                                                          const unsigned long long tap_masks, const int s2_out) {
   constexpr int NS = Fmt<PREC>::NS;
   constexpr bool F16 = Fmt<PREC>::F16;
   static_assert(NS == 2, "two-plane formats only");
@@ -560,14 +587,17 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
   };
   auto load_b = [&](int slab, int r, int part) {                          // part 0: chunk tid, part 1: chunk 1024 + tid (first half only)
     const uint4* s = bsrc + (size_t)(3 * r * nslabs + slab) * tiles_n * B_CHUNKS;
-    if (part == 0) rb0 = s[0];
-    else if (b_second) rb0 = s[2 * tap_stride];
+    const unsigned tm = (unsigned)(tap_masks >> (9 * cot)) & 0x1ffu;
+    if (part == 0) { if ((tm >> (3 * r + (tid >> 9))) & 1u) rb0 = s[0]; }
+    else if (b_second && ((tm >> (3 * r + 2)) & 1u)) rb0 = s[2 * tap_stride];
   };
   auto store_b = [&](int buf, int part) {
     if (part == 0) *reinterpret_cast<uint4*>(Bbase + buf * B_STAGE + tid * 16) = rb0;
     else if (b_second) *reinterpret_cast<uint4*>(Bbase + buf * B_STAGE + (tid + F_THREADS) * 16) = rb0;
   };
 
+  // (see the 8-wave kernel: taps this output-channel tile uses; a thread's filter chunk of a stage belongs to tap 3r + (tid >> 9) resp. 3r + 2)
+  const unsigned tmask = (unsigned)(tap_masks >> (9 * cot)) & 0x1ffu;
 #pragma unroll
   for (int i = 0; i < F_AU; ++i) {
     load_halo(0, i);
@@ -589,6 +619,7 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
 #pragma unroll
       for (int sft = 0; sft < 3; ++sft) {
         if (!last && sft < 2) load_b(nslab, nr, sft);
+        if ((tmask >> (3 * r + sft)) & 1u) {
         const unsigned char* Ab = Abase + hb * A_BUF + (lh * F_NPIX + (2 * wm + r) * SP_PW + sft + l31) * 16;
         const unsigned char* Bb = Bbase + bbuf * B_STAGE + sft * B_BUF + (lh * SP_BN + wn * 64 + l31) * 16;
         uint4 a[2][NS], b[2][NS];
@@ -612,6 +643,7 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
                 acc[mi][ni] = PROJ ? mfma16<F16>(b[ni][pb], a[mi][pa], acc[mi][ni])     // D^T: lane = pixel, registers = channels
                                    : mfma16<F16>(a[mi][pa], b[ni][pb], acc[mi][ni]);    // lane = channel, registers = pixels
           }
+        }
         if (!last && sft < 2) store_b(bbuf ^ 1, sft);
       }
       if (slab + 1 < nslabs) store_halo(hb ^ 1, r);
@@ -641,14 +673,18 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
       const float bv = (bias != nullptr && n < Cout) ? bias[n] : 0.f;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        float* yp = y + (((long)img * H + h0 + 2 * wm + mi) * W + w0) * Cout + n;
+        // s2_out: this output-channel tile is one PARITY CLASS (ph, pw) = (cot >> 1, cot & 1) of a stride-2 backward-data result: pixel
+        // (h, w) of the class is dx[2h + ph, 2w + pw], channels = the tile's 128 (the 4 class tiles interleave into [N, 2H, 2W, 128])
+        float* yp = s2_out ? y + (((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_tile % tiles_n >> 1)) * 2 * W + 2 * w0 + (e_tile % tiles_n & 1)) * SP_BN + (n - n0)
+                           : y + (((long)img * H + h0 + 2 * wm + mi) * W + w0) * Cout + n;
+        const long pstride = s2_out ? 2 * SP_BN : Cout;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int px = (e & 3) + 8 * (e >> 2) + 4 * lh;
           float v = acc[mi][ni][e];
           if (F16) v *= unscale;
           v = ladder_act_fn(v + bv, act);
-          if (n < Cout) yp[(long)px * Cout] = v;
+          if (n < Cout) yp[(long)px * pstride] = v;
           ymax = fmaxf(ymax, n < Cout ? fabsf(v) : 0.f);
         }
       }
@@ -1066,7 +1102,7 @@ int ladder_filter_pack_split(const float* w, void* packed, int ntaps, int Cin, i
   const dim3 grid((total + 255) / 256), block(256);
   float* wamax = reinterpret_cast<float*>(static_cast<unsigned char*>(packed) + pack_payload_bytes(ntaps, Cin, Cout, prec));
   if (prec == LADDER_PREC_F16X3) {
-    const int rc = ladder_absmax(w, (size_t)ntaps * Cin * Cout, wamax, stream);
+    const int rc = ladder_absmax(w, (size_t)ntaps * Cin * (transpose_flip == 2 ? Cout / 4 : Cout), wamax, stream);
     if (rc != LADDER_OK) return rc;
     hipLaunchKernelGGL(filter_pack_kernel<LADDER_PREC_F16X3>, grid, block, 0, stream, w, (uint4*)packed, ntaps, Cin, Cout, transpose_flip, total, wamax);
   } else if (prec == LADDER_PREC_BF16X6) {
@@ -1103,7 +1139,7 @@ int ladder_conv3x3_split_eligible(int N, int H, int W, int Cin, int Cout) { retu
 
 static int conv3x3_split_launch(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, float* y_absmax,
                                 const float* pw, const float* pb, float* pout, int pco, int N, int H, int W, int Cin, int Cout, int act,
-                                int prec, ladder_stream_t stream) {
+                                int prec, ladder_stream_t stream, unsigned long long tap_masks = ~0ull, int s2_out = 0) {
   if (!split_halo_ok(N, H, W, Cin, Cout) || !prec_ok(prec)) return LADDER_E_SHAPE;
   if (pout != nullptr && (pw == nullptr || pco < 1 || pco > 4 || Cout > SP_BN || !ladder_aligned16(pw))) return LADDER_E_SHAPE;
   if (pout == nullptr && y == nullptr) return LADDER_E_SHAPE;
@@ -1117,11 +1153,11 @@ static int conv3x3_split_launch(const float* x, const float* x_absmax, const voi
   if (y_absmax != nullptr && hipMemsetAsync(y_absmax, 0, LADDER_ABSMAX_FLOATS * sizeof(float), stream) != hipSuccess) return LADDER_E_LAUNCH;
 #define LADDER_SPLIT_LAUNCH_(P_, PROJ_) \
   hipLaunchKernelGGL((conv3x3_halo_split_kernel<P_, PROJ_>), grid, block, 0, stream, x, (const uint4*)packed, bias, y, N, H, W, Cin, Cout, act, tiles_n, x_absmax, wamax, y_absmax, \
-                     pw, pb, pout, pco)
+                     pw, pb, pout, pco, tap_masks, s2_out)
 #define LADDER_SPLIT_LAUNCH(P_) do { if (pout != nullptr) LADDER_SPLIT_LAUNCH_(P_, true); else LADDER_SPLIT_LAUNCH_(P_, false); } while (0)
 #define LADDER_SPLIT16_LAUNCH(P_, PROJ_) \
   hipLaunchKernelGGL((conv3x3_halo_split16_kernel<P_, PROJ_>), dim3(N * (H / F_H) * (W / SP_W) * tiles_n), dim3(F_THREADS), 0, stream, x, (const uint4*)packed, bias, y, N, H, W, Cin, Cout, act, tiles_n, x_absmax, wamax, y_absmax, \
-                     pw, pb, pout, pco)
+                     pw, pb, pout, pco, tap_masks, s2_out)
   if (split_halo16_ok(N, H, W, Cin, Cout, prec)) {
     if (pout != nullptr) {
       if (prec == LADDER_PREC_F16X3) LADDER_SPLIT16_LAUNCH(LADDER_PREC_F16X3, true); else LADDER_SPLIT16_LAUNCH(LADDER_PREC_BF16X3, true);
@@ -1149,6 +1185,39 @@ int ladder_conv3x3_split_proj(const float* x, const float* x_absmax, const void*
   if (proj_out == nullptr) return LADDER_E_SHAPE;
   return conv3x3_split_launch(x, x_absmax, packed, bias, y, nullptr, proj_w, proj_b, proj_out, proj_cout, N, H, W, Cin, Cout, act, prec,
                               stream);
+}
+
+// ---- backward-data of a 3x3 / stride-2 / SAME convolution (even maps: pad_t = pad_l = 0) as ONE launch of the halo kernel ---------------
+// dx[h, w] = sum over (r, s) with h - r, w - s even of dy[(h - r) / 2, (w - s) / 2] . w[r, s]^T splits into the four output-parity classes
+// (h % 2, w % 2), each a 3x3 / stride-1 correlation over dy that uses 4 / 2 / 2 / 1 of the nine taps.  The four classes are the four
+// 128-channel OUTPUT TILES of one halo-kernel launch over dy (filter bank [9][Cout][4 * 128], ladder_filter_pack_split with
+// transpose_flip = 2); a tile issues only its class's taps (tap mask) and its epilogue writes to the interleaved pixels of dx.  The
+// gather kernel ran the classes as four launches with K = 128 ... 512 each -- 345 us on enc.conv1 at batch 128 (1.43 GB moved at
+// 4.1 TB/s: bandwidth-bound on re-reading dy and the filter per tap); here dy is staged once per slab for all taps of a class.
+static unsigned long long s2_tap_masks() {
+  unsigned long long m = 0;
+  for (int cls = 0; cls < 4; ++cls) {
+    const int ph = cls >> 1, pw = cls & 1;
+    unsigned t = 0;
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b)
+        if ((a == 1 || (a == 0 && ph == 0)) && (b == 1 || (b == 0 && pw == 0))) t |= 1u << (a * 3 + b);
+    m |= (unsigned long long)t << (9 * cls);
+  }
+  return m;
+}
+
+int ladder_conv3x3_s2_bwd_data_split_eligible(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t,
+                                              int pad_l) {
+  return (KH == 3 && KW == 3 && stride == 2 && pad_t == 0 && pad_l == 0 && H == 2 * Ho && W == 2 * Wo && Cin == SP_BN &&
+          split_halo_ok(N, Ho, Wo, Cout, 4 * SP_BN)) ? 1 : 0;
+}
+
+int ladder_conv3x3_s2_bwd_data_split(const float* dy, const float* dy_absmax, const void* packed_s2, float* dx, float* dx_absmax, int N, int H,
+                                     int W, int Cin, int Ho, int Wo, int Cout, int prec, ladder_stream_t stream) {
+  if (!ladder_conv3x3_s2_bwd_data_split_eligible(N, H, W, Cin, Ho, Wo, Cout, 3, 3, 2, 0, 0)) return LADDER_E_SHAPE;
+  return conv3x3_split_launch(dy, dy_absmax, packed_s2, nullptr, dx, dx_absmax, nullptr, nullptr, nullptr, 0, N, Ho, Wo, Cout, 4 * SP_BN,
+                              LADDER_ACT_NONE, prec, stream, s2_tap_masks(), 1);
 }
 
 // (two-plane formats only: the double-buffered 2x32-pixel patch images of a three-plane format exceed the 160 KB of LDS)

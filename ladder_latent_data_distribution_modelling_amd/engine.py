@@ -467,6 +467,8 @@ class Conv2D:
         hipGraph is being captured, so that a replay re-packs the then-current weights)."""
         ns, ps = self.ctx.ns, self.ps
         cin, cout = (self.cout, self.cin) if transpose_flip else (self.cin, self.cout)
+        if transpose_flip == 2:                       # the four parity classes of a stride-2 backward-data as output-channel blocks
+            cout = 4 * self.cin
         ent = self._packed.get((transpose_flip, ns))
         if ent is None:
             nb = L.query("ladder_filter_pack_split_bytes", self.k * self.k, cin, cout, ns)
@@ -657,6 +659,17 @@ class Conv2D:
                     self.ctx.ns, st)
             self.ctx.set_amax(dx, dx_amax)
             _timed(256120 + self.ctx.ns, 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_split", args)
+        elif (need_dx and self.ctx.ns == 4 and not gate_prev and self.stride == 2
+              and L.query("ladder_conv3x3_s2_bwd_data_split_eligible", N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride,
+                          self.pt, self.pl)):
+            # 3x3 / stride 2 over a map whose gradient is halo-kernel sized (enc.conv1): the four output-parity classes in ONE launch
+            if dy_amax is None:
+                dy_amax = self.ctx.absmax(dy)
+            dx = self.ctx.empty(N, H, W, self.cin)
+            dx_amax = self.ctx.new_amax()
+            args = (_p(dy), _p(dy_amax), _p(self._packed_filter(2)), _p(dx), _p(dx_amax), N, H, W, self.cin, Ho, Wo, self.cout, self.ctx.ns, st)
+            self.ctx.set_amax(dx, dx_amax)
+            _timed(256120 + self.ctx.ns, 2.0 * N * Ho * Wo * 9 * self.cin * self.cout, "ladder_conv3x3_s2_bwd_data_split", args)
         elif need_dx and self.ctx.ns and L.query("ladder_conv2d_bwd_data_split_eligible", N, H, W, self.cin, Ho, Wo, self.cout, self.k,
                                                  self.k, self.stride, self.pt, self.pl, 1 if gate_prev else 0):
             geo = (N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl)

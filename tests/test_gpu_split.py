@@ -816,3 +816,50 @@ def test_absmax_samples_record(gpu_ctx):
         for n in range(N):
             shared = [m for m in range(N) if (m & 15) == (n & 15) and ((m >> 4) % 30) == ((n >> 4) % 30)]
             assert rec_sample(rec, n) == float(sm[shared].max()), (N, n)
+
+
+@pytest.mark.parametrize("kind", ["normal", "samples"])
+@pytest.mark.parametrize("geom", [(32, 64, 64, 128, 128), (64, 128, 64, 128, 256)], ids=["8wave", "16wave"])
+def test_conv3x3_stride2_bwd_data_as_one_halo_launch(gpu_ctx, geom, kind):
+    """Backward-data of a 3x3 / stride-2 / SAME convolution (the encoder layers, codes/models.py:398-460) as ONE launch of the halo kernel
+    over dy: the four output-parity classes are four output-channel tiles with tap masks (4 / 2 / 2 / 1 taps) and an interleaving
+    epilogue (ladder_conv3x3_s2_bwd_data_split; filter bank packed with transpose_flip = 2).  Against the float64 oracle: tensor-scale
+    bound of the other split kernels AND the per-output bound, on plain and on sample-disparity operands; the dx record is per sample."""
+    L = _lib()
+    from ladder_latent_data_distribution_modelling_amd import arch
+    N, H, W, Cin, Cout = geom
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(17)
+    pt, Ho = arch.conv_out(H, 3, 2, "same")
+    pl, Wo = arch.conv_out(W, 3, 2, "same")
+    assert (pt, pl) == (0, 0) and L.query("ladder_conv3x3_s2_bwd_data_split_eligible", N, H, W, Cin, Ho, Wo, Cout, 3, 3, 2, pt, pl) == 1
+    assert L.query("ladder_conv3x3_s2_bwd_data_split_eligible", N, H, W, 64, Ho, Wo, Cout, 3, 3, 2, pt, pl) == 0       # Cin != 128
+    assert L.query("ladder_conv3x3_s2_bwd_data_split_eligible", N, 32, 32, Cin, 16, 16, Cout, 3, 3, 2, 0, 0) == 0       # dy map 16 wide
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    dy = _disparity_fill(rng, (N, Ho, Wo, Cout), kind) if kind != "normal" else rng.standard_normal((N, Ho, Wo, Cout)).astype(np.float32)
+    xt = torch.zeros(N, H, W, Cin, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64)
+    dyt = torch.tensor(dy, dtype=torch.float64)
+    O.conv2d_tf(xt, wt, None, 2, "same").backward(dyt)
+    xm = torch.zeros(N, H, W, Cin, dtype=torch.float64, requires_grad=True)
+    O.conv2d_tf(xm, wt.abs(), None, 2, "same").backward(dyt.abs())
+    wd, dyd = dev(w), dev(dy)
+    pk = torch.empty(L.query("ladder_filter_pack_split_bytes", 9, Cout, 4 * Cin, 4), dtype=torch.uint8, device="cuda")
+    L.call("ladder_filter_pack_split", p(wd), p(pk), 9, Cout, 4 * Cin, 2, 4, st)
+    dx, rec = torch.empty(N, H, W, Cin, device="cuda"), torch.empty(L.ABSMAX_FLOATS, device="cuda")
+    L.call("ladder_conv3x3_s2_bwd_data_split", p(dyd), p(absmax_samples(L, dyd, st)), p(pk), p(dx), p(rec), N, H, W, Cin, Ho, Wo, Cout, 4, st)
+    close(dx, xt.grad, TOL["f16x3"][1], "dx")
+    e, _ = _per_output_err(dx, xt.grad.numpy(), xm.grad.numpy())
+    print("stride-2 backward-data in one halo launch %s %s: per-output %.2e" % (geom, kind, e))
+    assert e < PER_OUTPUT_TOL, e
+    assert recmax(rec) == dx.abs().max().item() and all(rec_sample(rec, n) == dx[n].abs().max().item() for n in (0, N // 2, N - 1))
+    # the gather path (four parity-class launches) agrees to rounding
+    geo = (N, H, W, Cin, Ho, Wo, Cout, 3, 3, 2, pt, pl)
+    if L.query("ladder_conv2d_bwd_data_split_eligible", *geo, 0):
+        pkT = torch.empty(L.query("ladder_filter_pack_split_bytes", 9, Cout, Cin, 4), dtype=torch.uint8, device="cuda")
+        L.call("ladder_filter_pack_split", p(wd), p(pkT), 9, Cout, Cin, 1, 4, st)
+        da = absmax_samples(L, dyd, st)
+        wsp, wsn = gpu_ctx.ws(max(L.query("ladder_conv2d_bwd_data_split_workspace_bytes", *geo), 16))
+        dx2 = torch.empty_like(dx)
+        L.call("ladder_conv2d_bwd_data_split", p(presplit(L, dyd, da, 4, st, n_samples=N)), p(da), p(pkT), p(dx2), *geo, None, 0, 4, wsp, wsn, st)
+        close(dx2, xt.grad, TOL["f16x3"][1], "dx (gather)")
