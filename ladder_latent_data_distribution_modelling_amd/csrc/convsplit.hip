@@ -1209,7 +1209,8 @@ static unsigned long long s2_tap_masks() {
 
 int ladder_conv3x3_s2_bwd_data_split_eligible(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t,
                                               int pad_l) {
-  return (KH == 3 && KW == 3 && stride == 2 && pad_t == 0 && pad_l == 0 && H == 2 * Ho && W == 2 * Wo && Cin == SP_BN &&
+  static const bool off = getenv("LADDER_DISABLE_S2HALO") != nullptr;          // (test-only switch, see include/ladder_hip.h)
+  return (!off && KH == 3 && KW == 3 && stride == 2 && pad_t == 0 && pad_l == 0 && H == 2 * Ho && W == 2 * Wo && Cin == SP_BN &&
           split_halo_ok(N, Ho, Wo, Cout, 4 * SP_BN)) ? 1 : 0;
 }
 
