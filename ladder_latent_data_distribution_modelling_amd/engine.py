@@ -61,7 +61,7 @@ class KernelProfiler:
 
 # config key `matmul_precision`: how the large 3x3 convolutions are contracted (csrc/convsplit.hip; values = LADDER_PREC_*).
 #   "f32"     v_mfma_f32_32x32x2_f32: bit-exact fp32 FMA chains at the fp32 vector rate
-#   "f16x3"   fp32 operands scaled per tensor by a power of two (from their absolute maximum) and split into 2 fp16 planes (22 bits),
+#   "f16x3"   fp32 operands scaled by a power of two (from the absolute maximum of their sample, or tensor) and split into 2 fp16 planes (22 bits),
 #             3 plane products on the fp16 matrix cores, fp32 accumulate: fp32-class error (measured: below the f32 FMA chain's)
 #   "bf16x6"  3 bf16 planes (24 bits), 6 plane products, no scaling: fp32-class error
 #   "bf16x3"  2 bf16 planes (16 bits), 3 products (error ~1e-5 relative per product: between TF32 and fp32)
@@ -70,8 +70,8 @@ DEFAULT_PRECISION = "f16x3"
 
 PRECISION_NOTES = {
     "f32": "native fp32 MFMA (v_mfma_f32_32x32x2_f32), bit-exact fp32 FMA chains",
-    "f16x3": "fp32-class EMULATION: fp32 operands as 2 scaled fp16 planes (22 significand bits, one power-of-two scale per tensor, "
-             "see DESIGN 4a), 3 fp16 MFMAs per product, fp32 accumulation; set \"matmul_precision\": \"f32\" for strict fp32",
+    "f16x3": "fp32-class EMULATION: fp32 operands as 2 scaled fp16 planes (22 significand bits, power-of-two scales per sample / "
+             "per tensor, see DESIGN 4a), 3 fp16 MFMAs per product, fp32 accumulation; set \"matmul_precision\": \"f32\" for strict fp32",
     "bf16x6": "fp32-class EMULATION: 3 bf16 planes (24 bits), 6 bf16 MFMAs per product, fp32 accumulation",
     "bf16x3": "REDUCED precision: 2 bf16 planes (16 bits), 3 bf16 MFMAs per product (between TF32 and fp32)"}
 

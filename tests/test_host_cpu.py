@@ -298,3 +298,32 @@ def test_resize_transpose_absmax_bound(h, oh):
     assert abs(float(x.grad.max()) - g * g) < 1e-9, (float(x.grad.max()), g)
     if oh == 2 * h and h > 1:
         assert g == 2.5
+
+
+def test_bench_refuses_a_gpu_count_it_cannot_honour():
+    """`python bench.py --gpus N` must never print an N-GPU line from fewer ranks.  Without a launcher it spawns the
+    ranks itself -- and refuses (exit 2, no JSON) when fewer than N GPUs are visible; under a launcher whose WORLD_SIZE disagrees with
+    --gpus it refuses as well.  (No GPU needed: both checks happen before any device is touched.)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LADDER_BENCH_SINGLE_DEVICE")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and "refusing" in p.stderr and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and "refusing" in p.stderr and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_workload_labels_and_default_graph_registry():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    cel = dict(exp_name="celeba", representation_size=2, n_mixtures=30)
+    assert bench.workload_index(cel, 1) == "2" and bench.workload_index(cel, 8) == "3" and "per-GPU leg" in bench.workload_index(cel, 2)
+    assert bench.workload_index(dict(cel, representation_size=8, n_mixtures=50), 8) == "4"
+    assert bench.workload_index(dict(exp_name="mnist_fashion"), 1) == "1"
+    assert abs(bench.FLOP_PER_IMG["celeba"]["executed"] - 40.172e9) < 1e6 and bench.FLOP_PER_IMG["celeba"]["algorithmic"] == 41.4e9
+    # codes.utils.count_trainable_variables(scope_name): the reference's single-argument form on the default "graph"
+    from codes.utils import count_trainable_variables, register_trainable_scope
+    register_trainable_scope("interpolation", 10)
+    assert count_trainable_variables("interpolation") == 10
+    with pytest.raises(TypeError):
+        count_trainable_variables(object(), "encoder")
