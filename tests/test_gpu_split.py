@@ -288,7 +288,8 @@ def test_split_abi_errors(gpu_ctx):
     assert lib.ladder_conv3x3_split(p(x), p(am), p(pk), None, p(y), None, 32, 60, 64, 32, 128, 0, 4, st) == -1      # H % 8
     assert lib.ladder_conv3x3_split(p(x), None, p(pk), None, p(y), None, 32, 64, 64, 32, 128, 0, 4, st) == -1       # f16x3 needs the scale
     assert lib.ladder_conv3x3_split(p(x) + 4, p(am), p(pk), None, p(y), None, 32, 64, 64, 32, 128, 0, 4, st) == -2   # alignment
-    assert lib.ladder_conv3x3_split(p(x), None, p(pk), None, p(y), None, 32, 64, 64, 32, 128, 0, 3, st) == 0        # bf16 needs none
+    pk3 = torch.zeros(L.query("ladder_filter_pack_split_bytes", 9, 32, 128, 3), dtype=torch.uint8, device="cuda")    # (a 3-plane image: the
+    assert lib.ladder_conv3x3_split(p(x), None, p(pk3), None, p(y), None, 32, 64, 64, 32, 128, 0, 3, st) == 0       # 2-plane buffer above is too small) bf16 needs none
     assert L.query("ladder_conv3x3_wgrad_split_eligible", 32, 64, 64, 64, 128, 3) == 0          # three planes do not fit LDS
     assert L.query("ladder_conv3x3_wgrad_split_eligible", 32, 64, 64, 64, 128, 4) == 1
     assert L.query("ladder_conv3x3_wgrad_split_eligible", 32, 63, 64, 64, 128, 4) == 0          # H % 2
