@@ -56,8 +56,7 @@ def _gm(cfg):
     return dict(weights=rng.dirichlet(np.ones(K)), means=rng.normal(0, 1.5, (K, R)), covs=A @ A.transpose(0, 2, 1) / R + 0.05 * np.eye(R))
 
 
-@pytest.mark.parametrize("prec", ["f16x3", "f32"])
-def test_celeba_r8k50_fullres_vs_live_oracle(prec):
+def test_celeba_r8k50_fullres_vs_live_oracle():
     """configs[4]'s network (codes/celeba_r8k50_config.json) at batch 8 against the float64 oracle on the same inputs and noise:
     RUN#1 fetches to 2e-5 (bar 1e-3 on the ELBO), RUN#3 fetches to 5e-5, every gradient tensor of both groups to
     max(1.5e-3 of its scale, 5x the deviation of the oracle evaluated in fp32)."""
@@ -65,32 +64,34 @@ def test_celeba_r8k50_fullres_vs_live_oracle(prec):
     cfg = _cfg("celeba_r8k50_config.json")
     assert cfg["representation_size"] == 8 and cfg["n_mixtures"] == 50 and cfg["num_hidden_units"] == 512 and cfg["code_size"] == 64
     cfg["batch_size"] = B = 8
-    cfg["matmul_precision"] = prec
     rng = np.random.default_rng(23)
     x = rng.random((B, 128, 128, 3)).astype(np.float32)
     P = O.init_params(cfg, seed=7)
     gm = {k: np.asarray(v, np.float32) for k, v in _gm(cfg).items()}
     noise = O.make_noise(cfg, B, rng, np.float32)
-    eng = LadderEngine(cfg, "cuda:0", values=P, seed=1)
-    eng.set_mixture(gm["weights"], gm["means"], gm["covs"])
-    for group, runner, names, tol in (("ae", eng.run_ae, SCALARS_RUN1, 2e-5), ("prior", eng.run_prior, SCALARS_RUN3, 5e-5)):
+    engs = {}
+    for prec in ("f16x3", "f32"):                      # (both precisions against ONE evaluation of the oracle)
+        engs[prec] = LadderEngine(dict(cfg, matmul_precision=prec), "cuda:0", values=P, seed=1)
+        engs[prec].set_mixture(gm["weights"], gm["means"], gm["covs"])
+    for group, names, tol in (("ae", SCALARS_RUN1, 2e-5), ("prior", SCALARS_RUN3, 5e-5)):
         ref = O.run(O.OracleState(cfg, P, np.float64), x, noise, gm, False, False, train=group, lr=0.0)
         ref32 = O.run(O.OracleState(cfg, P, np.float32), x, noise, gm, False, False, train=group, lr=0.0)
-        runner(x, 0.0, noise, False, False)
-        f = eng.fetch()
-        for k in names:
-            assert _ok(f[k], float(ref[k]), tol), (group, k, f[k], float(ref[k]))
-        worst = 0.0
-        for name, g in ref["_grads"].items():
-            got = eng.ps.g[name].cpu().numpy().reshape(g.shape).astype(np.float64)
-            scale = np.abs(g).max()
-            if scale < 1e-9:
-                continue
-            cond = np.abs(ref32["_grads"][name].astype(np.float64) - g).max()
-            err = np.abs(got - g).max()
-            worst = max(worst, err / max(1.5e-3 * scale, 5 * cond))
-            assert err < max(1.5e-3 * scale, 5 * cond), (prec, group, name, err, scale, cond)
-        print("r8k50 %s %s: worst gradient error / bound = %.3f" % (prec, group, worst))
+        for prec, eng in engs.items():
+            (eng.run_ae if group == "ae" else eng.run_prior)(x, 0.0, noise, False, False)
+            f = eng.fetch()
+            for k in names:
+                assert _ok(f[k], float(ref[k]), tol), (prec, group, k, f[k], float(ref[k]))
+            worst = 0.0
+            for name, g in ref["_grads"].items():
+                got = eng.ps.g[name].cpu().numpy().reshape(g.shape).astype(np.float64)
+                scale = np.abs(g).max()
+                if scale < 1e-9:
+                    continue
+                cond = np.abs(ref32["_grads"][name].astype(np.float64) - g).max()
+                err = np.abs(got - g).max()
+                worst = max(worst, err / max(1.5e-3 * scale, 5 * cond))
+                assert err < max(1.5e-3 * scale, 5 * cond), (prec, group, name, err, scale, cond)
+            print("r8k50 %s %s: worst gradient error / bound = %.3f" % (prec, group, worst))
 
 
 STEP_WORKER = r'''
