@@ -66,6 +66,25 @@ class BaseTrain:
         remain = (self.current_time - self.start_time) / (cur_epoch + 1) * total_epoch / 60 - elapsed
         print("Remaining {} min.\n".format(remain))
 
+    def draw_ellipse(self, position, covariance, weight, ax=None, color="r"):
+        """The 2-sigma outline of one mixture component on a matplotlib axes (reference codes/base.py:825-841, used by the notebook's
+        prior plots): a full 2x2 covariance gives the principal axes (SVD) and their angle, a length-2 diagonal an axis-aligned
+        ellipse; line width = 10 x the component weight.  Returns the patch."""
+        import matplotlib.pyplot as plt
+        from matplotlib.patches import Ellipse
+        ax = ax or plt.gca()
+        covariance = np.asarray(covariance, dtype=np.float64)
+        if covariance.shape == (2, 2):
+            U, s, _ = np.linalg.svd(covariance)
+            angle = float(np.degrees(np.arctan2(U[1, 0], U[0, 0])))
+            width, height = 2.0 * np.sqrt(s)
+        else:
+            angle = 0.0
+            width, height = 2.0 * np.sqrt(covariance)
+        nsig = 2
+        return ax.add_patch(Ellipse(tuple(np.asarray(position, dtype=np.float64)), nsig * float(width), nsig * float(height), angle=angle,
+                                    color=color, fill=False, lw=float(weight) * 10))
+
     # ------------------------------------------------------------------ regime / feed (base.py:862-899)
     def compute_feeddict(self, batch_data=None, model_to_train=None):
         """Selects the feed regime: SG pre-training (dummy N(0,I) mixture, use_standard_gaussian_prior=True)
