@@ -101,6 +101,7 @@ PROTOTYPES = {
     "ladder_vbgmm_workspace_bytes": (_z, [_i, _i]),
     "ladder_vbgmm_fit": (_i, [_p, _i, _i, _i, _p, _p, _i, _d, _d, _d, _d, _i, _p, _p, _p, _p, _z, _p]),
     "ladder_vbgmm_shard_stats_doubles": (_z, [_i, _i]),
+    "ladder_vbgmm_shard_workspace_bytes": (_z, [_i, _i, _i]),
     "ladder_vbgmm_shard_moments_doubles": (_z, [_i]),
     "ladder_vbgmm_shard_moments": (_i, [_p, _i, _i, _p, _p]),
     "ladder_vbgmm_shard_estep": (_i, [_p, _i, _i, _i, _p, _p, _i, _p, _p, _z, _p]),

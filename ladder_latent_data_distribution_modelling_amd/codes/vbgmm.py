@@ -16,6 +16,24 @@ import torch
 from .. import _lib as L
 
 
+class _OneRank:
+    """The communicator of a single-process fit: every exchange is the identity."""
+    on, rank, world = False, 0, 1
+
+    @staticmethod
+    def allreduce_(t):
+        return t
+
+    @staticmethod
+    def broadcast_(t, src):
+        return t
+
+
+# from this many samples on, fit() runs one E-step launch over 256-sample slices (one workgroup each) + one M-step launch per variational
+# iteration instead of the single persistent workgroup: 3.8 ms -> ~30 us per iteration at the 20 096 samples of the accurate fit
+SLICED_FIT_MIN_SAMPLES = 1024
+
+
 class DeviceBayesianGaussianMixture:
     def __init__(self, n_components=1, covariance_type="full", tol=1e-3, reg_covar=1e-6, max_iter=100, n_init=1,
                  init_params="kmeans", weight_concentration_prior_type="dirichlet_process", weight_concentration_prior=None,
@@ -47,6 +65,8 @@ class DeviceBayesianGaussianMixture:
         N, R = Xd.shape
         if N < K:
             raise ValueError("Expected n_samples >= n_components but got n_components = %d, n_samples = %d" % (K, N))
+        if N >= SLICED_FIT_MIN_SAMPLES:
+            return self.fit_sharded(Xd, _OneRank(), check_every=16)
         wc = 1.0 / K if self.weight_concentration_prior is None else float(self.weight_concentration_prior)
         mp = 1.0 if self.mean_precision_prior is None else float(self.mean_precision_prior)
         ptype = 0 if self.weight_concentration_prior_type == "dirichlet_distribution" else 1
@@ -105,7 +125,7 @@ class DeviceBayesianGaussianMixture:
         L.call("ladder_vbgmm_shard_moments", Xd.data_ptr(), Nl, R, mom.data_ptr(), st)
         comm.allreduce_(mom)
         stats = f64(L.query("ladder_vbgmm_shard_stats_doubles", K, R))
-        ws = torch.empty(L.query("ladder_vbgmm_workspace_bytes", Nl, K), dtype=torch.uint8, device=self.device)
+        ws = torch.empty(L.query("ladder_vbgmm_shard_workspace_bytes", Nl, K, R), dtype=torch.uint8, device=self.device)
         do_init = not (self.warm_start and self._state is not None and hasattr(self, "converged_"))
         rs = check_random_state(self.random_state)
         best = None
@@ -129,20 +149,31 @@ class DeviceBayesianGaussianMixture:
                 if comm.rank == 0:
                     lab.copy_(torch.as_tensor(self._kmeans_labels(allx.cpu().numpy().astype(np.float64), rs)))
                 comm.broadcast_(lab, 0)
+                if self._label_broadcast is not None and not comm.on:          # replicated fits of a data-parallel job: rank 0's labels
+                    self._label_broadcast(lab)
                 labels = lab[off:off + Nl].contiguous()
             w, m, c = (torch.empty(K, device=self.device), torch.empty(K, R, device=self.device), torch.empty(K, R, R, device=self.device))
             it, done = (0 if do_init else 1), False
+            # (the argument lists are constant over the iterations but for `labels` / `it`: bound once, the loop is two foreign calls)
+            lib = L.load()
+            estep, mstep = lib.ladder_vbgmm_shard_estep, lib.ladder_vbgmm_shard_mstep
+            e_tail = (state.data_ptr(), ptype, stats.data_ptr(), ws.data_ptr(), ws.numel(), st)
+            m_head = (stats.data_ptr(), mom.data_ptr(), K, R, state.data_ptr(), ptype, wc, mp, float(self.reg_covar), float(self.tol), self.max_iter)
+            m_tail = (w.data_ptr(), m.data_ptr(), c.data_ptr(), st)
+            xp, exchange = Xd.data_ptr(), (comm.allreduce_ if comm.on else None)
+            flag = state[-1:]
             while not done:
                 for _i in range(check_every):
-                    L.call("ladder_vbgmm_shard_estep", Xd.data_ptr(), Nl, K, R, labels.data_ptr() if (labels is not None and it == 0) else None,
-                           state.data_ptr(), ptype, stats.data_ptr(), ws.data_ptr(), ws.numel(), st)
-                    comm.allreduce_(stats)
-                    L.call("ladder_vbgmm_shard_mstep", stats.data_ptr(), mom.data_ptr(), K, R, state.data_ptr(), ptype, wc, mp,
-                           float(self.reg_covar), float(self.tol), self.max_iter, it, w.data_ptr(), m.data_ptr(), c.data_ptr(), st)
+                    rc = estep(xp, Nl, K, R, labels.data_ptr() if (labels is not None and it == 0) else None, *e_tail)
+                    if exchange is not None:
+                        exchange(stats)
+                    rc = rc or mstep(*m_head, it, *m_tail)
+                    if rc != 0:
+                        raise L.LadderHipError("sharded mixture fit failed: %s (%d)" % (L.ERRORS.get(rc, "?"), rc))
                     it += 1
                     if it > self.max_iter:
                         break
-                done = bool(state[-1].item() != 0) or it > self.max_iter     # (identical on every rank: same all-reduced statistics)
+                done = bool(flag.item() != 0) or it > self.max_iter          # (identical on every rank: same all-reduced statistics)
             tail = state[-4:-1].cpu().numpy()
             if tail[2] < 0:
                 raise ValueError("Fitting the mixture model failed because some components have ill-defined empirical covariance "

@@ -339,12 +339,21 @@ __global__ __launch_bounds__(VB_THREADS) void vbgmm_moments_kernel(const float* 
   }
 }
 
+// One workgroup = one SLICE of `per` local samples (the statistics are additive over samples: the slices of a rank are reduced in a fixed
+// order by vbgmm_stats_reduce_kernel exactly as the ranks are by the all-reduce) -- the accurate per-epoch fit runs on 20 096 samples,
+// which one workgroup walks in 3.8 ms per iteration and 79 workgroups in microseconds.
 __global__ __launch_bounds__(VB_THREADS) void vbgmm_shard_estep_kernel(const float* __restrict__ X, const int* __restrict__ labels,
                                                                        const double* __restrict__ state, VbCfg c,
-                                                                       double* __restrict__ resp, double* __restrict__ stats) {
-  const int N = c.N, K = c.K, R = c.R, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                                                       double* __restrict__ resp, double* __restrict__ stats,
+                                                                       const int per, const size_t stats_stride) {
+  const int K = c.K, R = c.R, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   VbState S(const_cast<double*>(state), K, R);
   if (S.tail[3] != 0.0) return;                                  // the fit is over: later (speculatively enqueued) iterations are no-ops
+  const int n_first = blockIdx.x * per, N = min(per, c.N - n_first);
+  X += (size_t)n_first * R;
+  if (labels != nullptr) labels += n_first;
+  resp += (size_t)n_first * K;
+  stats += (size_t)blockIdx.x * stats_stride;
   __shared__ double s_ck[VB_MAXK], s_mu[VB_MAXK * VB_MAXR], s_pc[VB_MAXK * VB_MAXR * VB_MAXR], s_red[VB_WAVES], s_scal[1];
   double entropy = 0.0;
   if (c.init_from_labels) {
@@ -442,6 +451,17 @@ __global__ __launch_bounds__(VB_THREADS) void vbgmm_shard_estep_kernel(const flo
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void vbgmm_stats_reduce_kernel(const double* __restrict__ partial, const double* __restrict__ state,
+                                                                 int K, int R, int G, int n, double* __restrict__ stats) {
+  VbState S(const_cast<double*>(state), K, R);
+  if (S.tail[3] != 0.0) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double a = 0.0;
+  for (int g = 0; g < G; ++g) a += partial[(size_t)g * n + i];       // fixed order: slice 0, 1, ...
+  stats[i] = a;
 }
 
 __global__ __launch_bounds__(256) void vbgmm_shard_mstep_kernel(const double* __restrict__ stats, const double* __restrict__ moments,
@@ -615,12 +635,29 @@ int ladder_vbgmm_shard_moments(const float* X, int N, int R, double* moments, la
   return LADDER_OK;
 }
 
+// local samples per workgroup of the sharded E-step (a slice); its statistics loop is wave-per-statistic over the slice
+static constexpr int VB_SLICE = 256;
+static int vb_slices(int N) { return (N + VB_SLICE - 1) / VB_SLICE; }
+
+size_t ladder_vbgmm_shard_workspace_bytes(int N, int K, int R) {
+  if (N < 1 || K < 1 || R < 1) return 0;
+  return ((size_t)N * K + (size_t)vb_slices(N) * ladder_vbgmm_shard_stats_doubles(K, R)) * sizeof(double);   // responsibilities + per-slice statistics
+}
+
 int ladder_vbgmm_shard_estep(const float* X, int N, int K, int R, const int* labels, const double* state, int prior_type, double* stats,
                              void* ws, size_t ws_bytes, ladder_stream_t stream) {
   if (N < 1 || K < 1 || K > VB_MAXK || R < 1 || R > VB_MAXR || (prior_type != 0 && prior_type != 1)) return LADDER_E_SHAPE;
-  if (ws == nullptr || ws_bytes < ladder_vbgmm_workspace_bytes(N, K)) return LADDER_E_WORKSPACE;
+  if (ws == nullptr || ws_bytes < ladder_vbgmm_shard_workspace_bytes(N, K, R)) return LADDER_E_WORKSPACE;
   VbCfg c{N, K, R, prior_type, 0, labels != nullptr ? 1 : 0, 0.0, 0.0, 0.0, 0.0};
-  hipLaunchKernelGGL(vbgmm_shard_estep_kernel, dim3(1), dim3(VB_THREADS), 0, stream, X, labels, state, c, (double*)ws, stats);
+  const int G = vb_slices(N), n = (int)ladder_vbgmm_shard_stats_doubles(K, R);
+  double* resp = (double*)ws;
+  double* partial = resp + (size_t)N * K;
+  if (G == 1) {
+    hipLaunchKernelGGL(vbgmm_shard_estep_kernel, dim3(1), dim3(VB_THREADS), 0, stream, X, labels, state, c, resp, stats, VB_SLICE, (size_t)0);
+  } else {
+    hipLaunchKernelGGL(vbgmm_shard_estep_kernel, dim3(G), dim3(VB_THREADS), 0, stream, X, labels, state, c, resp, partial, VB_SLICE, (size_t)n);
+    hipLaunchKernelGGL(vbgmm_stats_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const double*)partial, state, K, R, G, n, stats);
+  }
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
