@@ -174,6 +174,14 @@ int ladder_conv3x3_s2_bwd_data_split_eligible(int N, int H, int W, int Cin, int 
 int ladder_conv3x3_s2_bwd_data_split(const float* dy, const float* dy_absmax, const void* packed_s2, float* dx, float* dx_absmax, int N, int H,
                                      int W, int Cin, int Ho, int Wo, int Cout, int prec, ladder_stream_t stream);
 
+/* A 3x3 / SAME convolution of the factor-2 legacy-bilinear upsample of x [N, H, W, Cin] -> y [N, 2H, 2W, 128], without the upsampled tensor
+ * (replaces tf.image.resize_images(x, [2H, 2W]) + tf.layers.conv2d of the decoder, codes/models.py:554-578, in one launch; see csrc/convsplit.hip).
+ * packed_up2 = ladder_filter_pack_split(w, ., 9, Cin, 4 * 128, transpose_flip = 3, prec) from the layer's HWIO bank; bias [128]; the absmax
+ * record of x as for ladder_conv3x3_split.  The last output row and column are NOT final after this call: ladder_conv3x3_up2_edges. */
+int ladder_conv3x3_up2_split_eligible(int N, int H, int W, int Cin, int Cout, int prec);
+int ladder_conv3x3_up2_split(const float* x, const float* x_absmax, const void* packed_up2, const float* bias, float* y, float* y_absmax,
+                             int N, int H, int W, int Cin, int Cout, int act, int prec, ladder_stream_t stream);
+
 /* planes[p][i] = 16-bit plane p of x[i] (scaled by a power of two derived from x_absmax for LADDER_PREC_F16X3), plane-major,
  * n % 8 == 0, followed by 16 zero bytes (the source of out-of-image taps) and a 16-byte header; ladder_presplit_bytes = planes * n * 2 + 32.
  * n_samples > 0 (x is [n_samples, ...], (n / n_samples) % 8 == 0) AND a per-sample record (ladder_absmax_samples, or a producer that

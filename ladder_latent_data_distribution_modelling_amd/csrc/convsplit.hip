@@ -153,6 +153,22 @@ __device__ __forceinline__ void filter_pack_element(const float* __restrict__ w,
           const int r = a == 1 ? ph : 2, sx = b == 1 ? pw : 2;
           f = w[(((size_t)r * 3 + sx) * C + cc) * Cin + ci0 + j];
         }
+      } else if (transpose_flip == 3) {
+        // upsample-fused bank (ladder_conv3x3_up2_split): a 3x3 / SAME convolution of the factor-2 legacy-bilinear upsample of x equals,
+        // per output-parity class (a, b) = (row % 2, col % 2), a 3x3 correlation over x ITSELF with
+        //   W_eff[a,b][dr][dc] = sum_{r,s} A_a[dr][r] A_b[dc][s] w[r][s],   A_0 = [[1/2,0,0],[1/2,1,1/2],[0,0,1/2]],  A_1 = [[0,0,0],[1,1/2,0],[0,1/2,1]]
+        // (up[2i] = x[i], up[2i+1] = (x[i] + x[i+1]) / 2): class (a, b) issues 3 - a rows x 3 - b columns of taps, 25 instead of 36
+        // low-resolution tap products.  w = the layer's HWIO bank [3][3][Cin][C], C = Cout / 4; output column co = class * C + c.
+        const int C = Cout >> 2, cls = co / C, cc = co - cls * C, a = cls >> 1, b = cls & 1, dr = tap / 3, dc = tap - 3 * dr;
+        const float A0[3][3] = {{0.5f, 0.f, 0.f}, {0.5f, 1.f, 0.5f}, {0.f, 0.f, 0.5f}}, A1[3][3] = {{0.f, 0.f, 0.f}, {1.f, 0.5f, 0.f}, {0.f, 0.5f, 1.f}};
+        for (int r = 0; r < 3; ++r) {
+          const float ar = a ? A1[dr][r] : A0[dr][r];
+          if (ar == 0.f) continue;
+          for (int sx = 0; sx < 3; ++sx) {
+            const float bs = b ? A1[dc][sx] : A0[dc][sx];
+            if (bs != 0.f) f += (ar * bs) * w[(((size_t)r * 3 + sx) * Cin + ci0 + j) * C + cc];      // (ar * bs: exact powers of two)
+          }
+        }
       } else {
         f = transpose_flip ? w[((size_t)(ntaps - 1 - tap) * Cout + co) * Cin + ci0 + j] : w[((size_t)tap * Cin + ci0 + j) * Cout + co];
       }
@@ -165,6 +181,10 @@ __device__ __forceinline__ void filter_pack_element(const float* __restrict__ w,
   const size_t blk = ((size_t)(tap * nslabs + slab) * cots + cot) * (NS * 256);   // uint4 units
 #pragma unroll
   for (int p = 0; p < NS; ++p) out[blk + (size_t)p * 256 + kg * 128 + col] = make_uint4(lo[p].x, lo[p].y, hi[p].x, hi[p].y);
+}
+
+__global__ void record_times4_kernel(float* __restrict__ rec) {
+  for (int k = threadIdx.x; k < AMAX_SLOTS * AMAX_STRIDE; k += 256) rec[k] *= 4.f;
 }
 
 template <int PREC>
@@ -184,7 +204,7 @@ __global__ __launch_bounds__(256) void filter_pack_kernel(const float* __restric
 constexpr int PK_PARTS = 64;
 __global__ __launch_bounds__(256) void filter_absmax_multi_kernel(const ladder_pack_job_t* __restrict__ jobs, float* __restrict__ partial) {
   const ladder_pack_job_t j = jobs[blockIdx.y];
-  const size_t n = (size_t)j.ntaps * j.Cin * (j.transpose_flip == 2 ? j.Cout / 4 : j.Cout);   // Cin % 16 == 0: a multiple of 4; banks are 16-byte aligned views of the flat store
+  const size_t n = (size_t)j.ntaps * j.Cin * (j.transpose_flip >= 2 ? j.Cout / 4 : j.Cout);   // Cin % 16 == 0: a multiple of 4; banks are 16-byte aligned views of the flat store
   float m = 0.f;
   if ((reinterpret_cast<uintptr_t>(j.w) & 15u) == 0) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (size_t)PK_PARTS * 256) {
@@ -219,7 +239,7 @@ __global__ __launch_bounds__(256) void filter_pack_multi_kernel(const ladder_pac
     if (threadIdx.x == 0) amax_s = m;
   }
   __syncthreads();
-  const float amax = amax_s;
+  const float amax = j.transpose_flip == 3 ? 4.f * amax_s : amax_s;     // (upsample-fused bank: |W_eff| <= 2 x 2 x max|w|)
   float* rec = reinterpret_cast<float*>(static_cast<unsigned char*>(j.packed) + pack_payload_bytes_dev(j.ntaps, j.Cin, j.Cout, Fmt<PREC>::NS));
   if ((int)blockIdx.x == j.block_begin)                              // the bank's absmax record: slot 0 = the maximum, the rest 0
     for (int k = threadIdx.x; k < AMAX_SLOTS * AMAX_STRIDE; k += 256) rec[k] = k == 0 ? amax : 0.f;
@@ -244,7 +264,7 @@ constexpr int SP_AU = (SP_HALO_UNITS + SP_THREADS - 1) / SP_THREADS;   // 3
 // (two-plane formats: 128 registers and < 80 KB of LDS, so that TWO workgroups share a CU and one's staging / barrier phase hides behind
 // the other's MFMAs; the 9 taps are fully unrolled: fragment addresses become immediates, ~4 VALU instructions per tap are left)
 // PROJ: transposed accumulators (lane = pixel) for the fused projection; otherwise lane = channel and whole-line stores (see the 16-wave kernel)
-template <int PREC, bool PROJ>
+template <int PREC, bool PROJ, bool UP2 = false>
 __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x3_halo_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                                           const int N, const int H, const int W, const int Cin,
@@ -287,9 +307,14 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
     const int pix = u >> 2, kq = u & 3;
     const int hr = pix / SP_PW, hc = pix - hr * SP_PW;
     const int hi = h0 - 1 + hr, wi = w0 - 1 + hc;
-    const bool ok = (u < SP_HALO_UNITS) && hi >= 0 && hi < H && wi >= 0 && wi < W;
-    hsrc[i] = ok ? x + (((long)img * H + hi) * W + wi) * Cin + kq * 4 : nullptr;
-    hdst[i] = ((kq >> 1) * SP_NPIX + pix) * 16 + (kq & 1) * 8;
+    // s2_out == 2 (upsample-fused bank): the halo outside the map is the CLAMPED pixel, negated above / left of the map (the zero padding
+    // of the high-resolution convolution, exactly) and plain below / right of it (exact but for the last output row / column, which
+    // ladder_conv3x3_up2_split recomputes); bit 0 of hdst carries the sign (the offsets are multiples of 8)
+    const bool inside = hi >= 0 && hi < H && wi >= 0 && wi < W, up2 = UP2;
+    const bool ok = (u < SP_HALO_UNITS) && (inside || up2);
+    const int hs = up2 ? min(max(hi, 0), H - 1) : hi, ws_ = up2 ? min(max(wi, 0), W - 1) : wi;
+    hsrc[i] = ok ? x + (((long)img * H + hs) * W + ws_) * Cin + kq * 4 : nullptr;
+    hdst[i] = (((kq >> 1) * SP_NPIX + pix) * 16 + (kq & 1) * 8) | ((up2 && ((hi < 0) != (wi < 0))) ? 1 : 0);
   }
   const uint4* const bsrc = wp + (size_t)cot * B_CHUNKS + tid;             // + (tap*nslabs + slab) * tiles_n * B_CHUNKS
 
@@ -314,10 +339,11 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
       if (tid + i * SP_THREADS < SP_HALO_UNITS) {
         uint2 pl[NS];
         float4 v = ha[i];
-        if (F16) v = make_float4(v.x * cx, v.y * cx, v.z * cx, v.w * cx);
+        const float cm = (UP2 && (hdst[i] & 1)) ? -cx : cx;
+        if (F16 || UP2) v = make_float4(v.x * cm, v.y * cm, v.z * cm, v.w * cm);
         split4<NS, F16>(v, pl);
 #pragma unroll
-        for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(Abase + buf * A_BUF + p * SP_A_PLANE + hdst[i]) = pl[p];
+        for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(Abase + buf * A_BUF + p * SP_A_PLANE + (UP2 ? (hdst[i] & ~1) : hdst[i])) = pl[p];
       }
   };
   auto load_b = [&](int slab, int tap) {
@@ -398,7 +424,7 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int n = n0 + wn * 64 + ni * 32 + l31;
-      const float bv = (bias != nullptr && n < Cout) ? bias[n] : 0.f;
+      const float bv = (bias != nullptr && n < Cout) ? bias[s2_out ? n - n0 : n] : 0.f;    // (parity-class tiles share the layer's 128 channels)
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         // s2_out: this output-channel tile is one PARITY CLASS (ph, pw) = (cot >> 1, cot & 1) of a stride-2 backward-data result: pixel
@@ -507,7 +533,7 @@ constexpr int F_AU = (F_HALO_UNITS + F_THREADS - 1) / F_THREADS;               /
 // PROJ: transposed accumulators (lane = pixel; needed by the fused 1x1 projection).  Without it the accumulators are lane = channel and
 // every store instruction writes whole 128-byte lines (32 consecutive channels of a pixel per half-wave): +2 ... +5 % on the layers at
 // batch 128 against the 16-byte pieces of the transposed layout.
-template <int PREC, bool PROJ>
+template <int PREC, bool PROJ, bool UP2 = false>
 __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                                           const int N, const int H, const int W, const int Cin,
@@ -550,9 +576,14 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
     const int pix = u >> 2, kq = u & 3;
     const int hr = pix / SP_PW, hc = pix - hr * SP_PW;
     const int hi = h0 - 1 + hr, wi = w0 - 1 + hc;
-    const bool ok = (u < F_HALO_UNITS) && hi >= 0 && hi < H && wi >= 0 && wi < W;
-    hsrc[i] = ok ? x + (((long)img * H + hi) * W + wi) * Cin + kq * 4 : nullptr;
-    hdst[i] = ((kq >> 1) * F_NPIX + pix) * 16 + (kq & 1) * 8;
+    // s2_out == 2 (upsample-fused bank): the halo outside the map is the CLAMPED pixel, negated above / left of the map (the zero padding
+    // of the high-resolution convolution, exactly) and plain below / right of it (exact but for the last output row / column, which
+    // ladder_conv3x3_up2_split recomputes); bit 0 of hdst carries the sign (the offsets are multiples of 8)
+    const bool inside = hi >= 0 && hi < H && wi >= 0 && wi < W, up2 = UP2;
+    const bool ok = (u < F_HALO_UNITS) && (inside || up2);
+    const int hs = up2 ? min(max(hi, 0), H - 1) : hi, ws_ = up2 ? min(max(wi, 0), W - 1) : wi;
+    hsrc[i] = ok ? x + (((long)img * H + hs) * W + ws_) * Cin + kq * 4 : nullptr;
+    hdst[i] = (((kq >> 1) * F_NPIX + pix) * 16 + (kq & 1) * 8) | ((up2 && ((hi < 0) != (wi < 0))) ? 1 : 0);
   }
   // filter stage = the blocks of taps 3r .. 3r+2: 1536 chunks of 16 bytes, thread tid takes chunk tid (tap 3r + tid/512) and, the first
   // half of the workgroup, chunk 1024 + tid (tap 3r + 2)
@@ -579,10 +610,11 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
     if (tid + i * F_THREADS < F_HALO_UNITS) {
       uint2 pl[NS];
       float4 v = ha;
-      if (F16) v = make_float4(v.x * cx, v.y * cx, v.z * cx, v.w * cx);
+      const float cm = (UP2 && (hdst[i] & 1)) ? -cx : cx;
+      if (F16 || UP2) v = make_float4(v.x * cm, v.y * cm, v.z * cm, v.w * cm);
       split4<NS, F16>(v, pl);
 #pragma unroll
-      for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(Abase + buf * A_BUF + p * F_A_PLANE + hdst[i]) = pl[p];
+      for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(Abase + buf * A_BUF + p * F_A_PLANE + (UP2 ? (hdst[i] & ~1) : hdst[i])) = pl[p];
     }
   };
   auto load_b = [&](int slab, int r, int part) {                          // part 0: chunk tid, part 1: chunk 1024 + tid (first half only)
@@ -670,7 +702,7 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int n = n0 + wn * 64 + ni * 32 + l31;
-      const float bv = (bias != nullptr && n < Cout) ? bias[n] : 0.f;
+      const float bv = (bias != nullptr && n < Cout) ? bias[s2_out ? n - n0 : n] : 0.f;    // (parity-class tiles share the layer's 128 channels)
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         // s2_out: this output-channel tile is one PARITY CLASS (ph, pw) = (cot >> 1, cot & 1) of a stride-2 backward-data result: pixel
@@ -1102,8 +1134,9 @@ int ladder_filter_pack_split(const float* w, void* packed, int ntaps, int Cin, i
   const dim3 grid((total + 255) / 256), block(256);
   float* wamax = reinterpret_cast<float*>(static_cast<unsigned char*>(packed) + pack_payload_bytes(ntaps, Cin, Cout, prec));
   if (prec == LADDER_PREC_F16X3) {
-    const int rc = ladder_absmax(w, (size_t)ntaps * Cin * (transpose_flip == 2 ? Cout / 4 : Cout), wamax, stream);
+    const int rc = ladder_absmax(w, (size_t)ntaps * Cin * (transpose_flip >= 2 ? Cout / 4 : Cout), wamax, stream);
     if (rc != LADDER_OK) return rc;
+    if (transpose_flip == 3) hipLaunchKernelGGL(record_times4_kernel, dim3(1), dim3(256), 0, stream, wamax);   // |W_eff| <= 4 max|w|
     hipLaunchKernelGGL(filter_pack_kernel<LADDER_PREC_F16X3>, grid, block, 0, stream, w, (uint4*)packed, ntaps, Cin, Cout, transpose_flip, total, wamax);
   } else if (prec == LADDER_PREC_BF16X6) {
     hipLaunchKernelGGL(filter_pack_kernel<LADDER_PREC_BF16X6>, grid, block, 0, stream, w, (uint4*)packed, ntaps, Cin, Cout, transpose_flip, total, wamax);
@@ -1151,13 +1184,15 @@ static int conv3x3_split_launch(const float* x, const float* x_absmax, const voi
   const dim3 grid(tiles_m * tiles_n), block(SP_THREADS);
   const float* wamax = reinterpret_cast<const float*>(static_cast<const unsigned char*>(packed) + pack_payload_bytes(9, Cin, Cout, prec));
   if (y_absmax != nullptr && hipMemsetAsync(y_absmax, 0, LADDER_ABSMAX_FLOATS * sizeof(float), stream) != hipSuccess) return LADDER_E_LAUNCH;
-#define LADDER_SPLIT_LAUNCH_(P_, PROJ_) \
-  hipLaunchKernelGGL((conv3x3_halo_split_kernel<P_, PROJ_>), grid, block, 0, stream, x, (const uint4*)packed, bias, y, N, H, W, Cin, Cout, act, tiles_n, x_absmax, wamax, y_absmax, \
+#define LADDER_SPLIT_LAUNCH__(P_, PROJ_, UP2_) \
+  hipLaunchKernelGGL((conv3x3_halo_split_kernel<P_, PROJ_, UP2_>), grid, block, 0, stream, x, (const uint4*)packed, bias, y, N, H, W, Cin, Cout, act, tiles_n, x_absmax, wamax, y_absmax, \
                      pw, pb, pout, pco, tap_masks, s2_out)
+#define LADDER_SPLIT_LAUNCH_(P_, PROJ_) do { if (s2_out == 2) LADDER_SPLIT_LAUNCH__(P_, PROJ_, true); else LADDER_SPLIT_LAUNCH__(P_, PROJ_, false); } while (0)
 #define LADDER_SPLIT_LAUNCH(P_) do { if (pout != nullptr) LADDER_SPLIT_LAUNCH_(P_, true); else LADDER_SPLIT_LAUNCH_(P_, false); } while (0)
-#define LADDER_SPLIT16_LAUNCH(P_, PROJ_) \
-  hipLaunchKernelGGL((conv3x3_halo_split16_kernel<P_, PROJ_>), dim3(N * (H / F_H) * (W / SP_W) * tiles_n), dim3(F_THREADS), 0, stream, x, (const uint4*)packed, bias, y, N, H, W, Cin, Cout, act, tiles_n, x_absmax, wamax, y_absmax, \
+#define LADDER_SPLIT16_LAUNCH_(P_, PROJ_, UP2_) \
+  hipLaunchKernelGGL((conv3x3_halo_split16_kernel<P_, PROJ_, UP2_>), dim3(N * (H / F_H) * (W / SP_W) * tiles_n), dim3(F_THREADS), 0, stream, x, (const uint4*)packed, bias, y, N, H, W, Cin, Cout, act, tiles_n, x_absmax, wamax, y_absmax, \
                      pw, pb, pout, pco, tap_masks, s2_out)
+#define LADDER_SPLIT16_LAUNCH(P_, PROJ_) do { if (s2_out == 2) LADDER_SPLIT16_LAUNCH_(P_, PROJ_, true); else LADDER_SPLIT16_LAUNCH_(P_, PROJ_, false); } while (0)
   if (split_halo16_ok(N, H, W, Cin, Cout, prec)) {
     if (pout != nullptr) {
       if (prec == LADDER_PREC_F16X3) LADDER_SPLIT16_LAUNCH(LADDER_PREC_F16X3, true); else LADDER_SPLIT16_LAUNCH(LADDER_PREC_BF16X3, true);
@@ -1169,6 +1204,8 @@ static int conv3x3_split_launch(const float* x, const float* x_absmax, const voi
   else LADDER_SPLIT_LAUNCH(LADDER_PREC_BF16X3);
 #undef LADDER_SPLIT_LAUNCH
 #undef LADDER_SPLIT_LAUNCH_
+#undef LADDER_SPLIT_LAUNCH__
+#undef LADDER_SPLIT16_LAUNCH_
 #undef LADDER_SPLIT16_LAUNCH
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
@@ -1219,6 +1256,40 @@ int ladder_conv3x3_s2_bwd_data_split(const float* dy, const float* dy_absmax, co
   if (!ladder_conv3x3_s2_bwd_data_split_eligible(N, H, W, Cin, Ho, Wo, Cout, 3, 3, 2, 0, 0)) return LADDER_E_SHAPE;
   return conv3x3_split_launch(dy, dy_absmax, packed_s2, nullptr, dx, dx_absmax, nullptr, nullptr, nullptr, 0, N, Ho, Wo, Cout, 4 * SP_BN,
                               LADDER_ACT_NONE, prec, stream, s2_tap_masks(), 1);
+}
+
+// ---- a 3x3 / SAME convolution of the factor-2 legacy-bilinear UPSAMPLE of x, without the upsampled tensor ---------------------------------
+// (decoder: tf.image.resize_images(x, 2H x 2W) followed by conv2d, codes/models.py:554-578).  up[2i] = x[i], up[2i+1] = (x[i] + x[i+1]) / 2
+// (index clamped), so each output-parity class (row % 2, col % 2) of the convolution is a 3x3 correlation over x itself with effective
+// taps W_eff (ladder_filter_pack_split, transpose_flip = 3) -- 9 / 6 / 6 / 4 taps = 25 low-resolution tap products per 2x2 output block
+// instead of 36, and the 4x larger tensor is neither written nor read.  One launch of the halo kernel: the classes are its four
+// output-channel tiles (tap masks, interleaving epilogue, as for the stride-2 backward-data above), the halo outside the map is the
+// clamped pixel with the sign that reproduces the zero padding of the high-resolution convolution.  That is exact everywhere but in the
+// LAST output row and column (there the clamp of the resize and the padding of the convolution cannot both be expressed by one halo value):
+// those 2H + 2W - 1 pixels per image are recomputed from the last row / column of x by ladder_conv3x3_up2_edges.
+static unsigned long long up2_tap_masks() {
+  unsigned long long m = 0;
+  for (int cls = 0; cls < 4; ++cls) {
+    const int a = cls >> 1, b = cls & 1;
+    unsigned t = 0;
+    for (int dr = 0; dr < 3; ++dr)
+      for (int dc = 0; dc < 3; ++dc)
+        if ((a == 0 || dr >= 1) && (b == 0 || dc >= 1)) t |= 1u << (dr * 3 + dc);
+    m |= (unsigned long long)t << (9 * cls);
+  }
+  return m;
+}
+
+int ladder_conv3x3_up2_split_eligible(int N, int H, int W, int Cin, int Cout, int prec) {
+  static const bool off = getenv("LADDER_DISABLE_UP2") != nullptr;              // (test-only switch, see include/ladder_hip.h)
+  return (!off && prec_ok(prec) && Cout == SP_BN && split_halo_ok(N, H, W, Cin, 4 * SP_BN)) ? 1 : 0;
+}
+
+int ladder_conv3x3_up2_split(const float* x, const float* x_absmax, const void* packed_up2, const float* bias, float* y, float* y_absmax,
+                             int N, int H, int W, int Cin, int Cout, int act, int prec, ladder_stream_t stream) {
+  if (!ladder_conv3x3_up2_split_eligible(N, H, W, Cin, Cout, prec)) return LADDER_E_SHAPE;
+  return conv3x3_split_launch(x, x_absmax, packed_up2, bias, y, y_absmax, nullptr, nullptr, nullptr, 0, N, H, W, Cin, 4 * SP_BN, act, prec,
+                              stream, up2_tap_masks(), 2);
 }
 
 // (two-plane formats only: the double-buffered 2x32-pixel patch images of a three-plane format exceed the 160 KB of LDS)

@@ -1,0 +1,54 @@
+"""The upsample-fused decoder convolution (csrc/convsplit.hip: ladder_conv3x3_up2_split + ladder_conv3x3_up2_edges): a 3x3 / SAME convolution
+of the factor-2 legacy-bilinear upsample of x, computed from x itself as four output-parity classes with effective taps -- against the float64
+oracle's resize_bilinear_legacy + conv2d_tf (reference codes/models.py:554-578), through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ladder_oracle as O
+from test_gpu_split import PREC, TOL, _lib, absmax_samples, close, dev, p
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, w, b, act):
+    N, H, W, _ = x.shape
+    up = O.resize_bilinear_legacy(torch.as_tensor(x, dtype=torch.float64), 2 * H, 2 * W)
+    y = O.conv2d_tf(up, torch.as_tensor(w, dtype=torch.float64), torch.as_tensor(b, dtype=torch.float64), 1, "same")
+    if act == "leaky_relu":
+        y = torch.where(y > 0, y, 0.2 * y)
+    return up.numpy(), y.numpy()
+
+
+def _pack_up2(L, w, Cin, P, st):
+    wd = dev(w)
+    pk = torch.empty(L.query("ladder_filter_pack_split_bytes", 9, Cin, 512, P), dtype=torch.uint8, device="cuda")
+    L.call("ladder_filter_pack_split", p(wd), p(pk), 9, Cin, 512, 3, P, st)
+    return pk
+
+
+# N, H, W (low resolution), Cin, act, precision: 8-wave kernel (< 512 tiles) and 16-wave kernel, ragged sample scales
+CASES = [(64, 16, 32, 32, "leaky_relu", "f16x3"), (32, 32, 32, 64, None, "f16x3"), (16, 64, 64, 32, "leaky_relu", "f16x3"),
+         (64, 16, 32, 32, "leaky_relu", "bf16x3"), (128, 8, 32, 48, None, "f16x3")]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "n%d_%dx%d_c%d_%s_%s" % c)
+def test_up2_conv_interior_vs_oracle(gpu_ctx, case):
+    """Everything but the last output row / column is final after ladder_conv3x3_up2_split."""
+    L = _lib()
+    N, H, W, Cin, act, prec = case
+    P, st = PREC[prec], gpu_ctx.stream
+    rng = np.random.default_rng(H * 100 + Cin)
+    x = (rng.standard_normal((N, H, W, Cin)) * np.exp2(-6 * rng.random((N, 1, 1, 1)))).astype(np.float32)     # per-sample range disparity
+    w = (rng.standard_normal((3, 3, Cin, 128)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(128).astype(np.float32) * 0.1
+    assert L.query("ladder_conv3x3_up2_split_eligible", N, H, W, Cin, 128, P) == 1
+    xd, bd = dev(x), dev(b)
+    rec = absmax_samples(L, xd, st)
+    pk = _pack_up2(L, w, Cin, P, st)
+    y = torch.full((N, 2 * H, 2 * W, 128), float("nan"), device="cuda")
+    yrec = torch.empty(L.ABSMAX_FLOATS, device="cuda")
+    L.call("ladder_conv3x3_up2_split", p(xd), p(rec), p(pk), p(bd), p(y), p(yrec), N, H, W, Cin, 128, 1 if act else 0, P, st)
+    torch.cuda.synchronize()
+    _, ref = _ref(x, w, b, act)
+    close(y[:, :-1, :-1], ref[:, :-1, :-1], TOL[prec][0], "up2 interior")
