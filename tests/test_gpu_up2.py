@@ -33,8 +33,8 @@ CASES = [(64, 16, 32, 32, "leaky_relu", "f16x3"), (32, 32, 32, 64, None, "f16x3"
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "n%d_%dx%d_c%d_%s_%s" % c)
-def test_up2_conv_interior_vs_oracle(gpu_ctx, case):
-    """Everything but the last output row / column is final after ladder_conv3x3_up2_split."""
+def test_up2_conv_vs_oracle(gpu_ctx, case):
+    """Everything but the last output row / column is final after ladder_conv3x3_up2_split; ladder_conv3x3_up2_edges completes the map."""
     L = _lib()
     N, H, W, Cin, act, prec = case
     P, st = PREC[prec], gpu_ctx.stream
@@ -52,3 +52,16 @@ def test_up2_conv_interior_vs_oracle(gpu_ctx, case):
     torch.cuda.synchronize()
     _, ref = _ref(x, w, b, act)
     close(y[:, :-1, :-1], ref[:, :-1, :-1], TOL[prec][0], "up2 interior")
+    # the last output row / column: recomputed in fp32 from the last row / column of x
+    ws = torch.empty(L.query("ladder_conv3x3_up2_edges_workspace_bytes", N, H, W, Cin, 128), dtype=torch.uint8, device="cuda")
+    wd = dev(w)
+    L.call("ladder_conv3x3_up2_edges", p(xd), p(wd), p(bd), p(y), p(yrec), None, None, None, 0, N, H, W, Cin, 128, 1 if act else 0,
+           p(ws), ws.numel(), st)
+    torch.cuda.synchronize()
+    close(y, ref, TOL[prec][0], "up2 full map")
+    close(y[:, -1], ref[:, -1], 2e-5, "last row")
+    close(y[:, :, -1], ref[:, :, -1], 2e-5, "last column")
+    from test_gpu_split import rec_sample
+    for n in range(0, N, max(1, N // 7)):                                   # the per-sample record covers the final values
+        assert rec_sample(yrec, n) >= float(np.abs(ref[n]).max()) * (1 - 1e-4)
+        assert rec_sample(yrec, n) <= float(np.abs(ref[n]).max()) * 16      # (wrong pre-fix edge values may have raised it: still a bound)
