@@ -181,6 +181,9 @@ int ladder_conv3x3_s2_bwd_data_split(const float* dy, const float* dy_absmax, co
 int ladder_conv3x3_up2_split_eligible(int N, int H, int W, int Cin, int Cout, int prec);
 int ladder_conv3x3_up2_split(const float* x, const float* x_absmax, const void* packed_up2, const float* bias, float* y, float* y_absmax,
                              int N, int H, int W, int Cin, int Cout, int act, int prec, ladder_stream_t stream);
+int ladder_conv3x3_up2_split_proj(const float* x, const float* x_absmax, const void* packed_up2, const float* bias, float* y, const float* proj_w,
+                                  const float* proj_b, float* proj_out, int proj_cout, int N, int H, int W, int Cin, int Cout, int act, int prec,
+                                  ladder_stream_t stream);
 /* The last output row and column of the call above, recomputed in fp32 from the last row / column of x and the layer's HWIO bank w
  * [3][3][Cin][Cout] (row 2H-1 sees x[H-1] twice -- the resize clamps -- and the zero padding below; two [N*2W, 3 Cin] x [3 Cin, Cout] GEMMs):
  * written to y [N, 2H, 2W, Cout] and / or, through the fused 1x1 projection pw [Cout][pco] + pb, to pout [N, 2H, 2W, pco]; y_absmax (the

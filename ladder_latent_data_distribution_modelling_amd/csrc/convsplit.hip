@@ -459,13 +459,17 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
   for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      float* yp = y != nullptr ? y + (((long)img * H + h0 + 2 * wm + mi) * W + w0 + l31) * Cout : nullptr;
+      // (s2_out: this tile is one output-parity class of a [N, 2H, 2W, 128] map and owns all its 128 channels, see the lane = channel branch)
+      const long opix = s2_out ? ((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_tile % tiles_n >> 1)) * 2 * W + 2 * (w0 + l31) + (e_tile % tiles_n & 1)
+                               : ((long)img * H + h0 + 2 * wm + mi) * W + w0 + l31;
+      const int coff = s2_out ? n0 : 0;
+      float* yp = y != nullptr ? y + opix * (s2_out ? SP_BN : Cout) - coff : nullptr;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * lh;
         if (n < Cout) {                                      // Cout % 4 == 0: a channel quad is inside or outside as a whole
           float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (bias != nullptr) bv = *reinterpret_cast<const float4*>(bias + n);
+          if (bias != nullptr) bv = *reinterpret_cast<const float4*>(bias + n - coff);
           float4 v = make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
           if (F16) v = make_float4(v.x * unscale, v.y * unscale, v.z * unscale, v.w * unscale);
           v = make_float4(ladder_act_fn(v.x + bv.x, act), ladder_act_fn(v.y + bv.y, act), ladder_act_fn(v.z + bv.z, act),
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
           if (pout != nullptr) {                             // 1x1 projection: pw[Cout][pco], pco <= 4
             const float vv[4] = {v.x, v.y, v.z, v.w};
             if (pco == 3) {                                  // (the RGB output conv) rows n..n+3 = 12 consecutive floats, 16-byte aligned
-              const float4* q = reinterpret_cast<const float4*>(pw + (size_t)n * 3);
+              const float4* q = reinterpret_cast<const float4*>(pw + (size_t)(n - coff) * 3);
               const float4 q0 = q[0], q1 = q[1], q2 = q[2];
               const float wq[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
 #pragma unroll
@@ -485,7 +489,7 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
             } else {
 #pragma unroll
               for (int c4 = 0; c4 < 4; ++c4)
-                for (int o = 0; o < pco; ++o) pacc[mi][o] = fmaf(vv[c4], pw[(size_t)(n + c4) * pco + o], pacc[mi][o]);
+                for (int o = 0; o < pco; ++o) pacc[mi][o] = fmaf(vv[c4], pw[(size_t)(n - coff + c4) * pco + o], pacc[mi][o]);
             }
           }
         }
@@ -512,7 +516,9 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
       for (int mi = 0; mi < 2; ++mi) {
         const float4 other = *reinterpret_cast<const float4*>(red + (((wm * 2 + mi) * 32 + l31) * 4));
         const float t[4] = {pacc[mi][0] + other.x, pacc[mi][1] + other.y, pacc[mi][2] + other.z, pacc[mi][3] + other.w};
-        float* op = pout + (((long)img * H + h0 + 2 * wm + mi) * W + w0 + l31) * pco;
+        const long opix = s2_out ? ((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_tile % tiles_n >> 1)) * 2 * W + 2 * (w0 + l31) + (e_tile % tiles_n & 1)
+                                 : ((long)img * H + h0 + 2 * wm + mi) * W + w0 + l31;
+        float* op = pout + opix * pco;
         for (int o = 0; o < pco; ++o) op[o] = t[o] + (pb != nullptr ? pb[o] : 0.f);
       }
     }
@@ -737,13 +743,17 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
   for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      float* yp = y != nullptr ? y + (((long)img * H + h0 + 2 * wm + mi) * W + w0 + l31) * Cout : nullptr;
+      // (s2_out: this tile is one output-parity class of a [N, 2H, 2W, 128] map and owns all its 128 channels, see the lane = channel branch)
+      const long opix = s2_out ? ((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_tile % tiles_n >> 1)) * 2 * W + 2 * (w0 + l31) + (e_tile % tiles_n & 1)
+                               : ((long)img * H + h0 + 2 * wm + mi) * W + w0 + l31;
+      const int coff = s2_out ? n0 : 0;
+      float* yp = y != nullptr ? y + opix * (s2_out ? SP_BN : Cout) - coff : nullptr;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * lh;
         if (n < Cout) {                                      // Cout % 4 == 0: a channel quad is inside or outside as a whole
           float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (bias != nullptr) bv = *reinterpret_cast<const float4*>(bias + n);
+          if (bias != nullptr) bv = *reinterpret_cast<const float4*>(bias + n - coff);
           float4 v = make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
           if (F16) v = make_float4(v.x * unscale, v.y * unscale, v.z * unscale, v.w * unscale);
           v = make_float4(ladder_act_fn(v.x + bv.x, act), ladder_act_fn(v.y + bv.y, act), ladder_act_fn(v.z + bv.z, act),
@@ -753,7 +763,7 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
           if (pout != nullptr) {                             // 1x1 projection: pw[Cout][pco], pco <= 4
             const float vv[4] = {v.x, v.y, v.z, v.w};
             if (pco == 3) {                                  // (the RGB output conv) rows n..n+3 = 12 consecutive floats, 16-byte aligned
-              const float4* q = reinterpret_cast<const float4*>(pw + (size_t)n * 3);
+              const float4* q = reinterpret_cast<const float4*>(pw + (size_t)(n - coff) * 3);
               const float4 q0 = q[0], q1 = q[1], q2 = q[2];
               const float wq[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
 #pragma unroll
@@ -763,7 +773,7 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
             } else {
 #pragma unroll
               for (int c4 = 0; c4 < 4; ++c4)
-                for (int o = 0; o < pco; ++o) pacc[mi][o] = fmaf(vv[c4], pw[(size_t)(n + c4) * pco + o], pacc[mi][o]);
+                for (int o = 0; o < pco; ++o) pacc[mi][o] = fmaf(vv[c4], pw[(size_t)(n - coff + c4) * pco + o], pacc[mi][o]);
             }
           }
         }
@@ -790,7 +800,9 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
       for (int mi = 0; mi < 2; ++mi) {
         const float4 other = *reinterpret_cast<const float4*>(red + (((wm * 2 + mi) * 32 + l31) * 4));
         const float t[4] = {pacc[mi][0] + other.x, pacc[mi][1] + other.y, pacc[mi][2] + other.z, pacc[mi][3] + other.w};
-        float* op = pout + (((long)img * H + h0 + 2 * wm + mi) * W + w0 + l31) * pco;
+        const long opix = s2_out ? ((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_tile % tiles_n >> 1)) * 2 * W + 2 * (w0 + l31) + (e_tile % tiles_n & 1)
+                                 : ((long)img * H + h0 + 2 * wm + mi) * W + w0 + l31;
+        float* op = pout + opix * pco;
         for (int o = 0; o < pco; ++o) op[o] = t[o] + (pb != nullptr ? pb[o] : 0.f);
       }
     }
@@ -1249,7 +1261,7 @@ static int conv3x3_split_launch(const float* x, const float* x_absmax, const voi
                                 const float* pw, const float* pb, float* pout, int pco, int N, int H, int W, int Cin, int Cout, int act,
                                 int prec, ladder_stream_t stream, unsigned long long tap_masks = ~0ull, int s2_out = 0) {
   if (!split_halo_ok(N, H, W, Cin, Cout) || !prec_ok(prec)) return LADDER_E_SHAPE;
-  if (pout != nullptr && (pw == nullptr || pco < 1 || pco > 4 || Cout > SP_BN || !ladder_aligned16(pw))) return LADDER_E_SHAPE;
+  if (pout != nullptr && (pw == nullptr || pco < 1 || pco > 4 || (Cout > SP_BN && s2_out != 2) || !ladder_aligned16(pw))) return LADDER_E_SHAPE;
   if (pout == nullptr && y == nullptr) return LADDER_E_SHAPE;
   if (!ladder_aligned16(x) || !ladder_aligned16(packed) || !ladder_aligned16(y) || (bias != nullptr && !ladder_aligned16(bias)))
     return LADDER_E_ALIGN;
@@ -1364,6 +1376,15 @@ int ladder_conv3x3_up2_split(const float* x, const float* x_absmax, const void* 
                              int N, int H, int W, int Cin, int Cout, int act, int prec, ladder_stream_t stream) {
   if (!ladder_conv3x3_up2_split_eligible(N, H, W, Cin, Cout, prec)) return LADDER_E_SHAPE;
   return conv3x3_split_launch(x, x_absmax, packed_up2, bias, y, y_absmax, nullptr, nullptr, nullptr, 0, N, H, W, Cin, 4 * SP_BN, act, prec,
+                              stream, up2_tap_masks(), 2);
+}
+
+// ... with the 1x1 projection of ladder_conv3x3_split_proj fused behind it (y may be NULL in forward-only runs)
+int ladder_conv3x3_up2_split_proj(const float* x, const float* x_absmax, const void* packed_up2, const float* bias, float* y, const float* proj_w,
+                                  const float* proj_b, float* proj_out, int proj_cout, int N, int H, int W, int Cin, int Cout, int act, int prec,
+                                  ladder_stream_t stream) {
+  if (!ladder_conv3x3_up2_split_eligible(N, H, W, Cin, Cout, prec) || proj_out == nullptr || prec_planes(prec) != 2) return LADDER_E_SHAPE;
+  return conv3x3_split_launch(x, x_absmax, packed_up2, bias, y, nullptr, proj_w, proj_b, proj_out, proj_cout, N, H, W, Cin, 4 * SP_BN, act, prec,
                               stream, up2_tap_masks(), 2);
 }
 

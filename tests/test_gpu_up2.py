@@ -65,3 +65,33 @@ def test_up2_conv_vs_oracle(gpu_ctx, case):
     for n in range(0, N, max(1, N // 7)):                                   # the per-sample record covers the final values
         assert rec_sample(yrec, n) >= float(np.abs(ref[n]).max()) * (1 - 1e-4)
         assert rec_sample(yrec, n) <= float(np.abs(ref[n]).max()) * 16      # (wrong pre-fix edge values may have raised it: still a bound)
+
+
+@pytest.mark.parametrize("case", [(64, 16, 32, 32, "f16x3", True), (16, 64, 64, 32, "f16x3", False), (64, 16, 32, 32, "bf16x3", True)],
+                         ids=lambda c: "n%d_%dx%d_c%d_%s_y%d" % c)
+def test_up2_conv_with_fused_projection_vs_oracle(gpu_ctx, case):
+    """ladder_conv3x3_up2_split_proj + edges: the decoder's last two layers (conv2d_7 leaky + the 1x1 RGB conv2d_8, codes/models.py:571-587)
+    from the 64x64-type map, with and without materialising the 128-channel map (forward-only runs do not)."""
+    L = _lib()
+    N, H, W, Cin, prec, keep_y = case
+    P, st = PREC[prec], gpu_ctx.stream
+    rng = np.random.default_rng(H + Cin)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, 128)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(128).astype(np.float32) * 0.1
+    pw_ = (rng.standard_normal((128, 3)) / np.sqrt(128)).astype(np.float32)
+    pb_ = rng.standard_normal(3).astype(np.float32) * 0.1
+    xd, bd, wd, pwd, pbd = dev(x), dev(b), dev(w), dev(pw_), dev(pb_)
+    rec = absmax_samples(L, xd, st)
+    pk = _pack_up2(L, w, Cin, P, st)
+    y = torch.full((N, 2 * H, 2 * W, 128), float("nan"), device="cuda") if keep_y else None
+    out = torch.full((N, 2 * H, 2 * W, 3), float("nan"), device="cuda")
+    L.call("ladder_conv3x3_up2_split_proj", p(xd), p(rec), p(pk), p(bd), p(y), p(pwd), p(pbd), p(out), 3, N, H, W, Cin, 128, 1, P, st)
+    ws = torch.empty(L.query("ladder_conv3x3_up2_edges_workspace_bytes", N, H, W, Cin, 128), dtype=torch.uint8, device="cuda")
+    L.call("ladder_conv3x3_up2_edges", p(xd), p(wd), p(bd), p(y), None, p(pwd), p(pbd), p(out), 3, N, H, W, Cin, 128, 1, p(ws), ws.numel(), st)
+    torch.cuda.synchronize()
+    _, ref = _ref(x, w, b, "leaky_relu")
+    refp = ref @ pw_.astype(np.float64) + pb_.astype(np.float64)
+    close(out, refp, TOL[prec][0], "projection")
+    if keep_y:
+        close(y, ref, TOL[prec][0], "map")
