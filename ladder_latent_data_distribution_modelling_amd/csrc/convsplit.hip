@@ -1073,38 +1073,38 @@ WgradSplitPlan plan_wgrad_split(int N, int H, int W, int Cin, int Cout) {
 // ---- the last output row / column of the upsample-fused convolution (ladder_conv3x3_up2_edges) -----------------------------------------
 // Output row 2H-1 sees up-rows 2H-2 and 2H-1 (both = x[H-1] upsampled along W: the resize clamps) and the zero padding below:
 //   y[2H-1, X] = act(b + sum_s (w[0][s] + w[1][s]) . uL[X + s - 1]),   uL = 1-D legacy upsample of the last row of x, zero outside [0, 2W)
-// and likewise the last column with (w[r][0] + w[r][1]) and the 1-D upsample vL of the last column of x.  Both are small GEMMs
-// ([N * 2W, 3 Cin] x [3 Cin, 128]); this kernel lays out their operands: A_row, A_col (im2col of the 1-D upsampled lines) and the summed taps.
-__global__ __launch_bounds__(256) void up2_edge_operands_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ a_row,
-                                                                float* __restrict__ a_col, float* __restrict__ w_row, float* __restrict__ w_col,
+// and likewise the last column with (w[r][0] + w[r][1]) and the 1-D upsample vL of the last column of x: a 1x3 convolution over the line
+// tensor uL [N, 1, 2W, Cin] and a 3x1 convolution over vL [N, 2H, 1, Cin] (SAME padding) on the fp32 matrix cores.  This kernel writes the
+// two lines (float4 units) and the two summed filter banks.
+__global__ __launch_bounds__(256) void up2_edge_operands_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ u_row,
+                                                                float* __restrict__ v_col, float* __restrict__ w_row, float* __restrict__ w_col,
                                                                 int N, int H, int W, int Cin, int C) {
-  const int K = 3 * Cin;
-  const long n_row = (long)N * 2 * W * K, n_col = (long)N * 2 * H * K, n_w = (long)K * C;
+  const int CV = Cin >> 2;
+  const long n_row = (long)N * 2 * W * CV, n_col = (long)N * 2 * H * CV, n_w = (long)3 * Cin * C;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_row + n_col + 2 * n_w; i += (long)gridDim.x * 256) {
     if (i < n_row + n_col) {
       const bool row = i < n_row;
       const long j = row ? i : i - n_row;
       const int L = row ? W : H;                                  // low-resolution length of the line
-      const int ci = (int)(j % Cin);
-      const int t = (int)((j / Cin) % 3);
-      const int X = (int)((j / K) % (2 * L));
-      const int n = (int)(j / ((long)K * 2 * L));
-      const int q = X + t - 1;                                    // position on the upsampled line
-      float v = 0.f;
-      if (q >= 0 && q < 2 * L) {
-        const int lo = q >> 1, hi = min(lo + 1, L - 1);
-        const float* base = row ? x + (((long)n * H + (H - 1)) * W) * Cin + ci : x + (((long)n * H) * W + (W - 1)) * Cin + ci;
-        const long stride = row ? Cin : (long)W * Cin;
-        const float xl = base[lo * stride];
-        v = (q & 1) ? xl + (base[hi * stride] - xl) * 0.5f : xl;   // the arithmetic of resize_fwd_kernel (lerp, weight 1/2)
+      const int cv = (int)(j % CV);
+      const int q = (int)((j / CV) % (2 * L));                    // position on the upsampled line
+      const int n = (int)(j / ((long)CV * 2 * L));
+      const int lo = q >> 1, hi = min(lo + 1, L - 1);
+      const float4* base = reinterpret_cast<const float4*>(row ? x + (((long)n * H + (H - 1)) * W) * Cin : x + (((long)n * H) * W + (W - 1)) * Cin) + cv;
+      const long stride = row ? CV : (long)W * CV;
+      const float4 xl = base[lo * stride];
+      float4 v = xl;
+      if (q & 1) {                                                // the arithmetic of resize_fwd_kernel (lerp, weight 1/2)
+        const float4 xh = base[hi * stride];
+        v = make_float4(xl.x + (xh.x - xl.x) * 0.5f, xl.y + (xh.y - xl.y) * 0.5f, xl.z + (xh.z - xl.z) * 0.5f, xl.w + (xh.w - xl.w) * 0.5f);
       }
-      (row ? a_row : a_col)[j] = v;
+      reinterpret_cast<float4*>(row ? u_row : v_col)[j] = v;
     } else {
       const long j = i - n_row - n_col;
       const bool row = j < n_w;
       const long e = row ? j : j - n_w;
       const int co = (int)(e % C), ci = (int)((e / C) % Cin), t = (int)(e / ((long)C * Cin));
-      // row operand: taps (r = 0, s = t) + (r = 1, s = t); column operand: taps (r = t, s = 0) + (r = t, s = 1)
+      // row bank [1][3][Cin][C]: taps (r = 0, s = t) + (r = 1, s = t); column bank [3][1][Cin][C]: taps (r = t, s = 0) + (r = t, s = 1)
       const float v0 = row ? w[(((long)0 * 3 + t) * Cin + ci) * C + co] : w[(((long)t * 3 + 0) * Cin + ci) * C + co];
       const float v1 = row ? w[(((long)1 * 3 + t) * Cin + ci) * C + co] : w[(((long)t * 3 + 1) * Cin + ci) * C + co];
       (row ? w_row : w_col)[e] = v0 + v1;
@@ -1394,31 +1394,33 @@ size_t ladder_conv3x3_up2_edges_workspace_bytes(int N, int H, int W, int Cin, in
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
   const size_t K = (size_t)3 * Cin, mr = (size_t)N * 2 * W, mc = (size_t)N * 2 * H;
   const size_t g = ladder_igemm_fwd_workspace_bytes((long)(mr > mc ? mr : mc), (int)K, Cout);
-  return up2_align(mr * K * 4) + up2_align(mc * K * 4) + 2 * up2_align(K * Cout * 4) + up2_align(mr * Cout * 4) + up2_align(mc * Cout * 4) + up2_align(g) + 256;
+  return up2_align(mr * Cin * 4) + up2_align(mc * Cin * 4) + 2 * up2_align(K * Cout * 4) + up2_align(mr * Cout * 4) + up2_align(mc * Cout * 4) + up2_align(g) + 256;
 }
 
 // Recomputes the last output row and column of ladder_conv3x3_up2_split(_proj) from x and the layer's HWIO bank w [3][3][Cin][Cout] in
-// fp32 (two GEMMs on the fp32 matrix cores + operand / scatter kernels); y and / or pout (with pw [Cout][pco], pb [pco]) receive them, the
-// per-sample record y_absmax (already written by the main launch) is raised where an edge value exceeds it.
+// fp32 (a 1x3 and a 3x1 convolution over the 1-D upsampled last row / column on the fp32 matrix cores + operand / scatter kernels); y and / or
+// pout (with pw [Cout][pco], pb [pco]) receive them, the per-sample record y_absmax (already written by the main launch) is raised where an
+// edge value exceeds it.
 int ladder_conv3x3_up2_edges(const float* x, const float* w, const float* bias, float* y, float* y_absmax, const float* pw, const float* pb,
                              float* pout, int pco, int N, int H, int W, int Cin, int Cout, int act, void* ws, size_t ws_bytes,
                              ladder_stream_t stream) {
-  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (y == nullptr && pout == nullptr)) return LADDER_E_SHAPE;
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin % 4) != 0 || Cout <= 0 || (y == nullptr && pout == nullptr)) return LADDER_E_SHAPE;
   if (pout != nullptr && (pw == nullptr || pco < 1 || pco > 4)) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(x)) return LADDER_E_ALIGN;
   if (ws == nullptr || ws_bytes < ladder_conv3x3_up2_edges_workspace_bytes(N, H, W, Cin, Cout)) return LADDER_E_WORKSPACE;
   const size_t K = (size_t)3 * Cin, mr = (size_t)N * 2 * W, mc = (size_t)N * 2 * H;
   char* p = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-  float* a_row = (float*)p; p += up2_align(mr * K * 4);
-  float* a_col = (float*)p; p += up2_align(mc * K * 4);
+  float* u_row = (float*)p; p += up2_align(mr * Cin * 4);
+  float* v_col = (float*)p; p += up2_align(mc * Cin * 4);
   float* w_row = (float*)p; p += up2_align(K * Cout * 4);
   float* w_col = (float*)p; p += up2_align(K * Cout * 4);
   float* e_row = (float*)p; p += up2_align(mr * Cout * 4);
   float* e_col = (float*)p; p += up2_align(mc * Cout * 4);
   const size_t g = ws_bytes - (size_t)(p - (char*)ws);
-  hipLaunchKernelGGL(up2_edge_operands_kernel, dim3(2048), dim3(256), 0, stream, x, w, a_row, a_col, w_row, w_col, N, H, W, Cin, Cout);
-  int rc = ladder_dense_fwd(a_row, w_row, bias, e_row, (int)mr, (int)K, Cout, act, p, g, stream);
+  hipLaunchKernelGGL(up2_edge_operands_kernel, dim3(1024), dim3(256), 0, stream, x, w, u_row, v_col, w_row, w_col, N, H, W, Cin, Cout);
+  int rc = ladder_conv2d_fwd(u_row, w_row, bias, e_row, N, 1, 2 * W, Cin, 1, 2 * W, Cout, 1, 3, 1, 0, 1, act, p, g, stream);
   if (rc != LADDER_OK) return rc;
-  rc = ladder_dense_fwd(a_col, w_col, bias, e_col, (int)mc, (int)K, Cout, act, p, g, stream);
+  rc = ladder_conv2d_fwd(v_col, w_col, bias, e_col, N, 2 * H, 1, Cin, 2 * H, 1, Cout, 3, 1, 1, 1, 0, act, p, g, stream);
   if (rc != LADDER_OK) return rc;
   hipLaunchKernelGGL(up2_edge_scatter_kernel, dim3((2 * W + 2 * H - 1 + 3) / 4, N), dim3(256), 0, stream, (const float*)e_row, (const float*)e_col, y,
                      pw, pb, pout, pco, H, W, Cout, y_absmax);

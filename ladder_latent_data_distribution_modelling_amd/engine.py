@@ -202,6 +202,7 @@ class Ctx:
         self._ws_aux = None
         self.keep_activations = True   # False inside forward-only runs: fused kernels may skip writing tensors only a backward pass reads
         self.ns = 0          # LADDER_PREC_* of the split-precision contraction kernels (0 = native f32 MFMA); set by the engine
+        self.up2 = True      # resize -> 3x3 conv pairs of the decoder as ONE upsample-fused convolution in forward-only runs (config `upsample_fused_convs`)
 
     @property
     def stream(self):
@@ -466,9 +467,11 @@ class Conv2D:
         """Split bf16 planes of the filter bank in the kernel's LDS layout, re-packed when the weights changed (always while a
         hipGraph is being captured, so that a replay re-packs the then-current weights)."""
         ns, ps = self.ctx.ns, self.ps
-        cin, cout = (self.cout, self.cin) if transpose_flip else (self.cin, self.cout)
+        cin, cout = (self.cout, self.cin) if transpose_flip in (1, 2) else (self.cin, self.cout)
         if transpose_flip == 2:                       # the four parity classes of a stride-2 backward-data as output-channel blocks
             cout = 4 * self.cin
+        elif transpose_flip == 3:                     # the four output-parity classes of the upsample-fused forward (effective taps)
+            cout = 4 * self.cout
         ent = self._packed.get((transpose_flip, ns))
         if ent is None:
             nb = L.query("ladder_filter_pack_split_bytes", self.k * self.k, cin, cout, ns)
@@ -503,6 +506,44 @@ class Conv2D:
         self.x, self.y = x, y
         proj.x, proj.y = y, out
         return out
+
+    def up2_ok(self, N, H, W):
+        """This layer can take the LOW-resolution tensor [N, H, W, cin] that a factor-2 legacy-bilinear resize would have blown up for it
+        (ladder_conv3x3_up2_split: four output-parity classes with effective taps, 25 instead of 36 low-resolution tap products and no
+        upsampled tensor).  Forward-only runs use it; a training forward keeps the resized tensor for its backward pass."""
+        return bool(self.ctx.up2 and self.ctx.ns in (2, 4) and self.k == 3 and self.stride == 1 and self.padding == "same"
+                    and L.query("ladder_conv3x3_up2_split_eligible", N, H, W, self.cin, self.cout, self.ctx.ns))
+
+    def forward_up2(self, x, proj=None):
+        """conv(resize2x(x)) from x itself; with `proj` the 1x1 output conv rides on the epilogue as in forward_fused_proj (the 128-channel
+        map is then not written).  Forward-only: nothing is kept for a backward pass."""
+        ctx = self.ctx
+        N, H, W, _ = x.shape
+        self.pt = self.pl = 1
+        bias, wk = self.ps.w[self.name + "/bias"], self.ps.w[self.name + "/kernel"]
+        x_amax = ctx.absmax(x)
+        flops = 2.0 * N * 4 * H * W * 9 * self.cin * self.cout          # the reference's operation count (algorithmic), not the 25/36 executed
+        wsp, wsn = ctx.ws(L.query("ladder_conv3x3_up2_edges_workspace_bytes", N, H, W, self.cin, self.cout))
+        if proj is not None:
+            out = ctx.empty(N, 2 * H, 2 * W, proj.cout)
+            pw, pb = self.ps.w[proj.name + "/kernel"], self.ps.w[proj.name + "/bias"]
+            _timed(256120 + ctx.ns, flops, "ladder_conv3x3_up2_split_proj",
+                   (_p(x), _p(x_amax), _p(self._packed_filter(3)), _p(bias), None, _p(pw), _p(pb), _p(out), proj.cout, N, H, W, self.cin, self.cout,
+                    L.ACT[self.act], ctx.ns, ctx.stream))
+            L.call("ladder_conv3x3_up2_edges", _p(x), _p(wk), _p(bias), None, None, _p(pw), _p(pb), _p(out), proj.cout, N, H, W, self.cin, self.cout,
+                   L.ACT[self.act], wsp, wsn, ctx.stream)
+            self.x = self.y = proj.x = proj.y = None
+            return out
+        y = ctx.empty(N, 2 * H, 2 * W, self.cout)
+        y_amax = ctx.new_amax() if ctx.ns == 4 else None
+        _timed(256120 + ctx.ns, flops, "ladder_conv3x3_up2_split",
+               (_p(x), _p(x_amax), _p(self._packed_filter(3)), _p(bias), _p(y), _p(y_amax), N, H, W, self.cin, self.cout, L.ACT[self.act], ctx.ns,
+                ctx.stream))
+        L.call("ladder_conv3x3_up2_edges", _p(x), _p(wk), _p(bias), _p(y), _p(y_amax), None, None, None, 0, N, H, W, self.cin, self.cout,
+               L.ACT[self.act], wsp, wsn, ctx.stream)
+        ctx.set_amax(y, y_amax)
+        self.x = self.y = None
+        return y
 
     def forward(self, x):
         N, H, W, _ = x.shape
@@ -1060,22 +1101,37 @@ class CelebADecoder:
             d = lyr.forward(d)
         dlatent = d
         h = self.up0.forward(self.conv0.forward(encoded.view(B, 1, 1, self.nh)))
+        lowres = False            # h is the LOW-resolution input of a factor-2 resize that the next conv applies itself (forward-only runs)
         for bi, (conv, sty, norm, rs) in enumerate(self.blocks):
-            if bi == len(self.blocks) - 1 and norm is None and (rs is None or (rs.oh, rs.ow) == tuple(h.shape[1:3])):
+            if lowres:
+                lowres = False
+                last = bi == len(self.blocks) - 1 and norm is None and (rs is None or (rs.oh, rs.ow) == (2 * h.shape[1], 2 * h.shape[2]))
+                if last:
+                    return conv.forward_up2(h, self.conv_out)
+                h = conv.forward_up2(h)
+            elif bi == len(self.blocks) - 1 and norm is None and (rs is None or (rs.oh, rs.ow) == tuple(h.shape[1:3])):
                 # the last 3x3 conv feeds the 1x1 output conv directly (its resize is the identity): one fused launch
                 out = conv.forward_fused_proj(h, self.conv_out, keep_y=self.ctx.keep_activations)
                 if out is not None:
                     if rs is not None:
                         rs.in_shape = tuple(h.shape[:3]) + (conv.cout,)
                     return out
-            h = conv.forward(h)
+            else:
+                h = conv.forward(h)
+            # the resize behind this block folds into the NEXT conv when that one can take the low-resolution tensor (forward-only runs)
+            nxt = self.blocks[bi + 1][0] if bi + 1 < len(self.blocks) else None
+            fold = (rs is not None and nxt is not None and not self.ctx.keep_activations and (rs.oh, rs.ow) == (2 * h.shape[1], 2 * h.shape[2])
+                    and nxt.up2_ok(h.shape[0], h.shape[1], h.shape[2]))
             if norm is not None:
                 style = sty.forward(dlatent)
-                up = norm.forward_resized(h, style, rs) if rs is not None else None
+                up = norm.forward_resized(h, style, rs) if (rs is not None and not fold) else None
                 if up is not None:
                     h = up
                     continue
                 h = norm.forward(h, style)
+            if fold:
+                lowres = True
+                continue
             if rs is not None:
                 h = rs.forward(h)
         return self.conv_out.forward(h)
@@ -1192,6 +1248,7 @@ class LadderEngine:
         if prec not in PRECISIONS:
             raise ValueError("matmul_precision %r: expected one of %s" % (prec, sorted(PRECISIONS)))
         self.ctx.ns = PRECISIONS[prec]
+        self.ctx.up2 = bool(int(cfg.get("upsample_fused_convs", 1)))
         self.precision = prec
         if self.ctx.comm.rank == 0:
             print("Contraction precision (config key matmul_precision): {} -- {}".format(prec, PRECISION_NOTES[prec]))
