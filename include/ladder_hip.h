@@ -180,18 +180,20 @@ int ladder_conv3x3_s2_bwd_data_split(const float* dy, const float* dy_absmax, co
  * record of x as for ladder_conv3x3_split.  The last output row and column are NOT final after this call: ladder_conv3x3_up2_edges. */
 int ladder_conv3x3_up2_split_eligible(int N, int H, int W, int Cin, int Cout, int prec);
 int ladder_conv3x3_up2_split(const float* x, const float* x_absmax, const void* packed_up2, const float* bias, float* y, float* y_absmax,
-                             int N, int H, int W, int Cin, int Cout, int act, int prec, ladder_stream_t stream);
+                             int N, int H, int W, int Cin, int Cout, int act, int prec, int x_upsampled, ladder_stream_t stream);
+/* x_upsampled != 0 (here and in ladder_conv3x3_up2_edges): `x` points at an already upsampled tensor [N, 2H, 2W, Cin] whose even rows / columns
+ * are the low-resolution map (up[2i][2j] = x[i][j]) -- a training forward keeps that tensor for the backward pass of the layer. */
 int ladder_conv3x3_up2_split_proj(const float* x, const float* x_absmax, const void* packed_up2, const float* bias, float* y, const float* proj_w,
                                   const float* proj_b, float* proj_out, int proj_cout, int N, int H, int W, int Cin, int Cout, int act, int prec,
-                                  ladder_stream_t stream);
+                                  int x_upsampled, ladder_stream_t stream);
 /* The last output row and column of the call above, recomputed in fp32 from the last row / column of x and the layer's HWIO bank w
  * [3][3][Cin][Cout] (row 2H-1 sees x[H-1] twice -- the resize clamps -- and the zero padding below; two [N*2W, 3 Cin] x [3 Cin, Cout] GEMMs):
  * written to y [N, 2H, 2W, Cout] and / or, through the fused 1x1 projection pw [Cout][pco] + pb, to pout [N, 2H, 2W, pco]; y_absmax (the
  * record of the main launch) is raised where needed.  Call after ladder_conv3x3_up2_split(_proj) on the same stream. */
 size_t ladder_conv3x3_up2_edges_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int ladder_conv3x3_up2_edges(const float* x, const float* w, const float* bias, float* y, float* y_absmax, const float* proj_w, const float* proj_b,
-                             float* proj_out, int proj_cout, int N, int H, int W, int Cin, int Cout, int act, void* ws, size_t ws_bytes,
-                             ladder_stream_t stream);
+                             float* proj_out, int proj_cout, int N, int H, int W, int Cin, int Cout, int act, int x_upsampled, void* ws,
+                             size_t ws_bytes, ladder_stream_t stream);
 
 /* planes[p][i] = 16-bit plane p of x[i] (scaled by a power of two derived from x_absmax for LADDER_PREC_F16X3), plane-major,
  * n % 8 == 0, followed by 16 zero bytes (the source of out-of-image taps) and a 16-byte header; ladder_presplit_bytes = planes * n * 2 + 32.

@@ -124,10 +124,10 @@ PROTOTYPES = {
     "ladder_conv3x3_split": (_i, [_p, _p, _p, _p, _p, _p] + [_i] * 7 + [_p]),
     "ladder_conv3x3_s2_bwd_data_split_eligible": (_i, [_i] * 12),
     "ladder_conv3x3_up2_split_eligible": (_i, [_i] * 6),
-    "ladder_conv3x3_up2_split": (_i, [_p, _p, _p, _p, _p, _p] + [_i] * 7 + [_p]),
-    "ladder_conv3x3_up2_split_proj": (_i, [_p] * 8 + [_i] * 8 + [_p]),
+    "ladder_conv3x3_up2_split": (_i, [_p, _p, _p, _p, _p, _p] + [_i] * 8 + [_p]),
+    "ladder_conv3x3_up2_split_proj": (_i, [_p] * 8 + [_i] * 9 + [_p]),
     "ladder_conv3x3_up2_edges_workspace_bytes": (_z, [_i] * 5),
-    "ladder_conv3x3_up2_edges": (_i, [_p] * 8 + [_i] * 7 + [_p, _z, _p]),
+    "ladder_conv3x3_up2_edges": (_i, [_p] * 8 + [_i] * 8 + [_p, _z, _p]),
     "ladder_conv3x3_s2_bwd_data_split": (_i, [_p, _p, _p, _p, _p] + [_i] * 8 + [_p]),
     "ladder_dense_small_eligible": (_i, [_i, _i, _i]),
     "ladder_dense_fwd_small": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),

@@ -313,7 +313,10 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
     const bool inside = hi >= 0 && hi < H && wi >= 0 && wi < W, up2 = UP2;
     const bool ok = (u < SP_HALO_UNITS) && (inside || up2);
     const int hs = up2 ? min(max(hi, 0), H - 1) : hi, ws_ = up2 ? min(max(wi, 0), W - 1) : wi;
-    hsrc[i] = ok ? x + (((long)img * H + hs) * W + ws_) * Cin + kq * 4 : nullptr;
+    // (s2_out == 3: x is the even-row / even-column sub-grid of an ALREADY upsampled [N, 2H, 2W, Cin] tensor -- up[2i][2j] = x[i][j] -- that a
+    // training forward keeps for its backward pass)
+    const int sm = (UP2 && s2_out == 3) ? 2 : 1;
+    hsrc[i] = ok ? x + (((long)img * (H * sm) + hs * sm) * (W * sm) + ws_ * sm) * Cin + kq * 4 : nullptr;
     hdst[i] = (((kq >> 1) * SP_NPIX + pix) * 16 + (kq & 1) * 8) | ((up2 && ((hi < 0) != (wi < 0))) ? 1 : 0);
   }
   const uint4* const bsrc = wp + (size_t)cot * B_CHUNKS + tid;             // + (tap*nslabs + slab) * tiles_n * B_CHUNKS
@@ -588,7 +591,10 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
     const bool inside = hi >= 0 && hi < H && wi >= 0 && wi < W, up2 = UP2;
     const bool ok = (u < F_HALO_UNITS) && (inside || up2);
     const int hs = up2 ? min(max(hi, 0), H - 1) : hi, ws_ = up2 ? min(max(wi, 0), W - 1) : wi;
-    hsrc[i] = ok ? x + (((long)img * H + hs) * W + ws_) * Cin + kq * 4 : nullptr;
+    // (s2_out == 3: x is the even-row / even-column sub-grid of an ALREADY upsampled [N, 2H, 2W, Cin] tensor -- up[2i][2j] = x[i][j] -- that a
+    // training forward keeps for its backward pass)
+    const int sm = (UP2 && s2_out == 3) ? 2 : 1;
+    hsrc[i] = ok ? x + (((long)img * (H * sm) + hs * sm) * (W * sm) + ws_ * sm) * Cin + kq * 4 : nullptr;
     hdst[i] = (((kq >> 1) * F_NPIX + pix) * 16 + (kq & 1) * 8) | ((up2 && ((hi < 0) != (wi < 0))) ? 1 : 0);
   }
   // filter stage = the blocks of taps 3r .. 3r+2: 1536 chunks of 16 bytes, thread tid takes chunk tid (tap 3r + tid/512) and, the first
@@ -1078,8 +1084,8 @@ WgradSplitPlan plan_wgrad_split(int N, int H, int W, int Cin, int Cout) {
 // two lines (float4 units) and the two summed filter banks.
 __global__ __launch_bounds__(256) void up2_edge_operands_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ u_row,
                                                                 float* __restrict__ v_col, float* __restrict__ w_row, float* __restrict__ w_col,
-                                                                int N, int H, int W, int Cin, int C) {
-  const int CV = Cin >> 2;
+                                                                int N, int H, int W, int Cin, int C, int sm) {
+  const int CV = Cin >> 2;                                        // sm = 2: x is the even sub-grid of an upsampled [N, 2H, 2W, Cin] tensor
   const long n_row = (long)N * 2 * W * CV, n_col = (long)N * 2 * H * CV, n_w = (long)3 * Cin * C;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_row + n_col + 2 * n_w; i += (long)gridDim.x * 256) {
     if (i < n_row + n_col) {
@@ -1090,8 +1096,9 @@ __global__ __launch_bounds__(256) void up2_edge_operands_kernel(const float* __r
       const int q = (int)((j / CV) % (2 * L));                    // position on the upsampled line
       const int n = (int)(j / ((long)CV * 2 * L));
       const int lo = q >> 1, hi = min(lo + 1, L - 1);
-      const float4* base = reinterpret_cast<const float4*>(row ? x + (((long)n * H + (H - 1)) * W) * Cin : x + (((long)n * H) * W + (W - 1)) * Cin) + cv;
-      const long stride = row ? CV : (long)W * CV;
+      const float4* base = reinterpret_cast<const float4*>(row ? x + (((long)n * (H * sm) + (H - 1) * sm) * (W * sm)) * Cin
+                                                               : x + (((long)n * (H * sm)) * (W * sm) + (W - 1) * sm) * Cin) + cv;
+      const long stride = row ? (long)sm * CV : (long)sm * (W * sm) * CV;
       const float4 xl = base[lo * stride];
       float4 v = xl;
       if (q & 1) {                                                // the arithmetic of resize_fwd_kernel (lerp, weight 1/2)
@@ -1261,7 +1268,7 @@ static int conv3x3_split_launch(const float* x, const float* x_absmax, const voi
                                 const float* pw, const float* pb, float* pout, int pco, int N, int H, int W, int Cin, int Cout, int act,
                                 int prec, ladder_stream_t stream, unsigned long long tap_masks = ~0ull, int s2_out = 0) {
   if (!split_halo_ok(N, H, W, Cin, Cout) || !prec_ok(prec)) return LADDER_E_SHAPE;
-  if (pout != nullptr && (pw == nullptr || pco < 1 || pco > 4 || (Cout > SP_BN && s2_out != 2) || !ladder_aligned16(pw))) return LADDER_E_SHAPE;
+  if (pout != nullptr && (pw == nullptr || pco < 1 || pco > 4 || (Cout > SP_BN && s2_out < 2) || !ladder_aligned16(pw))) return LADDER_E_SHAPE;
   if (pout == nullptr && y == nullptr) return LADDER_E_SHAPE;
   if (!ladder_aligned16(x) || !ladder_aligned16(packed) || !ladder_aligned16(y) || (bias != nullptr && !ladder_aligned16(bias)))
     return LADDER_E_ALIGN;
@@ -1274,12 +1281,12 @@ static int conv3x3_split_launch(const float* x, const float* x_absmax, const voi
 #define LADDER_SPLIT_LAUNCH__(P_, PROJ_, UP2_) \
   hipLaunchKernelGGL((conv3x3_halo_split_kernel<P_, PROJ_, UP2_>), grid, block, 0, stream, x, (const uint4*)packed, bias, y, N, H, W, Cin, Cout, act, tiles_n, x_absmax, wamax, y_absmax, \
                      pw, pb, pout, pco, tap_masks, s2_out)
-#define LADDER_SPLIT_LAUNCH_(P_, PROJ_) do { if (s2_out == 2) LADDER_SPLIT_LAUNCH__(P_, PROJ_, true); else LADDER_SPLIT_LAUNCH__(P_, PROJ_, false); } while (0)
+#define LADDER_SPLIT_LAUNCH_(P_, PROJ_) do { if (s2_out >= 2) LADDER_SPLIT_LAUNCH__(P_, PROJ_, true); else LADDER_SPLIT_LAUNCH__(P_, PROJ_, false); } while (0)
 #define LADDER_SPLIT_LAUNCH(P_) do { if (pout != nullptr) LADDER_SPLIT_LAUNCH_(P_, true); else LADDER_SPLIT_LAUNCH_(P_, false); } while (0)
 #define LADDER_SPLIT16_LAUNCH_(P_, PROJ_, UP2_) \
   hipLaunchKernelGGL((conv3x3_halo_split16_kernel<P_, PROJ_, UP2_>), dim3(N * (H / F_H) * (W / SP_W) * tiles_n), dim3(F_THREADS), 0, stream, x, (const uint4*)packed, bias, y, N, H, W, Cin, Cout, act, tiles_n, x_absmax, wamax, y_absmax, \
                      pw, pb, pout, pco, tap_masks, s2_out)
-#define LADDER_SPLIT16_LAUNCH(P_, PROJ_) do { if (s2_out == 2) LADDER_SPLIT16_LAUNCH_(P_, PROJ_, true); else LADDER_SPLIT16_LAUNCH_(P_, PROJ_, false); } while (0)
+#define LADDER_SPLIT16_LAUNCH(P_, PROJ_) do { if (s2_out >= 2) LADDER_SPLIT16_LAUNCH_(P_, PROJ_, true); else LADDER_SPLIT16_LAUNCH_(P_, PROJ_, false); } while (0)
   if (split_halo16_ok(N, H, W, Cin, Cout, prec)) {
     if (pout != nullptr) {
       if (prec == LADDER_PREC_F16X3) LADDER_SPLIT16_LAUNCH(LADDER_PREC_F16X3, true); else LADDER_SPLIT16_LAUNCH(LADDER_PREC_BF16X3, true);
@@ -1373,19 +1380,19 @@ int ladder_conv3x3_up2_split_eligible(int N, int H, int W, int Cin, int Cout, in
 }
 
 int ladder_conv3x3_up2_split(const float* x, const float* x_absmax, const void* packed_up2, const float* bias, float* y, float* y_absmax,
-                             int N, int H, int W, int Cin, int Cout, int act, int prec, ladder_stream_t stream) {
+                             int N, int H, int W, int Cin, int Cout, int act, int prec, int x_upsampled, ladder_stream_t stream) {
   if (!ladder_conv3x3_up2_split_eligible(N, H, W, Cin, Cout, prec)) return LADDER_E_SHAPE;
   return conv3x3_split_launch(x, x_absmax, packed_up2, bias, y, y_absmax, nullptr, nullptr, nullptr, 0, N, H, W, Cin, 4 * SP_BN, act, prec,
-                              stream, up2_tap_masks(), 2);
+                              stream, up2_tap_masks(), x_upsampled ? 3 : 2);
 }
 
 // ... with the 1x1 projection of ladder_conv3x3_split_proj fused behind it (y may be NULL in forward-only runs)
 int ladder_conv3x3_up2_split_proj(const float* x, const float* x_absmax, const void* packed_up2, const float* bias, float* y, const float* proj_w,
                                   const float* proj_b, float* proj_out, int proj_cout, int N, int H, int W, int Cin, int Cout, int act, int prec,
-                                  ladder_stream_t stream) {
+                                  int x_upsampled, ladder_stream_t stream) {
   if (!ladder_conv3x3_up2_split_eligible(N, H, W, Cin, Cout, prec) || proj_out == nullptr || prec_planes(prec) != 2) return LADDER_E_SHAPE;
   return conv3x3_split_launch(x, x_absmax, packed_up2, bias, y, nullptr, proj_w, proj_b, proj_out, proj_cout, N, H, W, Cin, 4 * SP_BN, act, prec,
-                              stream, up2_tap_masks(), 2);
+                              stream, up2_tap_masks(), x_upsampled ? 3 : 2);
 }
 
 static size_t up2_align(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -1402,7 +1409,7 @@ size_t ladder_conv3x3_up2_edges_workspace_bytes(int N, int H, int W, int Cin, in
 // pout (with pw [Cout][pco], pb [pco]) receive them, the per-sample record y_absmax (already written by the main launch) is raised where an
 // edge value exceeds it.
 int ladder_conv3x3_up2_edges(const float* x, const float* w, const float* bias, float* y, float* y_absmax, const float* pw, const float* pb,
-                             float* pout, int pco, int N, int H, int W, int Cin, int Cout, int act, void* ws, size_t ws_bytes,
+                             float* pout, int pco, int N, int H, int W, int Cin, int Cout, int act, int x_upsampled, void* ws, size_t ws_bytes,
                              ladder_stream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin % 4) != 0 || Cout <= 0 || (y == nullptr && pout == nullptr)) return LADDER_E_SHAPE;
   if (pout != nullptr && (pw == nullptr || pco < 1 || pco > 4)) return LADDER_E_SHAPE;
@@ -1417,7 +1424,7 @@ int ladder_conv3x3_up2_edges(const float* x, const float* w, const float* bias, 
   float* e_row = (float*)p; p += up2_align(mr * Cout * 4);
   float* e_col = (float*)p; p += up2_align(mc * Cout * 4);
   const size_t g = ws_bytes - (size_t)(p - (char*)ws);
-  hipLaunchKernelGGL(up2_edge_operands_kernel, dim3(1024), dim3(256), 0, stream, x, w, u_row, v_col, w_row, w_col, N, H, W, Cin, Cout);
+  hipLaunchKernelGGL(up2_edge_operands_kernel, dim3(1024), dim3(256), 0, stream, x, w, u_row, v_col, w_row, w_col, N, H, W, Cin, Cout, x_upsampled ? 2 : 1);
   int rc = ladder_conv2d_fwd(u_row, w_row, bias, e_row, N, 1, 2 * W, Cin, 1, 2 * W, Cout, 1, 3, 1, 0, 1, act, p, g, stream);
   if (rc != LADDER_OK) return rc;
   rc = ladder_conv2d_fwd(v_col, w_col, bias, e_col, N, 2 * H, 1, Cin, 2 * H, 1, Cout, 3, 1, 1, 1, 0, act, p, g, stream);

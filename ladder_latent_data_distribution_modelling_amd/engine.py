@@ -514,35 +514,44 @@ class Conv2D:
         return bool(self.ctx.up2 and self.ctx.ns in (2, 4) and self.k == 3 and self.stride == 1 and self.padding == "same"
                     and L.query("ladder_conv3x3_up2_split_eligible", N, H, W, self.cin, self.cout, self.ctx.ns))
 
-    def forward_up2(self, x, proj=None):
-        """conv(resize2x(x)) from x itself; with `proj` the 1x1 output conv rides on the epilogue as in forward_fused_proj (the 128-channel
-        map is then not written).  Forward-only: nothing is kept for a backward pass."""
+    def forward_up2(self, x, proj=None, upsampled=None, keep_y=False):
+        """conv(resize2x(x)) from x itself; with `proj` the 1x1 output conv rides on the epilogue as in forward_fused_proj.  Forward-only runs
+        pass the low-resolution x and keep nothing.  A training forward passes `upsampled` = the resized tensor it has to keep for the
+        backward pass anyway (its even rows / columns ARE the low-resolution map): the kernel reads that sub-grid, and x / y are kept
+        exactly as forward_fused_proj keeps them."""
         ctx = self.ctx
-        N, H, W, _ = x.shape
+        src = x if upsampled is None else upsampled
+        N, H, W = (x.shape[0], x.shape[1], x.shape[2]) if upsampled is None else (upsampled.shape[0], upsampled.shape[1] // 2, upsampled.shape[2] // 2)
+        strided = 0 if upsampled is None else 1
         self.pt = self.pl = 1
         bias, wk = self.ps.w[self.name + "/bias"], self.ps.w[self.name + "/kernel"]
-        x_amax = ctx.absmax(x)
+        x_amax = ctx.absmax(src)                                         # (max |upsampled| = max |x|: the resize is a convex combination)
         flops = 2.0 * N * 4 * H * W * 9 * self.cin * self.cout          # the reference's operation count (algorithmic), not the 25/36 executed
         wsp, wsn = ctx.ws(L.query("ladder_conv3x3_up2_edges_workspace_bytes", N, H, W, self.cin, self.cout))
         if proj is not None:
+            proj.pt = proj.pl = 0
+            y = ctx.empty(N, 2 * H, 2 * W, self.cout) if keep_y else None
             out = ctx.empty(N, 2 * H, 2 * W, proj.cout)
             pw, pb = self.ps.w[proj.name + "/kernel"], self.ps.w[proj.name + "/bias"]
             _timed(256120 + ctx.ns, flops, "ladder_conv3x3_up2_split_proj",
-                   (_p(x), _p(x_amax), _p(self._packed_filter(3)), _p(bias), None, _p(pw), _p(pb), _p(out), proj.cout, N, H, W, self.cin, self.cout,
-                    L.ACT[self.act], ctx.ns, ctx.stream))
-            L.call("ladder_conv3x3_up2_edges", _p(x), _p(wk), _p(bias), None, None, _p(pw), _p(pb), _p(out), proj.cout, N, H, W, self.cin, self.cout,
-                   L.ACT[self.act], wsp, wsn, ctx.stream)
-            self.x = self.y = proj.x = proj.y = None
+                   (_p(src), _p(x_amax), _p(self._packed_filter(3)), _p(bias), _p(y), _p(pw), _p(pb), _p(out), proj.cout, N, H, W, self.cin, self.cout,
+                    L.ACT[self.act], ctx.ns, strided, ctx.stream))
+            L.call("ladder_conv3x3_up2_edges", _p(src), _p(wk), _p(bias), _p(y), None, _p(pw), _p(pb), _p(out), proj.cout, N, H, W, self.cin, self.cout,
+                   L.ACT[self.act], strided, wsp, wsn, ctx.stream)
+            self.x_amax = x_amax if keep_y else None
+            self.x, self.y = (upsampled, y) if keep_y else (None, None)
+            proj.x, proj.y = (y, out) if keep_y else (None, None)
             return out
         y = ctx.empty(N, 2 * H, 2 * W, self.cout)
         y_amax = ctx.new_amax() if ctx.ns == 4 else None
         _timed(256120 + ctx.ns, flops, "ladder_conv3x3_up2_split",
-               (_p(x), _p(x_amax), _p(self._packed_filter(3)), _p(bias), _p(y), _p(y_amax), N, H, W, self.cin, self.cout, L.ACT[self.act], ctx.ns,
-                ctx.stream))
-        L.call("ladder_conv3x3_up2_edges", _p(x), _p(wk), _p(bias), _p(y), _p(y_amax), None, None, None, 0, N, H, W, self.cin, self.cout,
-               L.ACT[self.act], wsp, wsn, ctx.stream)
+               (_p(src), _p(x_amax), _p(self._packed_filter(3)), _p(bias), _p(y), _p(y_amax), N, H, W, self.cin, self.cout, L.ACT[self.act], ctx.ns,
+                strided, ctx.stream))
+        L.call("ladder_conv3x3_up2_edges", _p(src), _p(wk), _p(bias), _p(y), _p(y_amax), None, None, None, 0, N, H, W, self.cin, self.cout,
+               L.ACT[self.act], strided, wsp, wsn, ctx.stream)
         ctx.set_amax(y, y_amax)
-        self.x = self.y = None
+        self.x_amax = x_amax if keep_y else None
+        self.x, self.y = (upsampled, y) if keep_y else (None, None)
         return y
 
     def forward(self, x):
@@ -1102,21 +1111,30 @@ class CelebADecoder:
         dlatent = d
         h = self.up0.forward(self.conv0.forward(encoded.view(B, 1, 1, self.nh)))
         lowres = False            # h is the LOW-resolution input of a factor-2 resize that the next conv applies itself (forward-only runs)
+        upsampled_from_prev = False   # h is the output of a factor-2 legacy-bilinear resize (fused with the instance norm in front of it)
         for bi, (conv, sty, norm, rs) in enumerate(self.blocks):
+            from_up, upsampled_from_prev = upsampled_from_prev, False
+            conv_done = False
             if lowres:
                 lowres = False
                 last = bi == len(self.blocks) - 1 and norm is None and (rs is None or (rs.oh, rs.ow) == (2 * h.shape[1], 2 * h.shape[2]))
                 if last:
                     return conv.forward_up2(h, self.conv_out)
                 h = conv.forward_up2(h)
+                conv_done = True
             elif bi == len(self.blocks) - 1 and norm is None and (rs is None or (rs.oh, rs.ow) == tuple(h.shape[1:3])):
+                if from_up and self.ctx.keep_activations and conv.up2_ok(h.shape[0], h.shape[1] // 2, h.shape[2] // 2):
+                    # training forward: h = the resized tensor (kept for the backward pass); the convolution reads its even sub-grid
+                    if rs is not None:
+                        rs.in_shape = tuple(h.shape[:3]) + (conv.cout,)
+                    return conv.forward_up2(None, self.conv_out, upsampled=h, keep_y=True)
                 # the last 3x3 conv feeds the 1x1 output conv directly (its resize is the identity): one fused launch
                 out = conv.forward_fused_proj(h, self.conv_out, keep_y=self.ctx.keep_activations)
                 if out is not None:
                     if rs is not None:
                         rs.in_shape = tuple(h.shape[:3]) + (conv.cout,)
                     return out
-            else:
+            if not conv_done:
                 h = conv.forward(h)
             # the resize behind this block folds into the NEXT conv when that one can take the low-resolution tensor (forward-only runs)
             nxt = self.blocks[bi + 1][0] if bi + 1 < len(self.blocks) else None
@@ -1127,6 +1145,7 @@ class CelebADecoder:
                 up = norm.forward_resized(h, style, rs) if (rs is not None and not fold) else None
                 if up is not None:
                     h = up
+                    upsampled_from_prev = True
                     continue
                 h = norm.forward(h, style)
             if fold:

@@ -48,14 +48,14 @@ def test_up2_conv_vs_oracle(gpu_ctx, case):
     pk = _pack_up2(L, w, Cin, P, st)
     y = torch.full((N, 2 * H, 2 * W, 128), float("nan"), device="cuda")
     yrec = torch.empty(L.ABSMAX_FLOATS, device="cuda")
-    L.call("ladder_conv3x3_up2_split", p(xd), p(rec), p(pk), p(bd), p(y), p(yrec), N, H, W, Cin, 128, 1 if act else 0, P, st)
+    L.call("ladder_conv3x3_up2_split", p(xd), p(rec), p(pk), p(bd), p(y), p(yrec), N, H, W, Cin, 128, 1 if act else 0, P, 0, st)
     torch.cuda.synchronize()
     _, ref = _ref(x, w, b, act)
     close(y[:, :-1, :-1], ref[:, :-1, :-1], TOL[prec][0], "up2 interior")
     # the last output row / column: recomputed in fp32 from the last row / column of x
     ws = torch.empty(L.query("ladder_conv3x3_up2_edges_workspace_bytes", N, H, W, Cin, 128), dtype=torch.uint8, device="cuda")
     wd = dev(w)
-    L.call("ladder_conv3x3_up2_edges", p(xd), p(wd), p(bd), p(y), p(yrec), None, None, None, 0, N, H, W, Cin, 128, 1 if act else 0,
+    L.call("ladder_conv3x3_up2_edges", p(xd), p(wd), p(bd), p(y), p(yrec), None, None, None, 0, N, H, W, Cin, 128, 1 if act else 0, 0,
            p(ws), ws.numel(), st)
     torch.cuda.synchronize()
     close(y, ref, TOL[prec][0], "up2 full map")
@@ -67,13 +67,14 @@ def test_up2_conv_vs_oracle(gpu_ctx, case):
         assert rec_sample(yrec, n) <= float(np.abs(ref[n]).max()) * 16      # (wrong pre-fix edge values may have raised it: still a bound)
 
 
-@pytest.mark.parametrize("case", [(64, 16, 32, 32, "f16x3", True), (16, 64, 64, 32, "f16x3", False), (64, 16, 32, 32, "bf16x3", True)],
-                         ids=lambda c: "n%d_%dx%d_c%d_%s_y%d" % c)
+@pytest.mark.parametrize("case", [(64, 16, 32, 32, "f16x3", True, 0), (16, 64, 64, 32, "f16x3", False, 0), (64, 16, 32, 32, "bf16x3", True, 0),
+                                  (64, 16, 32, 32, "f16x3", True, 1), (16, 64, 64, 32, "f16x3", True, 1)],
+                         ids=lambda c: "n%d_%dx%d_c%d_%s_y%d_ups%d" % c)
 def test_up2_conv_with_fused_projection_vs_oracle(gpu_ctx, case):
     """ladder_conv3x3_up2_split_proj + edges: the decoder's last two layers (conv2d_7 leaky + the 1x1 RGB conv2d_8, codes/models.py:571-587)
     from the 64x64-type map, with and without materialising the 128-channel map (forward-only runs do not)."""
     L = _lib()
-    N, H, W, Cin, prec, keep_y = case
+    N, H, W, Cin, prec, keep_y, ups = case
     P, st = PREC[prec], gpu_ctx.stream
     rng = np.random.default_rng(H + Cin)
     x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
@@ -83,12 +84,16 @@ def test_up2_conv_with_fused_projection_vs_oracle(gpu_ctx, case):
     pb_ = rng.standard_normal(3).astype(np.float32) * 0.1
     xd, bd, wd, pwd, pbd = dev(x), dev(b), dev(w), dev(pw_), dev(pb_)
     rec = absmax_samples(L, xd, st)
+    # ups: the kernels read the low-resolution map as the even sub-grid of the materialised upsample (what a training forward keeps)
+    src = dev(O.resize_bilinear_legacy(torch.as_tensor(x), 2 * H, 2 * W).numpy()) if ups else xd
+    if ups:
+        assert torch.equal(src[:, ::2, ::2], xd)
     pk = _pack_up2(L, w, Cin, P, st)
     y = torch.full((N, 2 * H, 2 * W, 128), float("nan"), device="cuda") if keep_y else None
     out = torch.full((N, 2 * H, 2 * W, 3), float("nan"), device="cuda")
-    L.call("ladder_conv3x3_up2_split_proj", p(xd), p(rec), p(pk), p(bd), p(y), p(pwd), p(pbd), p(out), 3, N, H, W, Cin, 128, 1, P, st)
+    L.call("ladder_conv3x3_up2_split_proj", p(src), p(rec), p(pk), p(bd), p(y), p(pwd), p(pbd), p(out), 3, N, H, W, Cin, 128, 1, P, ups, st)
     ws = torch.empty(L.query("ladder_conv3x3_up2_edges_workspace_bytes", N, H, W, Cin, 128), dtype=torch.uint8, device="cuda")
-    L.call("ladder_conv3x3_up2_edges", p(xd), p(wd), p(bd), p(y), None, p(pwd), p(pbd), p(out), 3, N, H, W, Cin, 128, 1, p(ws), ws.numel(), st)
+    L.call("ladder_conv3x3_up2_edges", p(src), p(wd), p(bd), p(y), None, p(pwd), p(pbd), p(out), 3, N, H, W, Cin, 128, 1, ups, p(ws), ws.numel(), st)
     torch.cuda.synchronize()
     _, ref = _ref(x, w, b, "leaky_relu")
     refp = ref @ pw_.astype(np.float64) + pb_.astype(np.float64)
