@@ -100,3 +100,64 @@ def test_up2_conv_with_fused_projection_vs_oracle(gpu_ctx, case):
     close(out, refp, TOL[prec][0], "projection")
     if keep_y:
         close(y, ref, TOL[prec][0], "map")
+
+
+def test_engine_uses_upsample_fused_convs_and_agrees_with_direct_path(monkeypatch):
+    """The full-resolution CelebA net at batch 8 with `upsample_fused_convs` on / off: the training forward (conv2d_7 on the kept upsample) and
+    the forward-only runs (conv2d_6 and conv2d_7 from the low-resolution maps, no resized tensors) must call the up2 entry points, and
+    every RUN#1 fetch, the decoded image, the sigma step and every gradient must agree with the direct path to fp32-class error."""
+    import json, os
+    from ladder_latent_data_distribution_modelling_amd import _lib as L
+    from ladder_latent_data_distribution_modelling_amd.engine import LadderEngine
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = json.load(open(os.path.join(root, "codes", "celeba_config.json")))
+    cfg["batch_size"] = B = 8
+    rng = np.random.default_rng(31)
+    x = rng.random((B, 128, 128, 3)).astype(np.float32)
+    Pm = O.init_params(cfg, seed=7)
+    noise = O.make_noise(cfg, B, rng, np.float32)
+    fix = np.load(os.path.join(root, "tests", "golden", "GM_prior_info.npz"))
+    K = int(cfg["n_mixtures"])
+    gm = (fix["w_full"][:K] / fix["w_full"][:K].sum(), fix["m_full"][:K], fix["K_full"][:K])
+    calls, real = [], L.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real(name, *a)
+
+    monkeypatch.setattr(L, "call", spy)
+    res = {}
+    for up2 in (0, 1):
+        eng = LadderEngine(dict(cfg, upsample_fused_convs=up2), "cuda:0", values=Pm, seed=1)
+        eng.set_mixture(*gm)
+        del calls[:]
+        eng.run_ae(x, 0.0, noise, False, False)
+        train_calls = list(calls)
+        f = eng.fetch()
+        grads = {k: v.detach().cpu().numpy().copy() for k, v in eng.ps.g.items()}
+        del calls[:]
+        eng.evaluate(x, noise, False, False)
+        eval_calls = list(calls)
+        ev = eng.fetch()
+        dec = eng.xhat.detach().cpu().numpy().copy()
+        res[up2] = (f, grads, ev, dec, train_calls, eval_calls)
+    f0, g0, e0, d0, tc0, ec0 = res[0]
+    f1, g1, e1, d1, tc1, ec1 = res[1]
+    assert not any("up2" in c for c in tc0 + ec0)
+    assert tc1.count("ladder_conv3x3_up2_split_proj") == 1 and "ladder_in_style_fwd_resize2x" in tc1      # training: the upsample is kept
+    n6 = ec1.count("ladder_conv3x3_up2_split")            # conv2d_6 (32x32 -> 64x64) joins from batch 32 on (>= 512 workgroups); batch 8: conv2d_7 only
+    assert ec1.count("ladder_conv3x3_up2_split_proj") == 1 and n6 in (0, 1) and ec1.count("ladder_conv3x3_up2_edges") == 1 + n6
+    assert ec1.count("ladder_in_style_fwd_resize2x") == ec0.count("ladder_in_style_fwd_resize2x") - 1        # the 64 -> 128 resize is gone
+    assert ec1.count("ladder_resize_bilinear_fwd") == ec0.count("ladder_resize_bilinear_fwd") - n6           # ... and the 32 -> 64 one
+    for k in ("elbo", "l1_reconstruction_error", "l2_reconstruction_error", "loss_ae", "sigma", "mean_pixel_error"):
+        assert abs(f1[k] - f0[k]) <= 2e-5 * abs(f0[k]) + 1e-6, (k, f1[k], f0[k])
+    for k in e0:
+        if isinstance(e0[k], float):
+            assert abs(e1[k] - e0[k]) <= 2e-5 * abs(e0[k]) + 1e-6, (k, e1[k], e0[k])
+    close(d1, d0, 2e-5, "decoded image")
+    worst = 0.0
+    for name in g0:
+        sc = np.abs(g0[name]).max()
+        if sc > 1e-9:
+            worst = max(worst, np.abs(g1[name] - g0[name]).max() / sc)
+    assert worst < 2e-4, worst
