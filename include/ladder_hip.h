@@ -10,8 +10,8 @@
  * Conventions (all exports):
  *   - extern "C", returns int: 0 = LADDER_OK, <0 = LADDER_E_*.  Never throws, never
  *     allocates, never synchronises the device, keeps no global mutable state.
- *     (Test-only exception: seven environment variables, read ONCE per process on first use, switch a specialised kernel family off so that
- *     tests can compare it with the generic path in situ -- LADDER_DISABLE_HALO, LADDER_DISABLE_HALO16, LADDER_DISABLE_S2HALO, LADDER_DISABLE_GEMM16,
+ *     (Test-only exception: eight environment variables, read ONCE per process on first use, switch a specialised kernel family off so that
+ *     tests can compare it with the generic path in situ -- LADDER_DISABLE_HALO, LADDER_DISABLE_HALO16, LADDER_DISABLE_S2HALO, LADDER_DISABLE_UP2, LADDER_DISABLE_GEMM16,
  *     LADDER_DISABLE_SMALLCIN, LADDER_DISABLE_COUT1, LADDER_DISABLE_SMALLCOUT.  They select between kernels with identical
  *     semantics, are never written by the library, and nothing in the product path sets them.)
  *   - every pointer is CALLER-OWNED DEVICE memory, fp32 unless stated, dense row-major,

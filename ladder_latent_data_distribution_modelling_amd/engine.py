@@ -43,18 +43,22 @@ class KernelProfiler:
     def __init__(self):
         self.records = {}
 
-    def add(self, kid, s, e, flops):
-        self.records.setdefault(kid, []).append((s, e, flops))
+    def add(self, kid, s, e, flops, executed=None):
+        """`flops` = the reference's operation count of the launch (algorithmic); `executed` = what the kernel issues when that is less
+        (the upsample-fused convolutions: 25 of the 36 low-resolution tap products per 2x2 output block)."""
+        self.records.setdefault(kid, []).append((s, e, flops, flops if executed is None else executed))
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
         for kid, recs in self.records.items():
-            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
-            fl = sum(f for _, _, f in recs)
+            ms = sum(s.elapsed_time(e) for s, e, _, _ in recs)
+            fl = sum(f for _, _, f, _ in recs)
+            fx = sum(x for _, _, _, x in recs)
             n = len(recs)
             out[kid] = dict(kernel=self.NAMES.get(kid, "igemm tile %d" % kid), launches=n, total_ms=ms, avg_ms=ms / n,
                             flops_per_launch=fl / n, tflops=(fl / (ms * 1e-3) / 1e12) if ms > 0 else 0.0,
+                            executed_flops_per_launch=fx / n, executed_tflops=(fx / (ms * 1e-3) / 1e12) if ms > 0 else 0.0,
                             bound="latency" if kid in self.LATENCY_BOUND else "mfma")
         return out
 
@@ -108,7 +112,7 @@ def _igemm(ctx, name, M, Cin, Cout, Kdim, *args, conv=None):
         L.call(name, *args)
 
 
-def _timed(kid, flops, name, args):
+def _timed(kid, flops, name, args, executed=None):
     """One launch, bracketed by HIP events on the launch stream when a profiler is installed (bench.py's roofline leg)."""
     if PROF is None:
         L.call(name, *args)
@@ -117,7 +121,7 @@ def _timed(kid, flops, name, args):
     s.record()
     L.call(name, *args)
     e.record()
-    PROF.add(kid, s, e, flops)
+    PROF.add(kid, s, e, flops, executed)
 
 
 class Comm:
@@ -202,6 +206,7 @@ class Ctx:
         self._ws_aux = None
         self.keep_activations = True   # False inside forward-only runs: fused kernels may skip writing tensors only a backward pass reads
         self.ns = 0          # LADDER_PREC_* of the split-precision contraction kernels (0 = native f32 MFMA); set by the engine
+        self.up2_used = {}   # layer name -> number of upsample-fused launches so far (bench.py's executed-FLOP model)
         self.up2 = True      # resize -> 3x3 conv pairs of the decoder as ONE upsample-fused convolution in forward-only runs (config `upsample_fused_convs`)
 
     @property
@@ -526,7 +531,9 @@ class Conv2D:
         self.pt = self.pl = 1
         bias, wk = self.ps.w[self.name + "/bias"], self.ps.w[self.name + "/kernel"]
         x_amax = ctx.absmax(src)                                         # (max |upsampled| = max |x|: the resize is a convex combination)
-        flops = 2.0 * N * 4 * H * W * 9 * self.cin * self.cout          # the reference's operation count (algorithmic), not the 25/36 executed
+        flops = 2.0 * N * 4 * H * W * 9 * self.cin * self.cout          # the reference's operation count (algorithmic) ...
+        executed = flops * 25.0 / 36.0                                   # ... of which 25 / 36 are issued
+        ctx.up2_used[self.name] = ctx.up2_used.get(self.name, 0) + 1
         wsp, wsn = ctx.ws(L.query("ladder_conv3x3_up2_edges_workspace_bytes", N, H, W, self.cin, self.cout))
         if proj is not None:
             proj.pt = proj.pl = 0
@@ -535,7 +542,7 @@ class Conv2D:
             pw, pb = self.ps.w[proj.name + "/kernel"], self.ps.w[proj.name + "/bias"]
             _timed(256120 + ctx.ns, flops, "ladder_conv3x3_up2_split_proj",
                    (_p(src), _p(x_amax), _p(self._packed_filter(3)), _p(bias), _p(y), _p(pw), _p(pb), _p(out), proj.cout, N, H, W, self.cin, self.cout,
-                    L.ACT[self.act], ctx.ns, strided, ctx.stream))
+                    L.ACT[self.act], ctx.ns, strided, ctx.stream), executed)
             L.call("ladder_conv3x3_up2_edges", _p(src), _p(wk), _p(bias), _p(y), None, _p(pw), _p(pb), _p(out), proj.cout, N, H, W, self.cin, self.cout,
                    L.ACT[self.act], strided, wsp, wsn, ctx.stream)
             self.x_amax = x_amax if keep_y else None
@@ -546,7 +553,7 @@ class Conv2D:
         y_amax = ctx.new_amax() if ctx.ns == 4 else None
         _timed(256120 + ctx.ns, flops, "ladder_conv3x3_up2_split",
                (_p(src), _p(x_amax), _p(self._packed_filter(3)), _p(bias), _p(y), _p(y_amax), N, H, W, self.cin, self.cout, L.ACT[self.act], ctx.ns,
-                strided, ctx.stream))
+                strided, ctx.stream), executed)
         L.call("ladder_conv3x3_up2_edges", _p(src), _p(wk), _p(bias), _p(y), _p(y_amax), None, None, None, 0, N, H, W, self.cin, self.cout,
                L.ACT[self.act], strided, wsp, wsn, ctx.stream)
         ctx.set_amax(y, y_amax)
