@@ -364,6 +364,9 @@ int ladder_in_style_bwd_absmax(const float* dy, const float* x, const float* sty
  * normalised tensor is never written.  C % 4 == 0, workspace required; up_absmax (may be NULL) receives the record of max|up|. */
 int ladder_in_style_fwd_resize2x(const float* x, const float* style, float* up, float* mean_rstd, int N, int H, int W, int C, float eps,
                                  int act, void* ws, size_t ws_bytes, float* up_absmax, ladder_stream_t stream);
+/* the same, also writing the normalised / styled / activated tensor y [N, H, W, C] itself (= the even rows and columns of `up`; may be NULL) */
+int ladder_in_style_fwd_resize2x_keep(const float* x, const float* style, float* up, float* y, float* mean_rstd, int N, int H, int W, int C,
+                                      float eps, int act, void* ws, size_t ws_bytes, float* up_absmax, ladder_stream_t stream);
 
 /* ---------------------------------------------------------------- N6: tf.image.resize_images (TF1 legacy bilinear)
  * codes/models.py:519,538,544,555,561,572,578.  align_corners=False, half_pixel_centers=False;

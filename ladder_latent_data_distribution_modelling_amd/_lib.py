@@ -152,6 +152,7 @@ PROTOTYPES = {
     "ladder_bn_bwd_apply_absmax": (_i, [_p, _p, _p, _p, _p, _p, _d, _p, _p, _p, _z, _i, _i, _p, _p]),
     "ladder_in_style_fwd_absmax": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _z, _p, _p]),
     "ladder_in_style_fwd_resize2x": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _z, _p, _p]),
+    "ladder_in_style_fwd_resize2x_keep": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _z, _p, _p]),
     "ladder_in_style_bwd_absmax": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _z, _p, _p]),
     "ladder_conv1x1_smallcout_bwd_absmax": (_i, [_p, _p, _p, _p, _p, _p, C.c_long, _i, _i, _i, _p, _z, _p, C.c_long, _p]),
     "ladder_absmax": (_i, [_p, _z, _p, _p]),

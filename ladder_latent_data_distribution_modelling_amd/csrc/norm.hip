@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(const float* __restrict
 // writing `up` (4x the input).  The record receives max|y| (a bilinear interpolation is a convex combination).
 __global__ __launch_bounds__(256) void in_apply_resize2x_kernel(const float* __restrict__ x, const float* __restrict__ style,
                                                                 const float* __restrict__ mean_rstd, float* __restrict__ up, int H, int W,
-                                                                int C, int act, float* __restrict__ yamax) {
+                                                                int C, int act, float* __restrict__ yamax, float* __restrict__ lo) {
   const int CV = C >> 2;
   const int n = blockIdx.y;
   const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;          // over H * W * CV
@@ -720,6 +720,7 @@ __global__ __launch_bounds__(256) void in_apply_resize2x_kernel(const float* __r
     const int OW = 2 * W;
     float* o = up + (((size_t)n * 2 * H + 2 * iy) * OW + 2 * ix) * C + c;
     *reinterpret_cast<float4*>(o) = tl;
+    if (lo != nullptr) *reinterpret_cast<float4*>(lo + (((size_t)n * H + iy) * W + ix) * C + c) = tl;      // the normalised tensor itself (= up[2i][2j])
     *reinterpret_cast<float4*>(o + C) = top;
     *reinterpret_cast<float4*>(o + (size_t)OW * C) = rz_lerp(tl, bl, 0.5f);
     *reinterpret_cast<float4*>(o + (size_t)OW * C + C) = rz_lerp(top, bot, 0.5f);
@@ -1092,7 +1093,15 @@ int ladder_in_style_fwd_absmax(const float* x, const float* style, float* y, flo
 // written.  Needs the vectorised path (C % 4 == 0, workspace, 16-byte alignment).
 int ladder_in_style_fwd_resize2x(const float* x, const float* style, float* up, float* mean_rstd, int N, int H, int W, int C, float eps,
                                  int act, void* ws, size_t ws_bytes, float* up_absmax, ladder_stream_t stream) {
+  return ladder_in_style_fwd_resize2x_keep(x, style, up, nullptr, mean_rstd, N, H, W, C, eps, act, ws, ws_bytes, up_absmax, stream);
+}
+
+// ... and, optionally, the normalised tensor y [N, H, W, C] beside it (a quarter of `up`, written in the same pass): the input of the
+// upsample-fused convolution of a training forward (ladder_conv3x3_up2_split), which would otherwise gather it out of the 4x larger tensor.
+int ladder_in_style_fwd_resize2x_keep(const float* x, const float* style, float* up, float* y, float* mean_rstd, int N, int H, int W, int C,
+                                      float eps, int act, void* ws, size_t ws_bytes, float* up_absmax, ladder_stream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return LADDER_E_SHAPE;
+  if (y != nullptr && !ladder_aligned16(y)) return LADDER_E_ALIGN;
   const int HW = H * W;
   if (!(C % 4 == 0 && ws != nullptr && ws_bytes >= ladder_in_style_workspace_bytes(N, HW, C) && ladder_aligned16(x) && ladder_aligned16(up)))
     return LADDER_E_SHAPE;
@@ -1102,7 +1111,7 @@ int ladder_in_style_fwd_resize2x(const float* x, const float* style, float* up, 
   hipLaunchKernelGGL(in_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, stream, x, (const float*)ws, mean_rstd, N, HW, C, sp, eps, up_absmax);
   const long units = (long)HW * (C / 4);
   hipLaunchKernelGGL(in_apply_resize2x_kernel, dim3((unsigned)((units + 255) / 256), N), dim3(256), 0, stream, x, style,
-                     (const float*)mean_rstd, up, H, W, C, act, up_absmax);
+                     (const float*)mean_rstd, up, H, W, C, act, up_absmax, y);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

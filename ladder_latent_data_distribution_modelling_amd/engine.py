@@ -519,15 +519,16 @@ class Conv2D:
         return bool(self.ctx.up2 and self.ctx.ns in (2, 4) and self.k == 3 and self.stride == 1 and self.padding == "same"
                     and L.query("ladder_conv3x3_up2_split_eligible", N, H, W, self.cin, self.cout, self.ctx.ns))
 
-    def forward_up2(self, x, proj=None, upsampled=None, keep_y=False):
-        """conv(resize2x(x)) from x itself; with `proj` the 1x1 output conv rides on the epilogue as in forward_fused_proj.  Forward-only runs
-        pass the low-resolution x and keep nothing.  A training forward passes `upsampled` = the resized tensor it has to keep for the
-        backward pass anyway (its even rows / columns ARE the low-resolution map): the kernel reads that sub-grid, and x / y are kept
-        exactly as forward_fused_proj keeps them."""
+    def forward_up2(self, x, proj=None, keep_y=False, x_for_backward=None):
+        """conv(resize2x(x)) from the low-resolution x itself; with `proj` the 1x1 output conv rides on the epilogue as in forward_fused_proj.
+        Forward-only runs keep nothing.  A training forward (`keep_y`) passes `x_for_backward` = the resized tensor, which it has to keep for
+        the backward pass anyway (filter gradient and backward-data are those of the plain convolution on it): x / y are then kept exactly
+        as forward_fused_proj keeps them."""
         ctx = self.ctx
-        src = x if upsampled is None else upsampled
-        N, H, W = (x.shape[0], x.shape[1], x.shape[2]) if upsampled is None else (upsampled.shape[0], upsampled.shape[1] // 2, upsampled.shape[2] // 2)
-        strided = 0 if upsampled is None else 1
+        src = x
+        N, H, W = x.shape[0], x.shape[1], x.shape[2]
+        strided = 0
+        upsampled = x_for_backward
         self.pt = self.pl = 1
         bias, wk = self.ps.w[self.name + "/bias"], self.ps.w[self.name + "/kernel"]
         x_amax = ctx.absmax(src)                                         # (max |upsampled| = max |x|: the resize is a convex combination)
@@ -908,18 +909,26 @@ class InstanceNormStyleAct:
         self.x, self.style = x, style
         return y
 
-    def forward_resized(self, x, style, rs):
+    def forward_resized(self, x, style, rs, keep_lowres=False):
         """forward() followed by the factor-2 resize `rs` in ONE pass over x (ladder_in_style_fwd_resize2x): the normalised tensor is
-        never written; returns None when the pair is not eligible.  The backward passes are those of the two separate layers."""
+        never written -- unless `keep_lowres` (then it is left in self.y_lo: the input of an upsample-fused convolution behind the resize);
+        returns None when the pair is not eligible.  The backward passes are those of the two separate layers."""
         N, H, W, C = x.shape
+        self.y_lo = None
         if not (C % 4 == 0 and (rs.oh, rs.ow) == (2 * H, 2 * W)):
             return None
         up = self.ctx.empty(N, 2 * H, 2 * W, C)
         self.mean_rstd = self.ctx.empty(N, 2 * C)
         wsp, wsn = self.ctx.ws(L.query("ladder_in_style_workspace_bytes", N, H * W, C))
         up_amax = self.ctx.new_amax() if self.ctx.ns == 4 else None
-        L.call("ladder_in_style_fwd_resize2x", _p(x), _p(style), _p(up), _p(self.mean_rstd), N, H, W, C, IN_EPS, L.ACT[self.act], wsp, wsn,
-               _p(up_amax), self.ctx.stream)
+        if keep_lowres:
+            self.y_lo = self.ctx.empty(N, H, W, C)
+            L.call("ladder_in_style_fwd_resize2x_keep", _p(x), _p(style), _p(up), _p(self.y_lo), _p(self.mean_rstd), N, H, W, C, IN_EPS,
+                   L.ACT[self.act], wsp, wsn, _p(up_amax), self.ctx.stream)
+            self.ctx.set_amax(self.y_lo, up_amax)              # max |y| = max |up| (the record receives max |y|)
+        else:
+            L.call("ladder_in_style_fwd_resize2x", _p(x), _p(style), _p(up), _p(self.mean_rstd), N, H, W, C, IN_EPS, L.ACT[self.act], wsp, wsn,
+                   _p(up_amax), self.ctx.stream)
         self.ctx.set_amax(up, up_amax)
         self.x, self.style = x, style
         rs.in_shape = (N, H, W, C)
@@ -1118,9 +1127,9 @@ class CelebADecoder:
         dlatent = d
         h = self.up0.forward(self.conv0.forward(encoded.view(B, 1, 1, self.nh)))
         lowres = False            # h is the LOW-resolution input of a factor-2 resize that the next conv applies itself (forward-only runs)
-        upsampled_from_prev = False   # h is the output of a factor-2 legacy-bilinear resize (fused with the instance norm in front of it)
+        lowres_copy = None        # training forward: the low-resolution tensor behind h = its factor-2 upsample (kept for the backward pass)
         for bi, (conv, sty, norm, rs) in enumerate(self.blocks):
-            from_up, upsampled_from_prev = upsampled_from_prev, False
+            x_lo, lowres_copy = lowres_copy, None
             conv_done = False
             if lowres:
                 lowres = False
@@ -1130,11 +1139,11 @@ class CelebADecoder:
                 h = conv.forward_up2(h)
                 conv_done = True
             elif bi == len(self.blocks) - 1 and norm is None and (rs is None or (rs.oh, rs.ow) == tuple(h.shape[1:3])):
-                if from_up and self.ctx.keep_activations and conv.up2_ok(h.shape[0], h.shape[1] // 2, h.shape[2] // 2):
-                    # training forward: h = the resized tensor (kept for the backward pass); the convolution reads its even sub-grid
+                if x_lo is not None:
+                    # training forward: h = the resized tensor (kept for the backward pass); the convolution reads the low-resolution one
                     if rs is not None:
                         rs.in_shape = tuple(h.shape[:3]) + (conv.cout,)
-                    return conv.forward_up2(None, self.conv_out, upsampled=h, keep_y=True)
+                    return conv.forward_up2(x_lo, self.conv_out, keep_y=True, x_for_backward=h)
                 # the last 3x3 conv feeds the 1x1 output conv directly (its resize is the identity): one fused launch
                 out = conv.forward_fused_proj(h, self.conv_out, keep_y=self.ctx.keep_activations)
                 if out is not None:
@@ -1149,10 +1158,13 @@ class CelebADecoder:
                     and nxt.up2_ok(h.shape[0], h.shape[1], h.shape[2]))
             if norm is not None:
                 style = sty.forward(dlatent)
-                up = norm.forward_resized(h, style, rs) if (rs is not None and not fold) else None
+                # (training forward: the LAST conv reads the low-resolution tensor, written beside the resized one it keeps for backward)
+                want_lo = (self.ctx.up2 >= 2 and rs is not None and not fold and self.ctx.keep_activations and bi + 2 == len(self.blocks) and self.blocks[bi + 1][2] is None
+                           and (rs.oh, rs.ow) == (2 * h.shape[1], 2 * h.shape[2]) and nxt.up2_ok(h.shape[0], h.shape[1], h.shape[2]))
+                up = norm.forward_resized(h, style, rs, keep_lowres=want_lo) if (rs is not None and not fold) else None
                 if up is not None:
                     h = up
-                    upsampled_from_prev = True
+                    lowres_copy = norm.y_lo if want_lo else None
                     continue
                 h = norm.forward(h, style)
             if fold:
@@ -1274,7 +1286,7 @@ class LadderEngine:
         if prec not in PRECISIONS:
             raise ValueError("matmul_precision %r: expected one of %s" % (prec, sorted(PRECISIONS)))
         self.ctx.ns = PRECISIONS[prec]
-        self.ctx.up2 = bool(int(cfg.get("upsample_fused_convs", 1)))
+        self.ctx.up2 = int(cfg.get("upsample_fused_convs", 2))      # 0: off, 1: forward-only runs, 2: also the training forward of the last 3x3 conv
         self.precision = prec
         if self.ctx.comm.rank == 0:
             print("Contraction precision (config key matmul_precision): {} -- {}".format(prec, PRECISION_NOTES[prec]))

@@ -144,7 +144,7 @@ def test_engine_uses_upsample_fused_convs_and_agrees_with_direct_path(monkeypatc
     f0, g0, e0, d0, tc0, ec0 = res[0]
     f1, g1, e1, d1, tc1, ec1 = res[1]
     assert not any("up2" in c for c in tc0 + ec0)
-    assert tc1.count("ladder_conv3x3_up2_split_proj") == 1 and "ladder_in_style_fwd_resize2x" in tc1      # training: the upsample is kept
+    assert tc1.count("ladder_conv3x3_up2_split_proj") == 1 and "ladder_in_style_fwd_resize2x_keep" in tc1  # training: the upsample is kept, the low-resolution tensor written beside it
     n6 = ec1.count("ladder_conv3x3_up2_split")            # conv2d_6 (32x32 -> 64x64) joins from batch 32 on (>= 512 workgroups); batch 8: conv2d_7 only
     assert ec1.count("ladder_conv3x3_up2_split_proj") == 1 and n6 in (0, 1) and ec1.count("ladder_conv3x3_up2_edges") == 1 + n6
     assert ec1.count("ladder_in_style_fwd_resize2x") == ec0.count("ladder_in_style_fwd_resize2x") - 1        # the 64 -> 128 resize is gone
