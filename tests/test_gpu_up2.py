@@ -161,3 +161,26 @@ def test_engine_uses_upsample_fused_convs_and_agrees_with_direct_path(monkeypatc
         if sc > 1e-9:
             worst = max(worst, np.abs(g1[name] - g0[name]).max() / sc)
     assert worst < 2e-4, worst
+
+
+def test_in_style_resize2x_keep_writes_the_lowres_tensor(gpu_ctx):
+    """ladder_in_style_fwd_resize2x_keep: the normalised / styled / activated tensor beside its factor-2 upsample, in one pass -- bit-identical
+    to the separate instance-norm launch, and equal to the even rows / columns of the upsample."""
+    L = _lib()
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(9)
+    N, H, W, C = 6, 16, 32, 128
+    x = dev(rng.standard_normal((N, H, W, C)) * 3 + 0.5)
+    style = dev(rng.standard_normal((N, 2 * C)) * 0.3)
+    ws = torch.empty(L.query("ladder_in_style_workspace_bytes", N, H * W, C), dtype=torch.uint8, device="cuda")
+    up, up2_, y = torch.empty(N, 2 * H, 2 * W, C, device="cuda"), torch.empty(N, 2 * H, 2 * W, C, device="cuda"), torch.empty(N, H, W, C, device="cuda")
+    mr, mr2, mr3 = (torch.empty(N, 2 * C, device="cuda") for _ in range(3))
+    rec, rec2, rec3 = (torch.empty(L.ABSMAX_FLOATS, device="cuda") for _ in range(3))
+    L.call("ladder_in_style_fwd_resize2x_keep", p(x), p(style), p(up), p(y), p(mr), N, H, W, C, 1e-6, 1, p(ws), ws.numel(), p(rec), st)
+    L.call("ladder_in_style_fwd_resize2x", p(x), p(style), p(up2_), p(mr2), N, H, W, C, 1e-6, 1, p(ws), ws.numel(), p(rec2), st)
+    y_ref = torch.empty(N, H, W, C, device="cuda")
+    L.call("ladder_in_style_fwd_absmax", p(x), p(style), p(y_ref), p(mr3), N, H * W, C, 1e-6, 1, p(ws), ws.numel(), p(rec3), st)
+    torch.cuda.synchronize()
+    assert torch.equal(up, up2_) and torch.equal(rec, rec2) and torch.equal(mr, mr2)
+    assert torch.equal(y, up[:, ::2, ::2])
+    assert torch.equal(y, y_ref)
