@@ -186,6 +186,13 @@ int ladder_conv3x3_up2_split(const float* x, const float* x_absmax, const void* 
 int ladder_conv3x3_up2_split_proj(const float* x, const float* x_absmax, const void* packed_up2, const float* bias, float* y, const float* proj_w,
                                   const float* proj_b, float* proj_out, int proj_cout, int N, int H, int W, int Cin, int Cout, int act, int prec,
                                   int x_upsampled, ladder_stream_t stream);
+/* Backward-data of the pair resize x2 -> 3x3 conv in one launch: dy [N, 2H, 2W, C] -> dx [N, H, W, Cout] (the gradient with respect to the
+ * LOW-resolution input; the [N, 2H, 2W, Cout] intermediate of conv backward-data + resize transpose is never written).  packed_up2t =
+ * ladder_filter_pack_split(w, ., 9, 4 * C, Cout, transpose_flip = 4, prec) from the layer's HWIO bank [3][3][Cout][C].  Exact everywhere but on
+ * the four border lines of dx (rows 0, H-1, columns 0, W-1), which the caller recomputes from strips of dy (engine.Conv2D.backward_up2). */
+int ladder_conv3x3_up2_bwd_data_split_eligible(int N, int H, int W, int C, int Cout, int prec);
+int ladder_conv3x3_up2_bwd_data_split(const float* dy, const float* dy_absmax, const void* packed_up2t, float* dx, float* dx_absmax, int N, int H,
+                                      int W, int C, int Cout, int prec, ladder_stream_t stream);
 /* The last output row and column of the call above, recomputed in fp32 from the last row / column of x and the layer's HWIO bank w
  * [3][3][Cin][Cout] (row 2H-1 sees x[H-1] twice -- the resize clamps -- and the zero padding below; two [N*2W, 3 Cin] x [3 Cin, Cout] GEMMs):
  * written to y [N, 2H, 2W, Cout] and / or, through the fused 1x1 projection pw [Cout][pco] + pb, to pout [N, 2H, 2W, pco]; y_absmax (the

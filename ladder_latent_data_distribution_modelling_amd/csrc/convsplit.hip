@@ -169,6 +169,21 @@ __device__ __forceinline__ void filter_pack_element(const float* __restrict__ w,
             if (bs != 0.f) f += (ar * bs) * w[(((size_t)r * 3 + sx) * Cin + ci0 + j) * C + cc];      // (ar * bs: exact powers of two)
           }
         }
+      } else if (transpose_flip == 4) {
+        // backward-data of the upsample-fused pair (ladder_conv3x3_up2_bwd_data_split): dx_lo[p] = sum_{k = -2..2} G_k^T dy[2p + k] per axis, a 5x5 /
+        // stride-2 correlation over dy = a 3x3 correlation over the four pixel-parity classes of dy taken as input-channel groups (class a
+        // holds the taps k = 2 (dr - 1) + a); G = the forward tables mirrored: coefficient of w[r] in tap dr of class a = A_a[2 - dr][r].
+        // w = the layer's HWIO bank [3][3][Cout][C] (its INPUT channels are this GEMM's outputs), C = Cin / 4 = channels of dy.
+        const int C = Cin >> 2, civ = ci0 + j, cls = civ / C, cc = civ - cls * C, a = cls >> 1, b = cls & 1, dr = tap / 3, dc = tap - 3 * dr;
+        const float A0[3][3] = {{0.5f, 0.f, 0.f}, {0.5f, 1.f, 0.5f}, {0.f, 0.f, 0.5f}}, A1[3][3] = {{0.f, 0.f, 0.f}, {1.f, 0.5f, 0.f}, {0.f, 0.5f, 1.f}};
+        for (int r = 0; r < 3; ++r) {
+          const float ar = a ? A1[2 - dr][r] : A0[2 - dr][r];
+          if (ar == 0.f) continue;
+          for (int sx = 0; sx < 3; ++sx) {
+            const float bs = b ? A1[2 - dc][sx] : A0[2 - dc][sx];
+            if (bs != 0.f) f += (ar * bs) * w[(((size_t)r * 3 + sx) * Cout + co) * C + cc];
+          }
+        }
       } else {
         f = transpose_flip ? w[((size_t)(ntaps - 1 - tap) * Cout + co) * Cin + ci0 + j] : w[((size_t)tap * Cin + ci0 + j) * Cout + co];
       }
@@ -204,7 +219,7 @@ __global__ __launch_bounds__(256) void filter_pack_kernel(const float* __restric
 constexpr int PK_PARTS = 64;
 __global__ __launch_bounds__(256) void filter_absmax_multi_kernel(const ladder_pack_job_t* __restrict__ jobs, float* __restrict__ partial) {
   const ladder_pack_job_t j = jobs[blockIdx.y];
-  const size_t n = (size_t)j.ntaps * j.Cin * (j.transpose_flip >= 2 ? j.Cout / 4 : j.Cout);   // Cin % 16 == 0: a multiple of 4; banks are 16-byte aligned views of the flat store
+  const size_t n = (size_t)j.ntaps * (j.transpose_flip == 4 ? j.Cin / 4 : j.Cin) * ((j.transpose_flip == 2 || j.transpose_flip == 3) ? j.Cout / 4 : j.Cout);   // Cin % 16 == 0: a multiple of 4; banks are 16-byte aligned views of the flat store
   float m = 0.f;
   if ((reinterpret_cast<uintptr_t>(j.w) & 15u) == 0) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (size_t)PK_PARTS * 256) {
@@ -239,7 +254,7 @@ __global__ __launch_bounds__(256) void filter_pack_multi_kernel(const ladder_pac
     if (threadIdx.x == 0) amax_s = m;
   }
   __syncthreads();
-  const float amax = j.transpose_flip == 3 ? 4.f * amax_s : amax_s;     // (upsample-fused bank: |W_eff| <= 2 x 2 x max|w|)
+  const float amax = j.transpose_flip >= 3 ? 4.f * amax_s : amax_s;     // (upsample-fused bank: |W_eff| <= 2 x 2 x max|w|)
   float* rec = reinterpret_cast<float*>(static_cast<unsigned char*>(j.packed) + pack_payload_bytes_dev(j.ntaps, j.Cin, j.Cout, Fmt<PREC>::NS));
   if ((int)blockIdx.x == j.block_begin)                              // the bank's absmax record: slot 0 = the maximum, the rest 0
     for (int k = threadIdx.x; k < AMAX_SLOTS * AMAX_STRIDE; k += 256) rec[k] = k == 0 ? amax : 0.f;
@@ -264,7 +279,7 @@ constexpr int SP_AU = (SP_HALO_UNITS + SP_THREADS - 1) / SP_THREADS;   // 3
 // (two-plane formats: 128 registers and < 80 KB of LDS, so that TWO workgroups share a CU and one's staging / barrier phase hides behind
 // the other's MFMAs; the 9 taps are fully unrolled: fragment addresses become immediates, ~4 VALU instructions per tap are left)
 // PROJ: transposed accumulators (lane = pixel) for the fused projection; otherwise lane = channel and whole-line stores (see the 16-wave kernel)
-template <int PREC, bool PROJ, bool UP2 = false>
+template <int PREC, bool PROJ, int UPM = 0>
 __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x3_halo_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                                           const int N, const int H, const int W, const int Cin,
@@ -310,12 +325,12 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
     // s2_out == 2 (upsample-fused bank): the halo outside the map is the CLAMPED pixel, negated above / left of the map (the zero padding
     // of the high-resolution convolution, exactly) and plain below / right of it (exact but for the last output row / column, which
     // ladder_conv3x3_up2_split recomputes); bit 0 of hdst carries the sign (the offsets are multiples of 8)
-    const bool inside = hi >= 0 && hi < H && wi >= 0 && wi < W, up2 = UP2;
+    const bool inside = hi >= 0 && hi < H && wi >= 0 && wi < W, up2 = UPM == 1;
     const bool ok = (u < SP_HALO_UNITS) && (inside || up2);
     const int hs = up2 ? min(max(hi, 0), H - 1) : hi, ws_ = up2 ? min(max(wi, 0), W - 1) : wi;
     // (s2_out == 3: x is the even-row / even-column sub-grid of an ALREADY upsampled [N, 2H, 2W, Cin] tensor -- up[2i][2j] = x[i][j] -- that a
     // training forward keeps for its backward pass)
-    const int sm = (UP2 && s2_out == 3) ? 2 : 1;
+    const int sm = (UPM == 1 && s2_out == 3) ? 2 : 1;
     hsrc[i] = ok ? x + (((long)img * (H * sm) + hs * sm) * (W * sm) + ws_ * sm) * Cin + kq * 4 : nullptr;
     hdst[i] = (((kq >> 1) * SP_NPIX + pix) * 16 + (kq & 1) * 8) | ((up2 && ((hi < 0) != (wi < 0))) ? 1 : 0);
   }
@@ -342,11 +357,11 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
       if (tid + i * SP_THREADS < SP_HALO_UNITS) {
         uint2 pl[NS];
         float4 v = ha[i];
-        const float cm = (UP2 && (hdst[i] & 1)) ? -cx : cx;
-        if (F16 || UP2) v = make_float4(v.x * cm, v.y * cm, v.z * cm, v.w * cm);
+        const float cm = (UPM == 1 && (hdst[i] & 1)) ? -cx : cx;
+        if (F16 || UPM == 1) v = make_float4(v.x * cm, v.y * cm, v.z * cm, v.w * cm);
         split4<NS, F16>(v, pl);
 #pragma unroll
-        for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(Abase + buf * A_BUF + p * SP_A_PLANE + (UP2 ? (hdst[i] & ~1) : hdst[i])) = pl[p];
+        for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(Abase + buf * A_BUF + p * SP_A_PLANE + (UPM == 1 ? (hdst[i] & ~1) : hdst[i])) = pl[p];
       }
   };
   auto load_b = [&](int slab, int tap) {
@@ -542,7 +557,7 @@ constexpr int F_AU = (F_HALO_UNITS + F_THREADS - 1) / F_THREADS;               /
 // PROJ: transposed accumulators (lane = pixel; needed by the fused 1x1 projection).  Without it the accumulators are lane = channel and
 // every store instruction writes whole 128-byte lines (32 consecutive channels of a pixel per half-wave): +2 ... +5 % on the layers at
 // batch 128 against the 16-byte pieces of the transposed layout.
-template <int PREC, bool PROJ, bool UP2 = false>
+template <int PREC, bool PROJ, int UPM = 0>
 __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                                           const int N, const int H, const int W, const int Cin,
@@ -588,13 +603,16 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
     // s2_out == 2 (upsample-fused bank): the halo outside the map is the CLAMPED pixel, negated above / left of the map (the zero padding
     // of the high-resolution convolution, exactly) and plain below / right of it (exact but for the last output row / column, which
     // ladder_conv3x3_up2_split recomputes); bit 0 of hdst carries the sign (the offsets are multiples of 8)
-    const bool inside = hi >= 0 && hi < H && wi >= 0 && wi < W, up2 = UP2;
+    const bool inside = hi >= 0 && hi < H && wi >= 0 && wi < W, up2 = UPM == 1;
     const bool ok = (u < F_HALO_UNITS) && (inside || up2);
     const int hs = up2 ? min(max(hi, 0), H - 1) : hi, ws_ = up2 ? min(max(wi, 0), W - 1) : wi;
     // (s2_out == 3: x is the even-row / even-column sub-grid of an ALREADY upsampled [N, 2H, 2W, Cin] tensor -- up[2i][2j] = x[i][j] -- that a
     // training forward keeps for its backward pass)
-    const int sm = (UP2 && s2_out == 3) ? 2 : 1;
-    hsrc[i] = ok ? x + (((long)img * (H * sm) + hs * sm) * (W * sm) + ws_ * sm) * Cin + kq * 4 : nullptr;
+    // (s2_out == 4, backward-data of the upsample-fused pair: x = dy [N, 2H, 2W, Cin / 4]; the kernel walks its four pixel-parity classes as
+    // four groups of input-channel slabs -- pixel (hi, wi) of class (a, b) is dy[2 hi + a][2 wi + b]; the class offset is added per slab)
+    const int sm = (UPM == 2 || (UPM == 1 && s2_out == 3)) ? 2 : 1;
+    const int cpp = (UPM == 2) ? (Cin >> 2) : Cin;            // channels per pixel of the tensor behind x
+    hsrc[i] = ok ? x + (((long)img * (H * sm) + hs * sm) * (W * sm) + ws_ * sm) * cpp + kq * 4 : nullptr;
     hdst[i] = (((kq >> 1) * F_NPIX + pix) * 16 + (kq & 1) * 8) | ((up2 && ((hi < 0) != (wi < 0))) ? 1 : 0);
   }
   // filter stage = the blocks of taps 3r .. 3r+2: 1536 chunks of 16 bytes, thread tid takes chunk tid (tap 3r + tid/512) and, the first
@@ -616,22 +634,27 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
   uint4 rb0;
   const bool b_second = tid < 512;
   auto load_halo = [&](int slab, int i) {
-    ha = *reinterpret_cast<const float4*>(hsrc[i] != nullptr ? hsrc[i] + slab * 16 : gs_zero16);
+    int soff = slab * 16;
+    if (UPM == 2) {                                                    // slab -> (parity class, 16-channel slab of dy)
+      const int spc = nslabs >> 2, cls = slab / spc;
+      soff = ((cls >> 1) * 2 * W + (cls & 1)) * (Cin >> 2) + (slab - cls * spc) * 16;
+    }
+    ha = *reinterpret_cast<const float4*>(hsrc[i] != nullptr ? hsrc[i] + soff : gs_zero16);
   };
   auto store_halo = [&](int buf, int i) {
     if (tid + i * F_THREADS < F_HALO_UNITS) {
       uint2 pl[NS];
       float4 v = ha;
-      const float cm = (UP2 && (hdst[i] & 1)) ? -cx : cx;
-      if (F16 || UP2) v = make_float4(v.x * cm, v.y * cm, v.z * cm, v.w * cm);
+      const float cm = (UPM == 1 && (hdst[i] & 1)) ? -cx : cx;
+      if (F16 || UPM == 1) v = make_float4(v.x * cm, v.y * cm, v.z * cm, v.w * cm);
       split4<NS, F16>(v, pl);
 #pragma unroll
-      for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(Abase + buf * A_BUF + p * F_A_PLANE + (UP2 ? (hdst[i] & ~1) : hdst[i])) = pl[p];
+      for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(Abase + buf * A_BUF + p * F_A_PLANE + (UPM == 1 ? (hdst[i] & ~1) : hdst[i])) = pl[p];
     }
   };
   auto load_b = [&](int slab, int r, int part) {                          // part 0: chunk tid, part 1: chunk 1024 + tid (first half only)
     const uint4* s = bsrc + (size_t)(3 * r * nslabs + slab) * tiles_n * B_CHUNKS;
-    const unsigned tm = (unsigned)(tap_masks >> (9 * cot)) & 0x1ffu;
+    const unsigned tm = (unsigned)(tap_masks >> (9 * ((UPM == 2) ? slab / (nslabs >> 2) : cot))) & 0x1ffu;
     if (part == 0) { if ((tm >> (3 * r + (tid >> 9))) & 1u) rb0 = s[0]; }
     else if (b_second && ((tm >> (3 * r + 2)) & 1u)) rb0 = s[2 * tap_stride];
   };
@@ -641,7 +664,7 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
   };
 
   // (see the 8-wave kernel: taps this output-channel tile uses; a thread's filter chunk of a stage belongs to tap 3r + (tid >> 9) resp. 3r + 2)
-  const unsigned tmask = (unsigned)(tap_masks >> (9 * cot)) & 0x1ffu;
+  const unsigned tmask0 = (unsigned)(tap_masks >> (9 * cot)) & 0x1ffu;
 #pragma unroll
   for (int i = 0; i < F_AU; ++i) {
     load_halo(0, i);
@@ -655,6 +678,8 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
   int bbuf = 0;
   for (int slab = 0; slab < nslabs; ++slab) {
     const int hb = slab & 1;
+    // (s2_out == 4: the taps depend on the parity class of the INPUT slab, not on the output-channel tile)
+    const unsigned tmask = (UPM == 2) ? (unsigned)(tap_masks >> (9 * (slab / (nslabs >> 2)))) & 0x1ffu : tmask0;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const bool last = (slab + 1 == nslabs) && (r == 2);
@@ -697,6 +722,7 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
   }
 
   {  // ---- epilogue scope
+  const int s2o = (UPM == 2) ? 0 : s2_out;               // (mode 4 writes the plain [N, H, W, Cout] layout)
   // Epilogue coordinates are RE-DERIVED from opaque copies of the thread / workgroup ids: computed before the main loop they were live
   // across it, and at 128 registers the compiler parked them in scratch (12-56 bytes per lane).
   int e_tid = threadIdx.x, e_bid = blockIdx.x;
@@ -714,14 +740,14 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int n = n0 + wn * 64 + ni * 32 + l31;
-      const float bv = (bias != nullptr && n < Cout) ? bias[s2_out ? n - n0 : n] : 0.f;    // (parity-class tiles share the layer's 128 channels)
+      const float bv = (bias != nullptr && n < Cout) ? bias[s2o ? n - n0 : n] : 0.f;    // (parity-class tiles share the layer's 128 channels)
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        // s2_out: this output-channel tile is one PARITY CLASS (ph, pw) = (cot >> 1, cot & 1) of a stride-2 backward-data result: pixel
+        // s2o: this output-channel tile is one PARITY CLASS (ph, pw) = (cot >> 1, cot & 1) of a stride-2 backward-data result: pixel
         // (h, w) of the class is dx[2h + ph, 2w + pw], channels = the tile's 128 (the 4 class tiles interleave into [N, 2H, 2W, 128])
-        float* yp = s2_out ? y + (((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_tile % tiles_n >> 1)) * 2 * W + 2 * w0 + (e_tile % tiles_n & 1)) * SP_BN + (n - n0)
+        float* yp = s2o ? y + (((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_tile % tiles_n >> 1)) * 2 * W + 2 * w0 + (e_tile % tiles_n & 1)) * SP_BN + (n - n0)
                            : y + (((long)img * H + h0 + 2 * wm + mi) * W + w0) * Cout + n;
-        const long pstride = s2_out ? 2 * SP_BN : Cout;
+        const long pstride = s2o ? 2 * SP_BN : Cout;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int px = (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -749,11 +775,11 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
   for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      // (s2_out: this tile is one output-parity class of a [N, 2H, 2W, 128] map and owns all its 128 channels, see the lane = channel branch)
-      const long opix = s2_out ? ((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_tile % tiles_n >> 1)) * 2 * W + 2 * (w0 + l31) + (e_tile % tiles_n & 1)
+      // (s2o: this tile is one output-parity class of a [N, 2H, 2W, 128] map and owns all its 128 channels, see the lane = channel branch)
+      const long opix = s2o ? ((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_tile % tiles_n >> 1)) * 2 * W + 2 * (w0 + l31) + (e_tile % tiles_n & 1)
                                : ((long)img * H + h0 + 2 * wm + mi) * W + w0 + l31;
-      const int coff = s2_out ? n0 : 0;
-      float* yp = y != nullptr ? y + opix * (s2_out ? SP_BN : Cout) - coff : nullptr;
+      const int coff = s2o ? n0 : 0;
+      float* yp = y != nullptr ? y + opix * (s2o ? SP_BN : Cout) - coff : nullptr;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * lh;
@@ -806,7 +832,7 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
       for (int mi = 0; mi < 2; ++mi) {
         const float4 other = *reinterpret_cast<const float4*>(red + (((wm * 2 + mi) * 32 + l31) * 4));
         const float t[4] = {pacc[mi][0] + other.x, pacc[mi][1] + other.y, pacc[mi][2] + other.z, pacc[mi][3] + other.w};
-        const long opix = s2_out ? ((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_tile % tiles_n >> 1)) * 2 * W + 2 * (w0 + l31) + (e_tile % tiles_n & 1)
+        const long opix = s2o ? ((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_tile % tiles_n >> 1)) * 2 * W + 2 * (w0 + l31) + (e_tile % tiles_n & 1)
                                  : ((long)img * H + h0 + 2 * wm + mi) * W + w0 + l31;
         float* op = pout + opix * pco;
         for (int o = 0; o < pco; ++o) op[o] = t[o] + (pb != nullptr ? pb[o] : 0.f);
@@ -1228,9 +1254,9 @@ int ladder_filter_pack_split(const float* w, void* packed, int ntaps, int Cin, i
   const dim3 grid((total + 255) / 256), block(256);
   float* wamax = reinterpret_cast<float*>(static_cast<unsigned char*>(packed) + pack_payload_bytes(ntaps, Cin, Cout, prec));
   if (prec == LADDER_PREC_F16X3) {
-    const int rc = ladder_absmax(w, (size_t)ntaps * Cin * (transpose_flip >= 2 ? Cout / 4 : Cout), wamax, stream);
+    const int rc = ladder_absmax(w, (size_t)ntaps * (transpose_flip == 4 ? Cin / 4 : Cin) * ((transpose_flip == 2 || transpose_flip == 3) ? Cout / 4 : Cout), wamax, stream);
     if (rc != LADDER_OK) return rc;
-    if (transpose_flip == 3) hipLaunchKernelGGL(record_times4_kernel, dim3(1), dim3(256), 0, stream, wamax);   // |W_eff| <= 4 max|w|
+    if (transpose_flip >= 3) hipLaunchKernelGGL(record_times4_kernel, dim3(1), dim3(256), 0, stream, wamax);   // |W_eff| <= 4 max|w|
     hipLaunchKernelGGL(filter_pack_kernel<LADDER_PREC_F16X3>, grid, block, 0, stream, w, (uint4*)packed, ntaps, Cin, Cout, transpose_flip, total, wamax);
   } else if (prec == LADDER_PREC_BF16X6) {
     hipLaunchKernelGGL(filter_pack_kernel<LADDER_PREC_BF16X6>, grid, block, 0, stream, w, (uint4*)packed, ntaps, Cin, Cout, transpose_flip, total, wamax);
@@ -1281,13 +1307,16 @@ static int conv3x3_split_launch(const float* x, const float* x_absmax, const voi
 #define LADDER_SPLIT_LAUNCH__(P_, PROJ_, UP2_) \
   hipLaunchKernelGGL((conv3x3_halo_split_kernel<P_, PROJ_, UP2_>), grid, block, 0, stream, x, (const uint4*)packed, bias, y, N, H, W, Cin, Cout, act, tiles_n, x_absmax, wamax, y_absmax, \
                      pw, pb, pout, pco, tap_masks, s2_out)
-#define LADDER_SPLIT_LAUNCH_(P_, PROJ_) do { if (s2_out >= 2) LADDER_SPLIT_LAUNCH__(P_, PROJ_, true); else LADDER_SPLIT_LAUNCH__(P_, PROJ_, false); } while (0)
+#define LADDER_SPLIT_LAUNCH_(P_, PROJ_) do { if (s2_out == 2 || s2_out == 3) LADDER_SPLIT_LAUNCH__(P_, PROJ_, 1); else LADDER_SPLIT_LAUNCH__(P_, PROJ_, 0); } while (0)
 #define LADDER_SPLIT_LAUNCH(P_) do { if (pout != nullptr) LADDER_SPLIT_LAUNCH_(P_, true); else LADDER_SPLIT_LAUNCH_(P_, false); } while (0)
 #define LADDER_SPLIT16_LAUNCH_(P_, PROJ_, UP2_) \
   hipLaunchKernelGGL((conv3x3_halo_split16_kernel<P_, PROJ_, UP2_>), dim3(N * (H / F_H) * (W / SP_W) * tiles_n), dim3(F_THREADS), 0, stream, x, (const uint4*)packed, bias, y, N, H, W, Cin, Cout, act, tiles_n, x_absmax, wamax, y_absmax, \
                      pw, pb, pout, pco, tap_masks, s2_out)
-#define LADDER_SPLIT16_LAUNCH(P_, PROJ_) do { if (s2_out >= 2) LADDER_SPLIT16_LAUNCH_(P_, PROJ_, true); else LADDER_SPLIT16_LAUNCH_(P_, PROJ_, false); } while (0)
-  if (split_halo16_ok(N, H, W, Cin, Cout, prec)) {
+#define LADDER_SPLIT16_LAUNCH(P_, PROJ_) do { if (s2_out == 2 || s2_out == 3) LADDER_SPLIT16_LAUNCH_(P_, PROJ_, 1); else LADDER_SPLIT16_LAUNCH_(P_, PROJ_, 0); } while (0)
+  if (s2_out == 4) {                                       // backward-data of the upsample-fused pair: 16-wave kernel, plain epilogue
+    if (pout != nullptr || !split_halo16_ok(N, H, W, Cin, Cout, prec)) return LADDER_E_SHAPE;
+    if (prec == LADDER_PREC_F16X3) LADDER_SPLIT16_LAUNCH_(LADDER_PREC_F16X3, false, 2); else LADDER_SPLIT16_LAUNCH_(LADDER_PREC_BF16X3, false, 2);
+  } else if (split_halo16_ok(N, H, W, Cin, Cout, prec)) {
     if (pout != nullptr) {
       if (prec == LADDER_PREC_F16X3) LADDER_SPLIT16_LAUNCH(LADDER_PREC_F16X3, true); else LADDER_SPLIT16_LAUNCH(LADDER_PREC_BF16X3, true);
     } else {
@@ -1393,6 +1422,37 @@ int ladder_conv3x3_up2_split_proj(const float* x, const float* x_absmax, const v
   if (!ladder_conv3x3_up2_split_eligible(N, H, W, Cin, Cout, prec) || proj_out == nullptr || prec_planes(prec) != 2) return LADDER_E_SHAPE;
   return conv3x3_split_launch(x, x_absmax, packed_up2, bias, y, nullptr, proj_w, proj_b, proj_out, proj_cout, N, H, W, Cin, 4 * SP_BN, act, prec,
                               stream, up2_tap_masks(), x_upsampled ? 3 : 2);
+}
+
+// Backward-data of the pair (factor-2 legacy-bilinear resize -> 3x3 / SAME convolution), dy [N, 2H, 2W, C] -> dx_lo [N, H, W, Cout], as ONE launch:
+// the composite transpose is a zero-padded 5x5 / stride-2 correlation over dy (25 tap products per low-resolution pixel instead of 36 +
+// the resize transpose, and the [N, 2H, 2W, Cout] intermediate is never written), exact everywhere but on the FOUR border lines of dx_lo
+// (rows 0 and H-1, columns 0 and W-1: there the resize's clamp and the convolution's zero padding change the coefficients) -- the caller
+// recomputes those from strips of dy with the plain backward-data + resize-transpose kernels.  packed_up2t =
+// ladder_filter_pack_split(w, ., 9, 4 * C, Cout, transpose_flip = 4, prec) from the layer's HWIO bank [3][3][Cout][C].  16-wave kernel only.
+static unsigned long long up2t_tap_masks() {
+  unsigned long long m = 0;
+  for (int cls = 0; cls < 4; ++cls) {
+    const int a = cls >> 1, b = cls & 1;
+    unsigned t = 0;
+    for (int dr = 0; dr < 3; ++dr)
+      for (int dc = 0; dc < 3; ++dc)
+        if ((a == 0 || dr <= 1) && (b == 0 || dc <= 1)) t |= 1u << (dr * 3 + dc);
+    m |= (unsigned long long)t << (9 * cls);
+  }
+  return m;
+}
+
+int ladder_conv3x3_up2_bwd_data_split_eligible(int N, int H, int W, int C, int Cout, int prec) {
+  static const bool off = getenv("LADDER_DISABLE_UP2") != nullptr;
+  return (!off && prec_ok(prec) && (C % 16) == 0 && split_halo_ok(N, H, W, 4 * C, Cout) && split_halo16_ok(N, H, W, 4 * C, Cout, prec)) ? 1 : 0;
+}
+
+int ladder_conv3x3_up2_bwd_data_split(const float* dy, const float* dy_absmax, const void* packed_up2t, float* dx, float* dx_absmax, int N, int H,
+                                      int W, int C, int Cout, int prec, ladder_stream_t stream) {
+  if (!ladder_conv3x3_up2_bwd_data_split_eligible(N, H, W, C, Cout, prec)) return LADDER_E_SHAPE;
+  return conv3x3_split_launch(dy, dy_absmax, packed_up2t, nullptr, dx, dx_absmax, nullptr, nullptr, nullptr, 0, N, H, W, 4 * C, Cout,
+                              LADDER_ACT_NONE, prec, stream, up2t_tap_masks(), 4);
 }
 
 static size_t up2_align(size_t b) { return (b + 255) & ~(size_t)255; }

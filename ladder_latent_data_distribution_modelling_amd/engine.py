@@ -477,6 +477,8 @@ class Conv2D:
             cout = 4 * self.cin
         elif transpose_flip == 3:                     # the four output-parity classes of the upsample-fused forward (effective taps)
             cout = 4 * self.cout
+        elif transpose_flip == 4:                     # backward-data of the upsample-fused pair: the four pixel-parity classes of dy as input groups
+            cin, cout = 4 * self.cout, self.cin
         ent = self._packed.get((transpose_flip, ns))
         if ent is None:
             nb = L.query("ladder_filter_pack_split_bytes", self.k * self.k, cin, cout, ns)
@@ -622,10 +624,55 @@ class Conv2D:
         self.x, self.y = x, y
         return y
 
-    def backward(self, dy, need_dx=True, wgrad=True, act_done=False, gate_prev=None):
+    def up2t_ok(self, N, H, W):
+        """The gradient with respect to the LOW-resolution tensor [N, H, W, cin] behind a factor-2 resize in front of this layer can come from
+        ONE launch (ladder_conv3x3_up2_bwd_data_split) + border strips, instead of backward-data on the upsampled map + the resize transpose."""
+        return bool(self.ctx.up2 >= 2 and self.ctx.ns in (2, 4) and self.k == 3 and self.stride == 1 and self.padding == "same"
+                    and L.query("ladder_conv3x3_up2_bwd_data_split_eligible", N, H, W, self.cout, self.cin, self.ctx.ns)
+                    and L.query("ladder_conv2d_bwd_data_split_eligible", N, 4, 2 * W, self.cin, 4, 2 * W, self.cout, 3, 3, 1, 1, 1, 0)
+                    and L.query("ladder_conv2d_bwd_data_split_eligible", N, 2 * H, 4, self.cin, 2 * H, 4, self.cout, 3, 3, 1, 1, 1, 0))
+
+    def _dx_lowres(self, dy, dy_amax):
+        """d loss / d x_lo for y = conv(resize2x(x_lo)): the composite transpose is a zero-padded 5x5 / stride-2 correlation over dy (one launch of
+        the halo kernel, 25 instead of 36 tap products per low-resolution pixel, the [N, 2H, 2W, cin] intermediate never written), exact on
+        every pixel but the four border lines of dx, where the resize's clamp and the convolution's padding change the coefficients: those
+        come from 4-pixel-wide strips of dy through the plain backward-data + resize-transpose kernels (exact there by construction)."""
+        ctx, st = self.ctx, self.ctx.stream
+        N, OH, OW, _ = dy.shape
+        H, W = OH // 2, OW // 2
+        dx = ctx.empty(N, H, W, self.cin)
+        dx_amax = ctx.new_amax() if ctx.ns == 4 else None
+        flops = 2.0 * N * OH * OW * 9 * self.cin * self.cout
+        _timed(256120 + ctx.ns, flops, "ladder_conv3x3_up2_bwd_data_split",
+               (_p(dy), _p(dy_amax), _p(self._packed_filter(4)), _p(dx), _p(dx_amax), N, H, W, self.cout, self.cin, ctx.ns, st), flops * 25.0 / 36.0)
+        pk = self._packed_filter(1)
+        for axis, sl in ((1, slice(0, 4)), (1, slice(OH - 4, OH)), (2, slice(0, 4)), (2, slice(OW - 4, OW))):
+            s = (dy[:, sl] if axis == 1 else dy[:, :, sl]).contiguous()
+            sh, sw = s.shape[1], s.shape[2]
+            geo = (N, sh, sw, self.cin, sh, sw, self.cout, 3, 3, 1, 1, 1)
+            s_amax = ctx.absmax(s)
+            wsp, wsn = ctx.ws(L.query("ladder_conv2d_bwd_data_split_workspace_bytes", *geo))
+            dup = ctx.empty(N, sh, sw, self.cin)
+            L.call("ladder_conv2d_bwd_data_split", _p(ctx.planes(s, self._ps(sh, sw))), _p(s_amax), _p(pk), _p(dup), *geo, None, 0, ctx.ns, wsp, wsn, st)
+            lo = ctx.empty(N, sh // 2, sw // 2, self.cin)
+            L.call("ladder_resize_bilinear_bwd", _p(dup), _p(lo), N, sh // 2, sw // 2, self.cin, sh, sw, st)
+            first = sl.start == 0
+            if axis == 1:
+                line = lo[:, 0] if first else lo[:, -1]
+                (dx[:, 0] if first else dx[:, -1]).copy_(line)
+            else:
+                line = lo[:, :, 0] if first else lo[:, :, -1]
+                (dx[:, :, 0] if first else dx[:, :, -1]).copy_(line)
+            if dx_amax is not None:                       # the record must bound the final values: fold the strip's per-sample maxima in
+                torch.maximum(dx_amax, ctx.absmax(lo), out=dx_amax)
+        ctx.set_amax(dx, dx_amax)
+        return dx
+
+    def backward(self, dy, need_dx=True, wgrad=True, act_done=False, gate_prev=None, lowres_dx=False):
         """`act_done`: dy already carries this layer's activation derivative (fused into the consumer's epilogue).
         `gate_prev`: activation name of the layer that produced this conv's input x: its derivative act'(x) is fused into
-        the backward-data epilogue, so that layer must then be called with act_done=True."""
+        the backward-data epilogue, so that layer must then be called with act_done=True.
+        `lowres_dx`: x is the factor-2 upsample of a tensor the caller wants the gradient of: return d / d (that tensor) (see _dx_lowres)."""
         x, y = self.x, self.y
         N, H, W, _ = x.shape
         _, Ho, Wo, _ = y.shape
@@ -710,7 +757,9 @@ class Conv2D:
             else:
                 L.call("ladder_conv2d_bwd_filter", *wargs)
         dx = None
-        if split_d:
+        if split_d and lowres_dx:
+            dx = self._dx_lowres(dy, dy_amax)
+        elif split_d:
             dx = self.ctx.empty(N, H, W, self.cin)
             dx_amax = self.ctx.new_amax() if self.ctx.ns == 4 else None
             args = (_p(dy), _p(dy_amax), _p(self._packed_filter(1)), None, _p(dx), _p(dx_amax), N, H, W, self.cout, self.cin, 0,
@@ -1183,9 +1232,12 @@ class CelebADecoder:
                      and (last_rs is None or tuple(last_rs.in_shape[1:3]) == (last_rs.oh, last_rs.ow)))
         dh = self.conv_out.backward(dxhat, gate_prev=last_conv.act if fuse_last else None)
         ddlat = None
+        lowres = False            # dh is already the gradient of the LOW-resolution tensor behind the next resize (fused into the conv's backward-data)
         for bi, (conv, sty, norm, rs) in enumerate(reversed(self.blocks)):
             gated = False
-            if rs is not None:
+            if lowres:
+                lowres = False                                   # (this block's resize transpose is done)
+            elif rs is not None:
                 if norm is None and conv.act is not None and not (bi == 0 and fuse_last):
                     dh, gated = rs.backward(dh, gate=(conv.y, conv.act))   # leaky conv -> resize: its activation backward rides on the transpose
                 else:
@@ -1194,7 +1246,13 @@ class CelebADecoder:
                 dh, dstyle = norm.backward(dh)
                 g = sty.backward(dstyle)
                 ddlat = g if ddlat is None else add_(ctx, ddlat, g)
-            dh = conv.backward(dh, act_done=(bi == 0 and fuse_last) or gated)
+            # the block below ends in instance norm + a factor-2 resize: this conv's backward-data can return the gradient of the resize's INPUT
+            below = self.blocks[len(self.blocks) - 2 - bi] if bi + 1 < len(self.blocks) else None
+            lowres = bool(bi == 0 and below is not None and below[2] is not None and below[3] is not None and conv.x is not None
+                          and (below[3].oh, below[3].ow) == tuple(conv.x.shape[1:3]) and conv.x.shape[1] % 2 == 0
+                          and tuple(getattr(below[3], "in_shape", (0, 0, 0))[1:3]) == (conv.x.shape[1] // 2, conv.x.shape[2] // 2)
+                          and conv.up2t_ok(conv.x.shape[0], conv.x.shape[1] // 2, conv.x.shape[2] // 2))
+            dh = conv.backward(dh, act_done=(bi == 0 and fuse_last) or gated, lowres_dx=lowres)
         dh = self.conv0.backward(self.up0.backward(dh))
         denc = dh.reshape(dh.shape[0], self.nh)
         # mapping MLP: each layer's backward-data epilogue applies the previous layer's leaky-ReLU derivative

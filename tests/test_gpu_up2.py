@@ -184,3 +184,89 @@ def test_in_style_resize2x_keep_writes_the_lowres_tensor(gpu_ctx):
     assert torch.equal(up, up2_) and torch.equal(rec, rec2) and torch.equal(mr, mr2)
     assert torch.equal(y, up[:, ::2, ::2])
     assert torch.equal(y, y_ref)
+
+
+def _ref_bwd(N, H, W, C_in, C_out, w, dy):
+    """float64 autograd of conv2d_tf(resize_bilinear_legacy(x)) with respect to the LOW-resolution x (the gradient is linear in dy, independent of x)."""
+    x = torch.zeros(N, H, W, C_in, dtype=torch.float64, requires_grad=True)
+    y = O.conv2d_tf(O.resize_bilinear_legacy(x, 2 * H, 2 * W), torch.as_tensor(w, dtype=torch.float64), None, 1, "same")
+    y.backward(torch.as_tensor(dy, dtype=torch.float64))
+    return x.grad.numpy()
+
+
+@pytest.mark.parametrize("case", [(64, 64, 64, 16, 128, "f16x3"), (32, 64, 64, 32, 256, "f16x3"), (64, 64, 64, 16, 128, "bf16x3")],
+                         ids=lambda c: "n%d_%dx%d_c%d_co%d_%s" % c)
+def test_up2_backward_data_interior_vs_autograd(gpu_ctx, case):
+    """ladder_conv3x3_up2_bwd_data_split: the gradient of resize x2 -> 3x3 conv with respect to the low-resolution input as ONE 5x5 / stride-2
+    correlation over dy (four pixel-parity classes of dy as input-channel groups, per-class tap masks) -- exact on every pixel of dx but its
+    four border lines (recomputed from strips by the engine)."""
+    L = _lib()
+    N, H, W, C, Cout, prec = case                      # dy [N, 2H, 2W, C] (the conv's OUTPUT channels), dx [N, H, W, Cout] (its input channels)
+    P, st = PREC[prec], gpu_ctx.stream
+    rng = np.random.default_rng(C + Cout)
+    w = (rng.standard_normal((3, 3, Cout, C)) / np.sqrt(9 * C)).astype(np.float32)            # HWIO of the layer: [3][3][in = Cout][out = C]
+    dy = (rng.standard_normal((N, 2 * H, 2 * W, C)) * np.exp2(-5 * rng.random((N, 1, 1, 1)))).astype(np.float32)
+    assert L.query("ladder_conv3x3_up2_bwd_data_split_eligible", N, H, W, C, Cout, P) == 1
+    dyd, wd = dev(dy), dev(w)
+    rec = absmax_samples(L, dyd, st)
+    pk = torch.empty(L.query("ladder_filter_pack_split_bytes", 9, 4 * C, Cout, P), dtype=torch.uint8, device="cuda")
+    L.call("ladder_filter_pack_split", p(wd), p(pk), 9, 4 * C, Cout, 4, P, st)
+    dx = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    dxrec = torch.empty(L.ABSMAX_FLOATS, device="cuda")
+    L.call("ladder_conv3x3_up2_bwd_data_split", p(dyd), p(rec), p(pk), p(dx), p(dxrec), N, H, W, C, Cout, P, st)
+    torch.cuda.synchronize()
+    ref = _ref_bwd(N, H, W, Cout, C, w, dy)
+    scale = np.abs(ref).max()
+    err = np.abs(dx.cpu().numpy().astype(np.float64) - ref)
+    assert np.isfinite(dx.cpu().numpy()).all()
+    assert err[:, 1:-1, 1:-1].max() / scale < TOL[prec][1], err[:, 1:-1, 1:-1].max() / scale
+    assert err[:, 0].max() / scale > 1e-3 and err[:, -1].max() / scale > 1e-3                 # the border lines are NOT final (documented)
+
+
+def test_engine_fused_lowres_backward_agrees_with_direct_path(monkeypatch):
+    """Batch 64, full resolution: with `upsample_fused_convs: 2` the backward-data of conv2d_7 returns the gradient of the 64x64 tensor behind
+    the resize (ladder_conv3x3_up2_bwd_data_split + border strips; the separate resize transpose disappears); every gradient of the AE group
+    must agree with the direct path to fp32-class error."""
+    import json, os
+    from ladder_latent_data_distribution_modelling_amd import _lib as L
+    from ladder_latent_data_distribution_modelling_amd.engine import LadderEngine
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = json.load(open(os.path.join(root, "codes", "celeba_config.json")))
+    cfg["batch_size"] = B = 64
+    rng = np.random.default_rng(41)
+    x = rng.random((B, 128, 128, 3)).astype(np.float32)
+    Pm = O.init_params(cfg, seed=7)
+    noise = O.make_noise(cfg, B, rng, np.float32)
+    fix = np.load(os.path.join(root, "tests", "golden", "GM_prior_info.npz"))
+    K = int(cfg["n_mixtures"])
+    gm = (fix["w_full"][:K] / fix["w_full"][:K].sum(), fix["m_full"][:K], fix["K_full"][:K])
+    calls, real = [], L.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real(name, *a)
+
+    monkeypatch.setattr(L, "call", spy)
+    res = {}
+    for up2 in (0, 2):
+        eng = LadderEngine(dict(cfg, upsample_fused_convs=up2), "cuda:0", values=Pm, seed=1)
+        eng.set_mixture(*gm)
+        del calls[:]
+        eng.run_ae(x, 0.0, noise, False, False)
+        res[up2] = (eng.fetch(), {k: v.detach().cpu().numpy().copy() for k, v in eng.ps.g.items()}, list(calls))
+        del eng
+        torch.cuda.empty_cache()
+    (f0, g0, c0), (f1, g1, c1) = res[0], res[2]
+    assert c1.count("ladder_conv3x3_up2_bwd_data_split") == 1 and "ladder_conv3x3_up2_bwd_data_split" not in c0
+    assert c1.count("ladder_resize_bilinear_bwd") == c0.count("ladder_resize_bilinear_bwd") - 1 + 4        # the 128 -> 64 transpose is gone; 4 strips
+    for k in ("elbo", "l1_reconstruction_error", "loss_ae"):
+        assert abs(f1[k] - f0[k]) <= 2e-5 * abs(f0[k]) + 1e-6, (k, f1[k], f0[k])
+    worst, wname = 0.0, None
+    for name in g0:
+        sc = np.abs(g0[name]).max()
+        if sc > 1e-9:
+            e = np.abs(g1[name] - g0[name]).max() / sc
+            if e > worst:
+                worst, wname = e, name
+    print("worst relative gradient difference %.2e (%s)" % (worst, wname))
+    assert worst < 2e-4, (worst, wname)
