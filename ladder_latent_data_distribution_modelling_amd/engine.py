@@ -629,8 +629,9 @@ class Conv2D:
         ONE launch (ladder_conv3x3_up2_bwd_data_split) + border strips, instead of backward-data on the upsampled map + the resize transpose."""
         return bool(self.ctx.up2 >= 2 and self.ctx.ns in (2, 4) and self.k == 3 and self.stride == 1 and self.padding == "same"
                     and L.query("ladder_conv3x3_up2_bwd_data_split_eligible", N, H, W, self.cout, self.cin, self.ctx.ns)
-                    and L.query("ladder_conv2d_bwd_data_split_eligible", N, 4, 2 * W, self.cin, 4, 2 * W, self.cout, 3, 3, 1, 1, 1, 0)
-                    and L.query("ladder_conv2d_bwd_data_split_eligible", N, 2 * H, 4, self.cin, 2 * H, 4, self.cout, 3, 3, 1, 1, 1, 0))
+                    and all(L.query("ladder_conv2d_bwd_data_split_eligible", *g, 0) for g in (
+                        (N, 2, 2 * W, self.cin, 3, 2 * W, self.cout, 3, 3, 1, 1, 1), (N, 3, 2 * W, self.cin, 4, 2 * W, self.cout, 3, 3, 1, 2, 1),
+                        (N, 2 * H, 2, self.cin, 2 * H, 3, self.cout, 3, 3, 1, 1, 1), (N, 2 * H, 3, self.cin, 2 * H, 4, self.cout, 3, 3, 1, 1, 2))))
 
     def _dx_lowres(self, dy, dy_amax):
         """d loss / d x_lo for y = conv(resize2x(x_lo)): the composite transpose is a zero-padded 5x5 / stride-2 correlation over dy (one launch of
@@ -646,24 +647,34 @@ class Conv2D:
         _timed(256120 + ctx.ns, flops, "ladder_conv3x3_up2_bwd_data_split",
                (_p(dy), _p(dy_amax), _p(self._packed_filter(4)), _p(dx), _p(dx_amax), N, H, W, self.cout, self.cin, ctx.ns, st), flops * 25.0 / 36.0)
         pk = self._packed_filter(1)
-        for axis, sl in ((1, slice(0, 4)), (1, slice(OH - 4, OH)), (2, slice(0, 4)), (2, slice(OW - 4, OW))):
+        # border lines: dx row 0 = R(d_up[0] + d_up[1] / 2), row H-1 = R(d_up[2H-3] / 2 + d_up[2H-2] + d_up[2H-1]) with d_up = the plain
+        # backward-data (needs dy rows 0..2 resp. 2H-4..2H-1) and R = the resize transpose ALONG the line; columns alike
+        for axis, first in ((1, True), (1, False), (2, True), (2, False)):
+            n_dy, n_up = (3, 2) if first else (4, 3)                      # strip widths: dy lines read, d_up lines produced
+            O_ = OH if axis == 1 else OW
+            sl = slice(0, n_dy) if first else slice(O_ - n_dy, O_)
             s = (dy[:, sl] if axis == 1 else dy[:, :, sl]).contiguous()
-            sh, sw = s.shape[1], s.shape[2]
-            geo = (N, sh, sw, self.cin, sh, sw, self.cout, 3, 3, 1, 1, 1)
+            pad = 1 if first else 2                                        # forward-convolution padding that aligns the strip (see csrc/igemm.hip)
+            if axis == 1:
+                geo = (N, n_up, OW, self.cin, n_dy, OW, self.cout, 3, 3, 1, pad, 1)
+                dup = ctx.empty(N, n_up, OW, self.cin)
+            else:
+                geo = (N, OH, n_up, self.cin, OH, n_dy, self.cout, 3, 3, 1, 1, pad)
+                dup = ctx.empty(N, OH, n_up, self.cin)
             s_amax = ctx.absmax(s)
             wsp, wsn = ctx.ws(L.query("ladder_conv2d_bwd_data_split_workspace_bytes", *geo))
-            dup = ctx.empty(N, sh, sw, self.cin)
-            L.call("ladder_conv2d_bwd_data_split", _p(ctx.planes(s, self._ps(sh, sw))), _p(s_amax), _p(pk), _p(dup), *geo, None, 0, ctx.ns, wsp, wsn, st)
-            lo = ctx.empty(N, sh // 2, sw // 2, self.cin)
-            L.call("ladder_resize_bilinear_bwd", _p(dup), _p(lo), N, sh // 2, sw // 2, self.cin, sh, sw, st)
-            first = sl.start == 0
+            L.call("ladder_conv2d_bwd_data_split", _p(ctx.planes(s, self._ps(geo[1], geo[2]))), _p(s_amax), _p(pk), _p(dup), *geo, None, 0, ctx.ns, wsp, wsn, st)
+            d = dup if axis == 1 else dup.transpose(1, 2)                  # [N, line index, position on the line, cin]
+            t = (d[:, 0] + 0.5 * d[:, 1]) if first else (0.5 * d[:, 0] + d[:, 1] + d[:, 2])
+            t = t.contiguous()
+            Lp = OW if axis == 1 else OH
+            lo = ctx.empty(N, 1, Lp // 2, self.cin)
+            L.call("ladder_resize_bilinear_bwd", _p(t), _p(lo), N, 1, Lp // 2, self.cin, 1, Lp, st)
             if axis == 1:
-                line = lo[:, 0] if first else lo[:, -1]
-                (dx[:, 0] if first else dx[:, -1]).copy_(line)
+                (dx[:, 0] if first else dx[:, -1]).copy_(lo[:, 0])
             else:
-                line = lo[:, :, 0] if first else lo[:, :, -1]
-                (dx[:, :, 0] if first else dx[:, :, -1]).copy_(line)
-            if dx_amax is not None:                       # the record must bound the final values: fold the strip's per-sample maxima in
+                (dx[:, :, 0] if first else dx[:, :, -1]).copy_(lo[:, 0])
+            if dx_amax is not None:                       # the record must bound the final values: fold the line's per-sample maxima in
                 torch.maximum(dx_amax, ctx.absmax(lo), out=dx_amax)
         ctx.set_amax(dx, dx_amax)
         return dx
@@ -1246,9 +1257,9 @@ class CelebADecoder:
                 dh, dstyle = norm.backward(dh)
                 g = sty.backward(dstyle)
                 ddlat = g if ddlat is None else add_(ctx, ddlat, g)
-            # the block below ends in instance norm + a factor-2 resize: this conv's backward-data can return the gradient of the resize's INPUT
+            # the block below ends in a factor-2 resize: this conv's backward-data can return the gradient of the resize's INPUT (conv2d_7, conv2d_6)
             below = self.blocks[len(self.blocks) - 2 - bi] if bi + 1 < len(self.blocks) else None
-            lowres = bool(bi == 0 and below is not None and below[2] is not None and below[3] is not None and conv.x is not None
+            lowres = bool(below is not None and below[3] is not None and conv.x is not None and (bi == 0 or self.ctx.up2 >= 3)
                           and (below[3].oh, below[3].ow) == tuple(conv.x.shape[1:3]) and conv.x.shape[1] % 2 == 0
                           and tuple(getattr(below[3], "in_shape", (0, 0, 0))[1:3]) == (conv.x.shape[1] // 2, conv.x.shape[2] // 2)
                           and conv.up2t_ok(conv.x.shape[0], conv.x.shape[1] // 2, conv.x.shape[2] // 2))
@@ -1344,7 +1355,8 @@ class LadderEngine:
         if prec not in PRECISIONS:
             raise ValueError("matmul_precision %r: expected one of %s" % (prec, sorted(PRECISIONS)))
         self.ctx.ns = PRECISIONS[prec]
-        self.ctx.up2 = int(cfg.get("upsample_fused_convs", 2))      # 0: off, 1: forward-only runs, 2: also the training forward of the last 3x3 conv
+        # 0: off, 1: forward-only runs, 2: also the training forward and the backward-data of the last 3x3 conv, 3: also conv2d_6's backward-data (no gain measured)
+        self.ctx.up2 = int(cfg.get("upsample_fused_convs", 2))
         self.precision = prec
         if self.ctx.comm.rank == 0:
             print("Contraction precision (config key matmul_precision): {} -- {}".format(prec, PRECISION_NOTES[prec]))

@@ -223,8 +223,9 @@ def test_up2_backward_data_interior_vs_autograd(gpu_ctx, case):
     assert err[:, 0].max() / scale > 1e-3 and err[:, -1].max() / scale > 1e-3                 # the border lines are NOT final (documented)
 
 
-def test_engine_fused_lowres_backward_agrees_with_direct_path(monkeypatch):
-    """Batch 64, full resolution: with `upsample_fused_convs: 2` the backward-data of conv2d_7 returns the gradient of the 64x64 tensor behind
+@pytest.mark.parametrize("mode", [2, 3])
+def test_engine_fused_lowres_backward_agrees_with_direct_path(monkeypatch, mode):
+    """Batch 128, full resolution: with `upsample_fused_convs: 2` the backward-data of conv2d_7 / conv2d_6 returns the gradient of the tensor behind
     the resize (ladder_conv3x3_up2_bwd_data_split + border strips; the separate resize transpose disappears); every gradient of the AE group
     must agree with the direct path to fp32-class error."""
     import json, os
@@ -232,7 +233,7 @@ def test_engine_fused_lowres_backward_agrees_with_direct_path(monkeypatch):
     from ladder_latent_data_distribution_modelling_amd.engine import LadderEngine
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg = json.load(open(os.path.join(root, "codes", "celeba_config.json")))
-    cfg["batch_size"] = B = 64
+    cfg["batch_size"] = B = 128          # (conv2d_6's pair needs 128 images for the 16-wave kernel's 512 workgroups, conv2d_7's 64)
     rng = np.random.default_rng(41)
     x = rng.random((B, 128, 128, 3)).astype(np.float32)
     Pm = O.init_params(cfg, seed=7)
@@ -248,7 +249,7 @@ def test_engine_fused_lowres_backward_agrees_with_direct_path(monkeypatch):
 
     monkeypatch.setattr(L, "call", spy)
     res = {}
-    for up2 in (0, 2):
+    for up2 in (0, mode):
         eng = LadderEngine(dict(cfg, upsample_fused_convs=up2), "cuda:0", values=Pm, seed=1)
         eng.set_mixture(*gm)
         del calls[:]
@@ -256,9 +257,11 @@ def test_engine_fused_lowres_backward_agrees_with_direct_path(monkeypatch):
         res[up2] = (eng.fetch(), {k: v.detach().cpu().numpy().copy() for k, v in eng.ps.g.items()}, list(calls))
         del eng
         torch.cuda.empty_cache()
-    (f0, g0, c0), (f1, g1, c1) = res[0], res[2]
-    assert c1.count("ladder_conv3x3_up2_bwd_data_split") == 1 and "ladder_conv3x3_up2_bwd_data_split" not in c0
-    assert c1.count("ladder_resize_bilinear_bwd") == c0.count("ladder_resize_bilinear_bwd") - 1 + 4        # the 128 -> 64 transpose is gone; 4 strips
+    (f0, g0, c0), (f1, g1, c1) = res[0], res[mode]
+    nl = mode - 1                                     # layers whose backward-data is fused: conv2d_7 (mode 2), + conv2d_6 (mode 3: no gain measured, off by default)
+    assert c1.count("ladder_conv3x3_up2_bwd_data_split") == nl and "ladder_conv3x3_up2_bwd_data_split" not in c0
+    assert c1.count("ladder_resize_bilinear_bwd") == c0.count("ladder_resize_bilinear_bwd") - 1 + 4 * nl   # the 128 -> 64 transpose is gone; 4 border lines per layer
+    assert c1.count("ladder_resize_bilinear_bwd_gated") == c0.count("ladder_resize_bilinear_bwd_gated") - (nl - 1)   # mode 3: the gated 64 -> 32 one too
     for k in ("elbo", "l1_reconstruction_error", "loss_ae"):
         assert abs(f1[k] - f0[k]) <= 2e-5 * abs(f0[k]) + 1e-6, (k, f1[k], f0[k])
     worst, wname = 0.0, None
