@@ -353,11 +353,11 @@ def main():
         executed_direct = fl["executed"]            # (the native-fp32 leg runs the direct convolutions)
         note = "RUN#3/#4 reuse RUN#2's encoder output (bit-identical): 1.23 GFLOP of the algorithmic 41.4 are not executed"
         used = getattr(trainer.engine.ctx, "up2_used", {})
-        if used:                                   # conv2d_7 (4.832 GFLOP / image forward) in RUN#1 + RUN#2, conv2d_6 (2.416) in RUN#2: 11 / 36 not issued
-            per = {"decoder/conv2d_7": 2 * 4.832e9, "decoder/conv2d_6": 2.416e9}
+        if used:                                   # conv2d_7 (4.832 GFLOP / image forward) in RUN#1 + RUN#2, conv2d_6 (2.416) in RUN#2, conv2d_7's backward-data: 11 / 36 not issued
+            per = {"decoder/conv2d_7": 2 * 4.832e9, "decoder/conv2d_6": 2.416e9, "decoder/conv2d_7:bwd": 4.832e9, "decoder/conv2d_6:bwd": 2.416e9}
             fl["executed"] -= sum(v for k, v in per.items() if k in used) * 11.0 / 36.0
-            note += ("; upsample-fused convolutions (%s): the factor-2 resize in front of the layer is folded into its taps, 25 of every 36 "
-                     "low-resolution tap products are issued" % ", ".join(sorted(used)))
+            note += ("; upsample-fused convolutions (%s): the factor-2 resize in front of the layer is folded into its taps (forward and, ':bwd', "
+                     "backward-data), 25 of every 36 low-resolution tap products are issued" % ", ".join(sorted(used)))
         out["flop_per_image"] = dict(fl, note=note)
         out["whole_step_tflops_per_gpu"] = round(fl["executed"] * value / world / 1e12, 2)
         if "native_f32" in out:

@@ -644,6 +644,7 @@ class Conv2D:
         dx = ctx.empty(N, H, W, self.cin)
         dx_amax = ctx.new_amax() if ctx.ns == 4 else None
         flops = 2.0 * N * OH * OW * 9 * self.cin * self.cout
+        ctx.up2_used[self.name + ":bwd"] = ctx.up2_used.get(self.name + ":bwd", 0) + 1
         _timed(256120 + ctx.ns, flops, "ladder_conv3x3_up2_bwd_data_split",
                (_p(dy), _p(dy_amax), _p(self._packed_filter(4)), _p(dx), _p(dx_amax), N, H, W, self.cout, self.cin, ctx.ns, st), flops * 25.0 / 36.0)
         pk = self._packed_filter(1)
