@@ -131,7 +131,11 @@ int ladder_absmax_samples(const float* x, int n_samples, size_t per_sample, floa
 /* ladder_filter_pack_split: once per weight update, HWIO fp32 bank of ntaps = KH*KW taps -> split planes in the kernels' LDS layout
  * (Cin % 16 == 0; output channels zero-padded to a multiple of 128).
  *   transpose_flip = 0: `w` = [KH][KW][Cin][Cout] (forward).  transpose_flip = 1: `w` = the layer's bank [KH][KW][Cout][Cin] read as
- *   the flipped, transposed filter of its backward-data pass (Cin = dy channels, Cout = dx channels). */
+ *   the flipped, transposed filter of its backward-data pass (Cin = dy channels, Cout = dx channels).
+ *   transpose_flip = 2: the four output-parity classes of a stride-2 backward-data as four 128-channel output tiles (ladder_conv3x3_s2_bwd_data_split).
+ *   transpose_flip = 3: the effective taps of the upsample-fused forward, four output-parity classes (Cout = 4 x 128; ladder_conv3x3_up2_split).
+ *   transpose_flip = 4: the effective taps of its backward-data, the four pixel-parity classes of dy as input groups (Cin = 4 x C;
+ *   ladder_conv3x3_up2_bwd_data_split).  For 3 and 4 the bank's absmax record holds 4 x max|w| (a bound of the effective taps). */
 size_t ladder_filter_pack_split_bytes(int ntaps, int Cin, int Cout, int prec);
 int ladder_filter_pack_split(const float* w, void* packed, int ntaps, int Cin, int Cout, int transpose_flip, int prec,
                              ladder_stream_t stream);
