@@ -197,6 +197,11 @@ int ladder_conv3x3_up2_split_proj(const float* x, const float* x_absmax, const v
 int ladder_conv3x3_up2_bwd_data_split_eligible(int N, int H, int W, int C, int Cout, int prec);
 int ladder_conv3x3_up2_bwd_data_split(const float* dy, const float* dy_absmax, const void* packed_up2t, float* dx, float* dx_absmax, int N, int H,
                                       int W, int C, int Cout, int prec, ladder_stream_t stream);
+/* One border line of dx (axis 1: row 0 / H-1, axis 2: column 0 / W-1; first != 0: the 0 side) from d_up = the plain backward-data on the adjoining
+ * strip of dy (rows strip [N, n_up, 2W, C] / columns strip [N, 2H, n_up, C], n_up = 2 on the 0 side, 3 on the other): the resize transpose across
+ * the strip and along the line in one pass; dx_absmax (the record of the main launch) is raised where needed. */
+int ladder_conv3x3_up2_bwd_border(const float* d_up, float* dx, float* dx_absmax, int N, int H, int W, int C, int axis, int first,
+                                  ladder_stream_t stream);
 /* The last output row and column of the call above, recomputed in fp32 from the last row / column of x and the layer's HWIO bank w
  * [3][3][Cin][Cout] (row 2H-1 sees x[H-1] twice -- the resize clamps -- and the zero padding below; two [N*2W, 3 Cin] x [3 Cin, Cout] GEMMs):
  * written to y [N, 2H, 2W, Cout] and / or, through the fused 1x1 projection pw [Cout][pco] + pb, to pout [N, 2H, 2W, pco]; y_absmax (the

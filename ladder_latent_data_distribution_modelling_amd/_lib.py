@@ -128,6 +128,7 @@ PROTOTYPES = {
     "ladder_conv3x3_up2_split_proj": (_i, [_p] * 8 + [_i] * 9 + [_p]),
     "ladder_conv3x3_up2_bwd_data_split_eligible": (_i, [_i] * 6),
     "ladder_conv3x3_up2_bwd_data_split": (_i, [_p] * 5 + [_i] * 6 + [_p]),
+    "ladder_conv3x3_up2_bwd_border": (_i, [_p, _p, _p] + [_i] * 6 + [_p]),
     "ladder_conv3x3_up2_edges_workspace_bytes": (_z, [_i] * 5),
     "ladder_conv3x3_up2_edges": (_i, [_p] * 8 + [_i] * 8 + [_p, _z, _p]),
     "ladder_conv3x3_s2_bwd_data_split": (_i, [_p, _p, _p, _p, _p] + [_i] * 8 + [_p]),

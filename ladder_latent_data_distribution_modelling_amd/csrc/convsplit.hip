@@ -1178,6 +1178,45 @@ __global__ __launch_bounds__(256) void up2_edge_scatter_kernel(const float* __re
   if (yamax != nullptr) amax_commit_block_sample(m, yamax, n);
 }
 
+// ---- border lines of the fused low-resolution backward-data (ladder_conv3x3_up2_bwd_border) -------------------------------------------------
+// d_up = the plain backward-data on a strip of dy next to an image border: n_up = 2 lines (first border: rows / columns 0, 1) or 3 lines (last
+// border: 2L-3 .. 2L-1).  The border line of dx_lo is the resize transpose across the strip -- t = d0 + d1 / 2 resp. d0 / 2 + d1 + d2 -- followed by
+// the 1-D legacy resize transpose ALONG the line: lo[q] = t[2q] + t[2q-1] / 2 (q > 0) + t[2q+1] x (1/2, or 1 at the clamped end).
+// One thread = one (sample, position q, channel quad); grid (ceil(L * C / 4 / 256), N).
+__global__ __launch_bounds__(256) void up2_bwd_border_kernel(const float* __restrict__ dup, float* __restrict__ dx, float* __restrict__ rec,
+                                                             int H, int W, int C, int axis, int first) {
+  const int n = blockIdx.y, CV = C >> 2;
+  const int Lq = axis == 1 ? W : H, n_up = first ? 2 : 3;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float m = 0.f;
+  if (i < Lq * CV) {
+    const int cv = i % CV, q = i / CV;
+    // element (line k, position X on the upsampled line) of the strip: rows strip [N][n_up][2W][C], columns strip [N][2H][n_up][C]
+    auto at = [&](int k, int X) -> float4 {
+      const size_t pix = axis == 1 ? ((size_t)n * n_up + k) * (2 * W) + X : ((size_t)n * (2 * H) + X) * n_up + k;
+      return reinterpret_cast<const float4*>(dup)[pix * CV + cv];
+    };
+    auto tline = [&](int X) -> float4 {
+      const float4 a = at(0, X), b = at(1, X);
+      if (first) return make_float4(a.x + 0.5f * b.x, a.y + 0.5f * b.y, a.z + 0.5f * b.z, a.w + 0.5f * b.w);
+      const float4 c = at(2, X);
+      return make_float4(0.5f * a.x + b.x + c.x, 0.5f * a.y + b.y + c.y, 0.5f * a.z + b.z + c.z, 0.5f * a.w + b.w + c.w);
+    };
+    float4 v = tline(2 * q);
+    if (q > 0) {
+      const float4 u = tline(2 * q - 1);
+      v = make_float4(v.x + 0.5f * u.x, v.y + 0.5f * u.y, v.z + 0.5f * u.z, v.w + 0.5f * u.w);
+    }
+    const float4 u = tline(2 * q + 1);
+    const float wt = q < Lq - 1 ? 0.5f : 1.f;
+    v = make_float4(v.x + wt * u.x, v.y + wt * u.y, v.z + wt * u.z, v.w + wt * u.w);
+    const size_t opix = axis == 1 ? ((size_t)n * H + (first ? 0 : H - 1)) * W + q : ((size_t)n * H + q) * W + (first ? 0 : W - 1);
+    reinterpret_cast<float4*>(dx)[opix * CV + cv] = v;
+    m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (rec != nullptr) amax_commit_block_sample(m, rec, n);
+}
+
 // the 16-row patch variant: two-plane formats, enough patches for two rounds of the chip
 bool split_halo16_ok(int N, int H, int W, int Cin, int Cout, int prec) {
   static const bool off = getenv("LADDER_DISABLE_HALO16") != nullptr;
@@ -1453,6 +1492,19 @@ int ladder_conv3x3_up2_bwd_data_split(const float* dy, const float* dy_absmax, c
   if (!ladder_conv3x3_up2_bwd_data_split_eligible(N, H, W, C, Cout, prec)) return LADDER_E_SHAPE;
   return conv3x3_split_launch(dy, dy_absmax, packed_up2t, nullptr, dx, dx_absmax, nullptr, nullptr, nullptr, 0, N, H, W, 4 * C, Cout,
                               LADDER_ACT_NONE, prec, stream, up2t_tap_masks(), 4);
+}
+
+// One border line of dx_lo [N, H, W, C] from the plain backward-data on the adjoining strip of dy (d_up: rows strip [N, n_up, 2W, C] for axis 1,
+// columns strip [N, 2H, n_up, C] for axis 2; n_up = 2 at the first border, 3 at the last): see the kernel.  dx_absmax (per-sample record of the
+// main launch) is raised where a border value exceeds it.
+int ladder_conv3x3_up2_bwd_border(const float* d_up, float* dx, float* dx_absmax, int N, int H, int W, int C, int axis, int first,
+                                  ladder_stream_t stream) {
+  if (N <= 0 || H <= 1 || W <= 1 || C <= 0 || (C % 4) != 0 || (axis != 1 && axis != 2)) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(d_up) || !ladder_aligned16(dx)) return LADDER_E_ALIGN;
+  const int Lq = axis == 1 ? W : H;
+  hipLaunchKernelGGL(up2_bwd_border_kernel, dim3((Lq * (C / 4) + 255) / 256, N), dim3(256), 0, stream, d_up, dx, dx_absmax, H, W, C, axis, first ? 1 : 0);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
 }
 
 static size_t up2_align(size_t b) { return (b + 255) & ~(size_t)255; }

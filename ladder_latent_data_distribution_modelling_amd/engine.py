@@ -665,18 +665,7 @@ class Conv2D:
             s_amax = ctx.absmax(s)
             wsp, wsn = ctx.ws(L.query("ladder_conv2d_bwd_data_split_workspace_bytes", *geo))
             L.call("ladder_conv2d_bwd_data_split", _p(ctx.planes(s, self._ps(geo[1], geo[2]))), _p(s_amax), _p(pk), _p(dup), *geo, None, 0, ctx.ns, wsp, wsn, st)
-            d = dup if axis == 1 else dup.transpose(1, 2)                  # [N, line index, position on the line, cin]
-            t = (d[:, 0] + 0.5 * d[:, 1]) if first else (0.5 * d[:, 0] + d[:, 1] + d[:, 2])
-            t = t.contiguous()
-            Lp = OW if axis == 1 else OH
-            lo = ctx.empty(N, 1, Lp // 2, self.cin)
-            L.call("ladder_resize_bilinear_bwd", _p(t), _p(lo), N, 1, Lp // 2, self.cin, 1, Lp, st)
-            if axis == 1:
-                (dx[:, 0] if first else dx[:, -1]).copy_(lo[:, 0])
-            else:
-                (dx[:, :, 0] if first else dx[:, :, -1]).copy_(lo[:, 0])
-            if dx_amax is not None:                       # the record must bound the final values: fold the line's per-sample maxima in
-                torch.maximum(dx_amax, ctx.absmax(lo), out=dx_amax)
+            L.call("ladder_conv3x3_up2_bwd_border", _p(dup), _p(dx), _p(dx_amax), N, H, W, self.cin, axis, 1 if first else 0, st)
         ctx.set_amax(dx, dx_amax)
         return dx
 

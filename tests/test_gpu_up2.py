@@ -260,7 +260,8 @@ def test_engine_fused_lowres_backward_agrees_with_direct_path(monkeypatch, mode)
     (f0, g0, c0), (f1, g1, c1) = res[0], res[mode]
     nl = mode - 1                                     # layers whose backward-data is fused: conv2d_7 (mode 2), + conv2d_6 (mode 3: no gain measured, off by default)
     assert c1.count("ladder_conv3x3_up2_bwd_data_split") == nl and "ladder_conv3x3_up2_bwd_data_split" not in c0
-    assert c1.count("ladder_resize_bilinear_bwd") == c0.count("ladder_resize_bilinear_bwd") - 1 + 4 * nl   # the 128 -> 64 transpose is gone; 4 border lines per layer
+    assert c1.count("ladder_resize_bilinear_bwd") == c0.count("ladder_resize_bilinear_bwd") - 1            # the 128 -> 64 transpose is gone
+    assert c1.count("ladder_conv3x3_up2_bwd_border") == 4 * nl                                            # 4 border lines per layer
     assert c1.count("ladder_resize_bilinear_bwd_gated") == c0.count("ladder_resize_bilinear_bwd_gated") - (nl - 1)   # mode 3: the gated 64 -> 32 one too
     for k in ("elbo", "l1_reconstruction_error", "loss_ae"):
         assert abs(f1[k] - f0[k]) <= 2e-5 * abs(f0[k]) + 1e-6, (k, f1[k], f0[k])
@@ -273,3 +274,36 @@ def test_engine_fused_lowres_backward_agrees_with_direct_path(monkeypatch, mode)
                 worst, wname = e, name
     print("worst relative gradient difference %.2e (%s)" % (worst, wname))
     assert worst < 2e-4, (worst, wname)
+
+
+@pytest.mark.parametrize("axis,first", [(1, 1), (1, 0), (2, 1), (2, 0)])
+def test_up2_bwd_border_line_kernel(gpu_ctx, axis, first):
+    """ladder_conv3x3_up2_bwd_border against the float64 transpose of the legacy factor-2 resize applied to a d_up that is zero outside the strip
+    (the border line of dx depends on the strip's lines only)."""
+    L = _lib()
+    rng = np.random.default_rng(axis * 2 + first)
+    N, H, W, C = 3, 6, 10, 8
+    n_up = 2 if first else 3
+    shape = (N, n_up, 2 * W, C) if axis == 1 else (N, 2 * H, n_up, C)
+    dup = rng.standard_normal(shape).astype(np.float32)
+    full = np.zeros((N, 2 * H, 2 * W, C))
+    if axis == 1:
+        full[:, (slice(0, 2) if first else slice(2 * H - 3, 2 * H))] = dup
+    else:
+        full[:, :, (slice(0, 2) if first else slice(2 * W - 3, 2 * W))] = dup
+    x = torch.zeros(N, H, W, C, dtype=torch.float64, requires_grad=True)
+    O.resize_bilinear_legacy(x, 2 * H, 2 * W).backward(torch.as_tensor(full))
+    ref = x.grad.numpy()
+    dx = torch.full((N, H, W, C), 7.0, device="cuda")
+    rec = torch.zeros(L.ABSMAX_FLOATS, device="cuda")
+    rec[1] = 1.0                                                    # a per-sample record (as the main launch leaves it)
+    L.call("ladder_conv3x3_up2_bwd_border", p(dev(dup)), p(dx), p(rec), N, H, W, C, axis, first, gpu_ctx.stream)
+    got = dx.cpu().numpy()
+    line = (slice(None), 0 if first else H - 1) if axis == 1 else (slice(None), slice(None), 0 if first else W - 1)
+    np.testing.assert_allclose(got[line], ref[line], rtol=1e-6, atol=1e-6)
+    mask = np.ones_like(got, bool)
+    mask[line] = False
+    assert (got[mask] == 7.0).all()                                  # nothing else is touched
+    from test_gpu_split import rec_sample
+    for n in range(N):
+        assert abs(rec_sample(rec, n) - float(np.abs(got[line][n]).max())) < 1e-6
