@@ -758,6 +758,8 @@ class Conv2D:
             else:
                 L.call("ladder_conv2d_bwd_filter", *wargs)
         dx = None
+        if lowres_dx and not split_d:
+            raise RuntimeError("%s: the low-resolution backward-data was requested for a call the split halo kernels do not take" % self.name)
         if split_d and lowres_dx:
             dx = self._dx_lowres(dy, dy_amax)
         elif split_d:
