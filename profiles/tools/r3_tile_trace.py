@@ -1,5 +1,5 @@
 """Per-workgroup timeline of the split halo kernels; needs the library built with profiles/tools/r3_tile_trace.patch applied
-(git apply profiles/tools/r3_tile_trace.patch; python -m ladder_latent_data_distribution_modelling_amd.csrc.build; revert afterwards).
+(the patch is against csrc/convsplit.hip of commit b1e9961: check that file out, git apply profiles/tools/r3_tile_trace.patch, python -m ladder_latent_data_distribution_modelling_amd.csrc.build; revert afterwards).
 usage: [LADDER_DISABLE_HALO16=1] [LADDER_HALO_STAGGER=n] python3 profiles/tools/r3_tile_trace.py"""
 import os, sys, json
 import numpy as np
