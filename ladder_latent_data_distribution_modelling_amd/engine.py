@@ -662,6 +662,7 @@ class Conv2D:
             else:
                 geo = (N, OH, n_up, self.cin, OH, n_dy, self.cout, 3, 3, 1, 1, pad)
                 dup = ctx.empty(N, OH, n_up, self.cin)
+            ctx.set_amax(s, dy_amax)                                       # (a strip of dy: the per-sample record of dy bounds it, no extra pass)
             s_amax = ctx.absmax(s)
             wsp, wsn = ctx.ws(L.query("ladder_conv2d_bwd_data_split_workspace_bytes", *geo))
             L.call("ladder_conv2d_bwd_data_split", _p(ctx.planes(s, self._ps(geo[1], geo[2]))), _p(s_amax), _p(pk), _p(dup), *geo, None, 0, ctx.ns, wsp, wsn, st)
