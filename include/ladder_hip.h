@@ -108,6 +108,13 @@ int ladder_conv1x1_smallcout_bwd_absmax(const float* x, const float* dy, const f
  *                       else per tensor (x_absmax: see the record layouts below; the filter's is taken by the pack call).
  *   LADDER_PREC_BF16X6  3 bf16 planes = 24 bits, 6 products, dropped terms <= 2^-23 relative (fp32 class); no scaling.
  *   LADDER_PREC_BF16X3  2 bf16 planes = 16 bits, 3 products, <= 3 * 2^-17 relative.
+ *   LADDER_PREC_F32     (round 4) NO splitting: the same fused kernels on v_mfma_f32_32x32x2_f32, bit-exact fp32 FMA chains
+ *                       (csrc/convf32.hip).  `packed` is then the fp32 bank [ntaps][Cin][Cout] of the orientation
+ *                       (ladder_filter_pack_split with this prec; orientation 0 = the HWIO bank itself, which may be passed directly),
+ *                       every *_absmax argument is ignored and may be NULL.  Accepted by ladder_filter_pack_split(_bytes / _multi),
+ *                       ladder_conv3x3_split(_proj), ladder_conv3x3_up2_split(_proj), ladder_conv3x3_up2_bwd_data_split and
+ *                       ladder_conv3x3_s2_bwd_data_split; the gather / filter-gradient *_split entry points are 16-bit only (their
+ *                       strict-fp32 counterparts are ladder_conv2d_fwd / _bwd_data / _bwd_filter).
  * Replaces the same call sites as ladder_conv2d_fwd / ladder_conv2d_bwd_data for 3x3 / stride 1 / SAME layers with W % 32 == 0,
  * H % 8 == 0, Cin % 16 == 0, Cout % 4 == 0, Cout >= 64 and >= 512 workgroups (codes/models.py:538-578: the decoder's
  * 32x32 ... 128x128 maps). */
@@ -290,6 +297,17 @@ int ladder_dense_bwd_weight_small(const float* x, const float* dy, float* dw, fl
 /* Both gradient calls of a layer in ONE launch (a launch costs as much as the arithmetic of one of them): dx and dw must not be NULL. */
 int ladder_dense_bwd_small(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int M, int K, int N,
                            const float* gate_y, int gate_act, ladder_stream_t stream);
+/* The same four calls in STRICT fp32 (round 4; the engine uses them when matmul_precision is "f32", the reference's arithmetic:
+ * tf.layers.dense on fp32 tensors, codes/models.py:478-510, codes/base.py:145-186): every product on v_mfma_f32_32x32x2_f32 /
+ * v_mfma_f32_16x16x4_f32 -- bit-exact fp32 FMA chains; same one-launch structure, same eligibility, deterministic fixed-order reduction
+ * over the workgroup's wavefronts.  Replaces ladder_dense_fwd / _bwd_data / _bwd_weight (+ ladder_filter_flip_transpose + the split-K
+ * second pass) for batch-sized layers. */
+int ladder_dense_fwd_small_f32(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act, ladder_stream_t stream);
+int ladder_dense_bwd_data_small_f32(const float* dy, const float* w, float* dx, int M, int K, int N, const float* gate_y, int gate_act,
+                                    ladder_stream_t stream);
+int ladder_dense_bwd_weight_small_f32(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, ladder_stream_t stream);
+int ladder_dense_bwd_small_f32(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int M, int K, int N,
+                               const float* gate_y, int gate_act, ladder_stream_t stream);
 
 
 /* The image-side convolution of the CelebA encoder (codes/models.py:398-405: 3x3, stride 2, SAME, 3 -> Cout channels over even-sized RGB

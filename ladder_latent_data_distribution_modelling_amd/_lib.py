@@ -137,6 +137,10 @@ PROTOTYPES = {
     "ladder_dense_bwd_data_small": (_i, [_p, _p, _p, _i, _i, _i, _p, _i, _p]),
     "ladder_dense_bwd_weight_small": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "ladder_dense_bwd_small": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _p]),
+    "ladder_dense_fwd_small_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "ladder_dense_bwd_data_small_f32": (_i, [_p, _p, _p, _i, _i, _i, _p, _i, _p]),
+    "ladder_dense_bwd_weight_small_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "ladder_dense_bwd_small_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _p]),
     "ladder_presplit_bytes": (_z, [_z, _i]),
     "ladder_presplit": (_i, [_p, _p, _p, _z, _i, _i, _p]),
     "ladder_absmax_samples": (_i, [_p, _i, _z, _p, _p]),

@@ -43,10 +43,14 @@ class BaseTrain:
         self._pending = []             # [(fetch handle, callback)] in enqueue order
         self._last_fetch_sigma, self._last_fetch_prior = None, None
 
-    def flush(self):
-        """Complete the record lists from every fetch still in flight (in order)."""
-        pend, self._pending = self._pending, []
-        for h, cb in pend:
+    def flush(self, wait=True):
+        """Complete the record lists from every fetch still in flight (in order).  `wait=False`: only the leading fetches whose copy has
+        already landed -- the host never blocks (the order of the record lists is kept: a fetch still in flight holds back the ones behind it)."""
+        while self._pending:
+            h, cb = self._pending[0]
+            if not wait and not h.ready():
+                break
+            self._pending.pop(0)
             cb(h.get())
 
     @property
@@ -167,7 +171,9 @@ class BaseTrain:
         if cfg["prior"] != "vampPrior" and int(cfg["TRAIN_inner_sigma"]) == 1:
             lr_i = float(cfg["learning_rate_inner_sigma"]) * (1.01 ** (self.cur_epoch - 1))
             eng.run_inner_sigma(batch_data, lr_i, noise[1] if noise else None, use_sg, use_mask, reuse_encoder=True)
-        self.flush()                          # RUN#2's sigma (finished before RUN#3 started: no wait), earlier iterations' values
+        # RUN#2's sigma and earlier iterations' values -- whatever has landed.  Never a blocking wait here: with the prior runs on the aux
+        # stream RUN#2 is still executing beside them, and a host stall now would delay the enqueue of the next RUN#1
+        self.flush(wait=False)
         self._pending.append((h3, self._record_prior))
         if not self.async_fetch:
             self.flush()
@@ -285,6 +291,12 @@ class BaseTrain:
                 print("Final fitted prior saved.")
         w = w.cpu().numpy() if isinstance(w, torch.Tensor) else np.asarray(w)
         print("There are {} active mixtures.".format(int(np.sum(w >= 1e-2))))
+        if comm.on and self._sharded_fit(self.model.GM_prior_training if mode == "fast" else self.GM_prior_final):
+            # the sharded fit kept every rank's samples local; the reference returns the set the mixture was fitted on (base.py:747,789):
+            # ONE all-gather at the end (rank-major), off the fit's critical path
+            parts = [torch.empty_like(samples) for _ in range(comm.world)]
+            comm.dist.all_gather(parts, samples.contiguous(), group=comm.group)
+            samples = torch.cat(parts, 0)
         return samples.cpu().numpy().astype(np.float64)
 
     def _fit_GMM_z(self, iterator, mode):

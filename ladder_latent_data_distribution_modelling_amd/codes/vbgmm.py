@@ -124,6 +124,10 @@ class DeviceBayesianGaussianMixture:
         mom = f64(L.query("ladder_vbgmm_shard_moments_doubles", R))
         L.call("ladder_vbgmm_shard_moments", Xd.data_ptr(), Nl, R, mom.data_ptr(), st)
         comm.allreduce_(mom)
+        n_glob = torch.full((1,), float(Nl), dtype=torch.float64, device=self.device)
+        comm.allreduce_(n_glob)
+        if int(n_glob.item()) < K:                                             # sklearn's check, on the GLOBAL sample count
+            raise ValueError("Expected n_samples >= n_components but got n_components = %d, n_samples = %d" % (K, int(n_glob.item())))
         stats = f64(L.query("ladder_vbgmm_shard_stats_doubles", K, R))
         ws = torch.empty(L.query("ladder_vbgmm_shard_workspace_bytes", Nl, K, R), dtype=torch.uint8, device=self.device)
         do_init = not (self.warm_start and self._state is not None and hasattr(self, "converged_"))

@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["igemm.hip", "convsplit.hip", "densesplit.hip", "convrgb.hip", "norm.hip", "elbo.hip", "hostutil.hip", "vbgmm.hip"]
+SOURCES = ["igemm.hip", "convsplit.hip", "convf32.hip", "densesplit.hip", "convrgb.hip", "norm.hip", "elbo.hip", "hostutil.hip", "vbgmm.hip"]
 LIB = os.path.join(HERE, "libladder_hip.so")
 
 
@@ -19,7 +19,7 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, "common.h"), os.path.join(HERE, "split16.h"),
+    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, h) for h in ("common.h", "split16.h", "filterbank.h", "convf32.h")] + [
                                                        os.path.join(ROOT, "include", "ladder_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 

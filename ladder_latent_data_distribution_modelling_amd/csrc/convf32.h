@@ -1,0 +1,20 @@
+// Internal interface of convf32.hip: the strict-fp32 (v_mfma_f32_32x32x2_f32) forms of the fused 3x3 halo convolutions.  The exported entry
+// points are the ladder_conv3x3_*_split* / ladder_filter_pack_split* functions of include/ladder_hip.h called with prec = LADDER_PREC_F32:
+// convsplit.hip forwards those calls here.
+#pragma once
+#include "common.h"
+
+// geometry the fp32 halo kernel takes (8x32-pixel x 128-channel tiles, >= 512 workgroups): the same predicate as the split kernels'
+bool conv3x3_f32_halo_ok(int N, int H, int W, int Cin, int Cout);
+
+// fp32 bank [ntaps][Cin][Cout] of the LOGICAL filter of an orientation (filterbank.h): bytes, one bank, all banks of a job table
+size_t filter_pack_f32_bytes(int ntaps, int Cin, int Cout);
+int filter_pack_f32(const float* w, float* bank, int ntaps, int Cin, int Cout, int transpose_flip, hipStream_t stream);
+int filter_pack_f32_multi(const ladder_pack_job_t* jobs_dev, int njobs, int total_blocks, hipStream_t stream);
+
+// y = act(conv3x3_same(x, bank) + bias) [+ fused 1x1 projection]; tap_masks / s2_out as in conv3x3_split_launch (convsplit.hip):
+//   s2_out 0 plain, 1 class-interleaved output of a stride-2 backward-data, 2 / 3 upsample-fused forward (x low-resolution / the even
+//   sub-grid of an upsampled tensor), 4 backward-data of the upsample-fused pair (x = dy, classes = input-channel groups)
+int conv3x3_f32_launch(const float* x, const float* bank, const float* bias, float* y, const float* pw, const float* pb, float* pout,
+                       int pco, int N, int H, int W, int Cin, int Cout, int act, hipStream_t stream, unsigned long long tap_masks,
+                       int s2_out);

@@ -27,6 +27,8 @@
 //                               planes while it is staged into LDS.
 #include <cstdlib>
 #include "split16.h"
+#include "filterbank.h"
+#include "convf32.h"
 
 namespace {
 
@@ -141,53 +143,8 @@ __device__ __forceinline__ void filter_pack_element(const float* __restrict__ w,
   float v[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    float f = 0.f;
-    if (co < Cout) {
-      if (transpose_flip == 2) {
-        // stride-2 parity bank (ladder_conv3x3_s2_bwd_data_split): w = the layer's HWIO bank [3][3][C][Cin] with C = Cout / 4 its INPUT channels;
-        // output column co = class * C + c, class = (ph, pw); tap (a, b) of the 3x3 / stride-1 correlation over dy carries w[r][s][c][ci]
-        // with r = (a == 1 ? ph : 2) for a in A(ph) = {1} u {0 if ph == 0}, s likewise -- zero elsewhere (those taps are never issued)
-        const int C = Cout >> 2, cls = co / C, cc = co - cls * C, ph = cls >> 1, pw = cls & 1, a = tap / 3, b = tap - 3 * a;
-        const bool va = a == 1 || (a == 0 && ph == 0), vb = b == 1 || (b == 0 && pw == 0);
-        if (va && vb) {
-          const int r = a == 1 ? ph : 2, sx = b == 1 ? pw : 2;
-          f = w[(((size_t)r * 3 + sx) * C + cc) * Cin + ci0 + j];
-        }
-      } else if (transpose_flip == 3) {
-        // upsample-fused bank (ladder_conv3x3_up2_split): a 3x3 / SAME convolution of the factor-2 legacy-bilinear upsample of x equals,
-        // per output-parity class (a, b) = (row % 2, col % 2), a 3x3 correlation over x ITSELF with
-        //   W_eff[a,b][dr][dc] = sum_{r,s} A_a[dr][r] A_b[dc][s] w[r][s],   A_0 = [[1/2,0,0],[1/2,1,1/2],[0,0,1/2]],  A_1 = [[0,0,0],[1,1/2,0],[0,1/2,1]]
-        // (up[2i] = x[i], up[2i+1] = (x[i] + x[i+1]) / 2): class (a, b) issues 3 - a rows x 3 - b columns of taps, 25 instead of 36
-        // low-resolution tap products.  w = the layer's HWIO bank [3][3][Cin][C], C = Cout / 4; output column co = class * C + c.
-        const int C = Cout >> 2, cls = co / C, cc = co - cls * C, a = cls >> 1, b = cls & 1, dr = tap / 3, dc = tap - 3 * dr;
-        const float A0[3][3] = {{0.5f, 0.f, 0.f}, {0.5f, 1.f, 0.5f}, {0.f, 0.f, 0.5f}}, A1[3][3] = {{0.f, 0.f, 0.f}, {1.f, 0.5f, 0.f}, {0.f, 0.5f, 1.f}};
-        for (int r = 0; r < 3; ++r) {
-          const float ar = a ? A1[dr][r] : A0[dr][r];
-          if (ar == 0.f) continue;
-          for (int sx = 0; sx < 3; ++sx) {
-            const float bs = b ? A1[dc][sx] : A0[dc][sx];
-            if (bs != 0.f) f += (ar * bs) * w[(((size_t)r * 3 + sx) * Cin + ci0 + j) * C + cc];      // (ar * bs: exact powers of two)
-          }
-        }
-      } else if (transpose_flip == 4) {
-        // backward-data of the upsample-fused pair (ladder_conv3x3_up2_bwd_data_split): dx_lo[p] = sum_{k = -2..2} G_k^T dy[2p + k] per axis, a 5x5 /
-        // stride-2 correlation over dy = a 3x3 correlation over the four pixel-parity classes of dy taken as input-channel groups (class a
-        // holds the taps k = 2 (dr - 1) + a); G = the forward tables mirrored: coefficient of w[r] in tap dr of class a = A_a[2 - dr][r].
-        // w = the layer's HWIO bank [3][3][Cout][C] (its INPUT channels are this GEMM's outputs), C = Cin / 4 = channels of dy.
-        const int C = Cin >> 2, civ = ci0 + j, cls = civ / C, cc = civ - cls * C, a = cls >> 1, b = cls & 1, dr = tap / 3, dc = tap - 3 * dr;
-        const float A0[3][3] = {{0.5f, 0.f, 0.f}, {0.5f, 1.f, 0.5f}, {0.f, 0.f, 0.5f}}, A1[3][3] = {{0.f, 0.f, 0.f}, {1.f, 0.5f, 0.f}, {0.f, 0.5f, 1.f}};
-        for (int r = 0; r < 3; ++r) {
-          const float ar = a ? A1[2 - dr][r] : A0[2 - dr][r];
-          if (ar == 0.f) continue;
-          for (int sx = 0; sx < 3; ++sx) {
-            const float bs = b ? A1[2 - dc][sx] : A0[2 - dc][sx];
-            if (bs != 0.f) f += (ar * bs) * w[(((size_t)r * 3 + sx) * Cout + co) * C + cc];
-          }
-        }
-      } else {
-        f = transpose_flip ? w[((size_t)(ntaps - 1 - tap) * Cout + co) * Cin + ci0 + j] : w[((size_t)tap * Cin + ci0 + j) * Cout + co];
-      }
-    }
+    // (the logical bank F[tap][ci][co] of the orientation: filterbank.h -- shared with the fp32 banks of convf32.hip)
+    const float f = co < Cout ? filter_bank_element(w, ntaps, Cin, Cout, transpose_flip, tap, ci0 + j, co) : 0.f;
     v[j] = f * c;
   }
   uint2 lo[NS], hi[NS];
@@ -303,7 +260,7 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
   const int l31 = lane & 31, lh = lane >> 5;
   const int wm = wid >> 1, wn = wid & 1;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt = tile / tiles_n, cot = tile % tiles_n, n0 = cot * SP_BN;
+  const int mt = tile / tiles_n, cot = class_tile(tile % tiles_n, mt, tiles_n, UPM != 2 && s2_out != 0), n0 = cot * SP_BN;   // (class tiles rotate with the patch: common.h)
   const int tw_n = W / SP_W, th_n = H / SP_H;
   const int img = mt / (tw_n * th_n), rem = mt - img * (tw_n * th_n);
   const int h0 = (rem / tw_n) * SP_H, w0 = (rem % tw_n) * SP_W;
@@ -433,7 +390,7 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
   const int e_lane = e_tid & 63, e_wid = e_tid >> 6;
   const int l31 = e_lane & 31, lh = e_lane >> 5, wm = e_wid >> 1, wn = e_wid & 1;
   const int e_tile = xcd_remap(e_bid, gridDim.x);
-  const int e_mt = e_tile / tiles_n, n0 = (e_tile % tiles_n) * SP_BN;
+  const int e_mt = e_tile / tiles_n, e_cot = class_tile(e_tile % tiles_n, e_mt, tiles_n, UPM != 2 && s2_out != 0), n0 = e_cot * SP_BN;
   const int e_twn = W / SP_W, e_thn = H / SP_H;
   const int img = e_mt / (e_twn * e_thn), e_rem = e_mt - img * (e_twn * e_thn);
   const int h0 = (e_rem / e_twn) * SP_H, w0 = (e_rem % e_twn) * SP_W;
@@ -447,7 +404,7 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
       for (int mi = 0; mi < 2; ++mi) {
         // s2_out: this output-channel tile is one PARITY CLASS (ph, pw) = (cot >> 1, cot & 1) of a stride-2 backward-data result: pixel
         // (h, w) of the class is dx[2h + ph, 2w + pw], channels = the tile's 128 (the 4 class tiles interleave into [N, 2H, 2W, 128])
-        float* yp = s2_out ? y + (((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_tile % tiles_n >> 1)) * 2 * W + 2 * w0 + (e_tile % tiles_n & 1)) * SP_BN + (n - n0)
+        float* yp = s2_out ? y + (((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_cot >> 1)) * 2 * W + 2 * w0 + (e_cot & 1)) * SP_BN + (n - n0)
                            : y + (((long)img * H + h0 + 2 * wm + mi) * W + w0) * Cout + n;
         const long pstride = s2_out ? 2 * SP_BN : Cout;
 #pragma unroll
@@ -478,7 +435,7 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       // (s2_out: this tile is one output-parity class of a [N, 2H, 2W, 128] map and owns all its 128 channels, see the lane = channel branch)
-      const long opix = s2_out ? ((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_tile % tiles_n >> 1)) * 2 * W + 2 * (w0 + l31) + (e_tile % tiles_n & 1)
+      const long opix = s2_out ? ((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_cot >> 1)) * 2 * W + 2 * (w0 + l31) + (e_cot & 1)
                                : ((long)img * H + h0 + 2 * wm + mi) * W + w0 + l31;
       const int coff = s2_out ? n0 : 0;
       float* yp = y != nullptr ? y + opix * (s2_out ? SP_BN : Cout) - coff : nullptr;
@@ -534,7 +491,7 @@ __global__ __launch_bounds__(SP_THREADS, Fmt<PREC>::NS == 2 ? 4 : 2) void conv3x
       for (int mi = 0; mi < 2; ++mi) {
         const float4 other = *reinterpret_cast<const float4*>(red + (((wm * 2 + mi) * 32 + l31) * 4));
         const float t[4] = {pacc[mi][0] + other.x, pacc[mi][1] + other.y, pacc[mi][2] + other.z, pacc[mi][3] + other.w};
-        const long opix = s2_out ? ((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_tile % tiles_n >> 1)) * 2 * W + 2 * (w0 + l31) + (e_tile % tiles_n & 1)
+        const long opix = s2_out ? ((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_cot >> 1)) * 2 * W + 2 * (w0 + l31) + (e_cot & 1)
                                  : ((long)img * H + h0 + 2 * wm + mi) * W + w0 + l31;
         float* op = pout + opix * pco;
         for (int o = 0; o < pco; ++o) op[o] = t[o] + (pb != nullptr ? pb[o] : 0.f);
@@ -581,7 +538,7 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
   const int l31 = lane & 31, lh = lane >> 5;
   const int wm = wid >> 1, wn = wid & 1;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt = tile / tiles_n, cot = tile % tiles_n, n0 = cot * SP_BN;
+  const int mt = tile / tiles_n, cot = class_tile(tile % tiles_n, mt, tiles_n, UPM != 2 && s2_out != 0), n0 = cot * SP_BN;   // (class tiles rotate with the patch: common.h)
   const int tw_n = W / SP_W, th_n = H / F_H;
   const int img = mt / (tw_n * th_n), rem = mt - img * (tw_n * th_n);
   const int h0 = (rem / tw_n) * F_H, w0 = (rem % tw_n) * SP_W;
@@ -731,7 +688,7 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
   const int e_lane = e_tid & 63, e_wid = e_tid >> 6;
   const int l31 = e_lane & 31, lh = e_lane >> 5, wm = e_wid >> 1, wn = e_wid & 1;
   const int e_tile = xcd_remap(e_bid, gridDim.x);
-  const int e_mt = e_tile / tiles_n, n0 = (e_tile % tiles_n) * SP_BN;
+  const int e_mt = e_tile / tiles_n, e_cot = class_tile(e_tile % tiles_n, e_mt, tiles_n, UPM != 2 && s2_out != 0), n0 = e_cot * SP_BN;
   const int e_twn = W / SP_W, e_thn = H / F_H;
   const int img = e_mt / (e_twn * e_thn), e_rem = e_mt - img * (e_twn * e_thn);
   const int h0 = (e_rem / e_twn) * F_H, w0 = (e_rem % e_twn) * SP_W;
@@ -745,7 +702,7 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
       for (int mi = 0; mi < 2; ++mi) {
         // s2o: this output-channel tile is one PARITY CLASS (ph, pw) = (cot >> 1, cot & 1) of a stride-2 backward-data result: pixel
         // (h, w) of the class is dx[2h + ph, 2w + pw], channels = the tile's 128 (the 4 class tiles interleave into [N, 2H, 2W, 128])
-        float* yp = s2o ? y + (((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_tile % tiles_n >> 1)) * 2 * W + 2 * w0 + (e_tile % tiles_n & 1)) * SP_BN + (n - n0)
+        float* yp = s2o ? y + (((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_cot >> 1)) * 2 * W + 2 * w0 + (e_cot & 1)) * SP_BN + (n - n0)
                            : y + (((long)img * H + h0 + 2 * wm + mi) * W + w0) * Cout + n;
         const long pstride = s2o ? 2 * SP_BN : Cout;
 #pragma unroll
@@ -776,7 +733,7 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       // (s2o: this tile is one output-parity class of a [N, 2H, 2W, 128] map and owns all its 128 channels, see the lane = channel branch)
-      const long opix = s2o ? ((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_tile % tiles_n >> 1)) * 2 * W + 2 * (w0 + l31) + (e_tile % tiles_n & 1)
+      const long opix = s2o ? ((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_cot >> 1)) * 2 * W + 2 * (w0 + l31) + (e_cot & 1)
                                : ((long)img * H + h0 + 2 * wm + mi) * W + w0 + l31;
       const int coff = s2o ? n0 : 0;
       float* yp = y != nullptr ? y + opix * (s2o ? SP_BN : Cout) - coff : nullptr;
@@ -832,7 +789,7 @@ __global__ __launch_bounds__(F_THREADS) void conv3x3_halo_split16_kernel(const f
       for (int mi = 0; mi < 2; ++mi) {
         const float4 other = *reinterpret_cast<const float4*>(red + (((wm * 2 + mi) * 32 + l31) * 4));
         const float t[4] = {pacc[mi][0] + other.x, pacc[mi][1] + other.y, pacc[mi][2] + other.z, pacc[mi][3] + other.w};
-        const long opix = s2o ? ((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_tile % tiles_n >> 1)) * 2 * W + 2 * (w0 + l31) + (e_tile % tiles_n & 1)
+        const long opix = s2o ? ((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (e_cot >> 1)) * 2 * W + 2 * (w0 + l31) + (e_cot & 1)
                                  : ((long)img * H + h0 + 2 * wm + mi) * W + w0 + l31;
         float* op = pout + opix * pco;
         for (int o = 0; o < pco; ++o) op[o] = t[o] + (pb != nullptr ? pb[o] : 0.f);
@@ -1279,12 +1236,18 @@ int ladder_presplit(const float* x, const float* x_absmax, void* planes, size_t 
 }
 
 size_t ladder_filter_pack_split_bytes(int ntaps, int Cin, int Cout, int prec) {
+  if (prec == LADDER_PREC_F32) return (ntaps > 0 && Cin > 0 && Cout > 0 && (Cin % 16) == 0) ? filter_pack_f32_bytes(ntaps, Cin, Cout) : 0;
   if (ntaps <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 16) != 0 || !prec_ok(prec)) return 0;
   return pack_payload_bytes(ntaps, Cin, Cout, prec) + LADDER_ABSMAX_FLOATS * sizeof(float);
 }
 
 int ladder_filter_pack_split(const float* w, void* packed, int ntaps, int Cin, int Cout, int transpose_flip, int prec,
                              ladder_stream_t stream) {
+  if (prec == LADDER_PREC_F32) {                                 // strict fp32: the fp32 bank [ntaps][Cin][Cout] of the orientation (convf32.hip)
+    if (ntaps <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 16) != 0 || transpose_flip < 0 || transpose_flip > 4) return LADDER_E_SHAPE;
+    if (!ladder_aligned16(packed) || !ladder_aligned16(w)) return LADDER_E_ALIGN;
+    return filter_pack_f32(w, (float*)packed, ntaps, Cin, Cout, transpose_flip, stream);
+  }
   if (ntaps <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 16) != 0 || !prec_ok(prec)) return LADDER_E_SHAPE;
   if (!ladder_aligned16(packed) || !ladder_aligned16(w)) return LADDER_E_ALIGN;
   const long total_l = (long)ntaps * (Cin / 16) * ((Cout + SP_BN - 1) / SP_BN) * 2 * SP_BN;
@@ -1316,6 +1279,10 @@ size_t ladder_filter_pack_split_multi_scratch_bytes(int njobs) { return njobs > 
 
 int ladder_filter_pack_split_multi(const ladder_pack_job_t* jobs_dev, int njobs, int total_blocks, int prec, void* scratch, size_t scratch_bytes,
                                    ladder_stream_t stream) {
+  if (prec == LADDER_PREC_F32) {                                 // (no scales: no scratch needed)
+    if (jobs_dev == nullptr || njobs <= 0 || total_blocks <= 0) return LADDER_E_SHAPE;
+    return filter_pack_f32_multi(jobs_dev, njobs, total_blocks, stream);
+  }
   if (jobs_dev == nullptr || njobs <= 0 || total_blocks <= 0 || !prec_ok(prec)) return LADDER_E_SHAPE;
   if (scratch == nullptr || scratch_bytes < ladder_filter_pack_split_multi_scratch_bytes(njobs)) return LADDER_E_WORKSPACE;
   hipLaunchKernelGGL(filter_absmax_multi_kernel, dim3(PK_PARTS, njobs), dim3(256), 0, stream, jobs_dev, (float*)scratch);
@@ -1332,6 +1299,8 @@ int ladder_conv3x3_split_eligible(int N, int H, int W, int Cin, int Cout) { retu
 static int conv3x3_split_launch(const float* x, const float* x_absmax, const void* packed, const float* bias, float* y, float* y_absmax,
                                 const float* pw, const float* pb, float* pout, int pco, int N, int H, int W, int Cin, int Cout, int act,
                                 int prec, ladder_stream_t stream, unsigned long long tap_masks = ~0ull, int s2_out = 0) {
+  if (prec == LADDER_PREC_F32)       // strict fp32 (v_mfma_f32_32x32x2_f32): `packed` = the fp32 bank, no absmax records
+    return conv3x3_f32_launch(x, (const float*)packed, bias, y, pw, pb, pout, pco, N, H, W, Cin, Cout, act, stream, tap_masks, s2_out);
   if (!split_halo_ok(N, H, W, Cin, Cout) || !prec_ok(prec)) return LADDER_E_SHAPE;
   if (pout != nullptr && (pw == nullptr || pco < 1 || pco > 4 || (Cout > SP_BN && s2_out < 2) || !ladder_aligned16(pw))) return LADDER_E_SHAPE;
   if (pout == nullptr && y == nullptr) return LADDER_E_SHAPE;
@@ -1393,18 +1362,7 @@ int ladder_conv3x3_split_proj(const float* x, const float* x_absmax, const void*
 // transpose_flip = 2); a tile issues only its class's taps (tap mask) and its epilogue writes to the interleaved pixels of dx.  The
 // gather kernel ran the classes as four launches with K = 128 ... 512 each -- 345 us on enc.conv1 at batch 128 (1.43 GB moved at
 // 4.1 TB/s: bandwidth-bound on re-reading dy and the filter per tap); here dy is staged once per slab for all taps of a class.
-static unsigned long long s2_tap_masks() {
-  unsigned long long m = 0;
-  for (int cls = 0; cls < 4; ++cls) {
-    const int ph = cls >> 1, pw = cls & 1;
-    unsigned t = 0;
-    for (int a = 0; a < 3; ++a)
-      for (int b = 0; b < 3; ++b)
-        if ((a == 1 || (a == 0 && ph == 0)) && (b == 1 || (b == 0 && pw == 0))) t |= 1u << (a * 3 + b);
-    m |= (unsigned long long)t << (9 * cls);
-  }
-  return m;
-}
+static unsigned long long s2_tap_masks() { return filter_bank_tap_masks(2); }
 
 int ladder_conv3x3_s2_bwd_data_split_eligible(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t,
                                               int pad_l) {
@@ -1429,22 +1387,11 @@ int ladder_conv3x3_s2_bwd_data_split(const float* dy, const float* dy_absmax, co
 // clamped pixel with the sign that reproduces the zero padding of the high-resolution convolution.  That is exact everywhere but in the
 // LAST output row and column (there the clamp of the resize and the padding of the convolution cannot both be expressed by one halo value):
 // those 2H + 2W - 1 pixels per image are recomputed from the last row / column of x by ladder_conv3x3_up2_edges.
-static unsigned long long up2_tap_masks() {
-  unsigned long long m = 0;
-  for (int cls = 0; cls < 4; ++cls) {
-    const int a = cls >> 1, b = cls & 1;
-    unsigned t = 0;
-    for (int dr = 0; dr < 3; ++dr)
-      for (int dc = 0; dc < 3; ++dc)
-        if ((a == 0 || dr >= 1) && (b == 0 || dc >= 1)) t |= 1u << (dr * 3 + dc);
-    m |= (unsigned long long)t << (9 * cls);
-  }
-  return m;
-}
+static unsigned long long up2_tap_masks() { return filter_bank_tap_masks(3); }
 
 int ladder_conv3x3_up2_split_eligible(int N, int H, int W, int Cin, int Cout, int prec) {
   static const bool off = getenv("LADDER_DISABLE_UP2") != nullptr;              // (test-only switch, see include/ladder_hip.h)
-  return (!off && prec_ok(prec) && Cout == SP_BN && split_halo_ok(N, H, W, Cin, 4 * SP_BN)) ? 1 : 0;
+  return (!off && (prec_ok(prec) || prec == LADDER_PREC_F32) && Cout == SP_BN && split_halo_ok(N, H, W, Cin, 4 * SP_BN)) ? 1 : 0;
 }
 
 int ladder_conv3x3_up2_split(const float* x, const float* x_absmax, const void* packed_up2, const float* bias, float* y, float* y_absmax,
@@ -1458,7 +1405,7 @@ int ladder_conv3x3_up2_split(const float* x, const float* x_absmax, const void* 
 int ladder_conv3x3_up2_split_proj(const float* x, const float* x_absmax, const void* packed_up2, const float* bias, float* y, const float* proj_w,
                                   const float* proj_b, float* proj_out, int proj_cout, int N, int H, int W, int Cin, int Cout, int act, int prec,
                                   int x_upsampled, ladder_stream_t stream) {
-  if (!ladder_conv3x3_up2_split_eligible(N, H, W, Cin, Cout, prec) || proj_out == nullptr || prec_planes(prec) != 2) return LADDER_E_SHAPE;
+  if (!ladder_conv3x3_up2_split_eligible(N, H, W, Cin, Cout, prec) || proj_out == nullptr || (prec != LADDER_PREC_F32 && prec_planes(prec) != 2)) return LADDER_E_SHAPE;
   return conv3x3_split_launch(x, x_absmax, packed_up2, bias, y, nullptr, proj_w, proj_b, proj_out, proj_cout, N, H, W, Cin, 4 * SP_BN, act, prec,
                               stream, up2_tap_masks(), x_upsampled ? 3 : 2);
 }
@@ -1469,21 +1416,11 @@ int ladder_conv3x3_up2_split_proj(const float* x, const float* x_absmax, const v
 // (rows 0 and H-1, columns 0 and W-1: there the resize's clamp and the convolution's zero padding change the coefficients) -- the caller
 // recomputes those from strips of dy with the plain backward-data + resize-transpose kernels.  packed_up2t =
 // ladder_filter_pack_split(w, ., 9, 4 * C, Cout, transpose_flip = 4, prec) from the layer's HWIO bank [3][3][Cout][C].  16-wave kernel only.
-static unsigned long long up2t_tap_masks() {
-  unsigned long long m = 0;
-  for (int cls = 0; cls < 4; ++cls) {
-    const int a = cls >> 1, b = cls & 1;
-    unsigned t = 0;
-    for (int dr = 0; dr < 3; ++dr)
-      for (int dc = 0; dc < 3; ++dc)
-        if ((a == 0 || dr <= 1) && (b == 0 || dc <= 1)) t |= 1u << (dr * 3 + dc);
-    m |= (unsigned long long)t << (9 * cls);
-  }
-  return m;
-}
+static unsigned long long up2t_tap_masks() { return filter_bank_tap_masks(4); }
 
 int ladder_conv3x3_up2_bwd_data_split_eligible(int N, int H, int W, int C, int Cout, int prec) {
   static const bool off = getenv("LADDER_DISABLE_UP2") != nullptr;
+  if (prec == LADDER_PREC_F32) return (!off && (C % 16) == 0 && split_halo_ok(N, H, W, 4 * C, Cout)) ? 1 : 0;      // (8-wave fp32 kernel)
   return (!off && prec_ok(prec) && (C % 16) == 0 && split_halo_ok(N, H, W, 4 * C, Cout) && split_halo16_ok(N, H, W, 4 * C, Cout, prec)) ? 1 : 0;
 }
 

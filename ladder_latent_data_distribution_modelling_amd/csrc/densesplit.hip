@@ -12,6 +12,12 @@
 //   forward        y  = x w        : i = m, j = n, r = k    A = x  (a_is = K, a_rs = 1)   B = w  (b_rs = N, b_js = 1)
 //   backward-data  dx = dy w^T     : i = m, j = k, r = n    A = dy (a_is = N, a_rs = 1)   B = w  (b_rs = 1, b_js = N)  -- no transposed copy
 //   backward-weight dw = x^T dy    : i = k, j = n, r = m    A = x  (a_is = 1, a_rs = K)   B = dy (b_rs = N, b_js = 1), db = column sums of dy
+//
+// Round 4: the same kernels in STRICT fp32 (template parameter F32; entry points ladder_dense_*_small_f32, used when matmul_precision is
+// "f32").  The 8 reduction elements a lane holds per step feed 8 fp32 MFMAs -- v_mfma_f32_32x32x2_f32 (lane half lh supplies reduction
+// index 8 lh + t in MFMA t) resp. v_mfma_f32_16x16x4_f32 (lane quarter lq supplies 8 lq + t): the reduction order inside a step is a
+// permutation of the indices, identical for both operands -- bit-exact fp32 FMA chains, no splitting.  One launch per call instead of the
+// gather kernel + split-K second pass of the round-1 path (18 + 6 us -> ~6 us), no transposed copy of the weights for backward-data.
 #include <cstdlib>
 #include "split16.h"
 
@@ -34,7 +40,13 @@ __device__ __forceinline__ void load8(const float* __restrict__ p, long rs, int 
   }
 }
 
+template <bool F32>
 __device__ __forceinline__ void mma_step(const float (&av)[8], const float (&bv)[8], f32x16& acc) {
+  if (F32) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+    return;
+  }
   uint2 alo[3], ahi[3], blo[3], bhi[3];
   split4<3, false>(make_float4(av[0], av[1], av[2], av[3]), alo);
   split4<3, false>(make_float4(av[4], av[5], av[6], av[7]), ahi);
@@ -66,7 +78,7 @@ struct GemmProb {
   GemmSmall g;
 };
 
-template <int NW, bool PAIR>
+template <int NW, bool PAIR, bool F32>
 __global__ __launch_bounds__(NW * 64) void gemm_small_split_kernel(const GemmProb p0, const GemmProb p1) {
   const GemmProb& pr = blockIdx.z ? p1 : p0;
   const GemmSmall& g = pr.g;
@@ -102,8 +114,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_split_kernel(const GemmPro
 #pragma unroll
       for (int e = 0; e < 8; ++e) csum += b0[e] + b1[e];
     }
-    mma_step(a0, b0, acc);
-    if (two) mma_step(a1, b1, acc);
+    mma_step<F32>(a0, b0, acc);
+    if (two) mma_step<F32>(a1, b1, acc);
   }
   // partial tiles of the NW wavefronts -> LDS (row-major 32 x 33), fixed-order sum, epilogue with 128-byte row segments
 #pragma unroll
@@ -146,7 +158,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_split_kernel(const GemmPro
 // latency chain (load -> split -> MFMA -> reduce).  Fragment layout of the 16x16x32 instruction: lane l holds row / column l % 16 and the
 // K-octet l / 16 (4 octets = 32); the accumulator (4 registers) holds column l % 16, rows 4 (l / 16) + 0..3.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <bool F32>
 __device__ __forceinline__ void mma_step16(const float (&av)[8], const float (&bv)[8], f32x4v& acc) {
+  if (F32) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[t], acc, 0, 0, 0);
+    return;
+  }
   uint2 alo[3], ahi[3], blo[3], bhi[3];
   split4<3, false>(make_float4(av[0], av[1], av[2], av[3]), alo);
   split4<3, false>(make_float4(av[4], av[5], av[6], av[7]), ahi);
@@ -162,7 +180,7 @@ __device__ __forceinline__ void mma_step16(const float (&av)[8], const float (&b
     }
 }
 
-template <int NW>
+template <int NW, bool F32>
 __global__ __launch_bounds__(NW * 64) void gemm_small16_split_kernel(const GemmProb p0, const GemmProb p1) {
   const GemmProb& pr = blockIdx.z ? p1 : p0;
   const GemmSmall& g = pr.g;
@@ -187,7 +205,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_small16_split_kernel(const GemmP
 #pragma unroll
       for (int e = 0; e < 8; ++e) csum += bv[e];
     }
-    mma_step16(av, bv, acc);
+    mma_step16<F32>(av, bv, acc);
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) red[wv][(4 * lq + e) * 17 + l15] = acc[e];
@@ -220,6 +238,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_small16_split_kernel(const GemmP
   }
 }
 
+template <bool F32>
 int launch_gemm_probs(const GemmProb& p0, const GemmProb* p1, hipStream_t st) {
   const GemmSmall& g = p0.g;
   if (g.I <= 0 || g.J <= 0 || g.R <= 0) return LADDER_E_SHAPE;
@@ -242,23 +261,54 @@ int launch_gemm_probs(const GemmProb& p0, const GemmProb* p1, hipStream_t st) {
   static const bool no16 = getenv("LADDER_DISABLE_GEMM16") != nullptr;
   if (!no16 && tiles * grid.z < 256 && tiles16 <= 4096) {   // the chip would be under-filled by 32x32 tiles: 16x16 tiles, K split over <= 8 wavefronts
     grid.x = (unsigned)tiles16;
-    if (steps32 >= 8) hipLaunchKernelGGL((gemm_small16_split_kernel<8>), grid, dim3(512), 0, st, p0, q);
-    else if (steps32 >= 4) hipLaunchKernelGGL((gemm_small16_split_kernel<4>), grid, dim3(256), 0, st, p0, q);
-    else hipLaunchKernelGGL((gemm_small16_split_kernel<2>), grid, dim3(128), 0, st, p0, q);
+    if (steps32 >= 8) hipLaunchKernelGGL((gemm_small16_split_kernel<8, F32>), grid, dim3(512), 0, st, p0, q);
+    else if (steps32 >= 4) hipLaunchKernelGGL((gemm_small16_split_kernel<4, F32>), grid, dim3(256), 0, st, p0, q);
+    else hipLaunchKernelGGL((gemm_small16_split_kernel<2, F32>), grid, dim3(128), 0, st, p0, q);
     LADDER_CHECK_LAUNCH();
     return LADDER_OK;
   }
   grid.x = (unsigned)tiles;
-  if (wide) hipLaunchKernelGGL((gemm_small_split_kernel<16, false>), grid, dim3(1024), 0, st, p0, q);
-  else hipLaunchKernelGGL((gemm_small_split_kernel<4, true>), grid, dim3(256), 0, st, p0, q);
+  if (wide) hipLaunchKernelGGL((gemm_small_split_kernel<16, false, F32>), grid, dim3(1024), 0, st, p0, q);
+  else hipLaunchKernelGGL((gemm_small_split_kernel<4, true, F32>), grid, dim3(256), 0, st, p0, q);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
 
+template <bool F32>
 int launch_gemm_small(const float* a, const float* b, const float* bias, float* c, const float* gate, float* colsum, const GemmSmall& g,
                       hipStream_t st) {
   const GemmProb p{a, b, bias, c, gate, colsum, g};
-  return launch_gemm_probs(p, nullptr, st);
+  return launch_gemm_probs<F32>(p, nullptr, st);
+}
+
+template <bool F32>
+int dense_fwd_small(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act, hipStream_t stream) {
+  if (!ladder_dense_small_eligible(M, K, N)) return LADDER_E_SHAPE;
+  const GemmSmall g{M, N, K, K, 1, N, 1, act, 0};
+  return launch_gemm_small<F32>(x, w, bias, y, nullptr, nullptr, g, stream);
+}
+
+template <bool F32>
+int dense_bwd_data_small(const float* dy, const float* w, float* dx, int M, int K, int N, const float* gate_y, int gate_act, hipStream_t stream) {
+  if (!ladder_dense_small_eligible(M, K, N)) return LADDER_E_SHAPE;
+  const GemmSmall g{M, K, N, N, 1, 1, N, LADDER_ACT_NONE, gate_act};
+  return launch_gemm_small<F32>(dy, w, nullptr, dx, gate_y, nullptr, g, stream);
+}
+
+template <bool F32>
+int dense_bwd_weight_small(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, hipStream_t stream) {
+  if (!ladder_dense_small_eligible(M, K, N)) return LADDER_E_SHAPE;
+  const GemmSmall g{K, N, M, 1, K, N, 1, LADDER_ACT_NONE, 0};
+  return launch_gemm_small<F32>(x, dy, nullptr, dw, nullptr, db, g, stream);
+}
+
+template <bool F32>
+int dense_bwd_small(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int M, int K, int N, const float* gate_y,
+                    int gate_act, hipStream_t stream) {
+  if (!ladder_dense_small_eligible(M, K, N) || dx == nullptr || dw == nullptr) return LADDER_E_SHAPE;
+  const GemmProb pd{dy, w, nullptr, dx, gate_y, nullptr, GemmSmall{M, K, N, N, 1, 1, N, LADDER_ACT_NONE, gate_act}};
+  const GemmProb pw{x, dy, nullptr, dw, nullptr, db, GemmSmall{K, N, M, 1, K, N, 1, LADDER_ACT_NONE, 0}};
+  return launch_gemm_probs<F32>(pd, &pw, stream);
 }
 
 }  // namespace
@@ -275,31 +325,42 @@ int ladder_dense_small_eligible(int M, int K, int N) {
 
 int ladder_dense_fwd_small(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act,
                            ladder_stream_t stream) {
-  if (!ladder_dense_small_eligible(M, K, N)) return LADDER_E_SHAPE;
-  const GemmSmall g{M, N, K, K, 1, N, 1, act, 0};
-  return launch_gemm_small(x, w, bias, y, nullptr, nullptr, g, stream);
+  return dense_fwd_small<false>(x, w, bias, y, M, K, N, act, stream);
 }
 
 int ladder_dense_bwd_data_small(const float* dy, const float* w, float* dx, int M, int K, int N, const float* gate_y, int gate_act,
                                 ladder_stream_t stream) {
-  if (!ladder_dense_small_eligible(M, K, N)) return LADDER_E_SHAPE;
-  const GemmSmall g{M, K, N, N, 1, 1, N, LADDER_ACT_NONE, gate_act};
-  return launch_gemm_small(dy, w, nullptr, dx, gate_y, nullptr, g, stream);
+  return dense_bwd_data_small<false>(dy, w, dx, M, K, N, gate_y, gate_act, stream);
 }
 
 int ladder_dense_bwd_weight_small(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, ladder_stream_t stream) {
-  if (!ladder_dense_small_eligible(M, K, N)) return LADDER_E_SHAPE;
-  const GemmSmall g{K, N, M, 1, K, N, 1, LADDER_ACT_NONE, 0};
-  return launch_gemm_small(x, dy, nullptr, dw, nullptr, db, g, stream);
+  return dense_bwd_weight_small<false>(x, dy, dw, db, M, K, N, stream);
 }
 
 // Both gradient GEMMs of a dense layer in ONE launch (dx = dy w^T with the optional activation gate, dw = x^T dy, db = column sums of dy).
 int ladder_dense_bwd_small(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int M, int K, int N,
                            const float* gate_y, int gate_act, ladder_stream_t stream) {
-  if (!ladder_dense_small_eligible(M, K, N) || dx == nullptr || dw == nullptr) return LADDER_E_SHAPE;
-  const GemmProb pd{dy, w, nullptr, dx, gate_y, nullptr, GemmSmall{M, K, N, N, 1, 1, N, LADDER_ACT_NONE, gate_act}};
-  const GemmProb pw{x, dy, nullptr, dw, nullptr, db, GemmSmall{K, N, M, 1, K, N, 1, LADDER_ACT_NONE, 0}};
-  return launch_gemm_probs(pd, &pw, stream);
+  return dense_bwd_small<false>(x, dy, w, dx, dw, db, M, K, N, gate_y, gate_act, stream);
+}
+
+// ---- the same four calls in strict fp32 (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32: bit-exact fp32 FMA chains) ---------------------
+int ladder_dense_fwd_small_f32(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act,
+                               ladder_stream_t stream) {
+  return dense_fwd_small<true>(x, w, bias, y, M, K, N, act, stream);
+}
+
+int ladder_dense_bwd_data_small_f32(const float* dy, const float* w, float* dx, int M, int K, int N, const float* gate_y, int gate_act,
+                                    ladder_stream_t stream) {
+  return dense_bwd_data_small<true>(dy, w, dx, M, K, N, gate_y, gate_act, stream);
+}
+
+int ladder_dense_bwd_weight_small_f32(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, ladder_stream_t stream) {
+  return dense_bwd_weight_small<true>(x, dy, dw, db, M, K, N, stream);
+}
+
+int ladder_dense_bwd_small_f32(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int M, int K, int N,
+                               const float* gate_y, int gate_act, ladder_stream_t stream) {
+  return dense_bwd_small<true>(x, dy, w, dx, dw, db, M, K, N, gate_y, gate_act, stream);
 }
 
 }  // extern "C"

@@ -27,6 +27,8 @@ class KernelProfiler:
     roofline leg).  Events are recorded on the stream the kernels are launched on (torch's current stream)."""
 
     NAMES = {256128: "conv3x3_halo_kernel (8x32 px x 128 ch LDS-halo tile, 8 waves, fp32 MFMA 32x32x2)",
+             256120: "conv3x3_halo_f32_kernel<PROJ, UPM> (8x32 px x 128 ch LDS-halo tile, 8 waves, fp32 MFMA 32x32x2; instantiations: plain, "
+                     "fused 1x1 projection, upsample-fused forward with / without projection, upsample-fused backward-data, stride-2 backward-data)",
              256123: "conv3x3_halo_split_kernel<bf16x6> (8x32 px x 128 ch LDS-halo tile, 8 waves, fp32 operands as 3 bf16 planes, 6 x MFMA 32x32x16 bf16)",
              256122: "conv3x3_halo_split16_kernel / conv3x3_halo_split_kernel<bf16x3> (16x32 px x 128 ch LDS-halo tile, 16 waves -- 8x32, 8 waves below 512 tiles; fp32 operands as 2 bf16 planes, 3 x MFMA 32x32x16 bf16)",
              256124: "conv3x3_halo_split16_kernel / conv3x3_halo_split_kernel<f16x3> (16x32 px x 128 ch LDS-halo tile, 16 waves -- 8x32, 8 waves below 512 tiles; fp32 operands as 2 scaled fp16 planes, 3 x MFMA 32x32x16 f16)",
@@ -70,7 +72,7 @@ class KernelProfiler:
 #   "bf16x6"  3 bf16 planes (24 bits), 6 plane products, no scaling: fp32-class error
 #   "bf16x3"  2 bf16 planes (16 bits), 3 products (error ~1e-5 relative per product: between TF32 and fp32)
 PRECISIONS = {"f32": 0, "bf16x3": 2, "bf16x6": 3, "f16x3": 4}
-DEFAULT_PRECISION = "f16x3"
+DEFAULT_PRECISION = "f32"       # the reference computes in fp32 end to end (codes/models.py:348,388): split formats are an explicit opt-in
 
 PRECISION_NOTES = {
     "f32": "native fp32 MFMA (v_mfma_f32_32x32x2_f32), bit-exact fp32 FMA chains",
@@ -208,6 +210,11 @@ class Ctx:
         self.ns = 0          # LADDER_PREC_* of the split-precision contraction kernels (0 = native f32 MFMA); set by the engine
         self.up2_used = {}   # layer name -> number of upsample-fused launches so far (bench.py's executed-FLOP model)
         self.up2 = True      # resize -> 3x3 conv pairs of the decoder as ONE upsample-fused convolution in forward-only runs (config `upsample_fused_convs`)
+
+    @property
+    def sfx(self):
+        """Suffix of the batch-sized dense entry points for the configured precision ("_f32": strict fp32 MFMA; "": bf16x6)."""
+        return "" if self.ns else "_f32"
 
     @property
     def stream(self):
@@ -434,13 +441,18 @@ class Conv2D:
         self.group = arch.group_of(name + "/kernel")           # optimiser group whose version stamps the packed images
         self.want_bn_sums, self.bn_sums = False, None          # batch-norm statistics of the output from the conv epilogue (RGB conv)
 
-    def _split_ok(self, N, H, W, cin, cout):
-        """The layer runs on the split-bf16 halo kernel (csrc/convsplit.hip) in the configured precision mode."""
-        return bool(self.ctx.ns and self.k == 3 and self.stride == 1 and self.padding == "same"
+    def _halo_ok(self, N, H, W, cin, cout):
+        """The layer runs on the fused 3x3 halo kernels of the configured precision (strict fp32: csrc/convf32.hip; split formats:
+        csrc/convsplit.hip) -- same tiling, same eligibility."""
+        return bool(self.k == 3 and self.stride == 1 and self.padding == "same"
                     and L.query("ladder_conv3x3_split_eligible", N, H, W, cin, cout))
 
+    def _split_ok(self, N, H, W, cin, cout):
+        """... and the precision is one of the 16-bit split formats (their filter gradient / planes / absmax machinery)."""
+        return bool(self.ctx.ns and self._halo_ok(N, H, W, cin, cout))
+
     def _as_dense(self, M):
-        return bool(self.ctx.ns and self.k == 1 and self.stride == 1 and M <= 512 and self.cin >= 16
+        return bool(self.k == 1 and self.stride == 1 and M <= 512 and self.cin >= 16
                     and L.query("ladder_dense_small_eligible", M, self.cin, self.cout))
 
     @staticmethod
@@ -472,6 +484,8 @@ class Conv2D:
         """Split bf16 planes of the filter bank in the kernel's LDS layout, re-packed when the weights changed (always while a
         hipGraph is being captured, so that a replay re-packs the then-current weights)."""
         ns, ps = self.ctx.ns, self.ps
+        if ns == 0 and transpose_flip == 0:           # strict fp32: the HWIO bank IS the forward bank [tap][Cin][Cout]
+            return ps.w[self.name + "/kernel"]
         cin, cout = (self.cout, self.cin) if transpose_flip in (1, 2) else (self.cin, self.cout)
         if transpose_flip == 2:                       # the four parity classes of a stride-2 backward-data as output-channel blocks
             cout = 4 * self.cin
@@ -497,7 +511,7 @@ class Conv2D:
         halo kernel (ladder_conv3x3_split_proj); returns proj's output or None when the pair is not eligible.  `keep_y` = the
         activation is needed later (training forward: both layers' backward read it); a forward-only run never writes it."""
         N, H, W, _ = x.shape
-        if not (self._split_ok(N, H, W, self.cin, self.cout) and self.cout <= 128 and proj.k == 1 and proj.stride == 1
+        if not (self._halo_ok(N, H, W, self.cin, self.cout) and self.cout <= 128 and proj.k == 1 and proj.stride == 1
                 and proj.cout <= 4 and proj.act is None and proj.cin == self.cout):
             return None
         self.pt, _ = arch.conv_out(H, self.k, self.stride, self.padding)
@@ -518,7 +532,7 @@ class Conv2D:
         """This layer can take the LOW-resolution tensor [N, H, W, cin] that a factor-2 legacy-bilinear resize would have blown up for it
         (ladder_conv3x3_up2_split: four output-parity classes with effective taps, 25 instead of 36 low-resolution tap products and no
         upsampled tensor).  Forward-only runs use it; a training forward keeps the resized tensor for its backward pass."""
-        return bool(self.ctx.up2 and self.ctx.ns in (2, 4) and self.k == 3 and self.stride == 1 and self.padding == "same"
+        return bool(self.ctx.up2 and self.ctx.ns in (0, 2, 4) and self.k == 3 and self.stride == 1 and self.padding == "same"
                     and L.query("ladder_conv3x3_up2_split_eligible", N, H, W, self.cin, self.cout, self.ctx.ns))
 
     def forward_up2(self, x, proj=None, keep_y=False, x_for_backward=None):
@@ -570,7 +584,7 @@ class Conv2D:
         self.pl, Wo = arch.conv_out(W, self.k, self.stride, self.padding)
         y = self.ctx.empty(N, Ho, Wo, self.cout)
         self.x_amax = None
-        if self._split_ok(N, H, W, self.cin, self.cout):
+        if self._halo_ok(N, H, W, self.cin, self.cout):
             self.x_amax = self.ctx.absmax(x)
             y_amax = self.ctx.new_amax() if self.ctx.ns == 4 else None
             args = (_p(x), _p(self.x_amax), _p(self._packed_filter(0)), _p(self.ps.w[self.name + "/bias"]), _p(y), _p(y_amax), N, H, W,
@@ -580,7 +594,7 @@ class Conv2D:
             self.x, self.y = x, y
             return y
         if self._as_dense(N * H * W):                   # 1x1 conv over a tiny map (decoder conv0 on the 1x1 map) = a batch-sized dense layer
-            L.call("ladder_dense_fwd_small", _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y), N * H * W,
+            L.call("ladder_dense_fwd_small" + self.ctx.sfx, _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y), N * H * W,
                    self.cin, self.cout, L.ACT[self.act], self.ctx.stream)
             self.x, self.y = x, y
             return y
@@ -627,11 +641,11 @@ class Conv2D:
     def up2t_ok(self, N, H, W):
         """The gradient with respect to the LOW-resolution tensor [N, H, W, cin] behind a factor-2 resize in front of this layer can come from
         ONE launch (ladder_conv3x3_up2_bwd_data_split) + border strips, instead of backward-data on the upsampled map + the resize transpose."""
-        return bool(self.ctx.up2 >= 2 and self.ctx.ns in (2, 4) and self.k == 3 and self.stride == 1 and self.padding == "same"
+        return bool(self.ctx.up2 >= 2 and self.ctx.ns in (0, 2, 4) and self.k == 3 and self.stride == 1 and self.padding == "same"
                     and L.query("ladder_conv3x3_up2_bwd_data_split_eligible", N, H, W, self.cout, self.cin, self.ctx.ns)
-                    and all(L.query("ladder_conv2d_bwd_data_split_eligible", *g, 0) for g in (
+                    and (self.ctx.ns == 0 or all(L.query("ladder_conv2d_bwd_data_split_eligible", *g, 0) for g in (
                         (N, 2, 2 * W, self.cin, 3, 2 * W, self.cout, 3, 3, 1, 1, 1), (N, 3, 2 * W, self.cin, 4, 2 * W, self.cout, 3, 3, 1, 2, 1),
-                        (N, 2 * H, 2, self.cin, 2 * H, 3, self.cout, 3, 3, 1, 1, 1), (N, 2 * H, 3, self.cin, 2 * H, 4, self.cout, 3, 3, 1, 1, 2))))
+                        (N, 2 * H, 2, self.cin, 2 * H, 3, self.cout, 3, 3, 1, 1, 1), (N, 2 * H, 3, self.cin, 2 * H, 4, self.cout, 3, 3, 1, 1, 2)))))
 
     def _dx_lowres(self, dy, dy_amax):
         """d loss / d x_lo for y = conv(resize2x(x_lo)): the composite transpose is a zero-padded 5x5 / stride-2 correlation over dy (one launch of
@@ -662,10 +676,14 @@ class Conv2D:
             else:
                 geo = (N, OH, n_up, self.cin, OH, n_dy, self.cout, 3, 3, 1, 1, pad)
                 dup = ctx.empty(N, OH, n_up, self.cin)
-            ctx.set_amax(s, dy_amax)                                       # (a strip of dy: the per-sample record of dy bounds it, no extra pass)
-            s_amax = ctx.absmax(s)
-            wsp, wsn = ctx.ws(L.query("ladder_conv2d_bwd_data_split_workspace_bytes", *geo))
-            L.call("ladder_conv2d_bwd_data_split", _p(ctx.planes(s, self._ps(geo[1], geo[2]))), _p(s_amax), _p(pk), _p(dup), *geo, None, 0, ctx.ns, wsp, wsn, st)
+            if ctx.ns == 0:                                                # strict fp32: the gather kernel on the flipped / transposed bank
+                _igemm(ctx, "ladder_conv2d_bwd_data", N * geo[1] * geo[2], self.cout, self.cin, 9 * self.cout, _p(s), _p(pk), _p(dup), *geo, None, 0,
+                       conv="skip")
+            else:
+                ctx.set_amax(s, dy_amax)                                   # (a strip of dy: the per-sample record of dy bounds it, no extra pass)
+                s_amax = ctx.absmax(s)
+                wsp, wsn = ctx.ws(L.query("ladder_conv2d_bwd_data_split_workspace_bytes", *geo))
+                L.call("ladder_conv2d_bwd_data_split", _p(ctx.planes(s, self._ps(geo[1], geo[2]))), _p(s_amax), _p(pk), _p(dup), *geo, None, 0, ctx.ns, wsp, wsn, st)
             L.call("ladder_conv3x3_up2_bwd_border", _p(dup), _p(dx), _p(dx_amax), N, H, W, self.cin, axis, 1 if first else 0, st)
         ctx.set_amax(dx, dx_amax)
         return dx
@@ -697,12 +715,12 @@ class Conv2D:
         if self._as_dense(N * H * W):
             M = N * H * W
             if wgrad:
-                L.call("ladder_dense_bwd_weight_small", _p(x), _p(dy), _p(self.ps.g[self.name + "/kernel"]),
+                L.call("ladder_dense_bwd_weight_small" + self.ctx.sfx, _p(x), _p(dy), _p(self.ps.g[self.name + "/kernel"]),
                        _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, M, self.cin, self.cout, st)
             dx = None
             if need_dx:
                 dx = self.ctx.empty(N, H, W, self.cin)
-                L.call("ladder_dense_bwd_data_small", _p(dy), _p(self.ps.w[self.name + "/kernel"]), _p(dx), M, self.cin, self.cout,
+                L.call("ladder_dense_bwd_data_small" + self.ctx.sfx, _p(dy), _p(self.ps.w[self.name + "/kernel"]), _p(dx), M, self.cin, self.cout,
                        _p(x) if gate_prev else None, L.ACT[gate_prev] if gate_prev else 0, st)
             self.x = self.y = None
             return dx
@@ -718,7 +736,7 @@ class Conv2D:
                        and L.query("ladder_conv3x3_wgrad_split_eligible", N, H, W, self.cin, self.cout, self.ctx.ns))
         if split_w and self.ctx.ns == 4 and getattr(self, "x_amax", None) is None:
             self.x_amax = self.ctx.absmax(x)
-        split_d = bool(need_dx and not gate_prev and self._split_ok(N, Ho, Wo, self.cout, self.cin))
+        split_d = bool(need_dx and not gate_prev and self._halo_ok(N, Ho, Wo, self.cout, self.cin))
         if split_w or split_d:
             dy_amax = self.ctx.absmax(dy)               # one pass serves the filter gradient and the backward-data call
         if split_w:
@@ -770,14 +788,14 @@ class Conv2D:
                     self.ctx.ns, st)
             self.ctx.set_amax(dx, dx_amax)
             _timed(256120 + self.ctx.ns, 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_split", args)
-        elif (need_dx and self.ctx.ns == 4 and not gate_prev and self.stride == 2
+        elif (need_dx and self.ctx.ns in (0, 4) and not gate_prev and self.stride == 2
               and L.query("ladder_conv3x3_s2_bwd_data_split_eligible", N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride,
                           self.pt, self.pl)):
             # 3x3 / stride 2 over a map whose gradient is halo-kernel sized (enc.conv1): the four output-parity classes in ONE launch
             if dy_amax is None:
                 dy_amax = self.ctx.absmax(dy)
             dx = self.ctx.empty(N, H, W, self.cin)
-            dx_amax = self.ctx.new_amax()
+            dx_amax = self.ctx.new_amax() if self.ctx.ns == 4 else None
             args = (_p(dy), _p(dy_amax), _p(self._packed_filter(2)), _p(dx), _p(dx_amax), N, H, W, self.cin, Ho, Wo, self.cout, self.ctx.ns, st)
             self.ctx.set_amax(dx, dx_amax)
             _timed(256120 + self.ctx.ns, 2.0 * N * Ho * Wo * 9 * self.cin * self.cout, "ladder_conv3x3_s2_bwd_data_split", args)
@@ -791,9 +809,12 @@ class Conv2D:
             L.call("ladder_conv2d_bwd_data_split", _p(self.ctx.planes(dy, self._ps(Ho, Wo))), _p(dy_amax), _p(self._packed_filter(1)), _p(dx), *geo,
                    _p(x) if gate_prev else None, L.ACT[gate_prev] if gate_prev else 0, self.ctx.ns, wsp, wsn, st)
         elif need_dx:
-            w = self.ps.w[self.name + "/kernel"]
-            wT = self.ctx.empty(w.numel())
-            L.call("ladder_filter_flip_transpose", _p(w), _p(wT), self.k, self.k, self.cin, self.cout, st)
+            if self.ctx.ns == 0 and self.cout % 16 == 0 and self.k == 3:
+                wT = self._packed_filter(1)               # flipped / transposed fp32 bank, re-packed with all others in one launch per step
+            else:
+                w = self.ps.w[self.name + "/kernel"]
+                wT = self.ctx.empty(w.numel())
+                L.call("ladder_filter_flip_transpose", _p(w), _p(wT), self.k, self.k, self.cin, self.cout, st)
             dx = self.ctx.empty(N, H, W, self.cin)
             _igemm(self.ctx, "ladder_conv2d_bwd_data", N * H * W, self.cout, self.cin, self.k * self.k * self.cout,
                    _p(dy), _p(wT), _p(dx), N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k,
@@ -812,14 +833,14 @@ class Dense:
         self.ctx, self.ps, self.name, self.cin, self.cout, self.act = ctx, ps, name, cin, cout, act
 
     def _small(self, M):
-        """Batch-sized layer in a split-precision mode: the one-launch bf16x6 kernels of csrc/densesplit.hip."""
-        return bool(self.ctx.ns and L.query("ladder_dense_small_eligible", M, self.cin, self.cout))
+        """Batch-sized layer: the one-launch kernels of csrc/densesplit.hip (strict fp32 MFMA when matmul_precision is "f32", else bf16x6)."""
+        return bool(L.query("ladder_dense_small_eligible", M, self.cin, self.cout))
 
     def forward(self, x):
         M = x.shape[0]
         y = self.ctx.empty(M, self.cout)
         if self._small(M):
-            L.call("ladder_dense_fwd_small", _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y),
+            L.call("ladder_dense_fwd_small" + self.ctx.sfx, _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y),
                    M, self.cin, self.cout, L.ACT[self.act], self.ctx.stream)
             self.x, self.y = x, y
             return y
@@ -837,18 +858,18 @@ class Dense:
         if self._small(M):
             if wgrad and need_dx:                               # both gradient GEMMs in one launch
                 dx = self.ctx.empty(M, self.cin)
-                L.call("ladder_dense_bwd_small", _p(x), _p(dy), _p(self.ps.w[self.name + "/kernel"]), _p(dx),
+                L.call("ladder_dense_bwd_small" + self.ctx.sfx, _p(x), _p(dy), _p(self.ps.w[self.name + "/kernel"]), _p(dx),
                        _p(self.ps.g[self.name + "/kernel"]), _p(self.ps.g[self.name + "/bias"]), M, self.cin, self.cout,
                        _p(x) if gate_prev else None, L.ACT[gate_prev] if gate_prev else 0, st)
                 self.x = self.y = None
                 return dx
             if wgrad:
-                L.call("ladder_dense_bwd_weight_small", _p(x), _p(dy), _p(self.ps.g[self.name + "/kernel"]),
+                L.call("ladder_dense_bwd_weight_small" + self.ctx.sfx, _p(x), _p(dy), _p(self.ps.g[self.name + "/kernel"]),
                        _p(self.ps.g[self.name + "/bias"]), M, self.cin, self.cout, st)
             dx = None
             if need_dx:
                 dx = self.ctx.empty(M, self.cin)
-                L.call("ladder_dense_bwd_data_small", _p(dy), _p(self.ps.w[self.name + "/kernel"]), _p(dx), M, self.cin, self.cout,
+                L.call("ladder_dense_bwd_data_small" + self.ctx.sfx, _p(dy), _p(self.ps.w[self.name + "/kernel"]), _p(dx), M, self.cin, self.cout,
                        _p(x) if gate_prev else None, L.ACT[gate_prev] if gate_prev else 0, st)
             self.x = self.y = None
             return dx
@@ -1320,6 +1341,10 @@ class _AsyncFetch:
     def __init__(self, host, event, names, pool):
         self._host, self._event, self._names, self._pool, self._val = host, event, names, pool, None
 
+    def ready(self):
+        """True when get() would not block."""
+        return self._val is not None or self._event.query()
+
     def get(self):
         if self._val is None:
             self._event.synchronize()
@@ -1395,6 +1420,7 @@ class LadderEngine:
         self._main_calls, self._aux_calls = 0, 0                    # noise calls of the last main forward / of the aux runs since
         self._on_aux = False
         self._fetch_src = None                                      # (scalars buffer, stream) of the last run
+        self._sigma_one = torch.ones(1, dtype=torch.float32, device=self.ctx.device)   # stand-in for sigma/Variable in decoder-less runs
 
     def enable_prior_overlap(self, on=True):
         """RUN#3 and RUN#4 (inner VAE forward / backward, mixture term, Adam on prior/* and inner_sigma: ~150 launches of a few
@@ -1482,6 +1508,9 @@ class LadderEngine:
         ctx, st = self.ctx, self.ctx.stream
         if not self._on_aux:
             self._join_aux()                       # (prior variables / noise position: the aux runs of the last iteration come first)
+            # whoever calls forward() on the main stream -- a run, evaluate(), sample_*, the Session facade -- fetches THIS forward's scalars
+            # (evaluate() after an overlapped RUN#3 / RUN#4 used to read the aux run's stale buffer)
+            self._fetch_src = (self.scalars, torch.cuda.current_stream(ctx.device))
         ctx.keep_activations = bool(keep_acts)     # forward-only runs (RUN#2, val_step): fused kernels skip backward-only tensors
         Z, R = self.Z, self.R
         P = self.partials
@@ -1548,7 +1577,13 @@ class LadderEngine:
                                1 if (self.has_inner and int(self.cfg["TRAIN_inner_sigma"]) == 1) else 0,
                                float(self.cfg.get("inner_sigma_lb", 0.0)), float(self.cfg.get("inner_sigma_ub", 0.0)),
                                1 if self.hier else 0, 1 if (self.gmm_z or vamp_on) else 0)
-        L.call("ladder_elbo_finalize", _p(P), _p(self.ps.w["sigma/Variable"]),
+        # A run without the decoder (RUN#3 / RUN#4, the t-sample passes of the mixture fit) has no pixel term: its sigma-dependent scalars
+        # (sigma, reconstruction likelihood, elbo, loss_ae) are not part of what the reference fetches from it (base.py:615-639).  They are
+        # evaluated against a CONSTANT 1 instead of sigma/Variable, which RUN#2's optimiser step may be writing on the main stream while
+        # these runs execute on the aux stream (cross-stream race; the values were timing-dependent).  inner_sigma/Variable is
+        # only read by runs that evaluate the inner VAE, all of which are ordered with its writer (RUN#4, same stream / joined).
+        sig = self.ps.w["sigma/Variable"] if "dec" in parts else self._sigma_one
+        L.call("ladder_elbo_finalize", _p(P), _p(sig),
                _p(self.ps.w["inner_sigma/Variable"]) if self.has_inner else None, ecfg, _p(self.scalars), st)
         if not early_aux:
             self._mark_for_aux()
@@ -1738,7 +1773,7 @@ class LadderEngine:
         mode only: a hipGraph capture keeps the lazy per-bank path (it re-packs inside the graph)."""
         ctx = self.ctx
         banks = ctx.pack_banks
-        if not banks or not ctx.ns or self.use_graphs or torch.cuda.is_current_stream_capturing():
+        if not banks or self.use_graphs or torch.cuda.is_current_stream_capturing():
             return
         tab = ctx._pack_table
         if tab is None or tab[0] != len(banks):

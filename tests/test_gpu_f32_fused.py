@@ -1,0 +1,356 @@
+"""Strict-fp32 forms of the fused 3x3 halo convolutions (csrc/convf32.hip; reached through the ladder_conv3x3_*_split* / ladder_filter_pack_split*
+entry points with prec = LADDER_PREC_F32) against the float64 oracle, through the C ABI:
+
+  * fp32 banks of every orientation (forward, flipped / transposed, stride-2 parity classes, upsample-fused forward / backward) against numpy;
+  * the plain convolution: against the oracle AND bit-identical to the round-1 kernel (conv3x3_halo_kernel via ladder_conv2d_fwd -- same
+    tiling, same accumulation order);
+  * resize x2 -> 3x3 conv as one convolution over the low-resolution map (reference codes/models.py:554-578), with and without the fused 1x1
+    RGB projection (models.py:573-586), from the low-resolution tensor and from the even sub-grid of a kept upsample;
+  * its backward-data as a 5x5 / stride-2 correlation over dy;
+  * backward-data of a 3x3 / stride-2 conv (models.py:409-418) as one launch;
+  * the engine in `matmul_precision: f32` must route through them and agree with the direct path.
+
+Tolerance (stated): fp32 accumulation of K = 9 Cin <= 2304 products -- 3e-6 of the output scale (measured ~3e-7), 2e-5 on edge lines."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ladder_oracle as O
+from test_gpu_split import _lib, close, dev, p
+
+pytestmark = pytest.mark.gpu
+F32 = 0
+TOL32 = 3e-6
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+A = np.zeros((2, 3, 3))
+A[0] = [[0.5, 0, 0], [0.5, 1, 0.5], [0, 0, 0.5]]
+A[1] = [[0, 0, 0], [1, 0.5, 0], [0, 0.5, 1]]
+
+
+def _bank(L, w, cin, cout, flip, st):
+    wd = dev(w)
+    nb = L.query("ladder_filter_pack_split_bytes", 9, cin, cout, F32)
+    assert nb == 9 * cin * cout * 4
+    bank = torch.full((9, cin, cout), float("nan"), device="cuda")
+    L.call("ladder_filter_pack_split", p(wd), p(bank), 9, cin, cout, flip, F32, st)
+    return bank
+
+
+def _logical_bank(w, flip):
+    """numpy restatement of csrc/filterbank.h (float64)."""
+    w = w.astype(np.float64)
+    if flip == 0:
+        return w.reshape(9, w.shape[2], w.shape[3])
+    if flip == 1:                                    # F[tap][co_layer][ci_layer] = w[8 - tap][ci_layer][co_layer]
+        return w.reshape(9, w.shape[2], w.shape[3])[::-1].transpose(0, 2, 1)
+    if flip == 2:                                    # w [3][3][C][Cin_l]: F[tap][Cin_l][4C]
+        C, Cl = w.shape[2], w.shape[3]
+        F = np.zeros((3, 3, Cl, 4, C))
+        for ph in range(2):
+            for pw in range(2):
+                for a in range(3):
+                    for b in range(3):
+                        if (a == 1 or (a == 0 and ph == 0)) and (b == 1 or (b == 0 and pw == 0)):
+                            F[a, b, :, ph * 2 + pw] = w[ph if a == 1 else 2, pw if b == 1 else 2].T
+        return F.reshape(9, Cl, 4 * C)
+    if flip == 3:                                    # w [3][3][Cin][C]: F[tap][Cin][4C]
+        Ci, C = w.shape[2], w.shape[3]
+        F = np.zeros((3, 3, Ci, 4, C))
+        for a in range(2):
+            for b in range(2):
+                F[:, :, :, a * 2 + b] = np.einsum("dr,es,rsio->deio", A[a], A[b], w)
+        return F.reshape(9, Ci, 4 * C)
+    Co, C = w.shape[2], w.shape[3]                   # flip 4: w [3][3][Cout][C]: F[tap][4C][Cout]
+    F = np.zeros((3, 3, 4, C, Co))
+    for a in range(2):
+        for b in range(2):
+            for dr in range(3):
+                for dc in range(3):
+                    F[dr, dc, a * 2 + b] = np.einsum("r,s,rsoc->co", A[a][2 - dr], A[b][2 - dc], w)
+    return F.reshape(9, 4 * C, Co)
+
+
+@pytest.mark.parametrize("flip", [0, 1, 2, 3, 4])
+def test_f32_filter_banks_match_the_table_definitions(gpu_ctx, flip):
+    L = _lib()
+    rng = np.random.default_rng(flip)
+    shape = {0: (3, 3, 32, 192), 1: (3, 3, 48, 160), 2: (3, 3, 128, 32), 3: (3, 3, 48, 128), 4: (3, 3, 64, 16)}[flip]
+    w = rng.standard_normal(shape).astype(np.float32)
+    ref = _logical_bank(w, flip)
+    cin, cout = ref.shape[1], ref.shape[2]
+    bank = _bank(L, w, cin, cout, flip, gpu_ctx.stream)
+    torch.cuda.synchronize()
+    got = bank.cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=3e-7 * np.abs(ref).max())
+    if flip in (0, 1, 2):                            # pure permutations: exact
+        assert np.array_equal(got, ref)
+
+
+def test_f32_bank_multi_pack_equals_single(gpu_ctx):
+    """All banks of a model in ONE launch (ladder_filter_pack_split_multi, prec f32) = the per-bank calls, bit for bit."""
+    L = _lib()
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(5)
+    jobs = [((3, 3, 32, 128), 32, 512, 3), ((3, 3, 64, 48), 48, 64, 1), ((3, 3, 128, 64), 64, 512, 2), ((3, 3, 64, 16), 64, 64, 4)]
+    dt = np.dtype([("w", "<u8"), ("packed", "<u8"), ("ntaps", "<i4"), ("cin", "<i4"), ("cout", "<i4"), ("flip", "<i4"), ("block_begin", "<i4"), ("reserved", "<i4")])
+    rows, blk, keep, singles = np.zeros(len(jobs), dtype=dt), 0, [], []
+    for r, (shape, cin, cout, flip) in zip(rows, jobs):
+        w = rng.standard_normal(shape).astype(np.float32)
+        wd = dev(w)
+        out = torch.full((9, cin, cout), float("nan"), device="cuda")
+        keep += [wd, out]
+        singles.append(_bank(L, w, cin, cout, flip, st))
+        r["w"], r["packed"], r["ntaps"], r["cin"], r["cout"], r["flip"], r["block_begin"] = wd.data_ptr(), out.data_ptr(), 9, cin, cout, flip, blk
+        blk += L.query("ladder_filter_pack_job_blocks", 9, cin, cout)
+    tab = torch.from_numpy(rows.view(np.uint8).copy()).cuda()
+    L.call("ladder_filter_pack_split_multi", p(tab), len(jobs), blk, F32, None, 0, st)
+    torch.cuda.synchronize()
+    for i, s in enumerate(singles):
+        assert torch.equal(keep[2 * i + 1], s), i
+
+
+def _conv64(x, w, b=None, act=None, stride=1):
+    y = O.conv2d_tf(torch.as_tensor(x, dtype=torch.float64), torch.as_tensor(w, dtype=torch.float64),
+                    None if b is None else torch.as_tensor(b, dtype=torch.float64), stride, "same")
+    if act == "leaky_relu":
+        y = torch.where(y > 0, y, 0.2 * y)
+    return y
+
+
+@pytest.mark.parametrize("case", [(16, 64, 64, 32, 256, "leaky_relu"), (256, 16, 32, 48, 128, None), (8, 64, 128, 16, 192, "leaky_relu")],
+                         ids=lambda c: "n%d_%dx%d_c%d_co%d_%s" % c)
+def test_f32_halo_conv_fwd_bwd_vs_oracle_and_round1_kernel(gpu_ctx, case):
+    L = _lib()
+    N, H, W, Cin, Cout, act = case
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(H + Cin + Cout)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32) * 0.1
+    assert L.query("ladder_conv3x3_split_eligible", N, H, W, Cin, Cout) == 1
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    y = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    L.call("ladder_conv3x3_split", p(xd), None, p(wd), p(bd), p(y), None, N, H, W, Cin, Cout, 1 if act else 0, F32, st)
+    close(y, _conv64(x, w, b, act), TOL32, "forward")
+    y1 = torch.empty_like(y)
+    wsp, wsn = gpu_ctx.ws(max(L.query("ladder_igemm_fwd_workspace_bytes", N * H * W, 9 * Cin, Cout), 16))
+    L.call("ladder_conv2d_fwd", p(xd), p(wd), p(bd), p(y1), N, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1 if act else 0, wsp, wsn, st)
+    assert L.query("ladder_conv2d_fwd_kernel_id", N, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1) == 256128
+    assert torch.equal(y, y1), "same tiling, same accumulation order: bit-identical to conv3x3_halo_kernel"
+    # backward-data = the same kernel over dy with the flipped / transposed bank (needs Cout % 16 == 0)
+    dy = rng.standard_normal((N, H, W, Cout)).astype(np.float32)
+    xt = torch.zeros(N, H, W, Cin, dtype=torch.float64, requires_grad=True)
+    O.conv2d_tf(xt, torch.as_tensor(w, dtype=torch.float64), None, 1, "same").backward(torch.as_tensor(dy, dtype=torch.float64))
+    if L.query("ladder_conv3x3_split_eligible", N, H, W, Cout, Cin):
+        bankT = _bank(L, w, Cout, Cin, 1, st)
+        dx = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+        L.call("ladder_conv3x3_split", p(dev(dy)), None, p(bankT), None, p(dx), None, N, H, W, Cout, Cin, 0, F32, st)
+        close(dx, xt.grad, TOL32, "backward-data")
+
+
+@pytest.mark.parametrize("keep_y", [True, False])
+def test_f32_halo_conv_fused_projection(gpu_ctx, keep_y):
+    """3x3 conv (leaky) + the 1x1 RGB conv in one launch (codes/models.py:571-587); y is optional (forward-only runs)."""
+    L = _lib()
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(3)
+    N, H, W, Cin, Cout = 16, 64, 128, 32, 128
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32) * 0.1
+    pw_ = (rng.standard_normal((Cout, 3)) / np.sqrt(Cout)).astype(np.float32)
+    pb_ = rng.standard_normal(3).astype(np.float32) * 0.1
+    y = torch.full((N, H, W, Cout), float("nan"), device="cuda") if keep_y else None
+    out = torch.full((N, H, W, 3), float("nan"), device="cuda")
+    L.call("ladder_conv3x3_split_proj", p(dev(x)), None, p(dev(w)), p(dev(b)), p(y), p(dev(pw_)), p(dev(pb_)), p(out), 3, N, H, W, Cin, Cout, 1, F32, st)
+    ref = _conv64(x, w, b, "leaky_relu").numpy()
+    close(out, ref @ pw_.astype(np.float64) + pb_.astype(np.float64), TOL32, "projection")
+    if keep_y:
+        close(y, ref, TOL32, "map")
+
+
+def _ref_up2(x, w, b, act):
+    N, H, W, _ = x.shape
+    up = O.resize_bilinear_legacy(torch.as_tensor(x, dtype=torch.float64), 2 * H, 2 * W)
+    return _conv64(up.numpy(), w, b, act).numpy()
+
+
+@pytest.mark.parametrize("case", [(64, 16, 32, 32, "leaky_relu"), (16, 64, 64, 32, "leaky_relu"), (128, 8, 32, 48, None)], ids=lambda c: "n%d_%dx%d_c%d_%s" % c)
+def test_f32_up2_conv_vs_oracle(gpu_ctx, case):
+    L = _lib()
+    N, H, W, Cin, act = case
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(H * 100 + Cin)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, 128)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(128).astype(np.float32) * 0.1
+    assert L.query("ladder_conv3x3_up2_split_eligible", N, H, W, Cin, 128, F32) == 1
+    xd, bd, wd = dev(x), dev(b), dev(w)
+    bank = _bank(L, w, Cin, 512, 3, st)
+    y = torch.full((N, 2 * H, 2 * W, 128), float("nan"), device="cuda")
+    L.call("ladder_conv3x3_up2_split", p(xd), None, p(bank), p(bd), p(y), None, N, H, W, Cin, 128, 1 if act else 0, F32, 0, st)
+    torch.cuda.synchronize()
+    ref = _ref_up2(x, w, b, act)
+    close(y[:, :-1, :-1], ref[:, :-1, :-1], TOL32, "up2 interior")
+    ws = torch.empty(L.query("ladder_conv3x3_up2_edges_workspace_bytes", N, H, W, Cin, 128), dtype=torch.uint8, device="cuda")
+    L.call("ladder_conv3x3_up2_edges", p(xd), p(wd), p(bd), p(y), None, None, None, None, 0, N, H, W, Cin, 128, 1 if act else 0, 0, p(ws), ws.numel(), st)
+    close(y, ref, TOL32, "up2 full map")
+
+
+@pytest.mark.parametrize("case", [(64, 16, 32, 32, True, 0), (16, 64, 64, 32, False, 0), (64, 16, 32, 32, True, 1), (16, 64, 64, 32, False, 1)],
+                         ids=lambda c: "n%d_%dx%d_c%d_y%d_ups%d" % c)
+def test_f32_up2_conv_with_fused_projection_vs_oracle(gpu_ctx, case):
+    L = _lib()
+    N, H, W, Cin, keep_y, ups = case
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(H + Cin)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, 128)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(128).astype(np.float32) * 0.1
+    pw_ = (rng.standard_normal((128, 3)) / np.sqrt(128)).astype(np.float32)
+    pb_ = rng.standard_normal(3).astype(np.float32) * 0.1
+    xd, bd, wd, pwd, pbd = dev(x), dev(b), dev(w), dev(pw_), dev(pb_)
+    src = dev(O.resize_bilinear_legacy(torch.as_tensor(x), 2 * H, 2 * W).numpy()) if ups else xd
+    bank = _bank(L, w, Cin, 512, 3, st)
+    y = torch.full((N, 2 * H, 2 * W, 128), float("nan"), device="cuda") if keep_y else None
+    out = torch.full((N, 2 * H, 2 * W, 3), float("nan"), device="cuda")
+    L.call("ladder_conv3x3_up2_split_proj", p(src), None, p(bank), p(bd), p(y), p(pwd), p(pbd), p(out), 3, N, H, W, Cin, 128, 1, F32, ups, st)
+    ws = torch.empty(L.query("ladder_conv3x3_up2_edges_workspace_bytes", N, H, W, Cin, 128), dtype=torch.uint8, device="cuda")
+    L.call("ladder_conv3x3_up2_edges", p(src), p(wd), p(bd), p(y), None, p(pwd), p(pbd), p(out), 3, N, H, W, Cin, 128, 1, ups, p(ws), ws.numel(), st)
+    ref = _ref_up2(x, w, b, "leaky_relu")
+    close(out, ref @ pw_.astype(np.float64) + pb_.astype(np.float64), TOL32, "projection")
+    if keep_y:
+        close(y, ref, TOL32, "map")
+
+
+@pytest.mark.parametrize("case", [(64, 64, 64, 16, 128), (32, 64, 64, 32, 256)], ids=lambda c: "n%d_%dx%d_c%d_co%d" % c)
+def test_f32_up2_backward_data_interior_vs_autograd(gpu_ctx, case):
+    L = _lib()
+    N, H, W, C, Cout = case                            # dy [N, 2H, 2W, C], dx [N, H, W, Cout]
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(C + Cout)
+    w = (rng.standard_normal((3, 3, Cout, C)) / np.sqrt(9 * C)).astype(np.float32)
+    dy = rng.standard_normal((N, 2 * H, 2 * W, C)).astype(np.float32)
+    assert L.query("ladder_conv3x3_up2_bwd_data_split_eligible", N, H, W, C, Cout, F32) == 1
+    bank = _bank(L, w, 4 * C, Cout, 4, st)
+    dx = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    L.call("ladder_conv3x3_up2_bwd_data_split", p(dev(dy)), None, p(bank), p(dx), None, N, H, W, C, Cout, F32, st)
+    torch.cuda.synchronize()
+    xz = torch.zeros(N, H, W, Cout, dtype=torch.float64, requires_grad=True)
+    O.conv2d_tf(O.resize_bilinear_legacy(xz, 2 * H, 2 * W), torch.as_tensor(w, dtype=torch.float64), None, 1, "same").backward(torch.as_tensor(dy, dtype=torch.float64))
+    ref = xz.grad.numpy()
+    got = dx.cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref)[:, 1:-1, 1:-1].max() / scale < TOL32
+    assert np.abs(got - ref)[:, 0].max() / scale > 1e-3           # the border lines are not final (the engine recomputes them from strips)
+
+
+@pytest.mark.parametrize("geom", [(32, 64, 64, 128, 128), (64, 128, 64, 128, 256)], ids=lambda g: "x".join(map(str, g)))
+def test_f32_conv3x3_stride2_bwd_data_as_one_halo_launch(gpu_ctx, geom):
+    L = _lib()
+    from ladder_latent_data_distribution_modelling_amd import arch
+    N, H, W, Cin, Cout = geom
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(17)
+    pt, Ho = arch.conv_out(H, 3, 2, "same")
+    pl, Wo = arch.conv_out(W, 3, 2, "same")
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    dy = rng.standard_normal((N, Ho, Wo, Cout)).astype(np.float32)
+    xt = torch.zeros(N, H, W, Cin, dtype=torch.float64, requires_grad=True)
+    O.conv2d_tf(xt, torch.as_tensor(w, dtype=torch.float64), None, 2, "same").backward(torch.as_tensor(dy, dtype=torch.float64))
+    bank = _bank(L, w, Cout, 4 * Cin, 2, st)
+    dx = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+    L.call("ladder_conv3x3_s2_bwd_data_split", p(dev(dy)), None, p(bank), p(dx), None, N, H, W, Cin, Ho, Wo, Cout, F32, st)
+    close(dx, xt.grad, TOL32, "dx")
+    # the round-1 path (four parity-class launches of the gather kernel) agrees to rounding
+    wT = torch.empty(9 * Cin * Cout, device="cuda")
+    L.call("ladder_filter_flip_transpose", p(dev(w)), p(wT), 3, 3, Cin, Cout, st)
+    dx2 = torch.empty_like(dx)
+    wsp, wsn = gpu_ctx.ws(1 << 20)
+    L.call("ladder_conv2d_bwd_data", p(dev(dy)), p(wT), p(dx2), N, H, W, Cin, Ho, Wo, Cout, 3, 3, 2, pt, pl, None, 0, wsp, wsn, st)
+    close(dx2, xt.grad, TOL32, "dx (gather)")
+
+
+def _celeba_setup(B, seed):
+    cfg = json.load(open(os.path.join(ROOT, "codes", "celeba_config.json")))
+    cfg["batch_size"] = B
+    cfg["matmul_precision"] = "f32"
+    rng = np.random.default_rng(seed)
+    x = rng.random((B, 128, 128, 3)).astype(np.float32)
+    Pm = O.init_params(cfg, seed=7)
+    noise = O.make_noise(cfg, B, rng, np.float32)
+    fix = np.load(os.path.join(ROOT, "tests", "golden", "GM_prior_info.npz"))
+    K = int(cfg["n_mixtures"])
+    gm = (fix["w_full"][:K] / fix["w_full"][:K].sum(), fix["m_full"][:K], fix["K_full"][:K])
+    return cfg, x, Pm, noise, gm
+
+
+def _worst_grad(g0, g1):
+    worst, wname = 0.0, None
+    for name in g0:
+        sc = np.abs(g0[name]).max()
+        if sc > 1e-9:
+            e = np.abs(g1[name] - g0[name]).max() / sc
+            if e > worst:
+                worst, wname = e, name
+    return worst, wname
+
+
+def test_f32_engine_routes_through_the_fused_kernels_and_agrees_with_the_direct_path(monkeypatch):
+    """Batch 128, full resolution, `matmul_precision: f32`: with `upsample_fused_convs: 2` the training forward runs conv2d_7 + the RGB projection
+    as one upsample-fused launch, its backward-data returns the gradient of the low-resolution tensor (one launch + 4 border strips), the
+    forward-only run fuses conv2d_6 as well and writes neither resized tensor nor the 128-channel activation, enc.conv2d_1's backward-data is
+    one launch -- and every fetch / gradient agrees with `upsample_fused_convs: 0` (direct fp32 kernels) at fp32 rounding level."""
+    from ladder_latent_data_distribution_modelling_amd import _lib as L
+    from ladder_latent_data_distribution_modelling_amd.engine import LadderEngine
+    cfg, x, Pm, noise, gm = _celeba_setup(128, 41)
+    calls, real = [], L.call
+
+    def spy(name, *a):
+        calls.append((name, a))
+        return real(name, *a)
+
+    monkeypatch.setattr(L, "call", spy)
+    res = {}
+    for up2 in (0, 2):
+        eng = LadderEngine(dict(cfg, upsample_fused_convs=up2), "cuda:0", values=Pm, seed=1)
+        assert eng.precision == "f32" and eng.ctx.ns == 0
+        eng.set_mixture(*gm)
+        del calls[:]
+        eng.run_ae(x, 0.0, noise, False, False)
+        tc = [c[0] for c in calls]
+        precs = {c[1][-2] for c in calls if c[0] in ("ladder_conv3x3_split", "ladder_conv3x3_up2_split_proj", "ladder_conv3x3_split_proj")}
+        f = eng.fetch()
+        g = {k: v.detach().cpu().numpy().copy() for k, v in eng.ps.g.items()}
+        del calls[:]
+        eng.evaluate(x, noise, False, False)
+        ec = [c[0] for c in calls]
+        ev, dec = eng.fetch(), eng.xhat.detach().cpu().numpy().copy()
+        res[up2] = (f, g, ev, dec, tc, ec, precs)
+        del eng
+        torch.cuda.empty_cache()
+    f0, g0, e0, d0, tc0, ec0, p0 = res[0]
+    f1, g1, e1, d1, tc1, ec1, p1 = res[2]
+    assert p0 == {0} and p1 == {0}, "every halo launch carries prec = LADDER_PREC_F32"
+    assert not any("up2" in c for c in tc0 + ec0)
+    assert tc1.count("ladder_conv3x3_up2_split_proj") == 1 and "ladder_in_style_fwd_resize2x_keep" in tc1
+    assert tc1.count("ladder_conv3x3_up2_bwd_data_split") == 1 and tc1.count("ladder_conv3x3_up2_bwd_border") == 4
+    assert tc1.count("ladder_conv3x3_s2_bwd_data_split") == 1 and tc0.count("ladder_conv3x3_s2_bwd_data_split") == 1
+    assert tc1.count("ladder_resize_bilinear_bwd") == tc0.count("ladder_resize_bilinear_bwd") - 1
+    assert ec1.count("ladder_conv3x3_up2_split_proj") == 1 and ec1.count("ladder_conv3x3_up2_split") == 1 and ec1.count("ladder_conv3x3_up2_edges") == 2
+    assert tc0.count("ladder_conv3x3_split_proj") == 1 and ec0.count("ladder_conv3x3_split_proj") == 1      # the fused projection without the upsample fusion
+    for k in ("elbo", "l1_reconstruction_error", "l2_reconstruction_error", "loss_ae", "sigma", "mean_pixel_error"):
+        assert abs(f1[k] - f0[k]) <= 2e-6 * abs(f0[k]) + 1e-7, (k, f1[k], f0[k])
+    for k in e0:
+        if isinstance(e0[k], float):
+            assert abs(e1[k] - e0[k]) <= 2e-6 * abs(e0[k]) + 1e-7, (k, e1[k], e0[k])
+    close(d1, d0, 5e-6, "decoded image")
+    worst, wname = _worst_grad(g0, g1)
+    print("f32 fused vs direct: worst relative gradient difference %.2e (%s)" % (worst, wname))
+    assert worst < 5e-5, (worst, wname)

@@ -396,9 +396,11 @@ def test_conv3x3_split_fused_projection(gpu_ctx, prec, keep_y):
 
 @pytest.mark.parametrize("M,K,N,act", [(128, 512, 512, "leaky_relu"), (128, 2048, 64, "relu"), (128, 2, 512, None), (128, 64, 512, "leaky_relu"),
                                        (7, 20, 36, "relu"), (256, 512, 1024, None), (33, 100, 70, "tanh"), (128, 512, 2, None)])
-def test_dense_small_bf16x6(gpu_ctx, M, K, N, act):
+@pytest.mark.parametrize("sfx", ["", "_f32"], ids=["bf16x6", "f32"])
+def test_dense_small_bf16x6(gpu_ctx, M, K, N, act, sfx):
     """Batch-sized dense layers on the bf16 matrix cores (bf16x6, one launch, csrc/densesplit.hip): forward, backward-data from the
-    UN-transposed weights (with and without the fused activation gate) and backward-weight + bias, at the fp32 kernels' tolerances."""
+    UN-transposed weights (with and without the fused activation gate) and backward-weight + bias, at the fp32 kernels' tolerances.
+    `_f32`: the same kernels on the fp32 MFMA (strict fp32, round 4) -- same bars."""
     L = _lib()
     rng = np.random.default_rng(M * 7 + K)
     x = rng.standard_normal((M, K)).astype(np.float32)
@@ -413,22 +415,22 @@ def test_dense_small_bf16x6(gpu_ctx, M, K, N, act):
     assert L.query("ladder_dense_small_eligible", M, K, N) == 1
     xd, wd, bd = dev(x), dev(w), dev(b)
     y = torch.empty(M, N, device="cuda")
-    L.call("ladder_dense_fwd_small", p(xd), p(wd), p(bd), p(y), M, K, N, L.ACT[act], st)
+    L.call("ladder_dense_fwd_small" + sfx, p(xd), p(wd), p(bd), p(y), M, K, N, L.ACT[act], st)
     close(y, yr, 2e-5, "fwd")
     dyd = dev(dy)
     if act is not None:
         L.call("ladder_act_bwd", p(dyd), p(dev(yr.detach().numpy())), p(dyd), dyd.numel(), L.ACT[act], st)
     dw, db, dx, dxg = torch.empty_like(wd), torch.empty_like(bd), torch.empty_like(xd), torch.empty_like(xd)
-    L.call("ladder_dense_bwd_weight_small", p(xd), p(dyd), p(dw), p(db), M, K, N, st)
+    L.call("ladder_dense_bwd_weight_small" + sfx, p(xd), p(dyd), p(dw), p(db), M, K, N, st)
     close(dw, wt.grad, 3e-5, "dw")
     close(db, bt.grad, 3e-5, "db")
-    L.call("ladder_dense_bwd_data_small", p(dyd), p(wd), p(dx), M, K, N, None, 0, st)
+    L.call("ladder_dense_bwd_data_small" + sfx, p(dyd), p(wd), p(dx), M, K, N, None, 0, st)
     close(dx, xt.grad, 3e-5, "dx")
-    L.call("ladder_dense_bwd_data_small", p(dyd), p(wd), p(dxg), M, K, N, p(xd), 1, st)
+    L.call("ladder_dense_bwd_data_small" + sfx, p(dyd), p(wd), p(dxg), M, K, N, p(xd), 1, st)
     assert torch.equal(dxg, dx * torch.where(xd > 0, 1.0, 0.2))
     # both gradient GEMMs in one launch: the same sums in the same order when the variant (wavefronts per tile) coincides, else to tolerance
     dw2, db2, dx2 = torch.empty_like(wd), torch.empty_like(bd), torch.empty_like(xd)
-    L.call("ladder_dense_bwd_small", p(xd), p(dyd), p(wd), p(dx2), p(dw2), p(db2), M, K, N, p(xd), 1, st)
+    L.call("ladder_dense_bwd_small" + sfx, p(xd), p(dyd), p(wd), p(dx2), p(dw2), p(db2), M, K, N, p(xd), 1, st)
     close(dw2, wt.grad, 3e-5, "dw (fused)")
     close(db2, bt.grad, 3e-5, "db (fused)")
     close(dx2, xt.grad * torch.where(xt.detach() > 0, 1.0, 0.2), 3e-5, "dx (fused, gated)")

@@ -102,7 +102,8 @@ def test_up2_conv_with_fused_projection_vs_oracle(gpu_ctx, case):
         close(y, ref, TOL[prec][0], "map")
 
 
-def test_engine_uses_upsample_fused_convs_and_agrees_with_direct_path(monkeypatch):
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_engine_uses_upsample_fused_convs_and_agrees_with_direct_path(monkeypatch, prec):
     """The full-resolution CelebA net at batch 8 with `upsample_fused_convs` on / off: the training forward (conv2d_7 on the kept upsample) and
     the forward-only runs (conv2d_6 and conv2d_7 from the low-resolution maps, no resized tensors) must call the up2 entry points, and
     every RUN#1 fetch, the decoded image, the sigma step and every gradient must agree with the direct path to fp32-class error."""
@@ -112,6 +113,7 @@ def test_engine_uses_upsample_fused_convs_and_agrees_with_direct_path(monkeypatc
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg = json.load(open(os.path.join(root, "codes", "celeba_config.json")))
     cfg["batch_size"] = B = 8
+    cfg["matmul_precision"] = prec
     rng = np.random.default_rng(31)
     x = rng.random((B, 128, 128, 3)).astype(np.float32)
     Pm = O.init_params(cfg, seed=7)
@@ -223,8 +225,9 @@ def test_up2_backward_data_interior_vs_autograd(gpu_ctx, case):
     assert err[:, 0].max() / scale > 1e-3 and err[:, -1].max() / scale > 1e-3                 # the border lines are NOT final (documented)
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
 @pytest.mark.parametrize("mode", [2, 3])
-def test_engine_fused_lowres_backward_agrees_with_direct_path(monkeypatch, mode):
+def test_engine_fused_lowres_backward_agrees_with_direct_path(monkeypatch, mode, prec):
     """Batch 128, full resolution: with `upsample_fused_convs: 2` the backward-data of conv2d_7 / conv2d_6 returns the gradient of the tensor behind
     the resize (ladder_conv3x3_up2_bwd_data_split + border strips; the separate resize transpose disappears); every gradient of the AE group
     must agree with the direct path to fp32-class error."""
@@ -234,6 +237,7 @@ def test_engine_fused_lowres_backward_agrees_with_direct_path(monkeypatch, mode)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg = json.load(open(os.path.join(root, "codes", "celeba_config.json")))
     cfg["batch_size"] = B = 128          # (conv2d_6's pair needs 128 images for the 16-wave kernel's 512 workgroups, conv2d_7's 64)
+    cfg["matmul_precision"] = prec
     rng = np.random.default_rng(41)
     x = rng.random((B, 128, 128, 3)).astype(np.float32)
     Pm = O.init_params(cfg, seed=7)
