@@ -247,6 +247,15 @@ size_t ladder_conv2d_fwd_split_bnstats_workspace_bytes(int N, int H, int W, int 
 int ladder_conv2d_fwd_split_bnstats(const void* x_planes, const float* x_absmax, const void* packed, const float* bias, float* y, int N,
                                     int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l,
                                     int act, int prec, float* sums4, void* stats_ws, size_t stats_ws_bytes, ladder_stream_t stream);
+/* The strict-fp32 form (round 4): ladder_conv2d_fwd (gather kernel, 128x128 tiles, no split-K) whose epilogue also leaves the batch-norm
+ * statistics of y in sums4 [4*Cout] = sum | sum of squares | min | max per channel (reference: tf.layers.batch_normalization behind
+ * tf.layers.conv2d, codes/models.py:398-460) -- the separate statistics pass over y disappears.  workspace_bytes == 0: the geometry does
+ * not run on that kernel configuration (the caller falls back to ladder_conv2d_fwd + ladder_bn_fwd_stats). */
+size_t ladder_conv2d_fwd_bnstats_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t,
+                                                 int pad_l);
+int ladder_conv2d_fwd_bnstats(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                              int KH, int KW, int stride, int pad_t, int pad_l, int act, float* sums4, void* stats_ws, size_t stats_ws_bytes,
+                              ladder_stream_t stream);
 int ladder_conv2d_bwd_data_split_eligible(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t,
                                           int pad_l, int gated);
 size_t ladder_conv2d_bwd_data_split_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,

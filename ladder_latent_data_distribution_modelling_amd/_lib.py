@@ -117,6 +117,8 @@ PROTOTYPES = {
     "ladder_conv2d_fwd_split": (_i, [_p, _p, _p, _p, _p] + [_i] * 14 + [_p, _z, _p]),
     "ladder_conv2d_fwd_split_bnstats_workspace_bytes": (_z, [_i] * 12),
     "ladder_conv2d_fwd_split_bnstats": (_i, [_p] * 5 + [_i] * 14 + [_p, _p, _z, _p]),
+    "ladder_conv2d_fwd_bnstats_workspace_bytes": (_z, [_i] * 12),
+    "ladder_conv2d_fwd_bnstats": (_i, [_p, _p, _p, _p] + [_i] * 13 + [_p, _p, _z, _p]),
     "ladder_conv2d_bwd_data_split_eligible": (_i, [_i] * 13),
     "ladder_conv2d_bwd_data_split_workspace_bytes": (_z, [_i] * 12),
     "ladder_conv2d_bwd_data_split": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p, _i, _i, _p, _z, _p]),

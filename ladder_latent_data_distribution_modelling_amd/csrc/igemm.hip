@@ -115,7 +115,8 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? IGEMM_FWD_MINW :
                                                              const float* __restrict__ bias, float* __restrict__ y,
                                                              const IgemmDesc d, const int tiles_n, const bool fast,
                                                              float* __restrict__ part, const int chunks_per_split,
-                                                             const float* __restrict__ gate, const int gate_act) {
+                                                             const float* __restrict__ gate, const int gate_act,
+                                                             float* __restrict__ stats_part) {
   constexpr int LDA = BK + 1;  // odd row stride: conflict-free ds_read_b32 of A fragments
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
   constexpr int A_UNITS = BM * (BK / 4), B_UNITS = BK * (BN / 4);
@@ -299,6 +300,12 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? IGEMM_FWD_MINW :
   }
   // epilogue: bias + activation, 128-byte row segments per half-wave
   const bool dense_out = d.out_sh == 1 && d.out_sw == 1 && d.OH == d.Ho && d.OW == d.Wo;
+  // batch-norm statistics of what is written (128x128 tiles only; lane = output channel: the column sums are local):
+  // stats_part [tile_m][4][Cout] = sum | sum of squares | min | max per tile, reduced by ladder_bn_stats_minmax_from_partials
+  constexpr bool STATS = (BM == 128 && BN == 128 && WM == 2);
+  float st0[NI], st1[NI], smn[NI], smx[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) { st0[ni] = 0.f; st1[ni] = 0.f; smn[ni] = INFINITY; smx[ni] = -INFINITY; }
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int n = n0 + wn * TN + ni * 32 + l31;
@@ -320,8 +327,37 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? IGEMM_FWD_MINW :
           // (fuses the previous layer's activation backward into this backward-data pass)
           if (gate != nullptr) v *= ladder_act_grad_from_out(gate[row * d.Cout + n], gate_act);
           y[row * d.Cout + n] = v;
+          if (STATS) {
+            st0[ni] += v;
+            st1[ni] += v * v;
+            smn[ni] = fminf(smn[ni], v);
+            smx[ni] = fmaxf(smx[ni], v);
+          }
         }
       }
+    }
+  }
+  if (STATS && stats_part != nullptr) {
+    float* sred = &Bs[0][0];                                 // [which 4][wm 2][128 channels] (the operand tiles are dead)
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const float a0 = st0[ni] + __shfl_xor(st0[ni], 32, 64), a1 = st1[ni] + __shfl_xor(st1[ni], 32, 64);
+      const float a2 = fminf(smn[ni], __shfl_xor(smn[ni], 32, 64)), a3 = fmaxf(smx[ni], __shfl_xor(smx[ni], 32, 64));
+      if (lh == 0) {
+        const int cc = wn * TN + ni * 32 + l31;
+        sred[(0 * 2 + wm) * 128 + cc] = a0;
+        sred[(1 * 2 + wm) * 128 + cc] = a1;
+        sred[(2 * 2 + wm) * 128 + cc] = a2;
+        sred[(3 * 2 + wm) * 128 + cc] = a3;
+      }
+    }
+    __syncthreads();
+    for (int t = tid; t < 4 * 128; t += kThreads) {
+      const int which = t >> 7, c = t & 127;
+      const float v0 = sred[(which * 2 + 0) * 128 + c], v1 = sred[(which * 2 + 1) * 128 + c];
+      const float r = which < 2 ? v0 + v1 : (which == 2 ? fminf(v0, v1) : fmaxf(v0, v1));
+      if (n0 + c < d.Cout) stats_part[((size_t)(tile / tiles_n) * 4 + which) * d.Cout + n0 + c] = r;
     }
   }
 }
@@ -1241,7 +1277,7 @@ SplitPlan plan_splitk(long M, int K, int Cout, int bm, int bn) {
 
 template <int BM, int BN, int WM, int WN>
 int launch_fwd(const float* x, const float* w, const float* bias, float* y, const IgemmDesc& d, void* ws, size_t ws_bytes,
-               hipStream_t st, const float* gate = nullptr, int gate_act = 0) {
+               hipStream_t st, const float* gate = nullptr, int gate_act = 0, float* stats_part = nullptr) {
   const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.Cout + BN - 1) / BN;
   const bool veca = (d.Cin % BK) == 0, vecb = (d.Cout % 4) == 0;
   const bool fast = d.ntaps > 0;
@@ -1250,11 +1286,12 @@ int launch_fwd(const float* x, const float* w, const float* bias, float* y, cons
   const size_t need = (size_t)sp.splits * d.M * d.Cout * sizeof(float);
   if (sp.splits > 1 && (ws == nullptr || ws_bytes < need)) sp = SplitPlan{1, (d.K + BK - 1) / BK};
   float* part = sp.splits > 1 ? (float*)ws : nullptr;
+  if (stats_part != nullptr && (part != nullptr || !dense_out || BM != 128 || BN != 128)) return LADDER_E_SHAPE;   // statistics come from the single-pass 128x128 epilogue
   dim3 grid(tiles_m * tiles_n, sp.splits), block(kThreads);
-  if (veca && vecb) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, x, w, bias, y, d, tiles_n, fast, part, sp.cps, part ? nullptr : gate, gate_act);
-  else if (veca) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, st, x, w, bias, y, d, tiles_n, fast, part, sp.cps, part ? nullptr : gate, gate_act);
-  else if (vecb) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, st, x, w, bias, y, d, tiles_n, fast, part, sp.cps, part ? nullptr : gate, gate_act);
-  else hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, x, w, bias, y, d, tiles_n, fast, part, sp.cps, part ? nullptr : gate, gate_act);
+  if (veca && vecb) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, x, w, bias, y, d, tiles_n, fast, part, sp.cps, part ? nullptr : gate, gate_act, stats_part);
+  else if (veca) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, st, x, w, bias, y, d, tiles_n, fast, part, sp.cps, part ? nullptr : gate, gate_act, stats_part);
+  else if (vecb) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, st, x, w, bias, y, d, tiles_n, fast, part, sp.cps, part ? nullptr : gate, gate_act, stats_part);
+  else hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, x, w, bias, y, d, tiles_n, fast, part, sp.cps, part ? nullptr : gate, gate_act, stats_part);
   if (part != nullptr) {
     const size_t mn = (size_t)d.M * d.Cout;
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, (const float*)part, bias, y,
@@ -2008,6 +2045,37 @@ int ladder_conv2d_fwd(const float* x, const float* w, const float* bias, float* 
 }
 
 size_t ladder_igemm_fwd_workspace_bytes(long M, int K, int Cout) { return fwd_ws_bytes(M, K, Cout); }
+
+// ---- strict-fp32 convolution whose epilogue also emits the batch-norm statistics of its output (round 4: the fp32 form of
+// ladder_conv2d_fwd_split_bnstats): 128x128-tile gather launches without split-K.  0 bytes = not available for this geometry.
+static bool fwd_bnstats_ok(const IgemmDesc& d) {
+  if (getenv("LADDER_DISABLE_BNSTATS") != nullptr) return false;       // (test-only switch: the statistics then come from the separate pass)
+  return (d.Cin % BK) == 0 && (d.Cout % 4) == 0 && d.ntaps > 0 && !halo_eligible(d) && select_fwd_tile(d.M, d.Cout) == 128128 &&
+         plan_splitk(d.M, d.K, d.Cout, 128, 128).splits == 1 && !smallcout_eligible(d.Cin, d.Cout, d.KH, d.KW, d.stride, d.M);
+}
+
+size_t ladder_conv2d_fwd_bnstats_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t,
+                                                 int pad_l) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return 0;
+  IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, 1, pad_t, pad_l, N * Ho * Wo, KH * KW * Cin, 0, make_fastdiv(Ho * Wo), make_fastdiv(Wo)};
+  set_conv_taps(d);
+  if (!fwd_bnstats_ok(d)) return 0;
+  return (((size_t)d.M + 127) / 128) * 4 * (size_t)Cout * sizeof(float);
+}
+
+int ladder_conv2d_fwd_bnstats(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                              int KH, int KW, int stride, int pad_t, int pad_l, int act, float* sums4, void* stats_ws, size_t stats_ws_bytes,
+                              ladder_stream_t stream) {
+  const size_t need = ladder_conv2d_fwd_bnstats_workspace_bytes(N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_t, pad_l);
+  if (need == 0 || sums4 == nullptr) return LADDER_E_SHAPE;
+  if (stats_ws == nullptr || stats_ws_bytes < need) return LADDER_E_WORKSPACE;
+  if (!ladder_aligned16(x) || !ladder_aligned16(w) || !ladder_aligned16(y)) return LADDER_E_ALIGN;
+  IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, 1, pad_t, pad_l, N * Ho * Wo, KH * KW * Cin, act, make_fastdiv(Ho * Wo), make_fastdiv(Wo)};
+  set_conv_taps(d);
+  const int rc = launch_fwd<128, 128, 2, 2>(x, w, bias, y, d, nullptr, 0, stream, nullptr, 0, (float*)stats_ws);
+  if (rc != LADDER_OK) return rc;
+  return ladder_bn_stats_minmax_from_partials((const float*)stats_ws, (int)(((size_t)d.M + 127) / 128), sums4, Cout, stream);
+}
 
 int ladder_conv2d_fwd_kernel_id(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int ups,
                                 int pad_t, int pad_l) {

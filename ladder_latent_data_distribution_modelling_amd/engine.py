@@ -137,16 +137,55 @@ class Comm:
         self.group = group
         self.world = dist.get_world_size(group) if self.on else 1
         self.rank = dist.get_rank(group) if self.on else 0
+        self.trace = None          # label -> [(start event, end event, bytes, exposed-start event or None)]: see enable_trace()
 
-    def allreduce_(self, t):
+    def enable_trace(self, on=True):
+        """Per-collective timing for `bench.py --gpus N` (the first multi-GPU run must be diagnosable).  Every exchange step
+        is bracketed by HIP events on the COMPUTE stream: `wall` = from the point the collective is issued to the point the compute stream
+        may continue behind it; for a blocking collective that is also the time it was EXPOSED (nothing else runs on the compute stream
+        meanwhile); for the asynchronous C1 bucket `exposed` = from wait() to completion only -- the rest ran under backward kernels."""
+        self.trace = {} if on else None
+
+    def _ev(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def trace_summary(self, steps):
+        """{label: calls / step, bytes / call, wall and exposed microseconds per call and per step} of the traced collectives."""
+        if not self.trace:
+            return {}
+        torch.cuda.synchronize()
+        out = {}
+        for label, recs in self.trace.items():
+            wall = sum(s.elapsed_time(e) for s, e, _, _ in recs) * 1e3
+            expo = sum((x if x is not None else s).elapsed_time(e) for s, e, _, x in recs) * 1e3
+            n = len(recs)
+            out[label] = {"calls_per_step": round(n / steps, 2), "bytes_per_call": int(sum(b for _, _, b, _ in recs) / n),
+                          "wall_us_per_call": round(wall / n, 1), "exposed_us_per_call": round(expo / n, 1),
+                          "wall_us_per_step": round(wall / steps, 1), "exposed_us_per_step": round(expo / steps, 1)}
+        return out
+
+    def allreduce_(self, t, label="allreduce"):
         if self.on:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            if self.trace is not None:
+                s = self._ev()
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+                self.trace.setdefault(label, []).append((s, self._ev(), t.numel() * t.element_size(), None))
+            else:
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
 
-    def allreduce_async_(self, t):
+    def allreduce_async_(self, t, label="allreduce (async)"):
         """Start the all-reduce and return a handle (None with one rank): the collective runs on the process group's own
         stream, so kernels enqueued afterwards on the compute stream overlap it; `wait()` orders the compute stream after it."""
-        return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True) if self.on else None
+        if not self.on:
+            return None
+        if self.trace is None:
+            return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        s = self._ev()
+        return _TracedWork(self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True), self, label, s,
+                           t.numel() * t.element_size())
 
     def broadcast_(self, t, src=0):
         if self.on:
@@ -154,14 +193,26 @@ class Comm:
         return t
 
 
+class _TracedWork:
+    """Handle of a traced asynchronous collective: wait() records when the compute stream started to wait and when it could continue."""
+
+    def __init__(self, work, comm, label, start, nbytes):
+        self.work, self.comm, self.label, self.start, self.nbytes = work, comm, label, start, nbytes
+
+    def wait(self):
+        x = self.comm._ev()
+        self.work.wait()
+        self.comm.trace.setdefault(self.label, []).append((self.start, self.comm._ev(), self.nbytes, x))
+
+
 class _NoComm:
     """Communicator stand-in for computations that are REPLICATED on every rank (the VampPrior pseudo-input pass)."""
     on, world, rank = False, 1, 0
 
-    def allreduce_(self, t):
+    def allreduce_(self, t, label=None):
         return t
 
-    def allreduce_async_(self, t):
+    def allreduce_async_(self, t, label=None):
         return None
 
     def broadcast_(self, t, src=0):
@@ -631,6 +682,15 @@ class Conv2D:
                 _timed(128120 + self.ctx.ns, 2.0 * N * Ho * Wo * self.k * self.k * self.cin * self.cout, "ladder_conv2d_fwd_split", args)
             self.x, self.y = x, y
             return y
+        if self.ctx.ns == 0 and self.want_bn_sums and self.act is None:
+            snb = L.query("ladder_conv2d_fwd_bnstats_workspace_bytes", *geo)
+            if snb:                                      # strict fp32: the epilogue also emits the batch-norm statistics of y (no second pass over it)
+                swp, swn = self.ctx.ws(snb)
+                self.bn_sums = self.ctx.empty(4 * self.cout)
+                L.call("ladder_conv2d_fwd_bnstats", _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y), *geo, 0,
+                       _p(self.bn_sums), swp, swn, self.ctx.stream)
+                self.x, self.y = x, y
+                return y
         _igemm(self.ctx, "ladder_conv2d_fwd", N * Ho * Wo, self.cin, self.cout, self.k * self.k * self.cin,
                _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y),
                N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl, L.ACT[self.act],
@@ -916,7 +976,7 @@ class BatchNormAct:
                 sums = ctx.empty(2 * C)
                 L.call("ladder_bn_fwd_stats", _p(x), _p(sums), rows, C, wsp, wsn, ctx.stream)
         want_planes = want_planes and sums.numel() == 4 * C
-        ctx.comm.allreduce_(sums[:2 * C])                       # (the extremes stay local: they bound THIS rank's tensor)
+        ctx.comm.allreduce_(sums[:2 * C], "C2 fwd " + self.name.split("/")[-1])   # (the extremes stay local: they bound THIS rank's tensor)
         self.count = float(rows) * ctx.comm.world
         self.mean_rstd = ctx.empty(2 * C)
         gam, bet = self.ps.w[self.name + "/gamma"], self.ps.w[self.name + "/beta"]
@@ -948,7 +1008,7 @@ class BatchNormAct:
         dsums = ctx.empty(2 * C)
         L.call("ladder_bn_bwd_stats", _p(dy), _p(x), _p(self.mean_rstd), _p(gam), _p(bet), _p(dsums), rows, C,
                L.ACT[self.act], wsp, wsn, ctx.stream)
-        ctx.comm.allreduce_(dsums)
+        ctx.comm.allreduce_(dsums, "C2 bwd " + self.name.split("/")[-1])
         dx = torch.empty_like(x) if need_dx else None
         # dgamma/dbeta are global sums already: written on every rank, the group all-reduce must not re-sum
         # them -> the engine divides BN parameter grads by world size before the flat all-reduce.
@@ -1570,7 +1630,7 @@ class LadderEngine:
                 if self._gm_packed is None:
                     raise L.LadderHipError("set_mixture()/set_sg_mixture() must be called before a run that evaluates the GM prior")
                 self.gmm_grads = self._mixture_term(mu_t, sd_t, noise, B)
-        ctx.comm.allreduce_(P)                                   # C3: scalar partials of the GLOBAL batch
+        ctx.comm.allreduce_(P, "C3 partials")                    # C3: scalar partials of the GLOBAL batch
         ecfg = L.LadderElboCfg(self.Bg, self.D, Z, R, self.Lmc,
                                1 if (self.cfg["exp_name"] == "celeba" or int(self.cfg["TRAIN_sigma"]) == 1) else 0,
                                1 if inner_on else 0, 1 if use_sg else 0,
@@ -1704,7 +1764,7 @@ class LadderEngine:
             # while the inner-VAE and encoder backward kernels keep the CUs busy.  The rest follows in _ae.
             lo, hi = self._dec_range
             ctx.join_side()                                       # the decoder's filter gradients are final only after the side stream
-            self._c1_pending = ctx.comm.allreduce_async_(self.ps.grad["ae"][lo:hi])
+            self._c1_pending = ctx.comm.allreduce_async_(self.ps.grad["ae"][lo:hi], "C1 bucket 1 (decoder, async)")
         mode = 1
         if self.has_inner and not self.use_sg:
             mu_t, sd_t, sdraw_t, eps_t, t = self.lat_t
@@ -1757,13 +1817,13 @@ class LadderEngine:
         if getattr(self, "_c1_pending", None) is not None:
             lo, hi = self._dec_range                              # decoder bucket already in flight: reduce what is left
             if lo > 0:
-                self.ctx.comm.allreduce_(g[:lo])
+                self.ctx.comm.allreduce_(g[:lo], "C1 bucket 2 (rest)")
             if hi < g.numel():
-                self.ctx.comm.allreduce_(g[hi:])
+                self.ctx.comm.allreduce_(g[hi:], "C1 bucket 2 (rest)")
             self._c1_pending.wait()
             self._c1_pending = None
         else:
-            self.ctx.comm.allreduce_(g)
+            self.ctx.comm.allreduce_(g, "C1 (one bucket)")
         self.ps.adam("ae", lr)
         self._repack_filters()
 
@@ -1806,12 +1866,12 @@ class LadderEngine:
                 g.zero_()
             else:
                 g.copy_(self._vamp_backward(wgrad=False, need_input_dx=True))
-            self.ctx.comm.allreduce_(self.ps.grad["prior"])       # C4
+            self.ctx.comm.allreduce_(self.ps.grad["prior"], "C4 prior gradients")       # C4
             self.ps.adam("prior", lr)
             return
         self.forward(x, noise, use_sg, use_mask, ("inner", "gmm"), reuse_encoder)
         self._backward_prior()
-        self.ctx.comm.allreduce_(self.ps.grad["prior"])           # C4
+        self.ctx.comm.allreduce_(self.ps.grad["prior"], "C4 prior gradients")           # C4
         self.ps.adam("prior", lr)
 
     def _inner_sigma(self, x, lr, noise, use_sg, use_mask, reuse_encoder=False):

@@ -155,7 +155,7 @@ if world > 1:
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=world)
 from ladder_latent_data_distribution_modelling_amd.engine import LadderEngine
 cfg = json.load(open(os.path.join(%(root)r, "codes", %(config)r)))
-cfg["matmul_precision"] = "f16x3"
+cfg["matmul_precision"] = %(prec)r
 Bg = 128
 Bl = Bg // world
 Z, R, Lmc, K = cfg["code_size"], cfg["representation_size"], cfg["n_MC_samples"], cfg["n_mixtures"]
@@ -196,16 +196,17 @@ if world > 1:
 '''
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
 @pytest.mark.parametrize("config", ["celeba_config.json", "celeba_r8k50_config.json"])
-def test_data_parallel_full_size_two_ranks_one_gpu(tmp_path, config):
+def test_data_parallel_full_size_two_ranks_one_gpu(tmp_path, config, prec):
     """configs[3] / configs[4] per-GPU legs as a 2-rank data-parallel job at FULL size on one GPU (2 x 64 images over gloo, both
-    ranks on cuda:0; RCCL refuses two ranks on one device) against the single-process step on the 128 images, f16x3, explicit
-    noise sharded by sample: the global-batch all-reduced step must equal the single-rank step -- RUN#1 fetches to 1e-5, the
-    all-reduced gradient (norm 1e-4; selected tensors incl. a batch-norm gamma, whose gradient is global BEFORE C1) and the
-    updated parameters to Adam-noise level."""
+    ranks on cuda:0; RCCL refuses two ranks on one device) against the single-process step on the 128 images, strict fp32 (the
+    default) and f16x3, explicit noise sharded by sample: the global-batch all-reduced step must equal the single-rank step -- RUN#1
+    fetches to 1e-5, the all-reduced gradient (norm 1e-4; selected tensors incl. a batch-norm gamma, whose gradient is global BEFORE
+    C1) to bars derived from the measured rounding sensitivity of each tensor (see below), and the updated parameters to Adam-noise level."""
     port = 31000 + os.getpid() % 2000
     script = tmp_path / "dp_worker.py"
-    script.write_text(DP_WORKER % dict(root=ROOT, port=port, config=config))
+    script.write_text(DP_WORKER % dict(root=ROOT, port=port, config=config, prec=prec))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out2, out1 = str(tmp_path / "dp2.npz"), str(tmp_path / "dp1.npz")
     procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", out2], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -225,11 +226,20 @@ def test_data_parallel_full_size_two_ranks_one_gpu(tmp_path, config):
     for k in a.files:
         if k.startswith("g/"):
             ga, gb = a[k].astype(np.float64), b[k].astype(np.float64)
-            # two ranks round every reduction differently (per-rank partial sums, per-rank f16x3 scales): leaky-ReLU mask flips of
-            # pre-activations within fp32 rounding of zero move deep-layer gradients by up to ~1e-2 of the tensor scale (same bars as the
-            # in-situ comparison of differently rounded fp32-class builds); the last decoder layer sees only its own rounding
-            tol = 2e-4 if k.endswith("conv2d_7/kernel") else 5e-2
-            assert np.isfinite(ga).all() and np.abs(ga - gb).max() < tol * np.abs(gb).max(), (k, np.abs(ga - gb).max(), np.abs(gb).max())
+            # Per SAMPLE the two jobs run the same kernels on the same tiles (a halo / gather tile never straddles images; the f16x3 scales
+            # are per sample since round 3), so activations differ only through the ROUNDING of the batch statistics (per-rank partial sums +
+            # all-reduce against one pass) and the gradients through the order of the filter-gradient reductions.  How far that alone moves
+            # these tensors was measured in round 4 on SINGLE-process pairs (profiles/r04_dp_sensitivity.txt): computing the batch-norm sums
+            # in the conv epilogue instead of a separate pass -- nothing else changed -- moves encoder/conv2d_1 by 1.5e-3, the batch-norm gamma
+            # by 1.7e-3 and decoder/dense by 2.2e-3 of their scale (this randomly initialised network amplifies a rounding-level change of
+            # the normalisation statistics ~1e4-fold on its deepest tensors).  2 x 64 against 1 x 128 measures 1.5e-5 / 2.4e-4 on the decoder
+            # convolutions and 4e-3 ... 7e-3 on those three (f16x3: 1.2e-3 ... 1.4e-3).  Bars: 4x the measured values (round 3: 5e-2 for
+            # everything); a wrong C2 backward term or a mis-scaled C1 bucket is an O(1) error on every tensor behind it, and the DP path is
+            # held against the float64 oracle with conditioning-based bounds in test_data_parallel_full_resolution_vs_live_float64_oracle.
+            tol = 2e-4 if k.endswith("conv2d_7/kernel") else (2e-3 if k.endswith("conv2d_5/kernel") else 2.5e-2)
+            err = np.abs(ga - gb).max() / np.abs(gb).max()
+            print("%s %s: all-reduced gradient of 2 x 64 images vs 1 x 128: max error %.1e of the tensor scale" % (prec, k, err))
+            assert np.isfinite(ga).all() and err < tol, (k, err)
         elif k.startswith("p/"):
             diff = np.abs(a[k].astype(np.float64) - b[k].astype(np.float64))
             assert np.median(diff) < 2e-6 and diff.max() <= 2 * 2.5e-4 + 1e-7, (k, np.median(diff), diff.max())
@@ -262,3 +272,98 @@ def test_graph_replay_then_eager_evaluation_sees_current_weights():
     assert torch.equal(xhat, fresh.xhat), float((xhat - fresh.xhat).abs().max())
     for k in ("elbo", "l1_reconstruction_error", "entropy_z", "crossEntropy_prior", "sigma_regularisor", "loss_ae"):
         assert got[k] == ref[k], (k, got[k], ref[k])
+
+
+DP_ORACLE_WORKER = r'''
+import json, os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+rank, world = int(sys.argv[1]), int(sys.argv[4])
+if world > 1:
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=world)
+from oracle import ladder_oracle as O
+from ladder_latent_data_distribution_modelling_amd.engine import LadderEngine
+from ladder_latent_data_distribution_modelling_amd import _lib as L
+cfg = json.load(open(os.path.join(%(root)r, "codes", "celeba_config.json")))
+cfg["matmul_precision"] = %(prec)r
+inp = np.load(sys.argv[2])
+Bg = inp["x"].shape[0]
+Bl = Bg // world
+cfg["batch_size"] = Bl
+sl = slice(Bl * rank, Bl * (rank + 1))
+noise = dict(eps_z=inp["eps_z"][sl], eps_t=inp["eps_t"][sl], eps_mc=np.ascontiguousarray(inp["eps_mc"][:, sl]))
+eng = LadderEngine(cfg, "cuda:0", values=O.init_params(cfg, seed=6), seed=1)
+assert eng.ctx.comm.world == world
+eng.set_mixture(inp["gm_w"], inp["gm_m"], inp["gm_c"])
+calls, real = [], L.call
+L.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+eng.run_ae(inp["x"][sl], 0.0, noise, False, False)
+L.call = real
+f = eng.fetch()
+if rank == 0:
+    np.savez(sys.argv[3], fetch=json.dumps(f), calls=json.dumps(sorted(set(calls))), **{"g/" + k: v.detach().cpu().numpy() for k, v in eng.ps.g.items()})
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_data_parallel_full_resolution_vs_live_float64_oracle(tmp_path, prec):
+    """VERDICT r3 #4: the PRODUCT data-parallel path at full resolution against the float64 ORACLE, not against another GPU run: 2 ranks x
+    8 images (the per-rank batch at which the fused halo kernels of conv2d_7 engage) over gloo on one GPU -- C2 (global-batch batch-norm
+    statistics, forward and backward, reference codes/models.py:398-460 on one device), C3 (ELBO partials) and C1 (gradient sum, both
+    buckets; clip after the mean, codes/base.py:462-464) -- must reproduce the oracle's single-process step on the 16 images: fetches to
+    2e-5, EVERY gradient tensor in relative L2 and in max norm (bars and their derivation below).  (That the oracle's own data-parallel
+    restatement equals its single-process step is pinned on the CPU by tests/test_host_cpu.py.)"""
+    cfg = _cfg("celeba_config.json")
+    Bg = 16
+    cfg["batch_size"] = Bg
+    rng = np.random.default_rng(23)
+    x = rng.random((Bg, 128, 128, 3)).astype(np.float32)
+    P = O.init_params(cfg, seed=6)
+    K = int(cfg["n_mixtures"])
+    fix = np.load(os.path.join(ROOT, "tests", "golden", "GM_prior_info.npz"))
+    gm = dict(weights=fix["w_full"][:K] / fix["w_full"][:K].sum(), means=fix["m_full"][:K], covs=fix["K_full"][:K])
+    noise = O.make_noise(cfg, Bg, rng, np.float32)
+    inp, outp = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
+    np.savez(inp, x=x, gm_w=gm["weights"], gm_m=gm["means"], gm_c=gm["covs"], **noise)
+    script = tmp_path / "dp_oracle_worker.py"
+    script.write_text(DP_ORACLE_WORKER % dict(root=ROOT, port=33000 + os.getpid() % 2000, prec=prec))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), inp, outp, "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    # the oracle runs on the host while the two ranks run on the GPU
+    ref = O.run(O.OracleState(cfg, P, np.float64), x, noise, gm, False, False, train="ae", lr=0.0)
+    ref32 = O.run(O.OracleState(cfg, P, np.float32), x, noise, gm, False, False, train="ae", lr=0.0)
+    outs = [p.communicate(timeout=1500)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[-2500:] for o in outs]
+    got = np.load(outp)
+    f, calls = json.loads(str(got["fetch"])), json.loads(str(got["calls"]))
+    # the fused forward pair (resize + conv2d_7 + RGB projection) engages at 8 images per rank; the fused backward-data needs 32 (512
+    # workgroups of 4x fewer pixels) -- that one is held against the direct path at batch 128 in tests/test_gpu_up2.py
+    assert "ladder_conv3x3_up2_split_proj" in calls and "ladder_in_style_fwd_resize2x_keep" in calls, calls
+    for k in SCALARS_RUN1:
+        assert _ok(f[k], float(ref[k]), 2e-5), (k, f[k], float(ref[k]))
+    # Per tensor: relative L2 error <= max(5e-3, 5 x the L2 deviation of the oracle evaluated in fp32 on the CPU) AND max error <= 5e-2 of the
+    # tensor's scale.  Why not the max-norm bar of the batch-8 test: at 16 images some leaky-ReLU pre-activation of the small decoder /
+    # encoder maps lands within fp32 rounding of zero in one build or another (measured in round 4, profiles/r04_dp_sensitivity.txt: the SINGLE
+    # process fp32 run flips one in decoder/conv2d_3's 8x8 map, the single-process f16x3 run one in the encoder's 4x4 map, the 2-rank
+    # runs other ones or none): the float64 oracle takes slope 1 where the GPU takes 0.2, which moves THAT output channel's gradient by
+    # 1-3 % of the tensor's largest element and everything behind it in the backward chain by ~1.5e-3 in L2 -- a property of the
+    # comparison against float64, not of the kernels (every convolution of these layers measures <= 2e-6 against float64 at batch 8 / 16 /
+    # 32).  A wrong C2 backward term or a mis-scaled C1 bucket is an O(1e-1 ... 1) L2 error on every tensor behind it.
+    worst, wname, wmax = 0.0, None, 0.0
+    for name, g in ref["_grads"].items():
+        a = got["g/" + name].reshape(g.shape).astype(np.float64)
+        n2, scale = np.linalg.norm(g), np.abs(g).max()
+        if scale < 1e-9:
+            continue
+        c2 = np.linalg.norm(ref32["_grads"][name].astype(np.float64) - g) / n2
+        e2, emax = np.linalg.norm(a - g) / n2, np.abs(a - g).max() / scale
+        bound = max(5e-3, 5 * c2)
+        if e2 / bound > worst:
+            worst, wname = e2 / bound, name
+        wmax = max(wmax, emax)
+        assert e2 < bound and emax < 5e-2, (prec, name, e2, c2, emax)
+    print("data parallel 2 x 8 images, %s: worst L2 gradient error / bound = %.3f (%s), worst max-norm error %.1e" % (prec, worst, wname, wmax))

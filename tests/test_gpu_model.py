@@ -639,6 +639,13 @@ def test_bench_script_two_ranks_one_gpu(tmp_path):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["config"]["global_batch"] == 512
     assert len(j["repeats_images_per_sec"]) == 2
+    # round 4: the per-collective table of the profiled region (C1 gradient buckets, C2 batch-norm statistics, C3 partials, C4 prior gradients)
+    cm = j["comm"]
+    labels = set(cm["collectives"])
+    assert any(k.startswith("C1") for k in labels) and "C3 partials" in labels and "C4 prior gradients" in labels, labels
+    assert cm["collectives"]["C3 partials"]["calls_per_step"] == 4.0 and cm["wall_ms_per_step"] >= cm["exposed_ms_per_step"] > 0
+    for v in cm["collectives"].values():
+        assert v["wall_us_per_call"] >= v["exposed_us_per_call"] >= 0 and v["bytes_per_call"] > 0
     # ... and refuses to print a number under a label it cannot honour: 8 ranks requested, one GPU visible, no test hook
     env8 = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LADDER_BENCH_SINGLE_DEVICE")}
     if torch.cuda.device_count() < 8:

@@ -190,6 +190,10 @@ GATHER_CASES = [
     (37, 3, 5, 128, 160, 3, 1, "same", None),              # ragged: M = 555, Cout = 128 + 32, K = 1152
     (64, 16, 16, 256, 256, 3, 2, "same", "leaky_relu"),    # encoder conv4: backward-data = 4 parity classes of 4096 pixels, K = 256 ... 1024
     (32, 9, 7, 128, 192, 3, 2, "same", None),              # odd map under stride 2: parity classes of different sizes
+    # round 4: the encoder's deep layers at batch 16 (M = 64 ... 256 pixels: one or two 128-row tiles; the batch of the full-resolution
+    # data-parallel test against the float64 oracle)
+    (16, 8, 8, 256, 512, 3, 2, "same", None),              # encoder conv2d_4: M = 256
+    (32, 4, 4, 512, 512, 3, 1, "valid", None),             # encoder conv2d_5: 4x4 VALID -> 2x2, M = 128 forward / 512 backward-data
 ]
 
 

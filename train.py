@@ -37,8 +37,9 @@ def join_process_group():
         return
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    dist.init_process_group("nccl")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))     # (bound to its GPU at once: no lazy communicator set-up inside the first collective)
 
 
 def wants_training(cfg):
