@@ -306,11 +306,12 @@ def main():
         fl = dict(fl)
         note = "RUN#3/#4 reuse RUN#2's encoder output (bit-identical): 1.23 GFLOP of the algorithmic 41.4 are not executed"
         used = getattr(eng.ctx, "up2_used", {})
-        if used:      # conv2d_7 (4.832 GFLOP / image forward) in RUN#1 + RUN#2, conv2d_6 (2.416) in RUN#2, conv2d_7's backward-data: 11 / 36 not issued
-            per = {"decoder/conv2d_7": 2 * 4.832e9, "decoder/conv2d_6": 2.416e9, "decoder/conv2d_7:bwd": 4.832e9, "decoder/conv2d_6:bwd": 2.416e9}
+        if used:      # conv2d_7 (4.832 GFLOP / image forward) and conv2d_6 (2.416) in RUN#1 (":train") and RUN#2, their backward-data (":bwd"): 11 / 36 not issued
+            per = {"decoder/conv2d_7": 4.832e9, "decoder/conv2d_7:train": 4.832e9, "decoder/conv2d_6": 2.416e9, "decoder/conv2d_6:train": 2.416e9,
+                   "decoder/conv2d_7:bwd": 4.832e9, "decoder/conv2d_6:bwd": 2.416e9, "decoder/conv2d_7:wgrad": 4.832e9, "decoder/conv2d_6:wgrad": 2.416e9}
             fl["executed"] -= sum(v for k, v in per.items() if k in used) * 11.0 / 36.0
-            note += ("; upsample-fused convolutions (%s): the factor-2 resize in front of the layer is folded into its taps (forward and, ':bwd', "
-                     "backward-data), 25 of every 36 low-resolution tap products are issued" % ", ".join(sorted(used)))
+            note += ("; upsample-fused convolutions (%s): the factor-2 resize in front of the layer is folded into its taps (forward, ':bwd' backward-data, "
+                     "':wgrad' filter gradient), 25 of every 36 low-resolution tap products are issued" % ", ".join(sorted(used)))
         return dict(fl, note=note)
 
     head = measure(trainer, args.steps, args.warmup, args.repeats, args.sustained_seconds, not args.no_profile)

@@ -209,6 +209,17 @@ int ladder_conv3x3_up2_bwd_data_split(const float* dy, const float* dy_absmax, c
  * the strip and along the line in one pass; dx_absmax (the record of the main launch) is raised where needed. */
 int ladder_conv3x3_up2_bwd_border(const float* d_up, float* dx, float* dx_absmax, int N, int H, int W, int C, int axis, int first,
                                   ladder_stream_t stream);
+/* Filter gradient of the same pair over the LOW-resolution map (round 4, strict fp32; csrc/convf32.hip): dw [3][3][Cin][Cout] (and db [Cout],
+ * may be NULL) of y = conv3x3_same(resize2x(x), w) from x [N, H, W, Cin] (x_upsampled != 0: x points at the materialised upsample
+ * [N, 2H, 2W, Cin] a training forward keeps, read at its even rows / columns) and dy [N, 2H, 2W, Cout]: per output-parity class the 9 / 6 / 6 / 4
+ * tap tiles G_ab[dr][dc] = sum x~[i+dr-1, j+dc-1] (x) dy[2i+a, 2j+b] (25 instead of the 36 the direct filter gradient on the upsampled map
+ * accumulates), recombined with the tables of filterbank.h, plus the 1x3 / 3x1 filter gradients of the last output row / column.
+ * Replaces ladder_conv2d_bwd_filter on the upsampled tensor (tf.gradients of codes/models.py:554-578 w.r.t. conv2d_6 / conv2d_7 kernels).
+ * W % 32 == 0, Cin % 64 == 0, Cout % 4 == 0, >= 2048 low-resolution 1x32-pixel patches. */
+int ladder_conv3x3_up2_wgrad_eligible(int N, int H, int W, int Cin, int Cout);
+size_t ladder_conv3x3_up2_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int ladder_conv3x3_up2_wgrad(const float* x, int x_upsampled, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
+                             void* ws, size_t ws_bytes, ladder_stream_t stream);
 /* The last output row and column of the call above, recomputed in fp32 from the last row / column of x and the layer's HWIO bank w
  * [3][3][Cin][Cout] (row 2H-1 sees x[H-1] twice -- the resize clamps -- and the zero padding below; two [N*2W, 3 Cin] x [3 Cin, Cout] GEMMs):
  * written to y [N, 2H, 2W, Cout] and / or, through the fused 1x1 projection pw [Cout][pco] + pb, to pout [N, 2H, 2W, pco]; y_absmax (the

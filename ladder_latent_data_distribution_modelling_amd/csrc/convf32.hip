@@ -354,3 +354,442 @@ int conv3x3_f32_launch(const float* x, const float* bank, const float* bias, flo
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Filter gradient of the pair (factor-2 legacy-bilinear resize -> 3x3 / SAME convolution) over the LOW-resolution map (round 4).
+//
+// Forward (filterbank.h, orientation 3): y[2i+a, 2j+b] = sum_{dr,dc} W_eff[a,b][dr,dc] . x~[i+dr-1, j+dc-1] with x~ = the low-resolution x
+// with the signed clamped halo and W_eff[a,b][dr,dc] = sum_{r,s} A_a[dr][r] A_b[dc][s] w[r][s] -- exact on every output pixel but the last
+// row / column.  Hence
+//     dL/dw[r][s] = sum_{a,b} sum_{dr,dc} A_a[dr][r] A_b[dc][s] . G_ab[dr][dc],    G_ab[dr][dc] = sum_{n,i,j} x~[n, i+dr-1, j+dc-1] (x) dy[n, 2i+a, 2j+b]
+// over all output pixels off the last row / column: 9 / 6 / 6 / 4 = 25 tap tiles of Cin x Cout instead of the 36 (4 pixel classes x 9 taps)
+// the direct filter gradient on the upsampled map accumulates -- the same 25 / 36 as the forward.  The last output row / column are a 1x3 /
+// 3x1 convolution of the 1-D upsampled last row / column of x with the taps w[0][s] + w[1][s] / w[r][0] + w[r][1] (convsplit.hip:
+// ladder_conv3x3_up2_edges), so their contribution is a 1x3 / 3x1 filter gradient E_row[s] / E_col[r] added to dw[0][s], dw[1][s] / dw[r][0],
+// dw[r][1].  Kernel = wgrad3x3_halo_kernel's structure (igemm.hip: 12 wavefronts, 64 ci x 128 co slab, 1x32-pixel patches, LDS-DMA staging,
+// double buffered) on ONE parity class per workgroup:
+//   classes (0, b): wavefront -> (filter row dr = 0..2, ci half, co pair); 3 - b column shifts x 2 co blocks = 6 / 4 MFMAs per k-step
+//   (patches are 2 x 32 low-resolution pixels -- the halo overhead halves and one LDS-DMA round trip / barrier carries twice the MFMA work:
+//   conv2d_7 at batch 128 5.8 -> 4.4 ms against 5.3 ms for the direct kernel under rocprofv3; the next patch is staged from inside the MFMA loop)
+//   classes (1, b): rows dr = 1, 2 only -> wavefront -> (dr, ci half, column shift); 4 co blocks = 4 MFMAs per k-step (b = 1: 8 of the
+//                   12 wavefronts, two per SIMD)
+// i.e. 18 / 12 / 12 / 8 MFMA slots per SIMD and k-step against 4 x 18 for the direct kernel = 25 / 36.  The pixel split of a class is sized
+// in proportion to that cost, so all workgroups of a launch run equally long (a fixed class order would hand every shader engine one class:
+// see class_tile in common.h).  The signs of the halo (negated above / left of the map) are applied to the A fragments after the LDS read:
+// the DMA staging cannot negate.
+constexpr int WU_CI = 64, WU_CO = 128, WU_PW = 32, WU_HW = WU_PW + 2;
+#ifndef WU_PH_ROWS
+#define WU_PH_ROWS 2      // rows per staged patch: 2 x 32 pixels halve the halo overhead and double the MFMA work behind one LDS-DMA round trip
+#endif
+constexpr int WU_PH = WU_PH_ROWS, WU_HH = WU_PH + 2;
+constexpr int WU_THREADS = 768, WU_PIX = WU_PH * WU_PW;
+constexpr int WU_XU = WU_HH * WU_HW * (WU_CI / 4), WU_DU = WU_PIX * (WU_CO / 4);           // float4 units per patch: 1632, 1024
+constexpr int WU_XN = (WU_XU + WU_THREADS - 1) / WU_THREADS, WU_DN = (WU_DU + WU_THREADS - 1) / WU_THREADS;   // 3, 2
+constexpr int WU_XF = WU_HH * WU_HW * WU_CI, WU_DF = WU_PIX * WU_CO;                       // floats per buffer
+constexpr int WU_NTAPS[4] = {9, 6, 6, 4}, WU_TAP0[4] = {0, 9, 15, 21};                    // taps per class, first combination index
+
+struct WgradUp2Plan { bool ok; int tiles_ci, tiles_co, ns[4], s0[4], total; };               // splits per class, first workgroup of each class (per slab pair)
+
+template <int CLS>
+__device__ __forceinline__ void wgrad_up2_body(float* __restrict__ lds, const float* __restrict__ x, const float* __restrict__ dy,
+                                               float* __restrict__ out, float* __restrict__ bias_part, const int N, const int H, const int W,
+                                               const int Cin, const int Cout, const int ci0, const int co0, const int split, const int nsplits,
+                                               const int xs) {
+  constexpr int A = CLS >> 1, B = CLS & 1, NS = 3 - B;
+  constexpr bool MODEB = A == 1;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;            // 12 wavefronts
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int Hc = H - A, WP = W / WU_PW;                // (a = 1: the last low-resolution row maps to the last output row: edge path)
+  const int Hg = (Hc + WU_PH - 1) / WU_PH;             // row groups of a patch column
+  const int q_total = N * Hg * WP;
+  const int pps = (q_total + nsplits - 1) / nsplits;
+  const int q0 = split * pps, q1 = min(q_total, q0 + pps);
+  // wavefront -> tiles
+  int dr, cb, sh = 0, njp = 0;
+  bool active = true;
+  if (!MODEB) {
+    dr = wv >> 2; cb = (wv >> 1) & 1; njp = wv & 1;
+  } else if (B == 0) {
+    dr = 1 + wv / 6; cb = (wv % 6) / 3; sh = (wv % 6) % 3;
+  } else {
+    active = wv < 8; dr = 1 + ((wv >> 2) & 1); cb = (wv >> 1) & 1; sh = 1 + (wv & 1);
+  }
+  const int a_off = (dr * WU_HW + lh) * WU_CI + cb * 32 + l31;          // + s * WU_CI (column shift) + 2 ks * WU_CI (pixel)
+  const int b_off = WU_XF + lh * WU_CO + l31;                           // + co block * 32 + 2 ks * WU_CO
+  const bool do_bias = (bias_part != nullptr) && (ci0 == 0) && dr == 1 && cb == 0 && active && (!MODEB || sh == 1);
+  constexpr int NACC = MODEB ? 4 : 6;
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  auto decode = [&](int q, int& n, int& i, int& j0) {            // i = first low-resolution row of the patch
+    n = q / (Hg * WP);
+    const int rem = q - n * (Hg * WP);
+    const int g = rem / WP;
+    i = g * WU_PH;
+    j0 = (rem - g * WP) * WU_PW;
+  };
+  // one staging unit (16 bytes per lane by LDS-DMA) of patch (n, i, j0) into buffer `buf`: units 0 .. WU_XN-1 = input halo, then dY
+  auto stage_unit = [&](int k, int n, int i, int j0, int buf) {
+    float* xb = &lds[buf * (WU_XF + WU_DF)];
+    if (k < WU_XN) {
+      const int u = tid + k * WU_THREADS;
+      if (u < WU_XU) {
+        const int pix = u >> 4, q4 = u & 15;
+        const int hr = pix / WU_HW, hc = pix - hr * WU_HW;
+        const int hs = min(max(i - 1 + hr, 0), H - 1), ws_ = min(max(j0 - 1 + hc, 0), W - 1);      // clamped: always inside the map
+        const float* src = x + (((long)n * (H * xs) + hs * xs) * (W * xs) + ws_ * xs) * Cin + ci0 + q4 * 4;
+        __builtin_amdgcn_global_load_lds(src, xb + u * 4, 16, 0, 0);
+      }
+    } else {
+      const int u = tid + (k - WU_XN) * WU_THREADS;
+      if (u < WU_DU) {
+        const int p = u >> 5, q4 = u & 31;
+        const int jj = j0 + (p & (WU_PW - 1)), ii = i + (p / WU_PW);
+        const bool ok = (co0 + q4 * 4) < Cout && ii < Hc && !(B == 1 && jj == W - 1);                // (a ragged last row group; the last output column: edge path)
+        const float* src = ok ? dy + (((long)n * 2 * H + 2 * ii + A) * 2 * W + 2 * jj + B) * Cout + co0 + q4 * 4 : f32_zero16;
+        __builtin_amdgcn_global_load_lds(src, xb + WU_XF + u * 4, 16, 0, 0);
+      }
+    }
+  };
+  constexpr int NUNITS = WU_XN + WU_DN;
+  static_assert(NUNITS <= WU_PIX / 8, "one staging unit per 4 k-steps");
+
+  if (q0 < q1) {
+    int n, i, j0;
+    decode(q0, n, i, j0);
+#pragma unroll
+    for (int k = 0; k < NUNITS; ++k) stage_unit(k, n, i, j0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int q = q0; q < q1; ++q) {
+    const int buf = (q - q0) & 1;
+    int n, i, j0, nn = 0, ni = 0, nj0 = 0;
+    decode(q, n, i, j0);
+    const bool has_next = q + 1 < q1;
+    if (has_next) decode(q + 1, nn, ni, nj0);
+    // halo signs: the row above the map (dr = 0 at i = 0) and the column left of it (halo column 0 at j0 = 0) are the NEGATED clamped pixels
+    const unsigned rsign0 = (dr == 0 && i == 0) ? 0x80000000u : 0u;   // (first pixel row of the patch only: its dr = 0 tap reads halo row 0)
+    const unsigned csign = (j0 == 0 && lh == 0) ? 0x80000000u : 0u;
+    const float* base = &lds[buf * (WU_XF + WU_DF)];
+    if (active) {
+#pragma unroll 4
+      for (int ks = 0; ks < WU_PIX / 2; ++ks) {
+        // the NEXT patch is staged from inside this loop, one unit every fourth k-step: the address arithmetic of a unit then runs in the
+        // shadow of this wavefront's own MFMAs.  Staged as a block in front of the loop it cost ~5 us per patch during which the matrix pipe of
+        // the compute unit had nothing to do (one workgroup per CU: nobody else fills the gap): 17.6 us per patch against 11 us of MFMA time.
+        if ((ks & 3) == 1 && has_next && (ks >> 2) < NUNITS) stage_unit(ks >> 2, nn, ni, nj0, buf ^ 1);
+        const int arow = ((ks >> 4) * WU_HW + ((2 * ks) & 31)) * WU_CI;     // pixel 2 ks (+ lh) of the patch -> halo row / column
+        const bool col0 = ((2 * ks) & 31) == 0;
+        const unsigned rsign = (ks < 16) ? rsign0 : 0u;
+        if (!MODEB) {
+          float a[3], b[2];
+#pragma unroll
+          for (int s = B; s < 3; ++s) {
+            const unsigned sg = rsign ^ ((col0 && s == 0) ? csign : 0u);
+            a[s] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, base[a_off + s * WU_CI + arow]) ^ sg);
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) b[j] = base[b_off + (njp * 2 + j) * 32 + 2 * ks * WU_CO];
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = B; s < 3; ++s) acc[j * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[j], acc[j * 3 + s], 0, 0, 0);
+          if (do_bias) {
+            bsum[0] += b[0];
+            bsum[1] += b[1];
+          }
+        } else {
+          const unsigned sg = (col0 && sh == 0) ? csign : 0u;                       // (dr >= 1: never the row above the map)
+          const float a = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, base[a_off + sh * WU_CI + arow]) ^ sg);
+          float b[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b[j] = base[b_off + j * 32 + 2 * ks * WU_CO];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], acc[j], 0, 0, 0);
+          if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bsum[j] += b[j];
+          }
+        }
+      }
+    } else if (has_next) {
+#pragma unroll
+      for (int k = 0; k < NUNITS; ++k) stage_unit(k, nn, ni, nj0, buf ^ 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's LDS-DMA pieces of the next patch have landed
+    __syncthreads();
+  }
+
+  if (!active) return;
+  // partial G tiles of this (class, split): out[split][local tap][Cin][Cout] (the class's block of the workspace)
+  float* const o0 = out + (size_t)split * WU_NTAPS[CLS] * Cin * Cout;
+  if (!MODEB) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int nn = co0 + (njp * 2 + j) * 32 + l31;
+#pragma unroll
+      for (int s = B; s < 3; ++s) {
+        float* o = o0 + (size_t)(dr * NS + (s - B)) * Cin * Cout;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int ci = ci0 + cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (nn < Cout) o[(size_t)ci * Cout + nn] = acc[j * 3 + s][e];
+        }
+      }
+      if (do_bias) {
+        const float v = bsum[j] + __shfl_down(bsum[j], 32, 64);   // odd + even pixels of the k-step pairs
+        if (lh == 0 && nn < Cout) bias_part[nn] = v;
+      }
+    }
+  } else {
+    float* o = o0 + (size_t)((dr - 1) * NS + (sh - B)) * Cin * Cout;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nn = co0 + j * 32 + l31;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ci = ci0 + cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (nn < Cout) o[(size_t)ci * Cout + nn] = acc[j][e];
+      }
+      if (do_bias) {
+        const float v = bsum[j] + __shfl_down(bsum[j], 32, 64);
+        if (lh == 0 && nn < Cout) bias_part[nn] = v;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(WU_THREADS, 3) void wgrad3x3_up2_f32_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                         float* __restrict__ out, float* __restrict__ bias_part,
+                                                                         const int N, const int H, const int W, const int Cin, const int Cout,
+                                                                         const WgradUp2Plan p, const int xs) {
+  // ONE LDS object (hipcc serialises LDS-DMA against ds_reads when several __shared__ objects exist): [buf][halo | dY]
+  __shared__ __attribute__((aligned(16))) float lds[2 * (WU_XF + WU_DF)];
+  // workgroup -> (slab pair, class, split of the class): the classes of a pair are laid out one after another
+  const int pair = blockIdx.x / p.total, w = blockIdx.x - pair * p.total;
+  const int cls = w >= p.s0[3] ? 3 : (w >= p.s0[2] ? 2 : (w >= p.s0[1] ? 1 : 0));
+  const int split = w - p.s0[cls];
+  const int ci0 = (pair / p.tiles_co) * WU_CI, co0 = (pair % p.tiles_co) * WU_CO;
+  // class block of the workspace: [class][split][tap][Cin][Cout]; bias partials [workgroup of a co tile with ci0 == 0][Cout]
+  size_t off = 0;
+  for (int c = 0; c < cls; ++c) off += (size_t)p.ns[c] * WU_NTAPS[c];
+  float* o = out + off * Cin * Cout;
+  float* bp = bias_part != nullptr ? bias_part + (size_t)w * Cout : nullptr;
+  switch (cls) {
+    case 0: wgrad_up2_body<0>(lds, x, dy, o, bp, N, H, W, Cin, Cout, ci0, co0, split, p.ns[0], xs); break;
+    case 1: wgrad_up2_body<1>(lds, x, dy, o, bp, N, H, W, Cin, Cout, ci0, co0, split, p.ns[1], xs); break;
+    case 2: wgrad_up2_body<2>(lds, x, dy, o, bp, N, H, W, Cin, Cout, ci0, co0, split, p.ns[2], xs); break;
+    default: wgrad_up2_body<3>(lds, x, dy, o, bp, N, H, W, Cin, Cout, ci0, co0, split, p.ns[3], xs); break;
+  }
+}
+
+// edge operands: the 1-D upsampled last row / column of x (float4 units) and the matching lines of dy (the corner belongs to the row)
+__global__ __launch_bounds__(256) void wgrad_up2_edge_operands_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                      float* __restrict__ u_row, float* __restrict__ v_col,
+                                                                      float* __restrict__ dy_row, float* __restrict__ dy_col, int N, int H, int W,
+                                                                      int Cin, int Cout, int xs) {
+  const int CV = Cin >> 2, DV = Cout >> 2;
+  const long n_row = (long)N * 2 * W * CV, n_col = (long)N * 2 * H * CV, d_row = (long)N * 2 * W * DV, d_col = (long)N * 2 * H * DV;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n_row + n_col + d_row + d_col; t += (long)gridDim.x * 256) {
+    if (t < n_row + n_col) {
+      const bool row = t < n_row;
+      const long j = row ? t : t - n_row;
+      const int L = row ? W : H;
+      const int cv = (int)(j % CV), q = (int)((j / CV) % (2 * L)), n = (int)(j / ((long)CV * 2 * L));
+      const int lo = q >> 1, hi = min(lo + 1, L - 1);
+      const float4* base = reinterpret_cast<const float4*>(row ? x + (((long)n * (H * xs) + (H - 1) * xs) * (W * xs)) * Cin
+                                                               : x + (((long)n * (H * xs)) * (W * xs) + (W - 1) * xs) * Cin) + cv;
+      const long stride = row ? (long)xs * CV : (long)xs * (W * xs) * CV;
+      const float4 xl = base[lo * stride];
+      float4 v = xl;
+      if (q & 1) {                                                // the arithmetic of the resize kernel (lerp, weight 1/2)
+        const float4 xh = base[hi * stride];
+        v = make_float4(xl.x + (xh.x - xl.x) * 0.5f, xl.y + (xh.y - xl.y) * 0.5f, xl.z + (xh.z - xl.z) * 0.5f, xl.w + (xh.w - xl.w) * 0.5f);
+      }
+      reinterpret_cast<float4*>(row ? u_row : v_col)[j] = v;
+    } else {
+      const long j0 = t - n_row - n_col;
+      const bool row = j0 < d_row;
+      const long j = row ? j0 : j0 - d_row;
+      const int L2 = row ? 2 * W : 2 * H;
+      const int cv = (int)(j % DV), q = (int)((j / DV) % L2), n = (int)(j / ((long)DV * L2));
+      const long pix = row ? ((long)n * 2 * H + 2 * H - 1) * 2 * W + q : ((long)n * 2 * H + q) * 2 * W + 2 * W - 1;
+      float4 v = reinterpret_cast<const float4*>(dy)[pix * DV + cv];
+      if (!row && q == 2 * H - 1) v = make_float4(0.f, 0.f, 0.f, 0.f);     // the corner is the row's
+      reinterpret_cast<float4*>(row ? dy_row : dy_col)[j] = v;
+    }
+  }
+}
+
+// dw[r][s] = sum_{a,b,dr,dc} A_a[dr][r] A_b[dc][s] G_ab[dr][dc] + [r < 2] E_row[s] + [s < 2] E_col[r];  G [25][Cin][Cout] (classes 9 | 6 | 6 | 4,
+// taps in (dr, dc) order), E_row [3][Cin][Cout], E_col [3][Cin][Cout]; one thread per (ci, co quad)
+__global__ __launch_bounds__(256) void wgrad_up2_combine_kernel(const float* __restrict__ G, const float* __restrict__ e_row,
+                                                                const float* __restrict__ e_col, float* __restrict__ dw, size_t kn4) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= kn4) return;
+  const float A0[3][3] = {{0.5f, 0.f, 0.f}, {0.5f, 1.f, 0.5f}, {0.f, 0.f, 0.5f}}, A1[3][3] = {{0.f, 0.f, 0.f}, {1.f, 0.5f, 0.f}, {0.f, 0.5f, 1.f}};
+  float4 o[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) o[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int combo = 0;
+#pragma unroll
+  for (int cls = 0; cls < 4; ++cls) {
+    const int a = cls >> 1, b = cls & 1;
+#pragma unroll
+    for (int dr = 0; dr < 3; ++dr)
+#pragma unroll
+      for (int dc = 0; dc < 3; ++dc) {
+        if ((a == 1 && dr == 0) || (b == 1 && dc == 0)) continue;
+        const float4 g = reinterpret_cast<const float4*>(G)[(size_t)combo * kn4 + t];
+        ++combo;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const float ar = a ? A1[dr][r] : A0[dr][r];
+          if (ar == 0.f) continue;
+#pragma unroll
+          for (int s = 0; s < 3; ++s) {
+            const float c = ar * (b ? A1[dc][s] : A0[dc][s]);
+            if (c == 0.f) continue;
+            float4& q = o[r * 3 + s];
+            q.x += c * g.x; q.y += c * g.y; q.z += c * g.z; q.w += c * g.w;
+          }
+        }
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      float4 q = o[r * 3 + s];
+      if (r < 2) { const float4 e = reinterpret_cast<const float4*>(e_row)[(size_t)s * kn4 + t]; q.x += e.x; q.y += e.y; q.z += e.z; q.w += e.w; }
+      if (s < 2) { const float4 e = reinterpret_cast<const float4*>(e_col)[(size_t)r * kn4 + t]; q.x += e.x; q.y += e.y; q.z += e.z; q.w += e.w; }
+      reinterpret_cast<float4*>(dw)[(size_t)(r * 3 + s) * kn4 + t] = q;
+    }
+}
+
+__global__ void wgrad_up2_bias_kernel(const float* __restrict__ db_main, const float* __restrict__ db_row, const float* __restrict__ db_col,
+                                      float* __restrict__ db, int Cout) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < Cout) db[c] = db_main[c] + db_row[c] + db_col[c];
+}
+
+WgradUp2Plan plan_wgrad_up2(int N, int H, int W, int Cin, int Cout) {
+  WgradUp2Plan p{};
+  p.ok = N > 0 && H >= 2 && (W % WU_PW) == 0 && (Cin % WU_CI) == 0 && (Cout % 4) == 0 && Cout >= 64 && (long)N * H * (W / WU_PW) >= 2048;
+  if (!p.ok) return p;
+  p.tiles_ci = Cin / WU_CI;
+  p.tiles_co = (Cout + WU_CO - 1) / WU_CO;
+  const long pairs = (long)p.tiles_ci * p.tiles_co;
+  // two rounds of the chip (one workgroup per CU: 84 KB of LDS), shared between the classes in proportion to their cost per patch (MFMA
+  // slots per SIMD and k-step: 18 / 12 / 12 / 8 -- the busiest SIMD of class 3 still issues 2 wavefronts x 4)
+  long per_pair = 512 / pairs;
+  if (per_pair < 8) per_pair = 8;
+  // measured per-patch time of the classes (2 x 32-pixel patches, one class at a time on the chip): 21.0 / 14.6 / 15.6 / 10.9 us -- the MFMA
+  // time (16.0 / 10.7 / 10.7 / 7.1 us) + ~4-5 us per patch that the direct kernel pays as well (its matrix pipe is 76 % busy); 512 or
+  // 2048 workgroups per launch measure the same
+  const int cost[4] = {210, 146, 156, 109};
+  const long g0 = (H + WU_PH - 1) / WU_PH, g1 = (H - 1 + WU_PH - 1) / WU_PH;          // row groups of the classes a = 0 / a = 1
+  const long q[4] = {(long)N * g0 * (W / WU_PW), (long)N * g0 * (W / WU_PW), (long)N * g1 * (W / WU_PW), (long)N * g1 * (W / WU_PW)};
+  double tot = 0;
+  for (int c = 0; c < 4; ++c) tot += (double)cost[c] * q[c];
+  int used = 0;
+  for (int c = 0; c < 4; ++c) {
+    long s = (long)(per_pair * ((double)cost[c] * q[c] / tot) + 0.5);
+    if (s < 1) s = 1;
+    if (s > q[c]) s = q[c];
+    p.ns[c] = (int)s;
+    p.s0[c] = used;
+    used += (int)s;
+  }
+  p.total = used;
+  return p;
+}
+
+static size_t wu_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" {
+
+int ladder_conv3x3_up2_wgrad_eligible(int N, int H, int W, int Cin, int Cout) {
+  static const bool off = getenv("LADDER_DISABLE_UP2") != nullptr;
+  return (!off && plan_wgrad_up2(N, H, W, Cin, Cout).ok) ? 1 : 0;
+}
+
+size_t ladder_conv3x3_up2_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+  const WgradUp2Plan p = plan_wgrad_up2(N, H, W, Cin, Cout);
+  if (!p.ok) return 0;
+  const size_t kn = (size_t)Cin * Cout;
+  size_t tiles = 0;
+  for (int c = 0; c < 4; ++c) tiles += (size_t)p.ns[c] * WU_NTAPS[c];
+  const size_t mr = (size_t)N * 2 * W, mc = (size_t)N * 2 * H;
+  const size_t g1 = ladder_conv2d_bwd_filter_workspace_bytes(N, 1, 2 * W, Cin, 1, 2 * W, Cout, 1, 3);
+  const size_t g2 = ladder_conv2d_bwd_filter_workspace_bytes(N, 2 * H, 1, Cin, 2 * H, 1, Cout, 3, 1);
+  return wu_align(tiles * kn * 4) + wu_align((size_t)(p.total + 1) * Cout * 4) + wu_align(25 * kn * 4) + 2 * wu_align(3 * kn * 4) + 2 * wu_align((size_t)Cout * 4) +
+         wu_align(mr * Cin * 4) + wu_align(mc * Cin * 4) + wu_align(mr * Cout * 4) + wu_align(mc * Cout * 4) + wu_align(g1 > g2 ? g1 : g2) + 512;
+}
+
+// dw [3][3][Cin][Cout] (and db [Cout], may be NULL) of y = conv3x3_same(resize2x(x), w) from the LOW-resolution x [N, H, W, Cin]
+// (x_upsampled != 0: x points at the materialised upsample [N, 2H, 2W, Cin], read at its even rows / columns) and dy [N, 2H, 2W, Cout].
+int ladder_conv3x3_up2_wgrad(const float* x, int x_upsampled, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
+                             void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  const WgradUp2Plan p = plan_wgrad_up2(N, H, W, Cin, Cout);
+  if (!p.ok) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(x) || !ladder_aligned16(dy) || !ladder_aligned16(dw)) return LADDER_E_ALIGN;
+  if (ws == nullptr || ws_bytes < ladder_conv3x3_up2_wgrad_workspace_bytes(N, H, W, Cin, Cout)) return LADDER_E_WORKSPACE;
+  const size_t kn = (size_t)Cin * Cout;
+  size_t tiles = 0;
+  for (int c = 0; c < 4; ++c) tiles += (size_t)p.ns[c] * WU_NTAPS[c];
+  const size_t mr = (size_t)N * 2 * W, mc = (size_t)N * 2 * H;
+  char* q = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  float* part = (float*)q; q += wu_align(tiles * kn * 4);
+  const int nbias = p.total;                              // bias partials: one row [Cout] per class split (written by its ci0 == 0 workgroups, one per co tile)
+  float* bias_part = (float*)q; q += wu_align((size_t)(nbias + 1) * Cout * 4);
+  float* db_main = bias_part + (size_t)nbias * Cout;
+  float* G = (float*)q; q += wu_align(25 * kn * 4);
+  float* e_row = (float*)q; q += wu_align(3 * kn * 4);
+  float* e_col = (float*)q; q += wu_align(3 * kn * 4);
+  float* db_row = (float*)q; q += wu_align((size_t)Cout * 4);
+  float* db_col = (float*)q; q += wu_align((size_t)Cout * 4);
+  float* u_row = (float*)q; q += wu_align(mr * Cin * 4);
+  float* v_col = (float*)q; q += wu_align(mc * Cin * 4);
+  float* dy_row = (float*)q; q += wu_align(mr * Cout * 4);
+  float* dy_col = (float*)q; q += wu_align(mc * Cout * 4);
+  const size_t g = ws_bytes - (size_t)(q - (char*)ws);
+  const int xs = x_upsampled ? 2 : 1;
+  if (db != nullptr && hipMemsetAsync(bias_part, 0, (size_t)nbias * Cout * 4, stream) != hipSuccess) return LADDER_E_LAUNCH;
+  // bias partial rows: the kernel indexes them by the workgroup's position inside its pair (w) -- pairs with ci0 == 0 are the first tiles_co
+  hipLaunchKernelGGL(wgrad3x3_up2_f32_kernel, dim3(p.tiles_ci * p.tiles_co * p.total), dim3(WU_THREADS), 0, stream, x, dy, part,
+                     db != nullptr ? bias_part : nullptr, N, H, W, Cin, Cout, p, xs);
+  size_t off = 0;
+  for (int c = 0; c < 4; ++c) {                            // G[class taps] = sum over the class's splits (fixed order)
+    const int rc = ladder_reduce_splits(part + off * kn, G + (size_t)WU_TAP0[c] * kn, p.ns[c], (size_t)WU_NTAPS[c] * kn, stream);
+    if (rc != LADDER_OK) return rc;
+    off += (size_t)p.ns[c] * WU_NTAPS[c];
+  }
+  hipLaunchKernelGGL(wgrad_up2_edge_operands_kernel, dim3(1024), dim3(256), 0, stream, x, dy, u_row, v_col, dy_row, dy_col, N, H, W, Cin, Cout, xs);
+  int rc = ladder_conv2d_bwd_filter(u_row, dy_row, e_row, db_row, N, 1, 2 * W, Cin, 1, 2 * W, Cout, 1, 3, 1, 0, 1, q, g, stream);
+  if (rc != LADDER_OK) return rc;
+  rc = ladder_conv2d_bwd_filter(v_col, dy_col, e_col, db_col, N, 2 * H, 1, Cin, 2 * H, 1, Cout, 3, 1, 1, 1, 0, q, g, stream);
+  if (rc != LADDER_OK) return rc;
+  hipLaunchKernelGGL(wgrad_up2_combine_kernel, dim3((unsigned)((kn / 4 + 255) / 256)), dim3(256), 0, stream, (const float*)G, (const float*)e_row,
+                     (const float*)e_col, dw, kn / 4);
+  if (db != nullptr) {
+    rc = ladder_reduce_splits(bias_part, db_main, nbias, (size_t)Cout, stream);
+    if (rc != LADDER_OK) return rc;
+    hipLaunchKernelGGL(wgrad_up2_bias_kernel, dim3((Cout + 255) / 256), dim3(256), 0, stream, (const float*)db_main, (const float*)db_row,
+                       (const float*)db_col, db, Cout);
+  }
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+}  // extern "C"

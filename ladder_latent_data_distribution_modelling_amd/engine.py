@@ -39,6 +39,8 @@ class KernelProfiler:
              9124: "wgrad3x3_split_kernel<f16x3> (64ci x 128co slab x 9 taps, 8 waves x 9 tiles, transposing LDS reads, 3 x MFMA 32x32x16 f16; incl. its split reduction)",
              9122: "wgrad3x3_split_kernel<bf16x3>", 9123: "wgrad3x3_split_kernel<bf16x6>",
              9128: "wgrad3x3_halo_kernel (64ci x 128co slab x 9 taps, 12 waves, LDS-DMA staged 1x32-pixel patches, fp32 MFMA 32x32x2)",
+             9120: "wgrad3x3_up2_f32_kernel + reductions / edge lines (filter gradient of resize x2 -> 3x3 conv over the low-resolution map: 25 of 36 tap tiles, "
+                   "one parity class per workgroup, 12 waves, LDS-DMA staged 1x32-pixel patches, fp32 MFMA 32x32x2)",
              7700: "gmm_logprob_kernel<R> + gmm_sum_kernel (mixture log-prob / responsibilities, lane = component, wave-shuffle logsumexp)"}
     LATENCY_BOUND = (7700,)          # not contraction kernels: reported beside the roofline, never as the dominant MFMA kernel
 
@@ -491,6 +493,7 @@ class Conv2D:
         self._packed = {}      # (transpose_flip, ns) -> [weight version, packed bf16 planes]
         self.group = arch.group_of(name + "/kernel")           # optimiser group whose version stamps the packed images
         self.want_bn_sums, self.bn_sums = False, None          # batch-norm statistics of the output from the conv epilogue (RGB conv)
+        self.x_is_up2 = False                                   # set by forward_up2(keep_y): self.x is a factor-2 legacy-bilinear upsample
 
     def _halo_ok(self, N, H, W, cin, cout):
         """The layer runs on the fused 3x3 halo kernels of the configured precision (strict fp32: csrc/convf32.hip; split formats:
@@ -576,6 +579,7 @@ class Conv2D:
                 L.ACT[self.act], self.ctx.ns, self.ctx.stream)
         _timed(256120 + self.ctx.ns, 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_split_proj", args)
         self.x, self.y = x, y
+        self.x_is_up2 = False
         proj.x, proj.y = y, out
         return out
 
@@ -601,7 +605,8 @@ class Conv2D:
         x_amax = ctx.absmax(src)                                         # (max |upsampled| = max |x|: the resize is a convex combination)
         flops = 2.0 * N * 4 * H * W * 9 * self.cin * self.cout          # the reference's operation count (algorithmic) ...
         executed = flops * 25.0 / 36.0                                   # ... of which 25 / 36 are issued
-        ctx.up2_used[self.name] = ctx.up2_used.get(self.name, 0) + 1
+        ukey = self.name + (":train" if keep_y else "")                   # (bench.py's executed-FLOP model: forward-only / training forward)
+        ctx.up2_used[ukey] = ctx.up2_used.get(ukey, 0) + 1
         wsp, wsn = ctx.ws(L.query("ladder_conv3x3_up2_edges_workspace_bytes", N, H, W, self.cin, self.cout))
         if proj is not None:
             proj.pt = proj.pl = 0
@@ -615,6 +620,7 @@ class Conv2D:
                    L.ACT[self.act], strided, wsp, wsn, ctx.stream)
             self.x_amax = x_amax if keep_y else None
             self.x, self.y = (upsampled, y) if keep_y else (None, None)
+            self.x_is_up2 = bool(keep_y)                                 # x = the factor-2 upsample of a tensor: the filter gradient may read its even sub-grid
             proj.x, proj.y = (y, out) if keep_y else (None, None)
             return out
         y = ctx.empty(N, 2 * H, 2 * W, self.cout)
@@ -627,6 +633,7 @@ class Conv2D:
         ctx.set_amax(y, y_amax)
         self.x_amax = x_amax if keep_y else None
         self.x, self.y = (upsampled, y) if keep_y else (None, None)
+        self.x_is_up2 = bool(keep_y)
         return y
 
     def forward(self, x):
@@ -635,6 +642,7 @@ class Conv2D:
         self.pl, Wo = arch.conv_out(W, self.k, self.stride, self.padding)
         y = self.ctx.empty(N, Ho, Wo, self.cout)
         self.x_amax = None
+        self.x_is_up2 = False
         if self._halo_ok(N, H, W, self.cin, self.cout):
             self.x_amax = self.ctx.absmax(x)
             y_amax = self.ctx.new_amax() if self.ctx.ns == 4 else None
@@ -822,6 +830,15 @@ class Conv2D:
                 L.call("ladder_conv2d_bwd_filter_split", _p(xpl), _p(self.x_amax), _p(dpl), _p(dy_amax), _p(self.ps.g[self.name + "/kernel"]),
                        _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k,
                        self.stride, self.pt, self.pl, self.ctx.ns, wsp, wsn, self.ctx.stream)
+        elif (wgrad and self.ctx.ns == 0 and self.x_is_up2 and self.ctx.up2 >= 2
+              and L.query("ladder_conv3x3_up2_wgrad_eligible", N, H // 2, W // 2, self.cin, self.cout)):
+            # strict fp32, x = resize2x(x_lo): 25 instead of 36 tap tiles, read from the even sub-grid of the kept upsample (csrc/convf32.hip)
+            wsp, wsn = self.ctx.ws(L.query("ladder_conv3x3_up2_wgrad_workspace_bytes", N, H // 2, W // 2, self.cin, self.cout))
+            fl = 2.0 * N * H * W * 9 * self.cin * self.cout
+            self.ctx.up2_used[self.name + ":wgrad"] = self.ctx.up2_used.get(self.name + ":wgrad", 0) + 1
+            _timed(9120, fl, "ladder_conv3x3_up2_wgrad",
+                   (_p(x), 1, _p(dy), _p(self.ps.g[self.name + "/kernel"]), _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, N, H // 2, W // 2,
+                    self.cin, self.cout, wsp, wsn, st), fl * 25.0 / 36.0)
         elif wgrad:
             nb = L.query("ladder_conv2d_bwd_filter_workspace_bytes", N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k)
             wsp, wsn = self.ctx.ws(nb)
@@ -1284,6 +1301,11 @@ class CelebADecoder:
                     if rs is not None:
                         rs.in_shape = tuple(h.shape[:3]) + (conv.cout,)
                     return out
+            if not conv_done and x_lo is not None:
+                # training forward of an inner layer (conv2d_6): h = the resized tensor, kept for this layer's filter gradient / backward-data;
+                # the convolution itself reads the low-resolution tensor (25 of 36 tap products)
+                h = conv.forward_up2(x_lo, keep_y=True, x_for_backward=h)
+                conv_done = True
             if not conv_done:
                 h = conv.forward(h)
             # the resize behind this block folds into the NEXT conv when that one can take the low-resolution tensor (forward-only runs)
@@ -1292,8 +1314,8 @@ class CelebADecoder:
                     and nxt.up2_ok(h.shape[0], h.shape[1], h.shape[2]))
             if norm is not None:
                 style = sty.forward(dlatent)
-                # (training forward: the LAST conv reads the low-resolution tensor, written beside the resized one it keeps for backward)
-                want_lo = (self.ctx.up2 >= 2 and rs is not None and not fold and self.ctx.keep_activations and bi + 2 == len(self.blocks) and self.blocks[bi + 1][2] is None
+                # (training forward: the NEXT conv reads the low-resolution tensor, written beside the resized one it keeps for backward)
+                want_lo = (self.ctx.up2 >= 2 and rs is not None and not fold and self.ctx.keep_activations and nxt is not None
                            and (rs.oh, rs.ow) == (2 * h.shape[1], 2 * h.shape[2]) and nxt.up2_ok(h.shape[0], h.shape[1], h.shape[2]))
                 up = norm.forward_resized(h, style, rs, keep_lowres=want_lo) if (rs is not None and not fold) else None
                 if up is not None:
@@ -1305,7 +1327,12 @@ class CelebADecoder:
                 lowres = True
                 continue
             if rs is not None:
+                # (training forward, un-normalised layer in front of a factor-2 resize -- conv2d_5: its output IS the low-resolution tensor)
+                keep_lo = (norm is None and self.ctx.up2 >= 2 and self.ctx.keep_activations and nxt is not None
+                           and (rs.oh, rs.ow) == (2 * h.shape[1], 2 * h.shape[2]) and nxt.up2_ok(h.shape[0], h.shape[1], h.shape[2]))
+                lo = h
                 h = rs.forward(h)
+                lowres_copy = lo if keep_lo else None
         return self.conv_out.forward(h)
 
     def backward(self, dxhat, need_dz=True):
@@ -1434,7 +1461,8 @@ class LadderEngine:
             raise ValueError("matmul_precision %r: expected one of %s" % (prec, sorted(PRECISIONS)))
         self.ctx.ns = PRECISIONS[prec]
         # 0: off, 1: forward-only runs, 2: also the training forward and the backward-data of the last 3x3 conv, 3: also conv2d_6's backward-data (no gain measured)
-        self.ctx.up2 = int(cfg.get("upsample_fused_convs", 2))
+        # (strict fp32 default 3: with the fp32 MFMA the 11 / 36 of conv2d_6's backward-data outweigh its border strips, +0.5 %; f16x3: no gain, 2)
+        self.ctx.up2 = int(cfg.get("upsample_fused_convs", 3 if prec == "f32" else 2))
         self.precision = prec
         if self.ctx.comm.rank == 0:
             print("Contraction precision (config key matmul_precision): {} -- {}".format(prec, PRECISION_NOTES[prec]))

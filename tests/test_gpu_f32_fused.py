@@ -344,6 +344,7 @@ def test_f32_engine_routes_through_the_fused_kernels_and_agrees_with_the_direct_
     assert p0 == {0} and p1 == {0}, "every halo launch carries prec = LADDER_PREC_F32"
     assert not any("up2" in c for c in tc0 + ec0)
     assert tc1.count("ladder_conv3x3_up2_split_proj") == 1 and "ladder_in_style_fwd_resize2x_keep" in tc1
+    assert tc1.count("ladder_conv3x3_up2_split") == 1       # conv2d_6's training forward reads conv2d_5's output; the resized tensor is kept for its backward
     assert tc1.count("ladder_conv3x3_up2_bwd_data_split") == 1 and tc1.count("ladder_conv3x3_up2_bwd_border") == 4
     assert tc1.count("ladder_conv3x3_s2_bwd_data_split") == 1 and tc0.count("ladder_conv3x3_s2_bwd_data_split") == 1
     assert tc1.count("ladder_resize_bilinear_bwd") == tc0.count("ladder_resize_bilinear_bwd") - 1
@@ -361,3 +362,36 @@ def test_f32_engine_routes_through_the_fused_kernels_and_agrees_with_the_direct_
     # nearly cancelling terms -- dz . eps against the entropy's 1 / sd -- so fp32 rounding differences of the two convolution
     # formulations show amplified there; every other tensor is below 5e-5.  The SAME bar as the f16x3 form of this test.)
     assert worst < 5e-4, (worst, wname)
+
+
+@pytest.mark.parametrize("case", [(64, 32, 32, 64, 128, True, 1), (16, 64, 64, 64, 64, False, 0), (64, 16, 64, 128, 192, True, 1)],
+                         ids=lambda c: "n%d_%dx%d_c%d_co%d_b%d_ups%d" % c)
+def test_f32_up2_filter_gradient_vs_autograd(gpu_ctx, case):
+    """ladder_conv3x3_up2_wgrad: the filter (and bias) gradient of resize x2 -> 3x3 conv from the low-resolution x (or the even sub-grid of the
+    materialised upsample) -- 25 tap tiles recombined with the A tables + the last-row / last-column line gradients -- against float64
+    autograd through resize_bilinear_legacy + conv2d_tf, and against the direct fp32 filter gradient on the upsampled tensor."""
+    L = _lib()
+    N, H, W, Cin, Cout, bias, ups = case
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(H + Cin + Cout)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    dy = rng.standard_normal((N, 2 * H, 2 * W, Cout)).astype(np.float32)
+    wt = torch.zeros(3, 3, Cin, Cout, dtype=torch.float64, requires_grad=True)
+    bt = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    up = O.resize_bilinear_legacy(torch.as_tensor(x, dtype=torch.float64), 2 * H, 2 * W)
+    O.conv2d_tf(up, wt, bt, 1, "same").backward(torch.as_tensor(dy, dtype=torch.float64))
+    assert L.query("ladder_conv3x3_up2_wgrad_eligible", N, H, W, Cin, Cout) == 1
+    xd, dyd = dev(x), dev(dy)
+    upd = dev(O.resize_bilinear_legacy(torch.as_tensor(x), 2 * H, 2 * W).numpy())
+    ws = torch.empty(L.query("ladder_conv3x3_up2_wgrad_workspace_bytes", N, H, W, Cin, Cout), dtype=torch.uint8, device="cuda")
+    dw = torch.full((3, 3, Cin, Cout), float("nan"), device="cuda")
+    db = torch.full((Cout,), float("nan"), device="cuda") if bias else None
+    L.call("ladder_conv3x3_up2_wgrad", p(upd if ups else xd), ups, p(dyd), p(dw), p(db), N, H, W, Cin, Cout, p(ws), ws.numel(), st)
+    close(dw, wt.grad, 3e-6, "dw")
+    if bias:
+        close(db, bt.grad, 3e-6, "db")
+    # the direct filter gradient on the upsampled tensor agrees to rounding
+    ws2 = torch.empty(max(L.query("ladder_conv2d_bwd_filter_workspace_bytes", N, 2 * H, 2 * W, Cin, 2 * H, 2 * W, Cout, 3, 3), 16), dtype=torch.uint8, device="cuda")
+    dw2, db2 = torch.empty_like(dw), torch.empty(Cout, device="cuda")
+    L.call("ladder_conv2d_bwd_filter", p(upd), p(dyd), p(dw2), p(db2), N, 2 * H, 2 * W, Cin, 2 * H, 2 * W, Cout, 3, 3, 1, 1, 1, p(ws2), ws2.numel(), st)
+    close(dw2, wt.grad, 3e-6, "dw (direct)")
