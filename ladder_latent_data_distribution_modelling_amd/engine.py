@@ -494,6 +494,7 @@ class Conv2D:
         self.group = arch.group_of(name + "/kernel")           # optimiser group whose version stamps the packed images
         self.want_bn_sums, self.bn_sums = False, None          # batch-norm statistics of the output from the conv epilogue (RGB conv)
         self.x_is_up2 = False                                   # set by forward_up2(keep_y): self.x is a factor-2 legacy-bilinear upsample
+        self.x_is_lo = False                                    # ... or self.x is the LOW-resolution tensor itself (the upsample was never materialised)
 
     def _halo_ok(self, N, H, W, cin, cout):
         """The layer runs on the fused 3x3 halo kernels of the configured precision (strict fp32: csrc/convf32.hip; split formats:
@@ -579,7 +580,7 @@ class Conv2D:
                 L.ACT[self.act], self.ctx.ns, self.ctx.stream)
         _timed(256120 + self.ctx.ns, 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_split_proj", args)
         self.x, self.y = x, y
-        self.x_is_up2 = False
+        self.x_is_up2 = self.x_is_lo = False
         proj.x, proj.y = y, out
         return out
 
@@ -589,6 +590,12 @@ class Conv2D:
         upsampled tensor).  Forward-only runs use it; a training forward keeps the resized tensor for its backward pass."""
         return bool(self.ctx.up2 and self.ctx.ns in (0, 2, 4) and self.k == 3 and self.stride == 1 and self.padding == "same"
                     and L.query("ladder_conv3x3_up2_split_eligible", N, H, W, self.cin, self.cout, self.ctx.ns))
+
+    def virtual_up2_ok(self, N, H, W):
+        """A training forward may skip materialising the factor-2 upsample of its [N, H, W, cin] input altogether: strict fp32, and forward,
+        backward-data AND filter gradient of this layer all run from the low-resolution tensor (csrc/convf32.hip)."""
+        return bool(self.ctx.ns == 0 and self.ctx.up2 >= 3 and self.up2_ok(N, H, W) and self.up2t_ok(N, H, W)
+                    and L.query("ladder_conv3x3_up2_wgrad_eligible", N, H, W, self.cin, self.cout))
 
     def forward_up2(self, x, proj=None, keep_y=False, x_for_backward=None):
         """conv(resize2x(x)) from the low-resolution x itself; with `proj` the 1x1 output conv rides on the epilogue as in forward_fused_proj.
@@ -619,8 +626,10 @@ class Conv2D:
             L.call("ladder_conv3x3_up2_edges", _p(src), _p(wk), _p(bias), _p(y), None, _p(pw), _p(pb), _p(out), proj.cout, N, H, W, self.cin, self.cout,
                    L.ACT[self.act], strided, wsp, wsn, ctx.stream)
             self.x_amax = x_amax if keep_y else None
-            self.x, self.y = (upsampled, y) if keep_y else (None, None)
-            self.x_is_up2 = bool(keep_y)                                 # x = the factor-2 upsample of a tensor: the filter gradient may read its even sub-grid
+            # (keep_y without a resized tensor: the LOW-resolution tensor is what the backward pass gets -- virtual_up2_ok)
+            self.x, self.y = ((upsampled if upsampled is not None else src), y) if keep_y else (None, None)
+            self.x_is_up2 = bool(keep_y and upsampled is not None)       # x = the factor-2 upsample of a tensor: the filter gradient reads its even sub-grid
+            self.x_is_lo = bool(keep_y and upsampled is None)
             proj.x, proj.y = (y, out) if keep_y else (None, None)
             return out
         y = ctx.empty(N, 2 * H, 2 * W, self.cout)
@@ -632,8 +641,9 @@ class Conv2D:
                L.ACT[self.act], strided, wsp, wsn, ctx.stream)
         ctx.set_amax(y, y_amax)
         self.x_amax = x_amax if keep_y else None
-        self.x, self.y = (upsampled, y) if keep_y else (None, None)
-        self.x_is_up2 = bool(keep_y)
+        self.x, self.y = ((upsampled if upsampled is not None else src), y) if keep_y else (None, None)
+        self.x_is_up2 = bool(keep_y and upsampled is not None)
+        self.x_is_lo = bool(keep_y and upsampled is None)
         return y
 
     def forward(self, x):
@@ -642,7 +652,7 @@ class Conv2D:
         self.pl, Wo = arch.conv_out(W, self.k, self.stride, self.padding)
         y = self.ctx.empty(N, Ho, Wo, self.cout)
         self.x_amax = None
-        self.x_is_up2 = False
+        self.x_is_up2 = self.x_is_lo = False
         if self._halo_ok(N, H, W, self.cin, self.cout):
             self.x_amax = self.ctx.absmax(x)
             y_amax = self.ctx.new_amax() if self.ctx.ns == 4 else None
@@ -763,6 +773,10 @@ class Conv2D:
         `lowres_dx`: x is the factor-2 upsample of a tensor the caller wants the gradient of: return d / d (that tensor) (see _dx_lowres)."""
         x, y = self.x, self.y
         N, H, W, _ = x.shape
+        if self.x_is_lo:                                  # x is the low-resolution tensor: the layer's input is its (never materialised) factor-2 upsample
+            H, W = 2 * H, 2 * W
+            if not lowres_dx and need_dx:
+                raise RuntimeError("%s: only the low-resolution gradient exists for a virtual upsample" % self.name)
         _, Ho, Wo, _ = y.shape
         st = self.ctx.stream
         if self.act is not None and not act_done:
@@ -830,14 +844,14 @@ class Conv2D:
                 L.call("ladder_conv2d_bwd_filter_split", _p(xpl), _p(self.x_amax), _p(dpl), _p(dy_amax), _p(self.ps.g[self.name + "/kernel"]),
                        _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k,
                        self.stride, self.pt, self.pl, self.ctx.ns, wsp, wsn, self.ctx.stream)
-        elif (wgrad and self.ctx.ns == 0 and self.x_is_up2 and self.ctx.up2 >= 2
+        elif (wgrad and self.ctx.ns == 0 and (self.x_is_up2 or self.x_is_lo) and self.ctx.up2 >= 2
               and L.query("ladder_conv3x3_up2_wgrad_eligible", N, H // 2, W // 2, self.cin, self.cout)):
             # strict fp32, x = resize2x(x_lo): 25 instead of 36 tap tiles, read from the even sub-grid of the kept upsample (csrc/convf32.hip)
             wsp, wsn = self.ctx.ws(L.query("ladder_conv3x3_up2_wgrad_workspace_bytes", N, H // 2, W // 2, self.cin, self.cout))
             fl = 2.0 * N * H * W * 9 * self.cin * self.cout
             self.ctx.up2_used[self.name + ":wgrad"] = self.ctx.up2_used.get(self.name + ":wgrad", 0) + 1
             _timed(9120, fl, "ladder_conv3x3_up2_wgrad",
-                   (_p(x), 1, _p(dy), _p(self.ps.g[self.name + "/kernel"]), _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, N, H // 2, W // 2,
+                   (_p(x), 0 if self.x_is_lo else 1, _p(dy), _p(self.ps.g[self.name + "/kernel"]), _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, N, H // 2, W // 2,
                     self.cin, self.cout, wsp, wsn, st), fl * 25.0 / 36.0)
         elif wgrad:
             nb = L.query("ladder_conv2d_bwd_filter_workspace_bytes", N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k)
@@ -1289,11 +1303,12 @@ class CelebADecoder:
                     return conv.forward_up2(h, self.conv_out)
                 h = conv.forward_up2(h)
                 conv_done = True
-            elif bi == len(self.blocks) - 1 and norm is None and (rs is None or (rs.oh, rs.ow) == tuple(h.shape[1:3])):
+            elif bi == len(self.blocks) - 1 and norm is None and (rs is None or h is None or (rs.oh, rs.ow) == tuple(h.shape[1:3])):
                 if x_lo is not None:
-                    # training forward: h = the resized tensor (kept for the backward pass); the convolution reads the low-resolution one
+                    # training forward: h = the resized tensor (kept for the backward pass) -- or None when every consumer of it runs from the
+                    # low-resolution tensor (virtual upsample); the convolution reads the low-resolution one
                     if rs is not None:
-                        rs.in_shape = tuple(h.shape[:3]) + (conv.cout,)
+                        rs.in_shape = (x_lo.shape[0], 2 * x_lo.shape[1], 2 * x_lo.shape[2], conv.cout)
                     return conv.forward_up2(x_lo, self.conv_out, keep_y=True, x_for_backward=h)
                 # the last 3x3 conv feeds the 1x1 output conv directly (its resize is the identity): one fused launch
                 out = conv.forward_fused_proj(h, self.conv_out, keep_y=self.ctx.keep_activations)
@@ -1317,6 +1332,13 @@ class CelebADecoder:
                 # (training forward: the NEXT conv reads the low-resolution tensor, written beside the resized one it keeps for backward)
                 want_lo = (self.ctx.up2 >= 2 and rs is not None and not fold and self.ctx.keep_activations and nxt is not None
                            and (rs.oh, rs.ow) == (2 * h.shape[1], 2 * h.shape[2]) and nxt.up2_ok(h.shape[0], h.shape[1], h.shape[2]))
+                if want_lo and nxt.virtual_up2_ok(h.shape[0], h.shape[1], h.shape[2]):
+                    # the resized tensor has no reader left (the next layer's forward, backward-data and filter gradient all take the
+                    # low-resolution tensor): plain instance norm, no resize, 1/4 of the bytes
+                    rs.in_shape = tuple(h.shape)
+                    lowres_copy = norm.forward(h, style)
+                    h = None
+                    continue
                 up = norm.forward_resized(h, style, rs, keep_lowres=want_lo) if (rs is not None and not fold) else None
                 if up is not None:
                     h = up
@@ -1331,7 +1353,11 @@ class CelebADecoder:
                 keep_lo = (norm is None and self.ctx.up2 >= 2 and self.ctx.keep_activations and nxt is not None
                            and (rs.oh, rs.ow) == (2 * h.shape[1], 2 * h.shape[2]) and nxt.up2_ok(h.shape[0], h.shape[1], h.shape[2]))
                 lo = h
-                h = rs.forward(h)
+                if keep_lo and nxt.virtual_up2_ok(h.shape[0], h.shape[1], h.shape[2]):
+                    rs.in_shape = tuple(h.shape)                 # (virtual upsample: see above)
+                    h = None
+                else:
+                    h = rs.forward(h)
                 lowres_copy = lo if keep_lo else None
         return self.conv_out.forward(h)
 
@@ -1360,10 +1386,11 @@ class CelebADecoder:
                 ddlat = g if ddlat is None else add_(ctx, ddlat, g)
             # the block below ends in a factor-2 resize: this conv's backward-data can return the gradient of the resize's INPUT (conv2d_7, conv2d_6)
             below = self.blocks[len(self.blocks) - 2 - bi] if bi + 1 < len(self.blocks) else None
-            lowres = bool(below is not None and below[3] is not None and conv.x is not None and (bi == 0 or self.ctx.up2 >= 3)
-                          and (below[3].oh, below[3].ow) == tuple(conv.x.shape[1:3]) and conv.x.shape[1] % 2 == 0
-                          and tuple(getattr(below[3], "in_shape", (0, 0, 0))[1:3]) == (conv.x.shape[1] // 2, conv.x.shape[2] // 2)
-                          and conv.up2t_ok(conv.x.shape[0], conv.x.shape[1] // 2, conv.x.shape[2] // 2))
+            lowres = bool(conv.x_is_lo or (
+                below is not None and below[3] is not None and conv.x is not None and (bi == 0 or self.ctx.up2 >= 3)
+                and (below[3].oh, below[3].ow) == tuple(conv.x.shape[1:3]) and conv.x.shape[1] % 2 == 0
+                and tuple(getattr(below[3], "in_shape", (0, 0, 0))[1:3]) == (conv.x.shape[1] // 2, conv.x.shape[2] // 2)
+                and conv.up2t_ok(conv.x.shape[0], conv.x.shape[1] // 2, conv.x.shape[2] // 2)))
             dh = conv.backward(dh, act_done=(bi == 0 and fuse_last) or gated, lowres_dx=lowres)
         dh = self.conv0.backward(self.up0.backward(dh))
         denc = dh.reshape(dh.shape[0], self.nh)

@@ -322,7 +322,7 @@ def test_f32_engine_routes_through_the_fused_kernels_and_agrees_with_the_direct_
 
     monkeypatch.setattr(L, "call", spy)
     res = {}
-    for up2 in (0, 2):
+    for up2 in (0, 2, 3):
         eng = LadderEngine(dict(cfg, upsample_fused_convs=up2), "cuda:0", values=Pm, seed=1)
         assert eng.precision == "f32" and eng.ctx.ns == 0
         eng.set_mixture(*gm)
@@ -357,6 +357,20 @@ def test_f32_engine_routes_through_the_fused_kernels_and_agrees_with_the_direct_
             assert abs(e1[k] - e0[k]) <= 2e-6 * abs(e0[k]) + 1e-7, (k, e1[k], e0[k])
     close(d1, d0, 5e-6, "decoded image")
     worst, wname = _worst_grad(g0, g1)
+    # level 3 (the strict-fp32 default): conv2d_6's pair joins in backward-data and BOTH filter gradients run over the low-resolution maps, so
+    # no reader of the resized tensors is left: they are never materialised (plain instance norm instead of the fused norm + resize, no
+    # 32 -> 64 resize pass), and no resize transpose remains in front of conv2d_6 / conv2d_7
+    f3, g3, e3, d3, tc3, ec3, p3 = res[3]
+    assert tc3.count("ladder_conv3x3_up2_wgrad") == 2 and tc3.count("ladder_conv3x3_up2_bwd_data_split") == 2 and tc3.count("ladder_conv3x3_up2_bwd_border") == 8
+    assert "ladder_in_style_fwd_resize2x_keep" not in tc3 and tc3.count("ladder_resize_bilinear_fwd") == tc0.count("ladder_resize_bilinear_fwd") - 1
+    assert tc3.count("ladder_resize_bilinear_bwd") + tc3.count("ladder_resize_bilinear_bwd_gated") == tc0.count("ladder_resize_bilinear_bwd") + tc0.count("ladder_resize_bilinear_bwd_gated") - 2
+    assert tc1.count("ladder_conv3x3_up2_wgrad") == 2           # (level 2 keeps the resized tensors: the filter gradients read their even sub-grids)
+    for k in ("elbo", "l1_reconstruction_error", "l2_reconstruction_error", "loss_ae", "sigma", "mean_pixel_error"):
+        assert abs(f3[k] - f0[k]) <= 2e-6 * abs(f0[k]) + 1e-7, (k, f3[k], f0[k])
+    close(d3, d0, 5e-6, "decoded image (level 3)")
+    worst3, wname3 = _worst_grad(g0, g3)
+    print("f32 fused (level 3) vs direct: worst relative gradient difference %.2e (%s)" % (worst3, wname3))
+    assert worst3 < 5e-4, (worst3, wname3)
     print("f32 fused vs direct: worst relative gradient difference %.2e (%s)" % (worst, wname))
     # (relative to the tensor's largest element; measured 1.8e-4 on encoder/code_std_dev/kernel, whose gradient is a difference of two
     # nearly cancelling terms -- dz . eps against the entropy's 1 / sd -- so fp32 rounding differences of the two convolution
