@@ -617,7 +617,7 @@ int ladder_vbgmm_shard_mstep(const double* stats, const double* moments, int K, 
 /* HOST function (no device work): CRC-32C (Castagnoli) of host memory, crc = 0 to start, chainable.  Used by the
  * tf.train.Saver checkpoint-v2 reader/writer (codes/base.py:37-85: saver_ae / saver_prior) for block and tensor checksums. */
 uint32_t ladder_crc32c_extend(uint32_t crc, const void* data, size_t n);
-/* out[i] (+)= scale * in[i]. accumulate!=0 adds into out. */
+/* accumulate 0: out[i] = scale * in[i] (in == out: in-place scaling); 1: out[i] += scale * in[i]; 2: out[i] = scale (fill; `in` is not read). */
 int ladder_axpy(const float* in, float* out, size_t n, float scale, int accumulate, ladder_stream_t stream);
 
 #ifdef __cplusplus

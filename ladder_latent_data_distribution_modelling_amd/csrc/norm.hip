@@ -935,7 +935,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
 __global__ void axpy_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n, float scale, int accumulate) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    out[i] = accumulate ? out[i] + scale * in[i] : scale * in[i];
+    out[i] = accumulate == 2 ? scale : (accumulate ? out[i] + scale * in[i] : scale * in[i]);      // 2: fill with `scale` (in is not read)
 }
 
 inline unsigned ew_grid(size_t work_items) {

@@ -463,7 +463,7 @@ class ParamStore:
     def set_lr(self, group, lr):
         """Write the learning rate into the device state (only when it changed; never inside a graph capture)."""
         if self._lr_host[group] != lr:
-            self.adam_state[group][0:1].fill_(float(lr))
+            L.call("ladder_axpy", None, _p(self.adam_state[group]), 1, float(lr), 2, self.ctx.stream)       # (fill: no torch elementwise launch on the path)
             self._lr_host[group] = lr
 
     def adam(self, group, lr, grad=None, n=None):
@@ -499,6 +499,8 @@ class Conv2D:
     def _halo_ok(self, N, H, W, cin, cout):
         """The layer runs on the fused 3x3 halo kernels of the configured precision (strict fp32: csrc/convf32.hip; split formats:
         csrc/convsplit.hip) -- same tiling, same eligibility."""
+        if self.ctx.ns == 0 and os.environ.get("LADDER_DISABLE_HALO") == "1":      # (test switch: the round-1 generic fp32 gather kernels everywhere)
+            return False
         return bool(self.k == 3 and self.stride == 1 and self.padding == "same"
                     and L.query("ladder_conv3x3_split_eligible", N, H, W, cin, cout))
 
@@ -588,6 +590,8 @@ class Conv2D:
         """This layer can take the LOW-resolution tensor [N, H, W, cin] that a factor-2 legacy-bilinear resize would have blown up for it
         (ladder_conv3x3_up2_split: four output-parity classes with effective taps, 25 instead of 36 low-resolution tap products and no
         upsampled tensor).  Forward-only runs use it; a training forward keeps the resized tensor for its backward pass."""
+        if self.ctx.ns == 0 and os.environ.get("LADDER_DISABLE_HALO") == "1":
+            return False
         return bool(self.ctx.up2 and self.ctx.ns in (0, 2, 4) and self.k == 3 and self.stride == 1 and self.padding == "same"
                     and L.query("ladder_conv3x3_up2_split_eligible", N, H, W, self.cin, self.cout, self.ctx.ns))
 
@@ -719,6 +723,8 @@ class Conv2D:
     def up2t_ok(self, N, H, W):
         """The gradient with respect to the LOW-resolution tensor [N, H, W, cin] behind a factor-2 resize in front of this layer can come from
         ONE launch (ladder_conv3x3_up2_bwd_data_split) + border strips, instead of backward-data on the upsampled map + the resize transpose."""
+        if self.ctx.ns == 0 and os.environ.get("LADDER_DISABLE_HALO") == "1":
+            return False
         return bool(self.ctx.up2 >= 2 and self.ctx.ns in (0, 2, 4) and self.k == 3 and self.stride == 1 and self.padding == "same"
                     and L.query("ladder_conv3x3_up2_bwd_data_split_eligible", N, H, W, self.cout, self.cin, self.ctx.ns)
                     and (self.ctx.ns == 0 or all(L.query("ladder_conv2d_bwd_data_split_eligible", *g, 0) for g in (
@@ -737,23 +743,30 @@ class Conv2D:
         dx_amax = ctx.new_amax() if ctx.ns == 4 else None
         flops = 2.0 * N * OH * OW * 9 * self.cin * self.cout
         ctx.up2_used[self.name + ":bwd"] = ctx.up2_used.get(self.name + ":bwd", 0) + 1
-        _timed(256120 + ctx.ns, flops, "ladder_conv3x3_up2_bwd_data_split",
-               (_p(dy), _p(dy_amax), _p(self._packed_filter(4)), _p(dx), _p(dx_amax), N, H, W, self.cout, self.cin, ctx.ns, st), flops * 25.0 / 36.0)
         pk = self._packed_filter(1)
+        pk4 = self._packed_filter(4)
         # border lines: dx row 0 = R(d_up[0] + d_up[1] / 2), row H-1 = R(d_up[2H-3] / 2 + d_up[2H-2] + d_up[2H-1]) with d_up = the plain
         # backward-data (needs dy rows 0..2 resp. 2H-4..2H-1) and R = the resize transpose ALONG the line; columns alike
+        strips = []
         for axis, first in ((1, True), (1, False), (2, True), (2, False)):
             n_dy, n_up = (3, 2) if first else (4, 3)                      # strip widths: dy lines read, d_up lines produced
             O_ = OH if axis == 1 else OW
             sl = slice(0, n_dy) if first else slice(O_ - n_dy, O_)
-            s = (dy[:, sl] if axis == 1 else dy[:, :, sl]).contiguous()
             pad = 1 if first else 2                                        # forward-convolution padding that aligns the strip (see csrc/igemm.hip)
             if axis == 1:
                 geo = (N, n_up, OW, self.cin, n_dy, OW, self.cout, 3, 3, 1, pad, 1)
-                dup = ctx.empty(N, n_up, OW, self.cin)
+                view, s, dup = dy[:, sl], ctx.empty(N, n_dy, OW, self.cout), ctx.empty(N, n_up, OW, self.cin)
             else:
                 geo = (N, OH, n_up, self.cin, OH, n_dy, self.cout, 3, 3, 1, 1, pad)
-                dup = ctx.empty(N, OH, n_up, self.cin)
+                view, s, dup = dy[:, :, sl], ctx.empty(N, OH, n_dy, self.cout), ctx.empty(N, OH, n_up, self.cin)
+            strips.append((axis, first, geo, view, s, dup))
+        # (Round 4 tried the four strips -- 256-384 tiles of the gather kernel each: a quarter of the chip's workgroup slots -- on four side
+        # streams beside each other: 3 125 -> 2 845 img/s.  Every cross-stream dependency drains both queues on this runtime; 18 of them per
+        # iteration cost far more than the 0.5 ms the overlap could save.  They run in a row on the main stream.)
+        _timed(256120 + ctx.ns, flops, "ladder_conv3x3_up2_bwd_data_split",
+               (_p(dy), _p(dy_amax), _p(pk4), _p(dx), _p(dx_amax), N, H, W, self.cout, self.cin, ctx.ns, st), flops * 25.0 / 36.0)
+        for axis, first, geo, view, s, dup in strips:
+            s.copy_(view)
             if ctx.ns == 0:                                                # strict fp32: the gather kernel on the flipped / transposed bank
                 _igemm(ctx, "ladder_conv2d_bwd_data", N * geo[1] * geo[2], self.cout, self.cin, 9 * self.cout, _p(s), _p(pk), _p(dup), *geo, None, 0,
                        conv="skip")
@@ -879,7 +892,7 @@ class Conv2D:
                     self.ctx.ns, st)
             self.ctx.set_amax(dx, dx_amax)
             _timed(256120 + self.ctx.ns, 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_split", args)
-        elif (need_dx and self.ctx.ns in (0, 4) and not gate_prev and self.stride == 2
+        elif (need_dx and self.ctx.ns in (0, 4) and not gate_prev and self.stride == 2 and not (self.ctx.ns == 0 and os.environ.get("LADDER_DISABLE_HALO") == "1")
               and L.query("ladder_conv3x3_s2_bwd_data_split_eligible", N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride,
                           self.pt, self.pl)):
             # 3x3 / stride 2 over a map whose gradient is halo-kernel sized (enc.conv1): the four output-parity classes in ONE launch
@@ -1050,8 +1063,8 @@ class BatchNormAct:
         if dx is not None:
             ctx.set_amax(dx, dx_amax)
         if wgrad and ctx.comm.world > 1:
-            self.ps.g[self.name + "/gamma"].mul_(1.0 / ctx.comm.world)
-            self.ps.g[self.name + "/beta"].mul_(1.0 / ctx.comm.world)
+            for t in (self.ps.g[self.name + "/gamma"], self.ps.g[self.name + "/beta"]):
+                L.call("ladder_axpy", _p(t), _p(t), t.numel(), 1.0 / ctx.comm.world, 0, ctx.stream)
         self.x = None
         return dx
 
@@ -1629,7 +1642,7 @@ class LadderEngine:
         ctx.keep_activations = bool(keep_acts)     # forward-only runs (RUN#2, val_step): fused kernels skip backward-only tensors
         Z, R = self.Z, self.R
         P = self.partials
-        P.zero_()
+        L.call("ladder_axpy", None, _p(P), P.numel(), 0.0, 2, st)
         self._run_calls = 0
         use_mask = bool(use_mask) and not self.hier
         # identity of the minibatch the caller handed in (set by _run; direct callers of forward() are identified by their tensor)
@@ -1918,7 +1931,7 @@ class LadderEngine:
             self.forward(x, noise, use_sg, use_mask, ("dec", "gmm"), reuse_encoder)
             g = self.ps.g["prior/Variable"]
             if use_sg:
-                g.zero_()
+                L.call("ladder_axpy", None, _p(g), g.numel(), 0.0, 2, self.ctx.stream)
             else:
                 g.copy_(self._vamp_backward(wgrad=False, need_input_dx=True))
             self.ctx.comm.allreduce_(self.ps.grad["prior"], "C4 prior gradients")       # C4

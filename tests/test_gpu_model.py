@@ -429,8 +429,10 @@ np.savez(sys.argv[1], fetch=json.dumps(out), **{k.replace("/", "."): v for k, v 
 def test_celeba_full_size_halo_kernels_in_situ(tmp_path):
     """BASELINE configs[2] at full size (nh=512, z=64, K=30, batch 128), the complete training step with the same seeds and the same
     device noise in four builds of the contraction path:
-      f32 generic   every convolution on the fp32 gather kernels (LADDER_DISABLE_HALO=1)          -- the yardstick
-      f32 halo      fp32 LDS-halo conv / filter-gradient kernels (engaged only at this scale)
+      f32 generic   every convolution on the round-1 fp32 gather kernels, batch-norm sums from a separate pass, no fusion
+                    (LADDER_DISABLE_HALO=1, LADDER_DISABLE_BNSTATS=1)                                            -- the yardstick
+      f32 halo      the strict-fp32 DEFAULT of round 4: fp32 LDS-halo kernels incl. the upsample-fused convolutions (forward, backward-data,
+                    filter gradient over the low-resolution maps), fused RGB projection, one-launch stride-2 backward-data, epilogue statistics
       f16x3         the default: split-precision kernels, 2 scaled fp16 planes, 3 MFMAs per product (16-wave halo kernel at this batch)
       bf16x6        split-precision kernels, 3 bf16 planes, 6 MFMAs per product
       f16x3-8wave   f16x3 with the 16x32-pixel halo kernel switched off (LADDER_DISABLE_HALO16=1): the 8-wave kernel at full size
@@ -442,7 +444,7 @@ def test_celeba_full_size_halo_kernels_in_situ(tmp_path):
     script = tmp_path / "halo_worker.py"
     script.write_text(HALO_WORKER % dict(root=root))
     res = {}
-    for tag, env in (("generic", {"LADDER_DISABLE_HALO": "1", "LADDER_TEST_PRECISION": "f32"}), ("halo", {"LADDER_TEST_PRECISION": "f32"}),
+    for tag, env in (("generic", {"LADDER_DISABLE_HALO": "1", "LADDER_DISABLE_BNSTATS": "1", "LADDER_TEST_PRECISION": "f32"}), ("halo", {"LADDER_TEST_PRECISION": "f32"}),
                      ("f16x3", {"LADDER_TEST_PRECISION": "f16x3"}), ("bf16x6", {"LADDER_TEST_PRECISION": "bf16x6"}),
                      ("f16x3-8wave", {"LADDER_TEST_PRECISION": "f16x3", "LADDER_DISABLE_HALO16": "1"})):
         outp = str(tmp_path / (tag + ".npz"))
@@ -453,7 +455,9 @@ def test_celeba_full_size_halo_kernels_in_situ(tmp_path):
     fb = json.loads(str(res["generic"]["fetch"]))
     for tag in ("halo", "f16x3", "bf16x6", "f16x3-8wave"):
         fa = json.loads(str(res[tag]["fetch"]))
-        split = tag != "halo"
+        # (round 4: the fp32 default no longer shares kernels with the yardstick either -- effective taps of the upsample-fused layers are
+        # fp32 sums of the filter taps, the batch-norm sums come from the conv epilogue: another fp32 ROUNDING, the same bars as the split formats)
+        split = True
         for k in SCALARS_RUN1:
             assert np.isfinite(fa["ae"][k]) and _ok(fa["ae"][k], fb["ae"][k], 2e-6, 1e-5), (tag, k, fa["ae"][k], fb["ae"][k])
         # RUN#3 is evaluated AFTER the first Adam step of RUN#1, whose update is lr * g / (|g| + eps): an element whose gradient sits
@@ -951,10 +955,42 @@ def test_async_fetch_equals_blocking_fetch(golden_dir):
             losses.append(tr.train_step_ae(cur_lr=1e-3, batch_data=x))
             tr.train_step_prior(batch_data=x)
             if mode == 1 and it == 1:
-                assert len(tr.code_elbo_train) == 1 and len(tr._pending) == 1      # RUN#3 of this iteration is still in flight
+                # RUN#3 of this iteration is still in flight (and, with the non-blocking flush of round 4, possibly RUN#2's sigma as well)
+                assert len(tr.code_elbo_train) == 1 and len(tr._pending) in (1, 2)
         lp = tr.last_fetch_prior                                                  # (property: flushes)
         assert not tr._pending and len(tr.code_elbo_train) == 4 and len(tr.sigma_train) == 4
         outs.append((losses, list(tr.elbo_train), list(tr.sigma_train), list(tr.code_elbo_train), list(tr.code_inner_sigma_train), lp,
                      {k: v.tobytes() for k, v in tr.engine.ps.to_dict().items()}))
     for o in outs[1:]:
         assert o == outs[0]
+
+
+def test_val_step_after_overlapped_prior_runs_reads_its_own_scalars(golden_dir):
+    """with RUN#3 / RUN#4 on the aux stream the last training run leaves the engine's fetch source pointing at the AUX scalars
+    buffer; evaluate() (val_step, test_step, the Session facade) calls forward() directly and used to fetch those stale aux scalars -- the
+    validation losses were wrong and constant across the validation loop.  Two training iterations, then val_step on two DIFFERENT batches
+    and test_step: every fetched value must equal the run with `overlap_prior_runs: 0`, and the two validation batches must differ."""
+    from ladder_latent_data_distribution_modelling_amd.codes.models import CelebAModel_densenet
+    from ladder_latent_data_distribution_modelling_amd.codes.base import BaseTrain_joint
+    d = np.load(os.path.join(golden_dir, "oracle_celeba.npz"))
+    base = json.loads(str(d["config"]))
+    base.update(checkpoint_dir="/tmp/", result_dir="/tmp/", use_hip_graphs=0)
+    x = torch.as_tensor(d["x"]).cuda()
+    xv = [torch.rand(x.shape, generator=torch.Generator().manual_seed(s_)).cuda() for s_ in (1, 2)]
+    rng = np.random.default_rng(5)
+    nz = [O.make_noise(base, x.shape[0], rng, np.float32) for _ in range(3)]
+    outs = []
+    for overlap in (0, 1):
+        cfg = dict(base, overlap_prior_runs=overlap)
+        tr = BaseTrain_joint(None, CelebAModel_densenet(cfg, device="cuda:0", seed=1), None, cfg)
+        assert tr.engine._aux_on == bool(overlap)
+        tr.cur_epoch = int(cfg["sg_pretraining"]) + 1
+        tr.gm_params = (d["gm_w"], d["gm_m"], d["gm_c"])
+        for _ in range(2):
+            tr.train_step_ae(cur_lr=1e-3, batch_data=x)
+            tr.train_step_prior(batch_data=x)
+        v = [tr.val_step("VAE", xv[0], nz[0]), tr.val_step("VAE", xv[1], nz[1]), tr.val_step("prior", xv[0], nz[0])]
+        t = tr.test_step(xv[1], noise=nz[2])
+        outs.append((v, list(tr.val_loss), list(tr.elbo_val), list(tr.code_elbo_val), list(tr.test_sigma), {k: t[k] for k in ("elbo", "sigma", "elbo_prior")}))
+    assert outs[0] == outs[1]
+    assert outs[1][0][0] != outs[1][0][1]                # two validation batches, two values (the stale buffer returned one value for all)
