@@ -209,6 +209,14 @@ int ladder_conv3x3_up2_bwd_data_split(const float* dy, const float* dy_absmax, c
  * the strip and along the line in one pass; dx_absmax (the record of the main launch) is raised where needed. */
 int ladder_conv3x3_up2_bwd_border(const float* d_up, float* dx, float* dx_absmax, int N, int H, int W, int C, int axis, int first,
                                   ladder_stream_t stream);
+/* Strict fp32 (round 4): the four border lines of ladder_conv3x3_up2_bwd_data_split's dx [N, H, W, Cout] made exact IN PLACE, from ONE d_up line per
+ * border -- exact = main - D_r (x) M_c - M_r (x) D_c + D_r (x) D_c (csrc/convf32.hip): row -1 / 2H-1 and column -1 / 2W-1 of the backward-data of the
+ * zero-padded dy as 1x3 / 2x3 / 3x1 / 3x2-tap convolutions over the first / last lines of dy [N, 2H, 2W, C]; w = the layer's HWIO bank
+ * [3][3][Cout][C].  Replaces the four strip launches + ladder_conv3x3_up2_bwd_border (45 -> 9 line-taps per axis).  Same stream, after the
+ * main launch. */
+size_t ladder_conv3x3_up2_bwd_borders_workspace_bytes(int N, int H, int W, int C, int Cout);
+int ladder_conv3x3_up2_bwd_borders(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int Cout, void* ws, size_t ws_bytes,
+                                   ladder_stream_t stream);
 /* Filter gradient of the same pair over the LOW-resolution map (round 4, strict fp32; csrc/convf32.hip): dw [3][3][Cin][Cout] (and db [Cout],
  * may be NULL) of y = conv3x3_same(resize2x(x), w) from x [N, H, W, Cin] (x_upsampled != 0: x points at the materialised upsample
  * [N, 2H, 2W, Cin] a training forward keeps, read at its even rows / columns) and dy [N, 2H, 2W, Cout]: per output-parity class the 9 / 6 / 6 / 4

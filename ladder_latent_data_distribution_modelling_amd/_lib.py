@@ -131,6 +131,8 @@ PROTOTYPES = {
     "ladder_conv3x3_up2_bwd_data_split_eligible": (_i, [_i] * 6),
     "ladder_conv3x3_up2_bwd_data_split": (_i, [_p] * 5 + [_i] * 6 + [_p]),
     "ladder_conv3x3_up2_bwd_border": (_i, [_p, _p, _p] + [_i] * 6 + [_p]),
+    "ladder_conv3x3_up2_bwd_borders_workspace_bytes": (_z, [_i] * 5),
+    "ladder_conv3x3_up2_bwd_borders": (_i, [_p, _p, _p] + [_i] * 5 + [_p, _z, _p]),
     "ladder_conv3x3_up2_wgrad_eligible": (_i, [_i] * 5),
     "ladder_conv3x3_up2_wgrad_workspace_bytes": (_z, [_i] * 5),
     "ladder_conv3x3_up2_wgrad": (_i, [_p, _i, _p, _p, _p] + [_i] * 5 + [_p, _z, _p]),

@@ -681,6 +681,103 @@ __global__ void wgrad_up2_bias_kernel(const float* __restrict__ db_main, const f
   if (c < Cout) db[c] = db_main[c] + db_row[c] + db_col[c];
 }
 
+// ---- exact border lines of the fused low-resolution backward-data (ladder_conv3x3_up2_bwd_borders) -------------------------------------
+// Per axis the exact transpose of the legacy factor-2 resize is (E v)[p] = v[2p] + v[2p-1] / 2 [p >= 1] + v[2p+1] / 2 [p <= L-2] + v[2L-1] [p = L-1],
+// while the 5x5 / stride-2 correlation of the main launch applies (M v)[p] = v[2p] + v[2p-1] / 2 + v[2p+1] / 2 to the backward-data d_up of
+// the ZERO-PADDED dy on the unbounded grid: M = E + D with (D v)[p] = v[-1] / 2 [p = 0] - v[2L-1] / 2 [p = L-1].  Hence
+//     exact = (M_r - D_r) (x) (M_c - D_c) d_up = main - D_r (x) M_c - M_r (x) D_c + D_r (x) D_c:
+// the correction needs ONE line of d_up per border -- row -1 (a 1x3 correlation of dy row 0 with the taps w[0][.]), row 2H-1 (2x3 taps
+// w[1..2][.] over dy rows 2H-2, 2H-1), column -1 (3x1, w[.][0]) and column 2W-1 (3x2, w[.][1..2]), each on the range [-1, 2L-1] of the other
+// axis -- instead of the 2-3 full lines with all 9 taps the strip path recomputes (45 -> 9 line-taps per axis).
+// operands: the four small banks in forward-convolution layout [KH][KW][C][Cout] (K[a][b] = w[2-a][2-b] restricted to the rows / columns
+// listed) and contiguous copies of the dy lines they read
+__global__ __launch_bounds__(256) void up2_border_operands_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ k_top,
+                                                                  float* __restrict__ k_bot, float* __restrict__ k_left, float* __restrict__ k_right,
+                                                                  float* __restrict__ in_top, float* __restrict__ in_bot, float* __restrict__ in_left,
+                                                                  float* __restrict__ in_right, int N, int H, int W, int C, int Cout) {
+  const long kn = (long)C * Cout, DV = C >> 2;
+  const long n_k = 18 * kn;                                                       // 3 + 6 + 3 + 6 tap matrices
+  const long n_top = (long)N * 2 * W * DV, n_bot = 2 * n_top, n_left = (long)N * 2 * H * DV, n_right = 2 * n_left;
+  const float4* dy4 = reinterpret_cast<const float4*>(dy);
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n_k + n_top + n_bot + n_left + n_right; t += (long)gridDim.x * 256) {
+    if (t < n_k) {
+      const int tap = (int)(t / kn);
+      const long e = t - (long)tap * kn;
+      const int co = (int)(e / Cout), ci = (int)(e - (long)co * Cout);             // bank element [tap][co (dy channel)][ci (dx channel)]
+      int r, sx;
+      float* dst;
+      if (tap < 3) { r = 0; sx = 2 - tap; dst = k_top + (long)tap * kn; }                                          // [1][3]: b = tap
+      else if (tap < 9) { const int a = (tap - 3) / 3, b = (tap - 3) % 3; r = 2 - a; sx = 2 - b; dst = k_bot + (long)(tap - 3) * kn; }      // [2][3]
+      else if (tap < 12) { const int a = tap - 9; r = 2 - a; sx = 0; dst = k_left + (long)a * kn; }                // [3][1]
+      else { const int a = (tap - 12) / 2, b = (tap - 12) % 2; r = 2 - a; sx = 2 - b; dst = k_right + (long)(tap - 12) * kn; }             // [3][2]
+      dst[e] = w[(((long)r * 3 + sx) * Cout + ci) * C + co];                       // w = the layer's HWIO bank [3][3][Cout (its input)][C (its output)]
+    } else {
+      long j = t - n_k;
+      if (j < n_top) {                                                             // dy row 0: [N][1][2W][C]
+        const long cv = j % DV, x_ = (j / DV) % (2 * W), n = j / (DV * 2 * W);
+        reinterpret_cast<float4*>(in_top)[j] = dy4[(((n * 2 * H + 0) * 2 * W) + x_) * DV + cv];
+      } else if ((j -= n_top) < n_bot) {                                           // dy rows 2H-2, 2H-1: [N][2][2W][C]
+        const long cv = j % DV, x_ = (j / DV) % (2 * W), a = (j / (DV * 2 * W)) % 2, n = j / (DV * 2 * W * 2);
+        reinterpret_cast<float4*>(in_bot)[j] = dy4[(((n * 2 * H + 2 * H - 2 + a) * 2 * W) + x_) * DV + cv];
+      } else if ((j -= n_bot) < n_left) {                                          // dy column 0: [N][2H][1][C]
+        const long cv = j % DV, y_ = (j / DV) % (2 * H), n = j / (DV * 2 * H);
+        reinterpret_cast<float4*>(in_left)[j] = dy4[(((n * 2 * H + y_) * 2 * W) + 0) * DV + cv];
+      } else {                                                                     // dy columns 2W-2, 2W-1: [N][2H][2][C]
+        j -= n_left;
+        const long cv = j % DV, b = (j / DV) % 2, y_ = (j / (DV * 2)) % (2 * H), n = j / (DV * 2 * 2 * H);
+        reinterpret_cast<float4*>(in_right)[j] = dy4[(((n * 2 * H + y_) * 2 * W) + 2 * W - 2 + b) * DV + cv];
+      }
+    }
+  }
+}
+
+// dx[border] += - D_r (x) M_c - M_r (x) D_c + D_r (x) D_c from the four d_up lines: rt / rb [N][2W+1][Cout] (index u = t + 1, t = -1 .. 2W-1),
+// cl / cr [N][2H+1][Cout] (index q + 1).  Row threads own the corners; column threads cover i = 1 .. H-2.
+__global__ __launch_bounds__(256) void up2_border_fixup_kernel(const float* __restrict__ rt, const float* __restrict__ rb, const float* __restrict__ cl,
+                                                               const float* __restrict__ cr, float* __restrict__ dx, int N, int H, int W, int Cout) {
+  const int CV = Cout >> 2;
+  const long n_rows = (long)N * 2 * W * CV, n_cols = (long)N * 2 * (H - 2) * CV;
+  const float4* rt4 = reinterpret_cast<const float4*>(rt);
+  const float4* rb4 = reinterpret_cast<const float4*>(rb);
+  const float4* cl4 = reinterpret_cast<const float4*>(cl);
+  const float4* cr4 = reinterpret_cast<const float4*>(cr);
+  auto M = [&](const float4* v, long base, int p) -> float4 {                      // (M v)[p] = v[2p] + v[2p-1] / 2 + v[2p+1] / 2 with index + 1
+    const float4 a = v[base + (long)(2 * p) * CV], b = v[base + (long)(2 * p + 1) * CV], c = v[base + (long)(2 * p + 2) * CV];
+    return make_float4(b.x + 0.5f * (a.x + c.x), b.y + 0.5f * (a.y + c.y), b.z + 0.5f * (a.z + c.z), b.w + 0.5f * (a.w + c.w));
+  };
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n_rows + n_cols; t += (long)gridDim.x * 256) {
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+    long o;
+    if (t < n_rows) {
+      const int cv = (int)(t % CV), j = (int)((t / CV) % W), bot = (int)((t / ((long)CV * W)) % 2), n = (int)(t / ((long)CV * W * 2));
+      const long lb = (long)n * (2 * W + 1) * CV + cv, cb = (long)n * (2 * H + 1) * CV + cv;
+      const float4 m = M(bot ? rb4 : rt4, lb, j);
+      const float sg = bot ? 0.5f : -0.5f;                                         // - D_r (x) M_c: -1/2 M_c(row -1) at p = 0, +1/2 M_c(row 2H-1) at p = H-1
+      d = make_float4(sg * m.x, sg * m.y, sg * m.z, sg * m.w);
+      const int i = bot ? H - 1 : 0;
+      if (j == 0 || j == W - 1) {                                                  // corner: also - M_r (x) D_c and + D_r (x) D_c
+        const float4 mc = M(j == 0 ? cl4 : cr4, cb, i);
+        const float sc = j == 0 ? -0.5f : 0.5f;
+        const float4 q = (bot ? rb4 : rt4)[lb + (long)(j == 0 ? 0 : 2 * W) * CV];
+        const float s3 = ((j == 0) == (bot == 0)) ? 0.25f : -0.25f;               // +1/4 at (0,0) and (H-1,W-1), -1/4 at the other two
+        d = make_float4(d.x + sc * mc.x + s3 * q.x, d.y + sc * mc.y + s3 * q.y, d.z + sc * mc.z + s3 * q.z, d.w + sc * mc.w + s3 * q.w);
+      }
+      o = (((long)n * H + i) * W + j) * CV + cv;
+    } else {
+      const long u = t - n_rows;
+      const int cv = (int)(u % CV), i = 1 + (int)((u / CV) % (H - 2)), right = (int)((u / ((long)CV * (H - 2))) % 2), n = (int)(u / ((long)CV * (H - 2) * 2));
+      const long cb = (long)n * (2 * H + 1) * CV + cv;
+      const float4 m = M(right ? cr4 : cl4, cb, i);
+      const float sg = right ? 0.5f : -0.5f;
+      d = make_float4(sg * m.x, sg * m.y, sg * m.z, sg * m.w);
+      o = (((long)n * H + i) * W + (right ? W - 1 : 0)) * CV + cv;
+    }
+    float4 v = reinterpret_cast<float4*>(dx)[o];
+    v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+    reinterpret_cast<float4*>(dx)[o] = v;
+  }
+}
+
 WgradUp2Plan plan_wgrad_up2(int N, int H, int W, int Cin, int Cout) {
   WgradUp2Plan p{};
   p.ok = N > 0 && H >= 2 && (W % WU_PW) == 0 && (Cin % WU_CI) == 0 && (Cout % 4) == 0 && Cout >= 64 && (long)N * H * (W / WU_PW) >= 2048;
@@ -788,6 +885,62 @@ int ladder_conv3x3_up2_wgrad(const float* x, int x_upsampled, const float* dy, f
     hipLaunchKernelGGL(wgrad_up2_bias_kernel, dim3((Cout + 255) / 256), dim3(256), 0, stream, (const float*)db_main, (const float*)db_row,
                        (const float*)db_col, db, Cout);
   }
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+
+// ---- exact border lines of ladder_conv3x3_up2_bwd_data_split's result (strict fp32) ----------------------------------------------------------
+static size_t up2b_part(size_t n) { return wu_align(n * 4); }
+
+size_t ladder_conv3x3_up2_bwd_borders_workspace_bytes(int N, int H, int W, int C, int Cout) {
+  if (N <= 0 || H < 3 || W < 3 || C <= 0 || Cout <= 0 || (C % 4) != 0 || (Cout % 4) != 0) return 0;
+  const size_t kn = (size_t)C * Cout, lw = (size_t)N * 2 * W, lh = (size_t)N * 2 * H;
+  size_t g = 0;
+  const size_t gs[4] = {ladder_igemm_fwd_workspace_bytes((long)N * (2 * W + 1), 3 * C, Cout), ladder_igemm_fwd_workspace_bytes((long)N * (2 * W + 1), 6 * C, Cout),
+                        ladder_igemm_fwd_workspace_bytes((long)N * (2 * H + 1), 3 * C, Cout), ladder_igemm_fwd_workspace_bytes((long)N * (2 * H + 1), 6 * C, Cout)};
+  for (size_t v : gs) g = v > g ? v : g;
+  return up2b_part(18 * kn) + up2b_part(lw * C) + up2b_part(2 * lw * C) + up2b_part(lh * C) + up2b_part(2 * lh * C) +
+         2 * up2b_part((size_t)N * (2 * W + 1) * Cout) + 2 * up2b_part((size_t)N * (2 * H + 1) * Cout) + wu_align(g) + 512;
+}
+
+// dx [N, H, W, Cout] = the result of ladder_conv3x3_up2_bwd_data_split(dy [N, 2H, 2W, C], ...): its four border lines are made exact IN PLACE
+// (w = the layer's HWIO bank [3][3][Cout][C]).  Must follow that launch on the same stream.
+int ladder_conv3x3_up2_bwd_borders(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int Cout, void* ws, size_t ws_bytes,
+                                   ladder_stream_t stream) {
+  const size_t need = ladder_conv3x3_up2_bwd_borders_workspace_bytes(N, H, W, C, Cout);
+  if (need == 0) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(dy) || !ladder_aligned16(w) || !ladder_aligned16(dx)) return LADDER_E_ALIGN;
+  if (ws == nullptr || ws_bytes < need) return LADDER_E_WORKSPACE;
+  const size_t kn = (size_t)C * Cout, lw = (size_t)N * 2 * W, lh = (size_t)N * 2 * H;
+  char* q = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  float* k_top = (float*)q;
+  float* k_bot = k_top + 3 * kn;
+  float* k_left = k_bot + 6 * kn;
+  float* k_right = k_left + 3 * kn;
+  q += up2b_part(18 * kn);
+  float* in_top = (float*)q; q += up2b_part(lw * C);
+  float* in_bot = (float*)q; q += up2b_part(2 * lw * C);
+  float* in_left = (float*)q; q += up2b_part(lh * C);
+  float* in_right = (float*)q; q += up2b_part(2 * lh * C);
+  float* rt = (float*)q; q += up2b_part((size_t)N * (2 * W + 1) * Cout);
+  float* rb = (float*)q; q += up2b_part((size_t)N * (2 * W + 1) * Cout);
+  float* cl = (float*)q; q += up2b_part((size_t)N * (2 * H + 1) * Cout);
+  float* cr = (float*)q; q += up2b_part((size_t)N * (2 * H + 1) * Cout);
+  const size_t g = ws_bytes - (size_t)(q - (char*)ws);
+  hipLaunchKernelGGL(up2_border_operands_kernel, dim3(1024), dim3(256), 0, stream, dy, w, k_top, k_bot, k_left, k_right, in_top, in_bot, in_left, in_right,
+                     N, H, W, C, Cout);
+  // the four d_up lines as small forward convolutions on the fp32 matrix cores (zero padding supplies the out-of-range taps)
+  int rc = ladder_conv2d_fwd(in_top, k_top, nullptr, rt, N, 1, 2 * W, C, 1, 2 * W + 1, Cout, 1, 3, 1, 0, 2, LADDER_ACT_NONE, q, g, stream);
+  if (rc != LADDER_OK) return rc;
+  rc = ladder_conv2d_fwd(in_bot, k_bot, nullptr, rb, N, 2, 2 * W, C, 1, 2 * W + 1, Cout, 2, 3, 1, 0, 2, LADDER_ACT_NONE, q, g, stream);
+  if (rc != LADDER_OK) return rc;
+  rc = ladder_conv2d_fwd(in_left, k_left, nullptr, cl, N, 2 * H, 1, C, 2 * H + 1, 1, Cout, 3, 1, 1, 2, 0, LADDER_ACT_NONE, q, g, stream);
+  if (rc != LADDER_OK) return rc;
+  rc = ladder_conv2d_fwd(in_right, k_right, nullptr, cr, N, 2 * H, 2, C, 2 * H + 1, 1, Cout, 3, 2, 1, 2, 0, LADDER_ACT_NONE, q, g, stream);
+  if (rc != LADDER_OK) return rc;
+  hipLaunchKernelGGL(up2_border_fixup_kernel, dim3(512), dim3(256), 0, stream, (const float*)rt, (const float*)rb, (const float*)cl, (const float*)cr, dx,
+                     N, H, W, Cout);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

@@ -743,8 +743,16 @@ class Conv2D:
         dx_amax = ctx.new_amax() if ctx.ns == 4 else None
         flops = 2.0 * N * OH * OW * 9 * self.cin * self.cout
         ctx.up2_used[self.name + ":bwd"] = ctx.up2_used.get(self.name + ":bwd", 0) + 1
-        pk = self._packed_filter(1)
         pk4 = self._packed_filter(4)
+        if ctx.ns == 0:
+            # strict fp32: the main launch, then its four border lines made exact in place from ONE d_up line per border (csrc/convf32.hip:
+            # ladder_conv3x3_up2_bwd_borders -- 9 instead of 45 line-taps per axis; the strip path below cost 1.07 ms per iteration)
+            _timed(256120, flops, "ladder_conv3x3_up2_bwd_data_split",
+                   (_p(dy), None, _p(pk4), _p(dx), None, N, H, W, self.cout, self.cin, 0, st), flops * 25.0 / 36.0)
+            wsp, wsn = ctx.ws(L.query("ladder_conv3x3_up2_bwd_borders_workspace_bytes", N, H, W, self.cout, self.cin))
+            L.call("ladder_conv3x3_up2_bwd_borders", _p(dy), _p(self.ps.w[self.name + "/kernel"]), _p(dx), N, H, W, self.cout, self.cin, wsp, wsn, st)
+            return dx
+        pk = self._packed_filter(1)
         # border lines: dx row 0 = R(d_up[0] + d_up[1] / 2), row H-1 = R(d_up[2H-3] / 2 + d_up[2H-2] + d_up[2H-1]) with d_up = the plain
         # backward-data (needs dy rows 0..2 resp. 2H-4..2H-1) and R = the resize transpose ALONG the line; columns alike
         strips = []
@@ -761,20 +769,16 @@ class Conv2D:
                 view, s, dup = dy[:, :, sl], ctx.empty(N, OH, n_dy, self.cout), ctx.empty(N, OH, n_up, self.cin)
             strips.append((axis, first, geo, view, s, dup))
         # (Round 4 tried the four strips -- 256-384 tiles of the gather kernel each: a quarter of the chip's workgroup slots -- on four side
-        # streams beside each other: 3 125 -> 2 845 img/s.  Every cross-stream dependency drains both queues on this runtime; 18 of them per
-        # iteration cost far more than the 0.5 ms the overlap could save.  They run in a row on the main stream.)
+        # streams beside each other in the fp32 build: 3 125 -> 2 845 img/s.  Every cross-stream dependency drains both queues on this runtime;
+        # 18 of them per iteration cost far more than the 0.5 ms the overlap could save.)
         _timed(256120 + ctx.ns, flops, "ladder_conv3x3_up2_bwd_data_split",
                (_p(dy), _p(dy_amax), _p(pk4), _p(dx), _p(dx_amax), N, H, W, self.cout, self.cin, ctx.ns, st), flops * 25.0 / 36.0)
         for axis, first, geo, view, s, dup in strips:
             s.copy_(view)
-            if ctx.ns == 0:                                                # strict fp32: the gather kernel on the flipped / transposed bank
-                _igemm(ctx, "ladder_conv2d_bwd_data", N * geo[1] * geo[2], self.cout, self.cin, 9 * self.cout, _p(s), _p(pk), _p(dup), *geo, None, 0,
-                       conv="skip")
-            else:
-                ctx.set_amax(s, dy_amax)                                   # (a strip of dy: the per-sample record of dy bounds it, no extra pass)
-                s_amax = ctx.absmax(s)
-                wsp, wsn = ctx.ws(L.query("ladder_conv2d_bwd_data_split_workspace_bytes", *geo))
-                L.call("ladder_conv2d_bwd_data_split", _p(ctx.planes(s, self._ps(geo[1], geo[2]))), _p(s_amax), _p(pk), _p(dup), *geo, None, 0, ctx.ns, wsp, wsn, st)
+            ctx.set_amax(s, dy_amax)                                       # (a strip of dy: the per-sample record of dy bounds it, no extra pass)
+            s_amax = ctx.absmax(s)
+            wsp, wsn = ctx.ws(L.query("ladder_conv2d_bwd_data_split_workspace_bytes", *geo))
+            L.call("ladder_conv2d_bwd_data_split", _p(ctx.planes(s, self._ps(geo[1], geo[2]))), _p(s_amax), _p(pk), _p(dup), *geo, None, 0, ctx.ns, wsp, wsn, st)
             L.call("ladder_conv3x3_up2_bwd_border", _p(dup), _p(dx), _p(dx_amax), N, H, W, self.cin, axis, 1 if first else 0, st)
         ctx.set_amax(dx, dx_amax)
         return dx

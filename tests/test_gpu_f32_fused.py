@@ -345,7 +345,7 @@ def test_f32_engine_routes_through_the_fused_kernels_and_agrees_with_the_direct_
     assert not any("up2" in c for c in tc0 + ec0)
     assert tc1.count("ladder_conv3x3_up2_split_proj") == 1 and "ladder_in_style_fwd_resize2x_keep" in tc1
     assert tc1.count("ladder_conv3x3_up2_split") == 1       # conv2d_6's training forward reads conv2d_5's output; the resized tensor is kept for its backward
-    assert tc1.count("ladder_conv3x3_up2_bwd_data_split") == 1 and tc1.count("ladder_conv3x3_up2_bwd_border") == 4
+    assert tc1.count("ladder_conv3x3_up2_bwd_data_split") == 1 and tc1.count("ladder_conv3x3_up2_bwd_borders") == 1 and "ladder_conv3x3_up2_bwd_border" not in tc1
     assert tc1.count("ladder_conv3x3_s2_bwd_data_split") == 1 and tc0.count("ladder_conv3x3_s2_bwd_data_split") == 1
     assert tc1.count("ladder_resize_bilinear_bwd") == tc0.count("ladder_resize_bilinear_bwd") - 1
     assert ec1.count("ladder_conv3x3_up2_split_proj") == 1 and ec1.count("ladder_conv3x3_up2_split") == 1 and ec1.count("ladder_conv3x3_up2_edges") == 2
@@ -361,7 +361,7 @@ def test_f32_engine_routes_through_the_fused_kernels_and_agrees_with_the_direct_
     # no reader of the resized tensors is left: they are never materialised (plain instance norm instead of the fused norm + resize, no
     # 32 -> 64 resize pass), and no resize transpose remains in front of conv2d_6 / conv2d_7
     f3, g3, e3, d3, tc3, ec3, p3 = res[3]
-    assert tc3.count("ladder_conv3x3_up2_wgrad") == 2 and tc3.count("ladder_conv3x3_up2_bwd_data_split") == 2 and tc3.count("ladder_conv3x3_up2_bwd_border") == 8
+    assert tc3.count("ladder_conv3x3_up2_wgrad") == 2 and tc3.count("ladder_conv3x3_up2_bwd_data_split") == 2 and tc3.count("ladder_conv3x3_up2_bwd_borders") == 2
     assert "ladder_in_style_fwd_resize2x_keep" not in tc3 and tc3.count("ladder_resize_bilinear_fwd") == tc0.count("ladder_resize_bilinear_fwd") - 1
     assert tc3.count("ladder_resize_bilinear_bwd") + tc3.count("ladder_resize_bilinear_bwd_gated") == tc0.count("ladder_resize_bilinear_bwd") + tc0.count("ladder_resize_bilinear_bwd_gated") - 2
     assert tc1.count("ladder_conv3x3_up2_wgrad") == 2           # (level 2 keeps the resized tensors: the filter gradients read their even sub-grids)
@@ -409,3 +409,32 @@ def test_f32_up2_filter_gradient_vs_autograd(gpu_ctx, case):
     dw2, db2 = torch.empty_like(dw), torch.empty(Cout, device="cuda")
     L.call("ladder_conv2d_bwd_filter", p(upd), p(dyd), p(dw2), p(db2), N, 2 * H, 2 * W, Cin, 2 * H, 2 * W, Cout, 3, 3, 1, 1, 1, p(ws2), ws2.numel(), st)
     close(dw2, wt.grad, 3e-6, "dw (direct)")
+
+
+@pytest.mark.parametrize("case", [(64, 64, 64, 16, 128), (32, 64, 64, 32, 256), (128, 32, 32, 32, 128)], ids=lambda c: "n%d_%dx%d_c%d_co%d" % c)
+def test_f32_up2_backward_data_with_exact_borders_vs_autograd(gpu_ctx, case):
+    """ladder_conv3x3_up2_bwd_data_split + ladder_conv3x3_up2_bwd_borders (strict fp32): the COMPLETE gradient of resize x2 -> 3x3 conv with respect
+    to the low-resolution input -- interior from the 5x5 / stride-2 correlation, the four border lines corrected in place from one d_up line per
+    border (exact = main - D_r (x) M_c - M_r (x) D_c + D_r (x) D_c) -- against float64 autograd, corners included."""
+    L = _lib()
+    N, H, W, C, Cout = case                            # dy [N, 2H, 2W, C], dx [N, H, W, Cout]
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(C + Cout + H)
+    w = (rng.standard_normal((3, 3, Cout, C)) / np.sqrt(9 * C)).astype(np.float32)
+    dy = rng.standard_normal((N, 2 * H, 2 * W, C)).astype(np.float32)
+    bank = _bank(L, w, 4 * C, Cout, 4, st)
+    dyd, wd = dev(dy), dev(w)
+    dx = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    L.call("ladder_conv3x3_up2_bwd_data_split", p(dyd), None, p(bank), p(dx), None, N, H, W, C, Cout, F32, st)
+    ws = torch.empty(L.query("ladder_conv3x3_up2_bwd_borders_workspace_bytes", N, H, W, C, Cout), dtype=torch.uint8, device="cuda")
+    L.call("ladder_conv3x3_up2_bwd_borders", p(dyd), p(wd), p(dx), N, H, W, C, Cout, p(ws), ws.numel(), st)
+    xz = torch.zeros(N, H, W, Cout, dtype=torch.float64, requires_grad=True)
+    O.conv2d_tf(O.resize_bilinear_legacy(xz, 2 * H, 2 * W), torch.as_tensor(w, dtype=torch.float64), None, 1, "same").backward(torch.as_tensor(dy, dtype=torch.float64))
+    ref = xz.grad.numpy()
+    got = dx.cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    scale = np.abs(ref).max()
+    for name, sl in (("interior", (slice(None), slice(1, -1), slice(1, -1))), ("row 0", (slice(None), 0)), ("row H-1", (slice(None), -1)),
+                     ("column 0", (slice(None), slice(None), 0)), ("column W-1", (slice(None), slice(None), -1))):
+        err = np.abs(got[sl] - ref[sl]).max() / scale
+        assert err < TOL32, (name, err)
