@@ -53,9 +53,14 @@ __global__ __launch_bounds__(FH_THREADS, 2) void conv3x3_halo_f32_kernel(const f
   const int l31 = lane & 31, lh = lane >> 5;
   const int wm = wid >> 1, wn = wid & 1;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt = tile / tiles_n;
-  // class tiles (s2_out 1 / 2 / 3) rotate with the patch index: see class_tile (common.h) for the measurement behind it
-  const int cot = class_tile(tile % tiles_n, mt, tiles_n, UPM != 2 && s2_out != 0), n0 = cot * FH_BN;
+  // cls_loop (bit 8 of s2_out; class launches only): ONE workgroup computes all four class tiles of its patch one after another -- every
+  // workgroup of the launch then carries the same 25 taps per slab (no class mix to balance, whole rounds of the chip) and the index
+  // arithmetic of the patch is done once; the grid is the patch count.  Else one class tile per workgroup, rotated with the patch index
+  // (class_tile, common.h).
+  const int s2_mode = s2_out & 0xff;
+  const bool cls_loop = (s2_out & 0x100) != 0;
+  const int mt = cls_loop ? tile : tile / tiles_n;
+  const int cot_first = cls_loop ? (mt & 3) : class_tile(tile % tiles_n, mt, tiles_n, UPM != 2 && s2_mode != 0);
   const int tw_n = W / FH_W, th_n = H / FH_H;
   const int img = mt / (tw_n * th_n), rem_t = mt - img * (tw_n * th_n);
   const int h0 = (rem_t / tw_n) * FH_H, w0 = (rem_t % tw_n) * FH_W;
@@ -80,13 +85,15 @@ __global__ __launch_bounds__(FH_THREADS, 2) void conv3x3_halo_f32_kernel(const f
     const int hs = up2 ? min(max(hi, 0), H - 1) : hi, ws_ = up2 ? min(max(wi, 0), W - 1) : wi;
     // s2_out 3: x is the even-row / even-column sub-grid of an ALREADY upsampled [N, 2H, 2W, Cin] tensor (up[2i][2j] = x[i][j]);
     // UPM 2: pixel (hi, wi) of class (a, b) is dy[2 hi + a][2 wi + b], the class offset is added per slab
-    const int sm = (UPM == 2 || (UPM == 1 && s2_out == 3)) ? 2 : 1;
+    const int sm = (UPM == 2 || (UPM == 1 && s2_mode == 3)) ? 2 : 1;
     const int cpp = (UPM == 2) ? (Cin >> 2) : Cin;                           // channels per pixel of the tensor behind x
     hsrc[i] = ok ? x + (((long)img * (H * sm) + hs * sm) * (W * sm) + ws_ * sm) * cpp + kq * 4 : nullptr;
     hdst[i] = pix * FH_LDA + kq * 4;
     if (up2 && ((hi < 0) != (wi < 0))) hneg |= 1u << i;
   }
   const int b_kr = tid >> 5, b_nq = tid & 31;                                // 16 rows x 32 float4 = 512 units
+  for (int cc = 0; cc < (cls_loop ? 4 : 1); ++cc) {
+  const int cot = (cot_first + cc) & (cls_loop ? 3 : 0x7fffffff), n0 = cot * FH_BN;
   const bool b_ok = (n0 + b_nq * 4) < Cout;
   const float* bsrc = w + (long)b_kr * Cout + n0 + b_nq * 4;
 
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(FH_THREADS, 2) void conv3x3_halo_f32_kernel(const f
     }
   }
 
-  const int s2o = (UPM == 2) ? 0 : s2_out;                 // (mode 4 writes the plain [N, H, W, Cout] layout)
+  const int s2o = (UPM == 2) ? 0 : s2_mode;                // (mode 4 writes the plain [N, H, W, Cout] layout)
   if (!PROJ) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(FH_THREADS, 2) void conv3x3_halo_f32_kernel(const f
         }
       }
     }
-    return;
+    continue;                                                // (next class of the patch, or done)
   }
   // Transposed accumulators: lane l31 = pixel of the patch row, register e -> channel (e & 3) + 8 (e >> 2) + 4 lh of the 32-channel tile,
   // i.e. four consecutive channels per register quad = one 16-byte store, and the channel sum of the 1x1 projection stays inside the lane.
@@ -266,7 +273,9 @@ __global__ __launch_bounds__(FH_THREADS, 2) void conv3x3_halo_f32_kernel(const f
         for (int o = 0; o < pco; ++o) op[o] = t[o] + (pb != nullptr ? pb[o] : 0.f);
       }
     }
+    __syncthreads();                                         // (the reduction scratch is the halo buffer the next class stages into)
   }
+  }  // class loop
 }
 
 // ---- fp32 banks of the logical filter (filterbank.h) ------------------------------------------------------------------------------
@@ -344,9 +353,13 @@ int conv3x3_f32_launch(const float* x, const float* bank, const float* bias, flo
     return LADDER_E_ALIGN;
   const int tiles_n = (Cout + FH_BN - 1) / FH_BN;
   const int tiles_m = N * (H / FH_H) * (W / FH_W);
-  const dim3 grid(tiles_m * tiles_n), block(FH_THREADS);
+  // class launches: all four class tiles of a patch in one workgroup when the patches alone fill whole rounds of the chip
+  static const int cls_env = getenv("LADDER_CLASS_LOOP") ? atoi(getenv("LADDER_CLASS_LOOP")) : -1;
+  const bool cls_loop = (s2_out >= 1 && s2_out <= 3) && (cls_env >= 0 ? cls_env != 0 : tiles_m >= 512);
+  const dim3 grid(cls_loop ? tiles_m : tiles_m * tiles_n), block(FH_THREADS);
+  const int s2x = s2_out | (cls_loop ? 0x100 : 0);
 #define LADDER_F32_LAUNCH(PROJ_, UPM_) \
-  hipLaunchKernelGGL((conv3x3_halo_f32_kernel<PROJ_, UPM_>), grid, block, 0, stream, x, bank, bias, y, N, H, W, Cin, Cout, act, tiles_n, pw, pb, pout, pco, tap_masks, s2_out)
+  hipLaunchKernelGGL((conv3x3_halo_f32_kernel<PROJ_, UPM_>), grid, block, 0, stream, x, bank, bias, y, N, H, W, Cin, Cout, act, tiles_n, pw, pb, pout, pco, tap_masks, s2x)
   if (s2_out == 4) LADDER_F32_LAUNCH(false, 2);
   else if (s2_out == 2 || s2_out == 3) { if (pout != nullptr) LADDER_F32_LAUNCH(true, 1); else LADDER_F32_LAUNCH(false, 1); }
   else { if (pout != nullptr) LADDER_F32_LAUNCH(true, 0); else LADDER_F32_LAUNCH(false, 0); }
