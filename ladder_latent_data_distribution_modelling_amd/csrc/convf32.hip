@@ -38,7 +38,7 @@ __device__ __attribute__((aligned(16))) float f32_zero16[4] = {0.f, 0.f, 0.f, 0.
 // UPM 0: the halo outside the map is zero; 1: upsample-fused forward (signed clamped halo; s2_out 2 / 3); 2: backward-data of the
 // upsample-fused pair (x = dy [N, 2H, 2W, Cin / 4], input slabs grouped by pixel-parity class; s2_out 4).
 template <bool PROJ, int UPM>
-__global__ __launch_bounds__(FH_THREADS, 2) void conv3x3_halo_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(FH_THREADS, 4) void conv3x3_halo_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                          const float* __restrict__ bias, float* __restrict__ y,
                                                                          const int N, const int H, const int W, const int Cin,
                                                                          const int Cout, const int act, const int tiles_n,
