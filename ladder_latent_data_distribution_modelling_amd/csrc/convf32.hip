@@ -47,6 +47,9 @@ __global__ __launch_bounds__(FH_THREADS, 4) void conv3x3_halo_f32_kernel(const f
                                                                          const unsigned long long tap_masks, const int s2_out) {
   __shared__ float Ah[2][FH_NPIX * FH_LDA];
   __shared__ __attribute__((aligned(16))) float Bh[2][FK * FH_BN];
+  // PROJ: the projection matrix (rows padded to 4 outputs) and the bias of the tile's 128 channels, staged once: the epilogue reads them
+  // as LDS broadcasts (from global memory its 64 dependent 16-byte loads per lane cost ~6 us per tile)
+  __shared__ __attribute__((aligned(16))) float Pw[PROJ ? FH_BN * 4 + FH_BN : 4];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -92,6 +95,12 @@ __global__ __launch_bounds__(FH_THREADS, 4) void conv3x3_halo_f32_kernel(const f
     if (up2 && ((hi < 0) != (wi < 0))) hneg |= 1u << i;
   }
   const int b_kr = tid >> 5, b_nq = tid & 31;                                // 16 rows x 32 float4 = 512 units
+  if (PROJ) {                                                                // (channels of a projecting tile are local: Cout <= 128 or class tiles)
+    const int c = tid >> 2, o = tid & 3;
+    const int cmax = min(Cout, FH_BN);
+    Pw[tid] = (pw != nullptr && c < cmax && o < pco) ? pw[c * pco + o] : 0.f;
+    if (tid < FH_BN) Pw[FH_BN * 4 + tid] = (bias != nullptr && tid < cmax) ? bias[tid] : 0.f;   // (visible after the first barrier of the tap loop)
+  }
   for (int cc = 0; cc < (cls_loop ? 4 : 1); ++cc) {
   const int cot = (cot_first + cc) & (cls_loop ? 3 : 0x7fffffff), n0 = cot * FH_BN;
   const bool b_ok = (n0 + b_nq * 4) < Cout;
@@ -212,6 +221,9 @@ __global__ __launch_bounds__(FH_THREADS, 4) void conv3x3_halo_f32_kernel(const f
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
     for (int o = 0; o < 4; ++o) pacc[mi][o] = 0.f;
+  // (bias quad + four projection rows per channel quad as 16-byte LDS broadcasts: a broadcast still returns 1 KB per instruction, so these
+  // 80 reads per lane, not the 256 FMAs, are what this epilogue costs -- ~2 us per tile; sharing the rows between the lane's two pixel rows
+  // was tried and lost to the spills it caused)
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
@@ -224,25 +236,20 @@ __global__ __launch_bounds__(FH_THREADS, 4) void conv3x3_halo_f32_kernel(const f
       for (int g = 0; g < 4; ++g) {
         const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * lh;
         if (n < Cout) {                                      // Cout % 4 == 0: a channel quad is inside or outside as a whole
-          float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (bias != nullptr) bv = *reinterpret_cast<const float4*>(bias + n - coff);
+          const int nl = n - n0;                             // local channel of the tile
+          const float4 bv = *reinterpret_cast<const float4*>(&Pw[FH_BN * 4 + nl]);
           const float4 v = make_float4(ladder_act_fn(acc[mi][ni][4 * g] + bv.x, act), ladder_act_fn(acc[mi][ni][4 * g + 1] + bv.y, act),
                                        ladder_act_fn(acc[mi][ni][4 * g + 2] + bv.z, act), ladder_act_fn(acc[mi][ni][4 * g + 3] + bv.w, act));
           if (yp != nullptr) *reinterpret_cast<float4*>(yp + n) = v;
-          if (pout != nullptr) {                             // 1x1 projection: pw[Cout][pco], pco <= 4
+          if (pout != nullptr) {                             // 1x1 projection: pw[Cout][pco], pco <= 4 (rows zero-padded to 4 in LDS)
             const float vv[4] = {v.x, v.y, v.z, v.w};
-            if (pco == 3) {                                  // (the RGB output conv) rows n..n+3 = 12 consecutive floats, 16-byte aligned
-              const float4* q = reinterpret_cast<const float4*>(pw + (size_t)(n - coff) * 3);
-              const float4 q0 = q[0], q1 = q[1], q2 = q[2];
-              const float wq[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
 #pragma unroll
-              for (int c4 = 0; c4 < 4; ++c4)
-#pragma unroll
-                for (int o = 0; o < 3; ++o) pacc[mi][o] = fmaf(vv[c4], wq[c4 * 3 + o], pacc[mi][o]);
-            } else {
-#pragma unroll
-              for (int c4 = 0; c4 < 4; ++c4)
-                for (int o = 0; o < pco; ++o) pacc[mi][o] = fmaf(vv[c4], pw[(size_t)(n - coff + c4) * pco + o], pacc[mi][o]);
+            for (int c4 = 0; c4 < 4; ++c4) {
+              const float4 q = *reinterpret_cast<const float4*>(&Pw[(nl + c4) * 4]);
+              pacc[mi][0] = fmaf(vv[c4], q.x, pacc[mi][0]);
+              pacc[mi][1] = fmaf(vv[c4], q.y, pacc[mi][1]);
+              pacc[mi][2] = fmaf(vv[c4], q.z, pacc[mi][2]);
+              pacc[mi][3] = fmaf(vv[c4], q.w, pacc[mi][3]);
             }
           }
         }
