@@ -1765,25 +1765,35 @@ int launch_wgrad(const float* x, const float* dy, float* out, float* bias_part, 
 // of this kernel: 2.0, 111 TF/s; shared-dY assignment: 1.33, 119 TF/s).  Per patch the 3x(32+2) input halo (64 channels, 26 KB)
 // and the 32x128 dY tile (16 KB) are brought into LDS ONCE by LDS-DMA (global_load_lds, no staging registers) and serve all 9
 // taps; the generic kernel streams both operands once per tap.  A fragment = halo shifted by (r,s), lane = ci; B = dY rows.
-constexpr int WH_CI = 64, WH_CO = 128, WH_PH = 1, WH_PW = 32, WH_HW = WH_PW + 2, WH_HH = WH_PH + 2;
-constexpr int WH_THREADS = 768, WH_PIX = WH_PH * WH_PW;
-constexpr int WH_XU = WH_HH * WH_HW * (WH_CI / 4), WH_DU = WH_PIX * (WH_CO / 4);           // float4 units per patch
-constexpr int WH_XN = (WH_XU + WH_THREADS - 1) / WH_THREADS, WH_DN = (WH_DU + WH_THREADS - 1) / WH_THREADS;   // 3, 2
-constexpr int WH_XF = WH_HH * WH_HW * WH_CI, WH_DF = WH_PIX * WH_CO;                       // floats per buffer
+// Patch shapes (round 4): 1 x 32 pixels for maps at least 32 wide; 2 x 16 and 4 x 8 for the 16 x 16 and 8 x 8 decoder maps (the halo of a
+// squarer patch is smaller: 72 / 60 halo pixels per 32 against 102) -- the generic kernel streamed both operands once per tap there
+// (~88 TF against ~125 TF here).  The pixel index of a k-step maps to (row, column) of the patch at compile time (PW is a power of two).
+constexpr int WH_CI = 64, WH_CO = 128, WH_PIX = 32;
+constexpr int WH_THREADS = 768;
+template <int PH, int PW> struct WhGeom {
+  static constexpr int HW = PW + 2, HH = PH + 2;
+  static constexpr int XU = HH * HW * (WH_CI / 4), DU = WH_PIX * (WH_CO / 4);             // float4 units per patch
+  static constexpr int XN = (XU + WH_THREADS - 1) / WH_THREADS, DN = (DU + WH_THREADS - 1) / WH_THREADS;   // 3 (2 for the small patches), 2
+  static constexpr int XF = HH * HW * WH_CI, DF = WH_PIX * WH_CO;                          // floats per buffer
+};
 #ifndef IGEMM_WH_MINW
 #define IGEMM_WH_MINW 3
 #endif
+template <int PH, int PW>
 __global__ __launch_bounds__(WH_THREADS, IGEMM_WH_MINW) void wgrad3x3_halo_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                   float* __restrict__ out, float* __restrict__ bias_part,
                                                                   const int N, const int H, const int W, const int Cin,
                                                                   const int Cout, const int tiles_co, const int patches_per_split) {
+  using G = WhGeom<PH, PW>;
+  static_assert(PH * PW == WH_PIX && (PW & (PW - 1)) == 0 && (PW % 2) == 0, "32-pixel patches, rows of a power of two");
+  constexpr int WH_HW = G::HW, WH_XF = G::XF, WH_DF = G::DF;
   // ONE LDS object (hipcc serialises LDS-DMA against ds_reads when several __shared__ objects exist): [buf][halo | dY]
   __shared__ __attribute__((aligned(16))) float lds[2 * (WH_XF + WH_DF)];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;            // 12 wavefronts
   const int l31 = lane & 31, lh = lane >> 5;
   const int ci0 = (blockIdx.x / tiles_co) * WH_CI, co0 = (blockIdx.x % tiles_co) * WH_CO;
-  const int WP = W / WH_PW, HP = H / WH_PH;
+  const int WP = W / PW, HP = H / PH;
   const int q_total = N * HP * WP;
   const int q0 = blockIdx.y * patches_per_split, q1 = min(q_total, q0 + patches_per_split);
   const int r = wv >> 2, cb = (wv >> 1) & 1, njp = wv & 1;
@@ -1801,13 +1811,13 @@ __global__ __launch_bounds__(WH_THREADS, IGEMM_WH_MINW) void wgrad3x3_halo_kerne
 
   auto stage_patch = [&](int q, int buf) {
     const int n = q / (HP * WP), rem = q - n * (HP * WP);
-    const int hp = rem / WP, h0 = hp * WH_PH, w0 = (rem - hp * WP) * WH_PW;
+    const int hp = rem / WP, h0 = hp * PH, w0 = (rem - hp * WP) * PW;
     float* xb = &lds[buf * (WH_XF + WH_DF)];
     float* db = xb + WH_XF;
 #pragma unroll
-    for (int i = 0; i < WH_XN; ++i) {
+    for (int i = 0; i < G::XN; ++i) {
       const int u = tid + i * WH_THREADS;
-      if (u < WH_XU) {
+      if (u < G::XU) {
         const int pix = u >> 4, q4 = u & 15;
         const int hr = pix / WH_HW, hc = pix - hr * WH_HW;
         const int hi = h0 - 1 + hr, wi = w0 - 1 + hc;
@@ -1817,12 +1827,12 @@ __global__ __launch_bounds__(WH_THREADS, IGEMM_WH_MINW) void wgrad3x3_halo_kerne
       }
     }
 #pragma unroll
-    for (int i = 0; i < WH_DN; ++i) {
+    for (int i = 0; i < G::DN; ++i) {
       const int u = tid + i * WH_THREADS;
-      if (u < WH_DU) {
+      if (u < G::DU) {
         const int p = u >> 5, q4 = u & 31;
         const bool ok = (co0 + q4 * 4) < Cout;
-        const float* src = ok ? dy + (((long)n * H + h0 + (p >> 5)) * W + w0 + (p & 31)) * Cout + co0 + q4 * 4 : g_zero16;
+        const float* src = ok ? dy + (((long)n * H + h0 + p / PW) * W + w0 + (p & (PW - 1))) * Cout + co0 + q4 * 4 : g_zero16;
         __builtin_amdgcn_global_load_lds(src, db + u * 4, 16, 0, 0);
       }
     }
@@ -1838,7 +1848,7 @@ __global__ __launch_bounds__(WH_THREADS, IGEMM_WH_MINW) void wgrad3x3_halo_kerne
 #pragma unroll 4
     for (int ks = 0; ks < WH_PIX / 2; ++ks) {
       float a[3], b[2];
-      const int arow = ((ks >> 4) * WH_HW + ((2 * ks) & 31)) * WH_CI;     // pixel 2ks(+lh) of the patch -> halo row/col
+      const int arow = (((2 * ks) / PW) * WH_HW + ((2 * ks) & (PW - 1))) * WH_CI;     // pixel 2ks(+lh) of the patch -> halo row/col
 #pragma unroll
       for (int s = 0; s < 3; ++s) a[s] = base[a_off + s * WH_CI + arow];
 #pragma unroll
@@ -1875,20 +1885,23 @@ __global__ __launch_bounds__(WH_THREADS, IGEMM_WH_MINW) void wgrad3x3_halo_kerne
   }
 }
 
-struct WgradHaloPlan { bool ok; int tiles_ci, tiles_co, splits, pps; };
+struct WgradHaloPlan { bool ok; int tiles_ci, tiles_co, splits, pps, pw; };    // pw: patch width 32 / 16 / 8 (patch = 32 / pw rows)
 WgradHaloPlan plan_wgrad_halo(const IgemmDesc& d) {
-  WgradHaloPlan p{false, 0, 0, 1, 0};
+  WgradHaloPlan p{false, 0, 0, 1, 0, 0};
   if (halo_disabled()) return p;
 #if IGEMM_HALO
+  static const int small_env = getenv("LADDER_WGRAD_SMALL_PATCHES") ? atoi(getenv("LADDER_WGRAD_SMALL_PATCHES")) : 1;   // (test switch)
+  const int pw = (d.W % 32) == 0 ? 32 : (small_env && d.W == 16 && (d.H % 2) == 0) ? 16 : (small_env && d.W == 8 && (d.H % 4) == 0) ? 8 : 0;
   if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.ups == 1 && d.pad_t == 1 && d.pad_l == 1 && d.Ho == d.H && d.Wo == d.W &&
-        (d.Cin % WH_CI) == 0 && (d.Cout % 4) == 0 && d.Cout >= 64 && (d.W % WH_PW) == 0 && (d.H % WH_PH) == 0))
+        (d.Cin % WH_CI) == 0 && (d.Cout % 4) == 0 && d.Cout >= 64 && pw != 0))
     return p;
-  const long q_total = (long)d.N * (d.H / WH_PH) * (d.W / WH_PW);
-  if (q_total * WH_PH < 4096) return p;                       // small maps stay on the generic kernel
+  const long q_total = (long)d.N * d.H * d.W / WH_PIX;
+  if (pw == 32 ? q_total < 4096 : q_total * (d.Cin / WH_CI) * ((d.Cout + WH_CO - 1) / WH_CO) < 4096) return p;   // small launches stay on the generic kernel
+  p.pw = pw;
   p.tiles_ci = d.Cin / WH_CI;
   p.tiles_co = (d.Cout + WH_CO - 1) / WH_CO;
   const long pairs = (long)p.tiles_ci * p.tiles_co;
-  long s = (IGEMM_WH_BLOCKS * 256L) / pairs;          // whole rounds of the chip
+  long s = ((pw < 32 ? 1 : IGEMM_WH_BLOCKS) * 256L) / pairs;   // whole rounds of the chip (small maps: one -- 690 / 718 / 765 / 792 us for 1 ... 4 rounds on 16x16 512 -> 256 at batch 128: the partial tiles cost more than the tail)
   if (s > q_total / 16) s = q_total / 16;
   if (s < 1) s = 1;
   p.pps = (int)((q_total + s - 1) / s);
@@ -1923,8 +1936,10 @@ int run_wgrad(const float* x, const float* dy, float* dw, float* db, const Igemm
     const size_t kn = (size_t)d.K * d.Cout;
     float* out = hp.splits > 1 ? (float*)ws : dw;
     float* bias_part = db != nullptr ? (float*)ws + (hp.splits > 1 ? (size_t)hp.splits * kn : 0) : nullptr;
-    hipLaunchKernelGGL(wgrad3x3_halo_kernel, dim3(hp.tiles_ci * hp.tiles_co, hp.splits), dim3(WH_THREADS), 0, st, x, dy, out, bias_part,
-                       d.N, d.H, d.W, d.Cin, d.Cout, hp.tiles_co, hp.pps);
+    const dim3 grid(hp.tiles_ci * hp.tiles_co, hp.splits), block(WH_THREADS);
+    if (hp.pw == 32) hipLaunchKernelGGL((wgrad3x3_halo_kernel<1, 32>), grid, block, 0, st, x, dy, out, bias_part, d.N, d.H, d.W, d.Cin, d.Cout, hp.tiles_co, hp.pps);
+    else if (hp.pw == 16) hipLaunchKernelGGL((wgrad3x3_halo_kernel<2, 16>), grid, block, 0, st, x, dy, out, bias_part, d.N, d.H, d.W, d.Cin, d.Cout, hp.tiles_co, hp.pps);
+    else hipLaunchKernelGGL((wgrad3x3_halo_kernel<4, 8>), grid, block, 0, st, x, dy, out, bias_part, d.N, d.H, d.W, d.Cin, d.Cout, hp.tiles_co, hp.pps);
     if (hp.splits > 1)
       launch_reduce_splits((const float*)ws, dw, hp.splits, kn, st);
     if (db != nullptr)

@@ -73,6 +73,8 @@ CONV_CASES = [
     (8, 128, 128, 64, 160, 3, 1, "same", "leaky_relu"),  # halo filter-gradient kernel: Cout edge (second 128-block has 32 channels)
     (32, 64, 64, 128, 64, 3, 1, "same", None),         # halo filter-gradient kernel: 2 ci slabs, Cout = 64 (half a channel pair idle)
     (32, 64, 64, 32, 128, 3, 1, "same", None),         # Cin = 32: halo forward / backward-data, generic filter gradient
+    (32, 16, 16, 512, 160, 3, 1, "same", None),        # halo filter gradient on 2 x 16-pixel patches (16-wide maps), Cout edge
+    (64, 8, 8, 512, 512, 3, 1, "same", "leaky_relu"),  # halo filter gradient on 4 x 8-pixel patches (8-wide maps)
 ]
 
 
