@@ -1770,21 +1770,25 @@ int launch_wgrad(const float* x, const float* dy, float* out, float* bias_part, 
 // (~88 TF against ~125 TF here).  The pixel index of a k-step maps to (row, column) of the patch at compile time (PW is a power of two).
 constexpr int WH_CI = 64, WH_CO = 128, WH_PIX = 32;
 constexpr int WH_THREADS = 768;
-template <int PH, int PW> struct WhGeom {
-  static constexpr int HW = PW + 2, HH = PH + 2;
+// Stride 2 (S = 2; SAME padding of an even map = one zero line below / right, none above / left): the input footprint of a patch is
+// (2 PH + 1) x (2 PW + 1) pixels, tap (r, s) of output pixel (i, j) reads footprint pixel (2 i + r, 2 j + s) -- the same kernel with a
+// pixel stride of 2 in the fragment addresses (encoder conv2d_1 ... 3: 522 / 251 / 138 us on the generic kernel at batch 128).
+template <int PH, int PW, int S> struct WhGeom {
+  static constexpr int HW = S * PW + 3 - S, HH = S * PH + 3 - S;
   static constexpr int XU = HH * HW * (WH_CI / 4), DU = WH_PIX * (WH_CO / 4);             // float4 units per patch
-  static constexpr int XN = (XU + WH_THREADS - 1) / WH_THREADS, DN = (DU + WH_THREADS - 1) / WH_THREADS;   // 3 (2 for the small patches), 2
+  static constexpr int XN = (XU + WH_THREADS - 1) / WH_THREADS, DN = (DU + WH_THREADS - 1) / WH_THREADS;   // 3 (2 for the small patches; 5 / 4 / 4 at stride 2), 2
   static constexpr int XF = HH * HW * WH_CI, DF = WH_PIX * WH_CO;                          // floats per buffer
 };
 #ifndef IGEMM_WH_MINW
 #define IGEMM_WH_MINW 3
 #endif
-template <int PH, int PW>
+template <int PH, int PW, int S>
 __global__ __launch_bounds__(WH_THREADS, IGEMM_WH_MINW) void wgrad3x3_halo_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                   float* __restrict__ out, float* __restrict__ bias_part,
                                                                   const int N, const int H, const int W, const int Cin,
                                                                   const int Cout, const int tiles_co, const int patches_per_split) {
-  using G = WhGeom<PH, PW>;
+  // H, W: the OUTPUT map (= the input map at stride 1; the input map is S H x S W)
+  using G = WhGeom<PH, PW, S>;
   static_assert(PH * PW == WH_PIX && (PW & (PW - 1)) == 0 && (PW % 2) == 0, "32-pixel patches, rows of a power of two");
   constexpr int WH_HW = G::HW, WH_XF = G::XF, WH_DF = G::DF;
   // ONE LDS object (hipcc serialises LDS-DMA against ds_reads when several __shared__ objects exist): [buf][halo | dY]
@@ -1797,7 +1801,7 @@ __global__ __launch_bounds__(WH_THREADS, IGEMM_WH_MINW) void wgrad3x3_halo_kerne
   const int q_total = N * HP * WP;
   const int q0 = blockIdx.y * patches_per_split, q1 = min(q_total, q0 + patches_per_split);
   const int r = wv >> 2, cb = (wv >> 1) & 1, njp = wv & 1;
-  const int a_off = (r * WH_HW + lh) * WH_CI + cb * 32 + l31;          // + s * WH_CI for the column shift s
+  const int a_off = (r * WH_HW + S * lh) * WH_CI + cb * 32 + l31;      // + s * WH_CI for the column shift s
   const int b_off = WH_XF + lh * WH_CO + njp * 64 + l31;               // + j * 32 for the second block of the pair
   // bias: the centre-tap tiles (r = 1, s = 1) of the cb = 0 wavefronts cover every output channel exactly once.
   const bool do_bias = (bias_part != nullptr) && (ci0 == 0) && r == 1 && cb == 0;
@@ -1820,9 +1824,9 @@ __global__ __launch_bounds__(WH_THREADS, IGEMM_WH_MINW) void wgrad3x3_halo_kerne
       if (u < G::XU) {
         const int pix = u >> 4, q4 = u & 15;
         const int hr = pix / WH_HW, hc = pix - hr * WH_HW;
-        const int hi = h0 - 1 + hr, wi = w0 - 1 + hc;
-        const bool ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
-        const float* src = ok ? x + (((long)n * H + hi) * W + wi) * Cin + ci0 + q4 * 4 : g_zero16;
+        const int hi = S * h0 - (2 - S) + hr, wi = S * w0 - (2 - S) + hc;
+        const bool ok = hi >= 0 && hi < S * H && wi >= 0 && wi < S * W;
+        const float* src = ok ? x + (((long)n * (S * H) + hi) * (S * W) + wi) * Cin + ci0 + q4 * 4 : g_zero16;
         __builtin_amdgcn_global_load_lds(src, xb + u * 4, 16, 0, 0);
       }
     }
@@ -1848,7 +1852,7 @@ __global__ __launch_bounds__(WH_THREADS, IGEMM_WH_MINW) void wgrad3x3_halo_kerne
 #pragma unroll 4
     for (int ks = 0; ks < WH_PIX / 2; ++ks) {
       float a[3], b[2];
-      const int arow = (((2 * ks) / PW) * WH_HW + ((2 * ks) & (PW - 1))) * WH_CI;     // pixel 2ks(+lh) of the patch -> halo row/col
+      const int arow = S * (((2 * ks) / PW) * WH_HW + ((2 * ks) & (PW - 1))) * WH_CI;     // pixel 2ks(+lh) of the patch -> halo row/col
 #pragma unroll
       for (int s = 0; s < 3; ++s) a[s] = base[a_off + s * WH_CI + arow];
 #pragma unroll
@@ -1885,23 +1889,25 @@ __global__ __launch_bounds__(WH_THREADS, IGEMM_WH_MINW) void wgrad3x3_halo_kerne
   }
 }
 
-struct WgradHaloPlan { bool ok; int tiles_ci, tiles_co, splits, pps, pw; };    // pw: patch width 32 / 16 / 8 (patch = 32 / pw rows)
+struct WgradHaloPlan { bool ok; int tiles_ci, tiles_co, splits, pps, pw, stride; };    // pw: patch width 32 / 16 / 8 (patch = 32 / pw rows)
 WgradHaloPlan plan_wgrad_halo(const IgemmDesc& d) {
-  WgradHaloPlan p{false, 0, 0, 1, 0, 0};
+  WgradHaloPlan p{false, 0, 0, 1, 0, 0, 1};
   if (halo_disabled()) return p;
 #if IGEMM_HALO
   static const int small_env = getenv("LADDER_WGRAD_SMALL_PATCHES") ? atoi(getenv("LADDER_WGRAD_SMALL_PATCHES")) : 1;   // (test switch)
-  const int pw = (d.W % 32) == 0 ? 32 : (small_env && d.W == 16 && (d.H % 2) == 0) ? 16 : (small_env && d.W == 8 && (d.H % 4) == 0) ? 8 : 0;
-  if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.ups == 1 && d.pad_t == 1 && d.pad_l == 1 && d.Ho == d.H && d.Wo == d.W &&
-        (d.Cin % WH_CI) == 0 && (d.Cout % 4) == 0 && d.Cout >= 64 && pw != 0))
+  const int pw = (d.Wo % 32) == 0 ? 32 : (small_env && d.Wo == 16 && (d.Ho % 2) == 0) ? 16 : (small_env && d.Wo == 8 && (d.Ho % 4) == 0) ? 8 : 0;
+  const bool s1 = d.stride == 1 && d.pad_t == 1 && d.pad_l == 1 && d.Ho == d.H && d.Wo == d.W;
+  const bool s2 = small_env && d.stride == 2 && d.pad_t == 0 && d.pad_l == 0 && d.H == 2 * d.Ho && d.W == 2 * d.Wo;
+  if (!(d.KH == 3 && d.KW == 3 && (s1 || s2) && d.ups == 1 && (d.Cin % WH_CI) == 0 && (d.Cout % 4) == 0 && d.Cout >= 64 && pw != 0))
     return p;
-  const long q_total = (long)d.N * d.H * d.W / WH_PIX;
-  if (pw == 32 ? q_total < 4096 : q_total * (d.Cin / WH_CI) * ((d.Cout + WH_CO - 1) / WH_CO) < 4096) return p;   // small launches stay on the generic kernel
+  p.stride = s2 ? 2 : 1;
+  const long q_total = (long)d.N * d.Ho * d.Wo / WH_PIX;
+  if (pw == 32 && s1 ? q_total < 4096 : q_total * (d.Cin / WH_CI) * ((d.Cout + WH_CO - 1) / WH_CO) < 4096) return p;   // small launches stay on the generic kernel
   p.pw = pw;
   p.tiles_ci = d.Cin / WH_CI;
   p.tiles_co = (d.Cout + WH_CO - 1) / WH_CO;
   const long pairs = (long)p.tiles_ci * p.tiles_co;
-  long s = ((pw < 32 ? 1 : IGEMM_WH_BLOCKS) * 256L) / pairs;   // whole rounds of the chip (small maps: one -- 690 / 718 / 765 / 792 us for 1 ... 4 rounds on 16x16 512 -> 256 at batch 128: the partial tiles cost more than the tail)
+  long s = ((pw < 32 || s2 ? 1 : IGEMM_WH_BLOCKS) * 256L) / pairs;   // whole rounds of the chip (small maps: one -- 690 / 718 / 765 / 792 us for 1 ... 4 rounds on 16x16 512 -> 256 at batch 128: the partial tiles cost more than the tail)
   if (s > q_total / 16) s = q_total / 16;
   if (s < 1) s = 1;
   p.pps = (int)((q_total + s - 1) / s);
@@ -1937,9 +1943,14 @@ int run_wgrad(const float* x, const float* dy, float* dw, float* db, const Igemm
     float* out = hp.splits > 1 ? (float*)ws : dw;
     float* bias_part = db != nullptr ? (float*)ws + (hp.splits > 1 ? (size_t)hp.splits * kn : 0) : nullptr;
     const dim3 grid(hp.tiles_ci * hp.tiles_co, hp.splits), block(WH_THREADS);
-    if (hp.pw == 32) hipLaunchKernelGGL((wgrad3x3_halo_kernel<1, 32>), grid, block, 0, st, x, dy, out, bias_part, d.N, d.H, d.W, d.Cin, d.Cout, hp.tiles_co, hp.pps);
-    else if (hp.pw == 16) hipLaunchKernelGGL((wgrad3x3_halo_kernel<2, 16>), grid, block, 0, st, x, dy, out, bias_part, d.N, d.H, d.W, d.Cin, d.Cout, hp.tiles_co, hp.pps);
-    else hipLaunchKernelGGL((wgrad3x3_halo_kernel<4, 8>), grid, block, 0, st, x, dy, out, bias_part, d.N, d.H, d.W, d.Cin, d.Cout, hp.tiles_co, hp.pps);
+#define LADDER_WH_LAUNCH(PH_, PW_, S_) \
+  hipLaunchKernelGGL((wgrad3x3_halo_kernel<PH_, PW_, S_>), grid, block, 0, st, x, dy, out, bias_part, d.N, d.Ho, d.Wo, d.Cin, d.Cout, hp.tiles_co, hp.pps)
+    if (hp.stride == 1) {
+      if (hp.pw == 32) LADDER_WH_LAUNCH(1, 32, 1); else if (hp.pw == 16) LADDER_WH_LAUNCH(2, 16, 1); else LADDER_WH_LAUNCH(4, 8, 1);
+    } else {
+      if (hp.pw == 32) LADDER_WH_LAUNCH(1, 32, 2); else if (hp.pw == 16) LADDER_WH_LAUNCH(2, 16, 2); else LADDER_WH_LAUNCH(4, 8, 2);
+    }
+#undef LADDER_WH_LAUNCH
     if (hp.splits > 1)
       launch_reduce_splits((const float*)ws, dw, hp.splits, kn, st);
     if (db != nullptr)
@@ -2297,9 +2308,14 @@ int ladder_conv2d_bwd_data_split(const void* dy_planes, const float* dy_absmax, 
 }
 
 size_t ladder_conv2d_bwd_filter_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW) {
-  // upper bound over the stride/pad variants of this geometry (the halo path needs stride 1 / pad 1 / Ho==H)
+  // upper bound over the stride/pad variants of this geometry (the halo path needs stride 1 / pad 1 / Ho==H, or stride 2 / pad 0 / H==2Ho)
   IgemmDesc d{N, H, W, Cin, Ho, Wo, Cout, KH, KW, 1, 1, 1, 1, N * Ho * Wo, KH * KW * Cin, 0, make_fastdiv(1), make_fastdiv(1)};
   size_t need = wgrad_ws_bytes_desc(d);
+  if (H == 2 * Ho && W == 2 * Wo) {
+    IgemmDesc d2{N, H, W, Cin, Ho, Wo, Cout, KH, KW, 2, 1, 0, 0, N * Ho * Wo, KH * KW * Cin, 0, make_fastdiv(1), make_fastdiv(1)};
+    const size_t n2 = wgrad_ws_bytes_desc(d2);
+    if (n2 > need) need = n2;
+  }
   if (cout1_eligible(Cin, Cout, KH, KW, 1, 0, 0, H, W, Ho, Wo) && cout1_wgrad_ws_bytes(N, Ho, Cin) > need) need = cout1_wgrad_ws_bytes(N, Ho, Cin);
   return need;
 }

@@ -75,6 +75,9 @@ CONV_CASES = [
     (32, 64, 64, 32, 128, 3, 1, "same", None),         # Cin = 32: halo forward / backward-data, generic filter gradient
     (32, 16, 16, 512, 160, 3, 1, "same", None),        # halo filter gradient on 2 x 16-pixel patches (16-wide maps), Cout edge
     (64, 8, 8, 512, 512, 3, 1, "same", "leaky_relu"),  # halo filter gradient on 4 x 8-pixel patches (8-wide maps)
+    (64, 64, 64, 128, 128, 3, 2, "same", None),        # stride-2 halo filter gradient, 1 x 32-pixel patches of the 32 x 32 output
+    (64, 32, 32, 256, 160, 3, 2, "same", "leaky_relu"),  # stride-2 halo filter gradient, 2 x 16 patches, Cout edge
+    (128, 16, 16, 256, 512, 3, 2, "same", None),       # stride-2 halo filter gradient, 4 x 8 patches
 ]
 
 
