@@ -455,26 +455,39 @@ __device__ __forceinline__ void wgrad_up2_body(float* __restrict__ lds, const fl
     i = g * WU_PH;
     j0 = (rem - g * WP) * WU_PW;
   };
-  // one staging unit (16 bytes per lane by LDS-DMA) of patch (n, i, j0) into buffer `buf`: units 0 .. WU_XN-1 = input halo, then dY
+  // one staging unit (16 bytes per lane by LDS-DMA) of patch (n, i, j0) into buffer `buf`: units 0 .. WU_XN-1 = input halo, then dY.
+  // A lane's halo pixel of unit k is fixed: (row, column) = xpk[k], packed once (the division by the halo width is not repeated per patch),
+  // and the source address is a 32-bit offset from the image's base -- a unit costs ~15 VALU instructions where the straightforward index
+  // arithmetic cost ~50 (x 5 units per patch against 192 MFMAs: staging was 9 % of the kernel).
+  // (kept in LDS behind the staging buffers, same object: registers are what this kernel is short of)
+  int* const xpk = reinterpret_cast<int*>(lds + 2 * (WU_XF + WU_DF));
+#pragma unroll
+  for (int k = 0; k < WU_XN; ++k) {
+    const int u = tid + k * WU_THREADS, pix = u >> 4;
+    const int hr = pix / WU_HW, hc = pix - hr * WU_HW;
+    xpk[u] = u < WU_XU ? ((hr << 8) | hc) : -1;            // (read back by the same lane only)
+  }
+  const int xq4 = (tid & 15) * 4, dq4 = (tid & 31) * 4;
+  const bool d_cok = (co0 + dq4) < Cout;
   auto stage_unit = [&](int k, int n, int i, int j0, int buf) {
     float* xb = &lds[buf * (WU_XF + WU_DF)];
     if (k < WU_XN) {
-      const int u = tid + k * WU_THREADS;
-      if (u < WU_XU) {
-        const int pix = u >> 4, q4 = u & 15;
-        const int hr = pix / WU_HW, hc = pix - hr * WU_HW;
-        const int hs = min(max(i - 1 + hr, 0), H - 1), ws_ = min(max(j0 - 1 + hc, 0), W - 1);      // clamped: always inside the map
-        const float* src = x + (((long)n * (H * xs) + hs * xs) * (W * xs) + ws_ * xs) * Cin + ci0 + q4 * 4;
-        __builtin_amdgcn_global_load_lds(src, xb + u * 4, 16, 0, 0);
+      const int pk = xpk[tid + k * WU_THREADS];
+      if (pk >= 0) {
+        const int hs = min(max(i - 1 + (pk >> 8), 0), H - 1), ws_ = min(max(j0 - 1 + (pk & 255), 0), W - 1);   // clamped: always inside the map
+        const unsigned off = ((unsigned)(hs * xs) * (unsigned)(W * xs) + (unsigned)(ws_ * xs)) * (unsigned)Cin + (unsigned)xq4;
+        const float* xn = x + (size_t)n * (H * xs) * (W * xs) * Cin + ci0;
+        __builtin_amdgcn_global_load_lds(xn + off, xb + (tid + k * WU_THREADS) * 4, 16, 0, 0);
       }
     } else {
       const int u = tid + (k - WU_XN) * WU_THREADS;
       if (u < WU_DU) {
-        const int p = u >> 5, q4 = u & 31;
+        const int p = u >> 5;
         const int jj = j0 + (p & (WU_PW - 1)), ii = i + (p / WU_PW);
-        const bool ok = (co0 + q4 * 4) < Cout && ii < Hc && !(B == 1 && jj == W - 1);                // (a ragged last row group; the last output column: edge path)
-        const float* src = ok ? dy + (((long)n * 2 * H + 2 * ii + A) * 2 * W + 2 * jj + B) * Cout + co0 + q4 * 4 : f32_zero16;
-        __builtin_amdgcn_global_load_lds(src, xb + WU_XF + u * 4, 16, 0, 0);
+        const bool ok = d_cok && ii < Hc && !(B == 1 && jj == W - 1);                               // (a ragged last row group; the last output column: edge path)
+        const unsigned off = ((unsigned)(2 * ii + A) * (unsigned)(2 * W) + (unsigned)(2 * jj + B)) * (unsigned)Cout + (unsigned)(co0 + dq4);
+        const float* dn = dy + (size_t)n * (2 * H) * (2 * W) * Cout;
+        __builtin_amdgcn_global_load_lds(ok ? dn + off : f32_zero16, xb + WU_XF + u * 4, 16, 0, 0);
       }
     }
   };
@@ -500,45 +513,60 @@ __device__ __forceinline__ void wgrad_up2_body(float* __restrict__ lds, const fl
     const unsigned csign = (j0 == 0 && lh == 0) ? 0x80000000u : 0u;
     const float* base = &lds[buf * (WU_XF + WU_DF)];
     if (active) {
+      // software pipeline of depth one: the fragments of k-step ks + 1 are requested BEFORE the MFMAs of k-step ks are issued, so the LDS
+      // latency runs behind the wavefront's own 6 (4) MFMAs instead of in front of them
+      constexpr int NA = MODEB ? 1 : 3, NB = MODEB ? 4 : 2;
+      float ac[NA], bc[NB], an[NA], bn[NB];
+      auto load_frag = [&](const int ks, float* af, float* bf) {
+        const int arow = ((ks >> 4) * WU_HW + ((2 * ks) & 31)) * WU_CI;
+        if (!MODEB) {
+#pragma unroll
+          for (int s = B; s < 3; ++s) af[s] = base[a_off + s * WU_CI + arow];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) bf[j] = base[b_off + (njp * 2 + j) * 32 + 2 * ks * WU_CO];
+        } else {
+          af[0] = base[a_off + sh * WU_CI + arow];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bf[j] = base[b_off + j * 32 + 2 * ks * WU_CO];
+        }
+      };
+      load_frag(0, ac, bc);
 #pragma unroll 4
       for (int ks = 0; ks < WU_PIX / 2; ++ks) {
-        // the NEXT patch is staged from inside this loop, one unit every fourth k-step: the address arithmetic of a unit then runs in the
-        // shadow of this wavefront's own MFMAs.  Staged as a block in front of the loop it cost ~5 us per patch during which the matrix pipe of
-        // the compute unit had nothing to do (one workgroup per CU: nobody else fills the gap): 17.6 us per patch against 11 us of MFMA time.
-        if ((ks & 3) == 1 && has_next && (ks >> 2) < NUNITS) stage_unit(ks >> 2, nn, ni, nj0, buf ^ 1);
-        const int arow = ((ks >> 4) * WU_HW + ((2 * ks) & 31)) * WU_CI;     // pixel 2 ks (+ lh) of the patch -> halo row / column
+        if (ks + 1 < WU_PIX / 2) load_frag(ks + 1, an, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        if ((ks & 3) == 1 && has_next && (ks >> 2) < NUNITS) stage_unit(ks >> 2, nn, ni, nj0, buf ^ 1);   // (the NEXT patch, one unit every fourth k-step)
         const bool col0 = ((2 * ks) & 31) == 0;
         const unsigned rsign = (ks < 16) ? rsign0 : 0u;
         if (!MODEB) {
-          float a[3], b[2];
+          float a[3];
 #pragma unroll
           for (int s = B; s < 3; ++s) {
             const unsigned sg = rsign ^ ((col0 && s == 0) ? csign : 0u);
-            a[s] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, base[a_off + s * WU_CI + arow]) ^ sg);
+            a[s] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, ac[s]) ^ sg);
           }
-#pragma unroll
-          for (int j = 0; j < 2; ++j) b[j] = base[b_off + (njp * 2 + j) * 32 + 2 * ks * WU_CO];
 #pragma unroll
           for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int s = B; s < 3; ++s) acc[j * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[j], acc[j * 3 + s], 0, 0, 0);
+            for (int s = B; s < 3; ++s) acc[j * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bc[j], acc[j * 3 + s], 0, 0, 0);
           if (do_bias) {
-            bsum[0] += b[0];
-            bsum[1] += b[1];
+            bsum[0] += bc[0];
+            bsum[1] += bc[1];
           }
         } else {
           const unsigned sg = (col0 && sh == 0) ? csign : 0u;                       // (dr >= 1: never the row above the map)
-          const float a = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, base[a_off + sh * WU_CI + arow]) ^ sg);
-          float b[4];
+          const float a = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, ac[0]) ^ sg);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) b[j] = base[b_off + j * 32 + 2 * ks * WU_CO];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], acc[j], 0, 0, 0);
+          for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bc[j], acc[j], 0, 0, 0);
           if (do_bias) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bsum[j] += b[j];
+            for (int j = 0; j < 4; ++j) bsum[j] += bc[j];
           }
         }
+#pragma unroll
+        for (int i2 = 0; i2 < NA; ++i2) ac[MODEB ? i2 : (i2 < B ? B : i2)] = an[MODEB ? i2 : (i2 < B ? B : i2)];
+#pragma unroll
+        for (int i2 = 0; i2 < NB; ++i2) bc[i2] = bn[i2];
       }
     } else if (has_next) {
 #pragma unroll
@@ -592,7 +620,7 @@ __global__ __launch_bounds__(WU_THREADS, 3) void wgrad3x3_up2_f32_kernel(const f
                                                                          const int N, const int H, const int W, const int Cin, const int Cout,
                                                                          const WgradUp2Plan p, const int xs) {
   // ONE LDS object (hipcc serialises LDS-DMA against ds_reads when several __shared__ objects exist): [buf][halo | dY]
-  __shared__ __attribute__((aligned(16))) float lds[2 * (WU_XF + WU_DF)];
+  __shared__ __attribute__((aligned(16))) float lds[2 * (WU_XF + WU_DF) + WU_XN * WU_THREADS];   // + the lanes' packed halo units
   // workgroup -> (slab pair, class, split of the class): the classes of a pair are laid out one after another
   const int pair = blockIdx.x / p.total, w = blockIdx.x - pair * p.total;
   const int cls = w >= p.s0[3] ? 3 : (w >= p.s0[2] ? 2 : (w >= p.s0[1] ? 1 : 0));
