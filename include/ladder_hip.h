@@ -62,6 +62,9 @@ int ladder_conv2d_fwd(const float* x, const float* w, const float* bias, float* 
  * fill the 256 CUs (small M*Cout, long K) the contraction is split over K into `ws` and summed in a fixed order by a
  * second kernel (bias/activation applied there).  ws == NULL or too small => single-pass kernel.  M, K, Cout = GEMM extents. */
 size_t ladder_igemm_fwd_workspace_bytes(long M, int K, int Cout);
+/* Split-K factor of a DENSE forward-type call of this geometry (1 = single pass; the workspace query above also covers the parity classes
+ * of a stride-2 backward-data, which split on their own). */
+int ladder_igemm_fwd_splits(long M, int K, int Cout);
 /* wT[KH-1-r][KW-1-s][co][ci] = w[r][s][ci][co]: the filter bank bwd_data consumes. */
 int ladder_filter_flip_transpose(const float* w, float* wT, int KH, int KW, int Cin, int Cout, ladder_stream_t stream);
 /* dx[n,hi,wi,ci] = sum dy[n,ho,wo,co] * w[r,s,ci,co] over {hi = ho*stride + r - pad_t, ...}; wT from above.

@@ -40,6 +40,7 @@ _p, _i, _f, _d, _z, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_
 PROTOTYPES = {
     "ladder_abi_version": (_i, []),
     "ladder_igemm_fwd_tile": (_i, [C.c_long, _i, _i]),
+    "ladder_igemm_fwd_splits": (_i, [C.c_long, _i, _i]),
     "ladder_conv2d_fwd_kernel_id": (_i, [_i] * 13),
     "ladder_conv2d_bwd_filter_kernel_id": (_i, [_i] * 12),
     "ladder_conv2d_fwd": (_i, [_p, _p, _p, _p] + [_i] * 13 + [_p, _z, _p]),

@@ -1282,7 +1282,10 @@ int launch_fwd(const float* x, const float* w, const float* bias, float* y, cons
   const bool veca = (d.Cin % BK) == 0, vecb = (d.Cout % 4) == 0;
   const bool fast = d.ntaps > 0;
   const bool dense_out = d.out_sh == 1 && d.out_sw == 1 && d.OH == d.Ho && d.OW == d.Wo;
-  SplitPlan sp = dense_out ? plan_splitk(d.M, d.K, d.Cout, BM, BN) : SplitPlan{1, (d.K + BK - 1) / BK};
+  // (round 4: also the parity classes of a stride-2 backward-data -- a quarter of the pixels, 1 ... 4 of the 9 taps: 32 tiles on 256 CUs
+  // for the 8x8 <- 4x4 layer -- through splitk_epilogue_strided_kernel: 241 -> 96 us for its four launches)
+  // (only the small ones: at 512 tiles the strided second pass costs more than the idle CUs -- 16x16 <- 8x8: 174 us single pass, 195 split)
+  SplitPlan sp = (dense_out || (long)tiles_m * tiles_n <= 256) ? plan_splitk(d.M, d.K, d.Cout, BM, BN) : SplitPlan{1, (d.K + BK - 1) / BK};
   const size_t need = (size_t)sp.splits * d.M * d.Cout * sizeof(float);
   if (sp.splits > 1 && (ws == nullptr || ws_bytes < need)) sp = SplitPlan{1, (d.K + BK - 1) / BK};
   float* part = sp.splits > 1 ? (float*)ws : nullptr;
@@ -1294,8 +1297,12 @@ int launch_fwd(const float* x, const float* w, const float* bias, float* y, cons
   else hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, x, w, bias, y, d, tiles_n, fast, part, sp.cps, part ? nullptr : gate, gate_act, stats_part);
   if (part != nullptr) {
     const size_t mn = (size_t)d.M * d.Cout;
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, (const float*)part, bias, y,
-                       sp.splits, mn, d.Cout, d.act, gate, gate_act);
+    if (dense_out)
+      hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, (const float*)part, bias, y,
+                         sp.splits, mn, d.Cout, d.act, gate, gate_act);
+    else
+      hipLaunchKernelGGL(splitk_epilogue_strided_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, (const float*)part, bias, y,
+                         sp.splits, mn, d.act, gate, gate_act, d);
   }
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
@@ -1713,7 +1720,16 @@ int dispatch_fwd(const float* x, const float* w, const float* bias, float* y, co
 size_t fwd_ws_bytes(long M, int K, int Cout) {
   const int t = select_fwd_tile(M, Cout);
   const SplitPlan sp = plan_splitk(M, K, Cout, t / 1000, t % 1000);
-  return sp.splits > 1 ? (size_t)sp.splits * M * Cout * sizeof(float) : 0;
+  size_t need = sp.splits > 1 ? (size_t)sp.splits * M * Cout * sizeof(float) : 0;
+  // the call may be a stride-2 backward-data: its parity classes (a quarter of the pixels, at most 4 of 9 taps) split on their own
+  if ((K % 9) == 0 && M >= 4) {
+    const long Mc = (M + 3) / 4;
+    const int Kc = K / 9 * 4, tc = select_fwd_tile(Mc, Cout);
+    const SplitPlan sc = plan_splitk(Mc, Kc, Cout, tc / 1000, tc % 1000);
+    const size_t nc = sc.splits > 1 ? (size_t)sc.splits * Mc * Cout * sizeof(float) : 0;
+    if (nc > need) need = nc;
+  }
+  return need;
 }
 
 // ---- wgrad planning (shared by the workspace query and the launcher)
@@ -2072,6 +2088,11 @@ int ladder_conv2d_fwd(const float* x, const float* w, const float* bias, float* 
 
 size_t ladder_igemm_fwd_workspace_bytes(long M, int K, int Cout) { return fwd_ws_bytes(M, K, Cout); }
 
+int ladder_igemm_fwd_splits(long M, int K, int Cout) {
+  const int t = select_fwd_tile(M, Cout);
+  return plan_splitk(M, K, Cout, t / 1000, t % 1000).splits;
+}
+
 // ---- strict-fp32 convolution whose epilogue also emits the batch-norm statistics of its output (round 4: the fp32 form of
 // ladder_conv2d_fwd_split_bnstats): 128x128-tile gather launches without split-K.  0 bytes = not available for this geometry.
 static bool fwd_bnstats_ok(const IgemmDesc& d) {
@@ -2166,7 +2187,7 @@ int ladder_conv2d_bwd_data(const float* dy, const float* wT, float* dx, int N, i
         }
         if (c.ntaps == 0) return dispatch_fwd(dy, wT, nullptr, dx, d, ws, ws_bytes, stream, gate_y, gate_act);   // degenerate: legacy path writes the zeros
         c.K = c.ntaps * Cout;
-        const int rc = dispatch_fwd(dy, wT, nullptr, dx, c, nullptr, 0, stream, gate_y, gate_act);
+        const int rc = dispatch_fwd(dy, wT, nullptr, dx, c, ws, ws_bytes, stream, gate_y, gate_act);   // (the classes run one after another: one workspace)
         if (rc != LADDER_OK) return rc;
       }
     return LADDER_OK;

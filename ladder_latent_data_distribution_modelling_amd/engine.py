@@ -103,7 +103,7 @@ def _igemm(ctx, name, M, Cin, Cout, Kdim, *args, conv=None):
     kid = _KID.get(kkey)
     if kid is None:
         kid = L.query("ladder_conv2d_fwd_kernel_id", *conv) if conv else L.query("ladder_igemm_fwd_tile", M, Cin, Cout)
-        if kid != 256128 and nb:
+        if kid != 256128 and nb and L.query("ladder_igemm_fwd_splits", M, Kdim, Cout) > 1:
             kid = 0         # split-K launch: two kernels, not attributed
         _KID[kkey] = kid
     if kid in (256128, 128128):

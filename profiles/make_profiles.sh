@@ -12,6 +12,17 @@ cd $R
 grep '^{"metric"' gpurun_out/r04_f32_bench_under_rocprof.log > gpurun_out/r04_f32_bench_under_rocprof.json
 python3 profiles/summarize_rocpd.py $(find gpurun_out/prof_k -name "*.db" | head -1) > gpurun_out/r04_f32_bench_kernel_stats.md
 python3 profiles/pmc_traffic.py $(find gpurun_out/pmc_f -name "*.db" | head -1) $(find gpurun_out/pmc_w -name "*.db" | head -1) gpurun_out/r04_f32_pmc_traffic.json \
-    conv3x3_halo_f32_kernel wgrad3x3_halo_kernel igemm_fwd_kernel igemm_wgrad_kernel gemm_small > /dev/null
-python3 profiles/tools/r3_percall.py --top 90 > gpurun_out/r04_f32_percall.md 2>/dev/null
+    conv3x3_halo_f32_kernel wgrad3x3_up2_f32_kernel wgrad3x3_halo_kernel igemm_fwd_kernel igemm_wgrad_kernel gemm_small > /dev/null
+python3 profiles/tools/r3_percall.py --precision f32 --top 90 > gpurun_out/r04_f32_percall.md 2>/dev/null
+# hardware counters of the hot fp32 kernels, one counter set per pass (kernel trace + pmc only)
+rm -rf gpurun_out/pmc_hot; mkdir -p gpurun_out/pmc_hot
+cd /tmp
+i=0
+for set in "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+           "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM" "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/pmc_hot/p$i -- python3 $R/profiles/tools/r4_pmc_probe.py > $R/gpurun_out/pmc_hot/p$i.log 2>&1
+done
+cd $R
+python3 profiles/tools/r4_pmc_probe.py --show $(find gpurun_out/pmc_hot -name "*.db") > gpurun_out/r04_f32_hot_kernels_pmc.txt 2>&1
 tail -c 1500 gpurun_out/r04_f32_bench_default.json
