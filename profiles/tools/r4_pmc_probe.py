@@ -32,7 +32,7 @@ def show(paths):
         for k, g, c, v, d, vg, lds, scr in db.execute("select kernel_name, grid_size, counter_name, value, duration, vgpr_count, "
                                                       "lds_block_size, scratch_size from counters_collection"):
             if any(t in k for t in KERNELS):
-                key = (k.split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", ""), g)
+                key = (k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0], g)
                 res.setdefault((key, c), []).append(v)
                 dur.setdefault(key, []).append(d)
                 meta[key] = (vg, lds, scr)
