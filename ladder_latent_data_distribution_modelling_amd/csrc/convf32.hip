@@ -492,7 +492,6 @@ __device__ __forceinline__ void wgrad_up2_body(float* __restrict__ lds, const fl
     }
   };
   constexpr int NUNITS = WU_XN + WU_DN;
-  static_assert(NUNITS <= WU_PIX / 8, "one staging unit per 4 k-steps");
 
   if (q0 < q1) {
     int n, i, j0;
@@ -530,12 +529,17 @@ __device__ __forceinline__ void wgrad_up2_body(float* __restrict__ lds, const fl
           for (int j = 0; j < 4; ++j) bf[j] = base[b_off + j * 32 + 2 * ks * WU_CO];
         }
       };
+      // the NEXT patch is requested in one block in front of the k-loop (5 LDS-DMA units of ~15 VALU instructions each since the halo-unit
+      // table; with the ~50-instruction index arithmetic of the first version, spreading the units over the loop was the faster order)
+      if (has_next) {
+#pragma unroll
+        for (int k = 0; k < NUNITS; ++k) stage_unit(k, nn, ni, nj0, buf ^ 1);
+      }
       load_frag(0, ac, bc);
 #pragma unroll 4
       for (int ks = 0; ks < WU_PIX / 2; ++ks) {
         if (ks + 1 < WU_PIX / 2) load_frag(ks + 1, an, bn);
         __builtin_amdgcn_sched_barrier(0);
-        if ((ks & 3) == 1 && has_next && (ks >> 2) < NUNITS) stage_unit(ks >> 2, nn, ni, nj0, buf ^ 1);   // (the NEXT patch, one unit every fourth k-step)
         const bool col0 = ((2 * ks) & 31) == 0;
         const unsigned rsign = (ks < 16) ? rsign0 : 0u;
         if (!MODEB) {
