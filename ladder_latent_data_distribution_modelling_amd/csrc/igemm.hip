@@ -2097,6 +2097,7 @@ int ladder_igemm_fwd_splits(long M, int K, int Cout) {
 // ladder_conv2d_fwd_split_bnstats): 128x128-tile gather launches without split-K.  0 bytes = not available for this geometry.
 static bool fwd_bnstats_ok(const IgemmDesc& d) {
   if (getenv("LADDER_DISABLE_BNSTATS") != nullptr) return false;       // (test-only switch: the statistics then come from the separate pass)
+  // (Cin % 16: the image-side conv, Cin = 3, is bound by writing its output -- the statistics epilogue costs it the 90 us the separate pass takes: measured, no gain)
   return (d.Cin % BK) == 0 && (d.Cout % 4) == 0 && d.ntaps > 0 && !halo_eligible(d) && select_fwd_tile(d.M, d.Cout) == 128128 &&
          plan_splitk(d.M, d.K, d.Cout, 128, 128).splits == 1 && !smallcout_eligible(d.Cin, d.Cout, d.KH, d.KW, d.stride, d.M);
 }

@@ -438,3 +438,34 @@ def test_f32_up2_backward_data_with_exact_borders_vs_autograd(gpu_ctx, case):
                      ("column 0", (slice(None), slice(None), 0)), ("column W-1", (slice(None), slice(None), -1))):
         err = np.abs(got[sl] - ref[sl]).max() / scale
         assert err < TOL32, (name, err)
+
+
+@pytest.mark.parametrize("geom", [(128, 64, 64, 128, 128, 2), (192, 16, 16, 64, 256, 1)], ids=lambda g: "x".join(map(str, g)))
+def test_f32_conv_epilogue_emits_the_batch_norm_statistics(gpu_ctx, geom):
+    """ladder_conv2d_fwd_bnstats (reference: tf.layers.conv2d -> tf.layers.batch_normalization, codes/models.py:398-460): the output is bit-identical
+    to ladder_conv2d_fwd's and the per-channel sum / sum of squares / min / max are those of that output."""
+    L = _lib()
+    N, H, W, Cin, Cout, s = geom
+    from ladder_latent_data_distribution_modelling_amd import arch
+    pt, Ho = arch.conv_out(H, 3, s, "same")
+    pl, Wo = arch.conv_out(W, 3, s, "same")
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    st = gpu_ctx.stream
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    geo = (N, H, W, Cin, Ho, Wo, Cout, 3, 3, s, pt, pl)
+    nb = L.query("ladder_conv2d_fwd_bnstats_workspace_bytes", *geo)
+    assert nb > 0, "this geometry must take the statistics epilogue (>= 640 tiles of 128 x 128: single pass)"
+    y0, y1 = torch.empty(N, Ho, Wo, Cout, device="cuda"), torch.empty(N, Ho, Wo, Cout, device="cuda")
+    L.call("ladder_conv2d_fwd", p(xd), p(wd), p(bd), p(y0), *geo, 0, None, 0, st)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    sums = torch.full((4 * Cout,), float("nan"), device="cuda")
+    L.call("ladder_conv2d_fwd_bnstats", p(xd), p(wd), p(bd), p(y1), *geo, 0, p(sums), p(ws), ws.numel(), st)
+    assert torch.equal(y0, y1)
+    yr = y0.double().cpu().numpy().reshape(-1, Cout)
+    got = sums.cpu().numpy().reshape(4, Cout)
+    assert np.abs(got[0] - yr.sum(0)).max() <= 1e-6 * np.abs(yr).sum(0).max()                  # fp32 partial sums over 128-pixel tiles, then a fixed tree (measured 6e-8)
+    assert np.abs(got[1] - (yr * yr).sum(0)).max() <= 2e-6 * (yr * yr).sum(0).max()
+    assert np.array_equal(got[2], yr.min(0).astype(np.float32)) and np.array_equal(got[3], yr.max(0).astype(np.float32))
