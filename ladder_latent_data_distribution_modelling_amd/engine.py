@@ -1539,7 +1539,8 @@ class LadderEngine:
         self._gm_packed = None
         self.use_graphs = False
         # filter gradients on a second stream beside the backward chain (config key `overlap_filter_gradients` / environment variable
-        # LADDER_OVERLAP_FILTER_GRADIENTS): +0.7-1 % per iteration, bit-identical results -- OFF by default because kernels that share the
+        # LADDER_OVERLAP_FILTER_GRADIENTS): +0.7-1 % per iteration with the f16x3 kernels, nothing with the fp32 ones (round 4: 3 328 / 3 327 img/s --
+        # both partners are bound by the fp32 matrix pipe), bit-identical results -- OFF by default because kernels that share the
         # chip stretch each other, so the per-kernel HIP-event durations bench.py reports (roofline.achieved) stop describing the kernels
         if bool(int(cfg.get("overlap_filter_gradients", os.environ.get("LADDER_OVERLAP_FILTER_GRADIENTS", 0)))):
             self.ctx.side = torch.cuda.Stream(device=self.ctx.device)
