@@ -355,6 +355,13 @@ int ladder_conv_rgb_s2_fwd_bnstats(const float* x, const float* w, const float* 
                                    float* sums4 /*[4 Cout]: sum | sum of squares | min | max*/, void* ws, size_t ws_bytes,
                                    ladder_stream_t stream);
 /* dw [3,3,3,Cout], db [Cout] (may be NULL); x_absmax / dy_absmax = the tensors' absolute-maximum records (ladder_absmax or a producer's). */
+/* Strict-fp32 instantiations of the two forward calls above (round 4): the im2col matrix and the filter stay fp32 in LDS, 14 K-steps of
+ * v_mfma_f32_32x32x2_f32, no operand scaling; same arguments, same statistics workspace.  (The filter gradient of this layer in strict fp32 is
+ * ladder_conv2d_bwd_filter.) */
+int ladder_conv_rgb_s2_fwd_f32(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act,
+                               ladder_stream_t stream);
+int ladder_conv_rgb_s2_fwd_bnstats_f32(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act,
+                                       float* sums, void* ws, size_t ws_bytes, ladder_stream_t stream);
 size_t ladder_conv_rgb_s2_bwd_filter_workspace_bytes(int N, int H, int W, int Cout);
 int ladder_conv_rgb_s2_bwd_filter(const float* x, const float* x_absmax, const float* dy, const float* dy_absmax, float* dw, float* db,
                                   int N, int H, int W, int Cout, void* ws, size_t ws_bytes, ladder_stream_t stream);

@@ -157,6 +157,8 @@ PROTOTYPES = {
     "ladder_conv_rgb_s2_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ladder_conv_rgb_s2_fwd_bnstats_workspace_bytes": (_z, [_i] * 4),
     "ladder_conv_rgb_s2_fwd_bnstats": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _z, _p]),
+    "ladder_conv_rgb_s2_fwd_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "ladder_conv_rgb_s2_fwd_bnstats_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _z, _p]),
     "ladder_bn_stats_from_partials": (_i, [_p, _i, _p, _i, _p]),
     "ladder_bn_stats_minmax_from_partials": (_i, [_p, _i, _p, _i, _p]),
     "ladder_bn_fwd_stats_minmax": (_i, [_p, _p, _z, _i, _p, _z, _p]),

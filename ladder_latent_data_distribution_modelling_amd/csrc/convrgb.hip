@@ -40,6 +40,11 @@ __device__ __forceinline__ float rgb_tap(const float* __restrict__ patch, int pr
   return patch[((2 * pr + r) * RGB_PW + 2 * pc + s) * 3 + ci];
 }
 
+// F32 (round 4: strict fp32): the im2col matrix A[256 pixels][28] (row stride 29: conflict-free fragment reads) and the filter B[28][128] are
+// built in LDS as fp32 and multiplied by 14 K-steps of v_mfma_f32_32x32x2_f32 -- no scales, no planes; everything else (patch load, tile
+// shape, lane = channel epilogue with whole-line stores, statistics) is shared.
+constexpr int RGB_K32 = 28, RGB_LDA32 = RGB_K32 + 1;
+template <bool F32>
 __global__ __launch_bounds__(RGB_THREADS, 4) void conv_rgb_s2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                         const float* __restrict__ bias, float* __restrict__ y,
                                                                         const int N, const int H, const int W, const int Cout,
@@ -68,6 +73,51 @@ __global__ __launch_bounds__(RGB_THREADS, 4) void conv_rgb_s2_fwd_kernel(const f
     patch[u] = v;
     xmax = fmaxf(xmax, fabsf(v));
   }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+  float cx = 1.f, cw = 1.f;
+  if constexpr (F32) {
+    static_assert(RGB_PIX * RGB_LDA32 * 4 <= 2 * RGB_A_PLANE && RGB_K32 * 128 * 4 <= 2 * RGB_B_PLANE, "the fp32 operands fit the plane buffers");
+    float* const A32 = reinterpret_cast<float*>(Ab);                 // [pixel][29]
+    float* const B32 = reinterpret_cast<float*>(Bb);                 // [k][128]
+    {
+      const int co = tid & 127, kq = tid >> 7;                       // thread = (channel, 7 taps)
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int k = kq * 7 + j;
+        B32[k * 128 + co] = (k < 27 && n0 + co < Cout) ? w[(long)k * Cout + n0 + co] : 0.f;
+      }
+    }
+    __syncthreads();                                                 // (the patch is complete)
+    {
+      const int p = tid & 255, kh = tid >> 8, pr = p >> 5, pc = p & 31;   // thread = (pixel, K half)
+#pragma unroll
+      for (int j = 0; j < 14; ++j) {
+        const int k = kh * 14 + j;
+        A32[p * RGB_LDA32 + k] = k < 27 ? rgb_tap(patch, pr, pc, k) : 0.f;
+      }
+    }
+    __syncthreads();
+    const float* Afr = A32 + (wm * 64 + l31) * RGB_LDA32 + lh;
+    const float* Bfr = B32 + lh * 128 + wn * 64 + l31;
+#pragma unroll
+    for (int ks = 0; ks < RGB_K32 / 2; ++ks) {
+      float a[2], b[2];
+      a[0] = Afr[2 * ks];
+      a[1] = Afr[32 * RGB_LDA32 + 2 * ks];
+      b[0] = Bfr[2 * ks * 128];
+      b[1] = Bfr[2 * ks * 128 + 32];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);   // lane = channel
+    }
+  } else {
   // 2. filter block -> registers (thread = channel co, K octet kq), its maximum
   const int co = tid & 127, kq = tid >> 7;
   float wv[8], wmax = 0.f;
@@ -77,8 +127,8 @@ __global__ __launch_bounds__(RGB_THREADS, 4) void conv_rgb_s2_fwd_kernel(const f
     wv[j] = (k < 27 && n0 + co < Cout) ? w[(long)k * Cout + n0 + co] : 0.f;
     wmax = fmaxf(wmax, fabsf(wv[j]));
   }
-  const float cx = scale_from_absmax(block_max_512(xmax, red));
-  const float cw = scale_from_absmax(block_max_512(wmax, red));     // (also orders the patch writes before the reads below)
+  cx = scale_from_absmax(block_max_512(xmax, red));
+  cw = scale_from_absmax(block_max_512(wmax, red));     // (also orders the patch writes before the reads below)
   {
     uint2 lo[2], hi[2];
     split4<2, true>(make_float4(wv[0] * cw, wv[1] * cw, wv[2] * cw, wv[3] * cw), lo);
@@ -108,13 +158,6 @@ __global__ __launch_bounds__(RGB_THREADS, 4) void conv_rgb_s2_fwd_kernel(const f
   }
   __syncthreads();
 
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     uint4 a[2][2], b[2][2];
@@ -135,6 +178,8 @@ __global__ __launch_bounds__(RGB_THREADS, 4) void conv_rgb_s2_fwd_kernel(const f
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma16<true>(a[mi][pa], b[ni][sum - pa], acc[mi][ni]);   // lane = channel, registers = pixels
+  }
+
   }
 
   // lane = channel: every store instruction writes whole 128-byte lines (32 consecutive channels of one pixel per half-wave) -- the call
@@ -353,14 +398,18 @@ int ladder_conv_rgb_s2_eligible(int N, int H, int W, int Cin, int Cout, int KH, 
 }
 
 static int rgb_fwd_launch(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act, float* stats_part,
-                          ladder_stream_t stream) {
+                          ladder_stream_t stream, bool f32 = false) {
   if (!rgb_s2_ok(N, H, W, 3, Cout, 3, 3, 2, 0, 0)) return LADDER_E_SHAPE;
   if (!ladder_aligned16(y) || (bias != nullptr && !ladder_aligned16(bias))) return LADDER_E_ALIGN;
   const int tiles_n = (Cout + 127) / 128;
   const long tiles = (long)N * (H / 2 / RGB_TH) * (W / 2 / RGB_TW) * tiles_n;
   if (tiles >= (1L << 31)) return LADDER_E_SHAPE;
-  hipLaunchKernelGGL(conv_rgb_s2_fwd_kernel, dim3((unsigned)tiles), dim3(RGB_THREADS), 0, stream, x, w, bias, y, N, H, W, Cout, act, tiles_n,
-                     stats_part);
+  if (f32)
+    hipLaunchKernelGGL(conv_rgb_s2_fwd_kernel<true>, dim3((unsigned)tiles), dim3(RGB_THREADS), 0, stream, x, w, bias, y, N, H, W, Cout, act, tiles_n,
+                       stats_part);
+  else
+    hipLaunchKernelGGL(conv_rgb_s2_fwd_kernel<false>, dim3((unsigned)tiles), dim3(RGB_THREADS), 0, stream, x, w, bias, y, N, H, W, Cout, act, tiles_n,
+                       stats_part);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
@@ -383,6 +432,22 @@ int ladder_conv_rgb_s2_fwd_bnstats(const float* x, const float* w, const float* 
   if (need == 0 || sums == nullptr) return LADDER_E_SHAPE;
   if (ws == nullptr || ws_bytes < need) return LADDER_E_WORKSPACE;
   const int rc = rgb_fwd_launch(x, w, bias, y, N, H, W, Cout, act, (float*)ws, stream);
+  if (rc != LADDER_OK) return rc;
+  return ladder_bn_stats_minmax_from_partials((const float*)ws, N * (H / 2 / RGB_TH) * (W / 2 / RGB_TW), sums, Cout, stream);
+}
+
+// Strict-fp32 instantiations of the two forward calls (fp32 MFMA, no operand scaling): same arguments, same workspace.
+int ladder_conv_rgb_s2_fwd_f32(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act,
+                               ladder_stream_t stream) {
+  return rgb_fwd_launch(x, w, bias, y, N, H, W, Cout, act, nullptr, stream, true);
+}
+
+int ladder_conv_rgb_s2_fwd_bnstats_f32(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act,
+                                       float* sums, void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  const size_t need = ladder_conv_rgb_s2_fwd_bnstats_workspace_bytes(N, H, W, Cout);
+  if (need == 0 || sums == nullptr) return LADDER_E_SHAPE;
+  if (ws == nullptr || ws_bytes < need) return LADDER_E_WORKSPACE;
+  const int rc = rgb_fwd_launch(x, w, bias, y, N, H, W, Cout, act, (float*)ws, stream, true);
   if (rc != LADDER_OK) return rc;
   return ladder_bn_stats_minmax_from_partials((const float*)ws, N * (H / 2 / RGB_TH) * (W / 2 / RGB_TW), sums, Cout, stream);
 }

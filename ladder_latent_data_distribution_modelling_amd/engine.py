@@ -523,6 +523,11 @@ class Conv2D:
         return bool(self.ctx.ns == 4 and self.cin == 3 and L.query("ladder_conv_rgb_s2_eligible", N, H, W, self.cin, self.cout, self.k, self.k,
                                                                self.stride, self.pt, self.pl))
 
+    def _rgb_fwd32(self, N, H, W):
+        # strict fp32: the forward of the same layer on the fp32 instantiation of the kernel (its filter gradient stays on the generic kernel)
+        return bool(self.ctx.ns == 0 and self.cin == 3 and os.environ.get("LADDER_DISABLE_HALO") != "1" and
+                    L.query("ladder_conv_rgb_s2_eligible", N, H, W, self.cin, self.cout, self.k, self.k, self.stride, self.pt, self.pl))
+
     def planes_demand(self, in_shape):
         """(wants_planes, needs_fp32) for an input of `in_shape`: whether this layer's forward reads the fp16 plane images of its input
         (split gather kernel) and whether anything of it still needs the fp32 tensor (a filter gradient outside the split kernel)."""
@@ -672,14 +677,15 @@ class Conv2D:
             self.x, self.y = x, y
             return y
         geo = (N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl)
-        if self._rgb(N, H, W):                           # the image-side encoder conv (3 -> Cout channels, stride 2): csrc/convrgb.hip
+        if self._rgb(N, H, W) or self._rgb_fwd32(N, H, W):   # the image-side encoder conv (3 -> Cout channels, stride 2): csrc/convrgb.hip
+            sfx = "" if self.ctx.ns else "_f32"
             if self.want_bn_sums and self.act is None:
                 wsp, wsn = self.ctx.ws(L.query("ladder_conv_rgb_s2_fwd_bnstats_workspace_bytes", N, H, W, self.cout))
                 self.bn_sums = self.ctx.empty(4 * self.cout)       # sum | sum of squares | min | max per channel
-                L.call("ladder_conv_rgb_s2_fwd_bnstats", _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y),
+                L.call("ladder_conv_rgb_s2_fwd_bnstats" + sfx, _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y),
                        N, H, W, self.cout, 0, _p(self.bn_sums), wsp, wsn, self.ctx.stream)
             else:
-                L.call("ladder_conv_rgb_s2_fwd", _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y), N, H,
+                L.call("ladder_conv_rgb_s2_fwd" + sfx, _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y), N, H,
                        W, self.cout, L.ACT[self.act], self.ctx.stream)
             self.x, self.y = x, y
             return y

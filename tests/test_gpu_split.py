@@ -464,6 +464,17 @@ def test_conv_rgb_stride2(gpu_ctx, case):
     st = gpu_ctx.stream
     xd, wd, bd = dev(x), dev(w), dev(b)
     y = torch.empty(N, Ho, Wo, Cout, device="cuda")
+    # strict-fp32 instantiation (round 4): fp32 operands in LDS, fp32 MFMA -- the tolerance of the native kernels; with its statistics
+    wsp, wsn = gpu_ctx.ws(L.query("ladder_conv_rgb_s2_fwd_bnstats_workspace_bytes", N, H, W, Cout))
+    y32, sums32 = torch.empty_like(y), torch.empty(4 * Cout, device="cuda")
+    L.call("ladder_conv_rgb_s2_fwd_f32", p(xd), p(wd), p(bd), p(y), N, H, W, Cout, L.ACT[act], st)
+    close(y, yr, 3e-6 if act != "tanh" else 2e-5, "fwd (fp32 instantiation)")      # (tanh: the device function's own error)
+    L.call("ladder_conv_rgb_s2_fwd_bnstats_f32", p(xd), p(wd), p(bd), p(y32), N, H, W, Cout, L.ACT[act], p(sums32), wsp, wsn, st)
+    assert torch.equal(y32, y)
+    y64 = y32.double().reshape(-1, Cout)
+    ref = torch.cat([y64.sum(0), (y64 * y64).sum(0)])
+    assert ((sums32[:2 * Cout].double() - ref).abs() <= 2e-6 * ref.abs().max()).all()
+    assert torch.equal(sums32[2 * Cout:3 * Cout], y32.reshape(-1, Cout).min(0).values) and torch.equal(sums32[3 * Cout:], y32.reshape(-1, Cout).max(0).values)
     L.call("ladder_conv_rgb_s2_fwd", p(xd), p(wd), p(bd), p(y), N, H, W, Cout, L.ACT[act], st)
     close(y, yr, 2e-5, "fwd")
     # the same call emitting the batch-norm statistics of its output (sum | sum of squares | min | max per channel): identical y
