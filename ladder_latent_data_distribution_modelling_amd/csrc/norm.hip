@@ -125,24 +125,37 @@ __global__ __launch_bounds__(256) void colstats_minmax_stage1_v4(const float* __
   }
 }
 
-// second stage for [nblk][4][C] partials: sums in fp64 (fixed order), extremes exactly; out [4C] = sum | sum of squares | min | max
-__global__ __launch_bounds__(256) void colstats_minmax_stage2(const float* __restrict__ ws, float* __restrict__ out, int nblk, int C) {
-  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+// second stage for [nblk][4][C] partials: sums in fp64 (fixed order), extremes exactly; out [4C] = sum | sum of squares | min | max.
+// 16 columns x 64 row lanes per workgroup, four independent accumulators per lane (round 4: with 16 row lanes and one dependent fp64 chain per
+// lane the 4 096 partial rows of the image-side conv took 47 us -- a third of the conv itself)
+__global__ __launch_bounds__(1024) void colstats_minmax_stage2(const float* __restrict__ ws, float* __restrict__ out, int nblk, int C) {
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;          // rl 0 .. 63
   const int i = blockIdx.x * 16 + cl;   // over 4C
   const int which = i < 4 * C ? i / C : 0, c = i < 4 * C ? i - which * C : 0;
-  double s = which == 2 ? (double)INFINITY : (which == 3 ? -(double)INFINITY : 0.0);
-  if (i < 4 * C)
-    for (int b = rl; b < nblk; b += 16) {
-      const double v = (double)ws[((size_t)b * 4 + which) * C + c];
-      s = which < 2 ? s + v : (which == 2 ? fmin(s, v) : fmax(s, v));
+  const double init = which == 2 ? (double)INFINITY : (which == 3 ? -(double)INFINITY : 0.0);
+  double s4[4] = {init, init, init, init};
+  if (i < 4 * C) {
+    int b = rl;
+    for (; b + 3 * 64 < nblk; b += 4 * 64) {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = (double)ws[((size_t)(b + u * 64) * 4 + which) * C + c];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s4[u] = which < 2 ? s4[u] + v[u] : (which == 2 ? fmin(s4[u], v[u]) : fmax(s4[u], v[u]));
     }
-  __shared__ double sm[16][17];
+    for (int u = 0; b < nblk; b += 64, ++u) {
+      const double v = (double)ws[((size_t)b * 4 + which) * C + c];
+      s4[u] = which < 2 ? s4[u] + v : (which == 2 ? fmin(s4[u], v) : fmax(s4[u], v));
+    }
+  }
+  const double s = which < 2 ? (s4[0] + s4[1]) + (s4[2] + s4[3]) : (which == 2 ? fmin(fmin(s4[0], s4[1]), fmin(s4[2], s4[3])) : fmax(fmax(s4[0], s4[1]), fmax(s4[2], s4[3])));
+  __shared__ double sm[64][17];
   sm[rl][cl] = s;
   __syncthreads();
   if (rl == 0 && i < 4 * C) {
     double t = sm[0][cl];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) t = which < 2 ? t + sm[k][cl] : (which == 2 ? fmin(t, sm[k][cl]) : fmax(t, sm[k][cl]));
+#pragma unroll 8
+    for (int k = 1; k < 64; ++k) t = which < 2 ? t + sm[k][cl] : (which == 2 ? fmin(t, sm[k][cl]) : fmax(t, sm[k][cl]));
     out[i] = (float)t;
   }
 }
@@ -1003,7 +1016,7 @@ int ladder_bn_fwd_stats_minmax(const float* x, float* sums4, size_t rows, int C,
   if (ws_bytes < nblk * 4 * (size_t)C * sizeof(float)) return LADDER_E_WORKSPACE;
   const size_t rpb = (rows + nblk - 1) / nblk;
   hipLaunchKernelGGL(colstats_minmax_stage1_v4, dim3((C + 63) / 64, (unsigned)nblk), dim3(256), 0, stream, x, (float*)ws, rows, C, rpb);
-  hipLaunchKernelGGL(colstats_minmax_stage2, dim3((4 * C + 15) / 16), dim3(256), 0, stream, (const float*)ws, sums4, (int)nblk, C);
+  hipLaunchKernelGGL(colstats_minmax_stage2, dim3((4 * C + 15) / 16), dim3(1024), 0, stream, (const float*)ws, sums4, (int)nblk, C);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
@@ -1011,7 +1024,7 @@ int ladder_bn_fwd_stats_minmax(const float* x, float* sums4, size_t rows, int C,
 // the second stage alone, for [nblk][4][C] partials emitted by a convolution epilogue
 int ladder_bn_stats_minmax_from_partials(const float* partials, int nblk, float* sums4, int C, ladder_stream_t stream) {
   if (nblk <= 0 || C <= 0) return LADDER_E_SHAPE;
-  hipLaunchKernelGGL(colstats_minmax_stage2, dim3((4 * C + 15) / 16), dim3(256), 0, stream, partials, sums4, nblk, C);
+  hipLaunchKernelGGL(colstats_minmax_stage2, dim3((4 * C + 15) / 16), dim3(1024), 0, stream, partials, sums4, nblk, C);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
