@@ -160,20 +160,25 @@ __global__ __launch_bounds__(1024) void colstats_minmax_stage2(const float* __re
   }
 }
 
-// stage 2: one workgroup per 64 (which,channel) columns; 4 row-lanes stride over the stage-1 partials, combined in a
-// fixed order (fp64) -> deterministic and ~nblk/4 dependent adds instead of nblk.
-__global__ __launch_bounds__(256) void colstats_stage2(const float* __restrict__ ws, float* __restrict__ out, int nblk, int C) {
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+// stage 2: one workgroup per 64 (which,channel) columns; 16 row-lanes stride over the stage-1 partials, combined in a
+// fixed order (fp64) -> deterministic and ~nblk/16 dependent adds instead of nblk (round 4: 4 row-lanes -> 16: 11 -> 6 us, 16 calls per iteration).
+__global__ __launch_bounds__(1024) void colstats_stage2(const float* __restrict__ ws, float* __restrict__ out, int nblk, int C) {
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;       // rl 0 .. 15
   const int i = blockIdx.x * 64 + cl;   // over 2C
   double s = 0.0;
   if (i < 2 * C) {
     const int which = i / C, c = i - which * C;
-    for (int b = rl; b < nblk; b += 4) s += (double)ws[((size_t)b * 2 + which) * C + c];
+    for (int b = rl; b < nblk; b += 16) s += (double)ws[((size_t)b * 2 + which) * C + c];
   }
-  __shared__ double sm[4][64];
+  __shared__ double sm[16][64];
   sm[rl][cl] = s;
   __syncthreads();
-  if (rl == 0 && i < 2 * C) out[i] = (float)((sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]));
+  if (rl == 0 && i < 2 * C) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sm[k][cl];
+    out[i] = (float)t;
+  }
 }
 
 // stage 2 for MANY partials (the per-tile column sums a convolution epilogue emits: thousands of blocks): 16 columns x 16 row lanes per
@@ -973,7 +978,7 @@ int ladder_bn_fwd_stats(const float* x, float* sums, size_t rows, int C, void* w
   else
     hipLaunchKernelGGL(colstats_stage1<1>, dim3((C + 63) / 64, (unsigned)nblk), dim3(256), 0, stream, x, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)ws, rows, C, rpb, 0);
-  hipLaunchKernelGGL(colstats_stage2, dim3((2 * C + 63) / 64), dim3(256), 0, stream, (const float*)ws, sums, (int)nblk, C);
+  hipLaunchKernelGGL(colstats_stage2, dim3((2 * C + 63) / 64), dim3(1024), 0, stream, (const float*)ws, sums, (int)nblk, C);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
@@ -1056,7 +1061,7 @@ int ladder_bn_bwd_stats(const float* dy, const float* x, const float* mean_rstd,
   else
     hipLaunchKernelGGL(colstats_stage1<2>, dim3((C + 63) / 64, (unsigned)nblk), dim3(256), 0, stream, dy, x, mean_rstd, gamma, beta,
                        (float*)ws, rows, C, rpb, act);
-  hipLaunchKernelGGL(colstats_stage2, dim3((2 * C + 63) / 64), dim3(256), 0, stream, (const float*)ws, dsums, (int)nblk, C);
+  hipLaunchKernelGGL(colstats_stage2, dim3((2 * C + 63) / 64), dim3(1024), 0, stream, (const float*)ws, dsums, (int)nblk, C);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

@@ -145,7 +145,8 @@ import json, os, sys
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, %(root)r)
 from oracle import ladder_oracle as O
-dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
+WORLD = %(world)d
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=WORLD)
 rank = dist.get_rank()
 d = np.load(os.path.join(%(root)r, "tests", "golden", "oracle_celeba.npz"))
 cfg = json.loads(str(d["config"]))
@@ -155,7 +156,8 @@ x = rng.random((4, 128, 128, 3)).astype(np.float32)
 noise = O.make_noise(cfg, 4, rng, np.float32)
 gm = dict(weights=d["gm_w"], means=d["gm_m"], covs=d["gm_c"])
 P = O.init_params(cfg, seed=1)
-sl = slice(2 * rank, 2 * rank + 2)
+per = 4 // WORLD
+sl = slice(per * rank, per * rank + per)
 nz = dict(eps_z=noise["eps_z"][sl], eps_t=noise["eps_t"][sl], eps_mc=noise["eps_mc"][:, sl])
 def summed(t):
     t = t.detach().clone()
@@ -190,13 +192,15 @@ dist.destroy_process_group()
 '''
 
 
-def test_data_parallel_scheme_world2_gloo(tmp_path):
-    """2 gloo ranks, each with half of the batch: all-reduced BN statistics (C2), scalar partials (C3) and summed
-    gradients of the global-mean loss (C1, clip AFTER the reduction) reproduce the single-process global-batch step."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_data_parallel_scheme_world2_gloo(tmp_path, world):
+    """2 (4) gloo ranks, each with half (a quarter: ONE image -- per-rank batch statistics would be degenerate) of the batch: all-reduced BN
+    statistics (C2), scalar partials (C3) and summed gradients of the global-mean loss (C1, clip AFTER the reduction) reproduce the
+    single-process global-batch step."""
     script = tmp_path / "dp_worker.py"
-    script.write_text(DP_WORKER % dict(root=ROOT, port=29500 + os.getpid() % 2000))
+    script.write_text(DP_WORKER % dict(root=ROOT, port=29500 + (os.getpid() + 7 * world) % 2000, world=world))
     procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-             for r in range(2)]
+             for r in range(world)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "DP_OK" in outs[0]
