@@ -78,6 +78,7 @@ CONV_CASES = [
     (64, 64, 64, 128, 128, 3, 2, "same", None),        # stride-2 halo filter gradient, 1 x 32-pixel patches of the 32 x 32 output
     (64, 32, 32, 256, 160, 3, 2, "same", "leaky_relu"),  # stride-2 halo filter gradient, 2 x 16 patches, Cout edge
     (128, 16, 16, 256, 512, 3, 2, "same", None),       # stride-2 halo filter gradient, 4 x 8 patches
+    (128, 8, 8, 256, 512, 3, 2, "same", "leaky_relu"),  # stride-2 backward-data: 128-tile parity classes split over K (strided second pass)
 ]
 
 
