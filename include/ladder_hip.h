@@ -356,12 +356,16 @@ int ladder_conv_rgb_s2_fwd_bnstats(const float* x, const float* w, const float* 
                                    ladder_stream_t stream);
 /* dw [3,3,3,Cout], db [Cout] (may be NULL); x_absmax / dy_absmax = the tensors' absolute-maximum records (ladder_absmax or a producer's). */
 /* Strict-fp32 instantiations of the two forward calls above (round 4): the im2col matrix and the filter stay fp32 in LDS, 14 K-steps of
- * v_mfma_f32_32x32x2_f32, no operand scaling; same arguments, same statistics workspace.  (The filter gradient of this layer in strict fp32 is
- * ladder_conv2d_bwd_filter.) */
+ * v_mfma_f32_32x32x2_f32, no operand scaling; same arguments, same statistics workspace. */
 int ladder_conv_rgb_s2_fwd_f32(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act,
                                ladder_stream_t stream);
 int ladder_conv_rgb_s2_fwd_bnstats_f32(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act,
                                        float* sums, void* ws, size_t ws_bytes, ladder_stream_t stream);
+/* Strict-fp32 filter (db != NULL: and bias) gradient of the same layer (reference: tf.gradients of the loss with respect to the first encoder
+ * conv2d's kernel / bias, models.py:398-405): fp32 im2col image in LDS, dY fragments straight from global memory, fp32 MFMA; no absmax records;
+ * workspace = ladder_conv_rgb_s2_bwd_filter_workspace_bytes. */
+int ladder_conv_rgb_s2_bwd_filter_f32(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cout, void* ws,
+                                      size_t ws_bytes, ladder_stream_t stream);
 size_t ladder_conv_rgb_s2_bwd_filter_workspace_bytes(int N, int H, int W, int Cout);
 int ladder_conv_rgb_s2_bwd_filter(const float* x, const float* x_absmax, const float* dy, const float* dy_absmax, float* dw, float* db,
                                   int N, int H, int W, int Cout, void* ws, size_t ws_bytes, ladder_stream_t stream);

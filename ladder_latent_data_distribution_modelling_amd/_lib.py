@@ -165,6 +165,7 @@ PROTOTYPES = {
     "ladder_bn_fwd_apply_planes": (_i, [_p, _p, _d, _p, _p, _p, _p, _p, _z, _i, _f, _i, _p, _p]),
     "ladder_conv_rgb_s2_bwd_filter_workspace_bytes": (_z, [_i] * 4),
     "ladder_conv_rgb_s2_bwd_filter": (_i, [_p] * 6 + [_i] * 4 + [_p, _z, _p]),
+    "ladder_conv_rgb_s2_bwd_filter_f32": (_i, [_p] * 4 + [_i] * 4 + [_p, _z, _p]),
     "ladder_bn_fwd_apply_absmax": (_i, [_p, _p, _d, _p, _p, _p, _p, _z, _i, _f, _i, _p, _p]),
     "ladder_bn_bwd_apply_absmax": (_i, [_p, _p, _p, _p, _p, _p, _d, _p, _p, _p, _z, _i, _i, _p, _p]),
     "ladder_in_style_fwd_absmax": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _z, _p, _p]),

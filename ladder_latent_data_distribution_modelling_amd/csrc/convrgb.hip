@@ -371,6 +371,104 @@ __global__ __launch_bounds__(RW_THREADS, 3) void conv_rgb_s2_wgrad_kernel(const 
   if (bias_part != nullptr && lh == 0 && n < Cout) bias_part[(size_t)split * Cout + n] = bsum * (1.f / cd);
 }
 
+// Strict-fp32 filter gradient (round 4): the same patch walk (2 x 32 output pixels per step, wavefront wv owns channels [32 wv, 32 wv + 32) of the
+// 128-channel slab), fp32 throughout.  A = im2col^T (rows = tap index k < 27 of 32, reduction index = pixel) is read from the fp32 im2col image
+// A[pixel][33] in LDS (lane = tap: consecutive words, no transposing read needed at 32 bits); B = dY is read ONCE, by the one wavefront that owns
+// its channel block, so its fragments go from global memory straight into registers (lane = channel: 128-byte segments) a whole patch ahead.
+// 32 K-steps of v_mfma_f32_32x32x2_f32 per patch and wavefront; the call is bound by reading dY (268 MB at batch 128).
+constexpr int RW_LDA32 = 33;
+__global__ __launch_bounds__(RW_THREADS, 4) void conv_rgb_s2_wgrad_f32_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                             float* __restrict__ part, float* __restrict__ bias_part,
+                                                                             const int N, const int H, const int W, const int Cout,
+                                                                             const int tiles_co, const int patches_per_split) {
+  __shared__ float A32[RW_PIX * RW_LDA32];
+  __shared__ float patch[RW_PATCH + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int split = blockIdx.x / tiles_co, co0 = (blockIdx.x - split * tiles_co) * 128;
+  const int Ho = H / 2, Wo = W / 2, WP = Wo / RW_PW, HP = Ho / RW_PH;
+  const int q_total = N * HP * WP;
+  const int q0 = split * patches_per_split, q1 = min(q_total, q0 + patches_per_split);
+  const int co = co0 + wv * 32 + l31;
+  const bool co_ok = co < Cout;
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  float bsum = 0.f;
+  float xr[RW_XU];                                             // the NEXT patch's input floats of this thread (one patch ahead)
+  auto decode = [&](int q, int& img, int& h0, int& w0) {
+    img = q / (HP * WP);
+    const int rem = q - img * (HP * WP), hp = rem / WP;
+    h0 = hp * RW_PH;
+    w0 = (rem - hp * WP) * RW_PW;
+  };
+  auto load_x = [&](int q) {
+    int img, h0, w0;
+    decode(q, img, h0, w0);
+#pragma unroll
+    for (int i = 0; i < RW_XU; ++i) {
+      const int v = tid + i * RW_THREADS;
+      const int r = v / (RW_XW * 3), c3 = v - r * (RW_XW * 3);
+      const int hi = 2 * h0 + r, wi3 = 2 * w0 * 3 + c3;
+      xr[i] = (v < RW_PATCH && hi < H && wi3 < W * 3) ? x[((long)img * H + hi) * W * 3 + wi3] : 0.f;
+    }
+  };
+
+  if (q0 < q1) load_x(q0);
+  for (int q = q0; q < q1; ++q) {
+    // this patch's dY fragments: requested first, they travel while the input patch and the im2col image go through LDS (several workgroups
+    // per CU -- 12 KB of LDS, ~90 registers -- cover the rest of the latency)
+    float b[RW_PIX / 2];
+    {
+      int img, h0, w0;
+      decode(q, img, h0, w0);
+      // pixel 2 ks + lh of the patch (row ks / 16, column 2 (ks % 16) + lh): a wave-uniform base per k-step + ONE per-lane offset (channel and
+      // pixel parity), so the 32 loads take scalar bases instead of 32 vector address pairs
+      const float* du = dy + (((long)img * Ho + h0) * Wo + w0) * Cout;
+      const unsigned loff = (unsigned)(co + lh * Cout);
+#pragma unroll
+      for (int ks = 0; ks < RW_PIX / 2; ++ks) {
+        const float* pk = du + ((long)(ks >> 4) * Wo + 2 * (ks & 15)) * Cout;
+        b[ks] = co_ok ? pk[loff] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RW_XU; ++i)
+      if (tid + i * RW_THREADS < RW_PATCH) patch[tid + i * RW_THREADS] = xr[i];
+    __syncthreads();
+    if (q + 1 < q1) load_x(q + 1);
+    {
+      const int p = tid & (RW_PIX - 1), kq = tid >> 6, pr = p >> 5, pc = p & 31;   // thread = (pixel, 8 taps)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = kq * 8 + j;
+        const int tap = k / 3, ci = k - tap * 3, r = tap / 3, sx = tap - r * 3;
+        A32[p * RW_LDA32 + k] = k < 27 ? patch[((2 * pr + r) * RW_XW + 2 * pc + sx) * 3 + ci] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < RW_PIX / 2; ++ks) {
+      const float a = A32[(2 * ks + lh) * RW_LDA32 + l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[ks], acc, 0, 0, 0);
+      bsum += b[ks];
+    }
+    __syncthreads();                                           // (the im2col image and the patch are rewritten next)
+  }
+
+  float* o = part + (size_t)split * 27 * Cout;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int k = (e & 3) + 8 * (e >> 2) + 4 * lh;
+    if (k < 27 && co_ok) o[(size_t)k * Cout + co] = acc[e];
+  }
+  if (bias_part != nullptr) {
+    const float v = bsum + __shfl_down(bsum, 32, 64);          // even + odd pixels of the k-step pairs
+    if (lh == 0 && co_ok) bias_part[(size_t)split * Cout + co] = v;
+  }
+}
+
 struct RgbWgradPlan { int tiles_co, splits, pps; };
 RgbWgradPlan plan_rgb_wgrad(int N, int H, int W, int Cout) {
   RgbWgradPlan p;
@@ -450,6 +548,24 @@ int ladder_conv_rgb_s2_fwd_bnstats_f32(const float* x, const float* w, const flo
   const int rc = rgb_fwd_launch(x, w, bias, y, N, H, W, Cout, act, (float*)ws, stream, true);
   if (rc != LADDER_OK) return rc;
   return ladder_bn_stats_minmax_from_partials((const float*)ws, N * (H / 2 / RGB_TH) * (W / 2 / RGB_TW), sums, Cout, stream);
+}
+
+// Strict-fp32 filter (and bias) gradient of the same layer: no absmax records, same workspace as ladder_conv_rgb_s2_bwd_filter.
+int ladder_conv_rgb_s2_bwd_filter_f32(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cout, void* ws,
+                                      size_t ws_bytes, ladder_stream_t stream) {
+  if (!rgb_s2_ok(N, H, W, 3, Cout, 3, 3, 2, 0, 0)) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(dw)) return LADDER_E_ALIGN;
+  const RgbWgradPlan p = plan_rgb_wgrad(N, H, W, Cout);
+  if (ws == nullptr || ws_bytes < (size_t)p.splits * (27 * (size_t)Cout + Cout) * sizeof(float)) return LADDER_E_WORKSPACE;
+  float* part = (float*)ws;
+  float* bias_part = db != nullptr ? part + (size_t)p.splits * 27 * Cout : nullptr;
+  hipLaunchKernelGGL(conv_rgb_s2_wgrad_f32_kernel, dim3(p.tiles_co * p.splits), dim3(RW_THREADS), 0, stream, x, dy, part, bias_part, N, H, W, Cout,
+                     p.tiles_co, p.pps);
+  LADDER_CHECK_LAUNCH();
+  int rc = ladder_reduce_splits(part, dw, p.splits, (size_t)27 * Cout, stream);
+  if (rc != LADDER_OK) return rc;
+  if (db != nullptr) rc = ladder_reduce_splits(bias_part, db, p.splits, (size_t)Cout, stream);
+  return rc;
 }
 
 size_t ladder_conv_rgb_s2_bwd_filter_workspace_bytes(int N, int H, int W, int Cout) {

@@ -836,6 +836,12 @@ class Conv2D:
                 L.call("ladder_conv_rgb_s2_bwd_filter", _p(x), _p(xa), _p(dy), _p(da), _p(self.ps.g[self.name + "/kernel"]),
                        _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, N, H, W, self.cout, wsp, wsn, self.ctx.stream)
             wgrad = False
+        if wgrad and self._rgb_fwd32(N, H, W):            # strict fp32: the fp32 filter-gradient kernel of the same layer
+            with self.ctx.side_or_main(x, dy):
+                wsp, wsn = self.ctx.ws(L.query("ladder_conv_rgb_s2_bwd_filter_workspace_bytes", N, H, W, self.cout))
+                L.call("ladder_conv_rgb_s2_bwd_filter_f32", _p(x), _p(dy), _p(self.ps.g[self.name + "/kernel"]),
+                       _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, N, H, W, self.cout, wsp, wsn, self.ctx.stream)
+            wgrad = False
         dy_amax = None
         split_w = bool(wgrad and self._split_ok(N, H, W, self.cin, self.cout)
                        and L.query("ladder_conv3x3_wgrad_split_eligible", N, H, W, self.cin, self.cout, self.ctx.ns))

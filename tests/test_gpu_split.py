@@ -493,6 +493,18 @@ def test_conv_rgb_stride2(gpu_ctx, case):
     dy[0, 0, 0, :] *= 50.0
     yr.backward(torch.tensor(dy, dtype=torch.float64))
     dyd = dev(dy)
+    # strict-fp32 filter / bias gradient (round 4): the fp32 kernels' tolerance; db == NULL leaves dw unchanged
+    if act is None or act == "leaky_relu":
+        dyg32 = dyd.clone()
+        if act is not None:
+            L.call("ladder_act_bwd", p(dyg32), p(dev(yr.detach().numpy())), p(dyg32), dyg32.numel(), L.ACT[act], st)
+        wsf, wsfn = gpu_ctx.ws(L.query("ladder_conv_rgb_s2_bwd_filter_workspace_bytes", N, H, W, Cout))
+        dw32, db32, dw32b = torch.empty_like(wd), torch.empty_like(bd), torch.empty_like(wd)
+        L.call("ladder_conv_rgb_s2_bwd_filter_f32", p(xd), p(dyg32), p(dw32), p(db32), N, H, W, Cout, wsf, wsfn, st)
+        close(dw32, wt.grad, 3e-6, "dw (fp32 instantiation)")
+        close(db32, bt.grad, 3e-6, "db (fp32 instantiation)")
+        L.call("ladder_conv_rgb_s2_bwd_filter_f32", p(xd), p(dyg32), p(dw32b), None, N, H, W, Cout, wsf, wsfn, st)
+        assert torch.equal(dw32b, dw32)
     if act is not None:
         L.call("ladder_act_bwd", p(dyd), p(dev(yr.detach().numpy())), p(dyd), dyd.numel(), L.ACT[act], st)
     xa, da = absmax(L, xd, st), absmax(L, dyd, st)
