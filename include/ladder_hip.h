@@ -145,7 +145,9 @@ int ladder_absmax_samples(const float* x, int n_samples, size_t per_sample, floa
  *   transpose_flip = 2: the four output-parity classes of a stride-2 backward-data as four 128-channel output tiles (ladder_conv3x3_s2_bwd_data_split).
  *   transpose_flip = 3: the effective taps of the upsample-fused forward, four output-parity classes (Cout = 4 x 128; ladder_conv3x3_up2_split).
  *   transpose_flip = 4: the effective taps of its backward-data, the four pixel-parity classes of dy as input groups (Cin = 4 x C;
- *   ladder_conv3x3_up2_bwd_data_split).  For 3 and 4 the bank's absmax record holds 4 x max|w| (a bound of the effective taps). */
+ *   ladder_conv3x3_up2_bwd_data_split).  For 3 and 4 the bank's absmax record holds 4 x max|w| (a bound of the effective taps).
+ *   transpose_flip = 5 (strict fp32 only): forward of a 3x3 / stride-2 conv, the four pixel-parity classes of x as input groups (Cin = 4 x C;
+ *   ladder_conv3x3_s2_fwd_f32). */
 size_t ladder_filter_pack_split_bytes(int ntaps, int Cin, int Cout, int prec);
 int ladder_filter_pack_split(const float* w, void* packed, int ntaps, int Cin, int Cout, int transpose_flip, int prec,
                              ladder_stream_t stream);
@@ -164,6 +166,10 @@ size_t ladder_filter_pack_split_multi_scratch_bytes(int njobs);
 int ladder_filter_pack_split_multi(const ladder_pack_job_t* jobs_dev, int njobs, int total_blocks, int prec, void* scratch,
                                    size_t scratch_bytes, ladder_stream_t stream);
 int ladder_conv3x3_split_eligible(int N, int H, int W, int Cin, int Cout);
+/* Strict fp32 (prec = LADDER_PREC_F32) additionally takes the 16- and 8-pixel-wide maps (round 5, csrc/convf32s.hip: 16x16 / 8x16 / 8x8-pixel
+ * sub-patches, 64- or 128-channel tiles, >= 256 workgroups; H % 8 == 0, W % 8 == 0, Cin % 16 == 0, Cout % 4 == 0) -- decoder conv2d_3
+ * and the backward-data of the encoder's deep layers (codes/models.py:420-460, 539-543).  1 when ladder_conv3x3_split(prec F32) takes the call. */
+int ladder_conv3x3_f32_eligible(int N, int H, int W, int Cin, int Cout);
 /* y = act(conv3x3_same(x, F) + bias) with F as packed above (bias may be NULL; x_absmax is read only for LADDER_PREC_F16X3 and may
  * hold any upper bound of max |x|: a looser bound only raises the absolute representation floor 2^-38 * bound).  y_absmax (may be
  * NULL): record of the output, produced in the epilogue. */
@@ -187,8 +193,21 @@ int ladder_conv3x3_s2_bwd_data_split_eligible(int N, int H, int W, int Cin, int 
                                               int pad_l);
 int ladder_conv3x3_s2_bwd_data_split(const float* dy, const float* dy_absmax, const void* packed_s2, float* dx, float* dx_absmax, int N, int H,
                                      int W, int Cin, int Ho, int Wo, int Cout, int prec, ladder_stream_t stream);
+/* Strict fp32 (round 5): the call above with prec = LADDER_PREC_F32 takes ANY class width Cin (% 64 == 0 on the small-map tilings of
+ * csrc/convf32s.hip, 128 on the 8x32-pixel tiling) and 16- / 8-pixel-wide dy maps -- encoder conv2d_2 ... conv2d_3 (codes/models.py:420-439). */
+int ladder_conv3x3_s2_bwd_data_f32_eligible(int N, int H, int W, int Cin, int Ho, int Wo, int Cout);
+/* FORWARD of a 3x3 / stride-2 / SAME convolution over an even map (TF padding: pad_t = pad_l = 0; codes/models.py:409-439, encoder conv2d_1 ...
+ * conv2d_3) as ONE launch of the fp32 halo kernels: a stride-1 correlation over the four pixel-parity classes of x [N, H, W, Cin] taken as four
+ * groups of input slabs, each group walking only its 4 / 2 / 2 / 1 taps -- x is staged once per slab for all taps instead of gathered per tap.
+ * bank_s2f = ladder_filter_pack_split(w, ., 9, 4 * Cin, Cout, transpose_flip = 5, LADDER_PREC_F32) from the layer's HWIO bank [3][3][Cin][Cout].
+ * y [N, H/2, W/2, Cout] = act(conv + bias).  Strict fp32 only. */
+int ladder_conv3x3_s2_fwd_f32_eligible(int N, int H, int W, int Cin, int Ho, int Wo, int Cout);
+int ladder_conv3x3_s2_fwd_f32(const float* x, const void* bank_s2f, const float* bias, float* y, int N, int H, int W, int Cin, int Ho, int Wo,
+                              int Cout, int act, ladder_stream_t stream);
 
-/* A 3x3 / SAME convolution of the factor-2 legacy-bilinear upsample of x [N, H, W, Cin] -> y [N, 2H, 2W, 128], without the upsampled tensor
+/* (strict fp32, round 5: Cout may be any multiple of 64 and the low-resolution map 16 or 8 pixels wide -- decoder conv2d_5 / conv2d_4,
+ * codes/models.py:544-560; the fused projection form stays at Cout = 128)
+ * A 3x3 / SAME convolution of the factor-2 legacy-bilinear upsample of x [N, H, W, Cin] -> y [N, 2H, 2W, 128], without the upsampled tensor
  * (replaces tf.image.resize_images(x, [2H, 2W]) + tf.layers.conv2d of the decoder, codes/models.py:554-578, in one launch; see csrc/convsplit.hip).
  * packed_up2 = ladder_filter_pack_split(w, ., 9, Cin, 4 * 128, transpose_flip = 3, prec) from the layer's HWIO bank; bias [128]; the absmax
  * record of x as for ladder_conv3x3_split.  The last output row and column are NOT final after this call: ladder_conv3x3_up2_edges. */
@@ -226,7 +245,8 @@ int ladder_conv3x3_up2_bwd_borders(const float* dy, const float* w, float* dx, i
  * tap tiles G_ab[dr][dc] = sum x~[i+dr-1, j+dc-1] (x) dy[2i+a, 2j+b] (25 instead of the 36 the direct filter gradient on the upsampled map
  * accumulates), recombined with the tables of filterbank.h, plus the 1x3 / 3x1 filter gradients of the last output row / column.
  * Replaces ladder_conv2d_bwd_filter on the upsampled tensor (tf.gradients of codes/models.py:554-578 w.r.t. conv2d_6 / conv2d_7 kernels).
- * W % 32 == 0, Cin % 64 == 0, Cout % 4 == 0, >= 2048 low-resolution 1x32-pixel patches. */
+ * Cin % 64 == 0, Cout % 4 == 0; patches of 64 low-resolution pixels: 2 x 32 (W % 32 == 0, >= 1024 patches), 4 x 16 or 8 x 8 (round 5: W % 16 == 0 /
+ * W % 8 == 0, >= 128 patches -- decoder conv2d_5 / conv2d_4, codes/models.py:544-560). */
 int ladder_conv3x3_up2_wgrad_eligible(int N, int H, int W, int Cin, int Cout);
 size_t ladder_conv3x3_up2_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int ladder_conv3x3_up2_wgrad(const float* x, int x_upsampled, const float* dy, float* dw, float* db, int N, int H, int W, int Cin, int Cout,

@@ -140,6 +140,10 @@ PROTOTYPES = {
     "ladder_conv3x3_up2_edges_workspace_bytes": (_z, [_i] * 5),
     "ladder_conv3x3_up2_edges": (_i, [_p] * 8 + [_i] * 8 + [_p, _z, _p]),
     "ladder_conv3x3_s2_bwd_data_split": (_i, [_p, _p, _p, _p, _p] + [_i] * 8 + [_p]),
+    "ladder_conv3x3_f32_eligible": (_i, [_i] * 5),
+    "ladder_conv3x3_s2_bwd_data_f32_eligible": (_i, [_i] * 7),
+    "ladder_conv3x3_s2_fwd_f32_eligible": (_i, [_i] * 7),
+    "ladder_conv3x3_s2_fwd_f32": (_i, [_p, _p, _p, _p] + [_i] * 8 + [_p]),
     "ladder_dense_small_eligible": (_i, [_i, _i, _i]),
     "ladder_dense_fwd_small": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "ladder_dense_bwd_data_small": (_i, [_p, _p, _p, _i, _i, _i, _p, _i, _p]),

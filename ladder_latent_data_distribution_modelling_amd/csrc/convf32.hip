@@ -348,14 +348,28 @@ int filter_pack_f32_multi(const ladder_pack_job_t* jobs_dev, int njobs, int tota
   return LADDER_OK;
 }
 
+// the 8x32-pixel x 128-channel tiling takes this call (class launches: classes of exactly 128 channels)
+static bool conv3x3_f32_big_ok(int N, int H, int W, int Cin, int Cout, int s2_out) {
+  if (!conv3x3_f32_halo_ok(N, H, W, Cin, Cout)) return false;
+  if ((s2_out == 4 || s2_out == 5) && (Cin % (4 * FK)) != 0) return false;
+  if ((s2_out >= 1 && s2_out <= 3) && Cout != 4 * FH_BN) return false;
+  return true;
+}
+
+bool conv3x3_f32_any_ok(int N, int H, int W, int Cin, int Cout, int s2_out) {
+  return conv3x3_f32_big_ok(N, H, W, Cin, Cout, s2_out) || conv3x3_f32s_ok(N, H, W, Cin, Cout, s2_out);
+}
+
 int conv3x3_f32_launch(const float* x, const float* bank, const float* bias, float* y, const float* pw, const float* pb, float* pout,
                        int pco, int N, int H, int W, int Cin, int Cout, int act, hipStream_t stream, unsigned long long tap_masks,
                        int s2_out) {
-  if (!conv3x3_f32_halo_ok(N, H, W, Cin, Cout)) return LADDER_E_SHAPE;
+  if (!conv3x3_f32_big_ok(N, H, W, Cin, Cout, s2_out)) {     // small maps / wide classes: convf32s.hip (no fused projection there)
+    if (pout != nullptr) return LADDER_E_SHAPE;
+    return conv3x3_f32s_launch(x, bank, bias, y, N, H, W, Cin, Cout, act, stream, tap_masks, s2_out);
+  }
   if (pout != nullptr && (pw == nullptr || pco < 1 || pco > 4 || (Cout > FH_BN && s2_out < 2) || !ladder_aligned16(pw))) return LADDER_E_SHAPE;
   if (pout == nullptr && y == nullptr) return LADDER_E_SHAPE;
-  if (s2_out == 4 && (pout != nullptr || (Cin % (4 * FK)) != 0)) return LADDER_E_SHAPE;
-  if ((s2_out >= 1 && s2_out <= 3) && Cout != 4 * FH_BN) return LADDER_E_SHAPE;          // class tiles = the layer's 128 channels each
+  if ((s2_out == 4 || s2_out == 5) && pout != nullptr) return LADDER_E_SHAPE;
   if (!ladder_aligned16(x) || !ladder_aligned16(bank) || !ladder_aligned16(y) || (bias != nullptr && !ladder_aligned16(bias)))
     return LADDER_E_ALIGN;
   const int tiles_n = (Cout + FH_BN - 1) / FH_BN;
@@ -367,7 +381,7 @@ int conv3x3_f32_launch(const float* x, const float* bank, const float* bias, flo
   const int s2x = s2_out | (cls_loop ? 0x100 : 0);
 #define LADDER_F32_LAUNCH(PROJ_, UPM_) \
   hipLaunchKernelGGL((conv3x3_halo_f32_kernel<PROJ_, UPM_>), grid, block, 0, stream, x, bank, bias, y, N, H, W, Cin, Cout, act, tiles_n, pw, pb, pout, pco, tap_masks, s2x)
-  if (s2_out == 4) LADDER_F32_LAUNCH(false, 2);
+  if (s2_out == 4 || s2_out == 5) LADDER_F32_LAUNCH(false, 2);
   else if (s2_out == 2 || s2_out == 3) { if (pout != nullptr) LADDER_F32_LAUNCH(true, 1); else LADDER_F32_LAUNCH(false, 1); }
   else { if (pout != nullptr) LADDER_F32_LAUNCH(true, 0); else LADDER_F32_LAUNCH(false, 0); }
 #undef LADDER_F32_LAUNCH
@@ -399,26 +413,28 @@ namespace {
 // in proportion to that cost, so all workgroups of a launch run equally long (a fixed class order would hand every shader engine one class:
 // see class_tile in common.h).  The signs of the halo (negated above / left of the map) are applied to the A fragments after the LDS read:
 // the DMA staging cannot negate.
-constexpr int WU_CI = 64, WU_CO = 128, WU_PW = 32, WU_HW = WU_PW + 2;
-#ifndef WU_PH_ROWS
-#define WU_PH_ROWS 2      // rows per staged patch: 2 x 32 pixels halve the halo overhead and double the MFMA work behind one LDS-DMA round trip
-#endif
-constexpr int WU_PH = WU_PH_ROWS, WU_HH = WU_PH + 2;
-constexpr int WU_THREADS = 768, WU_PIX = WU_PH * WU_PW;
-constexpr int WU_XU = WU_HH * WU_HW * (WU_CI / 4), WU_DU = WU_PIX * (WU_CO / 4);           // float4 units per patch: 1632, 1024
-constexpr int WU_XN = (WU_XU + WU_THREADS - 1) / WU_THREADS, WU_DN = (WU_DU + WU_THREADS - 1) / WU_THREADS;   // 3, 2
-constexpr int WU_XF = WU_HH * WU_HW * WU_CI, WU_DF = WU_PIX * WU_CO;                       // floats per buffer
+// A staged patch is 64 low-resolution pixels: 2 x 32 (maps of width % 32 == 0: 2 rows halve the halo overhead of a 1-row patch and double
+// the MFMA work behind one LDS-DMA round trip), 4 x 16 or 8 x 8 (round 5: the 16x16 / 8x8 maps of decoder conv2d_5 / conv2d_4).
+constexpr int WU_CI = 64, WU_CO = 128, WU_THREADS = 768, WU_PIX = 64;
+constexpr int WU_DU = WU_PIX * (WU_CO / 4), WU_DN = (WU_DU + WU_THREADS - 1) / WU_THREADS, WU_DF = WU_PIX * WU_CO;     // dY: float4 units per patch (1024), per lane (2), floats
+template <int PW> struct WuGeo {
+  static constexpr int PH = WU_PIX / PW, HW = PW + 2, HH = PH + 2;
+  static constexpr int XU = HH * HW * (WU_CI / 4), XN = (XU + WU_THREADS - 1) / WU_THREADS, XF = HH * HW * WU_CI;        // input halo: float4 units (2176 / 1728 / 1600), per lane (3), floats
+  static constexpr int LDS_FLOATS = 2 * (XF + WU_DF) + XN * WU_THREADS;
+};
 constexpr int WU_NTAPS[4] = {9, 6, 6, 4}, WU_TAP0[4] = {0, 9, 15, 21};                    // taps per class, first combination index
 
-struct WgradUp2Plan { bool ok; int tiles_ci, tiles_co, ns[4], s0[4], total; };               // splits per class, first workgroup of each class (per slab pair)
+struct WgradUp2Plan { bool ok; int pw, tiles_ci, tiles_co, ns[4], s0[4], total; };               // splits per class, first workgroup of each class (per slab pair)
 
-template <int CLS>
+template <int CLS, int WU_PW>
 __device__ __forceinline__ void wgrad_up2_body(float* __restrict__ lds, const float* __restrict__ x, const float* __restrict__ dy,
                                                float* __restrict__ out, float* __restrict__ bias_part, const int N, const int H, const int W,
                                                const int Cin, const int Cout, const int ci0, const int co0, const int split, const int nsplits,
                                                const int xs) {
   constexpr int A = CLS >> 1, B = CLS & 1, NS = 3 - B;
   constexpr bool MODEB = A == 1;
+  using WG_ = WuGeo<WU_PW>;
+  constexpr int WU_PH = WG_::PH, WU_HW = WG_::HW, WU_XU = WG_::XU, WU_XN = WG_::XN, WU_XF = WG_::XF;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;            // 12 wavefronts
   const int l31 = lane & 31, lh = lane >> 5;
@@ -517,7 +533,7 @@ __device__ __forceinline__ void wgrad_up2_body(float* __restrict__ lds, const fl
       constexpr int NA = MODEB ? 1 : 3, NB = MODEB ? 4 : 2;
       float ac[NA], bc[NB], an[NA], bn[NB];
       auto load_frag = [&](const int ks, float* af, float* bf) {
-        const int arow = ((ks >> 4) * WU_HW + ((2 * ks) & 31)) * WU_CI;
+        const int arow = (((2 * ks) / WU_PW) * WU_HW + ((2 * ks) & (WU_PW - 1))) * WU_CI;
         if (!MODEB) {
 #pragma unroll
           for (int s = B; s < 3; ++s) af[s] = base[a_off + s * WU_CI + arow];
@@ -540,8 +556,8 @@ __device__ __forceinline__ void wgrad_up2_body(float* __restrict__ lds, const fl
       for (int ks = 0; ks < WU_PIX / 2; ++ks) {
         if (ks + 1 < WU_PIX / 2) load_frag(ks + 1, an, bn);
         __builtin_amdgcn_sched_barrier(0);
-        const bool col0 = ((2 * ks) & 31) == 0;
-        const unsigned rsign = (ks < 16) ? rsign0 : 0u;
+        const bool col0 = ((2 * ks) & (WU_PW - 1)) == 0;
+        const unsigned rsign = (2 * ks < WU_PW) ? rsign0 : 0u;
         if (!MODEB) {
           float a[3];
 #pragma unroll
@@ -619,12 +635,13 @@ __device__ __forceinline__ void wgrad_up2_body(float* __restrict__ lds, const fl
   }
 }
 
+template <int WU_PW>
 __global__ __launch_bounds__(WU_THREADS, 3) void wgrad3x3_up2_f32_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                          float* __restrict__ out, float* __restrict__ bias_part,
                                                                          const int N, const int H, const int W, const int Cin, const int Cout,
                                                                          const WgradUp2Plan p, const int xs) {
   // ONE LDS object (hipcc serialises LDS-DMA against ds_reads when several __shared__ objects exist): [buf][halo | dY]
-  __shared__ __attribute__((aligned(16))) float lds[2 * (WU_XF + WU_DF) + WU_XN * WU_THREADS];   // + the lanes' packed halo units
+  __shared__ __attribute__((aligned(16))) float lds[WuGeo<WU_PW>::LDS_FLOATS];   // + the lanes' packed halo units
   // workgroup -> (slab pair, class, split of the class): the classes of a pair are laid out one after another
   const int pair = blockIdx.x / p.total, w = blockIdx.x - pair * p.total;
   const int cls = w >= p.s0[3] ? 3 : (w >= p.s0[2] ? 2 : (w >= p.s0[1] ? 1 : 0));
@@ -636,10 +653,10 @@ __global__ __launch_bounds__(WU_THREADS, 3) void wgrad3x3_up2_f32_kernel(const f
   float* o = out + off * Cin * Cout;
   float* bp = bias_part != nullptr ? bias_part + (size_t)w * Cout : nullptr;
   switch (cls) {
-    case 0: wgrad_up2_body<0>(lds, x, dy, o, bp, N, H, W, Cin, Cout, ci0, co0, split, p.ns[0], xs); break;
-    case 1: wgrad_up2_body<1>(lds, x, dy, o, bp, N, H, W, Cin, Cout, ci0, co0, split, p.ns[1], xs); break;
-    case 2: wgrad_up2_body<2>(lds, x, dy, o, bp, N, H, W, Cin, Cout, ci0, co0, split, p.ns[2], xs); break;
-    default: wgrad_up2_body<3>(lds, x, dy, o, bp, N, H, W, Cin, Cout, ci0, co0, split, p.ns[3], xs); break;
+    case 0: wgrad_up2_body<0, WU_PW>(lds, x, dy, o, bp, N, H, W, Cin, Cout, ci0, co0, split, p.ns[0], xs); break;
+    case 1: wgrad_up2_body<1, WU_PW>(lds, x, dy, o, bp, N, H, W, Cin, Cout, ci0, co0, split, p.ns[1], xs); break;
+    case 2: wgrad_up2_body<2, WU_PW>(lds, x, dy, o, bp, N, H, W, Cin, Cout, ci0, co0, split, p.ns[2], xs); break;
+    default: wgrad_up2_body<3, WU_PW>(lds, x, dy, o, bp, N, H, W, Cin, Cout, ci0, co0, split, p.ns[3], xs); break;
   }
 }
 
@@ -832,7 +849,10 @@ __global__ __launch_bounds__(256) void up2_border_fixup_kernel(const float* __re
 
 WgradUp2Plan plan_wgrad_up2(int N, int H, int W, int Cin, int Cout) {
   WgradUp2Plan p{};
-  p.ok = N > 0 && H >= 2 && (W % WU_PW) == 0 && (Cin % WU_CI) == 0 && (Cout % 4) == 0 && Cout >= 64 && (long)N * H * (W / WU_PW) >= 2048;
+  p.pw = (W % 32) == 0 ? 32 : ((W % 16) == 0 ? 16 : 8);                                // patch width: 2 x 32, 4 x 16 or 8 x 8 pixels
+  const int ph = WU_PIX / p.pw;
+  p.ok = N > 0 && H >= 2 && (W % p.pw) == 0 && (Cin % WU_CI) == 0 && (Cout % 4) == 0 && Cout >= 64 &&
+         (long)N * ((H + ph - 1) / ph) * (W / p.pw) >= (p.pw == 32 ? 1024 : 128);
   if (!p.ok) return p;
   p.tiles_ci = Cin / WU_CI;
   p.tiles_co = (Cout + WU_CO - 1) / WU_CO;
@@ -845,8 +865,8 @@ WgradUp2Plan plan_wgrad_up2(int N, int H, int W, int Cin, int Cout) {
   // time (16.0 / 10.7 / 10.7 / 7.1 us) + ~4-5 us per patch that the direct kernel pays as well (its matrix pipe is 76 % busy); 512 or
   // 2048 workgroups per launch measure the same
   const int cost[4] = {210, 146, 156, 109};
-  const long g0 = (H + WU_PH - 1) / WU_PH, g1 = (H - 1 + WU_PH - 1) / WU_PH;          // row groups of the classes a = 0 / a = 1
-  const long q[4] = {(long)N * g0 * (W / WU_PW), (long)N * g0 * (W / WU_PW), (long)N * g1 * (W / WU_PW), (long)N * g1 * (W / WU_PW)};
+  const long g0 = (H + ph - 1) / ph, g1 = (H - 1 + ph - 1) / ph;                      // row groups of the classes a = 0 / a = 1
+  const long q[4] = {(long)N * g0 * (W / p.pw), (long)N * g0 * (W / p.pw), (long)N * g1 * (W / p.pw), (long)N * g1 * (W / p.pw)};
   double tot = 0;
   for (int c = 0; c < 4; ++c) tot += (double)cost[c] * q[c];
   int used = 0;
@@ -916,8 +936,13 @@ int ladder_conv3x3_up2_wgrad(const float* x, int x_upsampled, const float* dy, f
   const int xs = x_upsampled ? 2 : 1;
   if (db != nullptr && hipMemsetAsync(bias_part, 0, (size_t)nbias * Cout * 4, stream) != hipSuccess) return LADDER_E_LAUNCH;
   // bias partial rows: the kernel indexes them by the workgroup's position inside its pair (w) -- pairs with ci0 == 0 are the first tiles_co
-  hipLaunchKernelGGL(wgrad3x3_up2_f32_kernel, dim3(p.tiles_ci * p.tiles_co * p.total), dim3(WU_THREADS), 0, stream, x, dy, part,
-                     db != nullptr ? bias_part : nullptr, N, H, W, Cin, Cout, p, xs);
+#define LADDER_WU_LAUNCH(PW_) \
+  hipLaunchKernelGGL(wgrad3x3_up2_f32_kernel<PW_>, dim3(p.tiles_ci * p.tiles_co * p.total), dim3(WU_THREADS), 0, stream, x, dy, part, \
+                     db != nullptr ? bias_part : nullptr, N, H, W, Cin, Cout, p, xs)
+  if (p.pw == 32) LADDER_WU_LAUNCH(32);
+  else if (p.pw == 16) LADDER_WU_LAUNCH(16);
+  else LADDER_WU_LAUNCH(8);
+#undef LADDER_WU_LAUNCH
   size_t off = 0;
   for (int c = 0; c < 4; ++c) {                            // G[class taps] = sum over the class's splits (fixed order)
     const int rc = ladder_reduce_splits(part + off * kn, G + (size_t)WU_TAP0[c] * kn, p.ns[c], (size_t)WU_NTAPS[c] * kn, stream);

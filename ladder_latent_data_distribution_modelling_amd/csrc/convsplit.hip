@@ -1244,7 +1244,7 @@ size_t ladder_filter_pack_split_bytes(int ntaps, int Cin, int Cout, int prec) {
 int ladder_filter_pack_split(const float* w, void* packed, int ntaps, int Cin, int Cout, int transpose_flip, int prec,
                              ladder_stream_t stream) {
   if (prec == LADDER_PREC_F32) {                                 // strict fp32: the fp32 bank [ntaps][Cin][Cout] of the orientation (convf32.hip)
-    if (ntaps <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 16) != 0 || transpose_flip < 0 || transpose_flip > 4) return LADDER_E_SHAPE;
+    if (ntaps <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 16) != 0 || transpose_flip < 0 || transpose_flip > 5) return LADDER_E_SHAPE;
     if (!ladder_aligned16(packed) || !ladder_aligned16(w)) return LADDER_E_ALIGN;
     return filter_pack_f32(w, (float*)packed, ntaps, Cin, Cout, transpose_flip, stream);
   }
@@ -1373,6 +1373,11 @@ int ladder_conv3x3_s2_bwd_data_split_eligible(int N, int H, int W, int Cin, int 
 
 int ladder_conv3x3_s2_bwd_data_split(const float* dy, const float* dy_absmax, const void* packed_s2, float* dx, float* dx_absmax, int N, int H,
                                      int W, int Cin, int Ho, int Wo, int Cout, int prec, ladder_stream_t stream) {
+  if (prec == LADDER_PREC_F32) {     // strict fp32: any class width the fp32 tilings take (csrc/convf32.hip, csrc/convf32s.hip)
+    if (!ladder_conv3x3_s2_bwd_data_f32_eligible(N, H, W, Cin, Ho, Wo, Cout)) return LADDER_E_SHAPE;
+    return conv3x3_f32_launch(dy, (const float*)packed_s2, nullptr, dx, nullptr, nullptr, nullptr, 0, N, Ho, Wo, Cout, 4 * Cin, LADDER_ACT_NONE, stream,
+                              s2_tap_masks(), 1);
+  }
   if (!ladder_conv3x3_s2_bwd_data_split_eligible(N, H, W, Cin, Ho, Wo, Cout, 3, 3, 2, 0, 0)) return LADDER_E_SHAPE;
   return conv3x3_split_launch(dy, dy_absmax, packed_s2, nullptr, dx, dx_absmax, nullptr, nullptr, nullptr, 0, N, Ho, Wo, Cout, 4 * SP_BN,
                               LADDER_ACT_NONE, prec, stream, s2_tap_masks(), 1);
@@ -1391,13 +1396,14 @@ static unsigned long long up2_tap_masks() { return filter_bank_tap_masks(3); }
 
 int ladder_conv3x3_up2_split_eligible(int N, int H, int W, int Cin, int Cout, int prec) {
   static const bool off = getenv("LADDER_DISABLE_UP2") != nullptr;              // (test-only switch, see include/ladder_hip.h)
+  if (prec == LADDER_PREC_F32) return (!off && Cout > 0 && conv3x3_f32_any_ok(N, H, W, Cin, 4 * Cout, 2)) ? 1 : 0;   // (any class width: convf32s.hip)
   return (!off && (prec_ok(prec) || prec == LADDER_PREC_F32) && Cout == SP_BN && split_halo_ok(N, H, W, Cin, 4 * SP_BN)) ? 1 : 0;
 }
 
 int ladder_conv3x3_up2_split(const float* x, const float* x_absmax, const void* packed_up2, const float* bias, float* y, float* y_absmax,
                              int N, int H, int W, int Cin, int Cout, int act, int prec, int x_upsampled, ladder_stream_t stream) {
   if (!ladder_conv3x3_up2_split_eligible(N, H, W, Cin, Cout, prec)) return LADDER_E_SHAPE;
-  return conv3x3_split_launch(x, x_absmax, packed_up2, bias, y, y_absmax, nullptr, nullptr, nullptr, 0, N, H, W, Cin, 4 * SP_BN, act, prec,
+  return conv3x3_split_launch(x, x_absmax, packed_up2, bias, y, y_absmax, nullptr, nullptr, nullptr, 0, N, H, W, Cin, 4 * Cout, act, prec,
                               stream, up2_tap_masks(), x_upsampled ? 3 : 2);
 }
 
@@ -1405,7 +1411,7 @@ int ladder_conv3x3_up2_split(const float* x, const float* x_absmax, const void* 
 int ladder_conv3x3_up2_split_proj(const float* x, const float* x_absmax, const void* packed_up2, const float* bias, float* y, const float* proj_w,
                                   const float* proj_b, float* proj_out, int proj_cout, int N, int H, int W, int Cin, int Cout, int act, int prec,
                                   int x_upsampled, ladder_stream_t stream) {
-  if (!ladder_conv3x3_up2_split_eligible(N, H, W, Cin, Cout, prec) || proj_out == nullptr || (prec != LADDER_PREC_F32 && prec_planes(prec) != 2)) return LADDER_E_SHAPE;
+  if (!ladder_conv3x3_up2_split_eligible(N, H, W, Cin, Cout, prec) || proj_out == nullptr || Cout != SP_BN || (prec != LADDER_PREC_F32 && prec_planes(prec) != 2)) return LADDER_E_SHAPE;
   return conv3x3_split_launch(x, x_absmax, packed_up2, bias, y, nullptr, proj_w, proj_b, proj_out, proj_cout, N, H, W, Cin, 4 * SP_BN, act, prec,
                               stream, up2_tap_masks(), x_upsampled ? 3 : 2);
 }
@@ -1420,7 +1426,7 @@ static unsigned long long up2t_tap_masks() { return filter_bank_tap_masks(4); }
 
 int ladder_conv3x3_up2_bwd_data_split_eligible(int N, int H, int W, int C, int Cout, int prec) {
   static const bool off = getenv("LADDER_DISABLE_UP2") != nullptr;
-  if (prec == LADDER_PREC_F32) return (!off && (C % 16) == 0 && split_halo_ok(N, H, W, 4 * C, Cout)) ? 1 : 0;      // (8-wave fp32 kernel)
+  if (prec == LADDER_PREC_F32) return (!off && (C % 16) == 0 && conv3x3_f32_any_ok(N, H, W, 4 * C, Cout, 4)) ? 1 : 0;      // (8-wave fp32 kernels)
   return (!off && prec_ok(prec) && (C % 16) == 0 && split_halo_ok(N, H, W, 4 * C, Cout) && split_halo16_ok(N, H, W, 4 * C, Cout, prec)) ? 1 : 0;
 }
 
@@ -1473,11 +1479,16 @@ int ladder_conv3x3_up2_edges(const float* x, const float* w, const float* bias, 
   float* e_row = (float*)p; p += up2_align(mr * Cout * 4);
   float* e_col = (float*)p; p += up2_align(mc * Cout * 4);
   const size_t g = ws_bytes - (size_t)(p - (char*)ws);
-  hipLaunchKernelGGL(up2_edge_operands_kernel, dim3(1024), dim3(256), 0, stream, x, w, u_row, v_col, w_row, w_col, N, H, W, Cin, Cout, x_upsampled ? 2 : 1);
-  int rc = ladder_conv2d_fwd(u_row, w_row, bias, e_row, N, 1, 2 * W, Cin, 1, 2 * W, Cout, 1, 3, 1, 0, 1, act, p, g, stream);
-  if (rc != LADDER_OK) return rc;
-  rc = ladder_conv2d_fwd(v_col, w_col, bias, e_col, N, 2 * H, 1, Cin, 2 * H, 1, Cout, 3, 1, 1, 1, 0, act, p, g, stream);
-  if (rc != LADDER_OK) return rc;
+  if (up2_edge_lines_f32_ok(N, H, W, Cin, Cout) && ladder_aligned16(w)) {     // round 5: both lines in one launch (csrc/convf32s.hip)
+    const int rc = up2_edge_lines_f32(x, w, bias, e_row, e_col, N, H, W, Cin, Cout, act, x_upsampled, stream);
+    if (rc != LADDER_OK) return rc;
+  } else {
+    hipLaunchKernelGGL(up2_edge_operands_kernel, dim3(1024), dim3(256), 0, stream, x, w, u_row, v_col, w_row, w_col, N, H, W, Cin, Cout, x_upsampled ? 2 : 1);
+    int rc = ladder_conv2d_fwd(u_row, w_row, bias, e_row, N, 1, 2 * W, Cin, 1, 2 * W, Cout, 1, 3, 1, 0, 1, act, p, g, stream);
+    if (rc != LADDER_OK) return rc;
+    rc = ladder_conv2d_fwd(v_col, w_col, bias, e_col, N, 2 * H, 1, Cin, 2 * H, 1, Cout, 3, 1, 1, 1, 0, act, p, g, stream);
+    if (rc != LADDER_OK) return rc;
+  }
   hipLaunchKernelGGL(up2_edge_scatter_kernel, dim3((2 * W + 2 * H - 1 + 3) / 4, N), dim3(256), 0, stream, (const float*)e_row, (const float*)e_col, y,
                      pw, pb, pout, pco, H, W, Cout, y_absmax);
   LADDER_CHECK_LAUNCH();

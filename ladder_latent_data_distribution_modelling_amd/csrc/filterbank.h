@@ -16,6 +16,10 @@
 //   4  backward-data of that pair: dx_lo[p] = sum_{k=-2..2} G_k^T dy[2p+k] per axis = a 3x3 correlation over the four pixel-parity
 //      classes of dy taken as four blocks of Cin / 4 INPUT channels (class a holds the taps k = 2 (dr - 1) + a; coefficient of w[r] in
 //      tap dr of class a = A_a[2 - dr][r])   (w = [3][3][Cout][Cin/4])
+//   5  forward of a 3x3 / stride-2 / SAME conv on an even map (TF padding: none above / left, one line below / right) as ONE stride-1
+//      correlation over the four pixel-parity classes of x taken as four blocks of Cin / 4 INPUT channels: class (a, b) holds x[2i+a, 2j+b];
+//      tap (dr, dc) reads class pixel (i + dr - 1, j + dc - 1) and carries w[2 (dr - 1) + a][2 (dc - 1) + b] -- rows dr = 1 (both classes)
+//      and dr = 2 (class a = 0 only), columns alike: 4 / 2 / 2 / 1 taps   (w = [3][3][Cin/4][Cout], strict fp32 only)
 // Sums have <= 9 terms with power-of-two weights, evaluated in fp32 in a fixed order.
 #pragma once
 
@@ -29,6 +33,12 @@ __device__ __forceinline__ float filter_bank_element(const float* __restrict__ w
     if (!(va && vb)) return 0.f;
     const int r = a == 1 ? ph : 2, sx = b == 1 ? pw : 2;
     return w[(((size_t)r * 3 + sx) * C + cc) * Cin + ci];
+  }
+  if (transpose_flip == 5) {
+    const int C = Cin >> 2, cls = ci / C, cc = ci - cls * C, a = cls >> 1, b = cls & 1, dr = tap / 3, dc = tap - 3 * dr;
+    const bool va = dr == 1 || (dr == 2 && a == 0), vb = dc == 1 || (dc == 2 && b == 0);
+    if (!(va && vb)) return 0.f;
+    return w[(((size_t)(2 * (dr - 1) + a) * 3 + (2 * (dc - 1) + b)) * C + cc) * Cout + co];
   }
   const float A0[3][3] = {{0.5f, 0.f, 0.f}, {0.5f, 1.f, 0.5f}, {0.f, 0.f, 0.5f}}, A1[3][3] = {{0.f, 0.f, 0.f}, {1.f, 0.5f, 0.f}, {0.f, 0.5f, 1.f}};
   float f = 0.f;
@@ -69,6 +79,7 @@ static inline unsigned long long filter_bank_tap_masks(int transpose_flip) {
         if (transpose_flip == 2) on = (dr == 1 || (dr == 0 && a == 0)) && (dc == 1 || (dc == 0 && b == 0));
         else if (transpose_flip == 3) on = (a == 0 || dr >= 1) && (b == 0 || dc >= 1);
         else if (transpose_flip == 4) on = (a == 0 || dr <= 1) && (b == 0 || dc <= 1);
+        else if (transpose_flip == 5) on = (dr == 1 || (dr == 2 && a == 0)) && (dc == 1 || (dc == 2 && b == 0));
         if (on) t |= 1u << (dr * 3 + dc);
       }
     m |= (unsigned long long)t << (9 * cls);

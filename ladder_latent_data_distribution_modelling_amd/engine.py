@@ -481,6 +481,10 @@ class ParamStore:
 
 
 # ------------------------------------------------------------------------------------------ layers
+UP2T_MIN_PIXELS = int(os.environ.get("LADDER_UP2T_MIN_PIXELS", "256"))      # smallest low-resolution map whose backward-data runs upsample-fused
+UP2W_MIN_PIXELS = int(os.environ.get("LADDER_UP2W_MIN_PIXELS", "256"))      # ... and whose filter gradient does (8x8: 758 us fused against 612 direct)
+
+
 class Conv2D:
     """tf.layers.conv2d (NHWC / HWIO), bias + activation fused in the kernel epilogue."""
 
@@ -501,8 +505,9 @@ class Conv2D:
         csrc/convsplit.hip) -- same tiling, same eligibility."""
         if self.ctx.ns == 0 and os.environ.get("LADDER_DISABLE_HALO") == "1":      # (test switch: the round-1 generic fp32 gather kernels everywhere)
             return False
+        # (strict fp32 also takes the 16- / 8-pixel-wide maps: csrc/convf32s.hip)
         return bool(self.k == 3 and self.stride == 1 and self.padding == "same"
-                    and L.query("ladder_conv3x3_split_eligible", N, H, W, cin, cout))
+                    and L.query("ladder_conv3x3_f32_eligible" if self.ctx.ns == 0 else "ladder_conv3x3_split_eligible", N, H, W, cin, cout))
 
     def _split_ok(self, N, H, W, cin, cout):
         """... and the precision is one of the 16-bit split formats (their filter gradient / planes / absmax machinery)."""
@@ -555,6 +560,8 @@ class Conv2D:
             cout = 4 * self.cout
         elif transpose_flip == 4:                     # backward-data of the upsample-fused pair: the four pixel-parity classes of dy as input groups
             cin, cout = 4 * self.cout, self.cin
+        elif transpose_flip == 5:                     # stride-2 forward: the four pixel-parity classes of x as input groups (strict fp32)
+            cin, cout = 4 * self.cin, self.cout
         ent = self._packed.get((transpose_flip, ns))
         if ent is None:
             nb = L.query("ladder_filter_pack_split_bytes", self.k * self.k, cin, cout, ns)
@@ -603,7 +610,7 @@ class Conv2D:
     def virtual_up2_ok(self, N, H, W):
         """A training forward may skip materialising the factor-2 upsample of its [N, H, W, cin] input altogether: strict fp32, and forward,
         backward-data AND filter gradient of this layer all run from the low-resolution tensor (csrc/convf32.hip)."""
-        return bool(self.ctx.ns == 0 and self.ctx.up2 >= 3 and self.up2_ok(N, H, W) and self.up2t_ok(N, H, W)
+        return bool(self.ctx.ns == 0 and self.ctx.up2 >= 3 and self.up2_ok(N, H, W) and self.up2t_ok(N, H, W) and H * W >= UP2W_MIN_PIXELS
                     and L.query("ladder_conv3x3_up2_wgrad_eligible", N, H, W, self.cin, self.cout))
 
     def forward_up2(self, x, proj=None, keep_y=False, x_for_backward=None):
@@ -719,6 +726,16 @@ class Conv2D:
                        _p(self.bn_sums), swp, swn, self.ctx.stream)
                 self.x, self.y = x, y
                 return y
+        if (self.ctx.ns == 0 and self.k == 3 and self.stride == 2 and self.pt == 0 and self.pl == 0 and os.environ.get("LADDER_DISABLE_HALO") != "1"
+                and L.query("ladder_conv3x3_s2_fwd_f32_eligible", N, H, W, self.cin, Ho, Wo, self.cout)):
+            # strict fp32, 3x3 / stride 2 over an even map (encoder conv2d_2 / conv2d_3): a stride-1 correlation over the four pixel-parity classes
+            # of x on the halo kernels (x staged once per slab for all taps; csrc/convf32s.hip): 185 / 115 us against 202 / 127 on the gather kernel.
+            # (Behind the statistics-epilogue branch above: conv2d_1 measures 344 us + a statistics pass here against 356 us with them.)
+            args = (_p(x), _p(self._packed_filter(5)), _p(self.ps.w[self.name + "/bias"]), _p(y), N, H, W, self.cin, Ho, Wo, self.cout,
+                    L.ACT[self.act], self.ctx.stream)
+            _timed(256120, 2.0 * N * Ho * Wo * 9 * self.cin * self.cout, "ladder_conv3x3_s2_fwd_f32", args)
+            self.x, self.y = x, y
+            return y
         _igemm(self.ctx, "ladder_conv2d_fwd", N * Ho * Wo, self.cin, self.cout, self.k * self.k * self.cin,
                _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y),
                N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl, L.ACT[self.act],
@@ -730,6 +747,10 @@ class Conv2D:
         """The gradient with respect to the LOW-resolution tensor [N, H, W, cin] behind a factor-2 resize in front of this layer can come from
         ONE launch (ladder_conv3x3_up2_bwd_data_split) + border strips, instead of backward-data on the upsampled map + the resize transpose."""
         if self.ctx.ns == 0 and os.environ.get("LADDER_DISABLE_HALO") == "1":
+            return False
+        if self.ctx.ns == 0 and H * W < UP2T_MIN_PIXELS:
+            # policy (measured, profiles/r05_small_maps.txt): on an 8x8 low-resolution map the four exact border lines cost more than the
+            # 11 / 36 of the products the fused launch saves (conv2d_4: 461 + 221 us against 595 + 26 for the direct pair)
             return False
         return bool(self.ctx.up2 >= 2 and self.ctx.ns in (0, 2, 4) and self.k == 3 and self.stride == 1 and self.padding == "same"
                     and L.query("ladder_conv3x3_up2_bwd_data_split_eligible", N, H, W, self.cout, self.cin, self.ctx.ns)
@@ -873,7 +894,7 @@ class Conv2D:
                 L.call("ladder_conv2d_bwd_filter_split", _p(xpl), _p(self.x_amax), _p(dpl), _p(dy_amax), _p(self.ps.g[self.name + "/kernel"]),
                        _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k,
                        self.stride, self.pt, self.pl, self.ctx.ns, wsp, wsn, self.ctx.stream)
-        elif (wgrad and self.ctx.ns == 0 and (self.x_is_up2 or self.x_is_lo) and self.ctx.up2 >= 2
+        elif (wgrad and self.ctx.ns == 0 and (self.x_is_up2 or self.x_is_lo) and self.ctx.up2 >= 2 and (H // 2) * (W // 2) >= UP2W_MIN_PIXELS
               and L.query("ladder_conv3x3_up2_wgrad_eligible", N, H // 2, W // 2, self.cin, self.cout)):
             # strict fp32, x = resize2x(x_lo): 25 instead of 36 tap tiles, read from the even sub-grid of the kept upsample (csrc/convf32.hip)
             wsp, wsn = self.ctx.ws(L.query("ladder_conv3x3_up2_wgrad_workspace_bytes", N, H // 2, W // 2, self.cin, self.cout))
@@ -883,6 +904,8 @@ class Conv2D:
                    (_p(x), 0 if self.x_is_lo else 1, _p(dy), _p(self.ps.g[self.name + "/kernel"]), _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, N, H // 2, W // 2,
                     self.cin, self.cout, wsp, wsn, st), fl * 25.0 / 36.0)
         elif wgrad:
+            if self.x_is_lo:        # (x is [N, H/2, W/2, cin]: the generic kernel would read 4x past it -- the forward's decision must hold here)
+                raise RuntimeError("%s: virtual upsample without the low-resolution filter gradient" % self.name)
             nb = L.query("ladder_conv2d_bwd_filter_workspace_bytes", N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k)
             wsp, wsn = self.ctx.ws(nb)
             wargs = (_p(x), _p(dy), _p(self.ps.g[self.name + "/kernel"]), _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None,
@@ -909,8 +932,9 @@ class Conv2D:
             self.ctx.set_amax(dx, dx_amax)
             _timed(256120 + self.ctx.ns, 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_split", args)
         elif (need_dx and self.ctx.ns in (0, 4) and not gate_prev and self.stride == 2 and not (self.ctx.ns == 0 and os.environ.get("LADDER_DISABLE_HALO") == "1")
-              and L.query("ladder_conv3x3_s2_bwd_data_split_eligible", N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride,
-                          self.pt, self.pl)):
+              and (L.query("ladder_conv3x3_s2_bwd_data_split_eligible", N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride,
+                           self.pt, self.pl) or (self.ctx.ns == 0 and self.k == 3 and self.pt == 0 and self.pl == 0 and
+                                                 L.query("ladder_conv3x3_s2_bwd_data_f32_eligible", N, H, W, self.cin, Ho, Wo, self.cout)))):
             # 3x3 / stride 2 over a map whose gradient is halo-kernel sized (enc.conv1): the four output-parity classes in ONE launch
             if dy_amax is None:
                 dy_amax = self.ctx.absmax(dy)

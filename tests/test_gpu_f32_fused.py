@@ -64,6 +64,17 @@ def _logical_bank(w, flip):
             for b in range(2):
                 F[:, :, :, a * 2 + b] = np.einsum("dr,es,rsio->deio", A[a], A[b], w)
         return F.reshape(9, Ci, 4 * C)
+    if flip == 5:                                    # w [3][3][C][Cout]: F[tap][4C][Cout], tap (dr, dc) of class (a, b) carries w[2 (dr - 1) + a][2 (dc - 1) + b]
+        C, Co = w.shape[2], w.shape[3]
+        F = np.zeros((3, 3, 4, C, Co))
+        for a in range(2):
+            for b in range(2):
+                for dr in range(1, 3):
+                    for dc in range(1, 3):
+                        r, sx = 2 * (dr - 1) + a, 2 * (dc - 1) + b
+                        if r < 3 and sx < 3:
+                            F[dr, dc, a * 2 + b] = w[r, sx]
+        return F.reshape(9, 4 * C, Co)
     Co, C = w.shape[2], w.shape[3]                   # flip 4: w [3][3][Cout][C]: F[tap][4C][Cout]
     F = np.zeros((3, 3, 4, C, Co))
     for a in range(2):
@@ -74,11 +85,11 @@ def _logical_bank(w, flip):
     return F.reshape(9, 4 * C, Co)
 
 
-@pytest.mark.parametrize("flip", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("flip", [0, 1, 2, 3, 4, 5])
 def test_f32_filter_banks_match_the_table_definitions(gpu_ctx, flip):
     L = _lib()
     rng = np.random.default_rng(flip)
-    shape = {0: (3, 3, 32, 192), 1: (3, 3, 48, 160), 2: (3, 3, 128, 32), 3: (3, 3, 48, 128), 4: (3, 3, 64, 16)}[flip]
+    shape = {0: (3, 3, 32, 192), 1: (3, 3, 48, 160), 2: (3, 3, 128, 32), 3: (3, 3, 48, 128), 4: (3, 3, 64, 16), 5: (3, 3, 16, 96)}[flip]
     w = rng.standard_normal(shape).astype(np.float32)
     ref = _logical_bank(w, flip)
     cin, cout = ref.shape[1], ref.shape[2]
@@ -87,7 +98,7 @@ def test_f32_filter_banks_match_the_table_definitions(gpu_ctx, flip):
     got = bank.cpu().numpy().astype(np.float64)
     assert np.isfinite(got).all()
     np.testing.assert_allclose(got, ref, rtol=0, atol=3e-7 * np.abs(ref).max())
-    if flip in (0, 1, 2):                            # pure permutations: exact
+    if flip in (0, 1, 2, 5):                         # pure permutations: exact
         assert np.array_equal(got, ref)
 
 
@@ -322,8 +333,11 @@ def test_f32_engine_routes_through_the_fused_kernels_and_agrees_with_the_direct_
 
     monkeypatch.setattr(L, "call", spy)
     res = {}
-    for up2 in (0, 2, 3):
-        eng = LadderEngine(dict(cfg, upsample_fused_convs=up2), "cuda:0", values=Pm, seed=1)
+    for up2 in (0, 2, 3, "generic"):
+        if up2 == "generic":      # a SECOND direct formulation (the round-1 gather kernels everywhere): the rounding-noise floor of the comparison
+            monkeypatch.setenv("LADDER_DISABLE_HALO", "1")
+            monkeypatch.setenv("LADDER_DISABLE_BNSTATS", "1")
+        eng = LadderEngine(dict(cfg, upsample_fused_convs=0 if up2 == "generic" else up2), "cuda:0", values=Pm, seed=1)
         assert eng.precision == "f32" and eng.ctx.ns == 0
         eng.set_mixture(*gm)
         del calls[:]
@@ -344,11 +358,14 @@ def test_f32_engine_routes_through_the_fused_kernels_and_agrees_with_the_direct_
     assert p0 == {0} and p1 == {0}, "every halo launch carries prec = LADDER_PREC_F32"
     assert not any("up2" in c for c in tc0 + ec0)
     assert tc1.count("ladder_conv3x3_up2_split_proj") == 1 and "ladder_in_style_fwd_resize2x_keep" in tc1
-    assert tc1.count("ladder_conv3x3_up2_split") == 1       # conv2d_6's training forward reads conv2d_5's output; the resized tensor is kept for its backward
+    # conv2d_6 / conv2d_5 / conv2d_4 (round 5: the 16x16 and 8x8 low-resolution maps, csrc/convf32s.hip) read the low-resolution tensor in the
+    # training forward; at level 2 the resized tensors are kept for their backward passes
+    assert tc1.count("ladder_conv3x3_up2_split") == 3
     assert tc1.count("ladder_conv3x3_up2_bwd_data_split") == 1 and tc1.count("ladder_conv3x3_up2_bwd_borders") == 1 and "ladder_conv3x3_up2_bwd_border" not in tc1
-    assert tc1.count("ladder_conv3x3_s2_bwd_data_split") == 1 and tc0.count("ladder_conv3x3_s2_bwd_data_split") == 1
+    # encoder conv2d_1 ... conv2d_3: the stride-2 backward-data as one class-structured launch each (round 5: any class width, 16- / 8-wide dy maps)
+    assert tc1.count("ladder_conv3x3_s2_bwd_data_split") == 3 and tc0.count("ladder_conv3x3_s2_bwd_data_split") == 3
     assert tc1.count("ladder_resize_bilinear_bwd") == tc0.count("ladder_resize_bilinear_bwd") - 1
-    assert ec1.count("ladder_conv3x3_up2_split_proj") == 1 and ec1.count("ladder_conv3x3_up2_split") == 1 and ec1.count("ladder_conv3x3_up2_edges") == 2
+    assert ec1.count("ladder_conv3x3_up2_split_proj") == 1 and ec1.count("ladder_conv3x3_up2_split") == 3 and ec1.count("ladder_conv3x3_up2_edges") == 4
     assert tc0.count("ladder_conv3x3_split_proj") == 1 and ec0.count("ladder_conv3x3_split_proj") == 1      # the fused projection without the upsample fusion
     for k in ("elbo", "l1_reconstruction_error", "l2_reconstruction_error", "loss_ae", "sigma", "mean_pixel_error"):
         assert abs(f1[k] - f0[k]) <= 2e-6 * abs(f0[k]) + 1e-7, (k, f1[k], f0[k])
@@ -361,24 +378,37 @@ def test_f32_engine_routes_through_the_fused_kernels_and_agrees_with_the_direct_
     # no reader of the resized tensors is left: they are never materialised (plain instance norm instead of the fused norm + resize, no
     # 32 -> 64 resize pass), and no resize transpose remains in front of conv2d_6 / conv2d_7
     f3, g3, e3, d3, tc3, ec3, p3 = res[3]
-    assert tc3.count("ladder_conv3x3_up2_wgrad") == 2 and tc3.count("ladder_conv3x3_up2_bwd_data_split") == 2 and tc3.count("ladder_conv3x3_up2_bwd_borders") == 2
+    # (round 5: conv2d_5's pair -- 16x16 low-resolution map -- joins in all three passes, so the 16 -> 32 upsample is virtual too; conv2d_4's pair --
+    # 8x8 -- takes the fused forward only: the border lines of its backward-data and the edge lines / partial sums of its filter gradient cost more than the fusion saves)
+    assert tc3.count("ladder_conv3x3_up2_wgrad") == 3 and tc3.count("ladder_conv3x3_up2_bwd_data_split") == 3 and tc3.count("ladder_conv3x3_up2_bwd_borders") == 3
     assert "ladder_in_style_fwd_resize2x_keep" not in tc3 and tc3.count("ladder_resize_bilinear_fwd") == tc0.count("ladder_resize_bilinear_fwd") - 1
-    assert tc3.count("ladder_resize_bilinear_bwd") + tc3.count("ladder_resize_bilinear_bwd_gated") == tc0.count("ladder_resize_bilinear_bwd") + tc0.count("ladder_resize_bilinear_bwd_gated") - 2
-    assert tc1.count("ladder_conv3x3_up2_wgrad") == 2           # (level 2 keeps the resized tensors: the filter gradients read their even sub-grids)
+    assert tc3.count("ladder_resize_bilinear_bwd") + tc3.count("ladder_resize_bilinear_bwd_gated") == tc0.count("ladder_resize_bilinear_bwd") + tc0.count("ladder_resize_bilinear_bwd_gated") - 3
+    assert tc1.count("ladder_conv3x3_up2_wgrad") == 3           # (level 2 keeps the resized tensors: the filter gradients read their even sub-grids)
     for k in ("elbo", "l1_reconstruction_error", "l2_reconstruction_error", "loss_ae", "sigma", "mean_pixel_error"):
         assert abs(f3[k] - f0[k]) <= 2e-6 * abs(f0[k]) + 1e-7, (k, f3[k], f0[k])
     close(d3, d0, 5e-6, "decoded image (level 3)")
     worst3, wname3 = _worst_grad(g0, g3)
     print("f32 fused (level 3) vs direct: worst relative gradient difference %.2e (%s)" % (worst3, wname3))
-    assert worst3 < 5e-4, (worst3, wname3)
     print("f32 fused vs direct: worst relative gradient difference %.2e (%s)" % (worst, wname))
-    # (relative to the tensor's largest element; measured 1.8e-4 on encoder/code_std_dev/kernel, whose gradient is a difference of two
-    # nearly cancelling terms -- dz . eps against the entropy's 1 / sd -- so fp32 rounding differences of the two convolution
-    # formulations show amplified there; every other tensor is below 5e-5.  The SAME bar as the f16x3 form of this test.)
-    assert worst < 5e-4, (worst, wname)
+    # The bar is DERIVED, not chosen: the same gradients from a second DIRECT formulation (gather kernels instead of the halo kernels:
+    # same 36 / 36 products, another summation order) give the rounding-noise floor of this comparison, tensor by tensor; a fused build may sit at
+    # most 3x above that floor on any tensor (and never above 2e-3).  encoder/code_std_dev/kernel -- a difference of two nearly cancelling terms,
+    # dz . eps against the entropy's 1 / sd -- carries the largest noise (measured 2e-4 ... 6e-4 in all three builds); every other tensor is below 5e-5.
+    gg = res["generic"][1]
+    floor, fname = _worst_grad(g0, gg)
+    print("f32 direct gather vs direct halo (noise floor): worst relative gradient difference %.2e (%s)" % (floor, fname))
+    for name in g0:
+        sc = np.abs(g0[name]).max()
+        if sc > 1e-9:
+            nf = np.abs(gg[name] - g0[name]).max() / sc
+            for lvl, g in ((2, g1), (3, g3)):
+                e = np.abs(g[name] - g0[name]).max() / sc
+                assert e <= max(3.0 * nf, 5e-5) and e < 2e-3, (name, lvl, e, nf)
 
 
-@pytest.mark.parametrize("case", [(64, 32, 32, 64, 128, True, 1), (16, 64, 64, 64, 64, False, 0), (64, 16, 64, 128, 192, True, 1)],
+@pytest.mark.parametrize("case", [(64, 32, 32, 64, 128, True, 1), (16, 64, 64, 64, 64, False, 0), (64, 16, 64, 128, 192, True, 1),
+                                  (128, 16, 16, 64, 128, True, 0), (128, 8, 8, 64, 256, True, 0), (64, 16, 16, 128, 64, False, 1), (130, 8, 8, 64, 128, True, 1),
+                                  (48, 24, 16, 64, 64, True, 0)],
                          ids=lambda c: "n%d_%dx%d_c%d_co%d_b%d_ups%d" % c)
 def test_f32_up2_filter_gradient_vs_autograd(gpu_ctx, case):
     """ladder_conv3x3_up2_wgrad: the filter (and bias) gradient of resize x2 -> 3x3 conv from the low-resolution x (or the even sub-grid of the
@@ -469,3 +499,134 @@ def test_f32_conv_epilogue_emits_the_batch_norm_statistics(gpu_ctx, geom):
     assert np.abs(got[0] - yr.sum(0)).max() <= 1e-6 * np.abs(yr).sum(0).max()                  # fp32 partial sums over 128-pixel tiles, then a fixed tree (measured 6e-8)
     assert np.abs(got[1] - (yr * yr).sum(0)).max() <= 2e-6 * (yr * yr).sum(0).max()
     assert np.array_equal(got[2], yr.min(0).astype(np.float32)) and np.array_equal(got[3], yr.max(0).astype(np.float32))
+
+
+# ---- round 5: the small-map tilings (csrc/convf32s.hip) -------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [(128, 16, 16, 64, 256, "leaky_relu"), (128, 8, 8, 64, 512, None), (64, 16, 16, 32, 192, "leaky_relu"),
+                                  (129, 8, 8, 32, 256, "leaky_relu"), (32, 32, 16, 48, 512, None), (128, 8, 16, 32, 128, None)],
+                         ids=lambda c: "n%d_%dx%d_c%d_co%d_%s" % c)
+def test_f32_small_map_conv_fwd_bwd_vs_oracle(gpu_ctx, case):
+    """Plain 3x3 / SAME convolution and its backward-data on 16- / 8-pixel-wide maps (decoder conv2d_3, reference codes/models.py:539-543):
+    16x16, 8x16 and 8x8-pixel sub-patches, 64- / 128-channel tiles, a ragged last workgroup (N = 129: two 8x8 images per workgroup)."""
+    L = _lib()
+    N, H, W, Cin, Cout, act = case
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(H + Cin + Cout)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32) * 0.1
+    assert L.query("ladder_conv3x3_split_eligible", N, H, W, Cin, Cout) == 0, "not a geometry of the 8x32-pixel tiling"
+    assert L.query("ladder_conv3x3_f32_eligible", N, H, W, Cin, Cout) == 1
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    y = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    L.call("ladder_conv3x3_split", p(xd), None, p(wd), p(bd), p(y), None, N, H, W, Cin, Cout, 1 if act else 0, F32, st)
+    close(y, _conv64(x, w, b, act), TOL32, "forward")
+    if L.query("ladder_conv3x3_f32_eligible", N, H, W, Cout, Cin):
+        dy = rng.standard_normal((N, H, W, Cout)).astype(np.float32)
+        xt = torch.zeros(N, H, W, Cin, dtype=torch.float64, requires_grad=True)
+        O.conv2d_tf(xt, torch.as_tensor(w, dtype=torch.float64), None, 1, "same").backward(torch.as_tensor(dy, dtype=torch.float64))
+        bankT = _bank(L, w, Cout, Cin, 1, st)
+        dx = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+        dyd = dev(dy)
+        L.call("ladder_conv3x3_split", p(dyd), None, p(bankT), None, p(dx), None, N, H, W, Cout, Cin, 0, F32, st)
+        close(dx, xt.grad, TOL32, "backward-data")
+
+
+@pytest.mark.parametrize("case", [(128, 16, 16, 32, 256, "leaky_relu", 0), (128, 8, 8, 64, 256, None, 0), (64, 16, 16, 32, 128, "leaky_relu", 1),
+                                  (256, 8, 8, 32, 64, "leaky_relu", 0), (64, 32, 32, 16, 256, None, 0)],
+                         ids=lambda c: "n%d_%dx%d_c%d_co%d_%s_ups%d" % c)
+def test_f32_up2_conv_small_maps_and_wide_classes_vs_oracle(gpu_ctx, case):
+    """resize x2 -> 3x3 conv over 16x16 / 8x8 low-resolution maps with classes of 64 ... 256 channels (decoder conv2d_5 / conv2d_4, reference
+    codes/models.py:544-560): class PAIRS per workgroup, class-interleaved epilogue, then the exact last row / column."""
+    L = _lib()
+    N, H, W, Cin, Cout, act, ups = case
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(H * 100 + Cin + Cout)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32) * 0.1
+    assert L.query("ladder_conv3x3_up2_split_eligible", N, H, W, Cin, Cout, F32) == 1
+    xd, bd, wd = dev(x), dev(b), dev(w)
+    src = dev(O.resize_bilinear_legacy(torch.as_tensor(x), 2 * H, 2 * W).numpy()) if ups else xd
+    bank = _bank(L, w, Cin, 4 * Cout, 3, st)
+    y = torch.full((N, 2 * H, 2 * W, Cout), float("nan"), device="cuda")
+    L.call("ladder_conv3x3_up2_split", p(src), None, p(bank), p(bd), p(y), None, N, H, W, Cin, Cout, 1 if act else 0, F32, ups, st)
+    torch.cuda.synchronize()
+    ref = _ref_up2(x, w, b, act)
+    close(y[:, :-1, :-1], ref[:, :-1, :-1], TOL32, "up2 interior")
+    ws = torch.empty(L.query("ladder_conv3x3_up2_edges_workspace_bytes", N, H, W, Cin, Cout), dtype=torch.uint8, device="cuda")
+    L.call("ladder_conv3x3_up2_edges", p(src), p(wd), p(bd), p(y), None, None, None, None, 0, N, H, W, Cin, Cout, 1 if act else 0, ups, p(ws), ws.numel(), st)
+    close(y, ref, TOL32, "up2 full map")
+
+
+@pytest.mark.parametrize("case", [(128, 16, 16, 64, 256), (128, 8, 8, 32, 512), (64, 16, 16, 16, 128), (129, 8, 8, 16, 256)],
+                         ids=lambda c: "n%d_%dx%d_c%d_co%d" % c)
+def test_f32_up2_backward_data_small_maps_with_exact_borders_vs_autograd(gpu_ctx, case):
+    """The complete low-resolution gradient of resize x2 -> 3x3 conv on 16x16 / 8x8 low-resolution maps (decoder conv2d_5 / conv2d_4)."""
+    L = _lib()
+    N, H, W, C, Cout = case                            # dy [N, 2H, 2W, C], dx [N, H, W, Cout]
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(C + Cout + H)
+    w = (rng.standard_normal((3, 3, Cout, C)) / np.sqrt(9 * C)).astype(np.float32)
+    dy = rng.standard_normal((N, 2 * H, 2 * W, C)).astype(np.float32)
+    assert L.query("ladder_conv3x3_up2_bwd_data_split_eligible", N, H, W, C, Cout, F32) == 1
+    bank = _bank(L, w, 4 * C, Cout, 4, st)
+    dyd, wd = dev(dy), dev(w)
+    dx = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    L.call("ladder_conv3x3_up2_bwd_data_split", p(dyd), None, p(bank), p(dx), None, N, H, W, C, Cout, F32, st)
+    ws = torch.empty(L.query("ladder_conv3x3_up2_bwd_borders_workspace_bytes", N, H, W, C, Cout), dtype=torch.uint8, device="cuda")
+    L.call("ladder_conv3x3_up2_bwd_borders", p(dyd), p(wd), p(dx), N, H, W, C, Cout, p(ws), ws.numel(), st)
+    xz = torch.zeros(N, H, W, Cout, dtype=torch.float64, requires_grad=True)
+    O.conv2d_tf(O.resize_bilinear_legacy(xz, 2 * H, 2 * W), torch.as_tensor(w, dtype=torch.float64), None, 1, "same").backward(torch.as_tensor(dy, dtype=torch.float64))
+    ref = xz.grad.numpy()
+    got = dx.cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    scale = np.abs(ref).max()
+    for name, sl in (("interior", (slice(None), slice(1, -1), slice(1, -1))), ("row 0", (slice(None), 0)), ("row H-1", (slice(None), -1)),
+                     ("column 0", (slice(None), slice(None), 0)), ("column W-1", (slice(None), slice(None), -1))):
+        err = np.abs(got[sl] - ref[sl]).max() / scale
+        assert err < TOL32, (name, err)
+
+
+@pytest.mark.parametrize("geom", [(128, 64, 64, 32, 128, "leaky_relu"), (128, 32, 32, 32, 256, None), (128, 16, 16, 64, 256, None), (64, 32, 32, 16, 192, "leaky_relu")],
+                         ids=lambda g: "x".join(map(str, g)))
+def test_f32_conv3x3_stride2_forward_as_one_halo_launch(gpu_ctx, geom):
+    """ladder_conv3x3_s2_fwd_f32 (encoder conv2d_1 ... conv2d_3, reference codes/models.py:409-439): the stride-2 convolution as a stride-1
+    correlation over the four pixel-parity classes of x (orientation 5 of csrc/filterbank.h) against the float64 oracle and the gather kernel."""
+    L = _lib()
+    from ladder_latent_data_distribution_modelling_amd import arch
+    N, H, W, Cin, Cout, act = geom
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(23 + H)
+    pt, Ho = arch.conv_out(H, 3, 2, "same")
+    pl, Wo = arch.conv_out(W, 3, 2, "same")
+    assert (pt, pl) == (0, 0)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32) * 0.1
+    assert L.query("ladder_conv3x3_s2_fwd_f32_eligible", N, H, W, Cin, Ho, Wo, Cout) == 1
+    xd, bd = dev(x), dev(b)
+    bank = _bank(L, w, 4 * Cin, Cout, 5, st)
+    y = torch.full((N, Ho, Wo, Cout), float("nan"), device="cuda")
+    L.call("ladder_conv3x3_s2_fwd_f32", p(xd), p(bank), p(bd), p(y), N, H, W, Cin, Ho, Wo, Cout, 1 if act else 0, st)
+    close(y, _conv64(x, w, b, act, stride=2), TOL32, "stride-2 forward")
+
+
+@pytest.mark.parametrize("geom", [(128, 32, 32, 64, 256), (128, 32, 32, 128, 256), (128, 16, 16, 256, 256), (128, 64, 64, 128, 128)], ids=lambda g: "x".join(map(str, g)))
+def test_f32_conv3x3_stride2_bwd_data_any_class_width(gpu_ctx, geom):
+    """ladder_conv3x3_s2_bwd_data_split with prec f32 on 16- / 8-pixel-wide dy maps and class widths other than 128 (encoder conv2d_2 / conv2d_3)."""
+    L = _lib()
+    N, H, W, Cin, Cout = geom
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(19)
+    Ho, Wo = H // 2, W // 2
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    dy = rng.standard_normal((N, Ho, Wo, Cout)).astype(np.float32)
+    xt = torch.zeros(N, H, W, Cin, dtype=torch.float64, requires_grad=True)
+    O.conv2d_tf(xt, torch.as_tensor(w, dtype=torch.float64), None, 2, "same").backward(torch.as_tensor(dy, dtype=torch.float64))
+    assert L.query("ladder_conv3x3_s2_bwd_data_f32_eligible", N, H, W, Cin, Ho, Wo, Cout) == 1
+    bank = _bank(L, w, Cout, 4 * Cin, 2, st)
+    dx = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+    dyd = dev(dy)
+    L.call("ladder_conv3x3_s2_bwd_data_split", p(dyd), None, p(bank), p(dx), None, N, H, W, Cin, Ho, Wo, Cout, F32, st)
+    close(dx, xt.grad, TOL32, "dx")

@@ -268,14 +268,17 @@ def test_engine_fused_lowres_backward_agrees_with_direct_path(monkeypatch, mode,
         del eng
         torch.cuda.empty_cache()
     (f0, g0, c0), (f1, g1, c1) = res[0], res[mode]
-    nl = mode - 1                                     # layers whose backward-data is fused: conv2d_7 (mode 2), + conv2d_6 (mode 3: no gain measured, off by default)
+    nl = mode - 1                                     # layers whose backward-data is fused: conv2d_7 (mode 2), + conv2d_6 (mode 3)
+    plain_gone = 1                                    # the 128 -> 64 transpose is gone
+    if prec == "f32" and mode == 3:                   # (round 5, strict fp32: + conv2d_5 on its 16x16 low-resolution map, csrc/convf32s.hip: the 32 -> 16 transpose goes too)
+        nl, plain_gone = 3, 2
     assert c1.count("ladder_conv3x3_up2_bwd_data_split") == nl and "ladder_conv3x3_up2_bwd_data_split" not in c0
-    assert c1.count("ladder_resize_bilinear_bwd") == c0.count("ladder_resize_bilinear_bwd") - 1            # the 128 -> 64 transpose is gone
+    assert c1.count("ladder_resize_bilinear_bwd") == c0.count("ladder_resize_bilinear_bwd") - plain_gone
     if prec == "f32":       # strict fp32: the four border lines are corrected in place from one d_up line each (one call per layer)
         assert c1.count("ladder_conv3x3_up2_bwd_borders") == nl and "ladder_conv3x3_up2_bwd_border" not in c1
     else:
         assert c1.count("ladder_conv3x3_up2_bwd_border") == 4 * nl                                        # 4 border lines per layer (strips)
-    assert c1.count("ladder_resize_bilinear_bwd_gated") == c0.count("ladder_resize_bilinear_bwd_gated") - (nl - 1)   # mode 3: the gated 64 -> 32 one too
+    assert c1.count("ladder_resize_bilinear_bwd_gated") == c0.count("ladder_resize_bilinear_bwd_gated") - (1 if mode == 3 else 0)   # mode 3: the gated 64 -> 32 one too
     for k in ("elbo", "l1_reconstruction_error", "loss_ae"):
         assert abs(f1[k] - f0[k]) <= 2e-5 * abs(f0[k]) + 1e-6, (k, f1[k], f0[k])
     worst, wname = 0.0, None
