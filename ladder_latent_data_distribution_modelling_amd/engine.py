@@ -132,7 +132,7 @@ class Comm:
     """Data-parallel exchange steps C1-C4 of SURVEY 2.3 over torch.distributed (RCCL on ROCm).
     With world_size 1 every method is a no-op."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, deterministic=False):
         import torch.distributed as dist
         self.dist = dist
         self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
@@ -140,6 +140,19 @@ class Comm:
         self.world = dist.get_world_size(group) if self.on else 1
         self.rank = dist.get_rank(group) if self.on else 0
         self.trace = None          # label -> [(start event, end event, bytes, exposed-start event or None)]: see enable_trace()
+        # deterministic (config key `deterministic_allreduce`): every all-reduce is an all-gather followed by the RANK-ORDERED sum
+        # ((r0 + r1) + r2) + ... on every rank -- a summation order that does not depend on the backend's ring / tree schedule, so an N-rank
+        # job is reproducible bit for bit by VirtualComm below ("fixed split order ... bit-stable").  N x the bytes of a ring
+        # all-reduce: a parity / debugging mode, not the production setting.  (With two ranks ANY all-reduce is a + b: already bit-stable.)
+        self.deterministic = bool(deterministic)
+
+    def _ordered_sum_(self, t):
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t.contiguous(), group=self.group)
+        t.copy_(parts[0])
+        for q in parts[1:]:
+            t.add_(q)
+        return t
 
     def enable_trace(self, on=True):
         """Per-collective timing for `bench.py --gpus N` (the first multi-GPU run must be diagnosable).  Every exchange step
@@ -169,6 +182,8 @@ class Comm:
         return out
 
     def allreduce_(self, t, label="allreduce"):
+        if self.on and self.deterministic:
+            return self._ordered_sum_(t)
         if self.on:
             if self.trace is not None:
                 s = self._ev()
@@ -183,6 +198,9 @@ class Comm:
         stream, so kernels enqueued afterwards on the compute stream overlap it; `wait()` orders the compute stream after it."""
         if not self.on:
             return None
+        if self.deterministic:
+            self._ordered_sum_(t)
+            return _DoneWork()
         if self.trace is None:
             return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
         s = self._ev()
@@ -205,6 +223,101 @@ class _TracedWork:
         x = self.comm._ev()
         self.work.wait()
         self.comm.trace.setdefault(self.label, []).append((self.start, self.comm._ev(), self.nbytes, x))
+
+
+class _DoneWork:
+    """Handle of a collective that completed inside the call."""
+
+    def wait(self):
+        return None
+
+
+class VirtualGroup:
+    """Shared state of `world` VIRTUAL ranks: engines that run in `world` Python threads of one process on one device and ONE HIP stream (the
+    default stream of every thread), so host issue order is device execution order."""
+
+    def __init__(self, world):
+        import threading
+        self.world = int(world)
+        self.barrier = threading.Barrier(self.world)
+        self.slots = [None] * self.world
+
+
+class VirtualComm:
+    """The exchange steps C1-C4 of an N-rank data-parallel job inside ONE process: each virtual rank runs the unchanged engine
+    on its shard of the batch -- the same launches, tiles and split plans a real rank of that per-rank batch runs -- and an all-reduce is
+    `deposit, barrier, rank-ordered sum ((r0 + r1) + r2) + ..., barrier`: the sum Comm(deterministic=True) forms across processes, and for two
+    ranks the a + b of any all-reduce.  An N-process job is therefore reproduced BIT FOR BIT (tests/test_gpu_configs_at_size.py:
+    test_data_parallel_equals_virtual_ranks_bit_for_bit); see run_virtual_ranks."""
+    deterministic = True
+
+    def __init__(self, group, rank):
+        self.g, self.rank, self.world = group, int(rank), group.world
+        self.on = self.world > 1
+        self.trace = None
+
+    def enable_trace(self, on=True):
+        self.trace = None
+
+    def trace_summary(self, steps):
+        return {}
+
+    def allreduce_(self, t, label=None):
+        if not self.on:
+            return t
+        g = self.g
+        g.slots[self.rank] = t
+        g.barrier.wait()                      # every rank's tensor is deposited (and its producers are enqueued on the shared stream)
+        acc = g.slots[0].clone()
+        for r in range(1, self.world):
+            acc.add_(g.slots[r])
+        g.barrier.wait()                      # every rank has enqueued its reads of all slots: the in-place results may now be written
+        t.copy_(acc)
+        return t
+
+    def allreduce_async_(self, t, label=None):
+        if not self.on:
+            return None
+        self.allreduce_(t)
+        return _DoneWork()
+
+    def broadcast_(self, t, src=0):
+        if not self.on:
+            return t
+        g = self.g
+        g.slots[self.rank] = t
+        g.barrier.wait()
+        v = g.slots[src].clone()
+        g.barrier.wait()
+        t.copy_(v)
+        return t
+
+
+def run_virtual_ranks(world, fn):
+    """fn(rank, comm) -> result in `world` threads, one VirtualComm each; returns the list of results.  An exception in one rank breaks the
+    barrier, so the others fail instead of waiting for ever."""
+    import threading
+    group = VirtualGroup(world)
+    out, err = [None] * world, []
+
+    def body(r):
+        try:
+            out[r] = fn(r, VirtualComm(group, r))
+        except BaseException as e:          # noqa: BLE001 -- reported below
+            err.append((r, e))
+            group.barrier.abort()
+
+    threads = [threading.Thread(target=body, args=(r,), name="virtual-rank-%d" % r) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    if err:
+        import threading as _t
+        first = [e for e in err if not isinstance(e[1], _t.BrokenBarrierError)] or err
+        raise RuntimeError("virtual rank %d failed: %r" % first[0]) from first[0][1]
+    return out
 
 
 class _NoComm:
@@ -1535,6 +1648,8 @@ class LadderEngine:
 
     def __init__(self, cfg, device="cuda:0", values=None, seed=1, comm=None, noise_seed=1234):
         self.cfg = cfg
+        if comm is None and bool(int(cfg.get("deterministic_allreduce", 0))):
+            comm = Comm(deterministic=True)
         self.ctx = Ctx(device, comm)
         prec = str(cfg.get("matmul_precision", DEFAULT_PRECISION))
         if prec not in PRECISIONS:

@@ -259,8 +259,11 @@ def test_engine_fused_lowres_backward_agrees_with_direct_path(monkeypatch, mode,
 
     monkeypatch.setattr(L, "call", spy)
     res = {}
-    for up2 in (0, mode):
-        eng = LadderEngine(dict(cfg, upsample_fused_convs=up2), "cuda:0", values=Pm, seed=1)
+    for up2 in (0, mode) + (("generic",) if prec == "f32" else ()):
+        if up2 == "generic":      # a SECOND direct formulation (round-1 gather kernels): the rounding-noise floor of this comparison, tensor by tensor
+            monkeypatch.setenv("LADDER_DISABLE_HALO", "1")
+            monkeypatch.setenv("LADDER_DISABLE_BNSTATS", "1")
+        eng = LadderEngine(dict(cfg, upsample_fused_convs=0 if up2 == "generic" else up2), "cuda:0", values=Pm, seed=1)
         eng.set_mixture(*gm)
         del calls[:]
         eng.run_ae(x, 0.0, noise, False, False)
@@ -288,8 +291,14 @@ def test_engine_fused_lowres_backward_agrees_with_direct_path(monkeypatch, mode,
             e = np.abs(g1[name] - g0[name]).max() / sc
             if e > worst:
                 worst, wname = e, name
+            if prec == "f32":
+                # derived bar: at most 3x what a second DIRECT formulation differs by on the same tensor (its rounding-noise floor; the
+                # worst tensor, encoder/code_std_dev/kernel, is a difference of two nearly cancelling terms and measures 2e-4 ... 6e-4 in every build)
+                nf = np.abs(res["generic"][1][name] - g0[name]).max() / sc
+                assert e <= max(3.0 * nf, 5e-5) and e < 2e-3, (name, e, nf)
     print("worst relative gradient difference %.2e (%s)" % (worst, wname))
-    assert worst < 2e-4, (worst, wname)
+    if prec != "f32":
+        assert worst < 2e-4, (worst, wname)
 
 
 @pytest.mark.parametrize("axis,first", [(1, 1), (1, 0), (2, 1), (2, 0)])
