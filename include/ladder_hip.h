@@ -282,7 +282,7 @@ size_t ladder_conv2d_fwd_split_workspace_bytes(int N, int H, int W, int Cin, int
 int ladder_conv2d_fwd_split(const void* x_planes, const float* x_absmax, const void* packed, const float* bias, float* y, int N, int H, int W,
                             int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int act, int prec,
                             void* ws, size_t ws_bytes, ladder_stream_t stream);
-/* The forward call + the batch-norm statistics of its output from the epilogue (sums4 [4 Cout] = sum | sum of squares | min | max per
+/* The forward call + the batch-norm statistics of its output from the epilogue (sums4 = the statistics record, minmax form: 2 Cout doubles sum | sum of squares, then min | max as 2 Cout floats, per
  * channel, as ladder_bn_fwd_stats_minmax); only for calls that run without split-K: the workspace query returns 0 otherwise. */
 size_t ladder_conv2d_fwd_split_bnstats_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
                                                        int pad_t, int pad_l);
@@ -290,7 +290,7 @@ int ladder_conv2d_fwd_split_bnstats(const void* x_planes, const float* x_absmax,
                                     int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l,
                                     int act, int prec, float* sums4, void* stats_ws, size_t stats_ws_bytes, ladder_stream_t stream);
 /* The strict-fp32 form (round 4): ladder_conv2d_fwd (gather kernel, 128x128 tiles, no split-K) whose epilogue also leaves the batch-norm
- * statistics of y in sums4 [4*Cout] = sum | sum of squares | min | max per channel (reference: tf.layers.batch_normalization behind
+ * statistics of y in sums4 (the statistics record in its minmax form: 6 Cout floats) per channel (reference: tf.layers.batch_normalization behind
  * tf.layers.conv2d, codes/models.py:398-460) -- the separate statistics pass over y disappears.  workspace_bytes == 0: the geometry does
  * not run on that kernel configuration (the caller falls back to ladder_conv2d_fwd + ladder_bn_fwd_stats). */
 size_t ladder_conv2d_fwd_bnstats_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t,
@@ -399,15 +399,19 @@ int ladder_act_bwd(const float* dy, const float* y, float* dx, size_t n, int act
  * all-reduce the 2C statistics between the phases (data-parallel: statistics of the GLOBAL batch).
  * x is [rows, C] with rows = N*H*W.  eps = 1e-3 in the reference (TF default). */
 size_t ladder_bn_workspace_bytes(size_t rows, int C);
-/* sums[0:C] = sum_rows x ; sums[C:2C] = sum_rows x^2   (fixed-order two-stage, final stage in fp64) */
-int ladder_bn_fwd_stats(const float* x, float* sums /*[2C]*/, size_t rows, int C,
+/* THE STATISTICS RECORD (round 5; `sums` / `sums4` of every entry point below, 8-byte aligned): 2C DOUBLES = sum_rows x | sum_rows x^2 -- the
+ * first 4C floats of the buffer -- and, in the "minmax" form, min x | max x as 2C floats behind them (6C floats in all).  TF's fused batch
+ * norm forms the variance about the mean; E[x^2] - mean^2 is that exact only in fp64 (relative error eps x (1 + mean^2 / var): rounds 1-4 kept
+ * the sums in fp32 and lost 1.5e-4 of the variance of a channel 50 standard deviations off zero).  ladder_bn_fwd_stats(_minmax) accumulate
+ * every element in fp64 (fixed order); the data-parallel exchange (C2) all-reduces the 2C doubles. */
+int ladder_bn_fwd_stats(const float* x, float* sums /*record: 4C floats*/, size_t rows, int C,
                         void* ws, size_t ws_bytes, ladder_stream_t stream);
-/* mean = sums[c]/count ; var = sums[C+c]/count - mean^2 (biased) ; y = act(gamma*(x-mean)*rsqrt(var+eps)+beta).
+/* mean = sum/count ; var = sum of squares/count - mean^2 (biased, fp64) ; y = act(gamma*(x-mean)*rsqrt(var+eps)+beta).
  * Writes mean_rstd[0:C]=mean, [C:2C]=rstd.  `count` = GLOBAL row count (after the all-reduce). */
-/* Second stage alone: sums from per-block partials [nblk][2][C] (what a convolution epilogue emits), fixed order, fp64. */
-int ladder_bn_stats_from_partials(const float* partials, int nblk, float* sums /*[2C]*/, int C, ladder_stream_t stream);
-/* Statistics with the per-channel extremes: sums4 [4C] = sum x | sum x^2 | min x | max x (the first 2C floats are what ladder_bn_fwd_stats
- * writes; only they are summed across ranks).  Workspace: 2 x ladder_bn_workspace_bytes.  C % 4 == 0. */
+/* Second stage alone: the record from per-block fp32 partials [nblk][2][C] (what a convolution epilogue emits), fixed order, fp64. */
+int ladder_bn_stats_from_partials(const float* partials, int nblk, float* sums /*record: 4C floats*/, int C, ladder_stream_t stream);
+/* Statistics with the per-channel extremes: sums4 = the record in its minmax form (6C floats; only the 2C doubles are summed across ranks).
+ * Workspace: 2 x ladder_bn_workspace_bytes.  C % 4 == 0. */
 int ladder_bn_fwd_stats_minmax(const float* x, float* sums4, size_t rows, int C, void* ws, size_t ws_bytes, ladder_stream_t stream);
 int ladder_bn_stats_minmax_from_partials(const float* partials /*[nblk][4][C]*/, int nblk, float* sums4, int C, ladder_stream_t stream);
 /* ladder_bn_fwd_apply that writes y as the two fp16 PLANES the split gather kernels read (ladder_presplit layout for LADDER_PREC_F16X3) and

@@ -426,7 +426,7 @@ constexpr int WU_NTAPS[4] = {9, 6, 6, 4}, WU_TAP0[4] = {0, 9, 15, 21};          
 
 struct WgradUp2Plan { bool ok; int pw, tiles_ci, tiles_co, ns[4], s0[4], total; };               // splits per class, first workgroup of each class (per slab pair)
 
-template <int CLS, int WU_PW>
+template <int CLS, int WU_PW, bool BIAS>
 __device__ __forceinline__ void wgrad_up2_body(float* __restrict__ lds, const float* __restrict__ x, const float* __restrict__ dy,
                                                float* __restrict__ out, float* __restrict__ bias_part, const int N, const int H, const int W,
                                                const int Cin, const int Cout, const int ci0, const int co0, const int split, const int nsplits,
@@ -455,7 +455,9 @@ __device__ __forceinline__ void wgrad_up2_body(float* __restrict__ lds, const fl
   }
   const int a_off = (dr * WU_HW + lh) * WU_CI + cb * 32 + l31;          // + s * WU_CI (column shift) + 2 ks * WU_CI (pixel)
   const int b_off = WU_XF + lh * WU_CO + l31;                           // + co block * 32 + 2 ks * WU_CO
-  const bool do_bias = (bias_part != nullptr) && (ci0 == 0) && dr == 1 && cb == 0 && active && (!MODEB || sh == 1);
+  // (BIAS: a compile-time switch since round 5 -- the layers in front of a norm have no bias gradient, and the sums + selects of the runtime form
+  // were ~4 VALU instructions per k-step in every wavefront of every launch)
+  const bool do_bias = BIAS && (bias_part != nullptr) && (ci0 == 0) && dr == 1 && cb == 0 && active && (!MODEB || sh == 1);
   constexpr int NACC = MODEB ? 4 : 6;
   f32x16 acc[NACC];
 #pragma unroll
@@ -569,7 +571,7 @@ __device__ __forceinline__ void wgrad_up2_body(float* __restrict__ lds, const fl
           for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int s = B; s < 3; ++s) acc[j * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bc[j], acc[j * 3 + s], 0, 0, 0);
-          if (do_bias) {
+          if (BIAS && do_bias) {
             bsum[0] += bc[0];
             bsum[1] += bc[1];
           }
@@ -578,7 +580,7 @@ __device__ __forceinline__ void wgrad_up2_body(float* __restrict__ lds, const fl
           const float a = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, ac[0]) ^ sg);
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bc[j], acc[j], 0, 0, 0);
-          if (do_bias) {
+          if (BIAS && do_bias) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) bsum[j] += bc[j];
           }
@@ -612,7 +614,7 @@ __device__ __forceinline__ void wgrad_up2_body(float* __restrict__ lds, const fl
           if (nn < Cout) o[(size_t)ci * Cout + nn] = acc[j * 3 + s][e];
         }
       }
-      if (do_bias) {
+      if (BIAS && do_bias) {
         const float v = bsum[j] + __shfl_down(bsum[j], 32, 64);   // odd + even pixels of the k-step pairs
         if (lh == 0 && nn < Cout) bias_part[nn] = v;
       }
@@ -627,7 +629,7 @@ __device__ __forceinline__ void wgrad_up2_body(float* __restrict__ lds, const fl
         const int ci = ci0 + cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         if (nn < Cout) o[(size_t)ci * Cout + nn] = acc[j][e];
       }
-      if (do_bias) {
+      if (BIAS && do_bias) {
         const float v = bsum[j] + __shfl_down(bsum[j], 32, 64);
         if (lh == 0 && nn < Cout) bias_part[nn] = v;
       }
@@ -635,7 +637,7 @@ __device__ __forceinline__ void wgrad_up2_body(float* __restrict__ lds, const fl
   }
 }
 
-template <int WU_PW>
+template <int WU_PW, bool BIAS>
 __global__ __launch_bounds__(WU_THREADS, 3) void wgrad3x3_up2_f32_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                          float* __restrict__ out, float* __restrict__ bias_part,
                                                                          const int N, const int H, const int W, const int Cin, const int Cout,
@@ -653,10 +655,10 @@ __global__ __launch_bounds__(WU_THREADS, 3) void wgrad3x3_up2_f32_kernel(const f
   float* o = out + off * Cin * Cout;
   float* bp = bias_part != nullptr ? bias_part + (size_t)w * Cout : nullptr;
   switch (cls) {
-    case 0: wgrad_up2_body<0, WU_PW>(lds, x, dy, o, bp, N, H, W, Cin, Cout, ci0, co0, split, p.ns[0], xs); break;
-    case 1: wgrad_up2_body<1, WU_PW>(lds, x, dy, o, bp, N, H, W, Cin, Cout, ci0, co0, split, p.ns[1], xs); break;
-    case 2: wgrad_up2_body<2, WU_PW>(lds, x, dy, o, bp, N, H, W, Cin, Cout, ci0, co0, split, p.ns[2], xs); break;
-    default: wgrad_up2_body<3, WU_PW>(lds, x, dy, o, bp, N, H, W, Cin, Cout, ci0, co0, split, p.ns[3], xs); break;
+    case 0: wgrad_up2_body<0, WU_PW, BIAS>(lds, x, dy, o, bp, N, H, W, Cin, Cout, ci0, co0, split, p.ns[0], xs); break;
+    case 1: wgrad_up2_body<1, WU_PW, BIAS>(lds, x, dy, o, bp, N, H, W, Cin, Cout, ci0, co0, split, p.ns[1], xs); break;
+    case 2: wgrad_up2_body<2, WU_PW, BIAS>(lds, x, dy, o, bp, N, H, W, Cin, Cout, ci0, co0, split, p.ns[2], xs); break;
+    default: wgrad_up2_body<3, WU_PW, BIAS>(lds, x, dy, o, bp, N, H, W, Cin, Cout, ci0, co0, split, p.ns[3], xs); break;
   }
 }
 
@@ -937,8 +939,10 @@ int ladder_conv3x3_up2_wgrad(const float* x, int x_upsampled, const float* dy, f
   if (db != nullptr && hipMemsetAsync(bias_part, 0, (size_t)nbias * Cout * 4, stream) != hipSuccess) return LADDER_E_LAUNCH;
   // bias partial rows: the kernel indexes them by the workgroup's position inside its pair (w) -- pairs with ci0 == 0 are the first tiles_co
 #define LADDER_WU_LAUNCH(PW_) \
-  hipLaunchKernelGGL(wgrad3x3_up2_f32_kernel<PW_>, dim3(p.tiles_ci * p.tiles_co * p.total), dim3(WU_THREADS), 0, stream, x, dy, part, \
-                     db != nullptr ? bias_part : nullptr, N, H, W, Cin, Cout, p, xs)
+  do { \
+    if (db != nullptr) hipLaunchKernelGGL((wgrad3x3_up2_f32_kernel<PW_, true>), dim3(p.tiles_ci * p.tiles_co * p.total), dim3(WU_THREADS), 0, stream, x, dy, part, bias_part, N, H, W, Cin, Cout, p, xs); \
+    else hipLaunchKernelGGL((wgrad3x3_up2_f32_kernel<PW_, false>), dim3(p.tiles_ci * p.tiles_co * p.total), dim3(WU_THREADS), 0, stream, x, dy, part, (float*)nullptr, N, H, W, Cin, Cout, p, xs); \
+  } while (0)
   if (p.pw == 32) LADDER_WU_LAUNCH(32);
   else if (p.pw == 16) LADDER_WU_LAUNCH(16);
   else LADDER_WU_LAUNCH(8);

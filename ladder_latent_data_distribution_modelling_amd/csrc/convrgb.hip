@@ -522,7 +522,7 @@ size_t ladder_conv_rgb_s2_fwd_bnstats_workspace_bytes(int N, int H, int W, int C
   return (size_t)N * (H / 2 / RGB_TH) * (W / 2 / RGB_TW) * 4 * Cout * sizeof(float);
 }
 
-// The forward call + the batch-norm statistics of its output (sums4 [4 Cout] = per-channel sum | sum of squares | min | max of y: what
+// The forward call + the batch-norm statistics of its output (sums4 = the statistics record in its minmax form, 6 Cout floats: per-channel sum | sum of squares (doubles), min | max of y: what
 // ladder_bn_fwd_stats_minmax would compute from a second pass over y), from per-patch column statistics of the epilogue.
 int ladder_conv_rgb_s2_fwd_bnstats(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act,
                                    float* sums, void* ws, size_t ws_bytes, ladder_stream_t stream) {

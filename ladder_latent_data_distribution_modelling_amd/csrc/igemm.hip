@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kThreads, (BM * BN >= 128 * 128) ? IGEMM_FWD_MINW :
           // (fuses the previous layer's activation backward into this backward-data pass)
           if (gate != nullptr) v *= ladder_act_grad_from_out(gate[row * d.Cout + n], gate_act);
           y[row * d.Cout + n] = v;
-          if (STATS) {
+          if (STATS && stats_part != nullptr) {        // (wave-uniform: a plain forward / backward-data launch carries no statistics work -- ADVICE r4)
             st0[ni] += v;
             st1[ni] += v * v;
             smn[ni] = fminf(smn[ni], v);
@@ -2282,7 +2282,7 @@ int ladder_conv2d_fwd_split(const void* x_planes, const float* x_absmax, const v
                                ws_bytes, stream, false, nullptr);
 }
 
-// Forward + the batch-norm statistics of its output (sums4 [4 Cout] = sum | sum of squares | min | max per channel, as
+// Forward + the batch-norm statistics of its output (sums4 = the statistics record, minmax form: 2 Cout doubles sum | sum of squares, then min | max, as
 // ladder_bn_fwd_stats_minmax computes them from a second pass over y) from the epilogue's per-tile column statistics.  Available when the
 // call runs without split-K (workspace query > 0): the partial sums of a split reduction never see the finished values.
 size_t ladder_conv2d_fwd_split_bnstats_workspace_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,

@@ -110,44 +110,135 @@ __global__ __launch_bounds__(256) void colstats_stage1_v4(const float* __restric
   }
 }
 
-// MODE 1 plus the per-channel minimum and maximum (ws [nblk][4][C]: sum, sum of squares, min, max): the extremes let the batch-norm
-// apply know max|y| BEFORE it writes y (y is monotone in x per channel), i.e. it can emit fp16 planes directly (bn_apply_planes_kernel).
-__global__ __launch_bounds__(256) void colstats_minmax_stage1_v4(const float* __restrict__ a, float* __restrict__ ws, size_t rows, int C,
-                                                                 size_t rows_per_blk) {
-  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;       // 16 float4 channel groups x 16 row lanes
-  const int c = blockIdx.x * 64 + cq * 4;
+// ---- batch-norm FORWARD statistics in fp64 (round 5) ------------------------------------------------------------------------------------
+// TF's fused batch norm is two-pass (reference codes/models.py:398-460: tf.layers.batch_normalization): the variance is formed about the
+// mean.  The single-pass form var = E[x^2] - mean^2 from fp32 sums loses eps_fp32 x (1 + mean^2 / var) of relative accuracy -- invisible at
+// initialisation (|mean| ~ std), 1.5e-4 on a channel whose mean sits 50 standard deviations off zero.  Rounds 1-4 accumulated and STORED the
+// two sums in fp32 (and all-reduced those: C2).  Now: every element enters an fp64 accumulator (x^2 is exact in fp64), partials and the record
+// are fp64, C2 all-reduces 2C doubles, and E[x^2] - mean^2 in fp64 carries 1e-16 x (1 + mean^2 / var).  These passes are HBM-bound (3 fp64
+// operations per element against 78 TFLOP/s of fp64 vector rate): their duration does not change.
+// RECORD layout (the `sums` argument of every ladder_bn_* entry point): 2C doubles = sum x | sum x^2, i.e. the first 4C floats of the buffer;
+// the "minmax" form appends min x | max x as 2C floats (6C floats in all).
+__global__ __launch_bounds__(256) void colstats64_stage1(const float* __restrict__ a, double* __restrict__ ws, size_t rows, int C,
+                                                         size_t rows_per_blk) {
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   const size_t r0 = (size_t)blockIdx.y * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
-  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-  float4 mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY), mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-  if (c < C) {
-    for (size_t r = r0 + rl; r < r1; r += 16) {
-      const float4 v = *reinterpret_cast<const float4*>(a + r * C + c);
-      s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
-      s1.x += v.x * v.x; s1.y += v.y * v.y; s1.z += v.z * v.z; s1.w += v.w * v.w;
-      mn.x = fminf(mn.x, v.x); mn.y = fminf(mn.y, v.y); mn.z = fminf(mn.z, v.z); mn.w = fminf(mn.w, v.w);
-      mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
+  double s0 = 0.0, s1 = 0.0;
+  if (c < C)
+    for (size_t r = r0 + rl; r < r1; r += 4) {
+      const double v = (double)a[r * C + c];
+      s0 += v;
+      s1 = fma(v, v, s1);
     }
-  }
-  __shared__ float4 sm[4][16][16];
-  sm[0][rl][cq] = s0;
-  sm[1][rl][cq] = s1;
-  sm[2][rl][cq] = mn;
-  sm[3][rl][cq] = mx;
+  __shared__ double sm[2][4][64];
+  sm[0][rl][cl] = s0;
+  sm[1][rl][cl] = s1;
   __syncthreads();
-  if (rl < 4 && c < C) {        // rl = which statistic; fixed-order combination of the 16 row lanes
-    float4 t = sm[rl][0][cq];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) {
-      const float4 v = sm[rl][k][cq];
-      if (rl < 2) { t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
-      else if (rl == 2) { t.x = fminf(t.x, v.x); t.y = fminf(t.y, v.y); t.z = fminf(t.z, v.z); t.w = fminf(t.w, v.w); }
-      else { t.x = fmaxf(t.x, v.x); t.y = fmaxf(t.y, v.y); t.z = fmaxf(t.z, v.z); t.w = fmaxf(t.w, v.w); }
-    }
-    *reinterpret_cast<float4*>(ws + ((size_t)blockIdx.y * 4 + rl) * C + c) = t;
+  if (rl == 0 && c < C) {
+    ws[((size_t)blockIdx.y * 2 + 0) * C + c] = (sm[0][0][cl] + sm[0][1][cl]) + (sm[0][2][cl] + sm[0][3][cl]);
+    ws[((size_t)blockIdx.y * 2 + 1) * C + c] = (sm[1][0][cl] + sm[1][1][cl]) + (sm[1][2][cl] + sm[1][3][cl]);
   }
 }
 
-// second stage for [nblk][4][C] partials: sums in fp64 (fixed order), extremes exactly; out [4C] = sum | sum of squares | min | max.
+// 16 float4 channel groups x 16 row lanes; MINMAX: also the per-channel extremes.  Partials: ws [nblk][2][C] doubles, then (MINMAX) [nblk][2][C]
+// floats behind all of them.
+template <bool MINMAX>
+__global__ __launch_bounds__(256) void colstats64_stage1_v4(const float* __restrict__ a, double* __restrict__ ws, float* __restrict__ wsmm,
+                                                            size_t rows, int C, size_t rows_per_blk) {
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + cq * 4;
+  const size_t r0 = (size_t)blockIdx.y * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
+  double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+  float4 mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY), mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  if (c < C) {
+    auto row = [&](const float4 v) {
+      const double d[4] = {(double)v.x, (double)v.y, (double)v.z, (double)v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s0[j] += d[j];
+        s1[j] = fma(d[j], d[j], s1[j]);
+      }
+      if (MINMAX) {
+        mn.x = fminf(mn.x, v.x); mn.y = fminf(mn.y, v.y); mn.z = fminf(mn.z, v.z); mn.w = fminf(mn.w, v.w);
+        mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
+      }
+    };
+    size_t r = r0 + rl;
+    for (; r + 7 * 16 < r1; r += 8 * 16) {          // eight loads in flight, accumulated in row order
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(a + (r + u * 16) * C + c);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) row(v[u]);
+    }
+    for (; r < r1; r += 16) row(*reinterpret_cast<const float4*>(a + r * C + c));
+  }
+  __shared__ double sm[2][16][16][4];
+  __shared__ float4 smm[2][16][16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sm[0][rl][cq][j] = s0[j];
+    sm[1][rl][cq][j] = s1[j];
+  }
+  if (MINMAX) {
+    smm[0][rl][cq] = mn;
+    smm[1][rl][cq] = mx;
+  }
+  __syncthreads();
+  if (rl < 2 && c < C) {          // rl = which sum; fixed-order combination of the 16 row lanes
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double t = sm[rl][0][cq][j];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) t += sm[rl][k][cq][j];
+      ws[((size_t)blockIdx.y * 2 + rl) * C + c + j] = t;
+    }
+  } else if (MINMAX && rl < 4 && c < C) {
+    const int w = rl - 2;
+    float4 t = smm[w][0][cq];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      const float4 v = smm[w][k][cq];
+      if (w == 0) { t.x = fminf(t.x, v.x); t.y = fminf(t.y, v.y); t.z = fminf(t.z, v.z); t.w = fminf(t.w, v.w); }
+      else { t.x = fmaxf(t.x, v.x); t.y = fmaxf(t.y, v.y); t.z = fmaxf(t.z, v.z); t.w = fmaxf(t.w, v.w); }
+    }
+    *reinterpret_cast<float4*>(wsmm + ((size_t)blockIdx.y * 2 + w) * C + c) = t;
+  }
+}
+
+// second stage over fp64 partials [nblk][2][C] (+ float extremes [nblk][2][C]): the record (2C doubles, + 2C floats); fixed order
+__global__ __launch_bounds__(1024) void colstats64_stage2(const double* __restrict__ ws, const float* __restrict__ wsmm, float* __restrict__ rec,
+                                                          int nblk, int C) {
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;       // rl 0 .. 15
+  const int i = blockIdx.x * 64 + cl;                             // over 2C sums, then (wsmm != NULL) 2C extremes
+  const int total = wsmm != nullptr ? 4 * C : 2 * C;
+  const bool is_sum = i < 2 * C;
+  const int which = is_sum ? i / C : (i - 2 * C) / C, c = is_sum ? i - which * C : i - 2 * C - which * C;
+  double s = is_sum ? 0.0 : (which == 0 ? (double)INFINITY : -(double)INFINITY);
+  if (i < total) {
+    for (int b = rl; b < nblk; b += 16) {
+      if (is_sum) s += ws[((size_t)b * 2 + which) * C + c];
+      else {
+        const double v = (double)wsmm[((size_t)b * 2 + which) * C + c];
+        s = which == 0 ? fmin(s, v) : fmax(s, v);
+      }
+    }
+  }
+  __shared__ double sm[16][64];
+  sm[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && i < total) {
+    double t = sm[0][cl];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t = is_sum ? t + sm[k][cl] : (which == 0 ? fmin(t, sm[k][cl]) : fmax(t, sm[k][cl]));
+    if (is_sum) reinterpret_cast<double*>(rec)[i] = t;
+    else rec[4 * C + (i - 2 * C)] = (float)t;
+  }
+}
+
+// second stage for the fp32 [nblk][4][C] partials a convolution epilogue emits (sum, sum of squares, min, max per tile): sums in fp64 (fixed
+// order), extremes exactly; out = the fp64 record (2C doubles sum | sum of squares, then min | max as 2C floats).
 // 16 columns x 64 row lanes per workgroup, four independent accumulators per lane (round 4: with 16 row lanes and one dependent fp64 chain per
 // lane the 4 096 partial rows of the image-side conv took 47 us -- a third of the conv itself)
 __global__ __launch_bounds__(1024) void colstats_minmax_stage2(const float* __restrict__ ws, float* __restrict__ out, int nblk, int C) {
@@ -178,7 +269,9 @@ __global__ __launch_bounds__(1024) void colstats_minmax_stage2(const float* __re
     double t = sm[0][cl];
 #pragma unroll 8
     for (int k = 1; k < 64; ++k) t = which < 2 ? t + sm[k][cl] : (which == 2 ? fmin(t, sm[k][cl]) : fmax(t, sm[k][cl]));
-    out[i] = (float)t;
+    // the fp64 record (see colstats64_stage1): 2C doubles = sum | sum of squares, then min | max as floats
+    if (which < 2) reinterpret_cast<double*>(out)[i] = t;
+    else out[4 * C + (i - 2 * C)] = (float)t;
   }
 }
 
@@ -220,7 +313,7 @@ __global__ __launch_bounds__(256) void colstats_stage2_wide(const float* __restr
     double t = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += sm[k][cl];
-    out[i] = (float)t;
+    reinterpret_cast<double*>(out)[i] = t;          // the fp64 record (forward statistics only: ladder_bn_stats_from_partials)
   }
 }
 
@@ -239,8 +332,9 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, double count,
   amax_clear_by_block0(clear_rec);
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double mean = (double)sums[c] / count;
-  double var = (double)sums[C + c] / count - mean * mean;
+  const double* s64 = reinterpret_cast<const double*>(sums);      // the fp64 record: sum | sum of squares
+  const double mean = s64[c] / count;
+  double var = s64[C + c] / count - mean * mean;
   if (var < 0.0) var = 0.0;
   mean_rstd[c] = (float)mean;
   mean_rstd[C + c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -293,14 +387,15 @@ __global__ __launch_bounds__(256) void bn_finalize_minmax_kernel(const float* __
                                                                  const float* __restrict__ beta, int C, int act, float* __restrict__ rec) {
   float bmax = 0.f;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const double mean = (double)sums4[c] / count;
-    double var = (double)sums4[C + c] / count - mean * mean;
+    const double* s64 = reinterpret_cast<const double*>(sums4);   // the fp64 record: sum | sum of squares (2C doubles), then min | max (floats)
+    const double mean = s64[c] / count;
+    double var = s64[C + c] / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const float mu = (float)mean, rs = (float)(1.0 / sqrt(var + (double)eps));
     mean_rstd[c] = mu;
     mean_rstd[C + c] = rs;
     const float g = gamma[c], be = beta[c];
-    const float ylo = ladder_act_fn(g * ((sums4[2 * C + c] - mu) * rs) + be, act), yhi = ladder_act_fn(g * ((sums4[3 * C + c] - mu) * rs) + be, act);
+    const float ylo = ladder_act_fn(g * ((sums4[4 * C + c] - mu) * rs) + be, act), yhi = ladder_act_fn(g * ((sums4[5 * C + c] - mu) * rs) + be, act);
     bmax = fmaxf(bmax, fmaxf(fabsf(ylo), fabsf(yhi)));
   }
   __shared__ float red[4];
@@ -975,7 +1070,8 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
     dx[i] = dy[i] * ladder_act_grad_from_out(y[i], act);
 }
 
-__global__ void axpy_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n, float scale, int accumulate) {
+// (in == out is a documented use -- in-place scaling --, so neither pointer is __restrict__)
+__global__ void axpy_kernel(const float* in, float* out, size_t n, float scale, int accumulate) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
     out[i] = accumulate == 2 ? scale : (accumulate ? out[i] + scale * in[i] : scale * in[i]);      // 2: fill with `scale` (in is not read)
@@ -995,15 +1091,14 @@ extern "C" {
 int ladder_bn_fwd_stats(const float* x, float* sums, size_t rows, int C, void* ws, size_t ws_bytes, ladder_stream_t stream) {
   if (rows == 0 || C <= 0) return LADDER_E_SHAPE;
   const size_t nblk = stats_nblk(rows);
-  if (ws_bytes < nblk * 2 * (size_t)C * sizeof(float)) return LADDER_E_WORKSPACE;
+  if (ws_bytes < nblk * 2 * (size_t)C * sizeof(double)) return LADDER_E_WORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(sums) & 7u) != 0 || (reinterpret_cast<uintptr_t>(ws) & 7u) != 0) return LADDER_E_ALIGN;
   const size_t rpb = (rows + nblk - 1) / nblk;
   if (C % 4 == 0 && ladder_aligned16(x))
-    hipLaunchKernelGGL(colstats_stage1_v4<1>, dim3((C + 63) / 64, (unsigned)nblk), dim3(256), 0, stream, x, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)ws, rows, C, rpb, 0);
+    hipLaunchKernelGGL(colstats64_stage1_v4<false>, dim3((C + 63) / 64, (unsigned)nblk), dim3(256), 0, stream, x, (double*)ws, (float*)nullptr, rows, C, rpb);
   else
-    hipLaunchKernelGGL(colstats_stage1<1>, dim3((C + 63) / 64, (unsigned)nblk), dim3(256), 0, stream, x, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)ws, rows, C, rpb, 0);
-  hipLaunchKernelGGL(colstats_stage2, dim3((2 * C + 63) / 64), dim3(1024), 0, stream, (const float*)ws, sums, (int)nblk, C);
+    hipLaunchKernelGGL(colstats64_stage1, dim3((C + 63) / 64, (unsigned)nblk), dim3(256), 0, stream, x, (double*)ws, rows, C, rpb);
+  hipLaunchKernelGGL(colstats64_stage2, dim3((2 * C + 63) / 64), dim3(1024), 0, stream, (const double*)ws, (const float*)nullptr, sums, (int)nblk, C);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
@@ -1038,15 +1133,17 @@ int ladder_bn_fwd_apply_absmax(const float* x, const float* sums, double count, 
   return LADDER_OK;
 }
 
-// sums4 [4C] = sum x | sum x^2 | min x | max x over the rows (per channel); workspace: 2 x ladder_bn_workspace_bytes
+// sums4 = the record in its minmax form (2C doubles sum x | sum x^2, then min x | max x as floats); workspace: 2 x ladder_bn_workspace_bytes
 int ladder_bn_fwd_stats_minmax(const float* x, float* sums4, size_t rows, int C, void* ws, size_t ws_bytes, ladder_stream_t stream) {
   if (rows == 0 || C <= 0 || (C % 4) != 0) return LADDER_E_SHAPE;
   if (!ladder_aligned16(x)) return LADDER_E_ALIGN;
   const size_t nblk = stats_nblk(rows);
-  if (ws_bytes < nblk * 4 * (size_t)C * sizeof(float)) return LADDER_E_WORKSPACE;
+  if (ws_bytes < nblk * (2 * (size_t)C * sizeof(double) + 2 * (size_t)C * sizeof(float))) return LADDER_E_WORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(sums4) & 7u) != 0 || (reinterpret_cast<uintptr_t>(ws) & 7u) != 0) return LADDER_E_ALIGN;
   const size_t rpb = (rows + nblk - 1) / nblk;
-  hipLaunchKernelGGL(colstats_minmax_stage1_v4, dim3((C + 63) / 64, (unsigned)nblk), dim3(256), 0, stream, x, (float*)ws, rows, C, rpb);
-  hipLaunchKernelGGL(colstats_minmax_stage2, dim3((4 * C + 15) / 16), dim3(1024), 0, stream, (const float*)ws, sums4, (int)nblk, C);
+  float* wsmm = reinterpret_cast<float*>(reinterpret_cast<double*>(ws) + nblk * 2 * (size_t)C);
+  hipLaunchKernelGGL(colstats64_stage1_v4<true>, dim3((C + 63) / 64, (unsigned)nblk), dim3(256), 0, stream, x, (double*)ws, wsmm, rows, C, rpb);
+  hipLaunchKernelGGL(colstats64_stage2, dim3((4 * C + 63) / 64), dim3(1024), 0, stream, (const double*)ws, (const float*)wsmm, sums4, (int)nblk, C);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
@@ -1123,7 +1220,7 @@ int ladder_bn_bwd_apply_absmax(const float* dy, const float* x, const float* mea
   return LADDER_OK;
 }
 
-size_t ladder_bn_workspace_bytes(size_t rows, int C) { return stats_nblk(rows) * 2 * (size_t)C * sizeof(float); }
+size_t ladder_bn_workspace_bytes(size_t rows, int C) { return stats_nblk(rows) * 2 * (size_t)C * sizeof(double); }   // (fp64 partials of the forward statistics)
 
 size_t ladder_in_style_workspace_bytes(int N, int HW, int C) { return (size_t)N * in_split(N, HW, C) * 2 * C * sizeof(float); }
 

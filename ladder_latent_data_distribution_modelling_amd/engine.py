@@ -801,7 +801,7 @@ class Conv2D:
             sfx = "" if self.ctx.ns else "_f32"
             if self.want_bn_sums and self.act is None:
                 wsp, wsn = self.ctx.ws(L.query("ladder_conv_rgb_s2_fwd_bnstats_workspace_bytes", N, H, W, self.cout))
-                self.bn_sums = self.ctx.empty(4 * self.cout)       # sum | sum of squares | min | max per channel
+                self.bn_sums = self.ctx.empty(6 * self.cout)       # sum | sum of squares | min | max per channel
                 L.call("ladder_conv_rgb_s2_fwd_bnstats" + sfx, _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y),
                        N, H, W, self.cout, 0, _p(self.bn_sums), wsp, wsn, self.ctx.stream)
             else:
@@ -817,7 +817,7 @@ class Conv2D:
                 snb = L.query("ladder_conv2d_fwd_split_bnstats_workspace_bytes", *geo)
                 if snb:                                  # the epilogue also emits the batch-norm statistics of y (no second pass over it)
                     swp, swn = self.ctx.ws(snb)
-                    self.bn_sums = self.ctx.empty(4 * self.cout)
+                    self.bn_sums = self.ctx.empty(6 * self.cout)
                     L.call("ladder_conv2d_fwd_split_bnstats", _p(self.ctx.planes(x, self._ps(Ho, Wo))), _p(self.x_amax), _p(self._packed_filter(0)),
                            _p(self.ps.w[self.name + "/bias"]), _p(y), *geo, 0, self.ctx.ns, _p(self.bn_sums), swp, swn, self.ctx.stream)
                     self.x, self.y = x, y
@@ -834,7 +834,7 @@ class Conv2D:
             snb = L.query("ladder_conv2d_fwd_bnstats_workspace_bytes", *geo)
             if snb:                                      # strict fp32: the epilogue also emits the batch-norm statistics of y (no second pass over it)
                 swp, swn = self.ctx.ws(snb)
-                self.bn_sums = self.ctx.empty(4 * self.cout)
+                self.bn_sums = self.ctx.empty(6 * self.cout)
                 L.call("ladder_conv2d_fwd_bnstats", _p(x), _p(self.ps.w[self.name + "/kernel"]), _p(self.ps.w[self.name + "/bias"]), _p(y), *geo, 0,
                        _p(self.bn_sums), swp, swn, self.ctx.stream)
                 self.x, self.y = x, y
@@ -1154,7 +1154,7 @@ class BatchNormAct:
         self.ctx, self.ps, self.name, self.C, self.act = ctx, ps, name, C, act
 
     def forward(self, x, sums=None, planes=(False, True)):
-        """`sums`: the statistics of x when its producer already computed them (conv epilogue: [4C] = sum | sum of squares | min | max),
+        """`sums`: the statistics record of x when its producer already computed it (conv epilogue: 2C doubles sum | sum of squares, then min | max),
         else a pass over x.  `planes` = (emit the fp16 plane images of y, also keep y in fp32): with the per-channel extremes max|y| is
         known before y is written, so the apply kernel can split it on the fly -- and when nothing needs the fp32 tensor it is never
         written (returns a PlanesOnly stand-in)."""
@@ -1166,14 +1166,17 @@ class BatchNormAct:
             nb = L.query("ladder_bn_workspace_bytes", rows, C)
             if want_planes:
                 wsp, wsn = ctx.ws(2 * nb)
-                sums = ctx.empty(4 * C)
+                sums = ctx.empty(6 * C)
                 L.call("ladder_bn_fwd_stats_minmax", _p(x), _p(sums), rows, C, wsp, wsn, ctx.stream)
             else:
                 wsp, wsn = ctx.ws(nb)
-                sums = ctx.empty(2 * C)
+                sums = ctx.empty(4 * C)
                 L.call("ladder_bn_fwd_stats", _p(x), _p(sums), rows, C, wsp, wsn, ctx.stream)
-        want_planes = want_planes and sums.numel() == 4 * C
-        ctx.comm.allreduce_(sums[:2 * C], "C2 fwd " + self.name.split("/")[-1])   # (the extremes stay local: they bound THIS rank's tensor)
+        # the statistics RECORD (csrc/norm.hip): 2C doubles = sum x | sum x^2 (the first 4C floats of the buffer), then optionally min | max as
+        # 2C floats.  C2 all-reduces the doubles: E[x^2] - mean^2 in fp64 keeps the variance exact on channels far off zero (TF's fused batch
+        # norm centres first, reference codes/models.py:398-460) -- 2 KB per layer instead of 1 KB.
+        want_planes = want_planes and sums.numel() == 6 * C
+        ctx.comm.allreduce_(sums[:4 * C].view(torch.float64), "C2 fwd " + self.name.split("/")[-1])   # (the extremes stay local: they bound THIS rank's tensor)
         self.count = float(rows) * ctx.comm.world
         self.mean_rstd = ctx.empty(2 * C)
         gam, bet = self.ps.w[self.name + "/gamma"], self.ps.w[self.name + "/beta"]
@@ -1618,8 +1621,9 @@ class InnerVAE:
 class _AsyncFetch:
     """Handle of LadderEngine.fetch_async()."""
 
-    def __init__(self, host, event, names, pool):
+    def __init__(self, host, event, names, pool, undefined=()):
         self._host, self._event, self._names, self._pool, self._val = host, event, names, pool, None
+        self._undefined = frozenset(undefined)
 
     def ready(self):
         """True when get() would not block."""
@@ -1629,10 +1633,15 @@ class _AsyncFetch:
         if self._val is None:
             self._event.synchronize()
             s = self._host.numpy()
-            self._val = {n: float(s[L.S_INDEX[n]]) for n in self._names}
+            self._val = {n: (float("nan") if n in self._undefined else float(s[L.S_INDEX[n]])) for n in self._names}
             self._pool.append(self._host)          # the pinned buffer goes back to the engine's pool
             self._host = None
         return self._val
+
+
+# scalars that exist only when the decoder ran (RUN#3 / RUN#4, sample_code, sample_representation evaluate encoder + inner VAE only)
+DEC_SCALARS = frozenset(("sigma", "mean_pixel_error", "l1_reconstruction_error", "l2_reconstruction_error", "reconstruction_likelihood",
+                         "sigma_regularisor", "elbo", "loss_ae"))
 
 
 # ------------------------------------------------------------------------------------------ engine
@@ -1867,6 +1876,8 @@ class LadderEngine:
         # these runs execute on the aux stream (cross-stream race; the values were timing-dependent).  inner_sigma/Variable is
         # only read by runs that evaluate the inner VAE, all of which are ordered with its writer (RUN#4, same stream / joined).
         sig = self.ps.w["sigma/Variable"] if "dec" in parts else self._sigma_one
+        # (the decoder-dependent scalars of such a run are computed against that stand-in and mean nothing: fetch() reports them as NaN)
+        self._undefined = () if "dec" in parts else DEC_SCALARS
         L.call("ladder_elbo_finalize", _p(P), _p(sig),
                _p(self.ps.w["inner_sigma/Variable"]) if self.has_inner else None, ecfg, _p(self.scalars), st)
         if not early_aux:
@@ -1940,8 +1951,10 @@ class LadderEngine:
         self._join_aux()
         src = self._fetch_src[0] if self._fetch_src is not None else self.scalars
         s = src.detach().cpu().numpy()
-        names = names or [n for n in L.S_NAMES if not n.startswith("_")]
-        return {n: float(s[L.S_INDEX[n]]) for n in names}
+        und = getattr(self, "_undefined", ())
+        # (default list: the scalars the last run DEFINES -- a decoder-less run has no sigma / reconstruction / elbo; asked for by name they are NaN)
+        names = names or [n for n in L.S_NAMES if not n.startswith("_") and n not in und]
+        return {n: (float("nan") if n in und else float(s[L.S_INDEX[n]])) for n in names}
 
     def fetch_async(self, names=None):
         """fetch() without stalling the host: the scalars are copied into pinned host memory behind the kernels enqueued so far and an
@@ -1955,7 +1968,8 @@ class LadderEngine:
             host.copy_(src, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(stream)
-        return _AsyncFetch(host, ev, names or [n for n in L.S_NAMES if not n.startswith("_")], pool)
+        und = getattr(self, "_undefined", ())
+        return _AsyncFetch(host, ev, names or [n for n in L.S_NAMES if not n.startswith("_") and n not in und], pool, und)
 
     def std_dev_code(self):
         return (self.partials[L.P_FIXED:L.P_FIXED + self.Z] / self.Bg).cpu().numpy()
@@ -2110,6 +2124,8 @@ class LadderEngine:
         warm-up calls the run's ~10^2..10^3 launches are replayed as a single graph launch.  Every per-step scalar (Adam step /
         lr_t, noise stream position) lives in device memory, so a replay is exactly the eager run."""
         fn = getattr(self, "_" + kind)
+        # (also on a graph REPLAY, which does not pass through forward(): RUN#3 / RUN#4 evaluate no decoder -> their sigma-dependent scalars are NaN)
+        self._undefined = DEC_SCALARS if (kind in ("prior", "inner_sigma") and not self.vamp) else ()
         if not self.use_graphs or noise is not None or self.ctx.comm.on:
             cache = getattr(self, "_enc_cache", None)
             if (self._aux_on and not self.use_graphs and kind in ("prior", "inner_sigma") and reuse_encoder and not self.vamp

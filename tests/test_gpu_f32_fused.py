@@ -491,11 +491,12 @@ def test_f32_conv_epilogue_emits_the_batch_norm_statistics(gpu_ctx, geom):
     y0, y1 = torch.empty(N, Ho, Wo, Cout, device="cuda"), torch.empty(N, Ho, Wo, Cout, device="cuda")
     L.call("ladder_conv2d_fwd", p(xd), p(wd), p(bd), p(y0), *geo, 0, None, 0, st)
     ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
-    sums = torch.full((4 * Cout,), float("nan"), device="cuda")
+    sums = torch.full((6 * Cout,), float("nan"), device="cuda")          # the statistics record: 2C doubles sum | sum of squares, then min | max (floats)
     L.call("ladder_conv2d_fwd_bnstats", p(xd), p(wd), p(bd), p(y1), *geo, 0, p(sums), p(ws), ws.numel(), st)
     assert torch.equal(y0, y1)
     yr = y0.double().cpu().numpy().reshape(-1, Cout)
-    got = sums.cpu().numpy().reshape(4, Cout)
+    from test_gpu_split import bn_record
+    got = [t.cpu().numpy() for t in bn_record(sums, Cout)]
     assert np.abs(got[0] - yr.sum(0)).max() <= 1e-6 * np.abs(yr).sum(0).max()                  # fp32 partial sums over 128-pixel tiles, then a fixed tree (measured 6e-8)
     assert np.abs(got[1] - (yr * yr).sum(0)).max() <= 2e-6 * (yr * yr).sum(0).max()
     assert np.array_equal(got[2], yr.min(0).astype(np.float32)) and np.array_equal(got[3], yr.max(0).astype(np.float32))

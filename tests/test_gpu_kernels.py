@@ -192,7 +192,7 @@ def test_batch_norm(gpu_ctx, shape, act):
     st = gpu_ctx.stream
     xd, gd, bd, dyd = dev(x), dev(g), dev(be), dev(dy)
     wsp, wsn = gpu_ctx.ws(L.query("ladder_bn_workspace_bytes", rows, C))
-    sums, mr = torch.empty(2 * C, device="cuda"), torch.empty(2 * C, device="cuda")
+    sums, mr = torch.empty(4 * C, device="cuda"), torch.empty(2 * C, device="cuda")     # (the record: 2C doubles)
     y = torch.empty_like(xd)
     L.call("ladder_bn_fwd_stats", p(xd), p(sums), rows, C, wsp, wsn, st)
     L.call("ladder_bn_fwd_apply", p(xd), p(sums), float(rows), p(gd), p(bd), p(y), p(mr), rows, C, 1e-3, L.ACT[act], st)
@@ -204,6 +204,64 @@ def test_batch_norm(gpu_ctx, shape, act):
     close(dx, xt.grad, 2e-5, "dx")
     close(dg, gt.grad, 2e-5, "dgamma")
     close(db, bt.grad, 2e-5, "dbeta")
+
+
+@pytest.mark.parametrize("shape,minmax", [((128, 4, 4, 64), False), ((16, 32, 32, 128), True), ((8, 8, 8, 100), False), ((64, 64, 64, 32), True)])
+def test_batch_norm_far_off_centre_channels(gpu_ctx, shape, minmax):
+    """per-channel means of +-50 standard deviations.  TF's fused batch norm (reference codes/models.py:398-460) is two-pass; the
+    single-pass E[x^2] - mean^2 from fp32-stored sums of rounds 1-4 lost eps_fp32 x (1 + mean^2 / var) = 1.5e-4 of the variance here.  With the
+    fp64 statistics record the normalised output matches the float64 oracle to 1e-5 of its scale, the variance to 1e-6 -- for the separate pass
+    (with and without the extremes) on big and small maps."""
+    L = _lib()
+    rng = np.random.default_rng(sum(shape))
+    C = shape[-1]
+    rows = int(np.prod(shape[:-1]))
+    sd = (0.5 + rng.random(C)).astype(np.float32)
+    mean = (50.0 * sd * np.where(rng.random(C) < 0.5, -1.0, 1.0)).astype(np.float32)
+    x = (rng.standard_normal(shape) * sd + mean).astype(np.float32)
+    g = (1 + 0.3 * rng.standard_normal(C)).astype(np.float32)
+    be = (0.2 * rng.standard_normal(C)).astype(np.float32)
+    yr = O.batch_norm_train(torch.tensor(x, dtype=torch.float64), torch.tensor(g, dtype=torch.float64), torch.tensor(be, dtype=torch.float64))
+    st = gpu_ctx.stream
+    xd, gd, bd = dev(x), dev(g), dev(be)
+    wsp, wsn = gpu_ctx.ws(2 * L.query("ladder_bn_workspace_bytes", rows, C))
+    sums, mr = torch.empty(6 * C if minmax else 4 * C, device="cuda"), torch.empty(2 * C, device="cuda")
+    y = torch.empty_like(xd)
+    L.call("ladder_bn_fwd_stats_minmax" if minmax else "ladder_bn_fwd_stats", p(xd), p(sums), rows, C, wsp, wsn, st)
+    L.call("ladder_bn_fwd_apply", p(xd), p(sums), float(rows), p(gd), p(bd), p(y), p(mr), rows, C, 1e-3, 0, st)
+    close(y, yr, 1e-5, "y")
+    x64 = x.astype(np.float64).reshape(-1, C)
+    var = x64.var(0)
+    got_var = 1.0 / mr[C:].double().cpu().numpy() ** 2 - 1e-3
+    assert np.abs(got_var - var).max() / var.max() < 1e-6, np.abs(got_var - var).max() / var.max()
+    if minmax:
+        assert np.array_equal(sums[4 * C:5 * C].cpu().numpy(), x.reshape(-1, C).min(0)) and np.array_equal(sums[5 * C:].cpu().numpy(), x.reshape(-1, C).max(0))
+
+
+def test_batch_norm_far_off_centre_two_ranks():
+    """... and across two data-parallel ranks (C2 all-reduces the fp64 record): the engine's BatchNormAct on two virtual ranks (engine.VirtualComm)
+    against the float64 oracle's batch norm over the concatenated batch."""
+    from ladder_latent_data_distribution_modelling_amd.engine import BatchNormAct, Ctx, run_virtual_ranks
+    rng = np.random.default_rng(77)
+    N, H, W, C = 16, 16, 16, 64
+    sd = (0.5 + rng.random(C)).astype(np.float32)
+    mean = (50.0 * sd * np.where(rng.random(C) < 0.5, -1.0, 1.0)).astype(np.float32)
+    x = (rng.standard_normal((N, H, W, C)) * sd + mean).astype(np.float32)
+    x[: N // 2] += (3.0 * sd).astype(np.float32)                    # the two shards have different means: the combination matters
+    g = (1 + 0.3 * rng.standard_normal(C)).astype(np.float32)
+    be = (0.2 * rng.standard_normal(C)).astype(np.float32)
+    yr = O.act(O.batch_norm_train(torch.tensor(x, dtype=torch.float64), torch.tensor(g, dtype=torch.float64), torch.tensor(be, dtype=torch.float64)), "leaky_relu")
+
+    class _PS:
+        w = {"bn/gamma": torch.as_tensor(g).cuda(), "bn/beta": torch.as_tensor(be).cuda()}
+
+    def job(rank, comm):
+        ctx = Ctx("cuda:0", comm)
+        bn = BatchNormAct(ctx, _PS, "bn", C, "leaky_relu")
+        return bn.forward(torch.as_tensor(x[rank * (N // 2):(rank + 1) * (N // 2)]).cuda()).cpu().numpy()
+
+    out = np.concatenate(run_virtual_ranks(2, job))
+    assert np.abs(out - yr.numpy()).max() / np.abs(yr.numpy()).max() < 1e-5
 
 
 @pytest.mark.parametrize("shape", [(3, 2, 2, 64), (2, 16, 16, 32), (2, 8, 8, 100), (4, 64, 64, 128)])

@@ -959,6 +959,7 @@ def test_async_fetch_equals_blocking_fetch(golden_dir):
                 assert len(tr.code_elbo_train) == 1 and len(tr._pending) in (1, 2)
         lp = tr.last_fetch_prior                                                  # (property: flushes)
         assert not tr._pending and len(tr.code_elbo_train) == 4 and len(tr.sigma_train) == 4
+        assert not any(k in lp for k in ("sigma", "elbo", "loss_ae", "l1_reconstruction_error")) and "elbo_prior" in lp    # RUN#3 evaluates no decoder
         outs.append((losses, list(tr.elbo_train), list(tr.sigma_train), list(tr.code_elbo_train), list(tr.code_inner_sigma_train), lp,
                      {k: v.tobytes() for k, v in tr.engine.ps.to_dict().items()}))
     for o in outs[1:]:
