@@ -144,8 +144,12 @@ def roofline_of(prof, precision, step_seconds, traffic_for=None):
             "launches": dom["launches"], "avg_launch_ms": round(dom["avg_ms"], 4),
             "flop_per_launch": dom.get("executed_flops_per_launch", dom["flops_per_launch"]), "effective_flop_per_launch": dom["flops_per_launch"],
             "share_of_step_time": round(dom["total_ms"] / (1e3 * step_seconds), 3),
-            "other_kernels": [{"kernel": r["kernel"], "achieved": round(r["tflops"], 2), "launches": r["launches"],
-                               "avg_launch_ms": round(r["avg_ms"], 4)} for r in prof.values() if r is not dom and r.get("bound", "mfma") == "mfma"]}
+            # (every row on ISSUED FLOPs, like the dominant kernel; `effective` = the reference's operation count of the same launches, which
+            # exceeds the peak where a fused launch issues 25 of 36 products -- VERDICT r4 weak #7)
+            "other_kernels": [{"kernel": r["kernel"], "achieved": round(r.get("executed_tflops", r["tflops"]), 2), "frac": round(r.get("executed_tflops", r["tflops"]) / peak, 4),
+                               "effective": round(r["tflops"], 2), "launches": r["launches"], "avg_launch_ms": round(r["avg_ms"], 4),
+                               "share_of_step_time": round(r["total_ms"] / (1e3 * step_seconds), 3)}
+                              for r in prof.values() if r is not dom and r.get("bound", "mfma") == "mfma"]}
 
 
 def main():
@@ -306,9 +310,11 @@ def main():
         fl = dict(fl)
         note = "RUN#3/#4 reuse RUN#2's encoder output (bit-identical): 1.23 GFLOP of the algorithmic 41.4 are not executed"
         used = getattr(eng.ctx, "up2_used", {})
-        if used:      # conv2d_7 (4.832 GFLOP / image forward) and conv2d_6 (2.416) in RUN#1 (":train") and RUN#2, their backward-data (":bwd"): 11 / 36 not issued
-            per = {"decoder/conv2d_7": 4.832e9, "decoder/conv2d_7:train": 4.832e9, "decoder/conv2d_6": 2.416e9, "decoder/conv2d_6:train": 2.416e9,
-                   "decoder/conv2d_7:bwd": 4.832e9, "decoder/conv2d_6:bwd": 2.416e9, "decoder/conv2d_7:wgrad": 4.832e9, "decoder/conv2d_6:wgrad": 2.416e9}
+        if used:      # conv2d_7 (4.832 GFLOP / image forward), conv2d_6 (2.416), conv2d_5 (1.208), conv2d_4 (0.604) in RUN#1 (":train") and RUN#2, ":bwd", ":wgrad": 11 / 36 not issued
+            per = {}
+            for lname, gf in (("decoder/conv2d_7", 4.832e9), ("decoder/conv2d_6", 2.416e9), ("decoder/conv2d_5", 1.208e9), ("decoder/conv2d_4", 0.604e9)):
+                for sfx in ("", ":train", ":bwd", ":wgrad"):      # forward-only run, training forward, backward-data, filter gradient
+                    per[lname + sfx] = gf
             fl["executed"] -= sum(v for k, v in per.items() if k in used) * 11.0 / 36.0
             note += ("; upsample-fused convolutions (%s): the factor-2 resize in front of the layer is folded into its taps (forward, ':bwd' backward-data, "
                      "':wgrad' filter gradient), 25 of every 36 low-resolution tap products are issued" % ", ".join(sorted(used)))
@@ -359,6 +365,22 @@ def main():
                        "backend": dist.get_backend(), "calls_per_step": round(sum(v["calls_per_step"] for v in head["comm"].values()), 1),
                        "note": "under data parallelism the engine keeps every run on one stream (no RUN#3 / RUN#4 overlap, eager launches): "
                                "`single_stream_cost` of the 1-GPU line says what that costs per rank"}
+        # ... and what a ring all-reduce over xGMI SHOULD cost for the same calls (the first real multi-GPU run is read against
+        # a model, not against nothing): per call 2 (N-1)/N x bytes over one 153 GB/s link direction (point-to-point xGMI, ring = per-link
+        # bound: MI355X_MICROARCH / brief) + a fixed latency of 2 (N-1) hops x 5 us (stated assumption: small-message RCCL ring step on xGMI;
+        # to be replaced by the first measured 8-byte all-reduce)
+        LINK_GBS, HOP_US = 153.0, 5.0
+        pred = {}
+        for label, v in head["comm"].items():
+            bw_us = 2.0 * (world - 1) / world * v["bytes_per_call"] / (LINK_GBS * 1e3)
+            lat_us = 2.0 * (world - 1) * HOP_US
+            pred[label] = {"predicted_us_per_call": round(bw_us + lat_us, 1), "bandwidth_term_us": round(bw_us, 1), "latency_term_us": round(lat_us, 1),
+                           "predicted_us_per_step": round((bw_us + lat_us) * v["calls_per_step"], 1)}
+        out["comm"]["predicted"] = {"model": "ring all-reduce: 2 (N-1)/N x bytes / %.0f GB/s per xGMI link direction + 2 (N-1) x %.0f us per call" % (LINK_GBS, HOP_US),
+                                    "n_ranks": world, "collectives": pred,
+                                    "wall_ms_per_step": round(sum(q["predicted_us_per_step"] for q in pred.values()) / 1e3, 3),
+                                    "note": "the asynchronous C1 decoder bucket overlaps the encoder's backward pass: its predicted time is exposed only "
+                                            "beyond that pass (~1.4 ms at batch 128)"}
     if "sustained" in head:
         out["sustained"] = head["sustained"]
     # also the AE-step-only (RUN#1) and forward-only (val_step, VAE fetches) rates; untimed extras after the metric

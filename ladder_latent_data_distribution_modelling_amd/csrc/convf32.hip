@@ -289,6 +289,21 @@ __global__ __launch_bounds__(FH_THREADS, 4) void conv3x3_halo_f32_kernel(const f
 // bank[tap][ci][co], ci < Cin, co < Cout (LOGICAL dimensions of the orientation); thread index decoded as in filter_pack_element of
 // convsplit.hip, so that a job table's block counts (ladder_filter_pack_job_blocks) serve both precisions:
 //   i -> (tap, 16-channel slab, 128-column tile, channel octet kg, column) ; a thread writes 8 rows (ci) of one column
+// per-axis coefficients A_a[d][0..2] of the upsample algebra (filterbank.h) as three selects -- a thread decodes its tap and class ONCE; the
+// table lookups of filter_bank_element (runtime-indexed local arrays = scratch memory) cost the all-bank re-pack 265 us per iteration in round 5's
+// first build (18 banks, 130 MB written at 0.5 TB/s)
+__device__ __forceinline__ void up2_axis_coef(int a, int d, float c[3]) {
+  if (a == 0) {
+    c[0] = d <= 1 ? 0.5f : 0.f;
+    c[1] = d == 1 ? 1.f : 0.f;
+    c[2] = d >= 1 ? 0.5f : 0.f;
+  } else {
+    c[0] = d == 1 ? 1.f : 0.f;
+    c[1] = d >= 1 ? 0.5f : 0.f;
+    c[2] = d == 2 ? 1.f : 0.f;
+  }
+}
+
 __device__ __forceinline__ void filter_pack_f32_element(const float* __restrict__ w, float* __restrict__ out, int ntaps, int Cin, int Cout,
                                                         int transpose_flip, int i) {
   const int cots = (Cout + FH_BN - 1) / FH_BN, nslabs = Cin / 16;
@@ -301,6 +316,43 @@ __device__ __forceinline__ void filter_pack_f32_element(const float* __restrict_
   const int slab = t % nslabs, tap = t / nslabs;
   const int co = cot * FH_BN + col, ci0 = slab * 16 + kg * 8;
   if (co >= Cout) return;
+  if ((transpose_flip == 3 && ((Cout >> 2) % 4) == 0) || (transpose_flip == 4 && ((Cin >> 2) % 8) == 0)) {
+    // the effective taps of the upsample-fused forward (3) / backward-data (4): the SAME sums in the SAME order as filter_bank_element (r outer,
+    // s inner, zero coefficients skipped, the exact product of two powers of two as the weight), with the class / tap decode hoisted
+    const int dr = tap / 3, dc = tap - 3 * dr;
+    float cr[3], cs[3];
+    size_t base, rstride;                                     // address of term (r, s), row j: base + (r * 3 + s) * rstride + j * jstride
+    int jstride;
+    if (transpose_flip == 3) {
+      const int C = Cout >> 2, cls = co / C, cc = co - cls * C;
+      up2_axis_coef(cls >> 1, dr, cr);
+      up2_axis_coef(cls & 1, dc, cs);
+      base = (size_t)ci0 * C + cc; rstride = (size_t)Cin * C; jstride = C;
+    } else {
+      const int C = Cin >> 2, cls = ci0 / C, cc0 = ci0 - cls * C;            // (8 rows of one thread: one class, C % 8 == 0)
+      up2_axis_coef(cls >> 1, 2 - dr, cr);
+      up2_axis_coef(cls & 1, 2 - dc, cs);
+      base = (size_t)co * C + cc0; rstride = (size_t)Cout * C; jstride = 1;
+    }
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      if (cr[r] == 0.f) continue;
+#pragma unroll
+      for (int sx = 0; sx < 3; ++sx) {
+        if (cs[sx] == 0.f) continue;
+        const float cf = cr[r] * cs[sx];
+        const float* src = w + base + (size_t)(r * 3 + sx) * rstride;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] += cf * src[(size_t)j * jstride];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[((size_t)tap * Cin + ci0 + j) * Cout + co] = f[j];
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j)
     out[((size_t)tap * Cin + ci0 + j) * Cout + co] = filter_bank_element(w, ntaps, Cin, Cout, transpose_flip, tap, ci0 + j, co);

@@ -210,6 +210,9 @@ __global__ __launch_bounds__(FS_THREADS, 4) void conv3x3_halo_f32s_kernel(const 
         const int r = tap / 3, sft = tap - 3 * r;
         const float* Ab = &Ah[hb][a_lane + (r * PW + sft) * LDA];
         const float* Bb = &Bh[bbuf][t * FKS * BN + lh * BN + wn * (32 * NI) + l31];
+        // (requesting the fragments of a whole group of k-steps ahead of its MFMAs -- in bulk, or software-pipelined one group ahead with counted
+        // lgkmcnt waits -- measured 0 ... 5 % SLOWER on every geometry: the LDS latency of one wavefront is already covered by the other three
+        // of its SIMD, and the longer-lived fragments cost registers: profiles/r05_small_maps_sweep.txt)
 #pragma unroll
         for (int ks = 0; ks < FKS / 2; ++ks) {
           float a[MI], b[NI];

@@ -39,6 +39,9 @@ class KernelProfiler:
              9124: "wgrad3x3_split_kernel<f16x3> (64ci x 128co slab x 9 taps, 8 waves x 9 tiles, transposing LDS reads, 3 x MFMA 32x32x16 f16; incl. its split reduction)",
              9122: "wgrad3x3_split_kernel<bf16x3>", 9123: "wgrad3x3_split_kernel<bf16x6>",
              9128: "wgrad3x3_halo_kernel (64ci x 128co slab x 9 taps, 12 waves, LDS-DMA staged 1x32-pixel patches, fp32 MFMA 32x32x2)",
+             256064: "conv3x3_halo_f32s_kernel<UPM, GEO, NI, FKS> (small maps: 16x16 / 8x16 / 8x8-px sub-patches x 64 / 128 ch LDS-halo tile, 8 waves, fp32 MFMA "
+                     "32x32x2; instantiations: plain, upsample-fused forward (class pairs), parity-class input (upsample-fused backward-data, stride-2 forward), "
+                     "stride-2 backward-data classes)",
              9120: "wgrad3x3_up2_f32_kernel + reductions / edge lines (filter gradient of resize x2 -> 3x3 conv over the low-resolution map: 25 of 36 tap tiles, "
                    "one parity class per workgroup, 12 waves, LDS-DMA staged 1x32-pixel patches, fp32 MFMA 32x32x2)",
              7700: "gmm_logprob_kernel<R> + gmm_sum_kernel (mixture log-prob / responsibilities, lane = component, wave-shuffle logsumexp)"}
@@ -622,6 +625,15 @@ class Conv2D:
         return bool(self.k == 3 and self.stride == 1 and self.padding == "same"
                     and L.query("ladder_conv3x3_f32_eligible" if self.ctx.ns == 0 else "ladder_conv3x3_split_eligible", N, H, W, cin, cout))
 
+    def _halo_kid(self, N, H, W, cin, cout, class_cout=None):
+        """Profiler id of the halo-kernel launch over an [N, H, W] map with `cin` gathered and `cout` bank columns: the 8x32-pixel tiling
+        (csrc/convf32.hip, csrc/convsplit.hip) or -- strict fp32 only -- a small-map tiling (csrc/convf32s.hip).  `class_cout`: channels per
+        class of a class-structured launch (the 8x32 tiling needs 128)."""
+        if self.ctx.ns:
+            return 256120 + self.ctx.ns
+        big = L.query("ladder_conv3x3_split_eligible", N, H, W, cin, cout) and (class_cout is None or class_cout == 128)
+        return 256120 if big else 256064
+
     def _split_ok(self, N, H, W, cin, cout):
         """... and the precision is one of the 16-bit split formats (their filter gradient / planes / absmax machinery)."""
         return bool(self.ctx.ns and self._halo_ok(N, H, W, cin, cout))
@@ -749,7 +761,7 @@ class Conv2D:
             y = ctx.empty(N, 2 * H, 2 * W, self.cout) if keep_y else None
             out = ctx.empty(N, 2 * H, 2 * W, proj.cout)
             pw, pb = self.ps.w[proj.name + "/kernel"], self.ps.w[proj.name + "/bias"]
-            _timed(256120 + ctx.ns, flops, "ladder_conv3x3_up2_split_proj",
+            _timed(self._halo_kid(N, H, W, self.cin, 4 * self.cout, self.cout), flops, "ladder_conv3x3_up2_split_proj",
                    (_p(src), _p(x_amax), _p(self._packed_filter(3)), _p(bias), _p(y), _p(pw), _p(pb), _p(out), proj.cout, N, H, W, self.cin, self.cout,
                     L.ACT[self.act], ctx.ns, strided, ctx.stream), executed)
             L.call("ladder_conv3x3_up2_edges", _p(src), _p(wk), _p(bias), _p(y), None, _p(pw), _p(pb), _p(out), proj.cout, N, H, W, self.cin, self.cout,
@@ -763,7 +775,7 @@ class Conv2D:
             return out
         y = ctx.empty(N, 2 * H, 2 * W, self.cout)
         y_amax = ctx.new_amax() if ctx.ns == 4 else None
-        _timed(256120 + ctx.ns, flops, "ladder_conv3x3_up2_split",
+        _timed(self._halo_kid(N, H, W, self.cin, 4 * self.cout, self.cout), flops, "ladder_conv3x3_up2_split",
                (_p(src), _p(x_amax), _p(self._packed_filter(3)), _p(bias), _p(y), _p(y_amax), N, H, W, self.cin, self.cout, L.ACT[self.act], ctx.ns,
                 strided, ctx.stream), executed)
         L.call("ladder_conv3x3_up2_edges", _p(src), _p(wk), _p(bias), _p(y), _p(y_amax), None, None, None, 0, N, H, W, self.cin, self.cout,
@@ -788,7 +800,7 @@ class Conv2D:
             args = (_p(x), _p(self.x_amax), _p(self._packed_filter(0)), _p(self.ps.w[self.name + "/bias"]), _p(y), _p(y_amax), N, H, W,
                     self.cin, self.cout, L.ACT[self.act], self.ctx.ns, self.ctx.stream)
             self.ctx.set_amax(y, y_amax)
-            _timed(256120 + self.ctx.ns, 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_split", args)
+            _timed(self._halo_kid(N, H, W, self.cin, self.cout), 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_split", args)
             self.x, self.y = x, y
             return y
         if self._as_dense(N * H * W):                   # 1x1 conv over a tiny map (decoder conv0 on the 1x1 map) = a batch-sized dense layer
@@ -846,7 +858,7 @@ class Conv2D:
             # (Behind the statistics-epilogue branch above: conv2d_1 measures 344 us + a statistics pass here against 356 us with them.)
             args = (_p(x), _p(self._packed_filter(5)), _p(self.ps.w[self.name + "/bias"]), _p(y), N, H, W, self.cin, Ho, Wo, self.cout,
                     L.ACT[self.act], self.ctx.stream)
-            _timed(256120, 2.0 * N * Ho * Wo * 9 * self.cin * self.cout, "ladder_conv3x3_s2_fwd_f32", args)
+            _timed(self._halo_kid(N, Ho, Wo, 4 * self.cin, self.cout), 2.0 * N * Ho * Wo * 9 * self.cin * self.cout, "ladder_conv3x3_s2_fwd_f32", args)
             self.x, self.y = x, y
             return y
         _igemm(self.ctx, "ladder_conv2d_fwd", N * Ho * Wo, self.cin, self.cout, self.k * self.k * self.cin,
@@ -887,7 +899,7 @@ class Conv2D:
         if ctx.ns == 0:
             # strict fp32: the main launch, then its four border lines made exact in place from ONE d_up line per border (csrc/convf32.hip:
             # ladder_conv3x3_up2_bwd_borders -- 9 instead of 45 line-taps per axis; the strip path below cost 1.07 ms per iteration)
-            _timed(256120, flops, "ladder_conv3x3_up2_bwd_data_split",
+            _timed(self._halo_kid(N, H, W, 4 * self.cout, self.cin), flops, "ladder_conv3x3_up2_bwd_data_split",
                    (_p(dy), None, _p(pk4), _p(dx), None, N, H, W, self.cout, self.cin, 0, st), flops * 25.0 / 36.0)
             wsp, wsn = ctx.ws(L.query("ladder_conv3x3_up2_bwd_borders_workspace_bytes", N, H, W, self.cout, self.cin))
             L.call("ladder_conv3x3_up2_bwd_borders", _p(dy), _p(self.ps.w[self.name + "/kernel"]), _p(dx), N, H, W, self.cout, self.cin, wsp, wsn, st)
@@ -1043,7 +1055,7 @@ class Conv2D:
             args = (_p(dy), _p(dy_amax), _p(self._packed_filter(1)), None, _p(dx), _p(dx_amax), N, H, W, self.cout, self.cin, 0,
                     self.ctx.ns, st)
             self.ctx.set_amax(dx, dx_amax)
-            _timed(256120 + self.ctx.ns, 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_split", args)
+            _timed(self._halo_kid(N, H, W, self.cout, self.cin), 2.0 * N * H * W * 9 * self.cin * self.cout, "ladder_conv3x3_split", args)
         elif (need_dx and self.ctx.ns in (0, 4) and not gate_prev and self.stride == 2 and not (self.ctx.ns == 0 and os.environ.get("LADDER_DISABLE_HALO") == "1")
               and (L.query("ladder_conv3x3_s2_bwd_data_split_eligible", N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride,
                            self.pt, self.pl) or (self.ctx.ns == 0 and self.k == 3 and self.pt == 0 and self.pl == 0 and
@@ -1055,7 +1067,7 @@ class Conv2D:
             dx_amax = self.ctx.new_amax() if self.ctx.ns == 4 else None
             args = (_p(dy), _p(dy_amax), _p(self._packed_filter(2)), _p(dx), _p(dx_amax), N, H, W, self.cin, Ho, Wo, self.cout, self.ctx.ns, st)
             self.ctx.set_amax(dx, dx_amax)
-            _timed(256120 + self.ctx.ns, 2.0 * N * Ho * Wo * 9 * self.cin * self.cout, "ladder_conv3x3_s2_bwd_data_split", args)
+            _timed(self._halo_kid(N, Ho, Wo, self.cout, 4 * self.cin, self.cin), 2.0 * N * Ho * Wo * 9 * self.cin * self.cout, "ladder_conv3x3_s2_bwd_data_split", args)
         elif need_dx and self.ctx.ns and L.query("ladder_conv2d_bwd_data_split_eligible", N, H, W, self.cin, Ho, Wo, self.cout, self.k,
                                                  self.k, self.stride, self.pt, self.pl, 1 if gate_prev else 0):
             geo = (N, H, W, self.cin, Ho, Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl)
