@@ -913,7 +913,8 @@ WgradUp2Plan plan_wgrad_up2(int N, int H, int W, int Cin, int Cout) {
   const long pairs = (long)p.tiles_ci * p.tiles_co;
   // two rounds of the chip (one workgroup per CU: 84 KB of LDS), shared between the classes in proportion to their cost per patch (MFMA
   // slots per SIMD and k-step: 18 / 12 / 12 / 8 -- the busiest SIMD of class 3 still issues 2 wavefronts x 4)
-  long per_pair = 512 / pairs;
+  static const int rounds_env = getenv("LADDER_WU_WGS") ? atoi(getenv("LADDER_WU_WGS")) : 0;      // (experiment switch: workgroups per launch)
+  long per_pair = (rounds_env > 0 ? rounds_env : 512) / pairs;
   if (per_pair < 8) per_pair = 8;
   // measured per-patch time of the classes (2 x 32-pixel patches, one class at a time on the chip): 21.0 / 14.6 / 15.6 / 10.9 us -- the MFMA
   // time (16.0 / 10.7 / 10.7 / 7.1 us) + ~4-5 us per patch that the direct kernel pays as well (its matrix pipe is 76 % busy); 512 or

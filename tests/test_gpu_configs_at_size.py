@@ -137,7 +137,9 @@ def test_celeba_r8k50_full_size_in_situ(tmp_path):
     fa, fb = json.loads(str(res["f16x3"]["fetch"])), json.loads(str(res["f32"]["fetch"]))
     for k in SCALARS_RUN1:
         assert np.isfinite(fa["ae"][k]) and _ok(fa["ae"][k], fb["ae"][k], 2e-6, 1e-5), (k, fa["ae"][k], fb["ae"][k])
-    assert _rel(fa["grad_norm"], fb["grad_norm"]) < 1e-4
+    # (round 5: 1.2e-4 measured -- the strict-fp32 build now contracts conv2d_5 / conv2d_4 against EFFECTIVE taps (sums of up to nine fp32 filter
+    # values, one more rounding per tap) where the f16x3 build keeps the direct form; round 4, both direct there: 4.7e-5)
+    assert _rel(fa["grad_norm"], fb["grad_norm"]) < 3e-4
     assert _ok(fa["sigma"]["sigma"], fb["sigma"]["sigma"], 1e-5)
     for k in SCALARS_RUN3:
         assert _ok(fa["prior"][k], fb["prior"][k], 2e-3, 1e-5), (k, fa["prior"][k], fb["prior"][k])
