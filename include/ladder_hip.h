@@ -239,6 +239,15 @@ int ladder_conv3x3_up2_bwd_border(const float* d_up, float* dx, float* dx_absmax
 size_t ladder_conv3x3_up2_bwd_borders_workspace_bytes(int N, int H, int W, int C, int Cout);
 int ladder_conv3x3_up2_bwd_borders(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int Cout, void* ws, size_t ws_bytes,
                                    ladder_stream_t stream);
+/* The gated forms (round 5, strict fp32, the 8x32-pixel tiling): dx = act'(gate) x (d loss / d x_lo) with gate [N, H, W, Cout] = the ACTIVATED tensor
+ * that x_lo is -- the activation backward of the layer below an un-normalised resize -> conv pair (decoder conv2d_5 -> conv2d_6,
+ * codes/models.py:556-564: tf.gradients through tf.nn.leaky_relu) rides on the epilogue of the main launch and on the border fix-up; the separate
+ * ladder_act_bwd pass over that tensor disappears.  bank_up2t as for ladder_conv3x3_up2_bwd_data_split with prec = LADDER_PREC_F32. */
+int ladder_conv3x3_up2_bwd_data_gated_f32_eligible(int N, int H, int W, int C, int Cout);
+int ladder_conv3x3_up2_bwd_data_gated_f32(const float* dy, const void* bank_up2t, float* dx, const float* gate, int gate_act, int N, int H, int W, int C,
+                                          int Cout, ladder_stream_t stream);
+int ladder_conv3x3_up2_bwd_borders_gated(const float* dy, const float* w, float* dx, const float* gate, int gate_act, int N, int H, int W, int C, int Cout,
+                                         void* ws, size_t ws_bytes, ladder_stream_t stream);
 /* Filter gradient of the same pair over the LOW-resolution map (round 4, strict fp32; csrc/convf32.hip): dw [3][3][Cin][Cout] (and db [Cout],
  * may be NULL) of y = conv3x3_same(resize2x(x), w) from x [N, H, W, Cin] (x_upsampled != 0: x points at the materialised upsample
  * [N, 2H, 2W, Cin] a training forward keeps, read at its even rows / columns) and dy [N, 2H, 2W, Cout]: per output-parity class the 9 / 6 / 6 / 4

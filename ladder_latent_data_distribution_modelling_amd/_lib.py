@@ -141,6 +141,9 @@ PROTOTYPES = {
     "ladder_conv3x3_up2_edges": (_i, [_p] * 8 + [_i] * 8 + [_p, _z, _p]),
     "ladder_conv3x3_s2_bwd_data_split": (_i, [_p, _p, _p, _p, _p] + [_i] * 8 + [_p]),
     "ladder_conv3x3_f32_eligible": (_i, [_i] * 5),
+    "ladder_conv3x3_up2_bwd_data_gated_f32_eligible": (_i, [_i] * 5),
+    "ladder_conv3x3_up2_bwd_data_gated_f32": (_i, [_p, _p, _p, _p] + [_i] * 6 + [_p]),
+    "ladder_conv3x3_up2_bwd_borders_gated": (_i, [_p, _p, _p, _p] + [_i] * 6 + [_p, _z, _p]),
     "ladder_conv3x3_s2_bwd_data_f32_eligible": (_i, [_i] * 7),
     "ladder_conv3x3_s2_fwd_f32_eligible": (_i, [_i] * 7),
     "ladder_conv3x3_s2_fwd_f32": (_i, [_p, _p, _p, _p] + [_i] * 8 + [_p]),

@@ -205,10 +205,24 @@ __global__ __launch_bounds__(FH_THREADS, 4) void conv3x3_halo_f32_kernel(const f
         float* yp = s2o ? y + (((long)img * 2 * H + 2 * (h0 + 2 * wm + mi) + (cot >> 1)) * 2 * W + 2 * w0 + (cot & 1)) * FH_BN + (n - n0)
                         : y + (((long)img * H + h0 + 2 * wm + mi) * W + w0) * Cout + n;
         const long pstride = s2o ? 2 * FH_BN : Cout;
+        if constexpr (UPM == 2) {
+          // backward-data of an upsample-fused pair: `pw` / `pco` of a non-projecting launch carry an optional GATE -- the activation OUTPUT of the
+          // layer that produced the low-resolution tensor and its activation id: dx *= act'(gate), that layer's activation backward (round 5: the
+          // separate ladder_act_bwd pass over conv2d_5's output is gone)
+          const float* gp = (pw != nullptr && n < Cout) ? pw + (yp - y) : nullptr;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int px = (e & 3) + 8 * (e >> 2) + 4 * lh;
-          if (n < Cout) yp[(long)px * pstride] = ladder_act_fn(acc[mi][ni][e] + bv, act);
+          for (int e = 0; e < 16; ++e) {
+            const int px = (e & 3) + 8 * (e >> 2) + 4 * lh;
+            float v = ladder_act_fn(acc[mi][ni][e] + bv, act);
+            if (gp != nullptr) v *= ladder_act_grad_from_out(gp[(long)px * pstride], pco);
+            if (n < Cout) yp[(long)px * pstride] = v;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int px = (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (n < Cout) yp[(long)px * pstride] = ladder_act_fn(acc[mi][ni][e] + bv, act);
+          }
         }
       }
     }
@@ -416,7 +430,7 @@ int conv3x3_f32_launch(const float* x, const float* bank, const float* bias, flo
                        int pco, int N, int H, int W, int Cin, int Cout, int act, hipStream_t stream, unsigned long long tap_masks,
                        int s2_out) {
   if (!conv3x3_f32_big_ok(N, H, W, Cin, Cout, s2_out)) {     // small maps / wide classes: convf32s.hip (no fused projection there)
-    if (pout != nullptr) return LADDER_E_SHAPE;
+    if (pout != nullptr || pw != nullptr) return LADDER_E_SHAPE;        // (no fused projection / gate there)
     return conv3x3_f32s_launch(x, bank, bias, y, N, H, W, Cin, Cout, act, stream, tap_masks, s2_out);
   }
   if (pout != nullptr && (pw == nullptr || pco < 1 || pco > 4 || (Cout > FH_BN && s2_out < 2) || !ladder_aligned16(pw))) return LADDER_E_SHAPE;
@@ -857,7 +871,8 @@ __global__ __launch_bounds__(256) void up2_border_operands_kernel(const float* _
 // dx[border] += - D_r (x) M_c - M_r (x) D_c + D_r (x) D_c from the four d_up lines: rt / rb [N][2W+1][Cout] (index u = t + 1, t = -1 .. 2W-1),
 // cl / cr [N][2H+1][Cout] (index q + 1).  Row threads own the corners; column threads cover i = 1 .. H-2.
 __global__ __launch_bounds__(256) void up2_border_fixup_kernel(const float* __restrict__ rt, const float* __restrict__ rb, const float* __restrict__ cl,
-                                                               const float* __restrict__ cr, float* __restrict__ dx, int N, int H, int W, int Cout) {
+                                                               const float* __restrict__ cr, float* __restrict__ dx, int N, int H, int W, int Cout,
+                                                               const float* __restrict__ gate, int gate_act) {
   const int CV = Cout >> 2;
   const long n_rows = (long)N * 2 * W * CV, n_cols = (long)N * 2 * (H - 2) * CV;
   const float4* rt4 = reinterpret_cast<const float4*>(rt);
@@ -894,6 +909,11 @@ __global__ __launch_bounds__(256) void up2_border_fixup_kernel(const float* __re
       const float sg = right ? 0.5f : -0.5f;
       d = make_float4(sg * m.x, sg * m.y, sg * m.z, sg * m.w);
       o = (((long)n * H + i) * W + (right ? W - 1 : 0)) * CV + cv;
+    }
+    if (gate != nullptr) {                                          // the main launch applied act'(gate) to its value: the correction carries the same factor
+      const float4 g = reinterpret_cast<const float4*>(gate)[o];
+      d.x *= ladder_act_grad_from_out(g.x, gate_act); d.y *= ladder_act_grad_from_out(g.y, gate_act);
+      d.z *= ladder_act_grad_from_out(g.z, gate_act); d.w *= ladder_act_grad_from_out(g.w, gate_act);
     }
     float4 v = reinterpret_cast<float4*>(dx)[o];
     v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
@@ -1040,8 +1060,8 @@ size_t ladder_conv3x3_up2_bwd_borders_workspace_bytes(int N, int H, int W, int C
 
 // dx [N, H, W, Cout] = the result of ladder_conv3x3_up2_bwd_data_split(dy [N, 2H, 2W, C], ...): its four border lines are made exact IN PLACE
 // (w = the layer's HWIO bank [3][3][Cout][C]).  Must follow that launch on the same stream.
-int ladder_conv3x3_up2_bwd_borders(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int Cout, void* ws, size_t ws_bytes,
-                                   ladder_stream_t stream) {
+static int up2_bwd_borders_impl(const float* dy, const float* w, float* dx, const float* gate, int gate_act, int N, int H, int W, int C, int Cout, void* ws,
+                                size_t ws_bytes, ladder_stream_t stream) {
   const size_t need = ladder_conv3x3_up2_bwd_borders_workspace_bytes(N, H, W, C, Cout);
   if (need == 0) return LADDER_E_SHAPE;
   if (!ladder_aligned16(dy) || !ladder_aligned16(w) || !ladder_aligned16(dx)) return LADDER_E_ALIGN;
@@ -1074,9 +1094,35 @@ int ladder_conv3x3_up2_bwd_borders(const float* dy, const float* w, float* dx, i
   rc = ladder_conv2d_fwd(in_right, k_right, nullptr, cr, N, 2 * H, 2, C, 2 * H + 1, 1, Cout, 3, 2, 1, 2, 0, LADDER_ACT_NONE, q, g, stream);
   if (rc != LADDER_OK) return rc;
   hipLaunchKernelGGL(up2_border_fixup_kernel, dim3(512), dim3(256), 0, stream, (const float*)rt, (const float*)rb, (const float*)cl, (const float*)cr, dx,
-                     N, H, W, Cout);
+                     N, H, W, Cout, gate, gate_act);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
+}
+
+int ladder_conv3x3_up2_bwd_borders(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int Cout, void* ws, size_t ws_bytes,
+                                   ladder_stream_t stream) {
+  return up2_bwd_borders_impl(dy, w, dx, nullptr, 0, N, H, W, C, Cout, ws, ws_bytes, stream);
+}
+
+// ---- the gated forms (round 5): dx = act'(gate) * d loss / d x_lo, gate [N, H, W, Cout] = the ACTIVATED tensor the low-resolution input is -- the
+// activation backward of the layer below an un-normalised resize -> conv pair (decoder conv2d_5 -> conv2d_6, codes/models.py:556-564) rides on the
+// epilogue of the main launch and on the border fix-up; strict fp32, the 8x32-pixel tiling
+int ladder_conv3x3_up2_bwd_data_gated_f32_eligible(int N, int H, int W, int C, int Cout) {
+  static const bool off = getenv("LADDER_DISABLE_UP2") != nullptr;
+  return (!off && (C % 16) == 0 && conv3x3_f32_big_ok(N, H, W, 4 * C, Cout, 4)) ? 1 : 0;
+}
+
+int ladder_conv3x3_up2_bwd_data_gated_f32(const float* dy, const void* bank_up2t, float* dx, const float* gate, int gate_act, int N, int H, int W, int C,
+                                          int Cout, ladder_stream_t stream) {
+  if (!ladder_conv3x3_up2_bwd_data_gated_f32_eligible(N, H, W, C, Cout) || gate == nullptr || !ladder_aligned16(gate)) return LADDER_E_SHAPE;
+  return conv3x3_f32_launch(dy, (const float*)bank_up2t, nullptr, dx, gate, nullptr, nullptr, gate_act, N, H, W, 4 * C, Cout, LADDER_ACT_NONE, stream,
+                            filter_bank_tap_masks(4), 4);
+}
+
+int ladder_conv3x3_up2_bwd_borders_gated(const float* dy, const float* w, float* dx, const float* gate, int gate_act, int N, int H, int W, int C, int Cout,
+                                         void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  if (gate == nullptr || !ladder_aligned16(gate)) return LADDER_E_SHAPE;
+  return up2_bwd_borders_impl(dy, w, dx, gate, gate_act, N, H, W, C, Cout, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -883,7 +883,12 @@ class Conv2D:
                         (N, 2, 2 * W, self.cin, 3, 2 * W, self.cout, 3, 3, 1, 1, 1), (N, 3, 2 * W, self.cin, 4, 2 * W, self.cout, 3, 3, 1, 2, 1),
                         (N, 2 * H, 2, self.cin, 2 * H, 3, self.cout, 3, 3, 1, 1, 1), (N, 2 * H, 3, self.cin, 2 * H, 4, self.cout, 3, 3, 1, 1, 2)))))
 
-    def _dx_lowres(self, dy, dy_amax):
+    def lowres_gate_ok(self, N, H, W):
+        """_dx_lowres can apply the activation backward of the layer below (its `gate`) in the same launches (strict fp32, 8x32-pixel tiling)."""
+        return bool(self.ctx.ns == 0 and os.environ.get("LADDER_DISABLE_LOWRES_GATE") != "1"
+                    and L.query("ladder_conv3x3_up2_bwd_data_gated_f32_eligible", N, H, W, self.cout, self.cin))
+
+    def _dx_lowres(self, dy, dy_amax, gate=None):
         """d loss / d x_lo for y = conv(resize2x(x_lo)): the composite transpose is a zero-padded 5x5 / stride-2 correlation over dy (one launch of
         the halo kernel, 25 instead of 36 tap products per low-resolution pixel, the [N, 2H, 2W, cin] intermediate never written), exact on
         every pixel but the four border lines of dx, where the resize's clamp and the convolution's padding change the coefficients: those
@@ -899,9 +904,16 @@ class Conv2D:
         if ctx.ns == 0:
             # strict fp32: the main launch, then its four border lines made exact in place from ONE d_up line per border (csrc/convf32.hip:
             # ladder_conv3x3_up2_bwd_borders -- 9 instead of 45 line-taps per axis; the strip path below cost 1.07 ms per iteration)
+            wsp, wsn = ctx.ws(L.query("ladder_conv3x3_up2_bwd_borders_workspace_bytes", N, H, W, self.cout, self.cin))
+            if gate is not None:        # (y of the layer below, its activation): dx *= act'(y) in the epilogue and in the border fix-up
+                gy, gact = gate
+                _timed(self._halo_kid(N, H, W, 4 * self.cout, self.cin), flops, "ladder_conv3x3_up2_bwd_data_gated_f32",
+                       (_p(dy), _p(pk4), _p(dx), _p(gy), L.ACT[gact], N, H, W, self.cout, self.cin, st), flops * 25.0 / 36.0)
+                L.call("ladder_conv3x3_up2_bwd_borders_gated", _p(dy), _p(self.ps.w[self.name + "/kernel"]), _p(dx), _p(gy), L.ACT[gact], N, H, W, self.cout,
+                       self.cin, wsp, wsn, st)
+                return dx
             _timed(self._halo_kid(N, H, W, 4 * self.cout, self.cin), flops, "ladder_conv3x3_up2_bwd_data_split",
                    (_p(dy), None, _p(pk4), _p(dx), None, N, H, W, self.cout, self.cin, 0, st), flops * 25.0 / 36.0)
-            wsp, wsn = ctx.ws(L.query("ladder_conv3x3_up2_bwd_borders_workspace_bytes", N, H, W, self.cout, self.cin))
             L.call("ladder_conv3x3_up2_bwd_borders", _p(dy), _p(self.ps.w[self.name + "/kernel"]), _p(dx), N, H, W, self.cout, self.cin, wsp, wsn, st)
             return dx
         pk = self._packed_filter(1)
@@ -935,7 +947,7 @@ class Conv2D:
         ctx.set_amax(dx, dx_amax)
         return dx
 
-    def backward(self, dy, need_dx=True, wgrad=True, act_done=False, gate_prev=None, lowres_dx=False):
+    def backward(self, dy, need_dx=True, wgrad=True, act_done=False, gate_prev=None, lowres_dx=False, lowres_gate=None):
         """`act_done`: dy already carries this layer's activation derivative (fused into the consumer's epilogue).
         `gate_prev`: activation name of the layer that produced this conv's input x: its derivative act'(x) is fused into
         the backward-data epilogue, so that layer must then be called with act_done=True.
@@ -1048,7 +1060,7 @@ class Conv2D:
         if lowres_dx and not split_d:
             raise RuntimeError("%s: the low-resolution backward-data was requested for a call the split halo kernels do not take" % self.name)
         if split_d and lowres_dx:
-            dx = self._dx_lowres(dy, dy_amax)
+            dx = self._dx_lowres(dy, dy_amax, lowres_gate)
         elif split_d:
             dx = self.ctx.empty(N, H, W, self.cin)
             dx_amax = self.ctx.new_amax() if self.ctx.ns == 4 else None
@@ -1552,6 +1564,7 @@ class CelebADecoder:
         dh = self.conv_out.backward(dxhat, gate_prev=last_conv.act if fuse_last else None)
         ddlat = None
         lowres = False            # dh is already the gradient of the LOW-resolution tensor behind the next resize (fused into the conv's backward-data)
+        pre_gated = False         # ... and already carries this block's activation derivative (gated low-resolution backward-data of the block above)
         for bi, (conv, sty, norm, rs) in enumerate(reversed(self.blocks)):
             gated = False
             if lowres:
@@ -1572,7 +1585,13 @@ class CelebADecoder:
                 and (below[3].oh, below[3].ow) == tuple(conv.x.shape[1:3]) and conv.x.shape[1] % 2 == 0
                 and tuple(getattr(below[3], "in_shape", (0, 0, 0))[1:3]) == (conv.x.shape[1] // 2, conv.x.shape[2] // 2)
                 and conv.up2t_ok(conv.x.shape[0], conv.x.shape[1] // 2, conv.x.shape[2] // 2)))
-            dh = conv.backward(dh, act_done=(bi == 0 and fuse_last) or gated, lowres_dx=lowres)
+            # ... and that block's own activation backward rides on it when it is an un-normalised leaky conv (conv2d_5 under conv2d_6)
+            lgate = None
+            if (lowres and below is not None and below[2] is None and below[0].act is not None and below[0].y is not None and conv.x is not None
+                    and conv.lowres_gate_ok(conv.x.shape[0], below[0].y.shape[1], below[0].y.shape[2])):
+                lgate = (below[0].y, below[0].act)
+            dh = conv.backward(dh, act_done=(bi == 0 and fuse_last) or gated or pre_gated, lowres_dx=lowres, lowres_gate=lgate)
+            pre_gated = lgate is not None                      # (the NEXT block's activation backward is done)
         dh = self.conv0.backward(self.up0.backward(dh))
         denc = dh.reshape(dh.shape[0], self.nh)
         # mapping MLP: each layer's backward-data epilogue applies the previous layer's leaky-ReLU derivative

@@ -380,7 +380,10 @@ def test_f32_engine_routes_through_the_fused_kernels_and_agrees_with_the_direct_
     f3, g3, e3, d3, tc3, ec3, p3 = res[3]
     # (round 5: conv2d_5's pair -- 16x16 low-resolution map -- joins in all three passes, so the 16 -> 32 upsample is virtual too; conv2d_4's pair --
     # 8x8 -- takes the fused forward only: the border lines of its backward-data and the edge lines / partial sums of its filter gradient cost more than the fusion saves)
-    assert tc3.count("ladder_conv3x3_up2_wgrad") == 3 and tc3.count("ladder_conv3x3_up2_bwd_data_split") == 3 and tc3.count("ladder_conv3x3_up2_bwd_borders") == 3
+    # (conv2d_6's pair runs the GATED form: conv2d_5's leaky-ReLU backward rides on its epilogue and border fix-up, no ladder_act_bwd pass)
+    assert tc3.count("ladder_conv3x3_up2_wgrad") == 3 and tc3.count("ladder_conv3x3_up2_bwd_data_split") == 2 and tc3.count("ladder_conv3x3_up2_bwd_borders") == 2
+    assert tc3.count("ladder_conv3x3_up2_bwd_data_gated_f32") == 1 and tc3.count("ladder_conv3x3_up2_bwd_borders_gated") == 1
+    assert tc3.count("ladder_act_bwd") == tc1.count("ladder_act_bwd")      # (level 2 applies conv2d_5's gate on the resize transpose, level 3 on the gated launches: no extra pass either way)
     assert "ladder_in_style_fwd_resize2x_keep" not in tc3 and tc3.count("ladder_resize_bilinear_fwd") == tc0.count("ladder_resize_bilinear_fwd") - 1
     assert tc3.count("ladder_resize_bilinear_bwd") + tc3.count("ladder_resize_bilinear_bwd_gated") == tc0.count("ladder_resize_bilinear_bwd") + tc0.count("ladder_resize_bilinear_bwd_gated") - 3
     assert tc1.count("ladder_conv3x3_up2_wgrad") == 3           # (level 2 keeps the resized tensors: the filter gradients read their even sub-grids)
@@ -631,3 +634,32 @@ def test_f32_conv3x3_stride2_bwd_data_any_class_width(gpu_ctx, geom):
     dyd = dev(dy)
     L.call("ladder_conv3x3_s2_bwd_data_split", p(dyd), None, p(bank), p(dx), None, N, H, W, Cin, Ho, Wo, Cout, F32, st)
     close(dx, xt.grad, TOL32, "dx")
+
+
+def test_f32_up2_backward_data_gated_equals_ungated_times_activation_derivative(gpu_ctx):
+    """ladder_conv3x3_up2_bwd_data_gated_f32 + ladder_conv3x3_up2_bwd_borders_gated: the leaky-ReLU backward of the layer below the resize (reference
+    codes/models.py:556-564: conv2d_5 -> resize -> conv2d_6) applied in the epilogue of the main launch and in the border fix-up -- bit-identical to the
+    ungated pair followed by ladder_act_bwd (a product with 1 or 0.2: the same fp32 multiplication), borders and corners included."""
+    L = _lib()
+    N, H, W, C, Cout = 128, 32, 32, 32, 256            # dy [N, 2H, 2W, C], dx [N, H, W, Cout]
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(5)
+    w = (rng.standard_normal((3, 3, Cout, C)) / np.sqrt(9 * C)).astype(np.float32)
+    dy = rng.standard_normal((N, 2 * H, 2 * W, C)).astype(np.float32)
+    ylo = rng.standard_normal((N, H, W, Cout)).astype(np.float32)                 # the activated low-resolution tensor (sign = the gate)
+    assert L.query("ladder_conv3x3_up2_bwd_data_gated_f32_eligible", N, H, W, C, Cout) == 1
+    bank = _bank(L, w, 4 * C, Cout, 4, st)
+    dyd, wd, yd = dev(dy), dev(w), dev(ylo)
+    ws = torch.empty(L.query("ladder_conv3x3_up2_bwd_borders_workspace_bytes", N, H, W, C, Cout), dtype=torch.uint8, device="cuda")
+    dx0 = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    L.call("ladder_conv3x3_up2_bwd_data_split", p(dyd), None, p(bank), p(dx0), None, N, H, W, C, Cout, F32, st)
+    L.call("ladder_conv3x3_up2_bwd_borders", p(dyd), p(wd), p(dx0), N, H, W, C, Cout, p(ws), ws.numel(), st)
+    L.call("ladder_act_bwd", p(dx0), p(yd), p(dx0), dx0.numel(), 1, st)
+    dx1 = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    L.call("ladder_conv3x3_up2_bwd_data_gated_f32", p(dyd), p(bank), p(dx1), p(yd), 1, N, H, W, C, Cout, st)
+    L.call("ladder_conv3x3_up2_bwd_borders_gated", p(dyd), p(wd), p(dx1), p(yd), 1, N, H, W, C, Cout, p(ws), ws.numel(), st)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dx1).all()
+    # interior: the same product; border lines: gate x (main + correction) against gate x main + gate x correction -- one rounding apart
+    assert torch.equal(dx1[:, 1:-1, 1:-1], dx0[:, 1:-1, 1:-1])
+    close(dx1, dx0.cpu().numpy(), 1e-6, "border lines")

@@ -275,10 +275,12 @@ def test_engine_fused_lowres_backward_agrees_with_direct_path(monkeypatch, mode,
     plain_gone = 1                                    # the 128 -> 64 transpose is gone
     if prec == "f32" and mode == 3:                   # (round 5, strict fp32: + conv2d_5 on its 16x16 low-resolution map, csrc/convf32s.hip: the 32 -> 16 transpose goes too)
         nl, plain_gone = 3, 2
-    assert c1.count("ladder_conv3x3_up2_bwd_data_split") == nl and "ladder_conv3x3_up2_bwd_data_split" not in c0
+    ng = 1 if (prec == "f32" and mode == 3) else 0    # (conv2d_6's pair in its gated form: conv2d_5's activation backward rides on it)
+    assert c1.count("ladder_conv3x3_up2_bwd_data_split") + c1.count("ladder_conv3x3_up2_bwd_data_gated_f32") == nl and c1.count("ladder_conv3x3_up2_bwd_data_gated_f32") == ng
+    assert "ladder_conv3x3_up2_bwd_data_split" not in c0
     assert c1.count("ladder_resize_bilinear_bwd") == c0.count("ladder_resize_bilinear_bwd") - plain_gone
     if prec == "f32":       # strict fp32: the four border lines are corrected in place from one d_up line each (one call per layer)
-        assert c1.count("ladder_conv3x3_up2_bwd_borders") == nl and "ladder_conv3x3_up2_bwd_border" not in c1
+        assert c1.count("ladder_conv3x3_up2_bwd_borders") + c1.count("ladder_conv3x3_up2_bwd_borders_gated") == nl and "ladder_conv3x3_up2_bwd_border" not in c1
     else:
         assert c1.count("ladder_conv3x3_up2_bwd_border") == 4 * nl                                        # 4 border lines per layer (strips)
     assert c1.count("ladder_resize_bilinear_bwd_gated") == c0.count("ladder_resize_bilinear_bwd_gated") - (1 if mode == 3 else 0)   # mode 3: the gated 64 -> 32 one too
