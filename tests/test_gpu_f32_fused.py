@@ -380,10 +380,8 @@ def test_f32_engine_routes_through_the_fused_kernels_and_agrees_with_the_direct_
     f3, g3, e3, d3, tc3, ec3, p3 = res[3]
     # (round 5: conv2d_5's pair -- 16x16 low-resolution map -- joins in all three passes, so the 16 -> 32 upsample is virtual too; conv2d_4's pair --
     # 8x8 -- takes the fused forward only: the border lines of its backward-data and the edge lines / partial sums of its filter gradient cost more than the fusion saves)
-    # (conv2d_6's pair runs the GATED form: conv2d_5's leaky-ReLU backward rides on its epilogue and border fix-up, no ladder_act_bwd pass)
-    assert tc3.count("ladder_conv3x3_up2_wgrad") == 3 and tc3.count("ladder_conv3x3_up2_bwd_data_split") == 2 and tc3.count("ladder_conv3x3_up2_bwd_borders") == 2
-    assert tc3.count("ladder_conv3x3_up2_bwd_data_gated_f32") == 1 and tc3.count("ladder_conv3x3_up2_bwd_borders_gated") == 1
-    assert tc3.count("ladder_act_bwd") == tc1.count("ladder_act_bwd")      # (level 2 applies conv2d_5's gate on the resize transpose, level 3 on the gated launches: no extra pass either way)
+    assert tc3.count("ladder_conv3x3_up2_wgrad") == 3 and tc3.count("ladder_conv3x3_up2_bwd_data_split") == 3 and tc3.count("ladder_conv3x3_up2_bwd_borders") == 3
+    assert "ladder_conv3x3_up2_bwd_data_gated_f32" not in tc3      # (the gated form is an opt-in: it measured no faster than the activation pass it removes)
     assert "ladder_in_style_fwd_resize2x_keep" not in tc3 and tc3.count("ladder_resize_bilinear_fwd") == tc0.count("ladder_resize_bilinear_fwd") - 1
     assert tc3.count("ladder_resize_bilinear_bwd") + tc3.count("ladder_resize_bilinear_bwd_gated") == tc0.count("ladder_resize_bilinear_bwd") + tc0.count("ladder_resize_bilinear_bwd_gated") - 3
     assert tc1.count("ladder_conv3x3_up2_wgrad") == 3           # (level 2 keeps the resized tensors: the filter gradients read their even sub-grids)

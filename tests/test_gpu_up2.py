@@ -275,7 +275,7 @@ def test_engine_fused_lowres_backward_agrees_with_direct_path(monkeypatch, mode,
     plain_gone = 1                                    # the 128 -> 64 transpose is gone
     if prec == "f32" and mode == 3:                   # (round 5, strict fp32: + conv2d_5 on its 16x16 low-resolution map, csrc/convf32s.hip: the 32 -> 16 transpose goes too)
         nl, plain_gone = 3, 2
-    ng = 1 if (prec == "f32" and mode == 3) else 0    # (conv2d_6's pair in its gated form: conv2d_5's activation backward rides on it)
+    ng = 0                                            # (the gated form of conv2d_6's pair is an opt-in: LADDER_ENABLE_LOWRES_GATE=1)
     assert c1.count("ladder_conv3x3_up2_bwd_data_split") + c1.count("ladder_conv3x3_up2_bwd_data_gated_f32") == nl and c1.count("ladder_conv3x3_up2_bwd_data_gated_f32") == ng
     assert "ladder_conv3x3_up2_bwd_data_split" not in c0
     assert c1.count("ladder_resize_bilinear_bwd") == c0.count("ladder_resize_bilinear_bwd") - plain_gone
