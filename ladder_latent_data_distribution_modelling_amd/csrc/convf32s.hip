@@ -98,8 +98,14 @@ __global__ __launch_bounds__(FS_THREADS, 4) void conv3x3_halo_f32s_kernel(const 
 
   // wavefront -> pixel tiles: m = wm * MI + mi; sub-patch s = m / MPS, first row (m % MPS) * RPM; lane -> pixel (l31 / TW, l31 % TW)
   const int m0 = wm * MI;
-  const int a_lane = (((m0 / MPS) * SPIX + (m0 % MPS) * RPM * PW + (l31 / TW) * PW + (l31 % TW)) * LDA) + lh;
-  constexpr int A_MI = RPM * PW * LDA;                                       // second pixel tile of the wavefront (same sub-patch)
+  // Rows of a pixel tile: consecutive (first row (m % MPS) * RPM), or -- 16x16 sub-patches, ROWI -- INTERLEAVED: tile m holds rows m % MPS and
+  // m % MPS + 8.  The fragment read ds_read_b32 serves 32 lanes per cycle from 32 banks at pixel stride LDA (odd): two pixels collide iff their halo
+  // indices are congruent mod 32.  Rows r, r + 1 of an 18-pixel-wide halo put lanes 30 / 31 on the banks of lanes 0 / 1 (indices 32, 33); rows r, r + 8
+  // are 144 = 4 x 32 + 16 apart: conflict-free (measured: 869 -> 867 us on conv2d_5's fused forward -- the LDS is not what bounds these kernels).
+  constexpr bool ROWI = (GEO == 0);
+  constexpr int RSTEP = ROWI ? MPS : 1, RMUL = ROWI ? 1 : RPM;                 // row step inside a tile, first-row multiplier of the tile index
+  const int a_lane = (((m0 / MPS) * SPIX + (m0 % MPS) * RMUL * PW + (l31 / TW) * RSTEP * PW + (l31 % TW)) * LDA) + lh;
+  constexpr int A_MI = RMUL * PW * LDA;                                      // second pixel tile of the wavefront (same sub-patch)
 
   const int subs = cls_mode ? creal / BN : 0;
   const int ncc = (cls_mode && pair) ? 2 : 1;
@@ -252,11 +258,11 @@ __global__ __launch_bounds__(FS_THREADS, 4) void conv3x3_halo_f32s_kernel(const 
       const long spg = (long)mt * NIMG + s;
       if (spg >= sp_total) continue;
       const int img = (int)(spg / sp_img), r2 = (int)(spg - (long)img * sp_img);
-      const int hb0 = (r2 / tw_n) * SH + (m % MPS) * RPM, wb0 = (r2 - (r2 / tw_n) * tw_n) * TW + 4 * lh;
+      const int hb0 = (r2 / tw_n) * SH + (m % MPS) * RMUL, wb0 = (r2 - (r2 / tw_n) * tw_n) * TW + 4 * lh;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int ce = (e & 3) + 8 * (e >> 2);
-        const int hh = hb0 + ce / TW, ww = wb0 + ce % TW;
+        const int hh = hb0 + (ce / TW) * RSTEP, ww = wb0 + ce % TW;
         float* yp = cls_mode ? y + (((long)img * 2 * H + 2 * hh + (cls >> 1)) * 2 * W + 2 * ww + (cls & 1)) * creal + nl
                              : y + (((long)img * H + hh) * W + ww) * Cout + n;
         if (n_ok) *yp = ladder_act_fn(acc[mi][ni][e] + bv, act);
