@@ -306,7 +306,7 @@ def main():
         return res
 
     def executed_flops(eng, fl):
-        """FLOP model of a leg: the algorithmic 41.4 GF minus what is never issued (encoder reuse in RUN#3 / #4; 11 / 36 of the upsample-fused launches)."""
+        """FLOP model of a leg: the algorithmic 41.4 GF minus what is never issued (encoder reuse in RUN#3 / #4; 27 / 36 resp. 11 / 36 of the launches that fold the factor-2 resize)."""
         fl = dict(fl)
         note = "RUN#3/#4 reuse RUN#2's encoder output (bit-identical): 1.23 GFLOP of the algorithmic 41.4 are not executed"
         used = getattr(eng.ctx, "up2_used", {})
@@ -315,9 +315,11 @@ def main():
             for lname, gf in (("decoder/conv2d_7", 4.832e9), ("decoder/conv2d_6", 2.416e9), ("decoder/conv2d_5", 1.208e9), ("decoder/conv2d_4", 0.604e9)):
                 for sfx in ("", ":train", ":bwd", ":wgrad"):      # forward-only run, training forward, backward-data, filter gradient
                     per[lname + sfx] = gf
-            fl["executed"] -= sum(v for k, v in per.items() if k in used) * 11.0 / 36.0
-            note += ("; upsample-fused convolutions (%s): the factor-2 resize in front of the layer is folded into its taps (forward, ':bwd' backward-data, "
-                     "':wgrad' filter gradient), 25 of every 36 low-resolution tap products are issued" % ", ".join(sorted(used)))
+            skipped = getattr(eng.ctx, "up2_skipped", {})
+            fl["executed"] -= sum(v * skipped.get(k, 11.0 / 36.0) for k, v in per.items() if k in used)
+            note += ("; resize x2 -> 3x3 conv pairs computed from the low-resolution tensor (%s; forward, ':bwd' backward-data, ':wgrad' filter gradient): "
+                     "projected form (nine 1x1 convolutions at low resolution + an elementwise combination) issues 9 of every 36 products of the "
+                     "reference's count, the tap-folded form 25 of 36" % ", ".join("%s %d/36" % (k, round(36 * (1 - skipped.get(k, 11.0 / 36.0)))) for k in sorted(used)))
         return dict(fl, note=note)
 
     head = measure(trainer, args.steps, args.warmup, args.repeats, args.sustained_seconds, not args.no_profile)

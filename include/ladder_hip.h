@@ -147,7 +147,9 @@ int ladder_absmax_samples(const float* x, int n_samples, size_t per_sample, floa
  *   transpose_flip = 4: the effective taps of its backward-data, the four pixel-parity classes of dy as input groups (Cin = 4 x C;
  *   ladder_conv3x3_up2_bwd_data_split).  For 3 and 4 the bank's absmax record holds 4 x max|w| (a bound of the effective taps).
  *   transpose_flip = 5 (strict fp32 only): forward of a 3x3 / stride-2 conv, the four pixel-parity classes of x as input groups (Cin = 4 x C;
- *   ladder_conv3x3_s2_fwd_f32). */
+ *   ladder_conv3x3_s2_fwd_f32).
+ *   transpose_flip = 6 / 7 (strict fp32 only, ntaps = 1): the nine taps side by side as one [Cin][9 C] matrix (Cout = 9 C) / its transpose
+ *   [9 C][Cin_layer] (Cin = 9 C) -- the operands of the "project, then upsample" form below (ladder_up2proj_*). */
 size_t ladder_filter_pack_split_bytes(int ntaps, int Cin, int Cout, int prec);
 int ladder_filter_pack_split(const float* w, void* packed, int ntaps, int Cin, int Cout, int transpose_flip, int prec,
                              ladder_stream_t stream);
@@ -204,6 +206,26 @@ int ladder_conv3x3_s2_bwd_data_f32_eligible(int N, int H, int W, int Cin, int Ho
 int ladder_conv3x3_s2_fwd_f32_eligible(int N, int H, int W, int Cin, int Ho, int Wo, int Cout);
 int ladder_conv3x3_s2_fwd_f32(const float* x, const void* bank_s2f, const float* bias, float* y, int N, int H, int W, int Cin, int Ho, int Wo,
                               int Cout, int act, ladder_stream_t stream);
+
+/* "Project, then upsample" (round 5, strict fp32; csrc/upproj.hip): tf.image.resize_images(x, [2H, 2W]) (TF1 legacy bilinear) followed by
+ * tf.layers.conv2d(3x3, SAME) -- decoder conv2d_4 ... conv2d_7, codes/models.py:544-578 -- with 9 / 36 of the direct form's products.  The resize is
+ * linear and per channel, so it commutes with the channel contraction: conv3x3(up(x))[p, q] = b + sum_{r,s} up(Z_rs)[p + r - 1, q + s - 1] with
+ * Z_rs = x . w[r][s], nine 1x1 convolutions at LOW resolution (up(.) = 0 outside the map: the convolution's zero padding).  Exact on every pixel:
+ * no edge / border helper launches.  A layer's three passes, M = N H W low-resolution pixels:
+ *   forward        ladder_dense_fwd(x, wcat, NULL, z, M, Cin, 9 Cout)  then  ladder_up2proj_fwd_combine(z, bias, y, ...)       y [N, 2H, 2W, Cout]
+ *   backward-data  ladder_up2proj_bwd_combine(dy, d, ...)              then  ladder_dense_fwd(d, wcatT, NULL, dx, M, 9 Cout, Cin)
+ *   filter grad.   ladder_dense_bwd_weight(x, d, dwcat, db9, M, Cin, 9 Cout)  then  ladder_up2proj_wgrad_unpack(dwcat, db9, dw, db, Cin, Cout)
+ * wcat [Cin][9 Cout] (wcat[ci][t Cout + co] = w[t][ci][co], t = 3 r + s) = ladder_filter_pack_split(w, ., 1, Cin, 9 Cout, transpose_flip = 6, LADDER_PREC_F32)
+ * and wcatT [9 Cout][Cin], its transpose, = ladder_filter_pack_split(w, ., 1, 9 Cout, Cin, transpose_flip = 7, LADDER_PREC_F32) -- once per weight update,
+ * batched with every other bank by ladder_filter_pack_split_multi.  z / d [M][9 Cout]: plane t of pixel m at [m][t Cout ...].
+ * fwd_combine: y = act(bias + combination) and / or, for Cout == 128, proj_out [N, 2H, 2W, proj_cout <= 4] = y . proj_w [128][proj_cout] + proj_b
+ * (the decoder's 1x1 conv2d_8, codes/models.py:580-586, fused; y may then be NULL).  bwd_combine: d = (shift o up)^T dy, dy [N, 2H, 2W, C] already
+ * multiplied by the activation's derivative.  wgrad_unpack: dw in the layer's HWIO layout, db (may be NULL) = the centre plane's column sums. */
+int ladder_up2proj_eligible(int N, int H, int W, int Cin, int Cout);
+int ladder_up2proj_fwd_combine(const float* z, const float* bias, float* y, const float* proj_w, const float* proj_b, float* proj_out, int proj_cout,
+                               int N, int H, int W, int C, int act, ladder_stream_t stream);
+int ladder_up2proj_bwd_combine(const float* dy, float* d, int N, int H, int W, int C, ladder_stream_t stream);
+int ladder_up2proj_wgrad_unpack(const float* dwcat, const float* db9, float* dw, float* db, int Cin, int Cout, ladder_stream_t stream);
 
 /* (strict fp32, round 5: Cout may be any multiple of 64 and the low-resolution map 16 or 8 pixels wide -- decoder conv2d_5 / conv2d_4,
  * codes/models.py:544-560; the fused projection form stays at Cout = 128)

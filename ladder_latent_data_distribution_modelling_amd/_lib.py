@@ -147,6 +147,10 @@ PROTOTYPES = {
     "ladder_conv3x3_s2_bwd_data_f32_eligible": (_i, [_i] * 7),
     "ladder_conv3x3_s2_fwd_f32_eligible": (_i, [_i] * 7),
     "ladder_conv3x3_s2_fwd_f32": (_i, [_p, _p, _p, _p] + [_i] * 8 + [_p]),
+    "ladder_up2proj_eligible": (_i, [_i] * 5),
+    "ladder_up2proj_fwd_combine": (_i, [_p] * 6 + [_i] * 6 + [_p]),
+    "ladder_up2proj_bwd_combine": (_i, [_p, _p] + [_i] * 4 + [_p]),
+    "ladder_up2proj_wgrad_unpack": (_i, [_p] * 4 + [_i, _i, _p]),
     "ladder_dense_small_eligible": (_i, [_i, _i, _i]),
     "ladder_dense_fwd_small": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "ladder_dense_bwd_data_small": (_i, [_p, _p, _p, _i, _i, _i, _p, _i, _p]),

@@ -1244,7 +1244,8 @@ size_t ladder_filter_pack_split_bytes(int ntaps, int Cin, int Cout, int prec) {
 int ladder_filter_pack_split(const float* w, void* packed, int ntaps, int Cin, int Cout, int transpose_flip, int prec,
                              ladder_stream_t stream) {
   if (prec == LADDER_PREC_F32) {                                 // strict fp32: the fp32 bank [ntaps][Cin][Cout] of the orientation (convf32.hip)
-    if (ntaps <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 16) != 0 || transpose_flip < 0 || transpose_flip > 5) return LADDER_E_SHAPE;
+    if (ntaps <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 16) != 0 || transpose_flip < 0 || transpose_flip > 7) return LADDER_E_SHAPE;
+    if (transpose_flip >= 6 && (ntaps != 1 || ((transpose_flip == 6 ? Cout : Cin) % 9) != 0)) return LADDER_E_SHAPE;
     if (!ladder_aligned16(packed) || !ladder_aligned16(w)) return LADDER_E_ALIGN;
     return filter_pack_f32(w, (float*)packed, ntaps, Cin, Cout, transpose_flip, stream);
   }

@@ -1,4 +1,4 @@
-// The LOGICAL filter bank F[tap][ci][co] (tap = r*3+s, ci < Cin, co < Cout) that the 3x3 halo kernels contract against, for the five
+// The LOGICAL filter bank F[tap][ci][co] (tap = r*3+s, ci < Cin, co < Cout) that the 3x3 halo kernels contract against, for the
 // orientations (`transpose_flip`) a layer's HWIO bank w can be used in.  Shared by the 16-bit plane images of convsplit.hip
 // (ladder_filter_pack_split, prec = f16x3 / bf16x3 / bf16x6) and the fp32 banks of convf32.hip (prec = f32), so that both precisions
 // contract against the SAME fp32 values.
@@ -20,6 +20,10 @@
 //      correlation over the four pixel-parity classes of x taken as four blocks of Cin / 4 INPUT channels: class (a, b) holds x[2i+a, 2j+b];
 //      tap (dr, dc) reads class pixel (i + dr - 1, j + dc - 1) and carries w[2 (dr - 1) + a][2 (dc - 1) + b] -- rows dr = 1 (both classes)
 //      and dr = 2 (class a = 0 only), columns alike: 4 / 2 / 2 / 1 taps   (w = [3][3][Cin/4][Cout], strict fp32 only)
+//   6  "project, then upsample" (csrc/upproj.hip), forward operand: the nine taps side by side as ONE [Cin][9 C] matrix (ntaps = 1, Cout = 9 C):
+//      F[0][ci][t C + co] = w[t][ci][co]   (w = [3][3][Cin][C], strict fp32 only)
+//   7  ... and its transpose, the backward-data operand [9 C][Cin_layer] (ntaps = 1, Cin = 9 C, Cout = the layer's Cin):
+//      F[0][t C + co][ci] = w[t][ci][co]   (w = [3][3][Cout][C], strict fp32 only)
 // Sums have <= 9 terms with power-of-two weights, evaluated in fp32 in a fixed order.
 #pragma once
 
@@ -33,6 +37,14 @@ __device__ __forceinline__ float filter_bank_element(const float* __restrict__ w
     if (!(va && vb)) return 0.f;
     const int r = a == 1 ? ph : 2, sx = b == 1 ? pw : 2;
     return w[(((size_t)r * 3 + sx) * C + cc) * Cin + ci];
+  }
+  if (transpose_flip == 6) {
+    const int C = Cout / 9, t = co / C;
+    return w[((size_t)t * Cin + ci) * C + (co - t * C)];
+  }
+  if (transpose_flip == 7) {
+    const int C = Cin / 9, t = ci / C;
+    return w[((size_t)t * Cout + co) * C + (ci - t * C)];
   }
   if (transpose_flip == 5) {
     const int C = Cin >> 2, cls = ci / C, cc = ci - cls * C, a = cls >> 1, b = cls & 1, dr = tap / 3, dc = tap - 3 * dr;

@@ -1,0 +1,220 @@
+// "Project, then upsample" (round 5): resize x2 -> 3x3 / SAME convolution with 9 / 36 of the reference's products, strict fp32.
+//
+// tf.image.resize_images (TF1 legacy bilinear, factor 2) is linear and acts on every channel separately, so it commutes with the channel
+// contraction of the convolution behind it (decoder conv2d_4 ... conv2d_7, reference codes/models.py:544-578):
+//
+//     conv3x3(up(x))[p, q] = b + sum_{r,s} up(Z_rs)[p + r - 1, q + s - 1],      Z_rs = x . w[r][s]   (nine 1x1 convolutions at LOW resolution)
+//
+// with up(Z) taken as zero outside the high-resolution map (the convolution's zero padding).  The contraction work is 9 products per
+// low-resolution pixel = 9 / 36 of the direct form on the upsampled map (the tap-folding of rounds 3-5: 25 / 36); what is added is an elementwise
+// pass over the nine low-resolution maps -- exact on every pixel, so the edge-line / border-line / line-gradient helpers of the tap-folded form
+// have no counterpart here.  Three GEMM-shaped calls on the dense kernels (igemm.hip) and three elementwise kernels (this file):
+//
+//   forward        Z [M, 9 Cout] = x [M, Cin] . Wcat [Cin, 9 Cout]            (ladder_dense_fwd; Wcat = orientation 6 of filterbank.h, ladder_filter_pack_split)
+//                  y = act(b + sum_rs shift_rs(up(Z_rs)))                      ladder_up2proj_fwd_combine (+ the fused 1x1 projection of the last layer)
+//   backward-data  D_rs = (shift_rs o up)^T dy   [M, 9 Cout]                   ladder_up2proj_bwd_combine
+//                  dx [M, Cin] = D . WcatT [9 Cout, Cin]                       (ladder_dense_fwd; orientation 7)
+//   filter grad.   dWcat [Cin, 9 Cout] = x^T D, db9 = column sums of D        (ladder_dense_bwd_weight), then
+//                  dw[t][ci][co] = dWcat[ci][t Cout + co], db = db9[4 Cout ..] ladder_up2proj_wgrad_unpack  (the centre tap's column sums ARE sum dy)
+//
+// Per axis (low-resolution length L, u = p + r - 1 the position on the upsampled line, valid for 0 <= u < 2L):  up(Z)[2i] = Z[i],
+// up(Z)[2i+1] = (Z[i] + Z[min(i+1, L-1)]) / 2.  Its transpose: D_r[i] = sum_{alpha=0..2} omega_alpha dy[2i - r + alpha], omega = (1/2 [i >= 1], 1,
+// 1/2 -- or 1 on the last line, where the clamp folds both halves onto it), every term gated by 0 <= 2i - r + alpha < 2L.
+#include "common.h"
+
+namespace {
+
+// forward weights of tap r for output parity a at low-resolution line i: rows (lo, hi) = (i-1, i) for r = 0, (i, min(i+1, L-1)) for r = 1, 2
+struct AxisW { int lo, hi; float wlo[2], whi[2]; };
+
+__device__ __forceinline__ AxisW up2_axis(int r, int i, int L) {
+  AxisW a;
+  if (r == 0) {
+    a.lo = i - 1; a.hi = i;
+    a.wlo[0] = i >= 1 ? 0.5f : 0.f; a.whi[0] = i >= 1 ? 0.5f : 0.f;      // u = 2i - 1: the zero padding above / left of the map at i = 0
+    a.wlo[1] = 0.f; a.whi[1] = 1.f;                                       // u = 2i
+    if (i < 1) a.lo = i;                                                  // (never read with a non-zero weight; keeps the address inside the map)
+  } else if (r == 1) {
+    a.lo = i; a.hi = min(i + 1, L - 1);
+    a.wlo[0] = 1.f; a.whi[0] = 0.f;                                       // u = 2i
+    a.wlo[1] = 0.5f; a.whi[1] = 0.5f;                                     // u = 2i + 1 (clamped)
+  } else {
+    a.lo = i; a.hi = min(i + 1, L - 1);
+    a.wlo[0] = 0.5f; a.whi[0] = 0.5f;                                     // u = 2i + 1 (clamped)
+    a.wlo[1] = 0.f; a.whi[1] = (i + 1 <= L - 1) ? 1.f : 0.f;              // u = 2i + 2: the zero padding below / right of the map on the last line
+  }
+  return a;
+}
+
+__device__ __forceinline__ float4 f4_fma(float s, float4 v, float4 a) {
+  return make_float4(fmaf(s, v.x, a.x), fmaf(s, v.y, a.y), fmaf(s, v.z, a.z), fmaf(s, v.w, a.w));
+}
+
+// y [N, 2H, 2W, C] (may be NULL) and / or pout [N, 2H, 2W, pco] = the 1x1 projection of the ACTIVATED value (pw [C][pco], pb [pco]; needs C == 128:
+// the 32 lanes of a half-wave hold one pixel's channels).  One thread = one low-resolution pixel x 4 channels = a 2x2 output block.
+template <bool PROJ>
+__global__ __launch_bounds__(256) void up2proj_fwd_combine_kernel(const float* __restrict__ z, const float* __restrict__ bias, float* __restrict__ y,
+                                                                  const float* __restrict__ pw, const float* __restrict__ pb,
+                                                                  float* __restrict__ pout, const int pco, const int N, const int H, const int W,
+                                                                  const int C, const int act) {
+  const int CV = C >> 2;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)N * H * W * CV;
+  const bool live = t < total;
+  const long tt = live ? t : 0;
+  const int cq = (int)(tt % CV);
+  const long pix = tt / CV;
+  const int j = (int)(pix % W), i = (int)((pix / W) % H), n = (int)(pix / ((long)W * H));
+  const float4* zb = reinterpret_cast<const float4*>(z) + (long)n * H * W * 9 * CV + cq;       // plane t at + t * CV, pixel stride 9 CV
+  float4 acc[2][2];
+  const float4 bv = bias != nullptr ? reinterpret_cast<const float4*>(bias)[cq] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = bv;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const AxisW R = up2_axis(r, i, H);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const AxisW S = up2_axis(s, j, W);
+      const float4* zp = zb + (r * 3 + s) * CV;
+      const float4 v00 = zp[((long)R.lo * W + S.lo) * 9 * CV], v01 = zp[((long)R.lo * W + S.hi) * 9 * CV];
+      const float4 v10 = zp[((long)R.hi * W + S.lo) * 9 * CV], v11 = zp[((long)R.hi * W + S.hi) * 9 * CV];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          float4 q = acc[a][b];
+          q = f4_fma(R.wlo[a] * S.wlo[b], v00, q);
+          q = f4_fma(R.wlo[a] * S.whi[b], v01, q);
+          q = f4_fma(R.whi[a] * S.wlo[b], v10, q);
+          q = f4_fma(R.whi[a] * S.whi[b], v11, q);
+          acc[a][b] = q;
+        }
+    }
+  }
+  float4 pwv[4];                                             // rows of the projection matrix for this thread's 4 channels (pco <= 4 columns, zero padded)
+  if (PROJ) {
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      const float* pr = pw + (long)(cq * 4 + c4) * pco;
+      pwv[c4] = make_float4(pr[0], pco > 1 ? pr[1] : 0.f, pco > 2 ? pr[2] : 0.f, pco > 3 ? pr[3] : 0.f);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float4 v = acc[a][b];
+      v = make_float4(ladder_act_fn(v.x, act), ladder_act_fn(v.y, act), ladder_act_fn(v.z, act), ladder_act_fn(v.w, act));
+      const long opix = ((long)n * 2 * H + 2 * i + a) * 2 * W + 2 * j + b;
+      if (live && y != nullptr) reinterpret_cast<float4*>(y)[opix * CV + cq] = v;
+      if (PROJ) {
+        // C == 128: lanes cq = 0 .. 31 of a half-wave hold the pixel; fixed-order butterfly
+        float4 pr = make_float4(0.f, 0.f, 0.f, 0.f);
+        pr = f4_fma(v.x, pwv[0], pr);
+        pr = f4_fma(v.y, pwv[1], pr);
+        pr = f4_fma(v.z, pwv[2], pr);
+        pr = f4_fma(v.w, pwv[3], pr);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+          pr.x += __shfl_xor(pr.x, o, 64); pr.y += __shfl_xor(pr.y, o, 64); pr.z += __shfl_xor(pr.z, o, 64); pr.w += __shfl_xor(pr.w, o, 64);
+        }
+        if (live && cq == 0) {
+          const float pv[4] = {pr.x, pr.y, pr.z, pr.w};
+          for (int o = 0; o < pco; ++o) pout[opix * pco + o] = pv[o] + (pb != nullptr ? pb[o] : 0.f);
+        }
+      }
+    }
+}
+
+// D [N, H, W, 9 C] from dy [N, 2H, 2W, C]: D_rs[i, j] = sum_{alpha, beta} omega_r[alpha] omega_c[beta] dy[2i - r + alpha, 2j - s + beta]
+__global__ __launch_bounds__(256) void up2proj_bwd_combine_kernel(const float* __restrict__ dy, float* __restrict__ d, const int N, const int H,
+                                                                  const int W, const int C) {
+  const int CV = C >> 2;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)N * H * W * CV) return;
+  const int cq = (int)(t % CV);
+  const long pix = t / CV;
+  const int j = (int)(pix % W), i = (int)((pix / W) % H), n = (int)(pix / ((long)W * H));
+  const float4* gy = reinterpret_cast<const float4*>(dy) + (long)n * 4 * H * W * CV + cq;
+  // the 5 x 5 neighbourhood rows 2i-2 .. 2i+2, columns 2j-2 .. 2j+2 (zero outside the map)
+  float4 g[5][5];
+#pragma unroll
+  for (int a = 0; a < 5; ++a)
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+      const int p = 2 * i - 2 + a, q = 2 * j - 2 + b;
+      g[a][b] = (p >= 0 && p < 2 * H && q >= 0 && q < 2 * W) ? gy[((long)p * 2 * W + q) * CV] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  const float wr[3] = {i >= 1 ? 0.5f : 0.f, 1.f, i == H - 1 ? 1.f : 0.5f}, wc[3] = {j >= 1 ? 0.5f : 0.f, 1.f, j == W - 1 ? 1.f : 0.5f};
+  float4* dp = reinterpret_cast<float4*>(d) + pix * 9 * CV + cq;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int al = 0; al < 3; ++al)
+#pragma unroll
+        for (int be = 0; be < 3; ++be) acc = f4_fma(wr[al] * wc[be], g[2 - r + al][2 - s + be], acc);     // row 2i - r + al = (2i - 2) + (2 - r + al)
+      dp[(r * 3 + s) * CV] = acc;
+    }
+}
+
+// dw [3][3][Cin][Cout] from dWcat [Cin][9 Cout]; db [Cout] (may be NULL) = the centre tap's column sums of D = sum over all pixels of dy
+__global__ __launch_bounds__(256) void up2proj_wgrad_unpack_kernel(const float* __restrict__ dwcat, const float* __restrict__ db9, float* __restrict__ dw,
+                                                                   float* __restrict__ db, const int Cin, const int Cout) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)9 * Cin * Cout;
+  if (t < total) {
+    const int co = (int)(t % Cout), ci = (int)((t / Cout) % Cin), tap = (int)(t / ((long)Cout * Cin));
+    dw[t] = dwcat[(long)ci * 9 * Cout + (long)tap * Cout + co];
+  }
+  if (db != nullptr && t < Cout) db[t] = db9[4 * Cout + t];
+}
+
+}  // namespace
+
+extern "C" {
+
+int ladder_up2proj_eligible(int N, int H, int W, int Cin, int Cout) {
+  static const bool off = getenv("LADDER_DISABLE_UP2PROJ") != nullptr;
+  return (!off && N > 0 && H >= 1 && W >= 1 && Cin > 0 && Cout > 0 && (Cin % 16) == 0 && (Cout % 16) == 0 && (long)N * H * W < (1L << 30)) ? 1 : 0;
+}
+
+int ladder_up2proj_fwd_combine(const float* z, const float* bias, float* y, const float* proj_w, const float* proj_b, float* proj_out, int proj_cout,
+                               int N, int H, int W, int C, int act, ladder_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4) != 0 || (y == nullptr && proj_out == nullptr)) return LADDER_E_SHAPE;
+  if (proj_out != nullptr && (proj_w == nullptr || proj_cout < 1 || proj_cout > 4 || C != 128)) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(z) || !ladder_aligned16(y) || (bias != nullptr && !ladder_aligned16(bias))) return LADDER_E_ALIGN;
+  const long total = (long)N * H * W * (C / 4);
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (proj_out != nullptr)
+    hipLaunchKernelGGL(up2proj_fwd_combine_kernel<true>, dim3(grid), dim3(256), 0, stream, z, bias, y, proj_w, proj_b, proj_out, proj_cout, N, H, W, C, act);
+  else
+    hipLaunchKernelGGL(up2proj_fwd_combine_kernel<false>, dim3(grid), dim3(256), 0, stream, z, bias, y, (const float*)nullptr, (const float*)nullptr,
+                       (float*)nullptr, 0, N, H, W, C, act);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_up2proj_bwd_combine(const float* dy, float* d, int N, int H, int W, int C, ladder_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4) != 0) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(dy) || !ladder_aligned16(d)) return LADDER_E_ALIGN;
+  const long total = (long)N * H * W * (C / 4);
+  hipLaunchKernelGGL(up2proj_bwd_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dy, d, N, H, W, C);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_up2proj_wgrad_unpack(const float* dwcat, const float* db9, float* dw, float* db, int Cin, int Cout, ladder_stream_t stream) {
+  if (Cin <= 0 || Cout <= 0 || dwcat == nullptr || dw == nullptr || (db != nullptr && db9 == nullptr)) return LADDER_E_SHAPE;
+  const long total = (long)9 * Cin * Cout;
+  hipLaunchKernelGGL(up2proj_wgrad_unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dwcat, db9, dw, db, Cin, Cout);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+}  // extern "C"

@@ -44,6 +44,7 @@ class KernelProfiler:
                      "stride-2 backward-data classes)",
              9120: "wgrad3x3_up2_f32_kernel + reductions / edge lines (filter gradient of resize x2 -> 3x3 conv over the low-resolution map: 25 of 36 tap tiles, "
                    "one parity class per workgroup, 12 waves, LDS-DMA staged 1x32-pixel patches, fp32 MFMA 32x32x2)",
+             9130: "igemm_wgrad_kernel<128,128> + its fixed-order split reduction (dWcat [Cin][9 Cout] = x^T D of the project-then-upsample pairs, fp32 MFMA 32x32x2)",
              7700: "gmm_logprob_kernel<R> + gmm_sum_kernel (mixture log-prob / responsibilities, lane = component, wave-shuffle logsumexp)"}
     LATENCY_BOUND = (7700,)          # not contraction kernels: reported beside the roofline, never as the dominant MFMA kernel
 
@@ -378,6 +379,7 @@ class Ctx:
         self.keep_activations = True   # False inside forward-only runs: fused kernels may skip writing tensors only a backward pass reads
         self.ns = 0          # LADDER_PREC_* of the split-precision contraction kernels (0 = native f32 MFMA); set by the engine
         self.up2_used = {}   # layer name -> number of upsample-fused launches so far (bench.py's executed-FLOP model)
+        self.up2_skipped = {}  # ... and the fraction of the reference's products such a launch never issues (11 / 36 tap-folded, 27 / 36 projected)
         self.up2 = True      # resize -> 3x3 conv pairs of the decoder as ONE upsample-fused convolution in forward-only runs (config `upsample_fused_convs`)
 
     @property
@@ -687,15 +689,20 @@ class Conv2D:
             cin, cout = 4 * self.cout, self.cin
         elif transpose_flip == 5:                     # stride-2 forward: the four pixel-parity classes of x as input groups (strict fp32)
             cin, cout = 4 * self.cin, self.cout
+        taps = self.k * self.k
+        if transpose_flip == 6:                       # project-then-upsample: the nine taps side by side, ONE [cin][9 cout] matrix (strict fp32) ...
+            taps, cin, cout = 1, self.cin, 9 * self.cout
+        elif transpose_flip == 7:                     # ... and its transpose [9 cout][cin], the backward-data operand
+            taps, cin, cout = 1, 9 * self.cout, self.cin
         ent = self._packed.get((transpose_flip, ns))
         if ent is None:
-            nb = L.query("ladder_filter_pack_split_bytes", self.k * self.k, cin, cout, ns)
+            nb = L.query("ladder_filter_pack_split_bytes", taps, cin, cout, ns)
             ent = self._packed[(transpose_flip, ns)] = [-1, torch.empty(nb, dtype=torch.uint8, device=self.ctx.device)]
             # known to the batched re-pack after an optimiser step (LadderEngine._repack_filters): (entry, bank, taps, cin, cout, flip, ns)
-            self.ctx.pack_banks.append((ent, ps.w[self.name + "/kernel"], self.k * self.k, cin, cout, transpose_flip, ns, self.group))
+            self.ctx.pack_banks.append((ent, ps.w[self.name + "/kernel"], taps, cin, cout, transpose_flip, ns, self.group))
         ver = ps.version[self.group]
         if ent[0] != ver or torch.cuda.is_current_stream_capturing():
-            L.call("ladder_filter_pack_split", _p(ps.w[self.name + "/kernel"]), _p(ent[1]), self.k * self.k, cin, cout, transpose_flip, ns,
+            L.call("ladder_filter_pack_split", _p(ps.w[self.name + "/kernel"]), _p(ent[1]), taps, cin, cout, transpose_flip, ns,
                    self.ctx.stream)
             ent[0] = ver
         return ent[1]
@@ -729,14 +736,89 @@ class Conv2D:
         upsampled tensor).  Forward-only runs use it; a training forward keeps the resized tensor for its backward pass."""
         if self.ctx.ns == 0 and os.environ.get("LADDER_DISABLE_HALO") == "1":
             return False
+        if self.proj_ok(N, H, W):
+            return True
         return bool(self.ctx.up2 and self.ctx.ns in (0, 2, 4) and self.k == 3 and self.stride == 1 and self.padding == "same"
                     and L.query("ladder_conv3x3_up2_split_eligible", N, H, W, self.cin, self.cout, self.ctx.ns))
+
+    def proj_ok(self, N, H, W):
+        """'Project, then upsample' (csrc/upproj.hip; strict fp32, config `upsample_fused_convs` >= 4): resize x2 -> this conv over a LOW-resolution
+        [N, H, W, cin] tensor as nine 1x1 convolutions on it (9 of the direct form's 36 products per 2x2 output block, against 25 for the tap-folded
+        form above) + an exact elementwise combination.  Forward, backward-data and the filter gradient all run from the low-resolution tensor."""
+        return bool(self.ctx.ns == 0 and self.ctx.up2 >= 4 and self.k == 3 and self.stride == 1 and self.padding == "same"
+                    and os.environ.get("LADDER_DISABLE_HALO") != "1" and L.query("ladder_up2proj_eligible", N, H, W, self.cin, self.cout))
 
     def virtual_up2_ok(self, N, H, W):
         """A training forward may skip materialising the factor-2 upsample of its [N, H, W, cin] input altogether: strict fp32, and forward,
         backward-data AND filter gradient of this layer all run from the low-resolution tensor (csrc/convf32.hip)."""
+        if self.proj_ok(N, H, W):
+            return True
         return bool(self.ctx.ns == 0 and self.ctx.up2 >= 3 and self.up2_ok(N, H, W) and self.up2t_ok(N, H, W) and H * W >= UP2W_MIN_PIXELS
                     and L.query("ladder_conv3x3_up2_wgrad_eligible", N, H, W, self.cin, self.cout))
+
+    def _forward_proj(self, x, proj, keep_y, upsampled):
+        """forward_up2 in the project-then-upsample form: Z [M, 9 cout] = x [M, cin] . wcat (dense kernel), then the elementwise combination with
+        bias, activation and -- for the last layer -- the 1x1 output conv on the activated value."""
+        ctx, st = self.ctx, self.ctx.stream
+        N, H, W = x.shape[0], x.shape[1], x.shape[2]
+        M, n9 = N * H * W, 9 * self.cout
+        self.pt = self.pl = 1
+        flops = 2.0 * N * 4 * H * W * 9 * self.cin * self.cout          # the reference's operation count (algorithmic) ...
+        executed = 2.0 * M * self.cin * n9                               # ... of which 9 / 36 are issued
+        ukey = self.name + (":train" if keep_y else "")
+        ctx.up2_used[ukey] = ctx.up2_used.get(ukey, 0) + 1
+        ctx.up2_skipped[ukey] = 27.0 / 36.0
+        z = ctx.empty(M, n9)
+        wsp, wsn = ctx.ws(L.query("ladder_igemm_fwd_workspace_bytes", M, self.cin, n9))
+        _timed(128128, flops, "ladder_dense_fwd", (_p(x), _p(self._packed_filter(6)), None, _p(z), M, self.cin, n9, 0, wsp, wsn, st), executed)
+        bias = self.ps.w[self.name + "/bias"]
+        if proj is not None:
+            proj.pt = proj.pl = 0
+            y = ctx.empty(N, 2 * H, 2 * W, self.cout) if keep_y else None
+            out = ctx.empty(N, 2 * H, 2 * W, proj.cout)
+            L.call("ladder_up2proj_fwd_combine", _p(z), _p(bias), _p(y), _p(self.ps.w[proj.name + "/kernel"]), _p(self.ps.w[proj.name + "/bias"]), _p(out),
+                   proj.cout, N, H, W, self.cout, L.ACT[self.act], st)
+            proj.x, proj.y = (y, out) if keep_y else (None, None)
+        else:
+            out = y = ctx.empty(N, 2 * H, 2 * W, self.cout)
+            L.call("ladder_up2proj_fwd_combine", _p(z), _p(bias), _p(y), None, None, None, 0, N, H, W, self.cout, L.ACT[self.act], st)
+        self.x_amax = None
+        self.x, self.y = ((upsampled if upsampled is not None else x), y) if keep_y else (None, None)
+        self.x_is_up2 = bool(keep_y and upsampled is not None)
+        self.x_is_lo = bool(keep_y and upsampled is None)
+        return out
+
+    def _backward_proj(self, dy, need_dx, wgrad, gate):
+        """Backward of the project-then-upsample form from the low-resolution x: D [M, 9 cout] = (shift o up)^T dy once (elementwise), then
+        dWcat = x^T D (+ the bias gradient as the centre plane's column sums) and dx_lo = D . wcatT -- two dense calls, exact on every pixel."""
+        ctx, st = self.ctx, self.ctx.stream
+        x = self.x
+        N, H, W, _ = x.shape
+        M, n9 = N * H * W, 9 * self.cout
+        flops = 2.0 * N * 4 * H * W * 9 * self.cin * self.cout
+        executed = 2.0 * M * self.cin * n9
+        d = ctx.empty(M, n9)
+        L.call("ladder_up2proj_bwd_combine", _p(dy), _p(d), N, H, W, self.cout, st)
+        if wgrad:
+            ctx.up2_used[self.name + ":wgrad"] = ctx.up2_used.get(self.name + ":wgrad", 0) + 1
+            ctx.up2_skipped[self.name + ":wgrad"] = 27.0 / 36.0
+            dwcat, db9 = ctx.empty(self.cin, n9), ctx.empty(n9)
+            wsp, wsn = ctx.ws(L.query("ladder_dense_bwd_weight_workspace_bytes", M, self.cin, n9))
+            _timed(9130, flops, "ladder_dense_bwd_weight", (_p(x), _p(d), _p(dwcat), _p(db9), M, self.cin, n9, wsp, wsn, st), executed)
+            L.call("ladder_up2proj_wgrad_unpack", _p(dwcat), _p(db9), _p(self.ps.g[self.name + "/kernel"]),
+                   _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, self.cin, self.cout, st)
+        dx = None
+        if need_dx:
+            ctx.up2_used[self.name + ":bwd"] = ctx.up2_used.get(self.name + ":bwd", 0) + 1
+            ctx.up2_skipped[self.name + ":bwd"] = 27.0 / 36.0
+            dx = ctx.empty(N, H, W, self.cin)
+            wsp, wsn = ctx.ws(L.query("ladder_igemm_fwd_workspace_bytes", M, n9, self.cin))
+            gy, gact = gate if gate is not None else (None, None)
+            # (ladder_dense_bwd_data: dx [M, K] = dy [M, N] . wT [N, K], optionally times act'(gate) -- here dy := D, wT := wcatT)
+            _timed(128128, flops, "ladder_dense_bwd_data", (_p(d), _p(self._packed_filter(7)), _p(dx), M, self.cin, n9, _p(gy), L.ACT[gact] if gact else 0,
+                                                           wsp, wsn, st), executed)
+        self.x = self.y = None
+        return dx
 
     def forward_up2(self, x, proj=None, keep_y=False, x_for_backward=None):
         """conv(resize2x(x)) from the low-resolution x itself; with `proj` the 1x1 output conv rides on the epilogue as in forward_fused_proj.
@@ -746,6 +828,8 @@ class Conv2D:
         ctx = self.ctx
         src = x
         N, H, W = x.shape[0], x.shape[1], x.shape[2]
+        if self.proj_ok(N, H, W):
+            return self._forward_proj(x, proj, keep_y, x_for_backward)
         strided = 0
         upsampled = x_for_backward
         self.pt = self.pl = 1
@@ -755,6 +839,7 @@ class Conv2D:
         executed = flops * 25.0 / 36.0                                   # ... of which 25 / 36 are issued
         ukey = self.name + (":train" if keep_y else "")                   # (bench.py's executed-FLOP model: forward-only / training forward)
         ctx.up2_used[ukey] = ctx.up2_used.get(ukey, 0) + 1
+        ctx.up2_skipped[ukey] = 11.0 / 36.0
         wsp, wsn = ctx.ws(L.query("ladder_conv3x3_up2_edges_workspace_bytes", N, H, W, self.cin, self.cout))
         if proj is not None:
             proj.pt = proj.pl = 0
@@ -873,6 +958,8 @@ class Conv2D:
         ONE launch (ladder_conv3x3_up2_bwd_data_split) + border strips, instead of backward-data on the upsampled map + the resize transpose."""
         if self.ctx.ns == 0 and os.environ.get("LADDER_DISABLE_HALO") == "1":
             return False
+        if self.proj_ok(N, H, W):
+            return True
         if self.ctx.ns == 0 and H * W < UP2T_MIN_PIXELS:
             # policy (measured, profiles/r05_small_maps.txt): on an 8x8 low-resolution map the four exact border lines cost more than the
             # 11 / 36 of the products the fused launch saves (conv2d_4: 461 + 221 us against 595 + 26 for the direct pair)
@@ -887,6 +974,8 @@ class Conv2D:
         """_dx_lowres can apply the activation backward of the layer below (its `gate`) in the same launches (strict fp32, 8x32-pixel tiling).
         OFF by default (LADDER_ENABLE_LOWRES_GATE=1 turns it on): measured in round 5, the 64 gate loads per lane in the epilogue of conv2d_6's fused
         backward-data cost 72 us (1 631 -> 1 703 us) -- the 67 us ladder_act_bwd pass they replace (profiles/r05_f32_percall.md was taken with it on)."""
+        if self.x_is_lo and self.proj_ok(N, H, W):      # (projected form: the gate rides on the dense kernel's epilogue)
+            return os.environ.get("LADDER_DISABLE_LOWRES_GATE") != "1"
         return bool(self.ctx.ns == 0 and os.environ.get("LADDER_ENABLE_LOWRES_GATE") == "1"
                     and L.query("ladder_conv3x3_up2_bwd_data_gated_f32_eligible", N, H, W, self.cout, self.cin))
 
@@ -902,6 +991,7 @@ class Conv2D:
         dx_amax = ctx.new_amax() if ctx.ns == 4 else None
         flops = 2.0 * N * OH * OW * 9 * self.cin * self.cout
         ctx.up2_used[self.name + ":bwd"] = ctx.up2_used.get(self.name + ":bwd", 0) + 1
+        ctx.up2_skipped[self.name + ":bwd"] = 11.0 / 36.0
         pk4 = self._packed_filter(4)
         if ctx.ns == 0:
             # strict fp32: the main launch, then its four border lines made exact in place from ONE d_up line per border (csrc/convf32.hip:
@@ -964,6 +1054,8 @@ class Conv2D:
         st = self.ctx.stream
         if self.act is not None and not act_done:
             L.call("ladder_act_bwd", _p(dy), _p(y), _p(dy), dy.numel(), L.ACT[self.act], st)
+        if self.x_is_lo and self.proj_ok(N, H // 2, W // 2):
+            return self._backward_proj(dy, need_dx, wgrad, lowres_gate)
         if (wgrad and self.k == 1 and self.stride == 1 and L.query("ladder_conv1x1_smallcout_eligible", N * H * W, self.cin, self.cout)):
             # 1x1 to <= 4 channels over a wide map (the CelebA output conv): dx, dW and db from ONE pass over x
             M = N * H * W
@@ -1039,6 +1131,7 @@ class Conv2D:
             wsp, wsn = self.ctx.ws(L.query("ladder_conv3x3_up2_wgrad_workspace_bytes", N, H // 2, W // 2, self.cin, self.cout))
             fl = 2.0 * N * H * W * 9 * self.cin * self.cout
             self.ctx.up2_used[self.name + ":wgrad"] = self.ctx.up2_used.get(self.name + ":wgrad", 0) + 1
+            self.ctx.up2_skipped[self.name + ":wgrad"] = 11.0 / 36.0
             _timed(9120, fl, "ladder_conv3x3_up2_wgrad",
                    (_p(x), 0 if self.x_is_lo else 1, _p(dy), _p(self.ps.g[self.name + "/kernel"]), _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, N, H // 2, W // 2,
                     self.cin, self.cout, wsp, wsn, st), fl * 25.0 / 36.0)
@@ -1699,7 +1792,7 @@ class LadderEngine:
         self.ctx.ns = PRECISIONS[prec]
         # 0: off, 1: forward-only runs, 2: also the training forward and the backward-data of the last 3x3 conv, 3: also conv2d_6's backward-data (no gain measured)
         # (strict fp32 default 3: with the fp32 MFMA the 11 / 36 of conv2d_6's backward-data outweigh its border strips, +0.5 %; f16x3: no gain, 2)
-        self.ctx.up2 = int(cfg.get("upsample_fused_convs", 3 if prec == "f32" else 2))
+        self.ctx.up2 = int(cfg.get("upsample_fused_convs", 4 if prec == "f32" else 2))
         self.precision = prec
         if self.ctx.comm.rank == 0:
             print("Contraction precision (config key matmul_precision): {} -- {}".format(prec, PRECISION_NOTES[prec]))

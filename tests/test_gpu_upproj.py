@@ -1,0 +1,159 @@
+"""'Project, then upsample' (csrc/upproj.hip, round 5, strict fp32): resize x2 (TF1 legacy bilinear) -> 3x3 / SAME convolution -- decoder conv2d_4 ...
+conv2d_7, reference codes/models.py:544-578 -- as nine 1x1 convolutions at LOW resolution + an exact elementwise combination, through the C ABI
+against the float64 oracle (oracle/ladder_oracle.py: resize_bilinear_legacy + conv2d_tf, and float64 autograd through them):
+
+  * the two operand layouts (orientations 6 / 7 of ladder_filter_pack_split) against numpy (bit-exact: a permutation);
+  * forward (with bias, activation, and the fused 1x1 projection of the last layer), every pixel including all four borders;
+  * backward-data and the filter / bias gradient, borders and corners included;
+  * ragged shapes: odd channel multiples of 16, non-square and 1-pixel-wide maps, batch sizes that are not a multiple of anything.
+
+Tolerance (stated): fp32 accumulation of K = Cin <= 512 products followed by <= 16 additions of fp32 values -- 3e-6 of the output scale for the
+forward and backward-data maps (measured ~3e-7), 3e-6 of the gradient scale for the filter gradient (M up to 2^17 terms, pairwise over splits)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ladder_oracle as O
+from test_gpu_split import _lib, close, dev, p
+
+pytestmark = pytest.mark.gpu
+TOL32 = 3e-6
+
+
+def _ws(n):
+    return torch.empty(max(int(n), 16), dtype=torch.uint8, device="cuda")
+
+
+def _pack(L, w, st):
+    cin, cout = w.shape[2], w.shape[3]
+    wd = dev(w)
+    wcat = torch.full((cin, 9 * cout), float("nan"), device="cuda")
+    wcatT = torch.full((9 * cout, cin), float("nan"), device="cuda")
+    assert L.query("ladder_filter_pack_split_bytes", 1, cin, 9 * cout, 0) == wcat.numel() * 4
+    L.call("ladder_filter_pack_split", p(wd), p(wcat), 1, cin, 9 * cout, 6, 0, st)
+    L.call("ladder_filter_pack_split", p(wd), p(wcatT), 1, 9 * cout, cin, 7, 0, st)
+    return wcat, wcatT
+
+
+def _forward(L, xd, wcat, bd, N, H, W, cin, cout, act, st, y=True, proj=None):
+    M = N * H * W
+    z = torch.full((M, 9 * cout), float("nan"), device="cuda")
+    ws = _ws(L.query("ladder_igemm_fwd_workspace_bytes", M, cin, 9 * cout))
+    L.call("ladder_dense_fwd", p(xd), p(wcat), None, p(z), M, cin, 9 * cout, 0, p(ws), ws.numel(), st)
+    yd = torch.full((N, 2 * H, 2 * W, cout), float("nan"), device="cuda") if y else None
+    out = None
+    if proj is not None:
+        pwd, pbd = proj
+        out = torch.full((N, 2 * H, 2 * W, pwd.shape[1]), float("nan"), device="cuda")
+        L.call("ladder_up2proj_fwd_combine", p(z), p(bd), p(yd), p(pwd), p(pbd), p(out), pwd.shape[1], N, H, W, cout, act, st)
+    else:
+        L.call("ladder_up2proj_fwd_combine", p(z), p(bd), p(yd), None, None, None, 0, N, H, W, cout, act, st)
+    return yd, out
+
+
+def _ref_fwd(x, w, b, act):
+    N, H, W, _ = x.shape
+    up = O.resize_bilinear_legacy(torch.as_tensor(x, dtype=torch.float64), 2 * H, 2 * W)
+    y = O.conv2d_tf(up, torch.as_tensor(w, dtype=torch.float64), None if b is None else torch.as_tensor(b, dtype=torch.float64), 1, "same")
+    return (O.leaky_relu(y) if act == "leaky_relu" else y).numpy()
+
+
+def test_upproj_operand_layouts_are_permutations_of_the_bank(gpu_ctx):
+    L = _lib()
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal((3, 3, 48, 32)).astype(np.float32)
+    wcat, wcatT = _pack(L, w, gpu_ctx.stream)
+    ref = w.reshape(9, 48, 32).transpose(1, 0, 2).reshape(48, 9 * 32)
+    assert np.array_equal(wcat.cpu().numpy(), ref)
+    assert np.array_equal(wcatT.cpu().numpy(), ref.T)
+    assert L.query("ladder_up2proj_eligible", 128, 64, 64, 128, 128) == 1
+    assert L.query("ladder_up2proj_eligible", 128, 64, 64, 120, 128) == 0
+
+
+CASES = [(16, 64, 64, 32, 128, "leaky_relu"), (128, 8, 8, 64, 256, "leaky_relu"), (3, 5, 7, 16, 48, None), (5, 1, 9, 48, 16, "leaky_relu"), (7, 6, 1, 16, 16, None),
+         (2, 1, 1, 32, 32, None), (64, 16, 16, 256, 64, "leaky_relu")]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "n%d_%dx%d_c%d_co%d_%s" % c)
+def test_upproj_forward_vs_oracle(gpu_ctx, case):
+    L = _lib()
+    N, H, W, cin, cout, act = case
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(H * 100 + cin + cout)
+    x = rng.standard_normal((N, H, W, cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32) * 0.1
+    wcat, _ = _pack(L, w, st)
+    y, _ = _forward(L, dev(x), wcat, dev(b), N, H, W, cin, cout, 1 if act else 0, st)
+    close(y, _ref_fwd(x, w, b, act), TOL32, "y (every pixel)")
+
+
+@pytest.mark.parametrize("case", [(16, 32, 32, 64, True), (4, 64, 64, 128, False), (3, 3, 5, 16, True)], ids=lambda c: "n%d_%dx%d_c%d_y%d" % c)
+def test_upproj_forward_with_fused_projection_vs_oracle(gpu_ctx, case):
+    L = _lib()
+    N, H, W, cin, keep_y = case
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(H + cin)
+    x = rng.standard_normal((N, H, W, cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, cin, 128)) / np.sqrt(9 * cin)).astype(np.float32)
+    b = rng.standard_normal(128).astype(np.float32) * 0.1
+    pw_ = (rng.standard_normal((128, 3)) / np.sqrt(128)).astype(np.float32)
+    pb_ = rng.standard_normal(3).astype(np.float32) * 0.1
+    wcat, _ = _pack(L, w, st)
+    y, out = _forward(L, dev(x), wcat, dev(b), N, H, W, cin, 128, 1, st, y=keep_y, proj=(dev(pw_), dev(pb_)))
+    ref = _ref_fwd(x, w, b, "leaky_relu")
+    close(out, ref @ pw_.astype(np.float64) + pb_.astype(np.float64), TOL32, "projection")
+    if keep_y:
+        close(y, ref, TOL32, "map")
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "n%d_%dx%d_c%d_co%d_%s" % c)
+def test_upproj_backward_vs_autograd(gpu_ctx, case):
+    """dx, dw and db of resize x2 -> 3x3 conv from dy, against float64 autograd through the oracle's resize + convolution."""
+    L = _lib()
+    N, H, W, cin, cout, _ = case
+    st = gpu_ctx.stream
+    M = N * H * W
+    rng = np.random.default_rng(cin + cout + H)
+    x = rng.standard_normal((N, H, W, cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    dy = rng.standard_normal((N, 2 * H, 2 * W, cout)).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    bt = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    O.conv2d_tf(O.resize_bilinear_legacy(xt, 2 * H, 2 * W), wt, bt, 1, "same").backward(torch.as_tensor(dy, dtype=torch.float64))
+    _, wcatT = _pack(L, w, st)
+    xd, dyd = dev(x), dev(dy)
+    d = torch.full((M, 9 * cout), float("nan"), device="cuda")
+    L.call("ladder_up2proj_bwd_combine", p(dyd), p(d), N, H, W, cout, st)
+    dx = torch.full((N, H, W, cin), float("nan"), device="cuda")
+    ws = _ws(L.query("ladder_igemm_fwd_workspace_bytes", M, 9 * cout, cin))
+    L.call("ladder_dense_fwd", p(d), p(wcatT), None, p(dx), M, 9 * cout, cin, 0, p(ws), ws.numel(), st)
+    close(dx, xt.grad, TOL32, "dx (every pixel)")
+    dwcat = torch.full((cin, 9 * cout), float("nan"), device="cuda")
+    db9 = torch.full((9 * cout,), float("nan"), device="cuda")
+    ws = _ws(L.query("ladder_dense_bwd_weight_workspace_bytes", M, cin, 9 * cout))
+    L.call("ladder_dense_bwd_weight", p(xd), p(d), p(dwcat), p(db9), M, cin, 9 * cout, p(ws), ws.numel(), st)
+    dw = torch.full((3, 3, cin, cout), float("nan"), device="cuda")
+    db = torch.full((cout,), float("nan"), device="cuda")
+    L.call("ladder_up2proj_wgrad_unpack", p(dwcat), p(db9), p(dw), p(db), cin, cout, st)
+    close(dw, wt.grad, TOL32, "dw")
+    close(db, bt.grad, TOL32, "db")
+
+
+def test_upproj_combine_is_the_transpose_of_itself(gpu_ctx):
+    """<combine(z), dy> == <z, combine^T(dy)> at the full conv2d_7 map size (size-independent adjointness property)."""
+    L = _lib()
+    st = gpu_ctx.stream
+    N, H, W, C = 8, 64, 64, 128
+    g = torch.Generator(device="cuda").manual_seed(3)
+    z = torch.randn(N * H * W, 9 * C, device="cuda", generator=g)
+    dy = torch.randn(N, 2 * H, 2 * W, C, device="cuda", generator=g)
+    y = torch.empty(N, 2 * H, 2 * W, C, device="cuda")
+    d = torch.empty_like(z)
+    L.call("ladder_up2proj_fwd_combine", p(z), None, p(y), None, None, None, 0, N, H, W, C, 0, st)
+    L.call("ladder_up2proj_bwd_combine", p(dy), p(d), N, H, W, C, st)
+    torch.cuda.synchronize()
+    a = float((y.double() * dy.double()).sum())
+    b = float((z.double() * d.double()).sum())
+    assert abs(a - b) < 1e-6 * (abs(a) + float(y.double().norm() * dy.double().norm())), (a, b)
