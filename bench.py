@@ -312,14 +312,14 @@ def main():
         used = getattr(eng.ctx, "up2_used", {})
         if used:      # conv2d_7 (4.832 GFLOP / image forward), conv2d_6 (2.416), conv2d_5 (1.208), conv2d_4 (0.604) in RUN#1 (":train") and RUN#2, ":bwd", ":wgrad": 11 / 36 not issued
             per = {}
-            for lname, gf in (("decoder/conv2d_7", 4.832e9), ("decoder/conv2d_6", 2.416e9), ("decoder/conv2d_5", 1.208e9), ("decoder/conv2d_4", 0.604e9)):
+            for lname, gf in (("decoder/conv2d_7", 4.832e9), ("decoder/conv2d_6", 2.416e9), ("decoder/conv2d_5", 1.208e9), ("decoder/conv2d_4", 0.604e9), ("decoder/conv2d_3", 0.302e9)):
                 for sfx in ("", ":train", ":bwd", ":wgrad"):      # forward-only run, training forward, backward-data, filter gradient
                     per[lname + sfx] = gf
             skipped = getattr(eng.ctx, "up2_skipped", {})
             fl["executed"] -= sum(v * skipped.get(k, 11.0 / 36.0) for k, v in per.items() if k in used)
             note += ("; resize x2 -> 3x3 conv pairs computed from the low-resolution tensor (%s; forward, ':bwd' backward-data, ':wgrad' filter gradient): "
                      "projected form (nine 1x1 convolutions at low resolution + an elementwise combination) issues 9 of every 36 products of the "
-                     "reference's count, the tap-folded form 25 of 36" % ", ".join("%s %d/36" % (k, round(36 * (1 - skipped.get(k, 11.0 / 36.0)))) for k in sorted(used)))
+                     "reference's count (1 of 16 behind the factor-4 resize), the tap-folded form 25 of 36" % ", ".join("%s %.4g/36" % (k, 36 * (1 - skipped.get(k, 11.0 / 36.0))) for k in sorted(used)))
         return dict(fl, note=note)
 
     head = measure(trainer, args.steps, args.warmup, args.repeats, args.sustained_seconds, not args.no_profile)

@@ -226,6 +226,11 @@ int ladder_up2proj_fwd_combine(const float* z, const float* bias, float* y, cons
                                int N, int H, int W, int C, int act, ladder_stream_t stream);
 int ladder_up2proj_bwd_combine(const float* dy, float* d, int N, int H, int W, int C, ladder_stream_t stream);
 int ladder_up2proj_wgrad_unpack(const float* dwcat, const float* db9, float* dw, float* db, int Cin, int Cout, ladder_stream_t stream);
+/* The two combinations for a resize factor of 2 or 4 (decoder conv2d_3 sits behind the 2x2 -> 8x8 resize, codes/models.py:536-542: up(Z)[F i + k] =
+ * (1 - k/F) Z[i] + (k/F) Z[min(i+1, L-1)] per axis): y [N, F H, F W, C], dy likewise; z / d [N H W][9 C] as above.  The GEMM-shaped calls do not change. */
+int ladder_upfproj_eligible(int factor, int N, int H, int W, int Cin, int Cout);
+int ladder_upfproj_fwd_combine(const float* z, const float* bias, float* y, int factor, int N, int H, int W, int C, int act, ladder_stream_t stream);
+int ladder_upfproj_bwd_combine(const float* dy, float* d, int factor, int N, int H, int W, int C, ladder_stream_t stream);
 
 /* (strict fp32, round 5: Cout may be any multiple of 64 and the low-resolution map 16 or 8 pixels wide -- decoder conv2d_5 / conv2d_4,
  * codes/models.py:544-560; the fused projection form stays at Cout = 128)

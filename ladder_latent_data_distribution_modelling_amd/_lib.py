@@ -151,6 +151,9 @@ PROTOTYPES = {
     "ladder_up2proj_fwd_combine": (_i, [_p] * 6 + [_i] * 6 + [_p]),
     "ladder_up2proj_bwd_combine": (_i, [_p, _p] + [_i] * 4 + [_p]),
     "ladder_up2proj_wgrad_unpack": (_i, [_p] * 4 + [_i, _i, _p]),
+    "ladder_upfproj_eligible": (_i, [_i] * 6),
+    "ladder_upfproj_fwd_combine": (_i, [_p] * 3 + [_i] * 6 + [_p]),
+    "ladder_upfproj_bwd_combine": (_i, [_p, _p] + [_i] * 5 + [_p]),
     "ladder_dense_small_eligible": (_i, [_i, _i, _i]),
     "ladder_dense_fwd_small": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "ladder_dense_bwd_data_small": (_i, [_p, _p, _p, _i, _i, _i, _p, _i, _p]),

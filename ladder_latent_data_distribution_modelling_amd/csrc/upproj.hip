@@ -175,6 +175,99 @@ __global__ __launch_bounds__(256) void up2proj_wgrad_unpack_kernel(const float* 
   if (db != nullptr && t < Cout) db[t] = db9[4 * Cout + t];
 }
 
+
+// ---- any integer resize factor F (decoder conv2d_3: the 2x2 -> 8x8 resize, F = 4; codes/models.py:536-542).  Per axis up(Z)[F i + k] = (1 - k/F) Z[i] + (k/F) Z[min(i+1, L-1)]
+// (TF1 legacy bilinear: source position = destination / F, no half-pixel offset).  Small maps: one thread per OUTPUT pixel x 4 channels forward,
+// one per low-resolution pixel x 4 channels backward; the operands live in L2.
+template <int F>
+__global__ __launch_bounds__(256) void upfproj_fwd_combine_kernel(const float* __restrict__ z, const float* __restrict__ bias, float* __restrict__ y,
+                                                                  const int N, const int H, const int W, const int C, const int act) {
+  const int CV = C >> 2;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)N * F * H * F * W * CV) return;
+  const int cq = (int)(t % CV);
+  const long pix = t / CV;
+  const int q = (int)(pix % (F * W)), p = (int)((pix / (F * W)) % (F * H)), n = (int)(pix / ((long)F * W * F * H));
+  const float4* zb = reinterpret_cast<const float4*>(z) + (long)n * H * W * 9 * CV + cq;
+  float4 acc = bias != nullptr ? reinterpret_cast<const float4*>(bias)[cq] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int u = p + r - 1;
+    if (u < 0 || u >= F * H) continue;
+    const int i0 = u / F, kr = u - i0 * F, i1 = min(i0 + 1, H - 1);
+    const float wr1 = (float)kr * (1.f / F), wr0 = 1.f - wr1;
+#pragma unroll
+    for (int sx = 0; sx < 3; ++sx) {
+      const int v = q + sx - 1;
+      if (v < 0 || v >= F * W) continue;
+      const int j0 = v / F, kc = v - j0 * F, j1 = min(j0 + 1, W - 1);
+      const float wc1 = (float)kc * (1.f / F), wc0 = 1.f - wc1;
+      const float4* zp = zb + (r * 3 + sx) * CV;
+      acc = f4_fma(wr0 * wc0, zp[((long)i0 * W + j0) * 9 * CV], acc);
+      if (kc) acc = f4_fma(wr0 * wc1, zp[((long)i0 * W + j1) * 9 * CV], acc);
+      if (kr) acc = f4_fma(wr1 * wc0, zp[((long)i1 * W + j0) * 9 * CV], acc);
+      if (kr && kc) acc = f4_fma(wr1 * wc1, zp[((long)i1 * W + j1) * 9 * CV], acc);
+    }
+  }
+  acc = make_float4(ladder_act_fn(acc.x, act), ladder_act_fn(acc.y, act), ladder_act_fn(acc.z, act), ladder_act_fn(acc.w, act));
+  reinterpret_cast<float4*>(y)[pix * CV + cq] = acc;
+}
+
+// coefficient of Z[i] in up(Z)[u] on an axis of low-resolution length L (u inside [0, F L))
+template <int F>
+__device__ __forceinline__ float upf_coef(int u, int i, int L) {
+  const int i0 = u / F, k = u - i0 * F, i1 = min(i0 + 1, L - 1);
+  const float w1 = (float)k * (1.f / F);
+  return (i0 == i ? 1.f - w1 : 0.f) + (i1 == i ? w1 : 0.f);
+}
+
+template <int F>
+__global__ __launch_bounds__(256) void upfproj_bwd_combine_kernel(const float* __restrict__ dy, float* __restrict__ d, const int N, const int H,
+                                                                  const int W, const int C) {
+  const int CV = C >> 2;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)N * H * W * CV) return;
+  const int cq = (int)(t % CV);
+  const long pix = t / CV;
+  const int j = (int)(pix % W), i = (int)((pix / W) % H), n = (int)(pix / ((long)W * H));
+  const float4* gy = reinterpret_cast<const float4*>(dy) + (long)n * F * H * F * W * CV + cq;
+  float4* dp = reinterpret_cast<float4*>(d) + pix * 9 * CV + cq;
+  // positions of the upsampled line that read Z[i]: u in (F (i - 1), F (i + 1)); the gradient there through tap r is dy[u - r + 1]
+  constexpr int NU = 2 * F - 1;
+  float cu[NU], cv[NU];
+#pragma unroll
+  for (int a = 0; a < NU; ++a) {
+    const int u = F * (i - 1) + 1 + a, v = F * (j - 1) + 1 + a;
+    cu[a] = (u >= 0 && u < F * H) ? upf_coef<F>(u, i, H) : 0.f;
+    cv[a] = (v >= 0 && v < F * W) ? upf_coef<F>(v, j, W) : 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    // E[b] = sum_u cu[u] dy[u - r + 1][q_b] for the NU + 2 columns q_b = F (j - 1) + b  (b = v_index + 1 - s + ... see below)
+    float4 e[NU + 2];
+#pragma unroll
+    for (int b = 0; b < NU + 2; ++b) {
+      const int q = F * (j - 1) + b;                     // q = v - s + 1 with v = F (j - 1) + 1 + a  ->  b = a + 2 - s
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q >= 0 && q < F * W) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) {
+          const int p = F * (i - 1) + 1 + a - r + 1;
+          if (cu[a] != 0.f && p >= 0 && p < F * H) acc = f4_fma(cu[a], gy[((long)p * F * W + q) * CV], acc);
+        }
+      }
+      e[b] = acc;
+    }
+#pragma unroll
+    for (int sx = 0; sx < 3; ++sx) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int a = 0; a < NU; ++a) acc = f4_fma(cv[a], e[a + 2 - sx], acc);
+      dp[(r * 3 + sx) * CV] = acc;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -213,6 +306,31 @@ int ladder_up2proj_wgrad_unpack(const float* dwcat, const float* db9, float* dw,
   if (Cin <= 0 || Cout <= 0 || dwcat == nullptr || dw == nullptr || (db != nullptr && db9 == nullptr)) return LADDER_E_SHAPE;
   const long total = (long)9 * Cin * Cout;
   hipLaunchKernelGGL(up2proj_wgrad_unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dwcat, db9, dw, db, Cin, Cout);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+// Any resize factor of {2, 4}: y [N, F H, F W, C] = act(bias + sum_rs shift_rs(up_F(Z_rs))) and d = (shift o up_F)^T dy.  Factor 2 takes the kernels above.
+int ladder_upfproj_eligible(int factor, int N, int H, int W, int Cin, int Cout) {
+  return ((factor == 2 || factor == 4) && ladder_up2proj_eligible(N, H, W, Cin, Cout) && (long)N * H * W * factor * factor < (1L << 30)) ? 1 : 0;
+}
+
+int ladder_upfproj_fwd_combine(const float* z, const float* bias, float* y, int factor, int N, int H, int W, int C, int act, ladder_stream_t stream) {
+  if (factor == 2) return ladder_up2proj_fwd_combine(z, bias, y, nullptr, nullptr, nullptr, 0, N, H, W, C, act, stream);
+  if (factor != 4 || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4) != 0 || y == nullptr) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(z) || !ladder_aligned16(y) || (bias != nullptr && !ladder_aligned16(bias))) return LADDER_E_ALIGN;
+  const long total = (long)N * 16 * H * W * (C / 4);
+  hipLaunchKernelGGL(upfproj_fwd_combine_kernel<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, z, bias, y, N, H, W, C, act);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+int ladder_upfproj_bwd_combine(const float* dy, float* d, int factor, int N, int H, int W, int C, ladder_stream_t stream) {
+  if (factor == 2) return ladder_up2proj_bwd_combine(dy, d, N, H, W, C, stream);
+  if (factor != 4 || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4) != 0) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(dy) || !ladder_aligned16(d)) return LADDER_E_ALIGN;
+  const long total = (long)N * H * W * (C / 4);
+  hipLaunchKernelGGL(upfproj_bwd_combine_kernel<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dy, d, N, H, W, C);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

@@ -617,6 +617,7 @@ class Conv2D:
         self.want_bn_sums, self.bn_sums = False, None          # batch-norm statistics of the output from the conv epilogue (RGB conv)
         self.x_is_up2 = False                                   # set by forward_up2(keep_y): self.x is a factor-2 legacy-bilinear upsample
         self.x_is_lo = False                                    # ... or self.x is the LOW-resolution tensor itself (the upsample was never materialised)
+        self.lo_factor = 2                                      # ... by this resize factor
 
     def _halo_ok(self, N, H, W, cin, cout):
         """The layer runs on the fused 3x3 halo kernels of the configured precision (strict fp32: csrc/convf32.hip; split formats:
@@ -741,12 +742,20 @@ class Conv2D:
         return bool(self.ctx.up2 and self.ctx.ns in (0, 2, 4) and self.k == 3 and self.stride == 1 and self.padding == "same"
                     and L.query("ladder_conv3x3_up2_split_eligible", N, H, W, self.cin, self.cout, self.ctx.ns))
 
-    def proj_ok(self, N, H, W):
+    def upf_ok(self, N, H, W, f):
+        """up2_ok for a resize factor f: 2 (every form) or 4 (projected form only -- decoder conv2d_3 behind the 2x2 -> 8x8 resize)."""
+        return self.up2_ok(N, H, W) if f == 2 else self.proj_ok(N, H, W, f)
+
+    def virtual_upf_ok(self, N, H, W, f):
+        return self.virtual_up2_ok(N, H, W) if f == 2 else self.proj_ok(N, H, W, f)
+
+    def proj_ok(self, N, H, W, f=2):
         """'Project, then upsample' (csrc/upproj.hip; strict fp32, config `upsample_fused_convs` >= 4): resize x2 -> this conv over a LOW-resolution
         [N, H, W, cin] tensor as nine 1x1 convolutions on it (9 of the direct form's 36 products per 2x2 output block, against 25 for the tap-folded
-        form above) + an exact elementwise combination.  Forward, backward-data and the filter gradient all run from the low-resolution tensor."""
+        form above) + an exact elementwise combination.  Forward, backward-data and the filter gradient all run from the low-resolution tensor.
+        `f` = the resize factor, 2 or 4 (1 of 16 products at 4)."""
         return bool(self.ctx.ns == 0 and self.ctx.up2 >= 4 and self.k == 3 and self.stride == 1 and self.padding == "same"
-                    and os.environ.get("LADDER_DISABLE_HALO") != "1" and L.query("ladder_up2proj_eligible", N, H, W, self.cin, self.cout))
+                    and os.environ.get("LADDER_DISABLE_HALO") != "1" and L.query("ladder_upfproj_eligible", f, N, H, W, self.cin, self.cout))
 
     def virtual_up2_ok(self, N, H, W):
         """A training forward may skip materialising the factor-2 upsample of its [N, H, W, cin] input altogether: strict fp32, and forward,
@@ -756,18 +765,18 @@ class Conv2D:
         return bool(self.ctx.ns == 0 and self.ctx.up2 >= 3 and self.up2_ok(N, H, W) and self.up2t_ok(N, H, W) and H * W >= UP2W_MIN_PIXELS
                     and L.query("ladder_conv3x3_up2_wgrad_eligible", N, H, W, self.cin, self.cout))
 
-    def _forward_proj(self, x, proj, keep_y, upsampled):
+    def _forward_proj(self, x, proj, keep_y, upsampled, f=2):
         """forward_up2 in the project-then-upsample form: Z [M, 9 cout] = x [M, cin] . wcat (dense kernel), then the elementwise combination with
         bias, activation and -- for the last layer -- the 1x1 output conv on the activated value."""
         ctx, st = self.ctx, self.ctx.stream
         N, H, W = x.shape[0], x.shape[1], x.shape[2]
         M, n9 = N * H * W, 9 * self.cout
         self.pt = self.pl = 1
-        flops = 2.0 * N * 4 * H * W * 9 * self.cin * self.cout          # the reference's operation count (algorithmic) ...
-        executed = 2.0 * M * self.cin * n9                               # ... of which 9 / 36 are issued
+        flops = 2.0 * N * f * f * H * W * 9 * self.cin * self.cout      # the reference's operation count (algorithmic) ...
+        executed = 2.0 * M * self.cin * n9                               # ... of which 9 / 36 are issued (factor 2; 1 / 16 at factor 4)
         ukey = self.name + (":train" if keep_y else "")
         ctx.up2_used[ukey] = ctx.up2_used.get(ukey, 0) + 1
-        ctx.up2_skipped[ukey] = 27.0 / 36.0
+        ctx.up2_skipped[ukey] = 1.0 - 1.0 / (f * f)
         z = ctx.empty(M, n9)
         wsp, wsn = ctx.ws(L.query("ladder_igemm_fwd_workspace_bytes", M, self.cin, n9))
         _timed(128128, flops, "ladder_dense_fwd", (_p(x), _p(self._packed_filter(6)), None, _p(z), M, self.cin, n9, 0, wsp, wsn, st), executed)
@@ -780,9 +789,10 @@ class Conv2D:
                    proj.cout, N, H, W, self.cout, L.ACT[self.act], st)
             proj.x, proj.y = (y, out) if keep_y else (None, None)
         else:
-            out = y = ctx.empty(N, 2 * H, 2 * W, self.cout)
-            L.call("ladder_up2proj_fwd_combine", _p(z), _p(bias), _p(y), None, None, None, 0, N, H, W, self.cout, L.ACT[self.act], st)
+            out = y = ctx.empty(N, f * H, f * W, self.cout)
+            L.call("ladder_upfproj_fwd_combine", _p(z), _p(bias), _p(y), f, N, H, W, self.cout, L.ACT[self.act], st)
         self.x_amax = None
+        self.lo_factor = f
         self.x, self.y = ((upsampled if upsampled is not None else x), y) if keep_y else (None, None)
         self.x_is_up2 = bool(keep_y and upsampled is not None)
         self.x_is_lo = bool(keep_y and upsampled is None)
@@ -794,14 +804,14 @@ class Conv2D:
         ctx, st = self.ctx, self.ctx.stream
         x = self.x
         N, H, W, _ = x.shape
-        M, n9 = N * H * W, 9 * self.cout
-        flops = 2.0 * N * 4 * H * W * 9 * self.cin * self.cout
+        M, n9, f = N * H * W, 9 * self.cout, self.lo_factor
+        flops = 2.0 * N * f * f * H * W * 9 * self.cin * self.cout
         executed = 2.0 * M * self.cin * n9
         d = ctx.empty(M, n9)
-        L.call("ladder_up2proj_bwd_combine", _p(dy), _p(d), N, H, W, self.cout, st)
+        L.call("ladder_upfproj_bwd_combine", _p(dy), _p(d), f, N, H, W, self.cout, st)
         if wgrad:
             ctx.up2_used[self.name + ":wgrad"] = ctx.up2_used.get(self.name + ":wgrad", 0) + 1
-            ctx.up2_skipped[self.name + ":wgrad"] = 27.0 / 36.0
+            ctx.up2_skipped[self.name + ":wgrad"] = 1.0 - 1.0 / (f * f)
             dwcat, db9 = ctx.empty(self.cin, n9), ctx.empty(n9)
             wsp, wsn = ctx.ws(L.query("ladder_dense_bwd_weight_workspace_bytes", M, self.cin, n9))
             _timed(9130, flops, "ladder_dense_bwd_weight", (_p(x), _p(d), _p(dwcat), _p(db9), M, self.cin, n9, wsp, wsn, st), executed)
@@ -810,7 +820,7 @@ class Conv2D:
         dx = None
         if need_dx:
             ctx.up2_used[self.name + ":bwd"] = ctx.up2_used.get(self.name + ":bwd", 0) + 1
-            ctx.up2_skipped[self.name + ":bwd"] = 27.0 / 36.0
+            ctx.up2_skipped[self.name + ":bwd"] = 1.0 - 1.0 / (f * f)
             dx = ctx.empty(N, H, W, self.cin)
             wsp, wsn = ctx.ws(L.query("ladder_igemm_fwd_workspace_bytes", M, n9, self.cin))
             gy, gact = gate if gate is not None else (None, None)
@@ -820,7 +830,7 @@ class Conv2D:
         self.x = self.y = None
         return dx
 
-    def forward_up2(self, x, proj=None, keep_y=False, x_for_backward=None):
+    def forward_up2(self, x, proj=None, keep_y=False, x_for_backward=None, factor=2):
         """conv(resize2x(x)) from the low-resolution x itself; with `proj` the 1x1 output conv rides on the epilogue as in forward_fused_proj.
         Forward-only runs keep nothing.  A training forward (`keep_y`) passes `x_for_backward` = the resized tensor, which it has to keep for
         the backward pass anyway (filter gradient and backward-data are those of the plain convolution on it): x / y are then kept exactly
@@ -828,8 +838,11 @@ class Conv2D:
         ctx = self.ctx
         src = x
         N, H, W = x.shape[0], x.shape[1], x.shape[2]
-        if self.proj_ok(N, H, W):
-            return self._forward_proj(x, proj, keep_y, x_for_backward)
+        if self.proj_ok(N, H, W, factor):
+            return self._forward_proj(x, proj, keep_y, x_for_backward, factor)
+        if factor != 2:
+            raise RuntimeError("%s: a factor-%d resize folds into the convolution in the projected form only" % (self.name, factor))
+        self.lo_factor = 2
         strided = 0
         upsampled = x_for_backward
         self.pt = self.pl = 1
@@ -974,7 +987,7 @@ class Conv2D:
         """_dx_lowres can apply the activation backward of the layer below (its `gate`) in the same launches (strict fp32, 8x32-pixel tiling).
         OFF by default (LADDER_ENABLE_LOWRES_GATE=1 turns it on): measured in round 5, the 64 gate loads per lane in the epilogue of conv2d_6's fused
         backward-data cost 72 us (1 631 -> 1 703 us) -- the 67 us ladder_act_bwd pass they replace (profiles/r05_f32_percall.md was taken with it on)."""
-        if self.x_is_lo and self.proj_ok(N, H, W):      # (projected form: the gate rides on the dense kernel's epilogue)
+        if self.x_is_lo and self.proj_ok(N, H, W, self.lo_factor):      # (projected form: the gate rides on the dense kernel's epilogue)
             return os.environ.get("LADDER_DISABLE_LOWRES_GATE") != "1"
         return bool(self.ctx.ns == 0 and os.environ.get("LADDER_ENABLE_LOWRES_GATE") == "1"
                     and L.query("ladder_conv3x3_up2_bwd_data_gated_f32_eligible", N, H, W, self.cout, self.cin))
@@ -1046,15 +1059,15 @@ class Conv2D:
         `lowres_dx`: x is the factor-2 upsample of a tensor the caller wants the gradient of: return d / d (that tensor) (see _dx_lowres)."""
         x, y = self.x, self.y
         N, H, W, _ = x.shape
-        if self.x_is_lo:                                  # x is the low-resolution tensor: the layer's input is its (never materialised) factor-2 upsample
-            H, W = 2 * H, 2 * W
+        if self.x_is_lo:                                  # x is the low-resolution tensor: the layer's input is its (never materialised) upsample
+            H, W = self.lo_factor * H, self.lo_factor * W
             if not lowres_dx and need_dx:
                 raise RuntimeError("%s: only the low-resolution gradient exists for a virtual upsample" % self.name)
         _, Ho, Wo, _ = y.shape
         st = self.ctx.stream
         if self.act is not None and not act_done:
             L.call("ladder_act_bwd", _p(dy), _p(y), _p(dy), dy.numel(), L.ACT[self.act], st)
-        if self.x_is_lo and self.proj_ok(N, H // 2, W // 2):
+        if self.x_is_lo and self.proj_ok(N, H // self.lo_factor, W // self.lo_factor, self.lo_factor):
             return self._backward_proj(dy, need_dx, wgrad, lowres_gate)
         if (wgrad and self.k == 1 and self.stride == 1 and L.query("ladder_conv1x1_smallcout_eligible", N * H * W, self.cin, self.cout)):
             # 1x1 to <= 4 channels over a wide map (the CelebA output conv): dx, dW and db from ONE pass over x
@@ -1579,20 +1592,28 @@ class CelebADecoder:
             d = lyr.forward(d)
         dlatent = d
         h = self.up0.forward(self.conv0.forward(encoded.view(B, 1, 1, self.nh)))
-        lowres = False            # h is the LOW-resolution input of a factor-2 resize that the next conv applies itself (forward-only runs)
-        lowres_copy = None        # training forward: the low-resolution tensor behind h = its factor-2 upsample (kept for the backward pass)
+        lowres = 0                # != 0: h is the LOW-resolution input of a resize by this factor that the next conv applies itself (forward-only runs)
+        lowres_copy = None        # training forward: the low-resolution tensor behind h = its upsample (kept for the backward pass) ...
+        lo_f = 2                  # ... by this factor
+
+        def _fac(rs_, t):         # integer factor (2 or 4) of resize `rs_` applied to t's map, 0 when it is neither
+            for f_ in (2, 4):
+                if (rs_.oh, rs_.ow) == (f_ * t.shape[1], f_ * t.shape[2]):
+                    return f_
+            return 0
         for bi, (conv, sty, norm, rs) in enumerate(self.blocks):
             x_lo, lowres_copy = lowres_copy, None
             conv_done = False
             if lowres:
-                lowres = False
-                last = bi == len(self.blocks) - 1 and norm is None and (rs is None or (rs.oh, rs.ow) == (2 * h.shape[1], 2 * h.shape[2]))
+                f_in, lowres = lowres, 0
+                last = (bi == len(self.blocks) - 1 and norm is None and f_in == 2
+                        and (rs is None or (rs.oh, rs.ow) == (2 * h.shape[1], 2 * h.shape[2])))
                 if last:
                     return conv.forward_up2(h, self.conv_out)
-                h = conv.forward_up2(h)
+                h = conv.forward_up2(h, factor=f_in)
                 conv_done = True
             elif bi == len(self.blocks) - 1 and norm is None and (rs is None or h is None or (rs.oh, rs.ow) == tuple(h.shape[1:3])):
-                if x_lo is not None:
+                if x_lo is not None and lo_f == 2:
                     # training forward: h = the resized tensor (kept for the backward pass) -- or None when every consumer of it runs from the
                     # low-resolution tensor (virtual upsample); the convolution reads the low-resolution one
                     if rs is not None:
@@ -1607,46 +1628,47 @@ class CelebADecoder:
             if not conv_done and x_lo is not None:
                 # training forward of an inner layer (conv2d_6): h = the resized tensor, kept for this layer's filter gradient / backward-data;
                 # the convolution itself reads the low-resolution tensor (25 of 36 tap products)
-                h = conv.forward_up2(x_lo, keep_y=True, x_for_backward=h)
+                h = conv.forward_up2(x_lo, keep_y=True, x_for_backward=h, factor=lo_f)
                 conv_done = True
             if not conv_done:
                 h = conv.forward(h)
             # the resize behind this block folds into the NEXT conv when that one can take the low-resolution tensor (forward-only runs)
             nxt = self.blocks[bi + 1][0] if bi + 1 < len(self.blocks) else None
-            fold = (rs is not None and nxt is not None and not self.ctx.keep_activations and (rs.oh, rs.ow) == (2 * h.shape[1], 2 * h.shape[2])
-                    and nxt.up2_ok(h.shape[0], h.shape[1], h.shape[2]))
+            f_rs = _fac(rs, h) if (rs is not None and nxt is not None) else 0
+            fold = bool(f_rs and not self.ctx.keep_activations and nxt.upf_ok(h.shape[0], h.shape[1], h.shape[2], f_rs))
             if norm is not None:
                 style = sty.forward(dlatent)
                 # (training forward: the NEXT conv reads the low-resolution tensor, written beside the resized one it keeps for backward)
-                want_lo = (self.ctx.up2 >= 2 and rs is not None and not fold and self.ctx.keep_activations and nxt is not None
-                           and (rs.oh, rs.ow) == (2 * h.shape[1], 2 * h.shape[2]) and nxt.up2_ok(h.shape[0], h.shape[1], h.shape[2]))
-                if want_lo and nxt.virtual_up2_ok(h.shape[0], h.shape[1], h.shape[2]):
+                want_lo = bool(self.ctx.up2 >= 2 and f_rs and not fold and self.ctx.keep_activations
+                               and nxt.upf_ok(h.shape[0], h.shape[1], h.shape[2], f_rs))
+                if want_lo and nxt.virtual_upf_ok(h.shape[0], h.shape[1], h.shape[2], f_rs):
                     # the resized tensor has no reader left (the next layer's forward, backward-data and filter gradient all take the
                     # low-resolution tensor): plain instance norm, no resize, 1/4 of the bytes
                     rs.in_shape = tuple(h.shape)
-                    lowres_copy = norm.forward(h, style)
+                    lowres_copy, lo_f = norm.forward(h, style), f_rs
                     h = None
                     continue
-                up = norm.forward_resized(h, style, rs, keep_lowres=want_lo) if (rs is not None and not fold) else None
+                up = norm.forward_resized(h, style, rs, keep_lowres=want_lo and f_rs == 2) if (rs is not None and not fold) else None
                 if up is not None:
                     h = up
-                    lowres_copy = norm.y_lo if want_lo else None
+                    lowres_copy, lo_f = (norm.y_lo if want_lo else None), 2
                     continue
                 h = norm.forward(h, style)
             if fold:
-                lowres = True
+                lowres = f_rs
                 continue
             if rs is not None:
                 # (training forward, un-normalised layer in front of a factor-2 resize -- conv2d_5: its output IS the low-resolution tensor)
-                keep_lo = (norm is None and self.ctx.up2 >= 2 and self.ctx.keep_activations and nxt is not None
-                           and (rs.oh, rs.ow) == (2 * h.shape[1], 2 * h.shape[2]) and nxt.up2_ok(h.shape[0], h.shape[1], h.shape[2]))
+                keep_lo = bool(norm is None and self.ctx.up2 >= 2 and self.ctx.keep_activations and f_rs
+                               and nxt.upf_ok(h.shape[0], h.shape[1], h.shape[2], f_rs)
+                               and (f_rs == 2 or nxt.virtual_upf_ok(h.shape[0], h.shape[1], h.shape[2], f_rs)))
                 lo = h
-                if keep_lo and nxt.virtual_up2_ok(h.shape[0], h.shape[1], h.shape[2]):
+                if keep_lo and nxt.virtual_upf_ok(h.shape[0], h.shape[1], h.shape[2], f_rs):
                     rs.in_shape = tuple(h.shape)                 # (virtual upsample: see above)
                     h = None
                 else:
                     h = rs.forward(h)
-                lowres_copy = lo if keep_lo else None
+                lowres_copy, lo_f = (lo if keep_lo else None), (f_rs or 2)
         return self.conv_out.forward(h)
 
     def backward(self, dxhat, need_dz=True):

@@ -157,3 +157,52 @@ def test_upproj_combine_is_the_transpose_of_itself(gpu_ctx):
     a = float((y.double() * dy.double()).sum())
     b = float((z.double() * d.double()).sum())
     assert abs(a - b) < 1e-6 * (abs(a) + float(y.double().norm() * dy.double().norm())), (a, b)
+
+
+F4_CASES = [(128, 2, 2, 64, 64), (3, 1, 1, 16, 32), (5, 3, 2, 32, 16), (2, 4, 5, 16, 16)]
+
+
+@pytest.mark.parametrize("case", F4_CASES, ids=lambda c: "n%d_%dx%d_c%d_co%d" % c)
+def test_upproj_factor4_forward_and_backward_vs_oracle(gpu_ctx, case):
+    """The 2x2 -> 8x8 resize in front of decoder conv2d_3 (codes/models.py:536-542) in the projected form: forward against the oracle's resize + conv,
+    dx / dw / db against float64 autograd through them."""
+    L = _lib()
+    N, H, W, cin, cout = case
+    st = gpu_ctx.stream
+    M, F = N * H * W, 4
+    assert L.query("ladder_upfproj_eligible", F, N, H, W, cin, cout) == 1
+    assert L.query("ladder_upfproj_eligible", 3, N, H, W, cin, cout) == 0
+    rng = np.random.default_rng(cin + cout + H)
+    x = rng.standard_normal((N, H, W, cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32) * 0.1
+    dy = rng.standard_normal((N, F * H, F * W, cout)).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    ref = O.leaky_relu(O.conv2d_tf(O.resize_bilinear_legacy(xt, F * H, F * W), wt, bt, 1, "same"))
+    wcat, wcatT = _pack(L, w, st)
+    xd, dyd = dev(x), dev(dy)
+    z = torch.full((M, 9 * cout), float("nan"), device="cuda")
+    ws = _ws(L.query("ladder_igemm_fwd_workspace_bytes", M, cin, 9 * cout))
+    L.call("ladder_dense_fwd", p(xd), p(wcat), None, p(z), M, cin, 9 * cout, 0, p(ws), ws.numel(), st)
+    y = torch.full((N, F * H, F * W, cout), float("nan"), device="cuda")
+    L.call("ladder_upfproj_fwd_combine", p(z), p(dev(b)), p(y), F, N, H, W, cout, 1, st)
+    close(y, ref.detach(), TOL32, "y")
+    # backward of the un-activated pair (the engine applies the activation derivative to dy first)
+    O.conv2d_tf(O.resize_bilinear_legacy(xt, F * H, F * W), wt, bt, 1, "same").backward(torch.as_tensor(dy, dtype=torch.float64))
+    d = torch.full((M, 9 * cout), float("nan"), device="cuda")
+    L.call("ladder_upfproj_bwd_combine", p(dyd), p(d), F, N, H, W, cout, st)
+    dx = torch.full((N, H, W, cin), float("nan"), device="cuda")
+    ws = _ws(L.query("ladder_igemm_fwd_workspace_bytes", M, 9 * cout, cin))
+    L.call("ladder_dense_fwd", p(d), p(wcatT), None, p(dx), M, 9 * cout, cin, 0, p(ws), ws.numel(), st)
+    close(dx, xt.grad, TOL32, "dx")
+    dwcat = torch.full((cin, 9 * cout), float("nan"), device="cuda")
+    db9 = torch.full((9 * cout,), float("nan"), device="cuda")
+    ws = _ws(L.query("ladder_dense_bwd_weight_workspace_bytes", M, cin, 9 * cout))
+    L.call("ladder_dense_bwd_weight", p(xd), p(d), p(dwcat), p(db9), M, cin, 9 * cout, p(ws), ws.numel(), st)
+    dw = torch.full((3, 3, cin, cout), float("nan"), device="cuda")
+    db = torch.full((cout,), float("nan"), device="cuda")
+    L.call("ladder_up2proj_wgrad_unpack", p(dwcat), p(db9), p(dw), p(db), cin, cout, st)
+    close(dw, wt.grad, TOL32, "dw")
+    close(db, bt.grad, TOL32, "db")
