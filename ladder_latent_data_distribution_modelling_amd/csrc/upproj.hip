@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256) void up2proj_fwd_combine_kernel(const float* _
       pwv[c4] = make_float4(pr[0], pco > 1 ? pr[1] : 0.f, pco > 2 ? pr[2] : 0.f, pco > 3 ? pr[3] : 0.f);
     }
   }
+  float pv[16];                                              // projection partials: [pixel a * 2 + b][output column]
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -111,22 +112,33 @@ __global__ __launch_bounds__(256) void up2proj_fwd_combine_kernel(const float* _
       const long opix = ((long)n * 2 * H + 2 * i + a) * 2 * W + 2 * j + b;
       if (live && y != nullptr) reinterpret_cast<float4*>(y)[opix * CV + cq] = v;
       if (PROJ) {
-        // C == 128: lanes cq = 0 .. 31 of a half-wave hold the pixel; fixed-order butterfly
         float4 pr = make_float4(0.f, 0.f, 0.f, 0.f);
         pr = f4_fma(v.x, pwv[0], pr);
         pr = f4_fma(v.y, pwv[1], pr);
         pr = f4_fma(v.z, pwv[2], pr);
         pr = f4_fma(v.w, pwv[3], pr);
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-          pr.x += __shfl_xor(pr.x, o, 64); pr.y += __shfl_xor(pr.y, o, 64); pr.z += __shfl_xor(pr.z, o, 64); pr.w += __shfl_xor(pr.w, o, 64);
-        }
-        if (live && cq == 0) {
-          const float pv[4] = {pr.x, pr.y, pr.z, pr.w};
-          for (int o = 0; o < pco; ++o) pout[opix * pco + o] = pv[o] + (pb != nullptr ? pb[o] : 0.f);
-        }
+        pv[(a * 2 + b) * 4 + 0] = pr.x; pv[(a * 2 + b) * 4 + 1] = pr.y; pv[(a * 2 + b) * 4 + 2] = pr.z; pv[(a * 2 + b) * 4 + 3] = pr.w;
       }
     }
+  if (PROJ) {
+    // C == 128: the 32 lanes cq = 0 .. 31 of a half-wave hold one low-resolution pixel.  Fixed-order reduce-scatter over them: at every step a
+    // lane keeps the half of its values its bit selects and adds the partner's copy of that half (8 + 4 + 2 + 1 + 1 = 16 exchanges for 16 sums).
+#pragma unroll
+    for (int half = 8, bit = 16; half >= 1; half >>= 1, bit >>= 1) {
+      const bool hi = (cq & bit) != 0;
+#pragma unroll
+      for (int k = 0; k < half; ++k) {
+        const float send = hi ? pv[k] : pv[k + half], keep = hi ? pv[k + half] : pv[k];
+        pv[k] = keep + __shfl_xor(send, bit, 64);
+      }
+    }
+    pv[0] += __shfl_xor(pv[0], 1, 64);
+    const int idx = cq >> 1, pixel = idx >> 2, o = idx & 3;          // this lane's sum: output column o of pixel (a, b) = (pixel >> 1, pixel & 1)
+    if (live && (cq & 1) == 0 && o < pco) {
+      const long opix = ((long)n * 2 * H + 2 * i + (pixel >> 1)) * 2 * W + 2 * j + (pixel & 1);
+      pout[opix * pco + o] = pv[0] + (pb != nullptr ? pb[o] : 0.f);
+    }
+  }
 }
 
 // D [N, H, W, 9 C] from dy [N, 2H, 2W, C]: D_rs[i, j] = sum_{alpha, beta} omega_r[alpha] omega_c[beta] dy[2i - r + alpha, 2j - s + beta]

@@ -1591,7 +1591,7 @@ class CelebADecoder:
         for lyr in self.mapping:
             d = lyr.forward(d)
         dlatent = d
-        h = self.up0.forward(self.conv0.forward(encoded.view(B, 1, 1, self.nh)))
+        h = self.conv0.forward(encoded.view(B, 1, 1, self.nh))
         lowres = 0                # != 0: h is the LOW-resolution input of a resize by this factor that the next conv applies itself (forward-only runs)
         lowres_copy = None        # training forward: the low-resolution tensor behind h = its upsample (kept for the backward pass) ...
         lo_f = 2                  # ... by this factor
@@ -1601,6 +1601,17 @@ class CelebADecoder:
                 if (rs_.oh, rs_.ow) == (f_ * t.shape[1], f_ * t.shape[2]):
                     return f_
             return 0
+        # the 1x1 -> 2x2 resize in front of conv2d_1 folds into it like every other one (projected form: all three passes from the 1x1 map)
+        f0 = _fac(self.up0, h)
+        self.up0_folded = bool(f0 and self.blocks[0][0].upf_ok(B, h.shape[1], h.shape[2], f0)
+                               and (not self.ctx.keep_activations or self.blocks[0][0].virtual_upf_ok(B, h.shape[1], h.shape[2], f0)))
+        if self.up0_folded and self.ctx.keep_activations:
+            self.up0.in_shape = tuple(h.shape)
+            lowres_copy, lo_f, h = h, f0, None
+        elif self.up0_folded:
+            lowres = f0
+        else:
+            h = self.up0.forward(h)
         for bi, (conv, sty, norm, rs) in enumerate(self.blocks):
             x_lo, lowres_copy = lowres_copy, None
             conv_done = False
@@ -1709,7 +1720,7 @@ class CelebADecoder:
                 lgate = (below[0].y, below[0].act)
             dh = conv.backward(dh, act_done=(bi == 0 and fuse_last) or gated or pre_gated, lowres_dx=lowres, lowres_gate=lgate)
             pre_gated = lgate is not None                      # (the NEXT block's activation backward is done)
-        dh = self.conv0.backward(self.up0.backward(dh))
+        dh = self.conv0.backward(dh if lowres else self.up0.backward(dh))     # (lowres: conv2d_1 returned the gradient of the 1x1 map itself)
         denc = dh.reshape(dh.shape[0], self.nh)
         # mapping MLP: each layer's backward-data epilogue applies the previous layer's leaky-ReLU derivative
         for i in range(len(self.mapping) - 1, -1, -1):
