@@ -49,6 +49,12 @@ int ladder_igemm_fwd_tile(long M, int Cin, int Cout);
  * For bwd_data pass the dy geometry (N,Ho,Wo,Cout as input; H,W,Cin as output), stride 1, ups = stride, flipped pads. */
 int ladder_conv2d_fwd_kernel_id(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int ups,
                                 int pad_t, int pad_l);
+/* Kernel the dense calls below dispatch to (strict fp32): 1 = the persistent 128x128x32 kernels of csrc/densef32.hip -- gemm_f32_kernel for
+ * ladder_dense_fwd (M x K x N) and ladder_dense_bwd_data (pass its M, N, K: the contraction runs over N), gemm_tn_f32_kernel + the fixed-order
+ * split sum for ladder_dense_bwd_weight; M >= 8192, M and the output width multiples of 128, the contraction a multiple of 32 -- 0 = the
+ * implicit-GEMM kernels of csrc/igemm.hip. */
+int ladder_dense_fwd_is_persistent(long M, int K, int N);
+int ladder_dense_bwd_weight_is_persistent(long M, int K, int N);
 
 /* ---------------------------------------------------------------- N1: tf.layers.conv2d
  * codes/models.py:51-71,115-148,203-229,273-315,398-460,514-585.

@@ -40,6 +40,8 @@ _p, _i, _f, _d, _z, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_
 PROTOTYPES = {
     "ladder_abi_version": (_i, []),
     "ladder_igemm_fwd_tile": (_i, [C.c_long, _i, _i]),
+    "ladder_dense_fwd_is_persistent": (_i, [C.c_long, _i, _i]),
+    "ladder_dense_bwd_weight_is_persistent": (_i, [C.c_long, _i, _i]),
     "ladder_igemm_fwd_splits": (_i, [C.c_long, _i, _i]),
     "ladder_conv2d_fwd_kernel_id": (_i, [_i] * 13),
     "ladder_conv2d_bwd_filter_kernel_id": (_i, [_i] * 12),

@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["igemm.hip", "convsplit.hip", "convf32.hip", "convf32s.hip", "upproj.hip", "densesplit.hip", "convrgb.hip", "norm.hip", "elbo.hip", "hostutil.hip", "vbgmm.hip"]
+SOURCES = ["igemm.hip", "convsplit.hip", "convf32.hip", "convf32s.hip", "upproj.hip", "densef32.hip", "densesplit.hip", "convrgb.hip", "norm.hip", "elbo.hip", "hostutil.hip", "vbgmm.hip"]
 LIB = os.path.join(HERE, "libladder_hip.so")
 
 

@@ -30,3 +30,15 @@ int filter_pack_f32_multi(const ladder_pack_job_t* jobs_dev, int njobs, int tota
 int conv3x3_f32_launch(const float* x, const float* bank, const float* bias, float* y, const float* pw, const float* pb, float* pout,
                        int pco, int N, int H, int W, int Cin, int Cout, int act, hipStream_t stream, unsigned long long tap_masks,
                        int s2_out);
+
+// csrc/densef32.hip: the persistent 128x128x32 strict-fp32 GEMM of the projected decoder pairs (C [M][N] = A [M][K] . B [K][N] + bias, activation, gate)
+bool dense_f32_big_ok(long M, int K, int N);
+int dense_f32_big_launch(const float* A, const float* B, const float* bias, float* C, const float* gate, int gate_act, long M, int K, int N, int act,
+                         hipStream_t stream);
+// ... and the filter-gradient form dW [K][N] = x^T dy over M rows: partial tiles [splits][K][N] (+ partial column sums of dy [splits][N]) for a
+// fixed-order second stage
+bool dense_wgrad_f32_ok(long M, int K, int N);
+void dense_wgrad_f32_plan(long M, int K, int N, int* splits, int* m_per_split);
+size_t dense_wgrad_f32_ws_bytes(long M, int K, int N);
+int dense_wgrad_f32_launch(const float* x, const float* dy, float* part, float* bias_part, long M, int K, int N, int splits, int m_per_split,
+                           hipStream_t stream);

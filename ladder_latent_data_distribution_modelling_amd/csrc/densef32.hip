@@ -1,0 +1,315 @@
+// Large strict-fp32 GEMMs of the "project, then upsample" decoder pairs (csrc/upproj.hip; round 5):  C [M][N] = A [M][K] . B [K][N], all row-major,
+// M = low-resolution pixels (8 192 ... 524 288), K / N = Cin and 9 Cout (128 ... 2 304), on v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA chains).
+//
+// Why not igemm_fwd_kernel (csrc/igemm.hip), which these calls ran on first: it is one workgroup per 128x128 tile with a 16-deep K chunk per barrier.
+// At K = 128 (conv2d_7's projection) a workgroup lives for 8 chunks = 256 MFMAs per wave, and its address set-up, the first global round trip and a
+// 64-store epilogue are not covered by anything: the MFMA pipe was busy 60 % of the time (profiles/r05_gemm_pmc.txt; 76 % at K = 1 152).  Here:
+//   * PERSISTENT workgroups (2 per CU): each walks a contiguous range of output tiles, N tiles innermost (the A panel stays in L2 / L1 for the 9 ... 18
+//     tiles that share it), and the operand pipeline runs straight across tile boundaries -- the first chunk of the next tile is in flight while the
+//     current tile's epilogue stores;
+//   * 32-deep chunks: one barrier per 64 MFMAs per wave, double-buffered LDS (68.9 KB), global -> registers issued before the chunk's MFMA block,
+//     registers -> LDS after it;
+//   * A fragments as ONE ds_read_b128 per 4 k-steps: lane (row, half) reads A[row][8 u + 4 half .. + 3] and uses element j in k-step (u, j); the B
+//     fragment of that step is B[8 u + 4 half + j][col] -- the K order inside a chunk is a permutation both operands agree on (a sum of products:
+//     the order of the fp32 FMA chain changes with it, nothing else).  A rows padded to 36 floats (16-byte aligned, conflict-free 128-bit reads).
+// Epilogue: bias, activation, optional gate (dx *= act'(gate), the fused activation backward of ladder_dense_bwd_data), 128-byte row segments per half-wave.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int GB_M = 128, GB_N = 128, GB_K = 32, GB_LDA = GB_K + 4, GB_THREADS = 256;
+
+__device__ __forceinline__ float4 g_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// EPI: bias / activation / gate in the epilogue (the plain projections carry none: a straight store keeps the kernel small -- the general epilogue is
+// 64 x (activation switch + gate) of straight-line code per wave)
+template <bool EPI>
+__global__ __launch_bounds__(GB_THREADS, 2) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
+                                                                 float* __restrict__ C, const float* __restrict__ gate, const int M, const int N,
+                                                                 const int K, const int act, const int gate_act, const int tiles_n,
+                                                                 const int tiles_total) {
+  __shared__ __attribute__((aligned(16))) float As[2][GB_M * GB_LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][GB_K * GB_N];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int cpt = K / GB_K;                                                           // chunks per tile
+  const int t0 = (int)((long)blockIdx.x * tiles_total / gridDim.x), t1 = (int)((long)(blockIdx.x + 1) * tiles_total / gridDim.x);
+  const int nchunks = (t1 - t0) * cpt;
+  if (nchunks <= 0) return;
+
+  // loader coordinates: A unit = (row tid / 8 + 32 i, k quad tid % 8), B unit = (k row tid / 32 + 8 i, n quad tid % 32)
+  const int a_r = tid >> 3, a_q = tid & 7, b_r = tid >> 5, b_q = tid & 31;
+  float4 ra[4], rb[4];
+  int lt = t0, lc = 0;                                                                 // tile / chunk the NEXT load fetches
+  auto load = [&]() {
+    const int mt = lt / tiles_n, nt = lt - mt * tiles_n;
+    const float* ap = A + ((long)mt * GB_M + a_r) * K + lc * GB_K + a_q * 4;
+    const float* bp = B + ((long)lc * GB_K + b_r) * N + nt * GB_N + b_q * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = g_ld4(ap + (long)32 * i * K);
+      rb[i] = g_ld4(bp + (long)8 * i * N);
+    }
+    if (++lc == cpt) { lc = 0; ++lt; }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<float4*>(&As[buf][(a_r + 32 * i) * GB_LDA + a_q * 4]) = ra[i];
+      *reinterpret_cast<float4*>(&Bs[buf][(b_r + 8 * i) * GB_N + b_q * 4]) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  load();
+  store(0);
+  __syncthreads();
+  int ct = t0, cc = 0;                                                                 // tile / chunk being multiplied
+  const int a_off = (wm * 64 + l31) * GB_LDA + 4 * lh, b_off = (4 * lh) * GB_N + wn * 64 + l31;
+  for (int g = 0; g < nchunks; ++g) {
+    const int buf = g & 1;
+    if (g + 1 < nchunks) load();
+    {
+      // software pipeline over the chunk's four 8-deep groups: the fragments of group u + 1 are requested before the 16 MFMAs of group u are issued
+      // (scheduling fences: left alone, the compiler sinks every LDS read to just in front of its first use and the MFMA pipe waits out each round trip)
+      const float* Ab = &As[buf][a_off];
+      const float* Bb = &Bs[buf][b_off];
+      float4 af[2][2];
+      float bf[2][4][2];
+      auto frags = [&](int u, int s) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) af[s][mi] = *reinterpret_cast<const float4*>(Ab + mi * 32 * GB_LDA + 8 * u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) bf[s][j][ni] = Bb[(8 * u + j) * GB_N + ni * 32];
+      };
+      frags(0, 0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s = u & 1;
+        if (u + 1 < 4) frags(u + 1, s ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            const float a = j == 0 ? af[s][mi].x : (j == 1 ? af[s][mi].y : (j == 2 ? af[s][mi].z : af[s][mi].w));
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf[s][j][ni], acc[mi][ni], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (++cc == cpt) {                                                                 // the tile is complete: write it, start the next one from zero
+      const int mt = ct / tiles_n, nt = ct - mt * tiles_n;
+      const long voff = (long)4 * lh * N + l31;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int n = nt * GB_N + wn * 64 + ni * 32;
+        const float bv = (EPI && bias != nullptr) ? bias[n + l31] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const long rbase = ((long)mt * GB_M + wm * 64 + mi * 32) * N + n;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const long o = rbase + (long)((e & 3) + 8 * (e >> 2)) * N + voff;
+            float v = acc[mi][ni][e];
+            if (EPI) {
+              v = ladder_act_fn(v + bv, act);
+              if (gate != nullptr) v *= ladder_act_grad_from_out(gate[o], gate_act);
+            }
+            C[o] = v;
+            acc[mi][ni][e] = 0.f;
+          }
+        }
+      }
+      cc = 0;
+      ++ct;
+    }
+    if (g + 1 < nchunks) store(buf ^ 1);
+    __syncthreads();
+  }
+}
+
+// Filter gradient of the projected pairs: dWcat [Kc][N] = X^T D, X [M][Kc] (the low-resolution layer input), D [M][N] (the nine gradient planes); the
+// reduction runs over the M pixels, so both operands sit in LDS pixel-major exactly as they lie in memory ([32 pixels][128 channels], 512-byte rows:
+// conflict-free 32-bit fragment reads, lane = channel) and a (128 x 128 tile, pixel range) pair is one workgroup.  Partial tiles [split][Kc][N] are
+// summed in a fixed order by the caller (launch_reduce_splits, csrc/igemm.hip): bit-reproducible.  The bias gradient (column sums of D) rides along
+// in the workgroups of tile row 0, which stream every D row anyway.  Same software pipeline as gemm_f32_kernel.
+__global__ __launch_bounds__(GB_THREADS, 2) void gemm_tn_f32_kernel(const float* __restrict__ X, const float* __restrict__ D, float* __restrict__ part,
+                                                                    float* __restrict__ bias_part, const int M, const int Kc, const int N,
+                                                                    const int tiles_n, const int m_per_split) {
+  __shared__ __attribute__((aligned(16))) float At[2][GB_K * GB_M];
+  __shared__ __attribute__((aligned(16))) float Bt[2][GB_K * GB_N];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int kt = blockIdx.x / tiles_n, nt = blockIdx.x - kt * tiles_n;
+  const int p0 = blockIdx.y * m_per_split, p1 = min(M, p0 + m_per_split);
+  const int nchunks = (p1 - p0 + GB_K - 1) / GB_K;
+  const int l_r = tid >> 5, l_q = tid & 31;                                            // loader unit i: pixel row l_r + 8 i of the chunk, channel quad l_q
+  const float* xp = X + (long)kt * GB_M + l_q * 4;
+  const float* dp = D + (long)nt * GB_N + l_q * 4;
+  const bool do_bias = bias_part != nullptr && kt == 0;
+  float4 ra[4], rb[4], bsum[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bsum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = p0 + c * GB_K + l_r + 8 * i;
+      const bool in = p < p1;
+      ra[i] = in ? g_ld4(xp + (long)p * Kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[i] = in ? g_ld4(dp + (long)p * N) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<float4*>(&At[buf][(l_r + 8 * i) * GB_M + l_q * 4]) = ra[i];
+      *reinterpret_cast<float4*>(&Bt[buf][(l_r + 8 * i) * GB_N + l_q * 4]) = rb[i];
+      if (do_bias) { bsum[i].x += rb[i].x; bsum[i].y += rb[i].y; bsum[i].z += rb[i].z; bsum[i].w += rb[i].w; }
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+  if (nchunks > 0) {
+    load(0);
+    store(0);
+  }
+  __syncthreads();
+  const int a_off = lh * GB_M + wm * 64 + l31, b_off = lh * GB_N + wn * 64 + l31;
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) load(c + 1);
+    {
+      const float* Ab = &At[buf][a_off];
+      const float* Bb = &Bt[buf][b_off];
+      float af[2][4][2], bf[2][4][2];
+      auto frags = [&](int u, int s) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) af[s][j][mi] = Ab[(8 * u + 2 * j) * GB_M + mi * 32];
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) bf[s][j][ni] = Bb[(8 * u + 2 * j) * GB_N + ni * 32];
+        }
+      };
+      frags(0, 0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s = u & 1;
+        if (u + 1 < 4) frags(u + 1, s ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][j][mi], bf[s][j][ni], acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (c + 1 < nchunks) store(buf ^ 1);
+    __syncthreads();
+  }
+  float* o = part + (size_t)blockIdx.y * Kc * N + ((long)kt * GB_M + wm * 64) * N + nt * GB_N + wn * 64 + (long)4 * lh * N + l31;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[(long)(mi * 32 + (e & 3) + 8 * (e >> 2)) * N + ni * 32] = acc[mi][ni][e];
+  if (do_bias) {                                                                       // fixed-order sum of the loaders' column sums through LDS
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Bt[0][(l_r + 8 * i) * GB_N + l_q * 4]) = bsum[i];
+    __syncthreads();
+    if (tid < GB_N) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int r = 0; r < GB_K; ++r) sacc += Bt[0][r * GB_N + tid];
+      bias_part[(size_t)blockIdx.y * N + nt * GB_N + tid] = sacc;
+    }
+  }
+}
+
+}  // namespace
+
+// C-ABI-internal entry (declared in convf32.h): returns false when the shape is not this kernel's
+bool dense_f32_big_ok(long M, int K, int N) {
+  static const bool off = getenv("LADDER_DISABLE_GEMM_F32") != nullptr;
+  return !off && M >= 8192 && (M % GB_M) == 0 && (N % GB_N) == 0 && (K % GB_K) == 0 && K >= GB_K && M < (1L << 31) && (M / GB_M) * (N / GB_N) < (1L << 30);
+}
+
+int dense_f32_big_launch(const float* A, const float* B, const float* bias, float* C, const float* gate, int gate_act, long M, int K, int N, int act,
+                         hipStream_t stream) {
+  if (!dense_f32_big_ok(M, K, N)) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(A) || !ladder_aligned16(B) || !ladder_aligned16(C)) return LADDER_E_ALIGN;
+  const int tiles_n = N / GB_N, tiles_total = (int)(M / GB_M) * tiles_n;
+  static int slots = 0;
+  if (slots == 0) {
+    const char* e = getenv("LADDER_GEMM_F32_WGS");
+    slots = e != nullptr ? atoi(e) : 512;                                              // 256 CUs x 2 resident workgroups
+    if (slots < 1) slots = 512;
+  }
+  // whole tiles per workgroup, as even as the count allows: tiles_total / ceil(tiles_total / slots) workgroups
+  const int per = (tiles_total + slots - 1) / slots;
+  const int grid = (tiles_total + per - 1) / per;
+  if (bias != nullptr || gate != nullptr || act != LADDER_ACT_NONE)
+    hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(grid), dim3(GB_THREADS), 0, stream, A, B, bias, C, gate, (int)M, N, K, act, gate_act, tiles_n, tiles_total);
+  else
+    hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(grid), dim3(GB_THREADS), 0, stream, A, B, bias, C, gate, (int)M, N, K, act, gate_act, tiles_n, tiles_total);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+// ---- filter gradient dW [K][N] = x^T dy over M rows: plan (splits over the rows so that tiles x splits fills 2 workgroups per CU once)
+bool dense_wgrad_f32_ok(long M, int K, int N) {
+  static const bool off = getenv("LADDER_DISABLE_GEMM_F32") != nullptr;
+  return !off && M >= 8192 && (K % GB_M) == 0 && (N % GB_N) == 0 && M < (1L << 31) && (long)(K / GB_M) * (N / GB_N) <= 512;
+}
+
+void dense_wgrad_f32_plan(long M, int K, int N, int* splits, int* m_per_split) {
+  const long tiles = (long)(K / GB_M) * (N / GB_N);
+  long s = 512 / tiles;
+  const long max_s = (M + 1023) / 1024;                                                // at least 1 024 rows per split
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  long mps = (M + s - 1) / s;
+  mps = (mps + GB_K - 1) / GB_K * GB_K;
+  *m_per_split = (int)mps;
+  *splits = (int)((M + mps - 1) / mps);
+}
+
+size_t dense_wgrad_f32_ws_bytes(long M, int K, int N) {
+  int splits, mps;
+  dense_wgrad_f32_plan(M, K, N, &splits, &mps);
+  return ((size_t)splits * K * N + (size_t)splits * N) * sizeof(float);
+}
+
+// writes the partial tiles [splits][K][N] to `part` and (bias_part != NULL) the partial column sums [splits][N]; the caller reduces them
+int dense_wgrad_f32_launch(const float* x, const float* dy, float* part, float* bias_part, long M, int K, int N, int splits, int m_per_split,
+                           hipStream_t stream) {
+  if (!dense_wgrad_f32_ok(M, K, N)) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(x) || !ladder_aligned16(dy) || !ladder_aligned16(part)) return LADDER_E_ALIGN;
+  const int tiles_n = N / GB_N;
+  hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3((K / GB_M) * tiles_n, splits), dim3(GB_THREADS), 0, stream, x, dy, part, bias_part, (int)M, K, N, tiles_n, m_per_split);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}

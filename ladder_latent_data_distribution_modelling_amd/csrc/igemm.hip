@@ -20,6 +20,7 @@
 // 16-byte access; padding lanes read a 16-byte zero buffer so loads stay unconditional.
 #include <cstdlib>
 #include "split16.h"
+#include "convf32.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -2052,6 +2053,9 @@ extern "C" {
 
 int ladder_abi_version(void) { return 1; }
 
+int ladder_dense_fwd_is_persistent(long M, int K, int N) { return dense_f32_big_ok(M, K, N) ? 1 : 0; }
+int ladder_dense_bwd_weight_is_persistent(long M, int K, int N) { return dense_wgrad_f32_ok(M, K, N) ? 1 : 0; }
+
 int ladder_igemm_fwd_tile(long M, int Cin, int Cout) {
   // BM*1000+BN of the kernel instantiation ladder_conv2d_fwd / _bwd_data / ladder_dense_* dispatch to; negative when the
   // vectorised (Cin%16==0 && Cout%4==0) instantiation is not used.  Lets a profiler attribute a launch to a kernel name.
@@ -2430,6 +2434,7 @@ int ladder_conv1x1_smallcout_bwd_absmax(const float* x, const float* dy, const f
 
 int ladder_dense_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act,
                      void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  if (dense_f32_big_ok(M, K, N)) return dense_f32_big_launch(x, w, bias, y, nullptr, 0, M, K, N, act, stream);     // (csrc/densef32.hip)
   IgemmDesc d{M, 1, 1, K, 1, 1, N, 1, 1, 1, 1, 0, 0, M, K, act, make_fastdiv(1), make_fastdiv(1)};
   set_conv_taps(d);
   return dispatch_fwd(x, w, bias, y, d, ws, ws_bytes, stream);
@@ -2437,15 +2442,34 @@ int ladder_dense_fwd(const float* x, const float* w, const float* bias, float* y
 
 int ladder_dense_bwd_data(const float* dy, const float* wT, float* dx, int M, int K, int N, const float* gate_y, int gate_act,
                           void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  if (dense_f32_big_ok(M, N, K)) return dense_f32_big_launch(dy, wT, nullptr, dx, gate_y, gate_act, M, N, K, LADDER_ACT_NONE, stream);
   IgemmDesc d{M, 1, 1, N, 1, 1, K, 1, 1, 1, 1, 0, 0, M, N, LADDER_ACT_NONE, make_fastdiv(1), make_fastdiv(1)};
   set_conv_taps(d);
   return dispatch_fwd(dy, wT, nullptr, dx, d, ws, ws_bytes, stream, gate_y, gate_act);
 }
 
-size_t ladder_dense_bwd_weight_workspace_bytes(int M, int K, int N) { return wgrad_ws_bytes(M, K, N); }
+size_t ladder_dense_bwd_weight_workspace_bytes(int M, int K, int N) {
+  const size_t a = wgrad_ws_bytes(M, K, N), b = dense_wgrad_f32_ok(M, K, N) ? dense_wgrad_f32_ws_bytes(M, K, N) : 0;
+  return a > b ? a : b;
+}
 
 int ladder_dense_bwd_weight(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, void* ws,
                             size_t ws_bytes, ladder_stream_t stream) {
+  if (dense_wgrad_f32_ok(M, K, N)) {                             // (csrc/densef32.hip: the filter gradients of the projected decoder pairs)
+    if (ws == nullptr || ws_bytes < dense_wgrad_f32_ws_bytes(M, K, N)) return LADDER_E_WORKSPACE;
+    if (!ladder_aligned16(dw)) return LADDER_E_ALIGN;
+    int splits, mps;
+    dense_wgrad_f32_plan(M, K, N, &splits, &mps);
+    const size_t kn = (size_t)K * N;
+    float* part = (float*)ws;
+    float* bias_part = db != nullptr ? part + (size_t)splits * kn : nullptr;
+    const int rc = dense_wgrad_f32_launch(x, dy, part, bias_part, M, K, N, splits, mps, stream);
+    if (rc != LADDER_OK) return rc;
+    launch_reduce_splits(part, dw, splits, kn, stream);
+    if (db != nullptr) launch_reduce_splits(bias_part, db, splits, (size_t)N, stream);
+    LADDER_CHECK_LAUNCH();
+    return LADDER_OK;
+  }
   IgemmDesc d{M, 1, 1, K, 1, 1, N, 1, 1, 1, 1, 0, 0, M, K, LADDER_ACT_NONE, make_fastdiv(1), make_fastdiv(1)};
   return run_wgrad(x, dy, dw, db, d, ws, ws_bytes, stream);
 }

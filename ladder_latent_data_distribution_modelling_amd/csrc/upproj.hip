@@ -50,6 +50,19 @@ __device__ __forceinline__ float4 f4_fma(float s, float4 v, float4 a) {
   return make_float4(fmaf(s, v.x, a.x), fmaf(s, v.y, a.y), fmaf(s, v.z, a.z), fmaf(s, v.w, a.w));
 }
 
+// one step of a reduce-scatter over the lanes of a half-wave: a lane keeps the HALF values its bit selects and adds the partner's copy of them
+// (bitwise selects: both operands stay in registers -- a `?:` on array elements becomes a 16-way select chain on the index)
+template <int HALF>
+__device__ __forceinline__ void rs_step(float (&pv)[16], const int cq, const int bit) {
+  const uint32_t m = (cq & bit) ? 0xffffffffu : 0u;
+#pragma unroll
+  for (int k = 0; k < HALF; ++k) {
+    const uint32_t a = __float_as_uint(pv[k]), b = __float_as_uint(pv[k + HALF]);
+    const float send = __uint_as_float((a & m) | (b & ~m)), keep = __uint_as_float((b & m) | (a & ~m));
+    pv[k] = keep + __shfl_xor(send, bit, 64);
+  }
+}
+
 // y [N, 2H, 2W, C] (may be NULL) and / or pout [N, 2H, 2W, pco] = the 1x1 projection of the ACTIVATED value (pw [C][pco], pb [pco]; needs C == 128:
 // the 32 lanes of a half-wave hold one pixel's channels).  One thread = one low-resolution pixel x 4 channels = a 2x2 output block.
 template <bool PROJ>
@@ -123,15 +136,10 @@ __global__ __launch_bounds__(256) void up2proj_fwd_combine_kernel(const float* _
   if (PROJ) {
     // C == 128: the 32 lanes cq = 0 .. 31 of a half-wave hold one low-resolution pixel.  Fixed-order reduce-scatter over them: at every step a
     // lane keeps the half of its values its bit selects and adds the partner's copy of that half (8 + 4 + 2 + 1 + 1 = 16 exchanges for 16 sums).
-#pragma unroll
-    for (int half = 8, bit = 16; half >= 1; half >>= 1, bit >>= 1) {
-      const bool hi = (cq & bit) != 0;
-#pragma unroll
-      for (int k = 0; k < half; ++k) {
-        const float send = hi ? pv[k] : pv[k + half], keep = hi ? pv[k + half] : pv[k];
-        pv[k] = keep + __shfl_xor(send, bit, 64);
-      }
-    }
+    rs_step<8>(pv, cq, 16);
+    rs_step<4>(pv, cq, 8);
+    rs_step<2>(pv, cq, 4);
+    rs_step<1>(pv, cq, 2);
     pv[0] += __shfl_xor(pv[0], 1, 64);
     const int idx = cq >> 1, pixel = idx >> 2, o = idx & 3;          // this lane's sum: output column o of pixel (a, b) = (pixel >> 1, pixel & 1)
     if (live && (cq & 1) == 0 && o < pco) {

@@ -45,6 +45,10 @@ class KernelProfiler:
              9120: "wgrad3x3_up2_f32_kernel + reductions / edge lines (filter gradient of resize x2 -> 3x3 conv over the low-resolution map: 25 of 36 tap tiles, "
                    "one parity class per workgroup, 12 waves, LDS-DMA staged 1x32-pixel patches, fp32 MFMA 32x32x2)",
              9130: "igemm_wgrad_kernel<128,128> + its fixed-order split reduction (dWcat [Cin][9 Cout] = x^T D of the project-then-upsample pairs, fp32 MFMA 32x32x2)",
+             9132: "gemm_tn_f32_kernel + its fixed-order split reduction (dWcat [Cin][9 Cout] = x^T D of the project-then-upsample pairs: 128x128 tile x pixel range "
+                   "per workgroup, 32-pixel chunks, software-pipelined LDS fragments, fp32 MFMA 32x32x2)",
+             128132: "gemm_f32_kernel (projection GEMMs of the project-then-upsample pairs, Z = x . wcat and dx = D . wcatT: persistent workgroups over 128x128 "
+                     "tiles, 32-deep chunks, 128-bit A fragments, software-pipelined LDS reads, fp32 MFMA 32x32x2)",
              7700: "gmm_logprob_kernel<R> + gmm_sum_kernel (mixture log-prob / responsibilities, lane = component, wave-shuffle logsumexp)"}
     LATENCY_BOUND = (7700,)          # not contraction kernels: reported beside the roofline, never as the dominant MFMA kernel
 
@@ -779,7 +783,8 @@ class Conv2D:
         ctx.up2_skipped[ukey] = 1.0 - 1.0 / (f * f)
         z = ctx.empty(M, n9)
         wsp, wsn = ctx.ws(L.query("ladder_igemm_fwd_workspace_bytes", M, self.cin, n9))
-        _timed(128128, flops, "ladder_dense_fwd", (_p(x), _p(self._packed_filter(6)), None, _p(z), M, self.cin, n9, 0, wsp, wsn, st), executed)
+        _timed(128132 if L.query("ladder_dense_fwd_is_persistent", M, self.cin, n9) else 128128, flops, "ladder_dense_fwd",
+               (_p(x), _p(self._packed_filter(6)), None, _p(z), M, self.cin, n9, 0, wsp, wsn, st), executed)
         bias = self.ps.w[self.name + "/bias"]
         if proj is not None:
             proj.pt = proj.pl = 0
@@ -814,7 +819,8 @@ class Conv2D:
             ctx.up2_skipped[self.name + ":wgrad"] = 1.0 - 1.0 / (f * f)
             dwcat, db9 = ctx.empty(self.cin, n9), ctx.empty(n9)
             wsp, wsn = ctx.ws(L.query("ladder_dense_bwd_weight_workspace_bytes", M, self.cin, n9))
-            _timed(9130, flops, "ladder_dense_bwd_weight", (_p(x), _p(d), _p(dwcat), _p(db9), M, self.cin, n9, wsp, wsn, st), executed)
+            _timed(9132 if L.query("ladder_dense_bwd_weight_is_persistent", M, self.cin, n9) else 9130, flops, "ladder_dense_bwd_weight",
+                   (_p(x), _p(d), _p(dwcat), _p(db9), M, self.cin, n9, wsp, wsn, st), executed)
             L.call("ladder_up2proj_wgrad_unpack", _p(dwcat), _p(db9), _p(self.ps.g[self.name + "/kernel"]),
                    _p(self.ps.g[self.name + "/bias"]) if self.bias_grad else None, self.cin, self.cout, st)
         dx = None
@@ -825,8 +831,8 @@ class Conv2D:
             wsp, wsn = ctx.ws(L.query("ladder_igemm_fwd_workspace_bytes", M, n9, self.cin))
             gy, gact = gate if gate is not None else (None, None)
             # (ladder_dense_bwd_data: dx [M, K] = dy [M, N] . wT [N, K], optionally times act'(gate) -- here dy := D, wT := wcatT)
-            _timed(128128, flops, "ladder_dense_bwd_data", (_p(d), _p(self._packed_filter(7)), _p(dx), M, self.cin, n9, _p(gy), L.ACT[gact] if gact else 0,
-                                                           wsp, wsn, st), executed)
+            _timed(128132 if L.query("ladder_dense_fwd_is_persistent", M, n9, self.cin) else 128128, flops, "ladder_dense_bwd_data",
+                   (_p(d), _p(self._packed_filter(7)), _p(dx), M, self.cin, n9, _p(gy), L.ACT[gact] if gact else 0, wsp, wsn, st), executed)
         self.x = self.y = None
         return dx
 

@@ -1,0 +1,11 @@
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+rm -rf $R/gpurun_out/pmc_gemm; mkdir -p $R/gpurun_out/pmc_gemm
+i=0
+for set in "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM" "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/pmc_gemm/p$i -- python3 $R/profiles/tools/r5_gemm_pmc_probe.py > $R/gpurun_out/pmc_gemm/p$i.log 2>&1
+done
+cd $R
+python3 profiles/tools/r5_gemm_pmc_probe.py --show $(find gpurun_out/pmc_gemm -name "*.db") > gpurun_out/r05_gemm_pmc.txt 2>&1
+python3 profiles/tools/r5_upproj_probe.py 2>&1 | grep "conv2d_7 fwd combine"

@@ -206,3 +206,52 @@ def test_upproj_factor4_forward_and_backward_vs_oracle(gpu_ctx, case):
     L.call("ladder_up2proj_wgrad_unpack", p(dwcat), p(db9), p(dw), p(db), cin, cout, st)
     close(dw, wt.grad, TOL32, "dw")
     close(db, bt.grad, TOL32, "db")
+
+
+@pytest.mark.parametrize("shape", [(8192, 128, 1152), (16384, 1152, 128), (8192, 512, 2304), (24576, 32, 256), (8320, 2304, 256)], ids=lambda s: "x".join(map(str, s)))
+def test_persistent_dense_kernel_vs_float64(gpu_ctx, shape):
+    """csrc/densef32.hip (the GEMM-shaped calls of the projected pairs: ladder_dense_fwd / ladder_dense_bwd_data with M >= 8192, M and N multiples of
+    128, K of 32): bias + activation forward, gated backward-data; against float64 numpy.  Tile counts that do not divide over the persistent
+    workgroups (8320 rows = 65 row tiles) included.  fp32 accumulation of K <= 2304 products: 3e-6 of the output scale."""
+    L = _lib()
+    M, K, N = shape
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(M + K + N)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    b = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32) * 0.1
+    ad, bd = dev(a), dev(b)
+    ref = a.astype(np.float64) @ b.astype(np.float64)
+    y = torch.full((M, N), float("nan"), device="cuda")
+    ws = _ws(L.query("ladder_igemm_fwd_workspace_bytes", M, K, N))
+    L.call("ladder_dense_fwd", p(ad), p(bd), p(dev(bias)), p(y), M, K, N, 1, p(ws), ws.numel(), st)
+    r1 = ref + bias.astype(np.float64)
+    close(y, np.where(r1 > 0, r1, 0.2 * r1), TOL32, "forward (bias, leaky ReLU)")
+    # backward-data form: dx [M, N] = dy [M, K] . wT [K, N], times act'(gate)
+    gate = rng.standard_normal((M, N)).astype(np.float32)
+    dx = torch.full((M, N), float("nan"), device="cuda")
+    L.call("ladder_dense_bwd_data", p(ad), p(bd), p(dx), M, N, K, p(dev(gate)), 1, p(ws), ws.numel(), st)
+    close(dx, ref * np.where(gate > 0, 1.0, 0.2), TOL32, "backward-data (gated)")
+
+
+@pytest.mark.parametrize("shape", [(16480, 128, 256), (8192, 256, 1152), (65536, 128, 1152), (8200, 512, 128)], ids=lambda s: "x".join(map(str, s)))
+def test_persistent_dense_filter_gradient_vs_float64(gpu_ctx, shape):
+    """gemm_tn_f32_kernel (csrc/densef32.hip) behind ladder_dense_bwd_weight: dW = x^T dy and db = column sums of dy over M rows, row counts that are
+    not a multiple of the 32-row chunk or of the split included; against float64 numpy.  Two runs must agree bit for bit (fixed-order split sums)."""
+    L = _lib()
+    M, K, N = shape
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(M + K + N)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    dy = rng.standard_normal((M, N)).astype(np.float32)
+    xd, dyd = dev(x), dev(dy)
+    ws = _ws(L.query("ladder_dense_bwd_weight_workspace_bytes", M, K, N))
+    outs = []
+    for _ in range(2):
+        dw = torch.full((K, N), float("nan"), device="cuda")
+        db = torch.full((N,), float("nan"), device="cuda")
+        L.call("ladder_dense_bwd_weight", p(xd), p(dyd), p(dw), p(db), M, K, N, p(ws), ws.numel(), st)
+        outs.append((dw.cpu().numpy(), db.cpu().numpy()))
+    close(outs[0][0], x.astype(np.float64).T @ dy.astype(np.float64), TOL32, "dw")
+    close(outs[0][1], dy.astype(np.float64).sum(0), TOL32, "db")
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
