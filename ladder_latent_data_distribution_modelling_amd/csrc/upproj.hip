@@ -149,6 +149,113 @@ __global__ __launch_bounds__(256) void up2proj_fwd_combine_kernel(const float* _
   }
 }
 
+// The same combination with one thread walking `seg` consecutive low-resolution rows of its (column, 4 channels): of the two Z rows a plane needs
+// per step, the upper one is the lower one of the step before and stays in registers -- 18 instead of 36 loads per 2x2 output block (the 4x re-read
+// of Z through L2, not HBM, bounded the one-pixel kernel above: 892 us for conv2d_7's 2.4 GB without a y write).
+template <bool PROJ>
+__global__ __launch_bounds__(256) void up2proj_fwd_combine_rows_kernel(const float* __restrict__ z, const float* __restrict__ bias, float* __restrict__ y,
+                                                                       const float* __restrict__ pw, const float* __restrict__ pb,
+                                                                       float* __restrict__ pout, const int pco, const int N, const int H, const int W,
+                                                                       const int C, const int act, const int seg) {
+  const int CV = C >> 2, nseg = (H + seg - 1) / seg;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)N * nseg * W * CV;
+  const bool live = t < total;
+  const long tt = live ? t : 0;
+  const int cq = (int)(tt % CV);
+  const long rest = tt / CV;
+  const int j = (int)(rest % W), sg = (int)((rest / W) % nseg), n = (int)(rest / ((long)W * nseg));
+  const int i0 = sg * seg, i1 = min(H, i0 + seg);
+  const float4* zb = reinterpret_cast<const float4*>(z) + (long)n * H * W * 9 * CV + cq;
+  const float4 bv = bias != nullptr ? reinterpret_cast<const float4*>(bias)[cq] : make_float4(0.f, 0.f, 0.f, 0.f);
+  AxisW S[3];
+#pragma unroll
+  for (int sx = 0; sx < 3; ++sx) S[sx] = up2_axis(sx, j, W);
+  float4 pwv[4];
+  if (PROJ) {
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      const float* pr = pw + (long)(cq * 4 + c4) * pco;
+      pwv[c4] = make_float4(pr[0], pco > 1 ? pr[1] : 0.f, pco > 2 ? pr[2] : 0.f, pco > 3 ? pr[3] : 0.f);
+    }
+  }
+  // lo[plane][column]: the plane's LOWER-index row of the current step: row i - 1 for the planes of tap row r = 0, row i for r = 1, 2
+  float4 lo[9][2], hi[9][2];
+  auto load_row = [&](float4 (&dst)[9][2], int r, int row) {
+#pragma unroll
+    for (int sx = 0; sx < 3; ++sx) {
+      const float4* zp = zb + (r * 3 + sx) * CV + (long)row * W * 9 * CV;
+      dst[r * 3 + sx][0] = zp[(long)S[sx].lo * 9 * CV];
+      dst[r * 3 + sx][1] = zp[(long)S[sx].hi * 9 * CV];
+    }
+  };
+  load_row(lo, 0, max(i0 - 1, 0));
+  load_row(lo, 1, i0);
+  load_row(lo, 2, i0);
+  for (int i = i0; i < i1; ++i) {
+    const int up = min(i + 1, H - 1);
+    load_row(hi, 0, i);
+    load_row(hi, 1, up);
+    load_row(hi, 2, up);
+    float4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = bv;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const AxisW R = up2_axis(r, i, H);
+#pragma unroll
+      for (int sx = 0; sx < 3; ++sx) {
+        const int pl = r * 3 + sx;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            float4 q = acc[a][b];
+            q = f4_fma(R.wlo[a] * S[sx].wlo[b], lo[pl][0], q);
+            q = f4_fma(R.wlo[a] * S[sx].whi[b], lo[pl][1], q);
+            q = f4_fma(R.whi[a] * S[sx].wlo[b], hi[pl][0], q);
+            q = f4_fma(R.whi[a] * S[sx].whi[b], hi[pl][1], q);
+            acc[a][b] = q;
+          }
+      }
+    }
+    float pv[16];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float4 v = acc[a][b];
+        v = make_float4(ladder_act_fn(v.x, act), ladder_act_fn(v.y, act), ladder_act_fn(v.z, act), ladder_act_fn(v.w, act));
+        const long opix = ((long)n * 2 * H + 2 * i + a) * 2 * W + 2 * j + b;
+        if (live && y != nullptr) reinterpret_cast<float4*>(y)[opix * CV + cq] = v;
+        if (PROJ) {
+          float4 pr = make_float4(0.f, 0.f, 0.f, 0.f);
+          pr = f4_fma(v.x, pwv[0], pr);
+          pr = f4_fma(v.y, pwv[1], pr);
+          pr = f4_fma(v.z, pwv[2], pr);
+          pr = f4_fma(v.w, pwv[3], pr);
+          pv[(a * 2 + b) * 4 + 0] = pr.x; pv[(a * 2 + b) * 4 + 1] = pr.y; pv[(a * 2 + b) * 4 + 2] = pr.z; pv[(a * 2 + b) * 4 + 3] = pr.w;
+        }
+      }
+    if (PROJ) {
+      rs_step<8>(pv, cq, 16);
+      rs_step<4>(pv, cq, 8);
+      rs_step<2>(pv, cq, 4);
+      rs_step<1>(pv, cq, 2);
+      pv[0] += __shfl_xor(pv[0], 1, 64);
+      const int idx = cq >> 1, pixel = idx >> 2, o = idx & 3;
+      if (live && (cq & 1) == 0 && o < pco) {
+        const long opix = ((long)n * 2 * H + 2 * i + (pixel >> 1)) * 2 * W + 2 * j + (pixel & 1);
+        pout[opix * pco + o] = pv[0] + (pb != nullptr ? pb[o] : 0.f);
+      }
+    }
+#pragma unroll
+    for (int pl = 0; pl < 9; ++pl) { lo[pl][0] = hi[pl][0]; lo[pl][1] = hi[pl][1]; }
+  }
+}
+
 // D [N, H, W, 9 C] from dy [N, 2H, 2W, C]: D_rs[i, j] = sum_{alpha, beta} omega_r[alpha] omega_c[beta] dy[2i - r + alpha, 2j - s + beta]
 __global__ __launch_bounds__(256) void up2proj_bwd_combine_kernel(const float* __restrict__ dy, float* __restrict__ d, const int N, const int H,
                                                                   const int W, const int C) {
@@ -302,6 +409,22 @@ int ladder_up2proj_fwd_combine(const float* z, const float* bias, float* y, cons
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4) != 0 || (y == nullptr && proj_out == nullptr)) return LADDER_E_SHAPE;
   if (proj_out != nullptr && (proj_w == nullptr || proj_cout < 1 || proj_cout > 4 || C != 128)) return LADDER_E_SHAPE;
   if (!ladder_aligned16(z) || !ladder_aligned16(y) || (bias != nullptr && !ladder_aligned16(bias))) return LADDER_E_ALIGN;
+  static const int seg_env = getenv("LADDER_UP2PROJ_SEG") != nullptr ? atoi(getenv("LADDER_UP2PROJ_SEG")) : -1;
+  // rows per thread: 16, fewer while the launch would not fill the chip with >= 4 waves per SIMD (256 K threads); 0 (env) = the one-pixel kernel
+  int seg = 16;
+  while (seg > 2 && (long)N * ((H + seg - 1) / seg) * W * (C / 4) < (1L << 18)) seg >>= 1;
+  if (seg_env >= 0) seg = seg_env;
+  if (seg >= 2 && H >= 2) {
+    const long total = (long)N * ((H + seg - 1) / seg) * W * (C / 4);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (proj_out != nullptr)
+      hipLaunchKernelGGL(up2proj_fwd_combine_rows_kernel<true>, dim3(grid), dim3(256), 0, stream, z, bias, y, proj_w, proj_b, proj_out, proj_cout, N, H, W, C, act, seg);
+    else
+      hipLaunchKernelGGL(up2proj_fwd_combine_rows_kernel<false>, dim3(grid), dim3(256), 0, stream, z, bias, y, (const float*)nullptr, (const float*)nullptr,
+                         (float*)nullptr, 0, N, H, W, C, act, seg);
+    LADDER_CHECK_LAUNCH();
+    return LADDER_OK;
+  }
   const long total = (long)N * H * W * (C / 4);
   const unsigned grid = (unsigned)((total + 255) / 256);
   if (proj_out != nullptr)
