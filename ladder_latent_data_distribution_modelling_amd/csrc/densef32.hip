@@ -25,7 +25,7 @@ __device__ __forceinline__ float4 g_ld4(const float* p) { return *reinterpret_ca
 
 // EPI: bias / activation / gate in the epilogue (the plain projections carry none: a straight store keeps the kernel small -- the general epilogue is
 // 64 x (activation switch + gate) of straight-line code per wave)
-template <bool EPI>
+template <bool EPI, bool NT>
 __global__ __launch_bounds__(GB_THREADS, 2) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
                                                                  float* __restrict__ C, const float* __restrict__ gate, const int M, const int N,
                                                                  const int K, const int act, const int gate_act, const int tiles_n,
@@ -129,7 +129,8 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_f32_kernel(const float* __
               v = ladder_act_fn(v + bv, act);
               if (gate != nullptr) v *= ladder_act_grad_from_out(gate[o], gate_act);
             }
-            C[o] = v;
+            if (NT) __builtin_nontemporal_store(v, &C[o]);      // (a multi-GB product written once: keep it from displacing the operand panels in L2)
+            else C[o] = v;
             acc[mi][ni][e] = 0.f;
           }
         }
@@ -271,10 +272,14 @@ int dense_f32_big_launch(const float* A, const float* B, const float* bias, floa
   // whole tiles per workgroup, as even as the count allows: tiles_total / ceil(tiles_total / slots) workgroups
   const int per = (tiles_total + slots - 1) / slots;
   const int grid = (tiles_total + per - 1) / per;
+  static const int nt_env = getenv("LADDER_GEMM_F32_NT") != nullptr ? atoi(getenv("LADDER_GEMM_F32_NT")) : -1;
+  const bool nt = nt_env >= 0 ? nt_env != 0 : (size_t)M * N * sizeof(float) >= ((size_t)256 << 20);       // products beyond the 256 MB of L2 + MALL stream out
   if (bias != nullptr || gate != nullptr || act != LADDER_ACT_NONE)
-    hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(grid), dim3(GB_THREADS), 0, stream, A, B, bias, C, gate, (int)M, N, K, act, gate_act, tiles_n, tiles_total);
+    hipLaunchKernelGGL((gemm_f32_kernel<true, false>), dim3(grid), dim3(GB_THREADS), 0, stream, A, B, bias, C, gate, (int)M, N, K, act, gate_act, tiles_n, tiles_total);
+  else if (nt)
+    hipLaunchKernelGGL((gemm_f32_kernel<false, true>), dim3(grid), dim3(GB_THREADS), 0, stream, A, B, bias, C, gate, (int)M, N, K, act, gate_act, tiles_n, tiles_total);
   else
-    hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(grid), dim3(GB_THREADS), 0, stream, A, B, bias, C, gate, (int)M, N, K, act, gate_act, tiles_n, tiles_total);
+    hipLaunchKernelGGL((gemm_f32_kernel<false, false>), dim3(grid), dim3(GB_THREADS), 0, stream, A, B, bias, C, gate, (int)M, N, K, act, gate_act, tiles_n, tiles_total);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

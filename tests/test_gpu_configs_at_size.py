@@ -140,10 +140,15 @@ def test_celeba_r8k50_full_size_in_situ(tmp_path):
     # (round 5: 1.2e-4 measured -- the strict-fp32 build now contracts conv2d_5 / conv2d_4 against EFFECTIVE taps (sums of up to nine fp32 filter
     # values, one more rounding per tap) where the f16x3 build keeps the direct form; round 4, both direct there: 4.7e-5)
     assert _rel(fa["grad_norm"], fb["grad_norm"]) < 3e-4
-    assert _ok(fa["sigma"]["sigma"], fb["sigma"]["sigma"], 1e-5)
+    # sigma AFTER the first Adam step (lr 2.5e-4): that step moves every weight by ~lr along the SIGN of its gradient, so the entries whose gradient is
+    # rounding noise land +-lr apart in two builds.  Measured (profiles/tools/r5_sigma_probe.py): the strict-fp32 build at `upsample_fused_convs` 0 / 3 / 4
+    # gives 0.6909418 / 0.6909575 / 0.6909476 (2e-5 among themselves), f16x3 0.6907746 (1.8e-4 from all three; its gradient norm differs by 1.2e-4)
+    assert _ok(fa["sigma"]["sigma"], fb["sigma"]["sigma"], 1e-5, 3e-4)
     for k in SCALARS_RUN3:
         assert _ok(fa["prior"][k], fb["prior"][k], 2e-3, 1e-5), (k, fa["prior"][k], fb["prior"][k])
-    assert _rel(fa["prior_grad_norm"], fb["prior_grad_norm"]) < 5e-3
+    # (the prior group's gradient norm after that Adam step: 483.23 / 483.21 / 484.13 for the strict-fp32 build at levels 0 / 3 / 4, 479.19 in f16x3 -- the
+    # same sign-of-noise amplification; 1.0 % measured between the two default builds)
+    assert _rel(fa["prior_grad_norm"], fb["prior_grad_norm"]) < 2e-2
     # the 8-dimensional posterior the mixture kernel integrates over is the same in both builds
     assert np.abs(res["f16x3"]["mu_t"] - res["f32"]["mu_t"]).max() < 1e-4 * max(1.0, np.abs(res["f32"]["mu_t"]).max())
 
@@ -274,7 +279,10 @@ def test_data_parallel_full_size_two_ranks_one_gpu(tmp_path, config, prec):
     for k in SCALARS_RUN1:
         assert _ok(fa["ae"][k], fb["ae"][k], 1e-5, 1e-5), (k, fa["ae"][k], fb["ae"][k])
     assert _rel(fa["grad_norm"], fb["grad_norm"]) < 1e-4
-    assert _ok(fa["sigma"]["sigma"], fb["sigma"]["sigma"], 1e-5)
+    # sigma AFTER the first Adam step (lr 2.5e-4): that step moves every weight by ~lr along the SIGN of its gradient, so the entries whose gradient is
+    # rounding noise land +-lr apart in two builds.  Measured (profiles/tools/r5_sigma_probe.py): the strict-fp32 build at `upsample_fused_convs` 0 / 3 / 4
+    # gives 0.6909418 / 0.6909575 / 0.6909476 (2e-5 among themselves), f16x3 0.6907746 (1.8e-4 from all three; its gradient norm differs by 1.2e-4)
+    assert _ok(fa["sigma"]["sigma"], fb["sigma"]["sigma"], 1e-5, 3e-4)
     for k in SCALARS_RUN3:          # evaluated after the first (sign-like) Adam step of RUN#1: see test_celeba_full_size_halo_kernels_in_situ
         assert _ok(fa["prior"][k], fb["prior"][k], 2e-3, 1e-5), (k, fa["prior"][k], fb["prior"][k])
     for k in a.files:
@@ -396,7 +404,11 @@ def test_data_parallel_full_resolution_vs_live_float64_oracle(tmp_path, prec):
     f, calls = json.loads(str(got["fetch"])), json.loads(str(got["calls"]))
     # the fused forward pair (resize + conv2d_7 + RGB projection) engages at 8 images per rank; the fused backward-data needs 32 (512
     # workgroups of 4x fewer pixels) -- that one is held against the direct path at batch 128 in tests/test_gpu_up2.py
-    assert "ladder_conv3x3_up2_split_proj" in calls and "ladder_in_style_fwd_resize2x_keep" in calls, calls
+    # (round 5, strict fp32: the PROJECTED form instead -- every resize -> conv pair from the low-resolution tensor at any batch size, no resize launch left)
+    if prec == "f32":
+        assert "ladder_up2proj_fwd_combine" in calls and "ladder_upfproj_bwd_combine" in calls and not any("resize" in c for c in calls), calls
+    else:
+        assert "ladder_conv3x3_up2_split_proj" in calls and "ladder_in_style_fwd_resize2x_keep" in calls, calls
     for k in SCALARS_RUN1:
         assert _ok(f[k], float(ref[k]), 2e-5), (k, f[k], float(ref[k]))
     # Per tensor: relative L2 error <= max(5e-3, 5 x the L2 deviation of the oracle evaluated in fp32 on the CPU) AND max error <= 5e-2 of the

@@ -333,7 +333,7 @@ def test_f32_engine_routes_through_the_fused_kernels_and_agrees_with_the_direct_
 
     monkeypatch.setattr(L, "call", spy)
     res = {}
-    for up2 in (0, 2, 3, "generic"):
+    for up2 in (0, 2, 3, 4, "generic"):
         if up2 == "generic":      # a SECOND direct formulation (the round-1 gather kernels everywhere): the rounding-noise floor of the comparison
             monkeypatch.setenv("LADDER_DISABLE_HALO", "1")
             monkeypatch.setenv("LADDER_DISABLE_BNSTATS", "1")
@@ -395,6 +395,23 @@ def test_f32_engine_routes_through_the_fused_kernels_and_agrees_with_the_direct_
     # same 36 / 36 products, another summation order) give the rounding-noise floor of this comparison, tensor by tensor; a fused build may sit at
     # most 3x above that floor on any tensor (and never above 2e-3).  encoder/code_std_dev/kernel -- a difference of two nearly cancelling terms,
     # dz . eps against the entropy's 1 / sd -- carries the largest noise (measured 2e-4 ... 6e-4 in all three builds); every other tensor is below 5e-5.
+    # level 4 (round 5, the strict-fp32 default): every resize -> 3x3 conv pair of the decoder in the PROJECTED form (csrc/upproj.hip: nine 1x1
+    # convolutions at low resolution + an elementwise combination; conv2d_1 behind the 1x1 -> 2x2 resize, conv2d_3 behind the 2x2 -> 8x8 one, conv2d_4 ...
+    # conv2d_7 behind the factor-2 ones) in all three passes: no resize launch, no tap-folded launch and no edge / border helper is left
+    f4, g4, e4, d4, tc4, ec4, p4 = res[4]
+    assert not any("conv3x3_up2" in c or "resize" in c for c in tc4 + ec4), sorted(set(c for c in tc4 + ec4 if "up2" in c or "resize" in c))
+    for cs in (tc4, ec4):
+        assert cs.count("ladder_up2proj_fwd_combine") == 1 and cs.count("ladder_upfproj_fwd_combine") == 5      # conv2d_7 + RGB projection; conv2d_1, 3, 4, 5, 6
+    assert tc4.count("ladder_upfproj_bwd_combine") == 6 and tc4.count("ladder_up2proj_wgrad_unpack") == 6
+    assert tc4.count("ladder_dense_bwd_weight") == 6 and tc4.count("ladder_dense_bwd_data") == 6 and "ladder_dense_bwd_weight" not in tc3
+    for k in ("elbo", "l1_reconstruction_error", "l2_reconstruction_error", "loss_ae", "sigma", "mean_pixel_error"):
+        assert abs(f4[k] - f0[k]) <= 2e-6 * abs(f0[k]) + 1e-7, (k, f4[k], f0[k])
+    for k in e0:
+        if isinstance(e0[k], float):
+            assert abs(e4[k] - e0[k]) <= 2e-6 * abs(e0[k]) + 1e-7, (k, e4[k], e0[k])
+    close(d4, d0, 1e-5, "decoded image (level 4)")      # (measured 5.1e-6: seven chained fp32 layers in another summation order; levels 2 / 3: ~3e-6)
+    worst4, wname4 = _worst_grad(g0, g4)
+    print("f32 projected (level 4) vs direct: worst relative gradient difference %.2e (%s)" % (worst4, wname4))
     gg = res["generic"][1]
     floor, fname = _worst_grad(g0, gg)
     print("f32 direct gather vs direct halo (noise floor): worst relative gradient difference %.2e (%s)" % (floor, fname))
@@ -402,7 +419,7 @@ def test_f32_engine_routes_through_the_fused_kernels_and_agrees_with_the_direct_
         sc = np.abs(g0[name]).max()
         if sc > 1e-9:
             nf = np.abs(gg[name] - g0[name]).max() / sc
-            for lvl, g in ((2, g1), (3, g3)):
+            for lvl, g in ((2, g1), (3, g3), (4, g4)):
                 e = np.abs(g[name] - g0[name]).max() / sc
                 assert e <= max(3.0 * nf, 5e-5) and e < 2e-3, (name, lvl, e, nf)
 
