@@ -93,12 +93,12 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_f32_kernel(const float* __
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) bf[s][j][ni] = Bb[(8 * u + j) * GB_N + ni * 32];
       };
+      __builtin_amdgcn_sched_barrier(0);
       frags(0, 0);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int s = u & 1;
         if (u + 1 < 4) frags(u + 1, s ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -108,8 +108,21 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_f32_kernel(const float* __
             for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf[s][j][ni], acc[mi][ni], 0, 0, 0);
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
+      // issue order of the block: group 0's six LDS reads, then ONE read of group u + 1 per two MFMAs of group u (a burst of reads in front of each
+      // group left the waves queueing on the LDS issue port: SQ_WAIT_INST_LDS 71 M quad-cycles per launch against 4 M in the library GEMM)
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (++cc == cpt) {                                                                 // the tile is complete: write it, start the next one from zero
       const int mt = ct / tiles_n, nt = ct - mt * tiles_n;
@@ -225,6 +238,8 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_tn_f32_kernel(const float*
             for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][j][mi], bf[s][j][ni], acc[mi][ni], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
+      // (the one-read-per-two-MFMAs issue order of gemm_f32_kernel measured 3 % SLOWER here -- 1 432 against 1 387 us on conv2d_7: this kernel's reads
+      // are all 32-bit pairs, twice as many per group -- so the groups stay fenced: reads of group u + 1, then the 16 MFMAs of group u)
     }
     if (c + 1 < nchunks) store(buf ^ 1);
     __syncthreads();
@@ -273,7 +288,7 @@ int dense_f32_big_launch(const float* A, const float* B, const float* bias, floa
   const int per = (tiles_total + slots - 1) / slots;
   const int grid = (tiles_total + per - 1) / per;
   static const int nt_env = getenv("LADDER_GEMM_F32_NT") != nullptr ? atoi(getenv("LADDER_GEMM_F32_NT")) : -1;
-  const bool nt = nt_env >= 0 ? nt_env != 0 : (size_t)M * N * sizeof(float) >= ((size_t)256 << 20);       // products beyond the 256 MB of L2 + MALL stream out
+  const bool nt = nt_env >= 0 ? nt_env != 0 : (size_t)M * N * sizeof(float) >= ((size_t)512 << 20);       // products well beyond the 256 MB of L2 + MALL stream out (conv2d_6: 714 -> 686 us)
   if (bias != nullptr || gate != nullptr || act != LADDER_ACT_NONE)
     hipLaunchKernelGGL((gemm_f32_kernel<true, false>), dim3(grid), dim3(GB_THREADS), 0, stream, A, B, bias, C, gate, (int)M, N, K, act, gate_act, tiles_n, tiles_total);
   else if (nt)

@@ -1,3 +1,4 @@
+# hardware counters of the dense kernels at the projected conv2d_7 shapes (one counter set per pass, kernel trace + pmc only) -> gpurun_out/r05_gemm_pmc.txt
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/pmc_gemm; mkdir -p $R/gpurun_out/pmc_gemm
@@ -8,4 +9,3 @@ for set in "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIV
 done
 cd $R
 python3 profiles/tools/r5_gemm_pmc_probe.py --show $(find gpurun_out/pmc_gemm -name "*.db") > gpurun_out/r05_gemm_pmc.txt 2>&1
-python3 profiles/tools/r5_upproj_probe.py 2>&1 | grep "conv2d_7 fwd combine"

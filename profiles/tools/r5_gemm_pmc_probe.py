@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import r5_pmc_probe as P
-P.KERNELS = ("igemm_fwd_kernel", "igemm_wgrad_kernel", "Cijk", "gemm_f32", "dense_f32")
+P.KERNELS = ("igemm_fwd_kernel", "igemm_wgrad_kernel", "Cijk", "gemm_f32", "gemm_tn_f32")
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--show":
