@@ -35,16 +35,28 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_f32_kernel(const float* __
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int wm = wid >> 1, wn = wid & 1;
   const int cpt = K / GB_K;                                                           // chunks per tile
-  const int t0 = (int)((long)blockIdx.x * tiles_total / gridDim.x), t1 = (int)((long)(blockIdx.x + 1) * tiles_total / gridDim.x);
-  const int nchunks = (t1 - t0) * cpt;
+  // Tile order.  Workgroup b runs on XCD b % 8 (round-robin dispatch), and an A panel (128 rows x K) serves the tiles_n column tiles of its row tile.
+  // Row tile mt belongs to XCD mt % 8; the (row tile, column tile) pairs of an XCD are numbered r = local row tile * tiles_n + column tile and the
+  // XCD's workgroups take r = i, i + W, i + 2W, ... (i = index inside the XCD, W = workgroups per XCD): at any moment the ~64 workgroups of an XCD
+  // are inside 7-8 row tiles, so a panel is fetched into that XCD's L2 once and hit by the others.  (A contiguous range of tiles per workgroup --
+  // the first version -- re-read every panel tiles_n times from beyond L2: 1.00 GB read per launch against 0.36 GB algorithmic,
+  // profiles/r05_f32_pmc_traffic.json of that build.)
+  const int tiles_m = tiles_total / tiles_n;
+  const bool by_xcd = (gridDim.x & 7) == 0;
+  const int xcd = by_xcd ? (int)(blockIdx.x & 7) : 0, wi = by_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, wpx = by_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int xs = by_xcd ? 8 : 1;
+  const int my_rows = (tiles_m - xcd + xs - 1) / xs;                                   // row tiles of this XCD
+  const int nr = my_rows * tiles_n;                                                    // tiles of this XCD
+  const int ntiles = wi < nr ? (nr - wi + wpx - 1) / wpx : 0;
+  const int nchunks = ntiles * cpt;
   if (nchunks <= 0) return;
 
   // loader coordinates: A unit = (row tid / 8 + 32 i, k quad tid % 8), B unit = (k row tid / 32 + 8 i, n quad tid % 32)
   const int a_r = tid >> 3, a_q = tid & 7, b_r = tid >> 5, b_q = tid & 31;
   float4 ra[4], rb[4];
-  int lt = t0, lc = 0;                                                                 // tile / chunk the NEXT load fetches
+  int lt = wi, lc = 0;                                                                 // tile (index r inside the XCD) / chunk the NEXT load fetches
   auto load = [&]() {
-    const int mt = lt / tiles_n, nt = lt - mt * tiles_n;
+    const int mrow = lt / tiles_n, nt = lt - mrow * tiles_n, mt = mrow * xs + xcd;
     const float* ap = A + ((long)mt * GB_M + a_r) * K + lc * GB_K + a_q * 4;
     const float* bp = B + ((long)lc * GB_K + b_r) * N + nt * GB_N + b_q * 4;
 #pragma unroll
@@ -52,7 +64,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_f32_kernel(const float* __
       ra[i] = g_ld4(ap + (long)32 * i * K);
       rb[i] = g_ld4(bp + (long)8 * i * N);
     }
-    if (++lc == cpt) { lc = 0; ++lt; }
+    if (++lc == cpt) { lc = 0; lt += wpx; }
   };
   auto store = [&](int buf) {
 #pragma unroll
@@ -73,7 +85,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_f32_kernel(const float* __
   load();
   store(0);
   __syncthreads();
-  int ct = t0, cc = 0;                                                                 // tile / chunk being multiplied
+  int ct = wi, cc = 0;                                                                 // tile / chunk being multiplied
   const int a_off = (wm * 64 + l31) * GB_LDA + 4 * lh, b_off = (4 * lh) * GB_N + wn * 64 + l31;
   for (int g = 0; g < nchunks; ++g) {
     const int buf = g & 1;
@@ -125,7 +137,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_f32_kernel(const float* __
       __builtin_amdgcn_sched_barrier(0);
     }
     if (++cc == cpt) {                                                                 // the tile is complete: write it, start the next one from zero
-      const int mt = ct / tiles_n, nt = ct - mt * tiles_n;
+      const int mrow = ct / tiles_n, nt = ct - mrow * tiles_n, mt = mrow * xs + xcd;
       const long voff = (long)4 * lh * N + l31;
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_f32_kernel(const float* __
         }
       }
       cc = 0;
-      ++ct;
+      ct += wpx;
     }
     if (g + 1 < nchunks) store(buf ^ 1);
     __syncthreads();
@@ -163,13 +175,21 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_f32_kernel(const float* __
 // in the workgroups of tile row 0, which stream every D row anyway.  Same software pipeline as gemm_f32_kernel.
 __global__ __launch_bounds__(GB_THREADS, 2) void gemm_tn_f32_kernel(const float* __restrict__ X, const float* __restrict__ D, float* __restrict__ part,
                                                                     float* __restrict__ bias_part, const int M, const int Kc, const int N,
-                                                                    const int tiles_n, const int m_per_split) {
+                                                                    const int tiles_n, const int m_per_split, const int splits, const int by_xcd) {
   __shared__ __attribute__((aligned(16))) float At[2][GB_K * GB_M];
   __shared__ __attribute__((aligned(16))) float Bt[2][GB_K * GB_N];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int wm = wid >> 1, wn = wid & 1;
-  const int kt = blockIdx.x / tiles_n, nt = blockIdx.x - kt * tiles_n;
-  const int p0 = blockIdx.y * m_per_split, p1 = min(M, p0 + m_per_split);
+  // 1-D grid, XCD-aware: workgroup b runs on XCD b % 8; the tiles of one pixel range (which all read the same rows of X and D) go to ONE XCD --
+  // split s belongs to XCD s % 8 and the (split, tile) pairs of an XCD are handed out in order, so a range's tiles are dispatched together and
+  // share the rows through that XCD's L2 (tile-major over all XCDs re-read them from beyond L2: 2.06 GB read per launch against 0.9 GB algorithmic)
+  // (by_xcd = 0: tile-major over the whole chip -- tile counts that do not fill an XCD's 64 workgroup slots evenly)
+  const int tiles = (Kc / GB_M) * tiles_n;
+  const int xcd = (int)(blockIdx.x & 7), wi = (int)(blockIdx.x >> 3);
+  const int split = by_xcd ? (wi / tiles) * 8 + xcd : (int)(blockIdx.x / tiles), tile = by_xcd ? wi % tiles : (int)(blockIdx.x % tiles);
+  if (split >= splits) return;
+  const int kt = tile / tiles_n, nt = tile - kt * tiles_n;
+  const int p0 = split * m_per_split, p1 = min(M, p0 + m_per_split);
   const int nchunks = (p1 - p0 + GB_K - 1) / GB_K;
   const int l_r = tid >> 5, l_q = tid & 31;                                            // loader unit i: pixel row l_r + 8 i of the chunk, channel quad l_q
   const float* xp = X + (long)kt * GB_M + l_q * 4;
@@ -244,7 +264,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_tn_f32_kernel(const float*
     if (c + 1 < nchunks) store(buf ^ 1);
     __syncthreads();
   }
-  float* o = part + (size_t)blockIdx.y * Kc * N + ((long)kt * GB_M + wm * 64) * N + nt * GB_N + wn * 64 + (long)4 * lh * N + l31;
+  float* o = part + (size_t)split * Kc * N + ((long)kt * GB_M + wm * 64) * N + nt * GB_N + wn * 64 + (long)4 * lh * N + l31;
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -260,7 +280,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_tn_f32_kernel(const float*
       float sacc = 0.f;
 #pragma unroll
       for (int r = 0; r < GB_K; ++r) sacc += Bt[0][r * GB_N + tid];
-      bias_part[(size_t)blockIdx.y * N + nt * GB_N + tid] = sacc;
+      bias_part[(size_t)split * N + nt * GB_N + tid] = sacc;
     }
   }
 }
@@ -284,9 +304,11 @@ int dense_f32_big_launch(const float* A, const float* B, const float* bias, floa
     slots = e != nullptr ? atoi(e) : 512;                                              // 256 CUs x 2 resident workgroups
     if (slots < 1) slots = 512;
   }
-  // whole tiles per workgroup, as even as the count allows: tiles_total / ceil(tiles_total / slots) workgroups
+  // whole tiles per workgroup, as even as the count allows: tiles_total / ceil(tiles_total / slots) workgroups, a multiple of the 8 XCDs
   const int per = (tiles_total + slots - 1) / slots;
-  const int grid = (tiles_total + per - 1) / per;
+  int grid = (tiles_total + per - 1) / per;
+  if (grid >= 8) grid = (grid + 7) / 8 * 8;
+  if (grid > slots && slots >= 8) grid = slots / 8 * 8;
   static const int nt_env = getenv("LADDER_GEMM_F32_NT") != nullptr ? atoi(getenv("LADDER_GEMM_F32_NT")) : -1;
   const bool nt = nt_env >= 0 ? nt_env != 0 : (size_t)M * N * sizeof(float) >= ((size_t)512 << 20);       // products well beyond the 256 MB of L2 + MALL stream out (conv2d_6: 714 -> 686 us)
   if (bias != nullptr || gate != nullptr || act != LADDER_ACT_NONE)
@@ -305,9 +327,19 @@ bool dense_wgrad_f32_ok(long M, int K, int N) {
   return !off && M >= 8192 && (K % GB_M) == 0 && (N % GB_N) == 0 && M < (1L << 31) && (long)(K / GB_M) * (N / GB_N) <= 512;
 }
 
+// XCD-aware split count: splits = 8 x (tile groups per XCD), one or two full rounds of an XCD's 64 workgroup slots; 0 = no even fit
+static int wgrad_xcd_groups(long tiles) {
+  static const bool off = getenv("LADDER_GEMM_TN_NO_XCD") != nullptr;
+  if (off) return 0;
+  if ((64 / tiles) * tiles >= 58) return (int)(64 / tiles);
+  if ((128 / tiles) * tiles >= 116) return (int)(128 / tiles);
+  return 0;
+}
+
 void dense_wgrad_f32_plan(long M, int K, int N, int* splits, int* m_per_split) {
   const long tiles = (long)(K / GB_M) * (N / GB_N);
-  long s = 512 / tiles;
+  const int g = wgrad_xcd_groups(tiles);
+  long s = g > 0 ? 8L * g : 512 / tiles;
   const long max_s = (M + 1023) / 1024;                                                // at least 1 024 rows per split
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -329,7 +361,10 @@ int dense_wgrad_f32_launch(const float* x, const float* dy, float* part, float* 
   if (!dense_wgrad_f32_ok(M, K, N)) return LADDER_E_SHAPE;
   if (!ladder_aligned16(x) || !ladder_aligned16(dy) || !ladder_aligned16(part)) return LADDER_E_ALIGN;
   const int tiles_n = N / GB_N;
-  hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3((K / GB_M) * tiles_n, splits), dim3(GB_THREADS), 0, stream, x, dy, part, bias_part, (int)M, K, N, tiles_n, m_per_split);
+  const int tiles = (K / GB_M) * tiles_n;
+  const int by_xcd = wgrad_xcd_groups(tiles) > 0 ? 1 : 0;
+  const unsigned grid = by_xcd ? 8u * ((splits + 7) / 8) * tiles : (unsigned)splits * tiles;
+  hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(grid), dim3(GB_THREADS), 0, stream, x, dy, part, bias_part, (int)M, K, N, tiles_n, m_per_split, splits, by_xcd);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

@@ -993,8 +993,10 @@ class Conv2D:
         """_dx_lowres can apply the activation backward of the layer below (its `gate`) in the same launches (strict fp32, 8x32-pixel tiling).
         OFF by default (LADDER_ENABLE_LOWRES_GATE=1 turns it on): measured in round 5, the 64 gate loads per lane in the epilogue of conv2d_6's fused
         backward-data cost 72 us (1 631 -> 1 703 us) -- the 67 us ladder_act_bwd pass they replace (profiles/r05_f32_percall.md was taken with it on)."""
-        if self.x_is_lo and self.proj_ok(N, H, W, self.lo_factor):      # (projected form: the gate rides on the dense kernel's epilogue)
-            return os.environ.get("LADDER_DISABLE_LOWRES_GATE") != "1"
+        if self.x_is_lo and self.proj_ok(N, H, W, self.lo_factor):
+            # (projected form: the gate would ride on the dense kernel's epilogue -- measured 772 against 655 us on conv2d_6's backward-data GEMM, more than
+            # the ~85 us activation pass it replaces: opt-in like the tap-folded form's)
+            return os.environ.get("LADDER_ENABLE_LOWRES_GATE") == "1"
         return bool(self.ctx.ns == 0 and os.environ.get("LADDER_ENABLE_LOWRES_GATE") == "1"
                     and L.query("ladder_conv3x3_up2_bwd_data_gated_f32_eligible", N, H, W, self.cout, self.cin))
 
