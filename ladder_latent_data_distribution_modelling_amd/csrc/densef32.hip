@@ -53,9 +53,12 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_f32_kernel(const float* __
 
   // loader coordinates: A unit = (row tid / 8 + 32 i, k quad tid % 8), B unit = (k row tid / 32 + 8 i, n quad tid % 32)
   const int a_r = tid >> 3, a_q = tid & 7, b_r = tid >> 5, b_q = tid & 31;
-  float4 ra[4], rb[4];
+  // TWO chunks of global loads in flight (register sets 0 / 1): the chunk written to LDS at the end of an iteration was requested one whole iteration
+  // (64 MFMAs = ~2 us) earlier.  With one set the loads of chunk c + 1 were issued at the top of iteration c and awaited at its bottom -- under load an
+  // HBM round trip is longer than the chunk's MFMA block, and both workgroups of a CU stalled on it together (MFMA pipe 0.69-0.82 busy).
+  float4 ra0[4], rb0[4], ra1[4], rb1[4];
   int lt = wi, lc = 0;                                                                 // tile (index r inside the XCD) / chunk the NEXT load fetches
-  auto load = [&]() {
+  auto load = [&](float4 (&ra)[4], float4 (&rb)[4]) {
     const int mrow = lt / tiles_n, nt = lt - mrow * tiles_n, mt = mrow * xs + xcd;
     const float* ap = A + ((long)mt * GB_M + a_r) * K + lc * GB_K + a_q * 4;
     const float* bp = B + ((long)lc * GB_K + b_r) * N + nt * GB_N + b_q * 4;
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_f32_kernel(const float* __
     }
     if (++lc == cpt) { lc = 0; lt += wpx; }
   };
-  auto store = [&](int buf) {
+  auto store = [&](int buf, const float4 (&ra)[4], const float4 (&rb)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       *reinterpret_cast<float4*>(&As[buf][(a_r + 32 * i) * GB_LDA + a_q * 4]) = ra[i];
@@ -82,14 +85,15 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_f32_kernel(const float* __
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-  load();
-  store(0);
+  load(ra0, rb0);
+  store(0, ra0, rb0);
+  if (nchunks > 1) load(ra1, rb1);
   __syncthreads();
   int ct = wi, cc = 0;                                                                 // tile / chunk being multiplied
   const int a_off = (wm * 64 + l31) * GB_LDA + 4 * lh, b_off = (4 * lh) * GB_N + wn * 64 + l31;
-  for (int g = 0; g < nchunks; ++g) {
-    const int buf = g & 1;
-    if (g + 1 < nchunks) load();
+  // one iteration: request chunk g + 2 into the set chunk g came from, multiply chunk g, write chunk g + 1 (requested an iteration ago) to the other buffer
+  auto iteration = [&](const int g, const int buf, float4 (&ra_ld)[4], float4 (&rb_ld)[4], const float4 (&ra_st)[4], const float4 (&rb_st)[4]) {
+    if (g + 2 < nchunks) load(ra_ld, rb_ld);
     {
       // software pipeline over the chunk's four 8-deep groups: the fragments of group u + 1 are requested before the 16 MFMAs of group u are issued
       // (scheduling fences: left alone, the compiler sinks every LDS read to just in front of its first use and the MFMA pipe waits out each round trip)
@@ -163,8 +167,12 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_f32_kernel(const float* __
       cc = 0;
       ct += wpx;
     }
-    if (g + 1 < nchunks) store(buf ^ 1);
+    if (g + 1 < nchunks) store(buf ^ 1, ra_st, rb_st);
     __syncthreads();
+  };
+  for (int g = 0; g < nchunks; g += 2) {
+    iteration(g, 0, ra0, rb0, ra1, rb1);
+    if (g + 1 < nchunks) iteration(g + 1, 1, ra1, rb1, ra0, rb0);
   }
 }
 
@@ -195,10 +203,10 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_tn_f32_kernel(const float*
   const float* xp = X + (long)kt * GB_M + l_q * 4;
   const float* dp = D + (long)nt * GB_N + l_q * 4;
   const bool do_bias = bias_part != nullptr && kt == 0;
-  float4 ra[4], rb[4], bsum[4];
+  float4 ra0[4], rb0[4], ra1[4], rb1[4], bsum[4];                                       // (two chunks of loads in flight, as in gemm_f32_kernel)
 #pragma unroll
   for (int i = 0; i < 4; ++i) bsum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto load = [&](int c) {
+  auto load = [&](int c, float4 (&ra)[4], float4 (&rb)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int p = p0 + c * GB_K + l_r + 8 * i;
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_tn_f32_kernel(const float*
       rb[i] = in ? g_ld4(dp + (long)p * N) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto store = [&](int buf) {
+  auto store = [&](int buf, const float4 (&ra)[4], const float4 (&rb)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       *reinterpret_cast<float4*>(&At[buf][(l_r + 8 * i) * GB_M + l_q * 4]) = ra[i];
@@ -223,14 +231,16 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_tn_f32_kernel(const float*
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
   if (nchunks > 0) {
-    load(0);
-    store(0);
+    load(0, ra0, rb0);
+    store(0, ra0, rb0);
   }
+  if (nchunks > 1) load(1, ra1, rb1);
   __syncthreads();
-  const int a_off = lh * GB_M + wm * 64 + l31, b_off = lh * GB_N + wn * 64 + l31;
-  for (int c = 0; c < nchunks; ++c) {
-    const int buf = c & 1;
-    if (c + 1 < nchunks) load(c + 1);
+  // fragment = ONE 64-bit read per operand and k-step: lane l31 holds channels (2 l31, 2 l31 + 1) of its wave's 64 -- MFMA tile mi / ni takes the even / odd
+  // ones (which 32 of the 64 rows a tile covers is free as long as the store below agrees) -- instead of two 32-bit reads 32 channels apart
+  const int a_off = lh * GB_M + wm * 64 + 2 * l31, b_off = lh * GB_N + wn * 64 + 2 * l31;
+  auto iteration = [&](const int c, const int buf, float4 (&ra_ld)[4], float4 (&rb_ld)[4], const float4 (&ra_st)[4], const float4 (&rb_st)[4]) {
+    if (c + 2 < nchunks) load(c + 2, ra_ld, rb_ld);
     {
       const float* Ab = &At[buf][a_off];
       const float* Bb = &Bt[buf][b_off];
@@ -238,10 +248,9 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_tn_f32_kernel(const float*
       auto frags = [&](int u, int s) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi) af[s][j][mi] = Ab[(8 * u + 2 * j) * GB_M + mi * 32];
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) bf[s][j][ni] = Bb[(8 * u + 2 * j) * GB_N + ni * 32];
+          const float2 a2 = *reinterpret_cast<const float2*>(Ab + (8 * u + 2 * j) * GB_M), b2 = *reinterpret_cast<const float2*>(Bb + (8 * u + 2 * j) * GB_N);
+          af[s][j][0] = a2.x; af[s][j][1] = a2.y;
+          bf[s][j][0] = b2.x; bf[s][j][1] = b2.y;
         }
       };
       frags(0, 0);
@@ -261,16 +270,20 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_tn_f32_kernel(const float*
       // (the one-read-per-two-MFMAs issue order of gemm_f32_kernel measured 3 % SLOWER here -- 1 432 against 1 387 us on conv2d_7: this kernel's reads
       // are all 32-bit pairs, twice as many per group -- so the groups stay fenced: reads of group u + 1, then the 16 MFMAs of group u)
     }
-    if (c + 1 < nchunks) store(buf ^ 1);
+    if (c + 1 < nchunks) store(buf ^ 1, ra_st, rb_st);
     __syncthreads();
+  };
+  for (int c = 0; c < nchunks; c += 2) {
+    iteration(c, 0, ra0, rb0, ra1, rb1);
+    if (c + 1 < nchunks) iteration(c + 1, 1, ra1, rb1, ra0, rb0);
   }
-  float* o = part + (size_t)split * Kc * N + ((long)kt * GB_M + wm * 64) * N + nt * GB_N + wn * 64 + (long)4 * lh * N + l31;
+  // tile (mi, ni) element e of lane (l31, lh): row r = (e & 3) + 8 (e >> 2) + 4 lh of the tile = channel 2 r + mi, column 2 l31 + ni
+  float* o = part + (size_t)split * Kc * N + ((long)kt * GB_M + wm * 64) * N + nt * GB_N + wn * 64 + (long)8 * lh * N + 2 * l31;
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
+  for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[(long)(mi * 32 + (e & 3) + 8 * (e >> 2)) * N + ni * 32] = acc[mi][ni][e];
+    for (int e = 0; e < 16; ++e)
+      *reinterpret_cast<float2*>(o + (long)(2 * ((e & 3) + 8 * (e >> 2)) + mi) * N) = make_float2(acc[mi][0][e], acc[mi][1][e]);
   if (do_bias) {                                                                       // fixed-order sum of the loaders' column sums through LDS
     __syncthreads();
 #pragma unroll
