@@ -53,6 +53,12 @@ int ladder_conv2d_fwd_kernel_id(int N, int H, int W, int Cin, int Ho, int Wo, in
  * ladder_dense_fwd (M x K x N) and ladder_dense_bwd_data (pass its M, N, K: the contraction runs over N), gemm_tn_f32_kernel + the fixed-order
  * split sum for ladder_dense_bwd_weight; M >= 8192, M and the output width multiples of 128, the contraction a multiple of 32 -- 0 = the
  * implicit-GEMM kernels of csrc/igemm.hip. */
+/* The two forward-type dense calls with the weight operand K-CONTIGUOUS (strict fp32, shapes for which ladder_dense_fwd_is_persistent is 1; LADDER_E_SHAPE
+ * otherwise): y [M,N] = act(x [M,K] . wT^T + bias) with wT [N][K], and dx [M,K] = (dy [M,N] . w^T ...) -- i.e. dx = dy . (w [K][N])^T -- times act'(gate_y).
+ * gemm_nt16_f32_kernel (csrc/densef32.hip): v_mfma_f32_16x16x4_f32, both fragments 128-bit LDS reads.  The projected decoder pairs hold both wcat and
+ * wcatT, so they call these: forward with wcatT (orientation 7), backward-data with wcat (orientation 6). */
+int ladder_dense_fwd_nt(const float* x, const float* wT, const float* bias, float* y, int M, int K, int N, int act, ladder_stream_t stream);
+int ladder_dense_bwd_data_nt(const float* dy, const float* w, float* dx, int M, int K, int N, const float* gate_y, int gate_act, ladder_stream_t stream);
 int ladder_dense_fwd_is_persistent(long M, int K, int N);
 int ladder_dense_bwd_weight_is_persistent(long M, int K, int N);
 

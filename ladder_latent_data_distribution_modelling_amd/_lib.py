@@ -41,6 +41,8 @@ PROTOTYPES = {
     "ladder_abi_version": (_i, []),
     "ladder_igemm_fwd_tile": (_i, [C.c_long, _i, _i]),
     "ladder_dense_fwd_is_persistent": (_i, [C.c_long, _i, _i]),
+    "ladder_dense_fwd_nt": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "ladder_dense_bwd_data_nt": (_i, [_p, _p, _p, _i, _i, _i, _p, _i, _p]),
     "ladder_dense_bwd_weight_is_persistent": (_i, [C.c_long, _i, _i]),
     "ladder_igemm_fwd_splits": (_i, [C.c_long, _i, _i]),
     "ladder_conv2d_fwd_kernel_id": (_i, [_i] * 13),

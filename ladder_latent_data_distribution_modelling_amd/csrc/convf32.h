@@ -35,6 +35,9 @@ int conv3x3_f32_launch(const float* x, const float* bank, const float* bias, flo
 bool dense_f32_big_ok(long M, int K, int N);
 int dense_f32_big_launch(const float* A, const float* B, const float* bias, float* C, const float* gate, int gate_act, long M, int K, int N, int act,
                          hipStream_t stream);
+// the same product with the second operand K-contiguous, Bt [N][K] (v_mfma_f32_16x16x4_f32 kernel)
+int dense_f32_nt_launch(const float* A, const float* Bt, const float* bias, float* C, const float* gate, int gate_act, long M, int K, int N, int act,
+                        hipStream_t stream);
 // ... and the filter-gradient form dW [K][N] = x^T dy over M rows: partial tiles [splits][K][N] (+ partial column sums of dy [splits][N]) for a
 // fixed-order second stage
 bool dense_wgrad_f32_ok(long M, int K, int N);

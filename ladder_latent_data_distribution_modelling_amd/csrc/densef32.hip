@@ -176,6 +176,149 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_f32_kernel(const float* __
   }
 }
 
+// ---- the same product on v_mfma_f32_16x16x4_f32, both operands K-contiguous ("NT"): C [M][N] = A [M][K] . Bt [N][K]^T ---------------------------------
+// Why a second kernel: un-profiled, gemm_f32_kernel sits at ~0.98 of the MFMA rate the chip sustains AT THE CLOCK IT RUNS (1.92-1.98 GHz under this kernel,
+// profiles/r05_gemm_pmc.txt) -- the limit is power, and the library GEMM runs the same shapes at 2.05-2.19 GHz.  Per flop the 16x16x4 instruction moves half
+// the accumulator registers of 32x32x2 (4 of them per 2 048 flop against 16 per 4 096), and with Bt given K-contiguous (the projected pairs hold both
+// wcat and wcatT) BOTH fragments are one 128-bit LDS read per four k-steps: 16 reads per 32-deep chunk instead of 24.  The roles are swapped in the
+// instruction (a = Bt rows, b = A rows) so that a lane ends up with four CONSECUTIVE output columns: the epilogue is 16 float4 stores per wave tile.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool EPI, bool NT>
+__global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt16_f32_kernel(const float* __restrict__ A, const float* __restrict__ Bt, const float* __restrict__ bias,
+                                                                      float* __restrict__ C, const float* __restrict__ gate, const int M, const int N,
+                                                                      const int K, const int act, const int gate_act, const int tiles_n,
+                                                                      const int tiles_total) {
+  __shared__ __attribute__((aligned(16))) float As[2][GB_M * GB_LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][GB_N * GB_LDA];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, kq = lane >> 4;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int cpt = K / GB_K;
+  const int tiles_m = tiles_total / tiles_n;
+  const bool by_xcd = (gridDim.x & 7) == 0;                                            // (tile order: see gemm_f32_kernel)
+  const int xcd = by_xcd ? (int)(blockIdx.x & 7) : 0, wi = by_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, wpx = by_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int xs = by_xcd ? 8 : 1;
+  const int my_rows = (tiles_m - xcd + xs - 1) / xs;
+  const int nr = my_rows * tiles_n;
+  const int ntiles = wi < nr ? (nr - wi + wpx - 1) / wpx : 0;
+  const int nchunks = ntiles * cpt;
+  if (nchunks <= 0) return;
+
+  const int a_r = tid >> 3, a_q = tid & 7;                                             // loader unit i of either operand: row a_r + 32 i, k quad a_q
+  float4 ra0[4], rb0[4], ra1[4], rb1[4];
+  int lt = wi, lc = 0;
+  auto load = [&](float4 (&ra)[4], float4 (&rb)[4]) {
+    const int mrow = lt / tiles_n, nt = lt - mrow * tiles_n, mt = mrow * xs + xcd;
+    const float* ap = A + ((long)mt * GB_M + a_r) * K + lc * GB_K + a_q * 4;
+    const float* bp = Bt + ((long)nt * GB_N + a_r) * K + lc * GB_K + a_q * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = g_ld4(ap + (long)32 * i * K);
+      rb[i] = g_ld4(bp + (long)32 * i * K);
+    }
+    if (++lc == cpt) { lc = 0; lt += wpx; }
+  };
+  auto store = [&](int buf, const float4 (&ra)[4], const float4 (&rb)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<float4*>(&As[buf][(a_r + 32 * i) * GB_LDA + a_q * 4]) = ra[i];
+      *reinterpret_cast<float4*>(&Bs[buf][(a_r + 32 * i) * GB_LDA + a_q * 4]) = rb[i];
+    }
+  };
+  f32x4 acc[4][4];                                                                     // [ni][mi]: rows of the instruction = 16 output columns, its columns = 16 output rows
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[ni][mi][e] = 0.f;
+
+  load(ra0, rb0);
+  store(0, ra0, rb0);
+  if (nchunks > 1) load(ra1, rb1);
+  __syncthreads();
+  int ct = wi, cc = 0;
+  const int a_off = (wm * 64 + r16) * GB_LDA + 4 * kq, b_off = (wn * 64 + r16) * GB_LDA + 4 * kq;
+  auto iteration = [&](const int g, const int buf, float4 (&ra_ld)[4], float4 (&rb_ld)[4], const float4 (&ra_st)[4], const float4 (&rb_st)[4]) {
+    if (g + 2 < nchunks) load(ra_ld, rb_ld);
+    {
+      const float* Ab = &As[buf][a_off];
+      const float* Bb = &Bs[buf][b_off];
+      float4 fa[2][4], fb[2][4];
+      auto frags = [&](int u, int s) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          fa[s][t] = *reinterpret_cast<const float4*>(Ab + t * 16 * GB_LDA + 16 * u);
+          fb[s][t] = *reinterpret_cast<const float4*>(Bb + t * 16 * GB_LDA + 16 * u);
+        }
+      };
+      __builtin_amdgcn_sched_barrier(0);
+      frags(0, 0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u == 0) frags(1, 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            const float b = j == 0 ? fb[u][ni].x : (j == 1 ? fb[u][ni].y : (j == 2 ? fb[u][ni].z : fb[u][ni].w));
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+              const float a = j == 0 ? fa[u][mi].x : (j == 1 ? fa[u][mi].y : (j == 2 ? fa[u][mi].z : fa[u][mi].w));
+              acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc[ni][mi], 0, 0, 0);
+            }
+          }
+      }
+      // issue order: the first group's eight reads, then one read of the second group per eight MFMAs of the first, then the second group's MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 64, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (++cc == cpt) {
+      const int mrow = ct / tiles_n, nt = ct - mrow * tiles_n, mt = mrow * xs + xcd;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int n = nt * GB_N + wn * 64 + ni * 16 + 4 * kq;
+        const float4 bv = (EPI && bias != nullptr) ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const long o = ((long)mt * GB_M + wm * 64 + mi * 16 + r16) * N + n;
+          float4 v = make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
+          if (EPI) {
+            v = make_float4(ladder_act_fn(v.x + bv.x, act), ladder_act_fn(v.y + bv.y, act), ladder_act_fn(v.z + bv.z, act), ladder_act_fn(v.w + bv.w, act));
+            if (gate != nullptr) {
+              const float4 gv = *reinterpret_cast<const float4*>(gate + o);
+              v.x *= ladder_act_grad_from_out(gv.x, gate_act); v.y *= ladder_act_grad_from_out(gv.y, gate_act);
+              v.z *= ladder_act_grad_from_out(gv.z, gate_act); v.w *= ladder_act_grad_from_out(gv.w, gate_act);
+            }
+          }
+          if (NT) {
+            __builtin_nontemporal_store(v.x, &C[o]); __builtin_nontemporal_store(v.y, &C[o + 1]);
+            __builtin_nontemporal_store(v.z, &C[o + 2]); __builtin_nontemporal_store(v.w, &C[o + 3]);
+          } else {
+            *reinterpret_cast<float4*>(C + o) = v;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[ni][mi][e] = 0.f;
+        }
+      }
+      cc = 0;
+      ct += wpx;
+    }
+    if (g + 1 < nchunks) store(buf ^ 1, ra_st, rb_st);
+    __syncthreads();
+  };
+  for (int g = 0; g < nchunks; g += 2) {
+    iteration(g, 0, ra0, rb0, ra1, rb1);
+    if (g + 1 < nchunks) iteration(g + 1, 1, ra1, rb1, ra0, rb0);
+  }
+}
+
 // Filter gradient of the projected pairs: dWcat [Kc][N] = X^T D, X [M][Kc] (the low-resolution layer input), D [M][N] (the nine gradient planes); the
 // reduction runs over the M pixels, so both operands sit in LDS pixel-major exactly as they lie in memory ([32 pixels][128 channels], 512-byte rows:
 // conflict-free 32-bit fragment reads, lane = channel) and a (128 x 128 tile, pixel range) pair is one workgroup.  Partial tiles [split][Kc][N] are
@@ -330,6 +473,31 @@ int dense_f32_big_launch(const float* A, const float* B, const float* bias, floa
     hipLaunchKernelGGL((gemm_f32_kernel<false, true>), dim3(grid), dim3(GB_THREADS), 0, stream, A, B, bias, C, gate, (int)M, N, K, act, gate_act, tiles_n, tiles_total);
   else
     hipLaunchKernelGGL((gemm_f32_kernel<false, false>), dim3(grid), dim3(GB_THREADS), 0, stream, A, B, bias, C, gate, (int)M, N, K, act, gate_act, tiles_n, tiles_total);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+// NT form: Bt [N][K]
+int dense_f32_nt_launch(const float* A, const float* Bt, const float* bias, float* C, const float* gate, int gate_act, long M, int K, int N, int act,
+                        hipStream_t stream) {
+  if (!dense_f32_big_ok(M, K, N)) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(A) || !ladder_aligned16(Bt) || !ladder_aligned16(C) || (bias != nullptr && !ladder_aligned16(bias)) ||
+      (gate != nullptr && !ladder_aligned16(gate)))
+    return LADDER_E_ALIGN;
+  const int tiles_n = N / GB_N, tiles_total = (int)(M / GB_M) * tiles_n;
+  const int slots = 512;
+  const int per = (tiles_total + slots - 1) / slots;
+  int grid = (tiles_total + per - 1) / per;
+  if (grid >= 8) grid = (grid + 7) / 8 * 8;
+  if (grid > slots) grid = slots;
+  static const int nt_env = getenv("LADDER_GEMM_F32_NT") != nullptr ? atoi(getenv("LADDER_GEMM_F32_NT")) : -1;
+  const bool nt = nt_env >= 0 ? nt_env != 0 : (size_t)M * N * sizeof(float) >= ((size_t)512 << 20);
+  if (bias != nullptr || gate != nullptr || act != LADDER_ACT_NONE)
+    hipLaunchKernelGGL((gemm_nt16_f32_kernel<true, false>), dim3(grid), dim3(GB_THREADS), 0, stream, A, Bt, bias, C, gate, (int)M, N, K, act, gate_act, tiles_n, tiles_total);
+  else if (nt)
+    hipLaunchKernelGGL((gemm_nt16_f32_kernel<false, true>), dim3(grid), dim3(GB_THREADS), 0, stream, A, Bt, bias, C, gate, (int)M, N, K, act, gate_act, tiles_n, tiles_total);
+  else
+    hipLaunchKernelGGL((gemm_nt16_f32_kernel<false, false>), dim3(grid), dim3(GB_THREADS), 0, stream, A, Bt, bias, C, gate, (int)M, N, K, act, gate_act, tiles_n, tiles_total);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

@@ -2440,6 +2440,14 @@ int ladder_dense_fwd(const float* x, const float* w, const float* bias, float* y
   return dispatch_fwd(x, w, bias, y, d, ws, ws_bytes, stream);
 }
 
+int ladder_dense_fwd_nt(const float* x, const float* wT, const float* bias, float* y, int M, int K, int N, int act, ladder_stream_t stream) {
+  return dense_f32_nt_launch(x, wT, bias, y, nullptr, 0, M, K, N, act, stream);                    // (csrc/densef32.hip; LADDER_E_SHAPE when not eligible)
+}
+
+int ladder_dense_bwd_data_nt(const float* dy, const float* w, float* dx, int M, int K, int N, const float* gate_y, int gate_act, ladder_stream_t stream) {
+  return dense_f32_nt_launch(dy, w, nullptr, dx, gate_y, gate_act, M, N, K, LADDER_ACT_NONE, stream);
+}
+
 int ladder_dense_bwd_data(const float* dy, const float* wT, float* dx, int M, int K, int N, const float* gate_y, int gate_act,
                           void* ws, size_t ws_bytes, ladder_stream_t stream) {
   if (dense_f32_big_ok(M, N, K)) return dense_f32_big_launch(dy, wT, nullptr, dx, gate_y, gate_act, M, N, K, LADDER_ACT_NONE, stream);

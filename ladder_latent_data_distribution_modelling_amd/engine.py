@@ -47,8 +47,10 @@ class KernelProfiler:
              9130: "igemm_wgrad_kernel<128,128> + its fixed-order split reduction (dWcat [Cin][9 Cout] = x^T D of the project-then-upsample pairs, fp32 MFMA 32x32x2)",
              9132: "gemm_tn_f32_kernel + its fixed-order split reduction (dWcat [Cin][9 Cout] = x^T D of the project-then-upsample pairs: 128x128 tile x pixel range "
                    "per workgroup, 32-pixel chunks, software-pipelined LDS fragments, fp32 MFMA 32x32x2)",
-             128132: "gemm_f32_kernel (projection GEMMs of the project-then-upsample pairs, Z = x . wcat and dx = D . wcatT: persistent workgroups over 128x128 "
-                     "tiles, 32-deep chunks, 128-bit A fragments, software-pipelined LDS reads, fp32 MFMA 32x32x2)",
+             128132: "gemm_f32_kernel (projection GEMMs of the project-then-upsample pairs, Z = x . wcat: persistent workgroups over 128x128 "
+                     "tiles, XCD-aware tile order, 32-deep chunks, 128-bit A fragments, software-pipelined LDS reads, fp32 MFMA 32x32x2)",
+             128134: "gemm_nt16_f32_kernel (backward-data GEMMs of the project-then-upsample pairs, dx = D . wcat^T with both operands K-contiguous: persistent "
+                     "workgroups over 128x128 tiles, 128-bit fragments of both operands, fp32 MFMA 16x16x4)",
              7700: "gmm_logprob_kernel<R> + gmm_sum_kernel (mixture log-prob / responsibilities, lane = component, wave-shuffle logsumexp)"}
     LATENCY_BOUND = (7700,)          # not contraction kernels: reported beside the roofline, never as the dominant MFMA kernel
 
@@ -831,8 +833,14 @@ class Conv2D:
             wsp, wsn = ctx.ws(L.query("ladder_igemm_fwd_workspace_bytes", M, n9, self.cin))
             gy, gact = gate if gate is not None else (None, None)
             # (ladder_dense_bwd_data: dx [M, K] = dy [M, N] . wT [N, K], optionally times act'(gate) -- here dy := D, wT := wcatT)
-            _timed(128132 if L.query("ladder_dense_fwd_is_persistent", M, n9, self.cin) else 128128, flops, "ladder_dense_bwd_data",
-                   (_p(d), _p(self._packed_filter(7)), _p(dx), M, self.cin, n9, _p(gy), L.ACT[gact] if gact else 0, wsp, wsn, st), executed)
+            if L.query("ladder_dense_fwd_is_persistent", M, n9, self.cin):
+                # K-contiguous weight operand = wcat itself (orientation 6): gemm_nt16_f32_kernel (v_mfma_f32_16x16x4_f32; 3-5 % ahead of the 32x32x2 kernel
+                # on this long-K shape: conv2d_7 1 202 against 1 266 us, profiles/r05_gemm_library_probe.txt)
+                _timed(128134, flops, "ladder_dense_bwd_data_nt",
+                       (_p(d), _p(self._packed_filter(6)), _p(dx), M, self.cin, n9, _p(gy), L.ACT[gact] if gact else 0, st), executed)
+            else:
+                _timed(128128, flops, "ladder_dense_bwd_data",
+                       (_p(d), _p(self._packed_filter(7)), _p(dx), M, self.cin, n9, _p(gy), L.ACT[gact] if gact else 0, wsp, wsn, st), executed)
         self.x = self.y = None
         return dx
 

@@ -24,8 +24,10 @@ for (name, H, Cin, Cout) in (("conv2d_7", 64, 128, 128), ("conv2d_6", 32, 256, 1
     fl = 2.0 * M * Cin * N9
     t = timeit(lambda: torch.mm(x, w, out=z)); print("%s fwd   [%d,%d]x[%d,%d]  %8.1f us %6.1f TF" % (name, M, Cin, Cin, N9, t, fl / t * 1e-6))
     t = timeit(lambda: L.call("ladder_dense_fwd", p(x), p(w), None, p(z), M, Cin, N9, 0, p(ws), ws.numel(), st)); print("%s fwd   in-tree kernel, same process    %8.1f us %6.1f TF" % (name, t, fl / t * 1e-6))
+    t = timeit(lambda: L.call("ladder_dense_fwd_nt", p(x), p(wT), None, p(z), M, Cin, N9, 0, st)); print("%s fwd   in-tree 16x16x4 NT kernel, same process %8.1f us %6.1f TF" % (name, t, fl / t * 1e-6))
     t = timeit(lambda: torch.mm(z, wT, out=dx)); print("%s bwd   [%d,%d]x[%d,%d]  %8.1f us %6.1f TF" % (name, M, N9, N9, Cin, t, fl / t * 1e-6))
     t = timeit(lambda: L.call("ladder_dense_fwd", p(z), p(wT), None, p(dx), M, N9, Cin, 0, p(ws), ws.numel(), st)); print("%s bwd   in-tree kernel, same process    %8.1f us %6.1f TF" % (name, t, fl / t * 1e-6))
+    t = timeit(lambda: L.call("ladder_dense_fwd_nt", p(z), p(w), None, p(dx), M, N9, Cin, 0, st)); print("%s bwd   in-tree 16x16x4 NT kernel, same process %8.1f us %6.1f TF" % (name, t, fl / t * 1e-6))
     t = timeit(lambda: torch.mm(x.t(), z, out=dw)); print("%s wgrad [%d,%d]^T x[%d,%d] %8.1f us %6.1f TF" % (name, M, Cin, M, N9, t, fl / t * 1e-6))
     del x, w, z, wT, dx, dw
     torch.cuda.empty_cache()

@@ -403,7 +403,9 @@ def test_f32_engine_routes_through_the_fused_kernels_and_agrees_with_the_direct_
     for cs in (tc4, ec4):
         assert cs.count("ladder_up2proj_fwd_combine") == 1 and cs.count("ladder_upfproj_fwd_combine") == 5      # conv2d_7 + RGB projection; conv2d_1, 3, 4, 5, 6
     assert tc4.count("ladder_upfproj_bwd_combine") == 6 and tc4.count("ladder_up2proj_wgrad_unpack") == 6
-    assert tc4.count("ladder_dense_bwd_weight") == 6 and tc4.count("ladder_dense_bwd_data") == 6 and "ladder_dense_bwd_weight" not in tc3
+    # (backward-data: the K-contiguous 16x16x4 kernel where M >= 8192 -- conv2d_4 ... conv2d_7 -- the implicit-GEMM kernel on the 1x1 and 2x2 maps)
+    assert tc4.count("ladder_dense_bwd_weight") == 6 and tc4.count("ladder_dense_bwd_data_nt") == 4 and tc4.count("ladder_dense_bwd_data") == 2
+    assert "ladder_dense_bwd_weight" not in tc3
     for k in ("elbo", "l1_reconstruction_error", "l2_reconstruction_error", "loss_ae", "sigma", "mean_pixel_error"):
         assert abs(f4[k] - f0[k]) <= 2e-6 * abs(f0[k]) + 1e-7, (k, f4[k], f0[k])
     for k in e0:

@@ -232,6 +232,17 @@ def test_persistent_dense_kernel_vs_float64(gpu_ctx, shape):
     dx = torch.full((M, N), float("nan"), device="cuda")
     L.call("ladder_dense_bwd_data", p(ad), p(bd), p(dx), M, N, K, p(dev(gate)), 1, p(ws), ws.numel(), st)
     close(dx, ref * np.where(gate > 0, 1.0, 0.2), TOL32, "backward-data (gated)")
+    # the K-contiguous forms (gemm_nt16_f32_kernel, v_mfma_f32_16x16x4_f32): the weight operand transposed, same results to rounding
+    bt = dev(np.ascontiguousarray(b.T))
+    y2 = torch.full((M, N), float("nan"), device="cuda")
+    L.call("ladder_dense_fwd_nt", p(ad), p(bt), p(dev(bias)), p(y2), M, K, N, 1, st)
+    close(y2, np.where(r1 > 0, r1, 0.2 * r1), TOL32, "forward, K-contiguous weights")
+    dx2 = torch.full((M, N), float("nan"), device="cuda")
+    L.call("ladder_dense_bwd_data_nt", p(ad), p(bt), p(dx2), M, N, K, p(dev(gate)), 1, st)
+    close(dx2, ref * np.where(gate > 0, 1.0, 0.2), TOL32, "backward-data, K-contiguous weights (gated)")
+    y3 = torch.full((M, N), float("nan"), device="cuda")
+    L.call("ladder_dense_fwd_nt", p(ad), p(bt), None, p(y3), M, K, N, 0, st)
+    close(y3, ref, TOL32, "plain product, K-contiguous weights")
 
 
 @pytest.mark.parametrize("shape", [(16480, 128, 256), (8192, 256, 1152), (65536, 128, 1152), (8200, 512, 128)], ids=lambda s: "x".join(map(str, s)))
