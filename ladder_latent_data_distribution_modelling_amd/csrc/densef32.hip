@@ -16,6 +16,7 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -182,8 +183,6 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_f32_kernel(const float* __
 // the accumulator registers of 32x32x2 (4 of them per 2 048 flop against 16 per 4 096), and with Bt given K-contiguous (the projected pairs hold both
 // wcat and wcatT) BOTH fragments are one 128-bit LDS read per four k-steps: 16 reads per 32-deep chunk instead of 24.  The roles are swapped in the
 // instruction (a = Bt rows, b = A rows) so that a lane ends up with four CONSECUTIVE output columns: the epilogue is 16 float4 stores per wave tile.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 template <bool EPI, bool NT>
 __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt16_f32_kernel(const float* __restrict__ A, const float* __restrict__ Bt, const float* __restrict__ bias,
                                                                       float* __restrict__ C, const float* __restrict__ gate, const int M, const int N,
@@ -298,8 +297,9 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt16_f32_kernel(const floa
             }
           }
           if (NT) {
-            __builtin_nontemporal_store(v.x, &C[o]); __builtin_nontemporal_store(v.y, &C[o + 1]);
-            __builtin_nontemporal_store(v.z, &C[o + 2]); __builtin_nontemporal_store(v.w, &C[o + 3]);
+            f32x4 v4;
+            v4[0] = v.x; v4[1] = v.y; v4[2] = v.z; v4[3] = v.w;
+            __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(C + o));
           } else {
             *reinterpret_cast<float4*>(C + o) = v;
           }
@@ -366,52 +366,58 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_tn_f32_kernel(const float*
       if (do_bias) { bsum[i].x += rb[i].x; bsum[i].y += rb[i].y; bsum[i].z += rb[i].z; bsum[i].w += rb[i].w; }
     }
   };
-  f32x16 acc[2][2];
+  f32x4 acc[4][4];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+      for (int e = 0; e < 4; ++e) acc[mi][ni][e] = 0.f;
   if (nchunks > 0) {
     load(0, ra0, rb0);
     store(0, ra0, rb0);
   }
   if (nchunks > 1) load(1, ra1, rb1);
   __syncthreads();
-  // fragment = ONE 64-bit read per operand and k-step: lane l31 holds channels (2 l31, 2 l31 + 1) of its wave's 64 -- MFMA tile mi / ni takes the even / odd
-  // ones (which 32 of the 64 rows a tile covers is free as long as the store below agrees) -- instead of two 32-bit reads 32 channels apart
-  const int a_off = lh * GB_M + wm * 64 + 2 * l31, b_off = lh * GB_N + wn * 64 + 2 * l31;
+  // v_mfma_f32_16x16x4_f32, fragment = ONE 128-bit read per operand and k-step (4 pixels): lane (r16, kq) reads pixel 4 s + kq, channels 4 r16 .. 4 r16 + 3 of
+  // its wave's 64 -- channel 4 r16 + t belongs to MFMA tile t (which 16 of the 64 rows a tile covers is free as long as the store below agrees)
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int a_off = kq * GB_M + wm * 64 + 4 * r16, b_off = kq * GB_N + wn * 64 + 4 * r16;
   auto iteration = [&](const int c, const int buf, float4 (&ra_ld)[4], float4 (&rb_ld)[4], const float4 (&ra_st)[4], const float4 (&rb_st)[4]) {
     if (c + 2 < nchunks) load(c + 2, ra_ld, rb_ld);
     {
       const float* Ab = &At[buf][a_off];
       const float* Bb = &Bt[buf][b_off];
-      float af[2][4][2], bf[2][4][2];
-      auto frags = [&](int u, int s) {
+      float4 fa[2], fb[2];
+      __builtin_amdgcn_sched_barrier(0);
+      fa[0] = *reinterpret_cast<const float4*>(Ab);
+      fb[0] = *reinterpret_cast<const float4*>(Bb);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float2 a2 = *reinterpret_cast<const float2*>(Ab + (8 * u + 2 * j) * GB_M), b2 = *reinterpret_cast<const float2*>(Bb + (8 * u + 2 * j) * GB_N);
-          af[s][j][0] = a2.x; af[s][j][1] = a2.y;
-          bf[s][j][0] = b2.x; bf[s][j][1] = b2.y;
+      for (int ks = 0; ks < 8; ++ks) {
+        const int s = ks & 1;
+        if (ks + 1 < 8) {
+          fa[s ^ 1] = *reinterpret_cast<const float4*>(Ab + 4 * (ks + 1) * GB_M);
+          fb[s ^ 1] = *reinterpret_cast<const float4*>(Bb + 4 * (ks + 1) * GB_N);
         }
-      };
-      frags(0, 0);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int s = u & 1;
-        if (u + 1 < 4) frags(u + 1, s ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int mi = 0; mi < 4; ++mi) {
+          const float a = mi == 0 ? fa[s].x : (mi == 1 ? fa[s].y : (mi == 2 ? fa[s].z : fa[s].w));
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][j][mi], bf[s][j][ni], acc[mi][ni], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int ni = 0; ni < 4; ++ni) {
+            const float b = ni == 0 ? fb[s].x : (ni == 1 ? fb[s].y : (ni == 2 ? fb[s].z : fb[s].w));
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[mi][ni], 0, 0, 0);
+          }
+        }
       }
-      // (the one-read-per-two-MFMAs issue order of gemm_f32_kernel measured 3 % SLOWER here -- 1 432 against 1 387 us on conv2d_7: this kernel's reads
-      // are all 32-bit pairs, twice as many per group -- so the groups stay fenced: reads of group u + 1, then the 16 MFMAs of group u)
+      // issue order: the first step's two reads; then the next step's two reads ahead of each step's 16 MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+      for (int ks = 0; ks < 7; ++ks) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (c + 1 < nchunks) store(buf ^ 1, ra_st, rb_st);
     __syncthreads();
@@ -420,13 +426,13 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_tn_f32_kernel(const float*
     iteration(c, 0, ra0, rb0, ra1, rb1);
     if (c + 1 < nchunks) iteration(c + 1, 1, ra1, rb1, ra0, rb0);
   }
-  // tile (mi, ni) element e of lane (l31, lh): row r = (e & 3) + 8 (e >> 2) + 4 lh of the tile = channel 2 r + mi, column 2 l31 + ni
-  float* o = part + (size_t)split * Kc * N + ((long)kt * GB_M + wm * 64) * N + nt * GB_N + wn * 64 + (long)8 * lh * N + 2 * l31;
+  // tile (mi, ni), register e of lane (c16 = r16, kq): tile row 4 kq + e = channel 4 (4 kq + e) + mi, tile column c16 = output column 4 c16 + ni
+  float* o = part + (size_t)split * Kc * N + ((long)kt * GB_M + wm * 64) * N + nt * GB_N + wn * 64 + 4 * r16;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int e = 0; e < 16; ++e)
-      *reinterpret_cast<float2*>(o + (long)(2 * ((e & 3) + 8 * (e >> 2)) + mi) * N) = make_float2(acc[mi][0][e], acc[mi][1][e]);
+    for (int e = 0; e < 4; ++e)
+      *reinterpret_cast<float4*>(o + (long)(4 * (4 * kq + e) + mi) * N) = make_float4(acc[mi][0][e], acc[mi][1][e], acc[mi][2][e], acc[mi][3][e]);
   if (do_bias) {                                                                       // fixed-order sum of the loaders' column sums through LDS
     __syncthreads();
 #pragma unroll
