@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import r5_pmc_probe as P
-P.KERNELS = ("igemm_fwd_kernel", "igemm_wgrad_kernel", "Cijk", "gemm_f32", "gemm_tn_f32")
+P.KERNELS = ("igemm_fwd_kernel", "igemm_wgrad_kernel", "Cijk", "gemm_f32", "gemm_tn_f32", "gemm_nt16_f32")
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--show":
@@ -26,7 +26,7 @@ def main():
     lib = os.environ.get("PROBE_LIBRARY", "1") == "1"
     for _ in range(3):
         L.call("ladder_dense_fwd", p(x), p(w), None, p(z), M, K, N9, 0, p(w1), w1.numel(), st)
-        L.call("ladder_dense_fwd", p(z), p(wT), None, p(dx), M, N9, K, 0, p(w2), w2.numel(), st)
+        L.call("ladder_dense_fwd_nt", p(z), p(w), None, p(dx), M, N9, K, 0, st)            # the backward-data GEMM as the engine issues it (16x16x4 kernel)
         L.call("ladder_dense_bwd_weight", p(x), p(z), p(dw), p(db), M, K, N9, p(w3), w3.numel(), st)
         if lib:
             torch.mm(x, w, out=z); torch.mm(z, wT, out=dx)

@@ -49,10 +49,10 @@ def show(paths):
             cyc = m["GRBM_GUI_ACTIVE"] / 8
             print("  -> effective clock %.2f GHz (GRBM_GUI_ACTIVE / 8 XCDs / duration)" % (cyc / us / 1e3))
             if m.get("SQ_INSTS_MFMA"):
-                tf = m["SQ_INSTS_MFMA"] * 4096 / us / 1e6
+                tf = m["SQ_INSTS_MFMA"] * (2048 if ("nt16" in key[0] or "gemm_tn" in key[0] or "MI16x16" in key[0]) else 4096) / us / 1e6
                 print("  -> MFMA pipe busy %.3f of the elapsed SIMD cycles (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x %.4g cycles)); %.0f busy cycles per MFMA"
                       % (m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc), cyc, m["SQ_VALU_MFMA_BUSY_CYCLES"] / m["SQ_INSTS_MFMA"]))
-                print("  -> executed fp32 MFMA rate %.1f TFLOP/s (SQ_INSTS_MFMA x 4096 flop / duration) = %.3f of %.1f" % (tf, tf / PEAK_TF, PEAK_TF))
+                print("  -> executed fp32 MFMA rate %.1f TFLOP/s (SQ_INSTS_MFMA x 4096 flop -- 2048 for the 16x16x4 kernels -- / duration) = %.3f of %.1f" % (tf, tf / PEAK_TF, PEAK_TF))
         if "SQ_WAVE_CYCLES" in m and "SQ_INSTS_VALU" in m:
             waves = key[1] / 64
             print("  -> per wave-cycle: issuing %.3f, waiting on anything %.3f, waiting to issue %.3f; VALU / LDS / MFMA instructions per wave = "
