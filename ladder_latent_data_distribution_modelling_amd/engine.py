@@ -33,6 +33,7 @@ class KernelProfiler:
              256122: "conv3x3_halo_split16_kernel / conv3x3_halo_split_kernel<bf16x3> (16x32 px x 128 ch LDS-halo tile, 16 waves -- 8x32, 8 waves below 512 tiles; fp32 operands as 2 bf16 planes, 3 x MFMA 32x32x16 bf16)",
              256124: "conv3x3_halo_split16_kernel / conv3x3_halo_split_kernel<f16x3> (16x32 px x 128 ch LDS-halo tile, 16 waves -- 8x32, 8 waves below 512 tiles; fp32 operands as 2 scaled fp16 planes, 3 x MFMA 32x32x16 f16)",
              128128: "igemm_fwd_kernel<128,128,2,2,true,true> (gather implicit GEMM, fp32 MFMA 32x32x2)",
+             64064: "igemm_fwd_kernel<64,64,2,2,true,true> (implicit GEMM, 64x64 tile, fp32 MFMA 32x32x2; here: the 128- / 512-row GEMMs of the projected pairs conv2d_1 / conv2d_3)",
              128124: "igemm_fwd_split_kernel<f16x3> (gather implicit GEMM, 128x128 tile, 3 x MFMA 32x32x16 f16)",
              128122: "igemm_fwd_split_kernel<bf16x3>", 128123: "igemm_fwd_split_kernel<bf16x6>",
              9003: "conv_smallcin_kernel (direct 1x1 from 3 channels, HBM-bound)",
@@ -785,7 +786,7 @@ class Conv2D:
         ctx.up2_skipped[ukey] = 1.0 - 1.0 / (f * f)
         z = ctx.empty(M, n9)
         wsp, wsn = ctx.ws(L.query("ladder_igemm_fwd_workspace_bytes", M, self.cin, n9))
-        _timed(128132 if L.query("ladder_dense_fwd_is_persistent", M, self.cin, n9) else 128128, flops, "ladder_dense_fwd",
+        _timed(128132 if L.query("ladder_dense_fwd_is_persistent", M, self.cin, n9) else abs(L.query("ladder_igemm_fwd_tile", M, self.cin, n9)), flops, "ladder_dense_fwd",
                (_p(x), _p(self._packed_filter(6)), None, _p(z), M, self.cin, n9, 0, wsp, wsn, st), executed)
         bias = self.ps.w[self.name + "/bias"]
         if proj is not None:
@@ -839,7 +840,7 @@ class Conv2D:
                 _timed(128134, flops, "ladder_dense_bwd_data_nt",
                        (_p(d), _p(self._packed_filter(6)), _p(dx), M, self.cin, n9, _p(gy), L.ACT[gact] if gact else 0, st), executed)
             else:
-                _timed(128128, flops, "ladder_dense_bwd_data",
+                _timed(abs(L.query("ladder_igemm_fwd_tile", M, n9, self.cin)), flops, "ladder_dense_bwd_data",
                        (_p(d), _p(self._packed_filter(7)), _p(dx), M, self.cin, n9, _p(gy), L.ACT[gact] if gact else 0, wsp, wsn, st), executed)
         self.x = self.y = None
         return dx
