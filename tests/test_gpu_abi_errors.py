@@ -47,6 +47,22 @@ def test_rejections_return_codes(gpu_ctx):
     assert q("ladder_elbo_finalize", x.data_ptr(), x.data_ptr(), None, L.LadderElboCfg(0, 1, 1, 1, 1, 0, 0, 0, 0, 0.0, 0.0, 0, 0), y.data_ptr(),
              st) == E_SHAPE
     assert q("ladder_adam_clip", x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 0, 0.1, 0.9, 0.95, 1e-8, 1.0, st) == 0   # n = 0: no-op
+    # round 5, projected resize -> conv pairs (csrc/upproj.hip, csrc/densef32.hip)
+    z = torch.zeros(2 * 8 * 8, 9 * 32, device="cuda"); y2 = torch.full((2, 16, 16, 32), 7.0, device="cuda"); po = torch.full((2, 16, 16, 3), 7.0, device="cuda")
+    assert q("ladder_up2proj_fwd_combine", z.data_ptr(), None, None, None, None, None, 0, 2, 8, 8, 32, 0, st) == E_SHAPE          # nothing to write
+    assert q("ladder_up2proj_fwd_combine", z.data_ptr(), None, y2.data_ptr(), w.data_ptr(), None, po.data_ptr(), 3, 2, 8, 8, 32, 0, st) == E_SHAPE   # fused projection needs C == 128
+    assert q("ladder_up2proj_fwd_combine", z.data_ptr() + 4, None, y2.data_ptr(), None, None, None, 0, 2, 8, 8, 32, 0, st) == E_ALIGN
+    assert q("ladder_up2proj_fwd_combine", z.data_ptr(), None, y2.data_ptr(), None, None, None, 0, 2, 8, 8, 30, 0, st) == E_SHAPE   # C % 4 != 0
+    assert q("ladder_upfproj_fwd_combine", z.data_ptr(), None, y2.data_ptr(), 3, 2, 8, 8, 32, 0, st) == E_SHAPE                     # factor 3: only 2 and 4
+    assert q("ladder_upfproj_bwd_combine", y2.data_ptr(), z.data_ptr(), 8, 2, 8, 8, 32, st) == E_SHAPE
+    assert q("ladder_up2proj_wgrad_unpack", None, None, w.data_ptr(), None, 16, 32, st) == E_SHAPE
+    assert torch.all(y2 == 7.0) and torch.all(po == 7.0)
+    assert q("ladder_upfproj_eligible", 2, 2, 8, 8, 24, 32) == 0 and q("ladder_upfproj_eligible", 4, 2, 8, 8, 32, 32) == 1      # Cin % 16
+    assert q("ladder_dense_fwd_is_persistent", 4096, 128, 1152) == 0 and q("ladder_dense_fwd_is_persistent", 8192, 128, 1152) == 1
+    assert q("ladder_dense_fwd_is_persistent", 8192, 128, 1100) == 0 and q("ladder_dense_bwd_weight_is_persistent", 8192, 96, 1152) == 0
+    assert q("ladder_dense_fwd_nt", x.data_ptr(), w.data_ptr(), None, y.data_ptr(), 128, 16, 32, 0, st) == E_SHAPE               # below the persistent kernel's sizes
+    assert q("ladder_filter_pack_split", w.data_ptr(), z.data_ptr(), 9, 16, 9 * 32, 6, 0, st) == E_SHAPE                            # orientation 6 is ONE [Cin][9 C] matrix: ntaps = 1
+    assert q("ladder_filter_pack_split", w.data_ptr(), z.data_ptr(), 1, 16, 9 * 32 + 16, 6, 0, st) == E_SHAPE                       # ... with 9 | Cout
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k,s,pad", [(1, 1, 1, 1, 1, 1, 1, "same"), (1, 3, 3, 1, 1, 3, 1, "valid"), (1, 2, 5, 3, 2, 3, 2, "same"),
