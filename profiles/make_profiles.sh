@@ -28,4 +28,5 @@ LADDER_BENCH_SINGLE_DEVICE=1 python3 bench.py --gpus 2 --steps 10 --warmup 3 --r
 bash profiles/tools/r5_gemm_pmc.sh
 # the same leg with the tap-folded forms of the first half of the round, for the A/B line of DESIGN 5
 python3 bench.py --steps 20 --warmup 5 --repeats 2 --sustained-seconds 0 --no-cpu-baseline --no-compare --set upsample_fused_convs=3 2>/dev/null | grep '^{"metric"' > gpurun_out/r05_f32_bench_level3.json
+python3 bench.py --config codes/celeba_r8k50_config.json --steps 20 --warmup 5 --repeats 2 --sustained-seconds 0 --no-cpu-baseline --no-compare 2>/dev/null | grep '^{"metric"' > gpurun_out/r05_bench_r8k50.json
 tail -c 1500 gpurun_out/r05_f32_bench_default.json
