@@ -46,6 +46,22 @@ __device__ __forceinline__ AxisW up2_axis(int r, int i, int L) {
   return a;
 }
 
+// streaming store of a tensor that is written once and read by a LATER kernel (y, D: GBs): non-temporal, so that it does not displace the lines the
+// neighbouring threads are about to re-read (Z resp. dy are re-read 2x / 6x through L2 inside these kernels).  LADDER_UPPROJ_NT=0 (build-time -D) turns it off.
+#ifndef LADDER_UPPROJ_NT
+#define LADDER_UPPROJ_NT 1
+#endif
+typedef float up_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_stream(float4* p, float4 v) {
+#if LADDER_UPPROJ_NT
+  up_f32x4 t;
+  t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+  __builtin_nontemporal_store(t, reinterpret_cast<up_f32x4*>(p));
+#else
+  *p = v;
+#endif
+}
+
 __device__ __forceinline__ float4 f4_fma(float s, float4 v, float4 a) {
   return make_float4(fmaf(s, v.x, a.x), fmaf(s, v.y, a.y), fmaf(s, v.z, a.z), fmaf(s, v.w, a.w));
 }
@@ -229,7 +245,7 @@ __global__ __launch_bounds__(256) void up2proj_fwd_combine_rows_kernel(const flo
         float4 v = acc[a][b];
         v = make_float4(ladder_act_fn(v.x, act), ladder_act_fn(v.y, act), ladder_act_fn(v.z, act), ladder_act_fn(v.w, act));
         const long opix = ((long)n * 2 * H + 2 * i + a) * 2 * W + 2 * j + b;
-        if (live && y != nullptr) reinterpret_cast<float4*>(y)[opix * CV + cq] = v;
+        if (live && y != nullptr) st_stream(reinterpret_cast<float4*>(y) + opix * CV + cq, v);
         if (PROJ) {
           float4 pr = make_float4(0.f, 0.f, 0.f, 0.f);
           pr = f4_fma(v.x, pwv[0], pr);
@@ -286,7 +302,7 @@ __global__ __launch_bounds__(256) void up2proj_bwd_combine_kernel(const float* _
       for (int al = 0; al < 3; ++al)
 #pragma unroll
         for (int be = 0; be < 3; ++be) acc = f4_fma(wr[al] * wc[be], g[2 - r + al][2 - s + be], acc);     // row 2i - r + al = (2i - 2) + (2 - r + al)
-      dp[(r * 3 + s) * CV] = acc;
+      st_stream(dp + (r * 3 + s) * CV, acc);
     }
 }
 
