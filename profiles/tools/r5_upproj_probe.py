@@ -42,7 +42,7 @@ for (name, H, Cin, Cout) in (("conv2d_7", 64, 128, 128), ("conv2d_6", 32, 256, 1
     print("%s bwd combine      %8.1f us %6.2f TB/s" % (name, t, by / t * 1e-6))
     dx = torch.empty(M, Cin, device="cuda")
     w2 = ws(L.query("ladder_igemm_fwd_workspace_bytes", M, N9, Cin))
-    t = timeit(lambda: L.call("ladder_dense_fwd", p(z), p(wcatT), None, p(dx), M, N9, Cin, 0, p(w2), w2.numel(), st)); tot["bwd"] += t
+    t = timeit(lambda: L.call("ladder_dense_bwd_data_nt", p(z), p(wcat), p(dx), M, Cin, N9, None, 0, st)); tot["bwd"] += t      # (as the engine issues it: K-contiguous weights, 16x16x4 kernel)
     print("%s bwd GEMM         %8.1f us %6.1f TF" % (name, t, fl / t * 1e-6))
     dw = torch.empty(Cin, N9, device="cuda"); db9 = torch.empty(N9, device="cuda"); dwo = torch.empty(3, 3, Cin, Cout, device="cuda"); db = torch.empty(Cout, device="cuda")
     w3 = ws(L.query("ladder_dense_bwd_weight_workspace_bytes", M, Cin, N9))
