@@ -457,7 +457,8 @@ bool dense_f32_big_ok(long M, int K, int N) {
 
 int dense_f32_big_launch(const float* A, const float* B, const float* bias, float* C, const float* gate, int gate_act, long M, int K, int N, int act,
                          hipStream_t stream) {
-  if (!dense_f32_big_ok(M, K, N)) return LADDER_E_SHAPE;
+  if (!dense_f32_big_ok(M, K, N) || A == nullptr || C == nullptr) return LADDER_E_SHAPE;
+  if (B == nullptr) return LADDER_E_SHAPE;
   if (!ladder_aligned16(A) || !ladder_aligned16(B) || !ladder_aligned16(C)) return LADDER_E_ALIGN;
   const int tiles_n = N / GB_N, tiles_total = (int)(M / GB_M) * tiles_n;
   static int slots = 0;
@@ -486,7 +487,8 @@ int dense_f32_big_launch(const float* A, const float* B, const float* bias, floa
 // NT form: Bt [N][K]
 int dense_f32_nt_launch(const float* A, const float* Bt, const float* bias, float* C, const float* gate, int gate_act, long M, int K, int N, int act,
                         hipStream_t stream) {
-  if (!dense_f32_big_ok(M, K, N)) return LADDER_E_SHAPE;
+  if (!dense_f32_big_ok(M, K, N) || A == nullptr || C == nullptr) return LADDER_E_SHAPE;
+  if (Bt == nullptr) return LADDER_E_SHAPE;
   if (!ladder_aligned16(A) || !ladder_aligned16(Bt) || !ladder_aligned16(C) || (bias != nullptr && !ladder_aligned16(bias)) ||
       (gate != nullptr && !ladder_aligned16(gate)))
     return LADDER_E_ALIGN;
@@ -545,7 +547,7 @@ size_t dense_wgrad_f32_ws_bytes(long M, int K, int N) {
 // writes the partial tiles [splits][K][N] to `part` and (bias_part != NULL) the partial column sums [splits][N]; the caller reduces them
 int dense_wgrad_f32_launch(const float* x, const float* dy, float* part, float* bias_part, long M, int K, int N, int splits, int m_per_split,
                            hipStream_t stream) {
-  if (!dense_wgrad_f32_ok(M, K, N)) return LADDER_E_SHAPE;
+  if (!dense_wgrad_f32_ok(M, K, N) || x == nullptr || dy == nullptr || part == nullptr) return LADDER_E_SHAPE;
   if (!ladder_aligned16(x) || !ladder_aligned16(dy) || !ladder_aligned16(part)) return LADDER_E_ALIGN;
   const int tiles_n = N / GB_N;
   const int tiles = (K / GB_M) * tiles_n;

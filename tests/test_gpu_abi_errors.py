@@ -61,6 +61,8 @@ def test_rejections_return_codes(gpu_ctx):
     assert q("ladder_dense_fwd_is_persistent", 4096, 128, 1152) == 0 and q("ladder_dense_fwd_is_persistent", 8192, 128, 1152) == 1
     assert q("ladder_dense_fwd_is_persistent", 8192, 128, 1100) == 0 and q("ladder_dense_bwd_weight_is_persistent", 8192, 96, 1152) == 0
     assert q("ladder_dense_fwd_nt", x.data_ptr(), w.data_ptr(), None, y.data_ptr(), 128, 16, 32, 0, st) == E_SHAPE               # below the persistent kernel's sizes
+    assert q("ladder_dense_fwd_nt", x.data_ptr(), w.data_ptr(), None, None, 8192, 128, 1152, 0, st) == E_SHAPE                      # no output
+    assert q("ladder_dense_fwd", x.data_ptr(), w.data_ptr(), None, None, 8192, 128, 1152, 0, None, 0, st) == E_SHAPE
     assert q("ladder_filter_pack_split", w.data_ptr(), z.data_ptr(), 9, 16, 9 * 32, 6, 0, st) == E_SHAPE                            # orientation 6 is ONE [Cin][9 C] matrix: ntaps = 1
     assert q("ladder_filter_pack_split", w.data_ptr(), z.data_ptr(), 1, 16, 9 * 32 + 16, 6, 0, st) == E_SHAPE                       # ... with 9 | Cout
 
