@@ -47,7 +47,9 @@ TRAFFIC_FILES = {"f16x3": ("r03_pmc_traffic.json", "r02_pmc_traffic.json"), "f32
 def cpu_baseline(cfg, gm, seconds_budget=20.0, threads=None):
     """The oracle (CPU restatement of the TF1 reference path, fp32) timed on a bounded sample of the same workload.
     Thread count: min(host cores, 32) -- torch-CPU convolutions at this batch size get slower, not faster, beyond
-    that on the 256-thread GPU hosts (measured: 256 threads ran 100x slower than 8)."""
+    that on the 256-thread GPU hosts (measured: 256 threads ran 100x slower than 8).
+    Returns (baseline record, parity sample): the FIRST timed iteration starts from the seeded initial parameters with explicit noise, and its
+    inputs + fetches are handed back so that the HIP engine can be run on exactly them in the same process (`parity` in the JSON line)."""
     import numpy as np
     import torch
     from oracle import ladder_oracle as O
@@ -56,26 +58,61 @@ def cpu_baseline(cfg, gm, seconds_budget=20.0, threads=None):
     Bc = 4
     rng = np.random.default_rng(0)
     x = rng.random((Bc, cfg["dim_input_x"], cfg["dim_input_y"], cfg["dim_input_channel"])).astype(np.float32)
-    st = O.OracleState(cfg, O.init_params(cfg, seed=1), np.float32)
+    params0 = O.init_params(cfg, seed=1)
     nrng = np.random.default_rng(2)
     epoch = int(cfg["sg_pretraining"]) + 1
 
-    def one(xb):
+    def one(st, xb):
         noises = [O.make_noise(cfg, xb.shape[0], nrng, np.float32) for _ in range(4)]
         t0 = time.time()
-        O.train_iteration(st, xb, noises, gm, cur_epoch=epoch, lr_ae=cfg["learning_rate_ae"])
-        return time.time() - t0
+        fetch = O.train_iteration(st, xb, noises, gm, cur_epoch=epoch, lr_ae=cfg["learning_rate_ae"])
+        return time.time() - t0, noises, fetch
 
-    one(x[:1])                                   # warm-up (thread pool, allocator), not timed
-    n_it, t_tot = 0, 0.0
+    one(O.OracleState(cfg, dict(params0), np.float32), x[:1])   # warm-up (thread pool, allocator) on a throw-away state, not timed
+    st = O.OracleState(cfg, dict(params0), np.float32)
+    n_it, t_tot, sample = 0, 0.0, None
     while n_it < 1 or (t_tot < seconds_budget and n_it < 8):
-        t_tot += one(x)
+        dt, noises, fetch = one(st, x)
+        if sample is None:
+            sample = dict(x=x, noises=noises, params=params0, epoch=epoch,
+                          cpu={"elbo": float(fetch["run1"]["elbo"]), "elbo_prior": float(fetch["run3"]["elbo_prior"]),
+                               "l1_reconstruction_error": float(fetch["run1"]["l1_reconstruction_error"])})
+        t_tot += dt
         n_it += 1
-    return dict(value=round(Bc * n_it / t_tot, 3), unit="images/sec", cores=cores, kind="port",
-                sample="%d full 4-run iterations at batch %d of the same %s %dx%d nh=%d z=%d R=%d K=%d network "
-                       "(oracle/ladder_oracle.py, torch-CPU fp32, %d threads)" % (
-                           n_it, Bc, cfg["exp_name"], cfg["dim_input_x"], cfg["dim_input_y"], cfg["num_hidden_units"], cfg["code_size"],
-                           cfg["representation_size"], cfg["n_mixtures"], cores))
+    rec = dict(value=round(Bc * n_it / t_tot, 3), unit="images/sec", cores=cores, kind="port",
+               sample="%d full 4-run iterations at batch %d of the same %s %dx%d nh=%d z=%d R=%d K=%d network "
+                      "(oracle/ladder_oracle.py, torch-CPU fp32, %d threads)" % (
+                          n_it, Bc, cfg["exp_name"], cfg["dim_input_x"], cfg["dim_input_y"], cfg["num_hidden_units"], cfg["code_size"],
+                          cfg["representation_size"], cfg["n_mixtures"], cores))
+    return rec, sample
+
+
+def parity_on_cpu_sample(cfg, gm, sample, device):
+    """north_star: "outputs match the reference CPU path on identical inputs ... in the same run".  The HIP engine evaluates the FIRST iteration of
+    the CPU-baseline leg -- the same 4 images, the same seeded initial parameters, the same four noise draws, the same mixture -- and the JSON line
+    carries the relative deviation of `elbo` (RUN#1) and `elbo_prior` (RUN#3) from the fp32 CPU oracle's values (tolerance 1e-3, BASELINE.json)."""
+    import contextlib
+    import io
+    from ladder_latent_data_distribution_modelling_amd.engine import LadderEngine
+    c4 = dict(cfg, batch_size=int(sample["x"].shape[0]))
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = LadderEngine(c4, device, values=sample["params"], seed=1)
+    eng.set_mixture(gm["weights"], gm["means"], gm["covs"])
+    e, x, nz = sample["epoch"], sample["x"], sample["noises"]
+    use_sg, use_mask = e <= int(cfg["sg_pretraining"]), e >= int(cfg["use_mask_start"])
+    eng.run_ae(x, float(cfg["learning_rate_ae"]), nz[0], use_sg, use_mask)
+    f1 = eng.fetch()
+    eng.run_sigma(x, float(cfg["learning_rate_sigma"]) * (0.99 ** (e - 1)), nz[1], use_sg, use_mask)
+    eng.run_prior(x, float(cfg["learning_rate_prior"]) * (1.01 ** (e - 1)), nz[2], use_sg, use_mask)
+    f3 = eng.fetch()
+    gpu = {"elbo": f1["elbo"], "elbo_prior": f3["elbo_prior"], "l1_reconstruction_error": f1["l1_reconstruction_error"]}
+    rel = {k: abs(gpu[k] - v) / max(abs(v), 1e-12) for k, v in sample["cpu"].items()}
+    tol = 1e-3
+    return {"elbo_rel_err": float("%.3e" % rel["elbo"]), "elbo_prior_rel_err": float("%.3e" % rel["elbo_prior"]),
+            "l1_reconstruction_error_rel_err": float("%.3e" % rel["l1_reconstruction_error"]), "tolerance": tol,
+            "ok": bool(rel["elbo"] <= tol and rel["elbo_prior"] <= tol), "gpu": gpu, "cpu": sample["cpu"],
+            "sample": "iteration 0 of the cpu_baseline leg: the same %d images, seeded initial parameters, four explicit noise draws and mixture; "
+                      "HIP engine (strict fp32) against oracle/ladder_oracle.py (torch-CPU fp32): RUN#1 elbo, RUN#3 elbo_prior" % x.shape[0]}
 
 
 def spawn_ranks(args):
@@ -206,6 +243,23 @@ def main():
     if ranks_seen != args.gpus:
         sys.stderr.write("bench.py: all-reduce of ones saw %d ranks, --gpus %d\n" % (ranks_seen, args.gpus))
         sys.exit(2)
+
+    # measured small-message all-reduce latency of THIS job's backend, before anything is timed (the ring model below used an
+    # ASSUMED 5 us per hop): 8 B = the pure latency of a collective launch, 2 KB = a C2 batch-norm statistics record, 352 B ~ the C3 partials
+    small_allreduce_us = None
+    if world > 1:
+        small_allreduce_us = {}
+        for nbytes in (8, 352, 2048):
+            t = torch.zeros(nbytes // 4, device="cuda")
+            for _ in range(20):
+                dist.all_reduce(t)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                dist.all_reduce(t)
+            torch.cuda.synchronize()
+            small_allreduce_us[str(nbytes)] = round((time.perf_counter() - t0) / 200 * 1e6, 2)
 
     from ladder_latent_data_distribution_modelling_amd import engine as E
     from ladder_latent_data_distribution_modelling_amd.codes.models import CelebAModel_densenet, MNISTModel_digit, MNISTModel_fashion
@@ -373,12 +427,15 @@ def main():
         # to be replaced by the first measured 8-byte all-reduce)
         LINK_GBS, HOP_US = 153.0, 5.0
         pred = {}
+        lat_meas = small_allreduce_us.get("8") if small_allreduce_us else None
+        out["comm"]["measured_small_allreduce_us"] = small_allreduce_us       # back-to-back 8 B / 352 B / 2 KB all-reduces of this backend, measured above
         for label, v in head["comm"].items():
             bw_us = 2.0 * (world - 1) / world * v["bytes_per_call"] / (LINK_GBS * 1e3)
-            lat_us = 2.0 * (world - 1) * HOP_US
+            lat_us = lat_meas if lat_meas is not None else 2.0 * (world - 1) * HOP_US       # the MEASURED 8-byte latency replaces the assumed hop cost
             pred[label] = {"predicted_us_per_call": round(bw_us + lat_us, 1), "bandwidth_term_us": round(bw_us, 1), "latency_term_us": round(lat_us, 1),
                            "predicted_us_per_step": round((bw_us + lat_us) * v["calls_per_step"], 1)}
-        out["comm"]["predicted"] = {"model": "ring all-reduce: 2 (N-1)/N x bytes / %.0f GB/s per xGMI link direction + 2 (N-1) x %.0f us per call" % (LINK_GBS, HOP_US),
+        out["comm"]["predicted"] = {"model": "ring all-reduce: 2 (N-1)/N x bytes / %.0f GB/s per xGMI link direction + %s per call" % (
+                                        LINK_GBS, ("the measured 8-byte all-reduce latency (%.1f us)" % lat_meas) if lat_meas is not None else "2 (N-1) x %.0f us (assumed)" % HOP_US),
                                     "n_ranks": world, "collectives": pred,
                                     "wall_ms_per_step": round(sum(q["predicted_us_per_step"] for q in pred.values()) / 1e3, 3),
                                     "note": "the asynchronous C1 decoder bucket overlaps the encoder's backward pass: its predicted time is exposed only "
@@ -433,7 +490,9 @@ def main():
         out["fast_f16x3"] = ex
         del trx, modelx
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, gm)
+        out["cpu_baseline"], sample = cpu_baseline(cfg, gm)
+        if cfg["prior"] == "ours":
+            out["parity"] = parity_on_cpu_sample(cfg, gm, sample, "cuda:%d" % local)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -37,7 +37,11 @@ typedef struct ihipStream_t* ladder_stream_t; /* == hipStream_t */
 enum { LADDER_OK = 0, LADDER_E_SHAPE = -1, LADDER_E_ALIGN = -2, LADDER_E_WORKSPACE = -3, LADDER_E_LAUNCH = -4 };
 enum { LADDER_ACT_NONE = 0, LADDER_ACT_LEAKY = 1 /* alpha 0.2 */, LADDER_ACT_RELU = 2, LADDER_ACT_TANH = 3 };
 
-/* Build/ABI identification. */
+/* Build/ABI identification.  LADDER_ABI_VERSION is bumped whenever the layout of a buffer behind an EXISTING entry point changes:
+ *   2 (round 5): the batch-norm statistics record of ladder_bn_fwd_stats / ladder_bn_stats_from_partials / the *_bnstats convolutions /
+ *                ladder_bn_fwd_apply* is 2C DOUBLES (sum | sum of squares; + optionally 2C floats min | max), was 2C / 4C floats in version 1.
+ * A caller built against another version must refuse to run (the Python binding does: _lib.load()). */
+#define LADDER_ABI_VERSION 2
 int ladder_abi_version(void);
 /* BM*1000+BN of the implicit-GEMM instantiation a forward-type call (conv fwd / bwd_data / dense fwd / bwd_data) with
  * GEMM extents M x (.) x Cout and gathered channel count Cin dispatches to; negative = non-vectorised variant. */

@@ -25,6 +25,7 @@ S_NAMES = ["sigma", "mean_pixel_error", "entropy_z", "crossEntropy_prior_sg", "c
 S_INDEX = {n: i for i, n in enumerate(S_NAMES)}
 S_COUNT = 32
 ABSMAX_FLOATS = 512      # LADDER_ABSMAX_FLOATS: size of an absolute-maximum record
+ABI_VERSION = 2          # LADDER_ABI_VERSION this binding was written against (buffer layouts behind the entry points: include/ladder_hip.h)
 
 
 class LadderElboCfg(C.Structure):
@@ -226,6 +227,10 @@ def load(path=None):
         fn = getattr(lib, name)      # AttributeError here == header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    got = lib.ladder_abi_version()
+    if got != ABI_VERSION:
+        raise LadderHipError("%s reports ABI version %d, this binding needs %d (stale build? re-run `python -m "
+                             "ladder_latent_data_distribution_modelling_amd.csrc.build`)" % (path, got, ABI_VERSION))
     _lib = lib
     return lib
 

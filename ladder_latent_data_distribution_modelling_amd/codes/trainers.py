@@ -19,6 +19,9 @@ class _JointEpochMixin:
     def _iterators(self):
         raise NotImplementedError
 
+    def _mid_epoch(self, i):
+        """Hook behind iteration i of the hot loop (the CelebA trainer records its mid-epoch test steps here)."""
+
     def _make_iterator(self, key, images, shuffle=True):
         """config["device_resident_data"] (default 1): the rank's shard of the split is uploaded to HBM once (uint8 for CelebA)
         and minibatches are gathered + normalised on the device; 0 keeps the host iterator (float32 numpy batches)."""
@@ -53,6 +56,7 @@ class _JointEpochMixin:
                 train_loss_cur_epoch += loss
             if self._prior_training_on():
                 self.train_step_prior(batch_data=batch)
+            self._mid_epoch(i)
         self.flush()                                                        # record lists of the last iteration (async_fetch)
         if int(cfg["TRAIN_VAE"]) == 1:
             self.train_loss_ave_epoch.append(train_loss_cur_epoch / max(self.n_train_iter, 1))
@@ -118,6 +122,15 @@ class CelebATrainer_joint_training(_JointEpochMixin, BaseTrain_joint):
         n_val = self.data.n_val if not self.data.synthetic else self._val.shape[0] * c.world
         self.n_train_iter = min(n_train // (bs * c.world), self._train.shape[0] // bs)
         self.n_val_iter = min(n_val // (bs * c.world), self._val.shape[0] // bs)
+        # trainers.py:139: iterations behind which the reference evaluates (and plots) the test batch inside the epoch
+        step = max(1, self.n_train_iter // max(1, int(config.get("num_iter_to_plot", 1))))
+        self.idx_check_point = np.arange(0, self.n_train_iter - 1, step)
+
+    def _mid_epoch(self, i):
+        """trainers.py:156-158: test_step(test_batch) at the check-point iterations -- the figure is out of scope, the state it records
+        (`test_sigma` -> result-npz `sigma`, `output_test`) is not: one entry per check point, as in a reference run."""
+        if int(self.config.get("num_iter_to_plot", 1)) > 1 and np.any(self.idx_check_point == i):
+            self.test_step(batch_data=self.test_batch, print_result=False)
 
     def _iterators(self):
         return (self._make_iterator("train", lambda: self._train),

@@ -2051,7 +2051,7 @@ int run_wgrad_split(const void* x, const float* xamax, const void* dy, const flo
 
 extern "C" {
 
-int ladder_abi_version(void) { return 1; }
+int ladder_abi_version(void) { return 2; }   // == LADDER_ABI_VERSION (include/ladder_hip.h)
 
 int ladder_dense_fwd_is_persistent(long M, int K, int N) { return dense_f32_big_ok(M, K, N) ? 1 : 0; }
 int ladder_dense_bwd_weight_is_persistent(long M, int K, int N) { return dense_wgrad_f32_ok(M, K, N) ? 1 : 0; }

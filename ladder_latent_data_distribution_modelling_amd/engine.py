@@ -251,7 +251,17 @@ class VirtualGroup:
         import threading
         self.world = int(world)
         self.barrier = threading.Barrier(self.world)
+        # a rank that issues fewer collectives than the others (or returns early) must FAIL the job, not hang it: every wait has a time-out
+        # (threading.BrokenBarrierError in all ranks) and run_virtual_ranks aborts the barrier as soon as one rank's function has returned
+        self.timeout = float(os.environ.get("LADDER_VIRTUAL_BARRIER_TIMEOUT", "300"))
+        self.lock, self.finished = threading.Lock(), 0
         self.slots = [None] * self.world
+
+    def wait(self):
+        with self.lock:
+            if self.finished:                 # a rank has already returned: this collective can never complete
+                self.barrier.abort()
+        self.barrier.wait(self.timeout)
 
 
 class VirtualComm:
@@ -277,12 +287,14 @@ class VirtualComm:
         if not self.on:
             return t
         g = self.g
+        # (ONE shared stream: host issue order is device order only on the default stream every thread starts with)
+        assert not t.is_cuda or torch.cuda.current_stream(t.device) == torch.cuda.default_stream(t.device), "VirtualComm needs the default stream"
         g.slots[self.rank] = t
-        g.barrier.wait()                      # every rank's tensor is deposited (and its producers are enqueued on the shared stream)
+        g.wait()             # every rank's tensor is deposited (and its producers are enqueued on the shared stream)
         acc = g.slots[0].clone()
         for r in range(1, self.world):
             acc.add_(g.slots[r])
-        g.barrier.wait()                      # every rank has enqueued its reads of all slots: the in-place results may now be written
+        g.wait()             # every rank has enqueued its reads of all slots: the in-place results may now be written
         t.copy_(acc)
         return t
 
@@ -297,16 +309,16 @@ class VirtualComm:
             return t
         g = self.g
         g.slots[self.rank] = t
-        g.barrier.wait()
+        g.wait()
         v = g.slots[src].clone()
-        g.barrier.wait()
+        g.wait()
         t.copy_(v)
         return t
 
 
 def run_virtual_ranks(world, fn):
     """fn(rank, comm) -> result in `world` threads, one VirtualComm each; returns the list of results.  An exception in one rank breaks the
-    barrier, so the others fail instead of waiting for ever."""
+    barrier, and so does a rank that returns while others still wait for (or later enter) a collective -- the job fails instead of hanging."""
     import threading
     group = VirtualGroup(world)
     out, err = [None] * world, []
@@ -314,6 +326,11 @@ def run_virtual_ranks(world, fn):
     def body(r):
         try:
             out[r] = fn(r, VirtualComm(group, r))
+            with group.lock:
+                group.finished += 1
+                # a rank still inside a collective waits for one this rank will never join (unequal collective counts): fail it now
+                if group.finished < world and group.barrier.n_waiting:
+                    group.barrier.abort()
         except BaseException as e:          # noqa: BLE001 -- reported below
             err.append((r, e))
             group.barrier.abort()
@@ -323,7 +340,8 @@ def run_virtual_ranks(world, fn):
         t.start()
     for t in threads:
         t.join()
-    torch.cuda.synchronize()
+    if torch.cuda.is_available():             # (the CPU unit test of the barrier logic runs without a device)
+        torch.cuda.synchronize()
     if err:
         import threading as _t
         first = [e for e in err if not isinstance(e[1], _t.BrokenBarrierError)] or err
@@ -607,6 +625,7 @@ class ParamStore:
 
 # ------------------------------------------------------------------------------------------ layers
 UP2T_MIN_PIXELS = int(os.environ.get("LADDER_UP2T_MIN_PIXELS", "256"))      # smallest low-resolution map whose backward-data runs upsample-fused
+PROJ_MAX_BYTES = int(os.environ.get("LADDER_PROJ_MAX_BYTES", str(32 << 30)))  # largest Z / D temporary of a projected pair (conv2d_7 at batch 128: 2.4 GB)
 UP2W_MIN_PIXELS = int(os.environ.get("LADDER_UP2W_MIN_PIXELS", "256"))      # ... and whose filter gradient does (8x8: 758 us fused against 612 direct)
 
 
@@ -625,6 +644,7 @@ class Conv2D:
         self.x_is_up2 = False                                   # set by forward_up2(keep_y): self.x is a factor-2 legacy-bilinear upsample
         self.x_is_lo = False                                    # ... or self.x is the LOW-resolution tensor itself (the upsample was never materialised)
         self.lo_factor = 2                                      # ... by this resize factor
+        self.x = self.y = None                                  # operands kept by a training forward for the backward pass
 
     def _halo_ok(self, N, H, W, cin, cout):
         """The layer runs on the fused 3x3 halo kernels of the configured precision (strict fp32: csrc/convf32.hip; split formats:
@@ -738,6 +758,10 @@ class Conv2D:
         proj.x, proj.y = y, out
         return out
 
+    def _proj_rides(self, proj):
+        """The 1x1 conv `proj` behind this layer can ride on the epilogue of its upsample-fused / projected launch."""
+        return bool(self.cout == 128 and proj.k == 1 and proj.stride == 1 and proj.cout <= 4 and proj.act is None and proj.cin == self.cout)
+
     def up2_ok(self, N, H, W):
         """This layer can take the LOW-resolution tensor [N, H, W, cin] that a factor-2 legacy-bilinear resize would have blown up for it
         (ladder_conv3x3_up2_split: four output-parity classes with effective taps, 25 instead of 36 low-resolution tap products and no
@@ -761,8 +785,10 @@ class Conv2D:
         [N, H, W, cin] tensor as nine 1x1 convolutions on it (9 of the direct form's 36 products per 2x2 output block, against 25 for the tap-folded
         form above) + an exact elementwise combination.  Forward, backward-data and the filter gradient all run from the low-resolution tensor.
         `f` = the resize factor, 2 or 4 (1 of 16 products at 4)."""
+        # (the nine planes Z / D are a transient [N H W, 9 cout] fp32 tensor: beyond PROJ_MAX_BYTES the layer takes the forms that allocate none)
         return bool(self.ctx.ns == 0 and self.ctx.up2 >= 4 and self.k == 3 and self.stride == 1 and self.padding == "same"
-                    and os.environ.get("LADDER_DISABLE_HALO") != "1" and L.query("ladder_upfproj_eligible", f, N, H, W, self.cin, self.cout))
+                    and os.environ.get("LADDER_DISABLE_HALO") != "1" and 36 * N * H * W * self.cout <= PROJ_MAX_BYTES
+                    and L.query("ladder_upfproj_eligible", f, N, H, W, self.cin, self.cout))
 
     def virtual_up2_ok(self, N, H, W):
         """A training forward may skip materialising the factor-2 upsample of its [N, H, W, cin] input altogether: strict fp32, and forward,
@@ -820,7 +846,7 @@ class Conv2D:
         if wgrad:
             ctx.up2_used[self.name + ":wgrad"] = ctx.up2_used.get(self.name + ":wgrad", 0) + 1
             ctx.up2_skipped[self.name + ":wgrad"] = 1.0 - 1.0 / (f * f)
-            dwcat, db9 = ctx.empty(self.cin, n9), ctx.empty(n9)
+            dwcat, db9 = ctx.empty(self.cin, n9), (ctx.empty(n9) if self.bias_grad else None)   # (a conv in front of a norm has no bias gradient)
             wsp, wsn = ctx.ws(L.query("ladder_dense_bwd_weight_workspace_bytes", M, self.cin, n9))
             _timed(9132 if L.query("ladder_dense_bwd_weight_is_persistent", M, self.cin, n9) else 9130, flops, "ladder_dense_bwd_weight",
                    (_p(x), _p(d), _p(dwcat), _p(db9), M, self.cin, n9, wsp, wsn, st), executed)
@@ -853,6 +879,14 @@ class Conv2D:
         ctx = self.ctx
         src = x
         N, H, W = x.shape[0], x.shape[1], x.shape[2]
+        if proj is not None and not self._proj_rides(proj):
+            # the fused 1x1 epilogues hold one pixel's 128 channels in a half-wave and project to <= 4 columns (csrc/upproj.hip, convf32.hip):
+            # any other last-layer width (num_hidden_units != 512) runs the pair unfused -- this conv from the low-resolution tensor, then `proj`
+            y = self.forward_up2(x, None, keep_y, x_for_backward, factor)
+            out = proj.forward(y)
+            if not keep_y:
+                proj.x = proj.y = None
+            return out
         if self.proj_ok(N, H, W, factor):
             return self._forward_proj(x, proj, keep_y, x_for_backward, factor)
         if factor != 2:
@@ -986,7 +1020,9 @@ class Conv2D:
         ONE launch (ladder_conv3x3_up2_bwd_data_split) + border strips, instead of backward-data on the upsampled map + the resize transpose."""
         if self.ctx.ns == 0 and os.environ.get("LADDER_DISABLE_HALO") == "1":
             return False
-        if self.proj_ok(N, H, W):
+        if self.proj_ok(N, H, W) and (self.x is None or self.x_is_lo):
+            # (asked before the forward: the geometry decides; asked in backward: only when the forward really kept the LOW-resolution tensor --
+            # a materialised upsample goes through the tap-folded eligibility below, ADVICE r5)
             return True
         if self.ctx.ns == 0 and H * W < UP2T_MIN_PIXELS:
             # policy (measured, profiles/r05_small_maps.txt): on an 8x8 low-resolution map the four exact border lines cost more than the

@@ -39,7 +39,7 @@ def test_celeba_trainer_from_tfrecords(tmp_path):
         dl.write_tfrecord(str(tmp_path / ("celebA_%s.tfrecords" % split)), imgs)
     cfg = tiny_config("celeba")
     cfg.update(batch_size=2, num_epochs=1, sg_pretraining=0, accurate_fit=5, GM_fit_restart=1, n_mixtures=2, data_path=str(tmp_path) + "/",
-               result_dir=str(tmp_path) + "/", checkpoint_dir=str(tmp_path) + "/")
+               result_dir=str(tmp_path) + "/", checkpoint_dir=str(tmp_path) + "/", num_iter_to_plot=2)
     data = dl.DataGenerator(cfg, None)
     data.n_train, data.n_val = 8, 4                       # (the reference hard-codes the 180 000 / 20 000 split sizes)
     model = CelebAModel_densenet(cfg)
@@ -50,3 +50,8 @@ def test_celeba_trainer_from_tfrecords(tmp_path):
     tr.train_epoch()
     assert len(tr.elbo_train) == 4 and np.isfinite(tr.elbo_train).all() and np.isfinite(tr.code_elbo_train).all()
     assert tr.gm_params is not None
+    # reference trainers.py:139,156-158: test_step(test_batch) behind iterations arange(0, n_train_iter - 1, n_train_iter // num_iter_to_plot)
+    # = [0, 2], then once more at the end of the epoch -> three `sigma` entries in the result npz, as in a reference run
+    assert list(tr.idx_check_point) == [0, 2] and len(tr.test_sigma) == 3
+    res = np.load(os.path.join(str(tmp_path), "celeba-result.npz"))
+    assert len(res["sigma"]) == 3 and np.isfinite(res["sigma"]).all()

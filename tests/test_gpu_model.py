@@ -645,6 +645,8 @@ def test_bench_script_two_ranks_one_gpu(tmp_path):
     assert len(j["repeats_images_per_sec"]) == 2
     # round 4: the per-collective table of the profiled region (C1 gradient buckets, C2 batch-norm statistics, C3 partials, C4 prior gradients)
     cm = j["comm"]
+    assert set(cm["measured_small_allreduce_us"]) == {"8", "352", "2048"} and all(v > 0 for v in cm["measured_small_allreduce_us"].values())
+    assert "measured 8-byte all-reduce latency" in cm["predicted"]["model"]
     labels = set(cm["collectives"])
     assert any(k.startswith("C1") for k in labels) and "C3 partials" in labels and "C4 prior gradients" in labels, labels
     assert cm["collectives"]["C3 partials"]["calls_per_step"] == 4.0 and cm["wall_ms_per_step"] >= cm["exposed_ms_per_step"] > 0

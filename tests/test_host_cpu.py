@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(lib_path):
         assert hasattr(lib, name), name
     # no-compute calls are safe without a GPU
     lib.ladder_abi_version.restype = ctypes.c_int
-    assert lib.ladder_abi_version() == 1
+    assert lib.ladder_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define LADDER_ABI_VERSION (\d+)", header).group(1))
     assert lib.ladder_gmm_packed_stride(2) == 6 and lib.ladder_gmm_packed_stride(8) == 45
     lib.ladder_conv2d_bwd_filter_workspace_bytes.restype = ctypes.c_size_t
     assert lib.ladder_conv2d_bwd_filter_workspace_bytes(128, 128, 128, 128, 128, 128, 128, 3, 3) > 0
@@ -138,6 +138,19 @@ def test_trainer_schedules():
         t.cur_epoch = e
         t.compute_cur_lr()
         assert abs(t.cur_lr - want) < 1e-12
+    # mid-epoch check points (reference trainers.py:139,156-158): the hook fires behind exactly those iterations
+    import numpy as np
+    calls = []
+    t.config, t.n_train_iter = dict(num_iter_to_plot=2), 1406
+    t.idx_check_point = np.arange(0, t.n_train_iter - 1, t.n_train_iter // 2)
+    t.test_batch = "tb"
+    t.test_step = lambda batch_data, print_result: calls.append((batch_data, print_result))
+    for i in range(t.n_train_iter):
+        t._mid_epoch(i)
+    assert list(t.idx_check_point) == [0, 703] and calls == [("tb", False)] * 2
+    t.config = dict(num_iter_to_plot=1)
+    t._mid_epoch(0)
+    assert len(calls) == 2
 
 
 DP_WORKER = r'''
@@ -352,3 +365,30 @@ def test_bench_workload_labels_and_default_graph_registry():
     assert count_trainable_variables("interpolation") == 10
     with pytest.raises(TypeError):
         count_trainable_variables(object(), "encoder")
+
+
+def test_virtual_ranks_fail_instead_of_hanging_on_unequal_collective_counts():
+    """a virtual rank that returns early (or issues fewer collectives) must make the job FAIL, not wait for ever."""
+    import time
+    import torch
+    from ladder_latent_data_distribution_modelling_amd.engine import run_virtual_ranks
+
+    def fn(rank, comm):
+        t = torch.full((4,), float(rank + 1))
+        comm.allreduce_(t)
+        if rank == 1:
+            time.sleep(0.2)
+            comm.allreduce_(t)            # rank 0 never joins this one
+        return t
+
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match="virtual rank 1 failed"):
+        run_virtual_ranks(2, fn)
+    assert time.time() - t0 < 30
+
+    def ok(rank, comm):
+        t = torch.full((4,), float(rank + 1))
+        return comm.allreduce_(comm.allreduce_(t))
+
+    a, b = run_virtual_ranks(2, ok)
+    assert a.tolist() == b.tolist() == [6.0] * 4
