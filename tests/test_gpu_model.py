@@ -426,25 +426,39 @@ np.savez(sys.argv[1], fetch=json.dumps(out), **{k.replace("/", "."): v for k, v 
 '''
 
 
+# per build: (RUN#1 scalars, RUN#3 scalars, gradient norm, sum |g|, conv2d_7 tensors, deeper tensors) -- relative deviations from the yardstick build
+IN_SITU_BARS = {
+    # strict-fp32 default (round 5: projected resize -> conv pairs on the persistent fp32 GEMMs, small-map halo kernels, epilogue batch-norm
+    # statistics): the SAME arithmetic as the yardstick with other summation orders -- its own bars, 3x what was measured on MI355X (round 6)
+    "f32-default": (2e-6, 2e-3, 1e-4, 3e-4, 1e-4, 5e-2),
+    # 16-bit split formats (opt-in): every contraction rounds its operands to 22 / 24 bits
+    "f16x3": (2e-6, 2e-3, 1e-4, 3e-4, 1e-4, 5e-2),
+    "bf16x6": (2e-6, 2e-3, 1e-4, 3e-4, 1e-4, 5e-2),
+    "f16x3-8wave": (2e-6, 2e-3, 1e-4, 3e-4, 1e-4, 5e-2),
+}
+
+
 def test_celeba_full_size_halo_kernels_in_situ(tmp_path):
     """BASELINE configs[2] at full size (nh=512, z=64, K=30, batch 128), the complete training step with the same seeds and the same
-    device noise in four builds of the contraction path:
-      f32 generic   every convolution on the round-1 fp32 gather kernels, batch-norm sums from a separate pass, no fusion
-                    (LADDER_DISABLE_HALO=1, LADDER_DISABLE_BNSTATS=1)                                            -- the yardstick
-      f32 halo      the strict-fp32 DEFAULT of round 4: fp32 LDS-halo kernels incl. the upsample-fused convolutions (forward, backward-data,
-                    filter gradient over the low-resolution maps), fused RGB projection, one-launch stride-2 backward-data, epilogue statistics
-      f16x3         the default: split-precision kernels, 2 scaled fp16 planes, 3 MFMAs per product (16-wave halo kernel at this batch)
-      bf16x6        split-precision kernels, 3 bf16 planes, 6 MFMAs per product
+    device noise in five builds of the contraction path:
+      f32-generic   every convolution on the round-1 fp32 gather kernels, batch-norm sums from a separate pass, nothing fused
+                    (LADDER_DISABLE_HALO=1, LADDER_DISABLE_BNSTATS=1: no projected pairs, no halo kernels)                    -- the yardstick
+      f32-default   the strict-fp32 DEFAULT (`upsample_fused_convs: 4`): every resize -> conv pair of the decoder in the projected form
+                    (persistent fp32 GEMMs + combination, csrc/densef32.hip / upproj.hip), stride-2 / small-map halo kernels, one-launch
+                    stride-2 backward-data, conv-epilogue batch-norm statistics
+      f16x3         opt-in split precision: 2 scaled fp16 planes, 3 MFMAs per product (16-wave halo kernel at this batch)
+      bf16x6        opt-in split precision: 3 bf16 planes, 6 MFMAs per product
       f16x3-8wave   f16x3 with the 16x32-pixel halo kernel switched off (LADDER_DISABLE_HALO16=1): the 8-wave kernel at full size
-    Every build must reproduce the yardstick: fetched ELBO terms of RUN#1 to 2e-6 relative, selected gradient tensors to 1e-4 of
-    their scale, finite everywhere (the fp32-class split formats get the SAME bars as the fp32 halo kernels)."""
+    Every build is held to the yardstick by IN_SITU_BARS (measured deviations are printed).  Accuracy against the float64 ORACLE at this batch:
+    tests/test_gpu_configs_at_size.py::test_celeba_configs2_full_batch_128_vs_float64_oracle."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "halo_worker.py"
     script.write_text(HALO_WORKER % dict(root=root))
     res = {}
-    for tag, env in (("generic", {"LADDER_DISABLE_HALO": "1", "LADDER_DISABLE_BNSTATS": "1", "LADDER_TEST_PRECISION": "f32"}), ("halo", {"LADDER_TEST_PRECISION": "f32"}),
+    for tag, env in (("f32-generic", {"LADDER_DISABLE_HALO": "1", "LADDER_DISABLE_BNSTATS": "1", "LADDER_TEST_PRECISION": "f32"}),
+                     ("f32-default", {"LADDER_TEST_PRECISION": "f32"}),
                      ("f16x3", {"LADDER_TEST_PRECISION": "f16x3"}), ("bf16x6", {"LADDER_TEST_PRECISION": "bf16x6"}),
                      ("f16x3-8wave", {"LADDER_TEST_PRECISION": "f16x3", "LADDER_DISABLE_HALO16": "1"})):
         outp = str(tmp_path / (tag + ".npz"))
@@ -452,35 +466,37 @@ def test_celeba_full_size_halo_kernels_in_situ(tmp_path):
         p = subprocess.run([sys.executable, str(script), outp], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
         assert p.returncode == 0, p.stdout[-2000:]
         res[tag] = np.load(outp)
-    fb = json.loads(str(res["generic"]["fetch"]))
-    for tag in ("halo", "f16x3", "bf16x6", "f16x3-8wave"):
+    fb = json.loads(str(res["f32-generic"]["fetch"]))
+    failures = []
+    for tag, (b_run1, b_run3, b_norm, b_abs, b_first, b_deep) in IN_SITU_BARS.items():
         fa = json.loads(str(res[tag]["fetch"]))
-        # (round 4: the fp32 default no longer shares kernels with the yardstick either -- effective taps of the upsample-fused layers are
-        # fp32 sums of the filter taps, the batch-norm sums come from the conv epilogue: another fp32 ROUNDING, the same bars as the split formats)
-        split = True
-        for k in SCALARS_RUN1:
-            assert np.isfinite(fa["ae"][k]) and _ok(fa["ae"][k], fb["ae"][k], 2e-6, 1e-5), (tag, k, fa["ae"][k], fb["ae"][k])
         # RUN#3 is evaluated AFTER the first Adam step of RUN#1, whose update is lr * g / (|g| + eps): an element whose gradient sits
-        # within rounding of zero moves by +-lr whichever way the last bit falls.  The fp32 halo build shares every encoder kernel
-        # with the yardstick (bit-identical there); the split builds round every contraction differently -> 2e-3 on these fetches.
-        for k in SCALARS_RUN3:
-            assert _ok(fa["prior"][k], fb["prior"][k], 2e-3 if split else 1e-5, 1e-5), (tag, k, fa["prior"][k], fb["prior"][k])
-        assert _rel(fa["grad_norm"], fb["grad_norm"]) < (1e-4 if split else 1e-5), tag
-        # (sum of |g| over all 30 M parameters: leaky-ReLU / ReLU mask flips of elements within rounding of zero move it by ~1e-4
-        # between ANY two differently rounded fp32-class builds -- measured 0.3e-4 ... 1.03e-4; accuracy itself is pinned against the
-        # live fp64 oracle in test_fullres_split_precision_vs_live_oracle)
-        assert _rel(fa["grad_abs_sum"], fb["grad_abs_sum"]) < (3e-4 if split else 1e-5), tag
+        # within rounding of zero moves by +-lr whichever way the last bit falls -- hence the wider bar on its fetches.
+        m = {"run1": max(_rel(fa["ae"][k], fb["ae"][k]) for k in SCALARS_RUN1 if abs(fb["ae"][k]) > 1e-3),
+             "run3": max(_rel(fa["prior"][k], fb["prior"][k]) for k in SCALARS_RUN3 if abs(fb["prior"][k]) > 1e-3),
+             "grad_norm": _rel(fa["grad_norm"], fb["grad_norm"]), "grad_abs_sum": _rel(fa["grad_abs_sum"], fb["grad_abs_sum"])}
+        assert all(np.isfinite(fa["ae"][k]) for k in SCALARS_RUN1), tag
+        first, deep = 0.0, 0.0
         for k in res[tag].files:
             if k == "fetch":
                 continue
-            a, b = res[tag][k].astype(np.float64), res["generic"][k].astype(np.float64)
-            # gradient tensors: the last decoder layer sees only its own contraction's rounding (1e-4 of scale for every build).  Deeper
-            # in the backward chain a differently-rounded forward flips leaky-ReLU masks of pre-activations within fp32 rounding of 0
-            # (1e8 activations at this size) and each flip changes that element's gradient by a factor 5: two fp32-CLASS paths then
-            # differ by 1e-4 .. 1e-2 of the tensor scale (bf16x6, whose products are exact to 2^-23, shows the same spread as f16x3).
-            # What pins the precision of the split formats is test_fullres_split_precision_vs_live_oracle (float64 truth).
-            tol = 1e-4 if (not split or k.startswith("decoder.conv2d_7")) else 5e-2
-            assert np.isfinite(a).all() and np.abs(a - b).max() < tol * np.abs(b).max(), (tag, k, np.abs(a - b).max(), np.abs(b).max())
+            a, b = res[tag][k].astype(np.float64), res["f32-generic"][k].astype(np.float64)
+            assert np.isfinite(a).all(), (tag, k)
+            # gradient tensors: the last decoder layer sees only its own contraction's rounding.  Deeper in the backward chain a differently
+            # rounded forward flips leaky-ReLU masks of pre-activations within fp32 rounding of 0 (1e8 activations at this size) and each flip
+            # changes that element's gradient by a factor 5: two fp32-CLASS paths then differ by 1e-4 .. 1e-2 of the tensor scale.
+            d = np.abs(a - b).max() / np.abs(b).max()
+            if k.startswith("decoder.conv2d_7"):
+                first = max(first, d)
+            else:
+                deep = max(deep, d)
+        print("%-12s RUN#1 %.1e  RUN#3 %.1e  |g| %.1e  sum|g| %.1e  conv2d_7 grads %.1e  deeper grads %.1e" % (
+            tag, m["run1"], m["run3"], m["grad_norm"], m["grad_abs_sum"], first, deep))
+        for name, val, bar in (("run1", m["run1"], b_run1), ("run3", m["run3"], b_run3), ("grad_norm", m["grad_norm"], b_norm),
+                               ("grad_abs_sum", m["grad_abs_sum"], b_abs), ("conv2d_7 grads", first, b_first), ("deeper grads", deep, b_deep)):
+            if not val <= bar:
+                failures.append((tag, name, val, bar))
+    assert not failures, failures
 
 
 @pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16x6"])
