@@ -247,6 +247,18 @@ int ladder_up2proj_wgrad_unpack(const float* dwcat, const float* db9, float* dw,
 int ladder_upfproj_eligible(int factor, int N, int H, int W, int Cin, int Cout);
 int ladder_upfproj_fwd_combine(const float* z, const float* bias, float* y, int factor, int N, int H, int W, int C, int act, ladder_stream_t stream);
 int ladder_upfproj_bwd_combine(const float* dy, float* d, int factor, int N, int H, int W, int C, ladder_stream_t stream);
+/* Round 6: the FORWARD of a factor-2 pair in ONE launch (reference codes/models.py:544-586: tf.image.resize_images -> tf.layers.conv2d, the last pair
+ * followed by the 1x1 conv2d_8) -- y = act(bias + sum_rs shift_rs(up(x . w_rs))) straight from x [N, H, W, Cin] and wcatT [9 Cout][Cin] (transpose_flip 7):
+ * a workgroup owns 64 / W images x 16 output channels, streams down the rows of the low-resolution map and keeps the nine planes of the last three rows
+ * in an LDS ring, so Z [N H W][9 Cout] never exists in HBM (2 x 2.4 GB per forward of conv2d_7 at batch 128).  Same products and sums as the two-call
+ * form above (9 of the direct form's 36 per 2x2 output block), exact on every pixel.  Eligible: W in {8, 16, 32, 64}, N a multiple of 64 / W, H >= 2,
+ * Cin a multiple of 32 (>= 64), Cout a multiple of 16.  proj_out != NULL: also proj_out [N, 2H, 2W, proj_cout] = y . proj_w + proj_b (proj_w
+ * [Cout][proj_cout], proj_cout <= 4) through per-slab partial sums in `ws` (ladder_up2proj_fused_workspace_bytes), added in a fixed order; y may then be
+ * NULL (forward-only runs never write the activation). */
+int ladder_up2proj_fused_eligible(int N, int H, int W, int Cin, int Cout);
+size_t ladder_up2proj_fused_workspace_bytes(int N, int H, int W, int Cout, int proj_cout);
+int ladder_up2proj_fused_fwd(const float* x, const float* wcatT, const float* bias, float* y, const float* proj_w, const float* proj_b, float* proj_out,
+                             int proj_cout, int N, int H, int W, int Cin, int Cout, int act, void* ws, size_t ws_bytes, ladder_stream_t stream);
 
 /* (strict fp32, round 5: Cout may be any multiple of 64 and the low-resolution map 16 or 8 pixels wide -- decoder conv2d_5 / conv2d_4,
  * codes/models.py:544-560; the fused projection form stays at Cout = 128)

@@ -52,6 +52,7 @@ __device__ __forceinline__ AxisW up2_axis(int r, int i, int L) {
 #define LADDER_UPPROJ_NT 1
 #endif
 typedef float up_f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_stream(float4* p, float4 v) {
 #if LADDER_UPPROJ_NT
   up_f32x4 t;
@@ -306,6 +307,211 @@ __global__ __launch_bounds__(256) void up2proj_bwd_combine_kernel(const float* _
     }
 }
 
+
+// ---- round 6: the forward pair in ONE launch -- Z never leaves the CU ------------------------------------------------------------------------------------
+// ladder_up2proj_fwd_combine reads back the nine planes Z [M][9 Cout] that the projection GEMM has just written: 2 x 2.4 GB per forward of conv2d_7 at
+// batch 128, 23.7 GB per iteration over all pairs.  Here a workgroup owns (a group of G = 64 / W images, a slab of 16 output
+// channels) and STREAMS DOWN THE ROWS of the low-resolution map:
+//   per row k:  Zrow [64 px][9 x 16] = X_k [64 px][Cin] . wslab [Cin][9 x 16]   -- v_mfma_f32_16x16x4_f32, K in chunks of 32 through double-buffered LDS
+//               (64 px = the row k of G images side by side: W in {8, 16, 32, 64}, so a row step never needs a column halo and the row halo is the ring)
+//               Zrow -> a RING in LDS: planes of tap row 0 keep 3 rows, tap rows 1 / 2 keep 2 (84 KB)
+//               output rows 2(k-1), 2(k-1)+1 of the group are combined from the ring (the elementwise pass of up2proj_fwd_combine_kernel, reading LDS)
+// so the only HBM traffic is x (re-read by the Cout / 16 slabs of a group, which sit next to each other on ONE XCD and share its L2), the weight slab
+// (L2-resident: 9 x 16 x Cin floats) and y.  No halo in either direction: the MFMA work is exactly the projection GEMM's (9 of 36 products).
+// Lane roles: the A operand of the MFMA is the WEIGHT slab (rows = 16 channels of one tap), the B operand the pixels, so a lane ends with 4 consecutive
+// channels of one pixel = one 128-bit ring write; 12 waves = 4 pixel tiles x 3 tap rows, each wave 3 taps (one x fragment feeds 3 MFMAs per k-step).
+// K order inside a 16-deep group is the permutation of gemm_nt16_f32_kernel (both fragments one ds_read_b128 per 4 k-steps).
+// The 1x1 output conv of the last pair (conv2d_8, 128 -> 3) needs all 128 channels of a pixel: every slab writes its PARTIAL projection
+// [slab][pixel][pco] and up2proj_proj_reduce_kernel sums the slabs in a fixed order (+ bias): bit-reproducible, 0.2 GB instead of the 1 GB activation.
+constexpr int UF_PX = 64, UF_CS = 16, UF_N = 9 * UF_CS, UF_K = 32, UF_LD = UF_K + 4, UF_THREADS = 768, UF_PLANE = UF_PX * UF_CS;
+constexpr int UF_RING_PLANES = 3 * 3 + 3 * 2 + 3 * 2;                                 // plane-rows in the ring
+
+__device__ __forceinline__ int uf_ring_base(int r, int s, int row) {
+  // tap row 0 keeps rows i - 1, i and the freshly written i + 1 (3 slots); tap rows 1, 2 keep rows i, i + 1 (2 slots)
+  return r == 0 ? (s * 3 + row % 3) * UF_PLANE : (9 + (r - 1) * 6 + s * 2 + (row & 1)) * UF_PLANE;
+}
+
+template <bool PROJ>
+__global__ __launch_bounds__(UF_THREADS, 3) void up2proj_fused_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wT, const float* __restrict__ bias,
+                                                                          float* __restrict__ y, const float* __restrict__ pw, float* __restrict__ ppart,
+                                                                          const int pco, const int N, const int H, const int W, const int wshift, const int Cin,
+                                                                          const int Cout, const int act) {
+  __shared__ __attribute__((aligned(16))) float Xs[2][UF_PX * UF_LD];
+  __shared__ __attribute__((aligned(16))) float Ws[2][UF_N * UF_LD];
+  __shared__ __attribute__((aligned(16))) float Zr[UF_RING_PLANES * UF_PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, kq = lane >> 4;
+  const int pt = wid & 3, tr = wid >> 2;                                              // pixel tile (16 px) / tap row of this wave
+  const int G = UF_PX >> wshift, ngroups = N / G, nslab = Cout / UF_CS;
+  // workgroup -> (group, slab): the slabs of one group are consecutive workgroups of ONE XCD (workgroup b runs on XCD b % 8), so the group's x rows
+  // are fetched into that L2 once and the two 64-byte halves of every y line are written from the same L2
+  int group, slab;
+  if ((ngroups & 7) == 0) {
+    const int xcd = (int)(blockIdx.x & 7), l = (int)(blockIdx.x >> 3);
+    group = (l / nslab) * 8 + xcd;
+    slab = l % nslab;
+  } else {
+    group = (int)blockIdx.x / nslab;
+    slab = (int)blockIdx.x % nslab;
+  }
+  const int n0 = group * G, c0 = slab * UF_CS;
+  const int cpt = Cin / UF_K, total = H * cpt;
+
+  // loaders: x row k of the group = 64 pixels x 32 floats per chunk (threads 0 .. 511: pixel tid / 8, k quad tid % 8);
+  //          weight slab chunk = 144 rows (tap t, channel c0 + c) x 32 floats (1152 quads over 768 threads: 1.5 rounds)
+  const int xm = (tid >> 3) & 63, xq = tid & 7;
+  const float* xbase = x + ((long)(n0 + (xm >> wshift)) * H * W + (xm & (W - 1))) * Cin + xq * 4;       // + (k W) Cin + c 32
+  const int w_nl0 = tid >> 3, w_nl1 = (tid + UF_THREADS) >> 3;                        // local rows of this thread's two weight items
+  const float* wbase0 = wT + ((long)(w_nl0 >> 4) * Cout + c0 + (w_nl0 & 15)) * Cin + xq * 4;
+  const float* wbase1 = wT + ((long)(w_nl1 >> 4) * Cout + c0 + (w_nl1 & 15)) * Cin + xq * 4;
+  const bool x_on = tid < 512, w1_on = tid + UF_THREADS < UF_N * 8;
+  float4 rx, rw0, rw1;
+  auto load = [&](int g) {
+    const int k = g / cpt, c = g - k * cpt;
+    if (x_on) rx = *reinterpret_cast<const float4*>(xbase + (long)k * W * Cin + c * UF_K);
+    rw0 = *reinterpret_cast<const float4*>(wbase0 + c * UF_K);
+    if (w1_on) rw1 = *reinterpret_cast<const float4*>(wbase1 + c * UF_K);
+  };
+  auto store = [&](int buf) {
+    if (x_on) *reinterpret_cast<float4*>(&Xs[buf][xm * UF_LD + xq * 4]) = rx;
+    *reinterpret_cast<float4*>(&Ws[buf][w_nl0 * UF_LD + xq * 4]) = rw0;
+    if (w1_on) *reinterpret_cast<float4*>(&Ws[buf][w_nl1 * UF_LD + xq * 4]) = rw1;
+  };
+
+  // combination role of threads 0 .. 511: (pixel m, channel quad q, output-row parity a)
+  const int cq = tid & 3, cm = (tid >> 2) & 63, ca = (tid >> 8) & 1;
+  const int cg = cm >> wshift, cj = cm & (W - 1);
+  const bool c_on = tid < 512;
+  AxisW S[3];
+#pragma unroll
+  for (int sx = 0; sx < 3; ++sx) S[sx] = up2_axis(sx, cj, W);
+  const float4 bv = bias != nullptr ? *reinterpret_cast<const float4*>(bias + c0 + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 pwv[4];
+  if (PROJ) {
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      const float* pr = pw + (long)(c0 + cq * 4 + c4) * pco;
+      pwv[c4] = make_float4(pr[0], pco > 1 ? pr[1] : 0.f, pco > 2 ? pr[2] : 0.f, pco > 3 ? pr[3] : 0.f);
+    }
+  }
+  const float4* Zq = reinterpret_cast<const float4*>(Zr) + cq;                        // + (plane base + pixel * 16) / 4
+  auto combine = [&](const int i) {                                                   // output rows 2 i + ca of the group, from the ring
+    if (!c_on) return;
+    float4 o0 = bv, o1 = bv;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const AxisW R = up2_axis(r, i, H);
+      const float wl = ca ? R.wlo[1] : R.wlo[0], wh = ca ? R.whi[1] : R.whi[0];      // (selects: a runtime index would put the struct in scratch)
+#pragma unroll
+      for (int sx = 0; sx < 3; ++sx) {
+        const int plo = (cg << wshift) + S[sx].lo, phi = (cg << wshift) + S[sx].hi;
+        if (wl != 0.f) {                                                              // (wave-uniform: i and ca are)
+          const float4* zp = Zq + (uf_ring_base(r, sx, R.lo) >> 2);
+          const float4 v0 = zp[plo * 4], v1 = zp[phi * 4];
+          o0 = f4_fma(wl * S[sx].wlo[0], v0, o0); o0 = f4_fma(wl * S[sx].whi[0], v1, o0);
+          o1 = f4_fma(wl * S[sx].wlo[1], v0, o1); o1 = f4_fma(wl * S[sx].whi[1], v1, o1);
+        }
+        if (wh != 0.f) {
+          const float4* zp = Zq + (uf_ring_base(r, sx, R.hi) >> 2);
+          const float4 v0 = zp[plo * 4], v1 = zp[phi * 4];
+          o0 = f4_fma(wh * S[sx].wlo[0], v0, o0); o0 = f4_fma(wh * S[sx].whi[0], v1, o0);
+          o1 = f4_fma(wh * S[sx].wlo[1], v0, o1); o1 = f4_fma(wh * S[sx].whi[1], v1, o1);
+        }
+      }
+    }
+    o0 = make_float4(ladder_act_fn(o0.x, act), ladder_act_fn(o0.y, act), ladder_act_fn(o0.z, act), ladder_act_fn(o0.w, act));
+    o1 = make_float4(ladder_act_fn(o1.x, act), ladder_act_fn(o1.y, act), ladder_act_fn(o1.z, act), ladder_act_fn(o1.w, act));
+    const long opix = ((long)(n0 + cg) * 2 * H + 2 * i + ca) * 2 * W + 2 * cj;          // output pixel of column parity 0; parity 1 is the next one
+    if (y != nullptr) {
+      float4* yp = reinterpret_cast<float4*>(y + opix * Cout + c0) + cq;
+      st_stream(yp, o0);
+      st_stream(yp + (Cout >> 2), o1);
+    }
+    if (PROJ) {
+      float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
+      p0 = f4_fma(o0.x, pwv[0], p0); p0 = f4_fma(o0.y, pwv[1], p0); p0 = f4_fma(o0.z, pwv[2], p0); p0 = f4_fma(o0.w, pwv[3], p0);
+      p1 = f4_fma(o1.x, pwv[0], p1); p1 = f4_fma(o1.y, pwv[1], p1); p1 = f4_fma(o1.z, pwv[2], p1); p1 = f4_fma(o1.w, pwv[3], p1);
+      float pv[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {                                                   // the 4 quads of a pixel are 4 consecutive lanes: fixed-order sum
+        pv[e] += __shfl_xor(pv[e], 1, 64);
+        pv[e] += __shfl_xor(pv[e], 2, 64);
+      }
+      if (cq == 0) {
+        float* pp = ppart + ((long)slab * N * 4 * H * W + opix) * pco;
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+          if (o < pco) { pp[o] = pv[o]; pp[pco + o] = pv[4 + o]; }
+      }
+    }
+  };
+
+  f32x4_t acc[3];
+#pragma unroll
+  for (int sx = 0; sx < 3; ++sx)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[sx][e] = 0.f;
+  load(0);
+  store(0);
+  __syncthreads();
+  const int x_off = (pt * 16 + r16) * UF_LD + 4 * kq, w_off = (tr * 3 * 16 + r16) * UF_LD + 4 * kq;
+  int k = 0, c = 0;
+  for (int g = 0; g < total; ++g) {
+    const int buf = g & 1;
+    if (g + 1 < total) load(g + 1);
+    {
+      const float* Xb = &Xs[buf][x_off];
+      const float* Wb = &Ws[buf][w_off];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float4 fx = *reinterpret_cast<const float4*>(Xb + 16 * u);
+        float4 fw[3];
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx) fw[sx] = *reinterpret_cast<const float4*>(Wb + sx * 16 * UF_LD + 16 * u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float b = j == 0 ? fx.x : (j == 1 ? fx.y : (j == 2 ? fx.z : fx.w));
+#pragma unroll
+          for (int sx = 0; sx < 3; ++sx) {
+            const float a = j == 0 ? fw[sx].x : (j == 1 ? fw[sx].y : (j == 2 ? fw[sx].z : fw[sx].w));
+            acc[sx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[sx], 0, 0, 0);
+          }
+        }
+      }
+    }
+    const bool row_done = c == cpt - 1;
+    if (row_done) {
+      // row k of the nine planes -> ring (lane: pixel pt 16 + r16, channels 4 kq .. + 3 of tap (tr, sx)).  The readers of the slot being overwritten
+      // (the combination of block row k - 2) finished before the barrier of this row's first chunk: needs cpt >= 2 (launcher)
+#pragma unroll
+      for (int sx = 0; sx < 3; ++sx) {
+        *reinterpret_cast<float4*>(&Zr[uf_ring_base(tr, sx, k) + (pt * 16 + r16) * UF_CS + 4 * kq]) = make_float4(acc[sx][0], acc[sx][1], acc[sx][2], acc[sx][3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[sx][e] = 0.f;
+      }
+    }
+    if (g + 1 < total) store(buf ^ 1);
+    __syncthreads();
+    if (row_done) {
+      if (k >= 1) combine(k - 1);
+      ++k;
+      c = 0;
+    } else {
+      ++c;
+    }
+  }
+  combine(H - 1);                                                                     // the last block row: its "row below" is the clamped last row itself
+}
+
+// pout [P][pco] = pb + sum over the slabs (in order) of the partial projections [nslab][P][pco]
+__global__ __launch_bounds__(256) void up2proj_proj_reduce_kernel(const float* __restrict__ ppart, const float* __restrict__ pb, float* __restrict__ pout,
+                                                                  const long total, const int pco, const int nslab) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  float sacc = pb != nullptr ? pb[t % pco] : 0.f;
+  for (int sl = 0; sl < nslab; ++sl) sacc += ppart[(long)sl * total + t];
+  pout[t] = sacc;
+}
+
 // dw [3][3][Cin][Cout] from dWcat [Cin][9 Cout]; db [Cout] (may be NULL) = the centre tap's column sums of D = sum over all pixels of dy
 __global__ __launch_bounds__(256) void up2proj_wgrad_unpack_kernel(const float* __restrict__ dwcat, const float* __restrict__ db9, float* __restrict__ dw,
                                                                    float* __restrict__ db, const int Cin, const int Cout) {
@@ -490,6 +696,45 @@ int ladder_upfproj_bwd_combine(const float* dy, float* d, int factor, int N, int
   if (!ladder_aligned16(dy) || !ladder_aligned16(d)) return LADDER_E_ALIGN;
   const long total = (long)N * H * W * (C / 4);
   hipLaunchKernelGGL(upfproj_bwd_combine_kernel<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dy, d, N, H, W, C);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+// ---- the fused forward of a pair (round 6) -------------------------------------------------------------------------------------------------------------
+// y [N, 2H, 2W, Cout] = act(bias + sum_rs shift_rs(up(x . w_rs))) straight from x [N, H, W, Cin] and wcatT [9 Cout][Cin] (orientation 7 of filterbank.h):
+// the nine planes live only in LDS.  proj_out != NULL: also the 1x1 conv of the activated value (proj_w [Cout][proj_cout], proj_cout <= 4) through
+// per-slab partials in `ws`; y may then be NULL (forward-only runs).
+int ladder_up2proj_fused_eligible(int N, int H, int W, int Cin, int Cout) {
+  static const bool off = getenv("LADDER_DISABLE_UP2FUSE") != nullptr;
+  if (off || N <= 0 || H < 2 || Cin < 2 * UF_K || (Cin % UF_K) != 0 || (Cout % UF_CS) != 0) return 0;
+  if (W != 8 && W != 16 && W != 32 && W != 64) return 0;
+  if (N % (UF_PX / W) != 0 || (long)N * H * W * 4 >= (1L << 30)) return 0;
+  return 1;
+}
+
+size_t ladder_up2proj_fused_workspace_bytes(int N, int H, int W, int Cout, int proj_cout) {
+  return proj_cout > 0 ? (size_t)(Cout / UF_CS) * N * 4 * H * W * proj_cout * sizeof(float) : 0;
+}
+
+int ladder_up2proj_fused_fwd(const float* x, const float* wcatT, const float* bias, float* y, const float* proj_w, const float* proj_b, float* proj_out,
+                             int proj_cout, int N, int H, int W, int Cin, int Cout, int act, void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  if (!ladder_up2proj_fused_eligible(N, H, W, Cin, Cout) || x == nullptr || wcatT == nullptr || (y == nullptr && proj_out == nullptr)) return LADDER_E_SHAPE;
+  if (proj_out != nullptr && (proj_w == nullptr || proj_cout < 1 || proj_cout > 4)) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(x) || !ladder_aligned16(wcatT) || !ladder_aligned16(y) || (bias != nullptr && !ladder_aligned16(bias))) return LADDER_E_ALIGN;
+  if (proj_out != nullptr && (ws == nullptr || ws_bytes < ladder_up2proj_fused_workspace_bytes(N, H, W, Cout, proj_cout))) return LADDER_E_WORKSPACE;
+  int wshift = 3;
+  while ((1 << wshift) < W) ++wshift;
+  const unsigned grid = (unsigned)(N / (UF_PX / W)) * (unsigned)(Cout / UF_CS);
+  if (proj_out != nullptr) {
+    hipLaunchKernelGGL(up2proj_fused_fwd_kernel<true>, dim3(grid), dim3(UF_THREADS), 0, stream, x, wcatT, bias, y, proj_w, (float*)ws, proj_cout, N, H, W, wshift, Cin,
+                       Cout, act);
+    const long total = (long)N * 4 * H * W * proj_cout;
+    hipLaunchKernelGGL(up2proj_proj_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const float*)ws, proj_b, proj_out, total, proj_cout,
+                       Cout / UF_CS);
+  } else {
+    hipLaunchKernelGGL(up2proj_fused_fwd_kernel<false>, dim3(grid), dim3(UF_THREADS), 0, stream, x, wcatT, bias, y, (const float*)nullptr, (float*)nullptr, 0, N, H, W,
+                       wshift, Cin, Cout, act);
+  }
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

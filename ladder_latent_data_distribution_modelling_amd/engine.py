@@ -50,6 +50,9 @@ class KernelProfiler:
                    "per workgroup, 32-pixel chunks, software-pipelined LDS fragments, fp32 MFMA 32x32x2)",
              128132: "gemm_f32_kernel (projection GEMMs of the project-then-upsample pairs, Z = x . wcat: persistent workgroups over 128x128 "
                      "tiles, XCD-aware tile order, 32-deep chunks, 128-bit A fragments, software-pipelined LDS reads, fp32 MFMA 32x32x2)",
+             128136: "up2proj_fused_fwd_kernel (forward of a project-then-upsample pair in ONE launch: per (64 / W images, 16 output channels) workgroup the "
+                     "projection GEMM Z = x . wcat row by row on fp32 MFMA 16x16x4, the nine planes of three rows in an LDS ring, the combination + activation "
+                     "(+ 1x1 output projection) from the ring; Z never written to HBM)",
              128134: "gemm_nt16_f32_kernel (backward-data GEMMs of the project-then-upsample pairs, dx = D . wcat^T with both operands K-contiguous: persistent "
                      "workgroups over 128x128 tiles, 128-bit fragments of both operands, fp32 MFMA 16x16x4)",
              7700: "gmm_logprob_kernel<R> + gmm_sum_kernel (mixture log-prob / responsibilities, lane = component, wave-shuffle logsumexp)"}
@@ -405,6 +408,7 @@ class Ctx:
         self.ns = 0          # LADDER_PREC_* of the split-precision contraction kernels (0 = native f32 MFMA); set by the engine
         self.up2_used = {}   # layer name -> number of upsample-fused launches so far (bench.py's executed-FLOP model)
         self.up2_skipped = {}  # ... and the fraction of the reference's products such a launch never issues (11 / 36 tap-folded, 27 / 36 projected)
+        self.fuse_fwd = True  # projected pairs: forward GEMM + combination in one launch (config `fused_projected_forward`, default 1)
         self.up2 = True      # resize -> 3x3 conv pairs of the decoder as ONE upsample-fused convolution in forward-only runs (config `upsample_fused_convs`)
 
     @property
@@ -810,11 +814,31 @@ class Conv2D:
         ukey = self.name + (":train" if keep_y else "")
         ctx.up2_used[ukey] = ctx.up2_used.get(ukey, 0) + 1
         ctx.up2_skipped[ukey] = 1.0 - 1.0 / (f * f)
+        bias = self.ps.w[self.name + "/bias"]
+        if f == 2 and ctx.fuse_fwd and L.query("ladder_up2proj_fused_eligible", N, H, W, self.cin, self.cout):
+            # round 6: GEMM + combination in ONE launch, the nine planes in an LDS ring (csrc/upproj.hip: up2proj_fused_fwd_kernel) -- Z never reaches HBM
+            y = ctx.empty(N, 2 * H, 2 * W, self.cout) if (keep_y or proj is None) else None
+            out, pw, pb, pco = y, None, None, 0
+            if proj is not None:
+                proj.pt = proj.pl = 0
+                out, pco = ctx.empty(N, 2 * H, 2 * W, proj.cout), proj.cout
+                pw, pb = self.ps.w[proj.name + "/kernel"], self.ps.w[proj.name + "/bias"]
+                proj.x, proj.y = (y, out) if keep_y else (None, None)
+            nb = L.query("ladder_up2proj_fused_workspace_bytes", N, H, W, self.cout, pco)
+            wsp, wsn = ctx.ws(nb) if nb else (None, 0)
+            _timed(128136, flops, "ladder_up2proj_fused_fwd",
+                   (_p(x), _p(self._packed_filter(7)), _p(bias), _p(y), _p(pw), _p(pb), _p(out) if proj is not None else None, pco, N, H, W, self.cin, self.cout,
+                    L.ACT[self.act], wsp, wsn, st), executed)
+            self.x_amax = None
+            self.lo_factor = f
+            self.x, self.y = ((upsampled if upsampled is not None else x), y) if keep_y else (None, None)
+            self.x_is_up2 = bool(keep_y and upsampled is not None)
+            self.x_is_lo = bool(keep_y and upsampled is None)
+            return out
         z = ctx.empty(M, n9)
         wsp, wsn = ctx.ws(L.query("ladder_igemm_fwd_workspace_bytes", M, self.cin, n9))
         _timed(128132 if L.query("ladder_dense_fwd_is_persistent", M, self.cin, n9) else abs(L.query("ladder_igemm_fwd_tile", M, self.cin, n9)), flops, "ladder_dense_fwd",
                (_p(x), _p(self._packed_filter(6)), None, _p(z), M, self.cin, n9, 0, wsp, wsn, st), executed)
-        bias = self.ps.w[self.name + "/bias"]
         if proj is not None:
             proj.pt = proj.pl = 0
             y = ctx.empty(N, 2 * H, 2 * W, self.cout) if keep_y else None
@@ -1879,6 +1903,7 @@ class LadderEngine:
         # 0: off, 1: forward-only runs, 2: also the training forward and the backward-data of the last 3x3 conv, 3: also conv2d_6's backward-data (no gain measured)
         # (strict fp32 default 3: with the fp32 MFMA the 11 / 36 of conv2d_6's backward-data outweigh its border strips, +0.5 %; f16x3: no gain, 2)
         self.ctx.up2 = int(cfg.get("upsample_fused_convs", 4 if prec == "f32" else 2))
+        self.ctx.fuse_fwd = bool(int(cfg.get("fused_projected_forward", 1)))
         self.precision = prec
         if self.ctx.comm.rank == 0:
             print("Contraction precision (config key matmul_precision): {} -- {}".format(prec, PRECISION_NOTES[prec]))

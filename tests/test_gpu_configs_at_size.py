@@ -440,8 +440,8 @@ def test_celeba_configs2_full_batch_128_vs_float64_oracle():
     float64 oracle evaluated live on the same 128 images, parameters and noise (~75 GB and a few minutes of host time: the GPU hosts have 3 TB) --
     not against another build of the same library.  RUN#1 (reference codes/base.py:587-594): every fetched scalar to 2e-5 (ELBO bar of
     BASELINE.json: 1e-3), the reconstruction to 2e-5 of its range, and the filter gradients of the layers that carry the step -- conv2d_7,
-    conv2d_6 (projected pairs at their largest maps), the 1x1 output conv, the image-side encoder conv and the first dense layer -- in relative
-    L2 (3e-3) and in max norm (1.5e-3 of the tensor scale; measured values are printed)."""
+    conv2d_6, conv2d_5 (projected pairs at their largest maps), the 1x1 output conv, the two image-side encoder convs and the first dense layer -- in
+    relative L2 and in max norm against per-tensor bars (a few times the measured values, which are printed)."""
     import time
     from ladder_latent_data_distribution_modelling_amd.engine import LadderEngine
     cfg = _cfg("celeba_config.json")
@@ -457,8 +457,13 @@ def test_celeba_configs2_full_batch_128_vs_float64_oracle():
     eng.run_ae(x, 0.0, noise, False, False)
     f = eng.fetch()
     xhat = eng.xhat.cpu().numpy().astype(np.float64)
-    names = ["decoder/conv2d_7/kernel", "decoder/conv2d_6/kernel", "decoder/conv2d_8/kernel", "decoder/conv2d_8/bias", "encoder/conv2d/kernel",
-             "decoder/dense/kernel"]
+    # name -> (bar on the relative L2 error, bar on max error / tensor scale); measured on MI355X (round 6): conv2d_7 9.9e-6 / 1.3e-5, conv2d_6 7.0e-5 / 9.7e-5,
+    # conv2d_8 4.5e-6 / 6.9e-6, encoder/conv2d 1.3e-3 / 1.3e-3, decoder/dense 6.4e-4 / 7.2e-4 (the deep tensors collect every leaky-ReLU pre-activation that
+    # float64 and fp32 put on different sides of zero)
+    bars = {"decoder/conv2d_7/kernel": (1e-4, 1e-4), "decoder/conv2d_6/kernel": (5e-4, 5e-4), "decoder/conv2d_5/kernel": (2e-3, 2e-3),
+            "decoder/conv2d_8/kernel": (5e-5, 5e-5), "decoder/conv2d_8/bias": (5e-5, 5e-5), "encoder/conv2d/kernel": (5e-3, 5e-3),
+            "encoder/conv2d_1/kernel": (5e-3, 5e-3), "decoder/dense/kernel": (3e-3, 3e-3)}
+    names = list(bars)
     got = {n: eng.ps.g[n].cpu().numpy().astype(np.float64) for n in names}
     del eng
     torch.cuda.empty_cache()
@@ -471,10 +476,10 @@ def test_celeba_configs2_full_batch_128_vs_float64_oracle():
     dec = np.asarray(ref["decoded"], np.float64)
     err = np.abs(xhat - dec).max() / np.abs(dec).max()
     print("reconstruction: max error / range = %.2e" % err)
-    assert err < 2e-5
+    assert err < 5e-5                                      # (measured 1.6e-5)
     for n in names:
         g = np.asarray(ref["_grads"][n], np.float64).reshape(got[n].shape)
         l2 = np.linalg.norm(got[n] - g) / np.linalg.norm(g)
         mx = np.abs(got[n] - g).max() / np.abs(g).max()
         print("%-28s rel L2 %.2e   max / scale %.2e" % (n, l2, mx))
-        assert l2 < 3e-3 and mx < 1.5e-3, (n, l2, mx)
+        assert l2 < bars[n][0] and mx < bars[n][1], (n, l2, mx)

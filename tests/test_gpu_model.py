@@ -430,7 +430,9 @@ np.savez(sys.argv[1], fetch=json.dumps(out), **{k.replace("/", "."): v for k, v 
 IN_SITU_BARS = {
     # strict-fp32 default (round 5: projected resize -> conv pairs on the persistent fp32 GEMMs, small-map halo kernels, epilogue batch-norm
     # statistics): the SAME arithmetic as the yardstick with other summation orders -- its own bars, 3x what was measured on MI355X (round 6)
-    "f32-default": (2e-6, 2e-3, 1e-4, 3e-4, 1e-4, 5e-2),
+    # (measured: RUN#1 1.2e-6, RUN#3 4.7e-4, |g| 8.7e-5, sum |g| 1.5e-4, conv2d_7 gradients 1.6e-5, deeper gradients 2.8e-2 -- the last one is mask flips of
+    # pre-activations within rounding of zero, not accuracy: against float64 the same tensors sit at 1e-3, see the batch-128 oracle test)
+    "f32-default": (4e-6, 1.5e-3, 3e-4, 5e-4, 5e-5, 8e-2),
     # 16-bit split formats (opt-in): every contraction rounds its operands to 22 / 24 bits
     "f16x3": (2e-6, 2e-3, 1e-4, 3e-4, 1e-4, 5e-2),
     "bf16x6": (2e-6, 2e-3, 1e-4, 3e-4, 1e-4, 5e-2),

@@ -266,3 +266,77 @@ def test_persistent_dense_filter_gradient_vs_float64(gpu_ctx, shape):
     close(outs[0][0], x.astype(np.float64).T @ dy.astype(np.float64), TOL32, "dw")
     close(outs[0][1], dy.astype(np.float64).sum(0), TOL32, "db")
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+# ---- round 6: the fused forward (Z in an LDS ring, csrc/upproj.hip: up2proj_fused_fwd_kernel) ------------------------------------------------------------
+# (N, H, W, Cin, Cout, act): every eligible width (8 / 16 / 32 / 64 -> 8 / 4 / 2 / 1 images per row step), H = 2 (one ring turn) ... 64, non-square maps,
+# several slabs, Cin = 64 (two chunks: the minimum) ... 512
+FUSED_CASES = [(2, 64, 64, 128, 128, "leaky_relu"), (4, 32, 32, 256, 128, "leaky_relu"), (8, 16, 16, 256, 256, None), (16, 8, 8, 512, 256, "leaky_relu"),
+               (8, 2, 8, 64, 16, None), (2, 3, 32, 96, 48, "leaky_relu"), (1, 5, 64, 64, 32, None), (12, 7, 16, 64, 16, "leaky_relu")]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES, ids=lambda c: "n%d_%dx%d_c%d_co%d_%s" % c)
+def test_upproj_fused_forward_vs_oracle(gpu_ctx, case):
+    """ladder_up2proj_fused_fwd against the float64 oracle's resize + convolution on every pixel (all four borders, image boundaries inside a row step),
+    and against the two-call form (GEMM + combination) it replaces: same products, another summation order -> the same 3e-6 bar."""
+    L = _lib()
+    N, H, W, cin, cout, act = case
+    st = gpu_ctx.stream
+    assert L.query("ladder_up2proj_fused_eligible", N, H, W, cin, cout) == 1
+    rng = np.random.default_rng(H * 100 + cin + cout + N)
+    x = rng.standard_normal((N, H, W, cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32) * 0.1
+    wcat, wcatT = _pack(L, w, st)
+    y = torch.full((N, 2 * H, 2 * W, cout), float("nan"), device="cuda")
+    L.call("ladder_up2proj_fused_fwd", p(dev(x)), p(wcatT), p(dev(b)), p(y), None, None, None, 0, N, H, W, cin, cout, 1 if act else 0, None, 0, st)
+    ref = _ref_fwd(x, w, b, act)
+    close(y, ref, TOL32, "y (every pixel)")
+    y2, _ = _forward(L, dev(x), wcat, dev(b), N, H, W, cin, cout, 1 if act else 0, st)
+    close(y, y2.cpu().numpy().astype(np.float64), TOL32, "fused vs two-call form")
+    # bit-reproducible: a second launch gives the identical tensor
+    y3 = torch.full_like(y, float("nan"))
+    L.call("ladder_up2proj_fused_fwd", p(dev(x)), p(wcatT), p(dev(b)), p(y3), None, None, None, 0, N, H, W, cin, cout, 1 if act else 0, None, 0, st)
+    assert torch.equal(y, y3)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 128, 128, 3, True), (4, 32, 32, 64, 128, 3, False), (8, 4, 16, 64, 64, 4, True), (8, 6, 8, 96, 32, 1, False)],
+                         ids=lambda c: "n%d_%dx%d_c%d_co%d_p%d_y%d" % c)
+def test_upproj_fused_forward_with_projection_vs_oracle(gpu_ctx, case):
+    """... with the 1x1 output conv through per-slab partial sums (any Cout that is a multiple of 16, proj_cout <= 4), with and without the y write."""
+    L = _lib()
+    N, H, W, cin, cout, pco, keep_y = case
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(H + cin + pco)
+    x = rng.standard_normal((N, H, W, cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32) * 0.1
+    pw_ = (rng.standard_normal((cout, pco)) / np.sqrt(cout)).astype(np.float32)
+    pb_ = rng.standard_normal(pco).astype(np.float32) * 0.1
+    _, wcatT = _pack(L, w, st)
+    y = torch.full((N, 2 * H, 2 * W, cout), float("nan"), device="cuda") if keep_y else None
+    out = torch.full((N, 2 * H, 2 * W, pco), float("nan"), device="cuda")
+    ws = _ws(L.query("ladder_up2proj_fused_workspace_bytes", N, H, W, cout, pco))
+    L.call("ladder_up2proj_fused_fwd", p(dev(x)), p(wcatT), p(dev(b)), p(y), p(dev(pw_)), p(dev(pb_)), p(out), pco, N, H, W, cin, cout, 1, p(ws), ws.numel(), st)
+    ref = _ref_fwd(x, w, b, "leaky_relu")
+    close(out, ref @ pw_.astype(np.float64) + pb_.astype(np.float64), TOL32, "projection")
+    if keep_y:
+        close(y, ref, TOL32, "map")
+
+
+def test_upproj_fused_eligibility_and_errors(gpu_ctx):
+    L = _lib()
+    q = lambda *a: L.query("ladder_up2proj_fused_eligible", *a)
+    assert q(128, 64, 64, 128, 128) == 1 and q(128, 32, 32, 256, 128) == 1 and q(128, 16, 16, 256, 256) == 1 and q(128, 8, 8, 512, 256) == 1
+    assert q(128, 1, 8, 512, 512) == 0          # one row: no ring turn
+    assert q(3, 8, 8, 512, 256) == 0            # 8 images per row step
+    assert q(8, 8, 8, 32, 16) == 0              # one K chunk (the ring hand-over needs two barriers per row)
+    assert q(8, 8, 12, 64, 16) == 0 and q(8, 8, 8, 64, 24) == 0 and q(8, 8, 8, 72, 16) == 0
+    from ladder_latent_data_distribution_modelling_amd._lib import LadderHipError
+    x = torch.zeros(8, 8, 8, 64, device="cuda")
+    wT = torch.zeros(9 * 16, 64, device="cuda")
+    y = torch.zeros(8, 16, 16, 16, device="cuda")
+    with pytest.raises(LadderHipError, match="LADDER_E_SHAPE"):
+        L.call("ladder_up2proj_fused_fwd", p(x), p(wT), None, None, None, None, None, 0, 8, 8, 8, 64, 16, 0, None, 0, gpu_ctx.stream)      # nothing to write
+    with pytest.raises(LadderHipError, match="LADDER_E_WORKSPACE"):
+        L.call("ladder_up2proj_fused_fwd", p(x), p(wT), None, p(y), p(wT), None, p(y), 3, 8, 8, 8, 64, 16, 0, None, 0, gpu_ctx.stream)      # projection without workspace
