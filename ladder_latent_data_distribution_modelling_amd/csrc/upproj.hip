@@ -312,35 +312,72 @@ __global__ __launch_bounds__(256) void up2proj_bwd_combine_kernel(const float* _
 // ladder_up2proj_fwd_combine reads back the nine planes Z [M][9 Cout] that the projection GEMM has just written: 2 x 2.4 GB per forward of conv2d_7 at
 // batch 128, 23.7 GB per iteration over all pairs.  Here a workgroup owns (a group of G = 64 / W images, a slab of 16 output
 // channels) and STREAMS DOWN THE ROWS of the low-resolution map:
-//   per row k:  Zrow [64 px][9 x 16] = X_k [64 px][Cin] . wslab [Cin][9 x 16]   -- v_mfma_f32_16x16x4_f32, K in chunks of 32 through double-buffered LDS
-//               (64 px = the row k of G images side by side: W in {8, 16, 32, 64}, so a row step never needs a column halo and the row halo is the ring)
-//               Zrow -> a RING in LDS: planes of tap row 0 keep 3 rows, tap rows 1 / 2 keep 2 (84 KB)
-//               output rows 2(k-1), 2(k-1)+1 of the group are combined from the ring (the elementwise pass of up2proj_fwd_combine_kernel, reading LDS)
+//   per row k:  Zrow [64 px][9 x 16] = X_k [64 px][Cin] . wslab [Cin][9 x 16]   -- v_mfma_f32_16x16x4_f32, K in chunks of 32 through a 3-stage LDS pipeline
+//               (64 px = row k of G images side by side: W in {8, 16, 32, 64}, so a row step never needs a column halo)
+//               Zrow -> ONE row of the nine planes in LDS (36 KB); the combination threads read it once, fold it along the columns into six values per
+//               (pixel, 4 channels) -- H_r^b = sum_s up-weights x Z_rs, tap row r, output-column parity b -- and keep the folded rows k - 1, k - 2 in
+//               REGISTERS: output rows 2(k-1), 2(k-1) + 1 are sums of <= 6 of those (18 LDS reads per row and thread instead of the 54 of a version
+//               that re-read three rows of a ring, and the row halo costs no LDS at all)
 // so the only HBM traffic is x (re-read by the Cout / 16 slabs of a group, which sit next to each other on ONE XCD and share its L2), the weight slab
 // (L2-resident: 9 x 16 x Cin floats) and y.  No halo in either direction: the MFMA work is exactly the projection GEMM's (9 of 36 products).
+//
+// ROLES (one workgroup per CU, 12 waves).  Waves 0-3 = one per SIMD -- do nothing but LDS fragment reads and MFMAs: wave w owns pixel tile w (16 px) and
+// all nine taps (one x fragment feeds 9 MFMAs per k-step; 9 independent accumulators keep the matrix pipe issuing back to back; the fragments of the
+// next 16-deep group -- across chunk and row boundaries -- are requested before the 36 MFMAs of the current one).  Waves 4-7 stage the x / weight chunks
+// (global -> registers three chunks ahead -> LDS, three stages); waves 8-11 combine.  The three sides never meet at an s_barrier: they hand stages over
+// through LDS counters (full / empty per stage, row written / row read for the plane row).  Measured on the way (profiles/r06_fused_*.txt, conv2d_7):
+// one __syncthreads per chunk + combination behind the row's last chunk 2 115 us (two launches: 2 052); specialised waves but the stage released after
+// its last MFMA 2 030 (a hand-over is two LDS round trips through a busy queue, ~1 000 cycles a hop: the chain was serial with the MFMAs); released as
+// soon as its last fragment read has returned 1 971; the 3-row ring and its 54 reads per thread cost 350 us of that.
 // Lane roles: the A operand of the MFMA is the WEIGHT slab (rows = 16 channels of one tap), the B operand the pixels, so a lane ends with 4 consecutive
-// channels of one pixel = one 128-bit ring write; 12 waves = 4 pixel tiles x 3 tap rows, each wave 3 taps (one x fragment feeds 3 MFMAs per k-step).
-// K order inside a 16-deep group is the permutation of gemm_nt16_f32_kernel (both fragments one ds_read_b128 per 4 k-steps).
+// channels of one pixel = one 128-bit LDS write.  K order inside a 16-deep group is the permutation of gemm_nt16_f32_kernel (both fragments one
+// ds_read_b128 per 4 k-steps).
 // The 1x1 output conv of the last pair (conv2d_8, 128 -> 3) needs all 128 channels of a pixel: every slab writes its PARTIAL projection
 // [slab][pixel][pco] and up2proj_proj_reduce_kernel sums the slabs in a fixed order (+ bias): bit-reproducible, 0.2 GB instead of the 1 GB activation.
-constexpr int UF_PX = 64, UF_CS = 16, UF_N = 9 * UF_CS, UF_K = 32, UF_LD = UF_K + 4, UF_THREADS = 768, UF_PLANE = UF_PX * UF_CS;
-constexpr int UF_RING_PLANES = 3 * 3 + 3 * 2 + 3 * 2;                                 // plane-rows in the ring
+//
+// UF_LD = 40: the fragment read of lane (r16, kq) is a 16-byte piece of row r16 at float offset 16 u + 4 kq; ds_read_b128 is serviced in the lane groups
+// {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+ 32): eight rows of one kq and the OTHER eight rows of the next.  With 40-float rows the first eight
+// land on even 16-byte bank groups and the second eight on odd ones (r x 10 mod 16 is even): conflict-free; 36-float rows are 2-way conflicted in 7 of 8.
+constexpr int UF_PX = 64, UF_CS = 16, UF_N = 9 * UF_CS, UF_K = 32, UF_LD = UF_K + 8, UF_THREADS = 768, UF_PLANE = UF_PX * UF_CS;
+constexpr int UF_STAGES = 3;
+constexpr int UF_MW = 4, UF_SW = 4, UF_CW = 4;                                           // MFMA / staging / combination waves
+enum { UF_FULL0 = 0, UF_EMPTY0 = UF_STAGES, UF_ZFULL = 2 * UF_STAGES, UF_CDONE = 2 * UF_STAGES + 1, UF_NFLAGS = 2 * UF_STAGES + 2 };
 
-__device__ __forceinline__ int uf_ring_base(int r, int s, int row) {
-  // tap row 0 keeps rows i - 1, i and the freshly written i + 1 (3 slots); tap rows 1, 2 keep rows i, i + 1 (2 slots)
-  return r == 0 ? (s * 3 + row % 3) * UF_PLANE : (9 + (r - 1) * 6 + s * 2 + (row & 1)) * UF_PLANE;
+// counters in LDS: the whole wave calls; its LDS reads / writes so far have completed before lane 0 bumps the counter (DS operations of a wave are
+// processed in order, and the counter is only ever read after the data accesses it publishes)
+__device__ __forceinline__ void uf_signal(int* f) {
+  // (the fence pins the MFMAs of the block in front of the hand-over: they are not memory operations, and the compiler otherwise sinks them below the
+  // wait -- which then sits in front of the matrix block and exposes the latency of the fragment reads just issued for the next chunk)
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int uf_peek(int* f) {
+  const int v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+  return v;
+}
+__device__ __forceinline__ void uf_wait(int* f, const int target) {
+  int spins = 0;
+  while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1 << 22)) __builtin_trap();                                        // (a hand-over that never comes is a bug: abort the launch, never hang the device)
+  }
+  asm volatile("" ::: "memory");
 }
 
 template <bool PROJ>
 __global__ __launch_bounds__(UF_THREADS, 3) void up2proj_fused_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wT, const float* __restrict__ bias,
                                                                           float* __restrict__ y, const float* __restrict__ pw, float* __restrict__ ppart,
                                                                           const int pco, const int N, const int H, const int W, const int wshift, const int Cin,
-                                                                          const int Cout, const int act) {
-  __shared__ __attribute__((aligned(16))) float Xs[2][UF_PX * UF_LD];
-  __shared__ __attribute__((aligned(16))) float Ws[2][UF_N * UF_LD];
-  __shared__ __attribute__((aligned(16))) float Zr[UF_RING_PLANES * UF_PLANE];
+                                                                          const int Cout, const int act, const int dbg) {
+  // dbg (ablation switches of profiles/tools/r6_fused_probe.py, 0 in production): 1 = the combination waves only hand the row over (no reads, no stores),
+  // 2 = the staging waves issue no global loads
+  __shared__ __attribute__((aligned(16))) float Xs[UF_STAGES][UF_PX * UF_LD];
+  __shared__ __attribute__((aligned(16))) float Ws[UF_STAGES][UF_N * UF_LD];
+  __shared__ __attribute__((aligned(16))) float Zr[9 * UF_PLANE];
+  __shared__ int flags[UF_NFLAGS];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, kq = lane >> 4;
-  const int pt = wid & 3, tr = wid >> 2;                                              // pixel tile (16 px) / tap row of this wave
   const int G = UF_PX >> wshift, ngroups = N / G, nslab = Cout / UF_CS;
   // workgroup -> (group, slab): the slabs of one group are consecutive workgroups of ONE XCD (workgroup b runs on XCD b % 8), so the group's x rows
   // are fetched into that L2 once and the two 64-byte halves of every y line are written from the same L2
@@ -355,32 +392,135 @@ __global__ __launch_bounds__(UF_THREADS, 3) void up2proj_fused_fwd_kernel(const 
   }
   const int n0 = group * G, c0 = slab * UF_CS;
   const int cpt = Cin / UF_K, total = H * cpt;
+  if (tid < UF_NFLAGS) flags[tid] = 0;
+  __syncthreads();                                                                    // (the only barrier of the kernel)
 
-  // loaders: x row k of the group = 64 pixels x 32 floats per chunk (threads 0 .. 511: pixel tid / 8, k quad tid % 8);
-  //          weight slab chunk = 144 rows (tap t, channel c0 + c) x 32 floats (1152 quads over 768 threads: 1.5 rounds)
-  const int xm = (tid >> 3) & 63, xq = tid & 7;
-  const float* xbase = x + ((long)(n0 + (xm >> wshift)) * H * W + (xm & (W - 1))) * Cin + xq * 4;       // + (k W) Cin + c 32
-  const int w_nl0 = tid >> 3, w_nl1 = (tid + UF_THREADS) >> 3;                        // local rows of this thread's two weight items
-  const float* wbase0 = wT + ((long)(w_nl0 >> 4) * Cout + c0 + (w_nl0 & 15)) * Cin + xq * 4;
-  const float* wbase1 = wT + ((long)(w_nl1 >> 4) * Cout + c0 + (w_nl1 & 15)) * Cin + xq * 4;
-  const bool x_on = tid < 512, w1_on = tid + UF_THREADS < UF_N * 8;
-  float4 rx, rw0, rw1;
-  auto load = [&](int g) {
-    const int k = g / cpt, c = g - k * cpt;
-    if (x_on) rx = *reinterpret_cast<const float4*>(xbase + (long)k * W * Cin + c * UF_K);
-    rw0 = *reinterpret_cast<const float4*>(wbase0 + c * UF_K);
-    if (w1_on) rw1 = *reinterpret_cast<const float4*>(wbase1 + c * UF_K);
-  };
-  auto store = [&](int buf) {
-    if (x_on) *reinterpret_cast<float4*>(&Xs[buf][xm * UF_LD + xq * 4]) = rx;
-    *reinterpret_cast<float4*>(&Ws[buf][w_nl0 * UF_LD + xq * 4]) = rw0;
-    if (w1_on) *reinterpret_cast<float4*>(&Ws[buf][w_nl1 * UF_LD + xq * 4]) = rw1;
-  };
+  if (wid < UF_MW) {
+    // ------------------------------------------------------------------------------------------------ MFMA waves
+    __builtin_amdgcn_s_setprio(2);                                                    // their LDS reads and MFMAs win the issue arbitration of their SIMD
+    const int pt = wid;
+    f32x4_t acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+    float4 fx0, fx1, fw0[9], fw1[9];
+    const int x_off = (pt * 16 + r16) * UF_LD + 4 * kq, w_off = r16 * UF_LD + 4 * kq;
+    auto rd = [&](float4& fx, float4 (&fw)[9], const int sg, const int u) __attribute__((always_inline)) {
+      fx = *reinterpret_cast<const float4*>(&Xs[sg][x_off + 16 * u]);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) fw[t] = *reinterpret_cast<const float4*>(&Ws[sg][w_off + t * 16 * UF_LD + 16 * u]);
+    };
+    auto mmj = [&](const float4& fx, const float4 (&fw)[9], const int j) __attribute__((always_inline)) {   // one k-step: 9 independent MFMAs
+      const float b = j == 0 ? fx.x : (j == 1 ? fx.y : (j == 2 ? fx.z : fx.w));
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float a = j == 0 ? fw[t].x : (j == 1 ? fw[t].y : (j == 2 ? fw[t].z : fw[t].w));
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+      }
+    };
+    uf_wait(&flags[UF_FULL0], UF_SW);
+    rd(fx0, fw0, 0, 0);
+    int k = 0, c = 0, sg = 0, round = 0;                                              // chunk g lives in stage sg = g % 3, its round = g / 3
+    for (int g = 0; g < total; ++g) {
+      // One chunk.  The stage is released as soon as its last fragment read has RETURNED (18 MFMAs into the chunk): a hand-over costs two LDS round
+      // trips through a busy queue, and with three stages the staging waves then run up to two chunks ahead.
+      const int sn = sg == UF_STAGES - 1 ? 0 : sg + 1, round_n = sg == UF_STAGES - 1 ? round + 1 : round;
+      rd(fx1, fw1, sg, 1);
+      const int nxt_target = (g + 1 < total) ? UF_SW * (round_n + 1) : 0;             // (last chunk: nothing to wait for)
+      const int seen = uf_peek(&flags[UF_FULL0 + sn]);                                // asked for ahead of the MFMAs: normally the staging waves are ahead
+      mmj(fx0, fw0, 0); mmj(fx0, fw0, 1);
+      uf_signal(&flags[UF_EMPTY0 + sg]);                                             // every fragment of this stage is in registers
+      if (seen < nxt_target) uf_wait(&flags[UF_FULL0 + sn], nxt_target);
+      mmj(fx0, fw0, 2); mmj(fx0, fw0, 3);
+      rd(fx0, fw0, sn, 0);                                                            // (unconditional: behind the last chunk it reads a stale stage, unused)
+      mmj(fx1, fw1, 0); mmj(fx1, fw1, 1); mmj(fx1, fw1, 2); mmj(fx1, fw1, 3);
+      sg = sn;
+      round = round_n;
+      if (c == cpt - 1) {
+        // row k of the nine planes -> LDS (lane: pixel pt 16 + r16, channels 4 kq .. + 3 of tap t) once the combination waves have read row k - 1
+        if (k >= 1) uf_wait(&flags[UF_CDONE], UF_CW * k);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          *reinterpret_cast<float4*>(&Zr[t * UF_PLANE + (pt * 16 + r16) * UF_CS + 4 * kq]) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+        }
+        uf_signal(&flags[UF_ZFULL]);
+        ++k;
+        c = 0;
+      } else {
+        ++c;
+      }
+    }
+    return;
+  }
 
-  // combination role of threads 0 .. 511: (pixel m, channel quad q, output-row parity a)
-  const int cq = tid & 3, cm = (tid >> 2) & 63, ca = (tid >> 8) & 1;
+  if (wid < UF_MW + UF_SW) {
+    // ------------------------------------------------------------------------------------------------ staging waves: global -> registers -> LDS
+    // x row k of the group = 64 pixels x 32 floats per chunk = 512 quads (item e: pixel e / 8, k quad e % 8); weight slab chunk = 144 rows (tap t,
+    // channel c0 + c) x 32 floats = 1152 quads.  256 threads: items st + 256 i -- 2 of x, 4.5 of the weights.  FOUR register sets: the chunk stored in
+    // an iteration was requested three iterations earlier (78 KB in flight per CU; one set ahead was latency-bound).
+    const int st = tid - UF_MW * 64, sq = st & 7, sr = st >> 3;                       // k quad / row of item 0 (rows sr + 32 i)
+    const float* xb[2];
+    const float* wb[5];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = sr + 32 * i;
+      xb[i] = x + ((long)(n0 + (m >> wshift)) * H * W + (m & (W - 1))) * Cin + sq * 4; // + (k W) Cin + c 32
+    }
+    const bool w4_on = st < 128;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int nl = (i < 4 || w4_on) ? sr + 32 * i : 0;
+      wb[i] = wT + ((long)(nl >> 4) * Cout + c0 + (nl & 15)) * Cin + sq * 4;
+    }
+    float4 s0[7], s1[7], s2[7], s3[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) s0[i] = s1[i] = s2[i] = s3[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load = [&](const int g, float4 (&r)[7]) __attribute__((always_inline)) {
+      const int kk = g / cpt, cc = g - kk * cpt;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) r[i] = *reinterpret_cast<const float4*>(xb[i] + (long)kk * W * Cin + cc * UF_K);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[2 + i] = *reinterpret_cast<const float4*>(wb[i] + cc * UF_K);
+      if (w4_on) r[6] = *reinterpret_cast<const float4*>(wb[4] + cc * UF_K);
+    };
+    auto store = [&](const int sg, const float4 (&r)[7]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&Xs[sg][(sr + 32 * i) * UF_LD + sq * 4]) = r[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Ws[sg][(sr + 32 * i) * UF_LD + sq * 4]) = r[2 + i];
+      if (w4_on) *reinterpret_cast<float4*>(&Ws[sg][(sr + 128) * UF_LD + sq * 4]) = r[6];
+    };
+    int sg = 0, round = 0;
+    auto step = [&](const int g, const float4 (&cur)[7], float4 (&nxt)[7]) __attribute__((always_inline)) {
+      if (g + 3 < total && !(dbg & 2)) load(g + 3, nxt);                              // into the set the previous iteration has just stored
+      if (round >= 1) uf_wait(&flags[UF_EMPTY0 + sg], UF_MW * round);                // chunk g - 3 (same stage) has been consumed
+      store(sg, cur);
+      uf_signal(&flags[UF_FULL0 + sg]);
+      if (++sg == UF_STAGES) { sg = 0; ++round; }
+    };
+    load(0, s0);
+    if (total > 1) load(1, s1);
+    if (total > 2) load(2, s2);
+    for (int g = 0; g < total; g += 4) {
+      step(g, s0, s3);
+      if (g + 1 < total) step(g + 1, s1, s0);
+      if (g + 2 < total) step(g + 2, s2, s1);
+      if (g + 3 < total) step(g + 3, s3, s2);
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------------- combination waves: plane row -> y
+  // thread = (pixel m, channel quad q).  Per low-resolution row k it reads its two columns of each of the nine planes (18 x 16 bytes), folds them along
+  // the columns (H_r^b: tap row r, output-column parity b) and releases the row; output rows 2i, 2i + 1 (i = k - 1) are then
+  //   bias + sum_r  wlo_r[a] H_r^b[row lo_r] + whi_r[a] H_r^b[row hi_r],   (lo, hi) = (i - 1, i) for r = 0, (i, min(i + 1, H - 1)) for r = 1, 2
+  // from the folded rows k (fresh), k - 1 and -- tap row 0 only -- k - 2, which live in registers.
+  const int ct = tid - (UF_MW + UF_SW) * 64;                                          // 0 .. 255
+  const int cq = ct & 3, cm = ct >> 2;
   const int cg = cm >> wshift, cj = cm & (W - 1);
-  const bool c_on = tid < 512;
   AxisW S[3];
 #pragma unroll
   for (int sx = 0; sx < 3; ++sx) S[sx] = up2_axis(sx, cj, W);
@@ -394,112 +534,73 @@ __global__ __launch_bounds__(UF_THREADS, 3) void up2proj_fused_fwd_kernel(const 
     }
   }
   const float4* Zq = reinterpret_cast<const float4*>(Zr) + cq;                        // + (plane base + pixel * 16) / 4
-  auto combine = [&](const int i) {                                                   // output rows 2 i + ca of the group, from the ring
-    if (!c_on) return;
-    float4 o0 = bv, o1 = bv;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 hn[3][2];                                                                    // folded row k (fresh)
+  float4 hc[3][2] = {{zero4, zero4}, {zero4, zero4}, {zero4, zero4}};                 // folded row k - 1
+  float4 h0m[2] = {zero4, zero4};                                                     // tap row 0 of row k - 2
+  auto emit = [&](const int i, const float4 (&n1)[2], const float4 (&n2)[2]) __attribute__((always_inline)) {   // block row i from h0m, hc and the rows below (n1, n2)
+    const AxisW R0 = up2_axis(0, i, H), R1 = up2_axis(1, i, H), R2 = up2_axis(2, i, H);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const AxisW R = up2_axis(r, i, H);
-      const float wl = ca ? R.wlo[1] : R.wlo[0], wh = ca ? R.whi[1] : R.whi[0];      // (selects: a runtime index would put the struct in scratch)
+    for (int ca = 0; ca < 2; ++ca) {
+      float4 o[2];
 #pragma unroll
-      for (int sx = 0; sx < 3; ++sx) {
-        const int plo = (cg << wshift) + S[sx].lo, phi = (cg << wshift) + S[sx].hi;
-        if (wl != 0.f) {                                                              // (wave-uniform: i and ca are)
-          const float4* zp = Zq + (uf_ring_base(r, sx, R.lo) >> 2);
-          const float4 v0 = zp[plo * 4], v1 = zp[phi * 4];
-          o0 = f4_fma(wl * S[sx].wlo[0], v0, o0); o0 = f4_fma(wl * S[sx].whi[0], v1, o0);
-          o1 = f4_fma(wl * S[sx].wlo[1], v0, o1); o1 = f4_fma(wl * S[sx].whi[1], v1, o1);
-        }
-        if (wh != 0.f) {
-          const float4* zp = Zq + (uf_ring_base(r, sx, R.hi) >> 2);
-          const float4 v0 = zp[plo * 4], v1 = zp[phi * 4];
-          o0 = f4_fma(wh * S[sx].wlo[0], v0, o0); o0 = f4_fma(wh * S[sx].whi[0], v1, o0);
-          o1 = f4_fma(wh * S[sx].wlo[1], v0, o1); o1 = f4_fma(wh * S[sx].whi[1], v1, o1);
-        }
+      for (int b = 0; b < 2; ++b) {
+        float4 v = bv;
+        v = f4_fma(R0.wlo[ca], h0m[b], v); v = f4_fma(R0.whi[ca], hc[0][b], v);
+        v = f4_fma(R1.wlo[ca], hc[1][b], v); v = f4_fma(R1.whi[ca], n1[b], v);
+        v = f4_fma(R2.wlo[ca], hc[2][b], v); v = f4_fma(R2.whi[ca], n2[b], v);
+        o[b] = make_float4(ladder_act_fn(v.x, act), ladder_act_fn(v.y, act), ladder_act_fn(v.z, act), ladder_act_fn(v.w, act));
       }
-    }
-    o0 = make_float4(ladder_act_fn(o0.x, act), ladder_act_fn(o0.y, act), ladder_act_fn(o0.z, act), ladder_act_fn(o0.w, act));
-    o1 = make_float4(ladder_act_fn(o1.x, act), ladder_act_fn(o1.y, act), ladder_act_fn(o1.z, act), ladder_act_fn(o1.w, act));
-    const long opix = ((long)(n0 + cg) * 2 * H + 2 * i + ca) * 2 * W + 2 * cj;          // output pixel of column parity 0; parity 1 is the next one
-    if (y != nullptr) {
-      float4* yp = reinterpret_cast<float4*>(y + opix * Cout + c0) + cq;
-      st_stream(yp, o0);
-      st_stream(yp + (Cout >> 2), o1);
-    }
-    if (PROJ) {
-      float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
-      p0 = f4_fma(o0.x, pwv[0], p0); p0 = f4_fma(o0.y, pwv[1], p0); p0 = f4_fma(o0.z, pwv[2], p0); p0 = f4_fma(o0.w, pwv[3], p0);
-      p1 = f4_fma(o1.x, pwv[0], p1); p1 = f4_fma(o1.y, pwv[1], p1); p1 = f4_fma(o1.z, pwv[2], p1); p1 = f4_fma(o1.w, pwv[3], p1);
-      float pv[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {                                                   // the 4 quads of a pixel are 4 consecutive lanes: fixed-order sum
-        pv[e] += __shfl_xor(pv[e], 1, 64);
-        pv[e] += __shfl_xor(pv[e], 2, 64);
+      const long opix = ((long)(n0 + cg) * 2 * H + 2 * i + ca) * 2 * W + 2 * cj;        // output pixel of column parity 0; parity 1 is the next one
+      if (y != nullptr) {
+        float4* yp = reinterpret_cast<float4*>(y + opix * Cout + c0) + cq;
+        st_stream(yp, o[0]);
+        st_stream(yp + (Cout >> 2), o[1]);
       }
-      if (cq == 0) {
-        float* pp = ppart + ((long)slab * N * 4 * H * W + opix) * pco;
+      if (PROJ) {
+        float4 p0 = zero4, p1 = zero4;
+        p0 = f4_fma(o[0].x, pwv[0], p0); p0 = f4_fma(o[0].y, pwv[1], p0); p0 = f4_fma(o[0].z, pwv[2], p0); p0 = f4_fma(o[0].w, pwv[3], p0);
+        p1 = f4_fma(o[1].x, pwv[0], p1); p1 = f4_fma(o[1].y, pwv[1], p1); p1 = f4_fma(o[1].z, pwv[2], p1); p1 = f4_fma(o[1].w, pwv[3], p1);
+        float pv[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
 #pragma unroll
-        for (int o = 0; o < 4; ++o)
-          if (o < pco) { pp[o] = pv[o]; pp[pco + o] = pv[4 + o]; }
+        for (int e = 0; e < 8; ++e) {                                                 // the 4 quads of a pixel are 4 consecutive lanes: fixed-order sum
+          pv[e] += __shfl_xor(pv[e], 1, 64);
+          pv[e] += __shfl_xor(pv[e], 2, 64);
+        }
+        if (cq == 0) {
+          float* pp = ppart + ((long)slab * N * 4 * H * W + opix) * pco;
+#pragma unroll
+          for (int o_ = 0; o_ < 4; ++o_)
+            if (o_ < pco) { pp[o_] = pv[o_]; pp[pco + o_] = pv[4 + o_]; }
+        }
       }
     }
   };
-
-  f32x4_t acc[3];
+  const int plo[3] = {(cg << wshift) + S[0].lo, (cg << wshift) + S[1].lo, (cg << wshift) + S[2].lo};
+  const int phi[3] = {(cg << wshift) + S[0].hi, (cg << wshift) + S[1].hi, (cg << wshift) + S[2].hi};
+  for (int k = 0; k < H; ++k) {
+    uf_wait(&flags[UF_ZFULL], UF_MW * (k + 1));
+    if (dbg & 1) { uf_signal(&flags[UF_CDONE]); continue; }
 #pragma unroll
-  for (int sx = 0; sx < 3; ++sx)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc[sx][e] = 0.f;
-  load(0);
-  store(0);
-  __syncthreads();
-  const int x_off = (pt * 16 + r16) * UF_LD + 4 * kq, w_off = (tr * 3 * 16 + r16) * UF_LD + 4 * kq;
-  int k = 0, c = 0;
-  for (int g = 0; g < total; ++g) {
-    const int buf = g & 1;
-    if (g + 1 < total) load(g + 1);
-    {
-      const float* Xb = &Xs[buf][x_off];
-      const float* Wb = &Ws[buf][w_off];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const float4 fx = *reinterpret_cast<const float4*>(Xb + 16 * u);
-        float4 fw[3];
-#pragma unroll
-        for (int sx = 0; sx < 3; ++sx) fw[sx] = *reinterpret_cast<const float4*>(Wb + sx * 16 * UF_LD + 16 * u);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float b = j == 0 ? fx.x : (j == 1 ? fx.y : (j == 2 ? fx.z : fx.w));
-#pragma unroll
-          for (int sx = 0; sx < 3; ++sx) {
-            const float a = j == 0 ? fw[sx].x : (j == 1 ? fw[sx].y : (j == 2 ? fw[sx].z : fw[sx].w));
-            acc[sx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[sx], 0, 0, 0);
-          }
-        }
-      }
-    }
-    const bool row_done = c == cpt - 1;
-    if (row_done) {
-      // row k of the nine planes -> ring (lane: pixel pt 16 + r16, channels 4 kq .. + 3 of tap (tr, sx)).  The readers of the slot being overwritten
-      // (the combination of block row k - 2) finished before the barrier of this row's first chunk: needs cpt >= 2 (launcher)
+    for (int r = 0; r < 3; ++r) {
+      float4 h0 = zero4, h1 = zero4;
 #pragma unroll
       for (int sx = 0; sx < 3; ++sx) {
-        *reinterpret_cast<float4*>(&Zr[uf_ring_base(tr, sx, k) + (pt * 16 + r16) * UF_CS + 4 * kq]) = make_float4(acc[sx][0], acc[sx][1], acc[sx][2], acc[sx][3]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[sx][e] = 0.f;
+        const float4* zp = Zq + ((r * 3 + sx) * UF_PLANE >> 2);
+        const float4 v0 = zp[plo[sx] * 4], v1 = zp[phi[sx] * 4];
+        h0 = f4_fma(S[sx].wlo[0], v0, h0); h0 = f4_fma(S[sx].whi[0], v1, h0);
+        h1 = f4_fma(S[sx].wlo[1], v0, h1); h1 = f4_fma(S[sx].whi[1], v1, h1);
       }
+      hn[r][0] = h0;
+      hn[r][1] = h1;
     }
-    if (g + 1 < total) store(buf ^ 1);
-    __syncthreads();
-    if (row_done) {
-      if (k >= 1) combine(k - 1);
-      ++k;
-      c = 0;
-    } else {
-      ++c;
-    }
+    uf_signal(&flags[UF_CDONE]);                                                      // row k has been read: the MFMA waves may write row k + 1
+    if (k >= 1) emit(k - 1, hn[1], hn[2]);
+    h0m[0] = hc[0][0]; h0m[1] = hc[0][1];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { hc[r][0] = hn[r][0]; hc[r][1] = hn[r][1]; }
   }
-  combine(H - 1);                                                                     // the last block row: its "row below" is the clamped last row itself
+  if (!(dbg & 1)) emit(H - 1, hc[1], hc[2]);                                          // the last block row: its "row below" is the clamped last row itself
 }
 
 // pout [P][pco] = pb + sum over the slabs (in order) of the partial projections [nslab][P][pco]
@@ -724,16 +825,17 @@ int ladder_up2proj_fused_fwd(const float* x, const float* wcatT, const float* bi
   if (proj_out != nullptr && (ws == nullptr || ws_bytes < ladder_up2proj_fused_workspace_bytes(N, H, W, Cout, proj_cout))) return LADDER_E_WORKSPACE;
   int wshift = 3;
   while ((1 << wshift) < W) ++wshift;
+  static const int dbg = getenv("LADDER_UP2FUSE_DBG") != nullptr ? atoi(getenv("LADDER_UP2FUSE_DBG")) : 0;
   const unsigned grid = (unsigned)(N / (UF_PX / W)) * (unsigned)(Cout / UF_CS);
   if (proj_out != nullptr) {
     hipLaunchKernelGGL(up2proj_fused_fwd_kernel<true>, dim3(grid), dim3(UF_THREADS), 0, stream, x, wcatT, bias, y, proj_w, (float*)ws, proj_cout, N, H, W, wshift, Cin,
-                       Cout, act);
+                       Cout, act, dbg);
     const long total = (long)N * 4 * H * W * proj_cout;
     hipLaunchKernelGGL(up2proj_proj_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const float*)ws, proj_b, proj_out, total, proj_cout,
                        Cout / UF_CS);
   } else {
     hipLaunchKernelGGL(up2proj_fused_fwd_kernel<false>, dim3(grid), dim3(UF_THREADS), 0, stream, x, wcatT, bias, y, (const float*)nullptr, (float*)nullptr, 0, N, H, W,
-                       wshift, Cin, Cout, act);
+                       wshift, Cin, Cout, act, dbg);
   }
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;

@@ -288,15 +288,16 @@ def test_upproj_fused_forward_vs_oracle(gpu_ctx, case):
     w = (rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
     b = rng.standard_normal(cout).astype(np.float32) * 0.1
     wcat, wcatT = _pack(L, w, st)
+    xd, bd = dev(x), dev(b)
     y = torch.full((N, 2 * H, 2 * W, cout), float("nan"), device="cuda")
-    L.call("ladder_up2proj_fused_fwd", p(dev(x)), p(wcatT), p(dev(b)), p(y), None, None, None, 0, N, H, W, cin, cout, 1 if act else 0, None, 0, st)
+    L.call("ladder_up2proj_fused_fwd", p(xd), p(wcatT), p(bd), p(y), None, None, None, 0, N, H, W, cin, cout, 1 if act else 0, None, 0, st)
     ref = _ref_fwd(x, w, b, act)
     close(y, ref, TOL32, "y (every pixel)")
-    y2, _ = _forward(L, dev(x), wcat, dev(b), N, H, W, cin, cout, 1 if act else 0, st)
+    y2, _ = _forward(L, xd, wcat, bd, N, H, W, cin, cout, 1 if act else 0, st)
     close(y, y2.cpu().numpy().astype(np.float64), TOL32, "fused vs two-call form")
     # bit-reproducible: a second launch gives the identical tensor
     y3 = torch.full_like(y, float("nan"))
-    L.call("ladder_up2proj_fused_fwd", p(dev(x)), p(wcatT), p(dev(b)), p(y3), None, None, None, 0, N, H, W, cin, cout, 1 if act else 0, None, 0, st)
+    L.call("ladder_up2proj_fused_fwd", p(xd), p(wcatT), p(bd), p(y3), None, None, None, 0, N, H, W, cin, cout, 1 if act else 0, None, 0, st)
     assert torch.equal(y, y3)
 
 
@@ -314,10 +315,11 @@ def test_upproj_fused_forward_with_projection_vs_oracle(gpu_ctx, case):
     pw_ = (rng.standard_normal((cout, pco)) / np.sqrt(cout)).astype(np.float32)
     pb_ = rng.standard_normal(pco).astype(np.float32) * 0.1
     _, wcatT = _pack(L, w, st)
+    xd, bd, pwd, pbd = dev(x), dev(b), dev(pw_), dev(pb_)
     y = torch.full((N, 2 * H, 2 * W, cout), float("nan"), device="cuda") if keep_y else None
     out = torch.full((N, 2 * H, 2 * W, pco), float("nan"), device="cuda")
     ws = _ws(L.query("ladder_up2proj_fused_workspace_bytes", N, H, W, cout, pco))
-    L.call("ladder_up2proj_fused_fwd", p(dev(x)), p(wcatT), p(dev(b)), p(y), p(dev(pw_)), p(dev(pb_)), p(out), pco, N, H, W, cin, cout, 1, p(ws), ws.numel(), st)
+    L.call("ladder_up2proj_fused_fwd", p(xd), p(wcatT), p(bd), p(y), p(pwd), p(pbd), p(out), pco, N, H, W, cin, cout, 1, p(ws), ws.numel(), st)
     ref = _ref_fwd(x, w, b, "leaky_relu")
     close(out, ref @ pw_.astype(np.float64) + pb_.astype(np.float64), TOL32, "projection")
     if keep_y:
