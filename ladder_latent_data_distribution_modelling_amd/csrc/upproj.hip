@@ -21,6 +21,7 @@
 // up(Z)[2i+1] = (Z[i] + Z[min(i+1, L-1)]) / 2.  Its transpose: D_r[i] = sum_{alpha=0..2} omega_alpha dy[2i - r + alpha], omega = (1/2 [i >= 1], 1,
 // 1/2 -- or 1 on the last line, where the clamp folds both halves onto it), every term gated by 0 <= 2i - r + alpha < 2L.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -333,50 +334,63 @@ __global__ __launch_bounds__(256) void up2proj_bwd_combine_kernel(const float* _
 // channels of one pixel = one 128-bit LDS write.  K order inside a 16-deep group is the permutation of gemm_nt16_f32_kernel (both fragments one
 // ds_read_b128 per 4 k-steps).
 // The 1x1 output conv of the last pair (conv2d_8, 128 -> 3) needs all 128 channels of a pixel: every slab writes its PARTIAL projection
-// [slab][pixel][pco] and up2proj_proj_reduce_kernel sums the slabs in a fixed order (+ bias): bit-reproducible, 0.2 GB instead of the 1 GB activation.
+// [slab][pco][pixel] and up2proj_proj_reduce_kernel sums the slabs in a fixed order (+ bias): bit-reproducible, 0.2 GB instead of the 1 GB activation.
 //
 // UF_LD = 40: the fragment read of lane (r16, kq) is a 16-byte piece of row r16 at float offset 16 u + 4 kq; ds_read_b128 is serviced in the lane groups
 // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+ 32): eight rows of one kq and the OTHER eight rows of the next.  With 40-float rows the first eight
 // land on even 16-byte bank groups and the second eight on odd ones (r x 10 mod 16 is even): conflict-free; 36-float rows are 2-way conflicted in 7 of 8.
 constexpr int UF_PX = 64, UF_CS = 16, UF_N = 9 * UF_CS, UF_K = 32, UF_LD = UF_K + 8, UF_THREADS = 768, UF_PLANE = UF_PX * UF_CS;
 constexpr int UF_STAGES = 3;
+// WRES (Cin <= 128): the whole weight slab [144][Cin] stays in LDS for the lifetime of the workgroup -- rows of Cin + 24 floats (conflict-free like UF_LD:
+// (Cin + 24) / 4 = 6 or 14 mod 16) -- and only x is staged per chunk.  Measured (profiles/r06_fused_ablation_v8_loads.txt, conv2d_7): the weight chunks,
+// re-fetched from L2 for every row (18 of the 26 KB a chunk stages), cost 280 us of the 1 760, the x chunks 170.
+constexpr int UF_WRES_CIN = 128, UF_WRES_PAD = 24;
+constexpr int UF_WS_FLOATS = UF_N * (UF_WRES_CIN + UF_WRES_PAD) > UF_STAGES * UF_N * UF_LD ? UF_N * (UF_WRES_CIN + UF_WRES_PAD) : UF_STAGES * UF_N * UF_LD;
 constexpr int UF_MW = 4, UF_SW = 4, UF_CW = 4;                                           // MFMA / staging / combination waves
-enum { UF_FULL0 = 0, UF_EMPTY0 = UF_STAGES, UF_ZFULL = 2 * UF_STAGES, UF_CDONE = 2 * UF_STAGES + 1, UF_NFLAGS = 2 * UF_STAGES + 2 };
+// hand-over words in LDS, four per event (one per wave of the publishing role; int4-aligned): FULL[stage] / EMPTY[stage] / ZFULL / CDONE
+enum { UF_FULL0 = 0, UF_EMPTY0 = 4 * UF_STAGES, UF_ZFULL = 8 * UF_STAGES, UF_CDONE = 8 * UF_STAGES + 4, UF_WREADY = 8 * UF_STAGES + 8, UF_NFLAGS = 8 * UF_STAGES + 12 };
 
-// counters in LDS: the whole wave calls; its LDS reads / writes so far have completed before lane 0 bumps the counter (DS operations of a wave are
-// processed in order, and the counter is only ever read after the data accesses it publishes)
-__device__ __forceinline__ void uf_signal(int* f) {
+// A hand-over is a PROGRESS WORD per publishing wave (monotonic: rounds of a stage, rows written, rows read), written with a plain LDS store once the
+// wave's own LDS reads / writes so far have completed (DS operations of a wave are processed in order), and read four at a time (one ds_read_b128,
+// all lanes the same address: a broadcast): no atomics.
+__device__ __forceinline__ void uf_publish(int* word, const int value) {
   // (the fence pins the MFMAs of the block in front of the hand-over: they are not memory operations, and the compiler otherwise sinks them below the
   // wait -- which then sits in front of the matrix block and exposes the latency of the fragment reads just issued for the next chunk)
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ int uf_peek(int* f) {
-  const int v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  // (lane 0 only: 64 lanes storing to ONE address are serialised by the LDS -- SQ_LDS_BANK_CONFLICT counted 218 cycles per chunk for the all-lane form)
+  if ((threadIdx.x & 63) == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   asm volatile("" ::: "memory");
-  return v;
 }
-__device__ __forceinline__ void uf_wait(int* f, const int target) {
+__device__ __forceinline__ int uf_peek(const int* words) {                            // the slowest of the four publishing waves
+  typedef int uf_i32x4 __attribute__((ext_vector_type(4)));
+  asm volatile("" ::: "memory");                                                      // (a fresh read every time: the clobbers keep it out of registers)
+  const uf_i32x4 v = *reinterpret_cast<const uf_i32x4*>(words);
+  asm volatile("" ::: "memory");
+  return min(min(v[0], v[1]), min(v[2], v[3]));
+}
+// SLEEP: units of 64 cycles between polls.  Every poll is an LDS read in the queue the MFMA waves' fragment reads wait in: the staging / combination
+// waves, which have chunks of slack, poll rarely; the MFMA waves (normally never waiting) poll tightly.
+template <int SLEEP = 1>
+__device__ __forceinline__ void uf_wait(const int* words, const int target) {
   int spins = 0;
-  while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
-    __builtin_amdgcn_s_sleep(1);
+  while (uf_peek(words) < target) {
+    __builtin_amdgcn_s_sleep(SLEEP);
     if (++spins > (1 << 22)) __builtin_trap();                                        // (a hand-over that never comes is a bug: abort the launch, never hang the device)
   }
-  asm volatile("" ::: "memory");
 }
 
-template <bool PROJ>
+template <bool PROJ, bool WRES>
 __global__ __launch_bounds__(UF_THREADS, 3) void up2proj_fused_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wT, const float* __restrict__ bias,
                                                                           float* __restrict__ y, const float* __restrict__ pw, float* __restrict__ ppart,
                                                                           const int pco, const int N, const int H, const int W, const int wshift, const int Cin,
                                                                           const int Cout, const int act, const int dbg) {
   // dbg (ablation switches of profiles/tools/r6_fused_probe.py, 0 in production): 1 = the combination waves only hand the row over (no reads, no stores),
-  // 2 = the staging waves issue no global loads
+  // 2 = the staging waves issue no global loads (8: none of x, 16: none of the weights), 32 = no y stores
   __shared__ __attribute__((aligned(16))) float Xs[UF_STAGES][UF_PX * UF_LD];
-  __shared__ __attribute__((aligned(16))) float Ws[UF_STAGES][UF_N * UF_LD];
+  __shared__ __attribute__((aligned(16))) float Ws[UF_WS_FLOATS];                      // [stage][144][UF_LD], or (WRES) the whole slab [144][Cin + 24]
   __shared__ __attribute__((aligned(16))) float Zr[9 * UF_PLANE];
-  __shared__ int flags[UF_NFLAGS];
+  __shared__ __attribute__((aligned(16))) int flags[UF_NFLAGS];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, kq = lane >> 4;
   const int G = UF_PX >> wshift, ngroups = N / G, nslab = Cout / UF_CS;
   // workgroup -> (group, slab): the slabs of one group are consecutive workgroups of ONE XCD (workgroup b runs on XCD b % 8), so the group's x rows
@@ -406,10 +420,21 @@ __global__ __launch_bounds__(UF_THREADS, 3) void up2proj_fused_fwd_kernel(const 
       for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
     float4 fx0, fx1, fw0[9], fw1[9];
     const int x_off = (pt * 16 + r16) * UF_LD + 4 * kq, w_off = r16 * UF_LD + 4 * kq;
-    auto rd = [&](float4& fx, float4 (&fw)[9], const int sg, const int u) __attribute__((always_inline)) {
+    // plane row: pixel p, channel quad q at float offset 16 p + 4 (q ^ ((p >> 1) & 3)).  ds_write_b128 is serviced in groups of 8 lanes = 8 consecutive
+    // pixels of ONE quad here: unswizzled they start on two bank groups only (4-way conflicts: 875 conflict cycles per row, profiles/r06_fused_pmc_v7*.txt);
+    // the swizzle spreads them over all eight, and a pixel's four quads stay inside its own 64 bytes (the combination's reads do not change banks)
+    const int z_px = pt * 16 + r16, z_off = z_px * UF_CS + 4 * (kq ^ ((z_px >> 1) & 3));
+    const int ldw = Cin + UF_WRES_PAD, w_off_res = r16 * ldw + 4 * kq;
+    auto rd = [&](float4& fx, float4 (&fw)[9], const int sg, const int u, const int cc) __attribute__((always_inline)) {   // cc: the chunk's index in its row (WRES)
       fx = *reinterpret_cast<const float4*>(&Xs[sg][x_off + 16 * u]);
+      if (WRES) {
+        const float* wp = &Ws[w_off_res + cc * UF_K + 16 * u];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) fw[t] = *reinterpret_cast<const float4*>(&Ws[sg][w_off + t * 16 * UF_LD + 16 * u]);
+        for (int t = 0; t < 9; ++t) fw[t] = *reinterpret_cast<const float4*>(wp + t * 16 * ldw);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) fw[t] = *reinterpret_cast<const float4*>(&Ws[sg * UF_N * UF_LD + w_off + t * 16 * UF_LD + 16 * u]);
+      }
     };
     auto mmj = [&](const float4& fx, const float4 (&fw)[9], const int j) __attribute__((always_inline)) {   // one k-step: 9 independent MFMAs
       const float b = j == 0 ? fx.x : (j == 1 ? fx.y : (j == 2 ? fx.z : fx.w));
@@ -419,39 +444,48 @@ __global__ __launch_bounds__(UF_THREADS, 3) void up2proj_fused_fwd_kernel(const 
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
       }
     };
-    uf_wait(&flags[UF_FULL0], UF_SW);
-    rd(fx0, fw0, 0, 0);
-    int k = 0, c = 0, sg = 0, round = 0;                                              // chunk g lives in stage sg = g % 3, its round = g / 3
-    for (int g = 0; g < total; ++g) {
-      // One chunk.  The stage is released as soon as its last fragment read has RETURNED (18 MFMAs into the chunk): a hand-over costs two LDS round
-      // trips through a busy queue, and with three stages the staging waves then run up to two chunks ahead.
-      const int sn = sg == UF_STAGES - 1 ? 0 : sg + 1, round_n = sg == UF_STAGES - 1 ? round + 1 : round;
-      rd(fx1, fw1, sg, 1);
-      const int nxt_target = (g + 1 < total) ? UF_SW * (round_n + 1) : 0;             // (last chunk: nothing to wait for)
-      const int seen = uf_peek(&flags[UF_FULL0 + sn]);                                // asked for ahead of the MFMAs: normally the staging waves are ahead
+    if (WRES) uf_wait(&flags[UF_WREADY], 1);
+    uf_wait(&flags[UF_FULL0], 1);
+    rd(fx0, fw0, 0, 0, 0);
+    int k = 0, c = 0, round = 0;                                                      // chunk g lives in stage g % 3, its round = g / 3 (published values: round + 1)
+    // One chunk, the stage index a compile-time constant (three copies of the body: every LDS offset an immediate, no address arithmetic between the
+    // MFMAs).  The stage is released as soon as its last fragment read has RETURNED (18 MFMAs into the chunk): a hand-over costs two LDS round trips
+    // through a busy queue, and with three stages the staging waves then run up to two chunks ahead.
+    auto chunk = [&](auto SG, const int g) __attribute__((always_inline)) {
+      constexpr int sg = decltype(SG)::value, sn = (sg + 1) % UF_STAGES;
+      const int round_n = sn == 0 ? round + 1 : round;
+      rd(fx1, fw1, sg, 1, c);
+      const int nxt_target = (g + 1 < total) ? round_n + 1 : 0;                       // (last chunk: nothing to wait for)
+      const int seen = uf_peek(&flags[UF_FULL0 + 4 * sn]);                            // asked for ahead of the MFMAs: normally the staging waves are ahead
+      __builtin_amdgcn_sched_barrier(0);                                              // (the eleven reads are ISSUED here, 18 MFMAs ahead of the wait in uf_publish)
       mmj(fx0, fw0, 0); mmj(fx0, fw0, 1);
-      uf_signal(&flags[UF_EMPTY0 + sg]);                                             // every fragment of this stage is in registers
-      if (seen < nxt_target) uf_wait(&flags[UF_FULL0 + sn], nxt_target);
+      uf_publish(&flags[UF_EMPTY0 + 4 * sg + wid], round + 1);                        // every fragment of this stage is in registers
+      if (seen < nxt_target) uf_wait(&flags[UF_FULL0 + 4 * sn], nxt_target);
       mmj(fx0, fw0, 2); mmj(fx0, fw0, 3);
-      rd(fx0, fw0, sn, 0);                                                            // (unconditional: behind the last chunk it reads a stale stage, unused)
+      rd(fx0, fw0, sn, 0, c == cpt - 1 ? 0 : c + 1);                                  // (unconditional: behind the last chunk it reads a stale stage, unused)
+      __builtin_amdgcn_sched_barrier(0);                                              // (... and these 36 MFMAs ahead of their first use)
       mmj(fx1, fw1, 0); mmj(fx1, fw1, 1); mmj(fx1, fw1, 2); mmj(fx1, fw1, 3);
-      sg = sn;
       round = round_n;
       if (c == cpt - 1) {
         // row k of the nine planes -> LDS (lane: pixel pt 16 + r16, channels 4 kq .. + 3 of tap t) once the combination waves have read row k - 1
-        if (k >= 1) uf_wait(&flags[UF_CDONE], UF_CW * k);
+        if (k >= 1) uf_wait(&flags[UF_CDONE], k);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-          *reinterpret_cast<float4*>(&Zr[t * UF_PLANE + (pt * 16 + r16) * UF_CS + 4 * kq]) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+          *reinterpret_cast<float4*>(&Zr[t * UF_PLANE + z_off]) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
         }
-        uf_signal(&flags[UF_ZFULL]);
         ++k;
+        uf_publish(&flags[UF_ZFULL + wid], k);                                        // rows 0 .. k - 1 of this wave's pixel tile are written
         c = 0;
       } else {
         ++c;
       }
+    };
+    for (int g = 0; g < total; g += 3) {
+      chunk(std::integral_constant<int, 0>{}, g);
+      if (g + 1 < total) chunk(std::integral_constant<int, 1>{}, g + 1);
+      if (g + 2 < total) chunk(std::integral_constant<int, 2>{}, g + 2);
     }
     return;
   }
@@ -481,24 +515,78 @@ __global__ __launch_bounds__(UF_THREADS, 3) void up2proj_fused_fwd_kernel(const 
     auto load = [&](const int g, float4 (&r)[7]) __attribute__((always_inline)) {
       const int kk = g / cpt, cc = g - kk * cpt;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) r[i] = *reinterpret_cast<const float4*>(xb[i] + (long)kk * W * Cin + cc * UF_K);
+      for (int i = 0; i < 2; ++i)
+        if (!(dbg & 8)) r[i] = *reinterpret_cast<const float4*>(xb[i] + (long)kk * W * Cin + cc * UF_K);
+      if (!WRES) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) r[2 + i] = *reinterpret_cast<const float4*>(wb[i] + cc * UF_K);
-      if (w4_on) r[6] = *reinterpret_cast<const float4*>(wb[4] + cc * UF_K);
+        for (int i = 0; i < 4; ++i)
+          if (!(dbg & 16)) r[2 + i] = *reinterpret_cast<const float4*>(wb[i] + cc * UF_K);
+        if (w4_on && !(dbg & 16)) r[6] = *reinterpret_cast<const float4*>(wb[4] + cc * UF_K);
+      }
     };
     auto store = [&](const int sg, const float4 (&r)[7]) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&Xs[sg][(sr + 32 * i) * UF_LD + sq * 4]) = r[i];
+      if (!WRES) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Ws[sg][(sr + 32 * i) * UF_LD + sq * 4]) = r[2 + i];
-      if (w4_on) *reinterpret_cast<float4*>(&Ws[sg][(sr + 128) * UF_LD + sq * 4]) = r[6];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Ws[sg * UF_N * UF_LD + (sr + 32 * i) * UF_LD + sq * 4]) = r[2 + i];
+        if (w4_on) *reinterpret_cast<float4*>(&Ws[sg * UF_N * UF_LD + (sr + 128) * UF_LD + sq * 4]) = r[6];
+      }
     };
+    if (WRES) {
+      // the whole slab, once: 144 rows x Cin / 4 quads over the 256 staging threads
+      const int qpr = Cin >> 2, ldw = Cin + UF_WRES_PAD;
+      for (int e = st; e < UF_N * qpr; e += UF_SW * 64) {
+        const int row = e / qpr, q4 = e - row * qpr;
+        const float4 v = *reinterpret_cast<const float4*>(wT + ((long)(row >> 4) * Cout + c0 + (row & 15)) * Cin + q4 * 4);
+        *reinterpret_cast<float4*>(&Ws[row * ldw + q4 * 4]) = v;
+      }
+      uf_publish(&flags[UF_WREADY + (wid - UF_MW)], 1);
+      // ... then only x per chunk (2 quads per thread): EIGHT register sets, the chunk stored in an iteration was requested seven iterations earlier
+      // (x comes from HBM for the first slab of a group to ask; three chunks ahead left the MFMA waves waiting: 160 us on conv2d_7)
+      float4 q0[2], q1[2], q2[2], q3[2], q4[2], q5[2], q6[2], q7[2];
+      auto xload = [&](const int g, float4 (&r)[2]) __attribute__((always_inline)) {
+        const int kk = g / cpt, cc = g - kk * cpt;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          if (!(dbg & 8)) r[i] = *reinterpret_cast<const float4*>(xb[i] + (long)kk * W * Cin + cc * UF_K);
+      };
+      int sgx = 0, roundx = 0;
+      auto xstep = [&](const int g, const float4 (&cur)[2], float4 (&nxt)[2]) __attribute__((always_inline)) {
+        if (g + 7 < total) xload(g + 7, nxt);
+        if (roundx >= 1) uf_wait<4>(&flags[UF_EMPTY0 + 4 * sgx], roundx);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&Xs[sgx][(sr + 32 * i) * UF_LD + sq * 4]) = cur[i];
+        uf_publish(&flags[UF_FULL0 + 4 * sgx + (wid - UF_MW)], roundx + 1);
+        if (++sgx == UF_STAGES) { sgx = 0; ++roundx; }
+      };
+#pragma unroll
+      for (int i = 0; i < 2; ++i) q0[i] = q1[i] = q2[i] = q3[i] = q4[i] = q5[i] = q6[i] = q7[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      xload(0, q0);
+      if (total > 1) xload(1, q1);
+      if (total > 2) xload(2, q2);
+      if (total > 3) xload(3, q3);
+      if (total > 4) xload(4, q4);
+      if (total > 5) xload(5, q5);
+      if (total > 6) xload(6, q6);
+      for (int g = 0; g < total; g += 8) {
+        xstep(g, q0, q7);
+        if (g + 1 < total) xstep(g + 1, q1, q0);
+        if (g + 2 < total) xstep(g + 2, q2, q1);
+        if (g + 3 < total) xstep(g + 3, q3, q2);
+        if (g + 4 < total) xstep(g + 4, q4, q3);
+        if (g + 5 < total) xstep(g + 5, q5, q4);
+        if (g + 6 < total) xstep(g + 6, q6, q5);
+        if (g + 7 < total) xstep(g + 7, q7, q6);
+      }
+      return;
+    }
     int sg = 0, round = 0;
     auto step = [&](const int g, const float4 (&cur)[7], float4 (&nxt)[7]) __attribute__((always_inline)) {
       if (g + 3 < total && !(dbg & 2)) load(g + 3, nxt);                              // into the set the previous iteration has just stored
-      if (round >= 1) uf_wait(&flags[UF_EMPTY0 + sg], UF_MW * round);                // chunk g - 3 (same stage) has been consumed
+      if (round >= 1) uf_wait<4>(&flags[UF_EMPTY0 + 4 * sg], round);                     // chunk g - 3 (same stage) has been consumed by all four MFMA waves
       store(sg, cur);
-      uf_signal(&flags[UF_FULL0 + sg]);
+      uf_publish(&flags[UF_FULL0 + 4 * sg + (wid - UF_MW)], round + 1);
       if (++sg == UF_STAGES) { sg = 0; ++round; }
     };
     load(0, s0);
@@ -533,7 +621,7 @@ __global__ __launch_bounds__(UF_THREADS, 3) void up2proj_fused_fwd_kernel(const 
       pwv[c4] = make_float4(pr[0], pco > 1 ? pr[1] : 0.f, pco > 2 ? pr[2] : 0.f, pco > 3 ? pr[3] : 0.f);
     }
   }
-  const float4* Zq = reinterpret_cast<const float4*>(Zr) + cq;                        // + (plane base + pixel * 16) / 4
+  const float4* Zq = reinterpret_cast<const float4*>(Zr);                             // + plane base / 4 + zoff(column)
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 hn[3][2];                                                                    // folded row k (fresh)
   float4 hc[3][2] = {{zero4, zero4}, {zero4, zero4}, {zero4, zero4}};                 // folded row k - 1
@@ -552,7 +640,7 @@ __global__ __launch_bounds__(UF_THREADS, 3) void up2proj_fused_fwd_kernel(const 
         o[b] = make_float4(ladder_act_fn(v.x, act), ladder_act_fn(v.y, act), ladder_act_fn(v.z, act), ladder_act_fn(v.w, act));
       }
       const long opix = ((long)(n0 + cg) * 2 * H + 2 * i + ca) * 2 * W + 2 * cj;        // output pixel of column parity 0; parity 1 is the next one
-      if (y != nullptr) {
+      if (y != nullptr && !(dbg & 32)) {
         float4* yp = reinterpret_cast<float4*>(y + opix * Cout + c0) + cq;
         st_stream(yp, o[0]);
         st_stream(yp + (Cout >> 2), o[1]);
@@ -567,34 +655,37 @@ __global__ __launch_bounds__(UF_THREADS, 3) void up2proj_fused_fwd_kernel(const 
           pv[e] += __shfl_xor(pv[e], 1, 64);
           pv[e] += __shfl_xor(pv[e], 2, 64);
         }
-        if (cq == 0) {
-          float* pp = ppart + ((long)slab * N * 4 * H * W + opix) * pco;
-#pragma unroll
-          for (int o_ = 0; o_ < 4; ++o_)
-            if (o_ < pco) { pp[o_] = pv[o_]; pp[pco + o_] = pv[4 + o_]; }
+        // every lane of the quad holds all sums: lane cq = o stores output channel o of the pixel pair (columns 2j, 2j + 1) as ONE 8-byte piece into
+        // the partial plane [slab][o][pixel] -- 16 pixels of a wave make 128 contiguous bytes (12-byte pieces per pixel cost 250 us on conv2d_7)
+        if (cq < pco) {
+          const float a0 = cq == 0 ? pv[0] : (cq == 1 ? pv[1] : (cq == 2 ? pv[2] : pv[3]));
+          const float a1 = cq == 0 ? pv[4] : (cq == 1 ? pv[5] : (cq == 2 ? pv[6] : pv[7]));
+          *reinterpret_cast<float2*>(ppart + ((long)slab * pco + cq) * ((long)N * 4 * H * W) + opix) = make_float2(a0, a1);
         }
       }
     }
   };
-  const int plo[3] = {(cg << wshift) + S[0].lo, (cg << wshift) + S[1].lo, (cg << wshift) + S[2].lo};
-  const int phi[3] = {(cg << wshift) + S[0].hi, (cg << wshift) + S[1].hi, (cg << wshift) + S[2].hi};
+  // float4 offsets of this thread's quad in its two columns of a plane (swizzled: see the MFMA waves' z_off)
+  auto zoff = [&](const int col) __attribute__((always_inline)) { const int p_ = (cg << wshift) + col; return p_ * 4 + (cq ^ ((p_ >> 1) & 3)); };
+  const int plo[3] = {zoff(S[0].lo), zoff(S[1].lo), zoff(S[2].lo)};
+  const int phi[3] = {zoff(S[0].hi), zoff(S[1].hi), zoff(S[2].hi)};
   for (int k = 0; k < H; ++k) {
-    uf_wait(&flags[UF_ZFULL], UF_MW * (k + 1));
-    if (dbg & 1) { uf_signal(&flags[UF_CDONE]); continue; }
+    uf_wait<6>(&flags[UF_ZFULL], k + 1);
+    if (dbg & 1) { uf_publish(&flags[UF_CDONE + (wid - UF_MW - UF_SW)], k + 1); continue; }
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       float4 h0 = zero4, h1 = zero4;
 #pragma unroll
       for (int sx = 0; sx < 3; ++sx) {
         const float4* zp = Zq + ((r * 3 + sx) * UF_PLANE >> 2);
-        const float4 v0 = zp[plo[sx] * 4], v1 = zp[phi[sx] * 4];
+        const float4 v0 = zp[plo[sx]], v1 = zp[phi[sx]];
         h0 = f4_fma(S[sx].wlo[0], v0, h0); h0 = f4_fma(S[sx].whi[0], v1, h0);
         h1 = f4_fma(S[sx].wlo[1], v0, h1); h1 = f4_fma(S[sx].whi[1], v1, h1);
       }
       hn[r][0] = h0;
       hn[r][1] = h1;
     }
-    uf_signal(&flags[UF_CDONE]);                                                      // row k has been read: the MFMA waves may write row k + 1
+    uf_publish(&flags[UF_CDONE + (wid - UF_MW - UF_SW)], k + 1);                      // row k has been read: the MFMA waves may write row k + 1
     if (k >= 1) emit(k - 1, hn[1], hn[2]);
     h0m[0] = hc[0][0]; h0m[1] = hc[0][1];
 #pragma unroll
@@ -603,14 +694,16 @@ __global__ __launch_bounds__(UF_THREADS, 3) void up2proj_fused_fwd_kernel(const 
   if (!(dbg & 1)) emit(H - 1, hc[1], hc[2]);                                          // the last block row: its "row below" is the clamped last row itself
 }
 
-// pout [P][pco] = pb + sum over the slabs (in order) of the partial projections [nslab][P][pco]
+// pout [P][pco] = pb + sum over the slabs (in order) of the partial projections [nslab][pco][P]; one thread per pixel
 __global__ __launch_bounds__(256) void up2proj_proj_reduce_kernel(const float* __restrict__ ppart, const float* __restrict__ pb, float* __restrict__ pout,
-                                                                  const long total, const int pco, const int nslab) {
+                                                                  const long P, const int pco, const int nslab) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= total) return;
-  float sacc = pb != nullptr ? pb[t % pco] : 0.f;
-  for (int sl = 0; sl < nslab; ++sl) sacc += ppart[(long)sl * total + t];
-  pout[t] = sacc;
+  if (t >= P) return;
+  for (int o = 0; o < pco; ++o) {
+    float sacc = pb != nullptr ? pb[o] : 0.f;
+    for (int sl = 0; sl < nslab; ++sl) sacc += ppart[((long)sl * pco + o) * P + t];
+    pout[t * pco + o] = sacc;
+  }
 }
 
 // dw [3][3][Cin][Cout] from dWcat [Cin][9 Cout]; db [Cout] (may be NULL) = the centre tap's column sums of D = sum over all pixels of dy
@@ -813,6 +906,13 @@ int ladder_up2proj_fused_eligible(int N, int H, int W, int Cin, int Cout) {
   return 1;
 }
 
+// ... and PREFERRED over the two-call form (measured, batch 128, profiles/r06_fused_probe_v10_final.txt): where the weight slab stays in LDS (Cin <= 128:
+// conv2d_7 1 565 against 2 066 us, with the RGB projection 1 791 / 1 666 against 2 102 / 1 968) and on the 8-pixel-wide maps (conv2d_4: 203 against
+// 226 us); conv2d_5 / conv2d_6 (Cin 256: the slab is re-staged for every row) are level with their GEMM + combination pair, which they keep.
+int ladder_up2proj_fused_preferred(int N, int H, int W, int Cin, int Cout) {
+  return (ladder_up2proj_fused_eligible(N, H, W, Cin, Cout) && (Cin <= UF_WRES_CIN || W <= 8)) ? 1 : 0;
+}
+
 size_t ladder_up2proj_fused_workspace_bytes(int N, int H, int W, int Cout, int proj_cout) {
   return proj_cout > 0 ? (size_t)(Cout / UF_CS) * N * 4 * H * W * proj_cout * sizeof(float) : 0;
 }
@@ -827,16 +927,21 @@ int ladder_up2proj_fused_fwd(const float* x, const float* wcatT, const float* bi
   while ((1 << wshift) < W) ++wshift;
   static const int dbg = getenv("LADDER_UP2FUSE_DBG") != nullptr ? atoi(getenv("LADDER_UP2FUSE_DBG")) : 0;
   const unsigned grid = (unsigned)(N / (UF_PX / W)) * (unsigned)(Cout / UF_CS);
+  static const bool wres_off = getenv("LADDER_UP2FUSE_NO_WRES") != nullptr;
+  const bool wres = Cin <= UF_WRES_CIN && !wres_off;                                   // the weight slab fits LDS beside the x stages and the plane row
+  float* pp = proj_out != nullptr ? (float*)ws : nullptr;
+  const float* pwp = proj_out != nullptr ? proj_w : nullptr;
+  const int pco = proj_out != nullptr ? proj_cout : 0;
+#define UF_LAUNCH(P, R) hipLaunchKernelGGL((up2proj_fused_fwd_kernel<P, R>), dim3(grid), dim3(UF_THREADS), 0, stream, x, wcatT, bias, y, pwp, pp, pco, N, H, W, wshift, Cin, Cout, act, dbg)
   if (proj_out != nullptr) {
-    hipLaunchKernelGGL(up2proj_fused_fwd_kernel<true>, dim3(grid), dim3(UF_THREADS), 0, stream, x, wcatT, bias, y, proj_w, (float*)ws, proj_cout, N, H, W, wshift, Cin,
-                       Cout, act, dbg);
-    const long total = (long)N * 4 * H * W * proj_cout;
-    hipLaunchKernelGGL(up2proj_proj_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const float*)ws, proj_b, proj_out, total, proj_cout,
+    if (wres) UF_LAUNCH(true, true); else UF_LAUNCH(true, false);
+    const long P = (long)N * 4 * H * W;
+    hipLaunchKernelGGL(up2proj_proj_reduce_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, (const float*)ws, proj_b, proj_out, P, proj_cout,
                        Cout / UF_CS);
   } else {
-    hipLaunchKernelGGL(up2proj_fused_fwd_kernel<false>, dim3(grid), dim3(UF_THREADS), 0, stream, x, wcatT, bias, y, (const float*)nullptr, (float*)nullptr, 0, N, H, W,
-                       wshift, Cin, Cout, act, dbg);
+    if (wres) UF_LAUNCH(false, true); else UF_LAUNCH(false, false);
   }
+#undef UF_LAUNCH
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

@@ -408,7 +408,7 @@ class Ctx:
         self.ns = 0          # LADDER_PREC_* of the split-precision contraction kernels (0 = native f32 MFMA); set by the engine
         self.up2_used = {}   # layer name -> number of upsample-fused launches so far (bench.py's executed-FLOP model)
         self.up2_skipped = {}  # ... and the fraction of the reference's products such a launch never issues (11 / 36 tap-folded, 27 / 36 projected)
-        self.fuse_fwd = True  # projected pairs: forward GEMM + combination in one launch (config `fused_projected_forward`, default 1)
+        self.fuse_fwd = 1    # projected pairs: forward GEMM + combination in one launch (config `fused_projected_forward`: 1 where measured faster, 2 wherever eligible, 0 off)
         self.up2 = True      # resize -> 3x3 conv pairs of the decoder as ONE upsample-fused convolution in forward-only runs (config `upsample_fused_convs`)
 
     @property
@@ -815,7 +815,7 @@ class Conv2D:
         ctx.up2_used[ukey] = ctx.up2_used.get(ukey, 0) + 1
         ctx.up2_skipped[ukey] = 1.0 - 1.0 / (f * f)
         bias = self.ps.w[self.name + "/bias"]
-        if f == 2 and ctx.fuse_fwd and L.query("ladder_up2proj_fused_eligible", N, H, W, self.cin, self.cout):
+        if f == 2 and ctx.fuse_fwd and L.query("ladder_up2proj_fused_eligible" if ctx.fuse_fwd >= 2 else "ladder_up2proj_fused_preferred", N, H, W, self.cin, self.cout):
             # round 6: GEMM + combination in ONE launch, the nine planes in an LDS ring (csrc/upproj.hip: up2proj_fused_fwd_kernel) -- Z never reaches HBM
             y = ctx.empty(N, 2 * H, 2 * W, self.cout) if (keep_y or proj is None) else None
             out, pw, pb, pco = y, None, None, 0
@@ -1903,7 +1903,7 @@ class LadderEngine:
         # 0: off, 1: forward-only runs, 2: also the training forward and the backward-data of the last 3x3 conv, 3: also conv2d_6's backward-data (no gain measured)
         # (strict fp32 default 3: with the fp32 MFMA the 11 / 36 of conv2d_6's backward-data outweigh its border strips, +0.5 %; f16x3: no gain, 2)
         self.ctx.up2 = int(cfg.get("upsample_fused_convs", 4 if prec == "f32" else 2))
-        self.ctx.fuse_fwd = bool(int(cfg.get("fused_projected_forward", 1)))
+        self.ctx.fuse_fwd = int(cfg.get("fused_projected_forward", 1))
         self.precision = prec
         if self.ctx.comm.rank == 0:
             print("Contraction precision (config key matmul_precision): {} -- {}".format(prec, PRECISION_NOTES[prec]))

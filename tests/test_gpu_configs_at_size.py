@@ -406,7 +406,8 @@ def test_data_parallel_full_resolution_vs_live_float64_oracle(tmp_path, prec):
     # workgroups of 4x fewer pixels) -- that one is held against the direct path at batch 128 in tests/test_gpu_up2.py
     # (round 5, strict fp32: the PROJECTED form instead -- every resize -> conv pair from the low-resolution tensor at any batch size, no resize launch left)
     if prec == "f32":
-        assert "ladder_up2proj_fwd_combine" in calls and "ladder_upfproj_bwd_combine" in calls and not any("resize" in c for c in calls), calls
+        # (round 6: the forward of a pair is the one-launch ladder_up2proj_fused_fwd)
+        assert "ladder_up2proj_fused_fwd" in calls and "ladder_upfproj_bwd_combine" in calls and not any("resize" in c for c in calls), calls
     else:
         assert "ladder_conv3x3_up2_split_proj" in calls and "ladder_in_style_fwd_resize2x_keep" in calls, calls
     for k in SCALARS_RUN1:

@@ -401,7 +401,9 @@ def test_f32_engine_routes_through_the_fused_kernels_and_agrees_with_the_direct_
     f4, g4, e4, d4, tc4, ec4, p4 = res[4]
     assert not any("conv3x3_up2" in c or "resize" in c for c in tc4 + ec4), sorted(set(c for c in tc4 + ec4 if "up2" in c or "resize" in c))
     for cs in (tc4, ec4):
-        assert cs.count("ladder_up2proj_fwd_combine") == 1 and cs.count("ladder_upfproj_fwd_combine") == 5      # conv2d_7 + RGB projection; conv2d_1, 3, 4, 5, 6
+        # round 6: the forward of conv2d_7 (with the RGB projection) and conv2d_4 is ONE launch each -- the nine planes stay in LDS (the shapes where that
+        # measured faster: ladder_up2proj_fused_preferred); conv2d_1, conv2d_3, conv2d_5, conv2d_6 keep the GEMM + combination pair
+        assert cs.count("ladder_up2proj_fused_fwd") == 2 and cs.count("ladder_up2proj_fwd_combine") == 0 and cs.count("ladder_upfproj_fwd_combine") == 4
     assert tc4.count("ladder_upfproj_bwd_combine") == 6 and tc4.count("ladder_up2proj_wgrad_unpack") == 6
     # (backward-data: the K-contiguous 16x16x4 kernel where M >= 8192 -- conv2d_4 ... conv2d_7 -- the implicit-GEMM kernel on the 1x1 and 2x2 maps)
     assert tc4.count("ladder_dense_bwd_weight") == 6 and tc4.count("ladder_dense_bwd_data_nt") == 4 and tc4.count("ladder_dense_bwd_data") == 2
@@ -680,3 +682,49 @@ def test_f32_up2_backward_data_gated_equals_ungated_times_activation_derivative(
     # interior: the same product; border lines: gate x (main + correction) against gate x main + gate x correction -- one rounding apart
     assert torch.equal(dx1[:, 1:-1, 1:-1], dx0[:, 1:-1, 1:-1])
     close(dx1, dx0.cpu().numpy(), 1e-6, "border lines")
+
+
+def test_f32_engine_fused_projected_forward_levels_agree(monkeypatch):
+    """`fused_projected_forward` (round 6): 0 = every pair as GEMM + combination (two launches, Z through HBM), 1 = the default (one launch where it
+    measured faster: conv2d_7 + RGB projection, conv2d_4), 2 = every eligible pair (conv2d_4 ... conv2d_7).  Batch 16 at full resolution, training step
+    and forward-only run: the routing is what the level says, and every fetch / the decoded image / every gradient tensor agrees with level 0 to
+    summation-order noise (the same 9 / 36 products in another order: fetches 2e-6, image 1e-5, gradients within 3x the direct-vs-direct floor)."""
+    from ladder_latent_data_distribution_modelling_amd import _lib as L
+    from ladder_latent_data_distribution_modelling_amd.engine import LadderEngine
+    cfg, x, Pm, noise, gm = _celeba_setup(16, 43)
+    calls, real = [], L.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real(name, *a)
+
+    monkeypatch.setattr(L, "call", spy)
+    res = {}
+    for lvl in (0, 1, 2):
+        eng = LadderEngine(dict(cfg, fused_projected_forward=lvl), "cuda:0", values=Pm, seed=1)
+        eng.set_mixture(*gm)
+        del calls[:]
+        eng.run_ae(x, 0.0, noise, False, False)
+        tc = list(calls)
+        f = eng.fetch()
+        g = {k: v.detach().cpu().numpy().copy() for k, v in eng.ps.g.items()}
+        del calls[:]
+        eng.evaluate(x, noise, False, False)
+        ec = list(calls)
+        res[lvl] = (f, g, eng.fetch(), eng.xhat.detach().cpu().numpy().copy(), tc, ec)
+        del eng
+        torch.cuda.empty_cache()
+    for lvl, n_fused in ((0, 0), (1, 2), (2, 4)):
+        for cs in (res[lvl][4], res[lvl][5]):
+            assert cs.count("ladder_up2proj_fused_fwd") == n_fused, (lvl, cs.count("ladder_up2proj_fused_fwd"))
+            assert cs.count("ladder_up2proj_fwd_combine") + cs.count("ladder_upfproj_fwd_combine") == 6 - n_fused
+    f0, g0, e0, d0 = res[0][:4]
+    for lvl in (1, 2):
+        f, g, e, d = res[lvl][:4]
+        for k in ("elbo", "l1_reconstruction_error", "l2_reconstruction_error", "loss_ae", "sigma", "mean_pixel_error"):
+            assert abs(f[k] - f0[k]) <= 2e-6 * abs(f0[k]) + 1e-7, (lvl, k, f[k], f0[k])
+            assert abs(e[k] - e0[k]) <= 2e-6 * abs(e0[k]) + 1e-7, (lvl, k, e[k], e0[k])
+        close(d, d0, 1e-5, "decoded image (fused forward level %d)" % lvl)
+        worst, wname = _worst_grad(g0, g)
+        print("fused_projected_forward %d vs 0: worst relative gradient difference %.2e (%s)" % (lvl, worst, wname))
+        assert worst < 2e-3, (lvl, worst, wname)
