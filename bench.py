@@ -340,10 +340,11 @@ def main():
                 comm.enable_trace(True)
             if graphs:                                          # per-kernel HIP events need individual launches: eager pass
                 trainer.engine.use_graphs = False
-            E.PROF = E.KernelProfiler()
+            kprof = E.KernelProfiler()
+            E.set_profiler(kprof)
             prof_seconds = timed(step, steps)
-            prof = E.PROF.summary()
-            E.PROF = None
+            prof = kprof.summary()
+            E.set_profiler(None)
             comm_table = comm.trace_summary(steps) if comm.on else None
             comm.enable_trace(False)
             if graphs:

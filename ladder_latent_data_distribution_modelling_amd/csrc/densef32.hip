@@ -188,8 +188,12 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt16_f32_kernel(const floa
                                                                       float* __restrict__ C, const float* __restrict__ gate, const int M, const int N,
                                                                       const int K, const int act, const int gate_act, const int tiles_n,
                                                                       const int tiles_total) {
-  __shared__ __attribute__((aligned(16))) float As[2][GB_M * GB_LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[2][GB_N * GB_LDA];
+  // Rows of exactly GB_K = 32 floats, the eight 16-byte quads of row r stored at position q ^ ((r >> 1) & 7).  ds_read_b128 is serviced in the lane groups
+  // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+ 32) = eight rows of one k quad and the OTHER eight rows of the next: with the round-5 layout (rows padded
+  // to 36 floats) 7 of every 8 positions were 2-way conflicted (SQ_LDS_BANK_CONFLICT = 1/3 of SQ_LDS_IDX_ACTIVE, profiles/r05_gemm_pmc.txt); with the XOR the
+  // sixteen lanes of a group hit sixteen different 16-byte bank groups, and the tile takes 64 KB instead of 72.
+  __shared__ __attribute__((aligned(16))) float As[2][GB_M * GB_K];
+  __shared__ __attribute__((aligned(16))) float Bs[2][GB_N * GB_K];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, kq = lane >> 4;
   const int wm = wid >> 1, wn = wid & 1;
   const int cpt = K / GB_K;
@@ -217,11 +221,12 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt16_f32_kernel(const floa
     }
     if (++lc == cpt) { lc = 0; lt += wpx; }
   };
+  const int st_off = a_r * GB_K + 4 * (a_q ^ ((a_r >> 1) & 7));                        // (rows a_r + 32 i share the swizzle: (32 i) >> 1 is a multiple of 8)
   auto store = [&](int buf, const float4 (&ra)[4], const float4 (&rb)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<float4*>(&As[buf][(a_r + 32 * i) * GB_LDA + a_q * 4]) = ra[i];
-      *reinterpret_cast<float4*>(&Bs[buf][(a_r + 32 * i) * GB_LDA + a_q * 4]) = rb[i];
+      *reinterpret_cast<float4*>(&As[buf][st_off + 32 * i * GB_K]) = ra[i];
+      *reinterpret_cast<float4*>(&Bs[buf][st_off + 32 * i * GB_K]) = rb[i];
     }
   };
   f32x4 acc[4][4];                                                                     // [ni][mi]: rows of the instruction = 16 output columns, its columns = 16 output rows
@@ -237,7 +242,9 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt16_f32_kernel(const floa
   if (nchunks > 1) load(ra1, rb1);
   __syncthreads();
   int ct = wi, cc = 0;
-  const int a_off = (wm * 64 + r16) * GB_LDA + 4 * kq, b_off = (wn * 64 + r16) * GB_LDA + 4 * kq;
+  // fragment of 16-deep group u: quad 4 u + kq of row (tile row + r16) -> position (4 u + kq) ^ ((r16 >> 1) & 7)
+  const int sw0 = 4 * (kq ^ ((r16 >> 1) & 7)), sw1 = sw0 ^ 16;
+  const int a_off = (wm * 64 + r16) * GB_K, b_off = (wn * 64 + r16) * GB_K;
   auto iteration = [&](const int g, const int buf, float4 (&ra_ld)[4], float4 (&rb_ld)[4], const float4 (&ra_st)[4], const float4 (&rb_st)[4]) {
     if (g + 2 < nchunks) load(ra_ld, rb_ld);
     {
@@ -247,8 +254,8 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt16_f32_kernel(const floa
       auto frags = [&](int u, int s) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          fa[s][t] = *reinterpret_cast<const float4*>(Ab + t * 16 * GB_LDA + 16 * u);
-          fb[s][t] = *reinterpret_cast<const float4*>(Bb + t * 16 * GB_LDA + 16 * u);
+          fa[s][t] = *reinterpret_cast<const float4*>(Ab + t * 16 * GB_K + (u ? sw1 : sw0));
+          fb[s][t] = *reinterpret_cast<const float4*>(Bb + t * 16 * GB_K + (u ? sw1 : sw0));
         }
       };
       __builtin_amdgcn_sched_barrier(0);
