@@ -41,7 +41,7 @@ FP32_PEAK_TFLOPS = 157.3                # MI355X_MICROARCH.md: fp32 MFMA (= vect
 F16_PEAK_TFLOPS = 2516.6                # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak (256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz)
 # matrix instructions issued per algorithmic fp32 multiply-add by each matmul_precision (csrc/convsplit.hip)
 MFMA_PER_PRODUCT = {"f32": 1, "f16x3": 3, "bf16x3": 3, "bf16x6": 6}
-TRAFFIC_FILES = {"f16x3": ("r03_pmc_traffic.json", "r02_pmc_traffic.json"), "f32": ("r05_f32_pmc_traffic.json", "r04_f32_pmc_traffic.json")}
+TRAFFIC_FILES = {"f16x3": ("r03_pmc_traffic.json", "r02_pmc_traffic.json"), "f32": ("r06_f32_pmc_traffic.json", "r05_f32_pmc_traffic.json", "r04_f32_pmc_traffic.json")}
 
 
 def cpu_baseline(cfg, gm, seconds_budget=20.0, threads=None):
