@@ -256,8 +256,8 @@ int ladder_upfproj_bwd_combine(const float* dy, float* d, int factor, int N, int
  * [Cout][proj_cout], proj_cout <= 4) through per-slab partial sums in `ws` (ladder_up2proj_fused_workspace_bytes), added in a fixed order; y may then be
  * NULL (forward-only runs never write the activation). */
 int ladder_up2proj_fused_eligible(int N, int H, int W, int Cin, int Cout);
-/* 1 where the fused form also measured FASTER than the two-call form (Cin <= 128: the weight slab stays in LDS; 8-pixel-wide maps): the engine's default
- * (`fused_projected_forward: 1`; 2 = every eligible pair, 0 = never). */
+/* 1 where the fused form also measured FASTER than the two-call form as an ISOLATED launch (Cin <= 128: the weight slab stays in LDS; 8-pixel-wide maps):
+ * the engine's `fused_projected_forward: 1`.  Its default is 2 = every eligible pair (fastest over the whole iteration); 0 = never. */
 int ladder_up2proj_fused_preferred(int N, int H, int W, int Cin, int Cout);
 size_t ladder_up2proj_fused_workspace_bytes(int N, int H, int W, int Cout, int proj_cout);
 int ladder_up2proj_fused_fwd(const float* x, const float* wcatT, const float* bias, float* y, const float* proj_w, const float* proj_b, float* proj_out,

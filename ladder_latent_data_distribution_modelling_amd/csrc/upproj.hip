@@ -908,7 +908,8 @@ int ladder_up2proj_fused_eligible(int N, int H, int W, int Cin, int Cout) {
 
 // ... and PREFERRED over the two-call form (measured, batch 128, profiles/r06_fused_probe_v10_final.txt): where the weight slab stays in LDS (Cin <= 128:
 // conv2d_7 1 565 against 2 066 us, with the RGB projection 1 791 / 1 666 against 2 102 / 1 968) and on the 8-pixel-wide maps (conv2d_4: 203 against
-// 226 us); conv2d_5 / conv2d_6 (Cin 256: the slab is re-staged for every row) are level with their GEMM + combination pair, which they keep.
+// 226 us); conv2d_5 / conv2d_6 (Cin 256: the slab is re-staged for every row) are level with their GEMM + combination pair as isolated launches.  (Over the
+// whole iteration fusing them too is what measured fastest -- the engine's default is every eligible pair; this predicate is its level 1.)
 int ladder_up2proj_fused_preferred(int N, int H, int W, int Cin, int Cout) {
   return (ladder_up2proj_fused_eligible(N, H, W, Cin, Cout) && (Cin <= UF_WRES_CIN || W <= 8)) ? 1 : 0;
 }

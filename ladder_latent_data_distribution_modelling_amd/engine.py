@@ -368,7 +368,10 @@ class LadderEngine:
         # 0: off, 1: forward-only runs, 2: also the training forward and the backward-data of the last 3x3 conv, 3: also conv2d_6's backward-data (no gain measured)
         # (strict fp32 default 3: with the fp32 MFMA the 11 / 36 of conv2d_6's backward-data outweigh its border strips, +0.5 %; f16x3: no gain, 2)
         self.ctx.up2 = int(cfg.get("upsample_fused_convs", 4 if prec == "f32" else 2))
-        self.ctx.fuse_fwd = int(cfg.get("fused_projected_forward", 1))
+        # (default 2: in the whole iteration fusing EVERY eligible pair measured fastest -- 19.24 ms against 19.39 with only the pairs that win as isolated
+        # launches and 19.81 with none, same box, profiles/r06_f32_bench_fused_level*.json: a pair that is level in isolation still spares its neighbours 1.2 GB
+        # of HBM traffic and an allocation)
+        self.ctx.fuse_fwd = int(cfg.get("fused_projected_forward", 2))
         self.precision = prec
         if self.ctx.comm.rank == 0:
             print("Contraction precision (config key matmul_precision): {} -- {}".format(prec, PRECISION_NOTES[prec]))

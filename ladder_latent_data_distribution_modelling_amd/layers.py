@@ -121,7 +121,7 @@ class Ctx:
         self.ns = 0          # LADDER_PREC_* of the split-precision contraction kernels (0 = native f32 MFMA); set by the engine
         self.up2_used = {}   # layer name -> number of upsample-fused launches so far (bench.py's executed-FLOP model)
         self.up2_skipped = {}  # ... and the fraction of the reference's products such a launch never issues (11 / 36 tap-folded, 27 / 36 projected)
-        self.fuse_fwd = 1    # projected pairs: forward GEMM + combination in one launch (config `fused_projected_forward`: 1 where measured faster, 2 wherever eligible, 0 off)
+        self.fuse_fwd = 2    # projected pairs: forward GEMM + combination in one launch (config `fused_projected_forward`: 2 wherever eligible (default), 1 only where the isolated launch measured faster, 0 off)
         self.up2 = True      # resize -> 3x3 conv pairs of the decoder as ONE upsample-fused convolution in forward-only runs (config `upsample_fused_convs`)
 
     @property

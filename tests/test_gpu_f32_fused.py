@@ -401,9 +401,9 @@ def test_f32_engine_routes_through_the_fused_kernels_and_agrees_with_the_direct_
     f4, g4, e4, d4, tc4, ec4, p4 = res[4]
     assert not any("conv3x3_up2" in c or "resize" in c for c in tc4 + ec4), sorted(set(c for c in tc4 + ec4 if "up2" in c or "resize" in c))
     for cs in (tc4, ec4):
-        # round 6: the forward of conv2d_7 (with the RGB projection) and conv2d_4 is ONE launch each -- the nine planes stay in LDS (the shapes where that
-        # measured faster: ladder_up2proj_fused_preferred); conv2d_1, conv2d_3, conv2d_5, conv2d_6 keep the GEMM + combination pair
-        assert cs.count("ladder_up2proj_fused_fwd") == 2 and cs.count("ladder_up2proj_fwd_combine") == 0 and cs.count("ladder_upfproj_fwd_combine") == 4
+        # round 6: the forward of conv2d_4 ... conv2d_7 (conv2d_7 with the RGB projection) is ONE launch each -- the nine planes stay in LDS; the 1x1 and 2x2
+        # maps (conv2d_1 behind the 1x1 -> 2x2 resize, conv2d_3 behind the factor-4 one) keep the GEMM + combination pair
+        assert cs.count("ladder_up2proj_fused_fwd") == 4 and cs.count("ladder_up2proj_fwd_combine") == 0 and cs.count("ladder_upfproj_fwd_combine") == 2
     assert tc4.count("ladder_upfproj_bwd_combine") == 6 and tc4.count("ladder_up2proj_wgrad_unpack") == 6
     # (backward-data: the K-contiguous 16x16x4 kernel where M >= 8192 -- conv2d_4 ... conv2d_7 -- the implicit-GEMM kernel on the 1x1 and 2x2 maps)
     assert tc4.count("ladder_dense_bwd_weight") == 6 and tc4.count("ladder_dense_bwd_data_nt") == 4 and tc4.count("ladder_dense_bwd_data") == 2
@@ -685,8 +685,8 @@ def test_f32_up2_backward_data_gated_equals_ungated_times_activation_derivative(
 
 
 def test_f32_engine_fused_projected_forward_levels_agree(monkeypatch):
-    """`fused_projected_forward` (round 6): 0 = every pair as GEMM + combination (two launches, Z through HBM), 1 = the default (one launch where it
-    measured faster: conv2d_7 + RGB projection, conv2d_4), 2 = every eligible pair (conv2d_4 ... conv2d_7).  Batch 16 at full resolution, training step
+    """`fused_projected_forward` (round 6): 0 = every pair as GEMM + combination (two launches, Z through HBM), 1 = one launch where the isolated launch
+    measured faster (conv2d_7 + RGB projection, conv2d_4), 2 = every eligible pair (conv2d_4 ... conv2d_7; the default).  Batch 16 at full resolution, training step
     and forward-only run: the routing is what the level says, and every fetch / the decoded image / every gradient tensor agrees with level 0 to
     summation-order noise (the same 9 / 36 products in another order: fetches 2e-6, image 1e-5, gradients within 3x the direct-vs-direct floor)."""
     from ladder_latent_data_distribution_modelling_amd import _lib as L
