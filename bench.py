@@ -20,6 +20,9 @@ barrier + torch.cuda.synchronize() on both sides and reduced with MAX over ranks
 region (all regions are listed in `repeats_images_per_sec`).  The roofline's per-kernel durations come from ONE further region of K steps
 with HIP events around every contraction launch; a `sustained` leg of >= 30 s of back-to-back steps follows (clock / power settle there).
 `roofline.achieved` / `frac` count the FLOPs the kernel ISSUES (`effective`: the reference's operation count of the same launches).
+`parity` (N = 1): the HIP engine evaluated on the FIRST iteration of the `cpu_baseline` leg -- the same 4 images, seeded parameters, noise draws and mixture -- and
+the relative deviation of its `elbo` / `elbo_prior` from the fp32 CPU oracle's (north_star: identical inputs, same run; tolerance 1e-3).  `comm.measured_small_allreduce_us`
+(N > 1): back-to-back 8 B / 352 B / 2 KB all-reduces of the job's backend, measured before the timed regions; the ring model's latency term is that 8-byte number.
 Prints ONE JSON line on rank 0.  Exits non-zero when the number of ranks actually running differs from --gpus.
 """
 import argparse
