@@ -256,9 +256,13 @@ int ladder_upfproj_bwd_combine(const float* dy, float* d, int factor, int N, int
  * [Cout][proj_cout], proj_cout <= 4) through per-slab partial sums in `ws` (ladder_up2proj_fused_workspace_bytes), added in a fixed order; y may then be
  * NULL (forward-only runs never write the activation). */
 int ladder_up2proj_fused_eligible(int N, int H, int W, int Cin, int Cout);
-/* 1 where the fused form also measured FASTER than the two-call form as an ISOLATED launch (Cin <= 128: the weight slab stays in LDS; 8-pixel-wide maps):
+/* 1 where the fused form also measured FASTER than the two-call form as an ISOLATED launch (Cin <= 128: the weight slab stays in LDS; 8-pixel-wide maps; the shapes of
+ * ladder_up2proj_fused_wide_tile):
  * the engine's `fused_projected_forward: 1`.  Its default is 2 = every eligible pair (fastest over the whole iteration); 0 = never. */
 int ladder_up2proj_fused_preferred(int N, int H, int W, int Cin, int Cout);
+/* 1 when the call (without projection) runs the 128-pixel row step variant: an MFMA wave owns two 16-pixel tiles, so a weight fragment feeds 8 MFMAs -- used
+ * where the weight slab cannot stay in LDS (Cin > 128), W is 16 or 32, N a multiple of 128 / W and the grid (N W / 128) x (Cout / 16) >= 256 workgroups. */
+int ladder_up2proj_fused_wide_tile(int N, int H, int W, int Cin, int Cout);
 size_t ladder_up2proj_fused_workspace_bytes(int N, int H, int W, int Cout, int proj_cout);
 int ladder_up2proj_fused_fwd(const float* x, const float* wcatT, const float* bias, float* y, const float* proj_w, const float* proj_b, float* proj_out,
                              int proj_cout, int N, int H, int W, int Cin, int Cout, int act, void* ws, size_t ws_bytes, ladder_stream_t stream);

@@ -161,6 +161,7 @@ PROTOTYPES = {
     "ladder_upfproj_bwd_combine": (_i, [_p, _p] + [_i] * 5 + [_p]),
     "ladder_up2proj_fused_eligible": (_i, [_i] * 5),
     "ladder_up2proj_fused_preferred": (_i, [_i] * 5),
+    "ladder_up2proj_fused_wide_tile": (_i, [_i] * 5),
     "ladder_up2proj_fused_workspace_bytes": (_z, [_i] * 5),
     "ladder_up2proj_fused_fwd": (_i, [_p] * 7 + [_i] * 7 + [_p, _z, _p]),
     "ladder_dense_small_eligible": (_i, [_i, _i, _i]),

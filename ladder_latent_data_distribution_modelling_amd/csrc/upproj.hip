@@ -694,6 +694,261 @@ __global__ __launch_bounds__(UF_THREADS, 3) void up2proj_fused_fwd_kernel(const 
   if (!(dbg & 1)) emit(H - 1, hc[1], hc[2]);                                          // the last block row: its "row below" is the clamped last row itself
 }
 
+// ---- the same kernel with a 32-PIXEL wave tile (Cin > 128: the weight slab is re-staged for every row) -----------------------------------------------------------
+// A row step covers 128 pixels (row k of 2 x 64 / W images): an MFMA wave owns TWO pixel tiles, so one weight fragment feeds 8 MFMAs instead of 4 -- half the
+// fragment reads per MFMA and half the slab traffic per flop of the 16-pixel tile (profiles/r06_fused_probe.txt: conv2d_6 / conv2d_5 ran at 0.60 of peak there).
+// LDS: two x rows per stage and a 128-pixel plane row leave room for TWO stages (160.9 KB); registers: 72 accumulators, so the fragments are not double-buffered
+// as a set but ROLLED -- tap t's weight fragment of the NEXT 16-deep group is requested right after tap t's eight MFMAs of the current one, into the register those
+// MFMAs have just released (at any time nine weight fragments are live).  A stage is released five tap blocks into its second group with an explicit
+// `s_waitcnt lgkmcnt(2)`: LDS returns in order, the stage's last read is at least seven requests old by then.  No RGB projection (that pair has Cin = 128).
+constexpr int UF2_PX = 128, UF2_PLANE = UF2_PX * UF_CS, UF2_STAGES = 2;
+enum { UF2_FULL0 = 0, UF2_EMPTY0 = 4 * UF2_STAGES, UF2_ZFULL = 8 * UF2_STAGES, UF2_CDONE = 8 * UF2_STAGES + 4, UF2_NFLAGS = 8 * UF2_STAGES + 8 };
+
+__global__ __launch_bounds__(UF_THREADS, 3) void up2proj_fused2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wT, const float* __restrict__ bias,
+                                                                           float* __restrict__ y, const int N, const int H, const int W, const int wshift,
+                                                                           const int Cin, const int Cout, const int act) {
+  __shared__ __attribute__((aligned(16))) float Xs[UF2_STAGES][UF2_PX * UF_LD];
+  __shared__ __attribute__((aligned(16))) float Ws[UF2_STAGES][UF_N * UF_LD];
+  __shared__ __attribute__((aligned(16))) float Zr[9 * UF2_PLANE];
+  __shared__ __attribute__((aligned(16))) int flags[UF2_NFLAGS];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, kq = lane >> 4;
+  const int G = UF2_PX >> wshift, ngroups = N / G, nslab = Cout / UF_CS;
+  int group, slab;                                                                    // (as in the 64-pixel kernel: the slabs of a group on one XCD)
+  if ((ngroups & 7) == 0) {
+    const int xcd = (int)(blockIdx.x & 7), l = (int)(blockIdx.x >> 3);
+    group = (l / nslab) * 8 + xcd;
+    slab = l % nslab;
+  } else {
+    group = (int)blockIdx.x / nslab;
+    slab = (int)blockIdx.x % nslab;
+  }
+  const int n0 = group * G, c0 = slab * UF_CS;
+  const int cpt = Cin / UF_K, total = H * cpt;
+  if (tid < UF2_NFLAGS) flags[tid] = 0;
+  __syncthreads();
+
+  if (wid < UF_MW) {
+    // ------------------------------------------------------------------------------------------------ MFMA waves: pixel tiles wid and wid + 4
+    __builtin_amdgcn_s_setprio(2);
+    const int pt = wid;
+    f32x4_t acc[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int p_ = 0; p_ < 2; ++p_)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][p_][e] = 0.f;
+    float4 fx[2], nfx[2], fw[9];
+    const int x_off0 = (pt * 16 + r16) * UF_LD + 4 * kq, x_off1 = x_off0 + 64 * UF_LD, w_off = r16 * UF_LD + 4 * kq;
+    const int z_px0 = pt * 16 + r16, z_off0 = z_px0 * UF_CS + 4 * (kq ^ ((z_px0 >> 1) & 3));     // (pixel + 64 has the same swizzle)
+    auto rdx = [&](float4 (&d)[2], const int sg, const int u) __attribute__((always_inline)) {
+      d[0] = *reinterpret_cast<const float4*>(&Xs[sg][x_off0 + 16 * u]);
+      d[1] = *reinterpret_cast<const float4*>(&Xs[sg][x_off1 + 16 * u]);
+    };
+    auto rdw = [&](const int t, const int sg, const int u) __attribute__((always_inline)) {
+      fw[t] = *reinterpret_cast<const float4*>(&Ws[sg][w_off + t * 16 * UF_LD + 16 * u]);
+    };
+    auto mmt = [&](const int t) __attribute__((always_inline)) {                      // tap t of the current group: 4 k-steps x 2 pixel tiles
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = j == 0 ? fw[t].x : (j == 1 ? fw[t].y : (j == 2 ? fw[t].z : fw[t].w));
+#pragma unroll
+        for (int p_ = 0; p_ < 2; ++p_) {
+          const float b = j == 0 ? fx[p_].x : (j == 1 ? fx[p_].y : (j == 2 ? fx[p_].z : fx[p_].w));
+          acc[t][p_] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t][p_], 0, 0, 0);
+        }
+      }
+    };
+    uf_wait(&flags[UF2_FULL0], 1);
+    rdx(fx, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) rdw(t, 0, 0);
+    int k = 0, c = 0, round = 0;                                                      // chunk g lives in stage g & 1, its round = g >> 1
+    auto chunk = [&](auto SG, const int g) __attribute__((always_inline)) {
+      constexpr int sg = decltype(SG)::value, sn = sg ^ 1;
+      const int round_n = sn == 0 ? round + 1 : round;
+      // group 0: its fragments are in registers; the requests issued beside its MFMAs are those of group 1 of the same stage
+      const int seen = uf_peek(&flags[UF2_FULL0 + 4 * sn]);
+      rdx(nfx, sg, 1);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        __builtin_amdgcn_sched_barrier(0);
+        mmt(t);
+        rdw(t, sg, 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      fx[0] = nfx[0]; fx[1] = nfx[1];
+      // group 1: the requests beside its MFMAs go to the NEXT stage
+      const int nxt_target = (g + 1 < total) ? round_n + 1 : 0;
+      if (seen < nxt_target) uf_wait(&flags[UF2_FULL0 + 4 * sn], nxt_target);
+      rdx(nfx, sn, 0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        __builtin_amdgcn_sched_barrier(0);
+        mmt(t);
+        rdw(t, sn, 0);
+        if (t == 4) {
+          // every fragment read of stage sg is >= 7 requests old (2 of x + 5 of the weights of the next stage since): release it without waiting for the newest two
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+          if (lane == 0) __hip_atomic_store(&flags[UF2_EMPTY0 + 4 * sg + wid], round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          asm volatile("" ::: "memory");
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      fx[0] = nfx[0]; fx[1] = nfx[1];
+      round = round_n;
+      if (c == cpt - 1) {
+        if (k >= 1) uf_wait(&flags[UF2_CDONE], k);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int p_ = 0; p_ < 2; ++p_) {
+            *reinterpret_cast<float4*>(&Zr[t * UF2_PLANE + p_ * 64 * UF_CS + z_off0]) = make_float4(acc[t][p_][0], acc[t][p_][1], acc[t][p_][2], acc[t][p_][3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][p_][e] = 0.f;
+          }
+        ++k;
+        uf_publish(&flags[UF2_ZFULL + wid], k);
+        c = 0;
+      } else {
+        ++c;
+      }
+    };
+    for (int g = 0; g < total; g += 2) {
+      chunk(std::integral_constant<int, 0>{}, g);
+      if (g + 1 < total) chunk(std::integral_constant<int, 1>{}, g + 1);
+    }
+    return;
+  }
+
+  if (wid < UF_MW + UF_SW) {
+    // ------------------------------------------------------------------------------------------------ staging waves: 128 x rows + 144 weight rows per chunk
+    const int st = tid - UF_MW * 64, sq = st & 7, sr = st >> 3;
+    const float* xb[4];
+    const float* wb[5];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = sr + 32 * i;
+      xb[i] = x + ((long)(n0 + (m >> wshift)) * H * W + (m & (W - 1))) * Cin + sq * 4;
+    }
+    const bool w4_on = st < 128;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int nl = (i < 4 || w4_on) ? sr + 32 * i : 0;
+      wb[i] = wT + ((long)(nl >> 4) * Cout + c0 + (nl & 15)) * Cin + sq * 4;
+    }
+    float4 s0[9], s1[9], s2[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s0[i] = s1[i] = s2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load = [&](const int g, float4 (&r)[9]) __attribute__((always_inline)) {
+      const int kk = g / cpt, cc = g - kk * cpt;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const float4*>(xb[i] + (long)kk * W * Cin + cc * UF_K);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[4 + i] = *reinterpret_cast<const float4*>(wb[i] + cc * UF_K);
+      if (w4_on) r[8] = *reinterpret_cast<const float4*>(wb[4] + cc * UF_K);
+    };
+    int sg = 0, round = 0;
+    auto step = [&](const int g, const float4 (&cur)[9], float4 (&nxt)[9]) __attribute__((always_inline)) {
+      if (g + 2 < total) load(g + 2, nxt);                                            // (a chunk is 4 608 MFMA cycles here: two ahead covers what four covered at 64 pixels)
+      if (round >= 1) uf_wait<4>(&flags[UF2_EMPTY0 + 4 * sg], round);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Xs[sg][(sr + 32 * i) * UF_LD + sq * 4]) = cur[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Ws[sg][(sr + 32 * i) * UF_LD + sq * 4]) = cur[4 + i];
+      if (w4_on) *reinterpret_cast<float4*>(&Ws[sg][(sr + 128) * UF_LD + sq * 4]) = cur[8];
+      uf_publish(&flags[UF2_FULL0 + 4 * sg + (wid - UF_MW)], round + 1);
+      if (++sg == UF2_STAGES) { sg = 0; ++round; }
+    };
+    load(0, s0);
+    if (total > 1) load(1, s1);
+    for (int g = 0; g < total; g += 3) {
+      step(g, s0, s2);
+      if (g + 1 < total) step(g + 1, s1, s0);
+      if (g + 2 < total) step(g + 2, s2, s1);
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------------- combination waves: two (pixel, quad) items per thread
+  const int ct = tid - (UF_MW + UF_SW) * 64;
+  const int cq = ct & 3, cm = ct >> 2;                                                // items: pixel cm and pixel cm + 64 (same column, 64 / W images further)
+  const int cg = cm >> wshift, cj = cm & (W - 1), gstep = 64 >> wshift;
+  AxisW S[3];
+#pragma unroll
+  for (int sx = 0; sx < 3; ++sx) S[sx] = up2_axis(sx, cj, W);
+  const float4 bv = bias != nullptr ? *reinterpret_cast<const float4*>(bias + c0 + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* Zq = reinterpret_cast<const float4*>(Zr);
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // Per item the row halo is carried as the PARTIAL outputs of the open block row (everything that does not depend on the row below: 2 x 2 x 4 values) and
+  // the folded tap-row-0 values of the previous row -- 24 registers instead of the 56 of three folded rows (two items per thread have to fit 168 VGPRs).
+  float4 pp[2][2][2], h0p[2][2];                                                       // [item][output-row parity][column parity], [item][column parity]
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    h0p[it][0] = h0p[it][1] = zero4;
+#pragma unroll
+    for (int ca = 0; ca < 2; ++ca) pp[it][ca][0] = pp[it][ca][1] = zero4;
+  }
+  auto zoff = [&](const int it, const int col) __attribute__((always_inline)) { const int p_ = ((cg + it * gstep) << wshift) + col; return p_ * 4 + (cq ^ ((p_ >> 1) & 3)); };
+  // block row i of item `it` is complete: add the terms of the row below (folded tap rows 1, 2: n1, n2), activate, store
+  auto finish = [&](const int i, const int it, const float4 (&n1)[2], const float4 (&n2)[2]) __attribute__((always_inline)) {
+    const AxisW R1 = up2_axis(1, i, H), R2 = up2_axis(2, i, H);
+#pragma unroll
+    for (int ca = 0; ca < 2; ++ca) {
+      float4 o[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float4 v = pp[it][ca][b];
+        v = f4_fma(R1.whi[ca], n1[b], v);
+        v = f4_fma(R2.whi[ca], n2[b], v);
+        o[b] = make_float4(ladder_act_fn(v.x, act), ladder_act_fn(v.y, act), ladder_act_fn(v.z, act), ladder_act_fn(v.w, act));
+      }
+      const long opix = ((long)(n0 + cg + it * gstep) * 2 * H + 2 * i + ca) * 2 * W + 2 * cj;
+      float4* yp = reinterpret_cast<float4*>(y + opix * Cout + c0) + cq;
+      st_stream(yp, o[0]);
+      st_stream(yp + (Cout >> 2), o[1]);
+    }
+  };
+  for (int k = 0; k < H; ++k) {
+    uf_wait<6>(&flags[UF2_ZFULL], k + 1);
+    const AxisW R0 = up2_axis(0, k, H), R1 = up2_axis(1, k, H), R2 = up2_axis(2, k, H);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      float4 hn[3][2];                                                                // row k of item `it`, folded along the columns
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        float4 h0 = zero4, h1 = zero4;
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx) {
+          const float4* zp = Zq + ((r * 3 + sx) * UF2_PLANE >> 2);
+          const float4 v0 = zp[zoff(it, S[sx].lo)], v1 = zp[zoff(it, S[sx].hi)];
+          h0 = f4_fma(S[sx].wlo[0], v0, h0); h0 = f4_fma(S[sx].whi[0], v1, h0);
+          h1 = f4_fma(S[sx].wlo[1], v0, h1); h1 = f4_fma(S[sx].whi[1], v1, h1);
+        }
+        hn[r][0] = h0;
+        hn[r][1] = h1;
+      }
+      if (it == 1) uf_publish(&flags[UF2_CDONE + (wid - UF_MW - UF_SW)], k + 1);     // both items have read row k: the MFMA waves may write row k + 1
+      if (k >= 1) finish(k - 1, it, hn[1], hn[2]);
+      // open block row k: bias + tap row 0 (rows k - 1, k) + the own-row terms of tap rows 1, 2
+#pragma unroll
+      for (int ca = 0; ca < 2; ++ca)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          float4 v = bv;
+          v = f4_fma(R0.wlo[ca], h0p[it][b], v); v = f4_fma(R0.whi[ca], hn[0][b], v);
+          v = f4_fma(R1.wlo[ca], hn[1][b], v);
+          v = f4_fma(R2.wlo[ca], hn[2][b], v);
+          pp[it][ca][b] = v;
+        }
+      h0p[it][0] = hn[0][0]; h0p[it][1] = hn[0][1];
+      if (k == H - 1) finish(H - 1, it, hn[1], hn[2]);                                // the last block row: its "row below" is the clamped last row itself
+      __builtin_amdgcn_sched_barrier(0);                                              // (one item after the other: their temporaries must not be live together)
+    }
+  }
+}
+
 // pout [P][pco] = pb + sum over the slabs (in order) of the partial projections [nslab][pco][P]; one thread per pixel
 __global__ __launch_bounds__(256) void up2proj_proj_reduce_kernel(const float* __restrict__ ppart, const float* __restrict__ pb, float* __restrict__ pout,
                                                                   const long P, const int pco, const int nslab) {
@@ -906,12 +1161,21 @@ int ladder_up2proj_fused_eligible(int N, int H, int W, int Cin, int Cout) {
   return 1;
 }
 
-// ... and PREFERRED over the two-call form (measured, batch 128, profiles/r06_fused_probe_v10_final.txt): where the weight slab stays in LDS (Cin <= 128:
-// conv2d_7 1 565 against 2 066 us, with the RGB projection 1 791 / 1 666 against 2 102 / 1 968) and on the 8-pixel-wide maps (conv2d_4: 203 against
-// 226 us); conv2d_5 / conv2d_6 (Cin 256: the slab is re-staged for every row) are level with their GEMM + combination pair as isolated launches.  (Over the
-// whole iteration fusing them too is what measured fastest -- the engine's default is every eligible pair; this predicate is its level 1.)
+// ... and PREFERRED over the two-call form as an isolated launch (measured, batch 128, profiles/r06_fused_probe.txt): where the weight slab stays in LDS (Cin <= 128:
+// conv2d_7 1 559 against 2 022 us, with the RGB projection 1 809 / 1 670 against 2 062 / 1 950), on the 8-pixel-wide maps (conv2d_4: 199 against 226 us) and where the
+// 128-pixel row step applies (conv2d_6 705 against 799 us, conv2d_5 340 against 398).  (The engine's default fuses every ELIGIBLE pair.)
+int ladder_up2proj_fused_wide_tile(int N, int H, int W, int Cin, int Cout);
 int ladder_up2proj_fused_preferred(int N, int H, int W, int Cin, int Cout) {
-  return (ladder_up2proj_fused_eligible(N, H, W, Cin, Cout) && (Cin <= UF_WRES_CIN || W <= 8)) ? 1 : 0;
+  return (ladder_up2proj_fused_eligible(N, H, W, Cin, Cout) && (Cin <= UF_WRES_CIN || W <= 8 || ladder_up2proj_fused_wide_tile(N, H, W, Cin, Cout))) ? 1 : 0;
+}
+
+// 1 when ladder_up2proj_fused_fwd (without projection) runs the 128-pixel row step / 32-pixel wave tile kernel: the slab cannot stay resident (Cin > 128), two
+// 64-pixel groups exist per row step (W 16 or 32) and the grid still covers the chip
+int ladder_up2proj_fused_wide_tile(int N, int H, int W, int Cin, int Cout) {
+  static const bool pt2_off = getenv("LADDER_UP2FUSE_NO_PT2") != nullptr;
+  static const bool any = getenv("LADDER_UP2FUSE_PT2_ANY") != nullptr;                // (experiment switch: also where the slab would fit, and on 64-pixel-wide maps)
+  return (!pt2_off && ladder_up2proj_fused_eligible(N, H, W, Cin, Cout) && (any || (Cin > UF_WRES_CIN && (W == 16 || W == 32))) && W <= 64 && N % (UF2_PX / W) == 0 &&
+          (long)(N / (UF2_PX / W)) * (Cout / UF_CS) >= 256) ? 1 : 0;
 }
 
 size_t ladder_up2proj_fused_workspace_bytes(int N, int H, int W, int Cout, int proj_cout) {
@@ -928,6 +1192,13 @@ int ladder_up2proj_fused_fwd(const float* x, const float* wcatT, const float* bi
   while ((1 << wshift) < W) ++wshift;
   static const int dbg = getenv("LADDER_UP2FUSE_DBG") != nullptr ? atoi(getenv("LADDER_UP2FUSE_DBG")) : 0;
   const unsigned grid = (unsigned)(N / (UF_PX / W)) * (unsigned)(Cout / UF_CS);
+  // 128-pixel row steps (32-pixel wave tiles) where the slab cannot stay resident, two images fill the row step and the grid still covers the chip
+  if (proj_out == nullptr && y != nullptr && dbg == 0 && ladder_up2proj_fused_wide_tile(N, H, W, Cin, Cout)) {
+    const unsigned grid2 = (unsigned)(N / (UF2_PX / W)) * (unsigned)(Cout / UF_CS);
+    hipLaunchKernelGGL(up2proj_fused2_fwd_kernel, dim3(grid2), dim3(UF_THREADS), 0, stream, x, wcatT, bias, y, N, H, W, wshift, Cin, Cout, act);
+    LADDER_CHECK_LAUNCH();
+    return LADDER_OK;
+  }
   static const bool wres_off = getenv("LADDER_UP2FUSE_NO_WRES") != nullptr;
   const bool wres = Cin <= UF_WRES_CIN && !wres_off;                                   // the weight slab fits LDS beside the x stages and the plane row
   float* pp = proj_out != nullptr ? (float*)ws : nullptr;

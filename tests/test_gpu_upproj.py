@@ -301,6 +301,37 @@ def test_upproj_fused_forward_vs_oracle(gpu_ctx, case):
     assert torch.equal(y, y3)
 
 
+# shapes that take the 128-pixel row step (32-pixel wave tile): Cin > 128, W 16 / 32, >= 256 workgroups -- two rows (one hand-over of the plane row), odd row counts,
+# the real conv2d_5 / conv2d_6 shapes
+WIDE_CASES = [(128, 2, 32, 160, 128, "leaky_relu"), (128, 5, 32, 256, 128, None), (64, 3, 16, 192, 512, "leaky_relu"), (128, 16, 16, 256, 256, "leaky_relu"),
+              (128, 32, 32, 256, 128, "leaky_relu")]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES, ids=lambda c: "n%d_%dx%d_c%d_co%d_%s" % c)
+def test_upproj_fused_forward_wide_tile_vs_oracle(gpu_ctx, case):
+    """up2proj_fused2_fwd_kernel (two pixel tiles per MFMA wave, rolled weight fragments, two stages, two combination items per thread) against the float64
+    oracle on every pixel and against the 64-pixel kernel's result (LADDER_UP2FUSE_NO_PT2 cannot be toggled in-process: the two-call form stands in)."""
+    L = _lib()
+    N, H, W, cin, cout, act = case
+    st = gpu_ctx.stream
+    assert L.query("ladder_up2proj_fused_wide_tile", N, H, W, cin, cout) == 1
+    rng = np.random.default_rng(H * 10 + cin + N)
+    x = rng.standard_normal((N, H, W, cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32) * 0.1
+    wcat, wcatT = _pack(L, w, st)
+    xd, bd = dev(x), dev(b)
+    y = torch.full((N, 2 * H, 2 * W, cout), float("nan"), device="cuda")
+    L.call("ladder_up2proj_fused_fwd", p(xd), p(wcatT), p(bd), p(y), None, None, None, 0, N, H, W, cin, cout, 1 if act else 0, None, 0, st)
+    y2, _ = _forward(L, xd, wcat, bd, N, H, W, cin, cout, 1 if act else 0, st)
+    close(y, y2.cpu().numpy().astype(np.float64), TOL32, "wide tile vs two-call form")
+    if N * H * W * cout <= (1 << 24):                                        # (the float64 convolution of the two largest cases takes minutes on the host)
+        close(y, _ref_fwd(x, w, b, act), TOL32, "y (every pixel)")
+    y3 = torch.full_like(y, float("nan"))
+    L.call("ladder_up2proj_fused_fwd", p(xd), p(wcatT), p(bd), p(y3), None, None, None, 0, N, H, W, cin, cout, 1 if act else 0, None, 0, st)
+    assert torch.equal(y, y3)
+
+
 @pytest.mark.parametrize("case", [(2, 64, 64, 128, 128, 3, True), (4, 32, 32, 64, 128, 3, False), (8, 4, 16, 64, 64, 4, True), (8, 6, 8, 96, 32, 1, False)],
                          ids=lambda c: "n%d_%dx%d_c%d_co%d_p%d_y%d" % c)
 def test_upproj_fused_forward_with_projection_vs_oracle(gpu_ctx, case):
