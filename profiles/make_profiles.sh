@@ -12,7 +12,7 @@ cd $R
 grep '^{"metric"' gpurun_out/r06_f32_bench_under_rocprof.log > gpurun_out/r06_f32_bench_under_rocprof.json
 python3 profiles/summarize_rocpd.py $(find gpurun_out/prof_k -name "*.db" | head -1) > gpurun_out/r06_f32_bench_kernel_stats.md
 python3 profiles/pmc_traffic.py $(find gpurun_out/pmc_f -name "*.db" | head -1) $(find gpurun_out/pmc_w -name "*.db" | head -1) gpurun_out/r06_f32_pmc_traffic.json \
-    up2proj_fused_fwd_kernel gemm_f32_kernel gemm_nt16_f32_kernel gemm_tn_f32_kernel up2proj_fwd_combine_rows_kernel up2proj_bwd_combine_kernel up2proj_proj_reduce_kernel conv3x3_halo_f32_kernel conv3x3_halo_f32s_kernel wgrad3x3_halo_kernel igemm_fwd_kernel igemm_wgrad_kernel gemm_small > /dev/null
+    up2proj_fused gemm_f32_kernel gemm_nt16_f32_kernel gemm_tn_f32_kernel up2proj_fwd_combine_rows_kernel up2proj_bwd_combine_kernel up2proj_proj_reduce_kernel conv3x3_halo_f32_kernel conv3x3_halo_f32s_kernel wgrad3x3_halo_kernel igemm_fwd_kernel igemm_wgrad_kernel gemm_small > /dev/null
 python3 profiles/tools/r3_percall.py --precision f32 --top 90 > gpurun_out/r06_f32_percall.md 2>/dev/null
 python3 profiles/tools/r6_fused_probe.py > gpurun_out/r06_fused_probe.txt 2>/dev/null
 python3 profiles/tools/r5_upproj_probe.py > gpurun_out/r06_upproj_probe.txt 2>/dev/null

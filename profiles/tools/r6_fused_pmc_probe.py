@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import r5_pmc_probe as P
-P.KERNELS = ("up2proj_fused_fwd", "gemm_f32_kernel", "up2proj_fwd_combine")
+P.KERNELS = ("up2proj_fused", "gemm_f32_kernel", "up2proj_fwd_combine")
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--show":
