@@ -706,7 +706,7 @@ enum { UF2_FULL0 = 0, UF2_EMPTY0 = 4 * UF2_STAGES, UF2_ZFULL = 8 * UF2_STAGES, U
 
 __global__ __launch_bounds__(UF_THREADS, 3) void up2proj_fused2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wT, const float* __restrict__ bias,
                                                                            float* __restrict__ y, const int N, const int H, const int W, const int wshift,
-                                                                           const int Cin, const int Cout, const int act) {
+                                                                           const int Cin, const int Cout, const int act, const int poll) {
   __shared__ __attribute__((aligned(16))) float Xs[UF2_STAGES][UF2_PX * UF_LD];
   __shared__ __attribute__((aligned(16))) float Ws[UF2_STAGES][UF_N * UF_LD];
   __shared__ __attribute__((aligned(16))) float Zr[9 * UF2_PLANE];
@@ -852,7 +852,13 @@ __global__ __launch_bounds__(UF_THREADS, 3) void up2proj_fused2_fwd_kernel(const
     int sg = 0, round = 0;
     auto step = [&](const int g, const float4 (&cur)[9], float4 (&nxt)[9]) __attribute__((always_inline)) {
       if (g + 2 < total) load(g + 2, nxt);                                            // (a chunk is 4 608 MFMA cycles here: two ahead covers what four covered at 64 pixels)
-      if (round >= 1) uf_wait<4>(&flags[UF2_EMPTY0 + 4 * sg], round);
+      if (round >= 1) {
+        int spins = 0;
+        while (uf_peek(&flags[UF2_EMPTY0 + 4 * sg]) < round) {
+          for (int q = 0; q < poll; ++q) __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1 << 22)) __builtin_trap();
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Xs[sg][(sr + 32 * i) * UF_LD + sq * 4]) = cur[i];
 #pragma unroll
@@ -1195,7 +1201,8 @@ int ladder_up2proj_fused_fwd(const float* x, const float* wcatT, const float* bi
   // 128-pixel row steps (32-pixel wave tiles) where the slab cannot stay resident, two images fill the row step and the grid still covers the chip
   if (proj_out == nullptr && y != nullptr && dbg == 0 && ladder_up2proj_fused_wide_tile(N, H, W, Cin, Cout)) {
     const unsigned grid2 = (unsigned)(N / (UF2_PX / W)) * (unsigned)(Cout / UF_CS);
-    hipLaunchKernelGGL(up2proj_fused2_fwd_kernel, dim3(grid2), dim3(UF_THREADS), 0, stream, x, wcatT, bias, y, N, H, W, wshift, Cin, Cout, act);
+    static const int poll = getenv("LADDER_UP2FUSE_POLL") != nullptr ? atoi(getenv("LADDER_UP2FUSE_POLL")) : 4;   // staging waves: x 64 cycles between polls
+    hipLaunchKernelGGL(up2proj_fused2_fwd_kernel, dim3(grid2), dim3(UF_THREADS), 0, stream, x, wcatT, bias, y, N, H, W, wshift, Cin, Cout, act, poll);
     LADDER_CHECK_LAUNCH();
     return LADDER_OK;
   }
