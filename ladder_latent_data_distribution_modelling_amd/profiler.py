@@ -30,9 +30,10 @@ class KernelProfiler:
                    "per workgroup, 32-pixel chunks, software-pipelined LDS fragments, fp32 MFMA 32x32x2)",
              128132: "gemm_f32_kernel (projection GEMMs of the project-then-upsample pairs, Z = x . wcat: persistent workgroups over 128x128 "
                      "tiles, XCD-aware tile order, 32-deep chunks, 128-bit A fragments, software-pipelined LDS reads, fp32 MFMA 32x32x2)",
-             128136: "up2proj_fused_fwd_kernel (forward of a project-then-upsample pair in ONE launch: per (64 / W images, 16 output channels) workgroup the "
-                     "projection GEMM Z = x . wcat row by row on fp32 MFMA 16x16x4, the nine planes of three rows in an LDS ring, the combination + activation "
-                     "(+ 1x1 output projection) from the ring; Z never written to HBM)",
+             128136: "up2proj_fused_fwd_kernel / up2proj_fused2_fwd_kernel (forward of a project-then-upsample pair in ONE launch: per (few images, 16 output channels) "
+                     "workgroup the projection GEMM Z = x . wcat row by row on fp32 MFMA 16x16x4 by four MFMA-only waves -- weight slab resident in LDS at Cin 128, "
+                     "32-pixel wave tiles with rolled fragments above --, one row of the nine planes in LDS, the row halo in registers, combination + activation "
+                     "(+ 1x1 output projection) by four other waves; Z never written to HBM)",
              128134: "gemm_nt16_f32_kernel (backward-data GEMMs of the project-then-upsample pairs, dx = D . wcat^T with both operands K-contiguous: persistent "
                      "workgroups over 128x128 tiles, 128-bit fragments of both operands, fp32 MFMA 16x16x4)",
              7700: "gmm_logprob_kernel<R> + gmm_sum_kernel (mixture log-prob / responsibilities, lane = component, wave-shuffle logsumexp)"}
