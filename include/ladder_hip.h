@@ -247,6 +247,19 @@ int ladder_up2proj_wgrad_unpack(const float* dwcat, const float* db9, float* dw,
 int ladder_upfproj_eligible(int factor, int N, int H, int W, int Cin, int Cout);
 int ladder_upfproj_fwd_combine(const float* z, const float* bias, float* y, int factor, int N, int H, int W, int C, int act, ladder_stream_t stream);
 int ladder_upfproj_bwd_combine(const float* dy, float* d, int factor, int N, int H, int W, int C, ladder_stream_t stream);
+/* Round 6: the backward combination of the LAST factor-2 pair straight from the gradient of the 1x1 convolution behind it (reference codes/models.py:572-586:
+ * conv2d_7 -> leaky ReLU -> conv2d_8): d = (shift o up)^T dy with dy = act'(y) * (dyp . pw^T) formed where it is consumed -- y [N, 2H, 2W, C] the pair's
+ * activated output, dyp [N, 2H, 2W, pco] the gradient of the 1x1 convolution's (pre-activation) output, pw [C][pco] its filter -- and the 1x1 convolution's
+ * own filter / bias gradient dpw [C][pco] / dpb [pco] (dpb may be NULL; both overwritten) from the same read of y.  Replaces ladder_conv1x1_smallcout_bwd
+ * followed by ladder_up2proj_bwd_combine: dy (1.07 GB at batch 128) is neither written nor read.  Eligible: C / 4 a power of two in [5 pco, 64], pco <= 4, H >= 4, act in {none, leaky, relu};
+ * `ws` >= ladder_up2proj_bwd_combine_proj_workspace_bytes (per-workgroup partial sums, added in a fixed order). */
+/* ladder_up2proj_bwd_combine as a walk down the rows (a thread keeps the column-folded rows of its 5-row window in registers: 10 instead of 25 loads per
+ * low-resolution pixel); rows_per_thread 0 = chosen by the library.  H >= 4. */
+int ladder_up2proj_bwd_combine_walk(const float* dy, float* d, int N, int H, int W, int C, int rows_per_thread, ladder_stream_t stream);
+int ladder_up2proj_bwd_combine_proj_eligible(int N, int H, int W, int C, int pco);
+size_t ladder_up2proj_bwd_combine_proj_workspace_bytes(int N, int H, int W, int C, int pco);
+int ladder_up2proj_bwd_combine_proj(const float* y, const float* dyp, const float* pw, float* d, float* dpw, float* dpb, int pco, int N, int H, int W, int C,
+                                    int act, void* ws, size_t ws_bytes, ladder_stream_t stream);
 /* Round 6: the FORWARD of a factor-2 pair in ONE launch (reference codes/models.py:544-586: tf.image.resize_images -> tf.layers.conv2d, the last pair
  * followed by the 1x1 conv2d_8) -- y = act(bias + sum_rs shift_rs(up(x . w_rs))) straight from x [N, H, W, Cin] and wcatT [9 Cout][Cin] (transpose_flip 7):
  * a workgroup owns 64 / W images x 16 output channels, streams down the rows of the low-resolution map and keeps the nine planes of the last three rows

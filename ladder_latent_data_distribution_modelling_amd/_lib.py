@@ -159,6 +159,10 @@ PROTOTYPES = {
     "ladder_upfproj_eligible": (_i, [_i] * 6),
     "ladder_upfproj_fwd_combine": (_i, [_p] * 3 + [_i] * 6 + [_p]),
     "ladder_upfproj_bwd_combine": (_i, [_p, _p] + [_i] * 5 + [_p]),
+    "ladder_up2proj_bwd_combine_walk": (_i, [_p, _p] + [_i] * 5 + [_p]),
+    "ladder_up2proj_bwd_combine_proj_eligible": (_i, [_i] * 5),
+    "ladder_up2proj_bwd_combine_proj_workspace_bytes": (_z, [_i] * 5),
+    "ladder_up2proj_bwd_combine_proj": (_i, [_p] * 6 + [_i] * 6 + [_p, _z, _p]),
     "ladder_up2proj_fused_eligible": (_i, [_i] * 5),
     "ladder_up2proj_fused_preferred": (_i, [_i] * 5),
     "ladder_up2proj_fused_wide_tile": (_i, [_i] * 5),

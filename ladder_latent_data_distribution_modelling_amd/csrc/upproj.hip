@@ -309,6 +309,199 @@ __global__ __launch_bounds__(256) void up2proj_bwd_combine_kernel(const float* _
 }
 
 
+// ---- round 6: the backward combination as a WALK DOWN THE ROWS, optionally straight from the gradient of the 1x1 projection behind the pair ----------------
+// up2proj_bwd_combine_kernel loads the 5 x 5 neighbourhood of every low-resolution pixel (25 float4 per thread, every dy value fetched 6.25 times through
+// L1 / L2) and needs dy itself in HBM.  The combination is separable -- D_rs[i, j] = sum_alpha omega_r[alpha] C_s[2i - r + alpha], C_s[p] = sum_beta
+// omega_c[beta] dy[p, 2j - s + beta] -- so a thread that owns (image, column j, channel quad) and walks down a segment of rows folds every high-resolution
+// row ONCE along the columns (5 loads -> 3 folded values) and keeps the folded rows of the 5-row window in registers: 10 loads per low-resolution pixel.
+// PCO > 0 (the last pair: conv2d_7 under the 1x1 conv2d_8): dy is never materialised -- it is formed where it is consumed,
+//   dy[p, q, c] = act'(y[p, q, c]) * sum_o dyp[p, q, o] pw[c][o]
+// from the pair's activated output y and the PCO-channel gradient dyp, and the walk also owns the 2 x 2 pixels under its low-resolution pixel for the
+// projection's filter / bias gradient (per-block partials in the layout of conv1x1_smallcout_kernel, summed in a fixed order): the separate pass that
+// read y (1.07 GB at batch 128) and wrote dy (1.07 GB), and this kernel's read of dy, become ONE read of y.
+template <int PCO>
+__global__ __launch_bounds__(256) void up2proj_bwd_combine_walk_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ dyp,
+                                                                       const float* __restrict__ pw, float* __restrict__ d, float* __restrict__ part,
+                                                                       const int N, const int H, const int W, const int C, const int seg, const int act) {
+  constexpr int PC = PCO > 0 ? PCO : 1;
+  const int CV = C >> 2, nseg = (H + seg - 1) / seg;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = t < (long)N * nseg * W * CV;
+  const int cq = (int)(t % CV);
+  const long u = t / CV;
+  const int j = (int)(u % W), sg = (int)((u / W) % nseg), n = live ? (int)(u / ((long)W * nseg)) : 0;
+  const float4* gy = reinterpret_cast<const float4*>(PCO > 0 ? y : dy) + (long)n * 4 * H * W * CV + cq;
+  const float* gp = PCO > 0 ? dyp + (long)n * 4 * H * W * PCO : nullptr;
+  float4 wq[PC], gw[PC];
+  float gb[PC];
+#pragma unroll
+  for (int o = 0; o < PC; ++o) {
+    wq[o] = PCO > 0 ? make_float4(pw[(4 * cq + 0) * PC + o], pw[(4 * cq + 1) * PC + o], pw[(4 * cq + 2) * PC + o], pw[(4 * cq + 3) * PC + o]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    gw[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    gb[o] = 0.f;
+  }
+  const float wc0 = j >= 1 ? 0.5f : 0.f, wc2 = j == W - 1 ? 1.f : 0.5f;
+  // (PCO > 0) the 5 x PCO gradient values of a row are the same for the CV <= 64 lanes that share the pixel: lane k < 5 PCO of the group fetches ONE of
+  // them (consecutive addresses), the group passes them round through its LDS slot -- one load, one ds_write and <= 5 broadcast ds_read_b128 per row instead of
+  // 5 PCO loads per lane (which made the texture-address path, not HBM, the limit: 1 549 us against the two launches' 1 117, profiles/r06_bwd_walk_probe.txt).
+  // The lanes of a group sit in ONE wavefront, whose LDS operations complete in order: no s_barrier, only the compiler's convergence point.
+  __shared__ __attribute__((aligned(16))) float gsl[PCO > 0 ? 256 / 4 * 40 : 4];
+  float* slot = gsl + (PCO > 0 ? (threadIdx.x / CV) * 40 : 0);                      // (two rows of 20 floats per group)
+  const float neg = act == LADDER_ACT_LEAKY ? 0.2f : (act == LADDER_ACT_RELU ? 0.f : 1.f);      // act'(y) = y > 0 ? 1 : neg
+  constexpr int GL = 1;                                                             // gradient values a lane fetches per row: CV >= 5 PCO (eligibility)
+  // the global loads of one high-resolution row p: five float4 of y (or dy) and this lane's share of the row's 5 x PCO projection-gradient values
+  auto load_row = [&](const int p, float4 (&v)[5], float (&gl)[GL]) __attribute__((always_inline)) {
+    const bool rok = live && p >= 0 && p < 2 * H;
+#pragma unroll
+    for (int b5 = 0; b5 < 5; ++b5) {
+      const int q = 2 * j - 2 + b5;
+      v[b5] = (rok && q >= 0 && q < 2 * W) ? gy[((long)p * 2 * W + q) * CV] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (PCO > 0) {
+#pragma unroll
+      for (int tr = 0; tr < GL; ++tr) {
+        const int k = cq + tr * CV, q = 2 * j - 2 + k / PC;
+        gl[tr] = (tr * CV < 5 * PC && k < 5 * PC && rok && q >= 0 && q < 2 * W) ? gp[((long)p * 2 * W + q) * PC + (k - (k / PC) * PC)] : 0.f;
+      }
+    }
+  };
+  // ... and the row folded along the columns: c[s] = sum_beta omega_c[beta] dy[p, 2j - s + beta]
+  auto fold_row = [&](const float4 (&v)[5], const float (&gl)[GL], float* sl, const bool own, float4 (&c)[3]) __attribute__((always_inline)) {
+    float4 g[5];
+    float go[5 * PC];
+    if (PCO > 0) {
+#pragma unroll
+      for (int tr = 0; tr < GL; ++tr) {
+        const int k = cq + tr * CV;
+        if (tr * CV < 5 * PC && k < 5 * PC) sl[k] = gl[tr];
+      }
+      // (convergent: without it the compiler sinks the reads into both sides of the branch above, and the lanes that do not write may read first)
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k4 = 0; k4 < (5 * PC + 3) / 4; ++k4) {
+        const float4 t4 = *reinterpret_cast<const float4*>(sl + 4 * k4);
+        go[4 * k4] = t4.x;
+        if (4 * k4 + 1 < 5 * PC) go[4 * k4 + 1] = t4.y;
+        if (4 * k4 + 2 < 5 * PC) go[4 * k4 + 2] = t4.z;
+        if (4 * k4 + 3 < 5 * PC) go[4 * k4 + 3] = t4.w;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int b5 = 0; b5 < 5; ++b5) {
+      if (PCO == 0) {
+        g[b5] = v[b5];
+      } else {
+        float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int o = 0; o < PC; ++o) {
+          d4 = f4_fma(go[b5 * PC + o], wq[o], d4);
+          if ((b5 == 2 || b5 == 3) && own) {                                      // the 2 x 2 pixels under (i, j) belong to this thread
+            gw[o] = f4_fma(go[b5 * PC + o], v[b5], gw[o]);
+            gb[o] += go[b5 * PC + o];
+          }
+        }
+        g[b5] = make_float4(d4.x * (v[b5].x > 0.f ? 1.f : neg), d4.y * (v[b5].y > 0.f ? 1.f : neg), d4.z * (v[b5].z > 0.f ? 1.f : neg),
+                            d4.w * (v[b5].w > 0.f ? 1.f : neg));
+      }
+    }
+#pragma unroll
+    for (int sft = 0; sft < 3; ++sft) c[sft] = f4_fma(wc0, g[2 - sft], f4_fma(wc2, g[4 - sft], g[3 - sft]));
+  };
+  const int i0 = sg * seg, i1 = min(H, i0 + seg);
+  float4 cw[5][3];                                                                   // folded rows 2i - 2 ... 2i + 2
+  float4 va[5], vb[5], na[5];
+  float ga[GL], gb2[GL], nga[GL];
+  load_row(2 * i0 - 2, va, ga);
+  load_row(2 * i0 - 1, vb, gb2);
+  load_row(2 * i0, na, nga);
+  fold_row(va, ga, slot, false, cw[2]);
+  fold_row(vb, gb2, slot + 20, false, cw[3]);
+  fold_row(na, nga, slot, true, cw[4]);
+  if (PCO > 0) {
+    load_row(2 * i0 + 1, va, ga);
+    load_row(2 * i0 + 2, vb, gb2);
+  }
+  for (int i = i0; i < i1; ++i) {
+#pragma unroll
+    for (int sft = 0; sft < 3; ++sft) { cw[0][sft] = cw[2][sft]; cw[1][sft] = cw[3][sft]; cw[2][sft] = cw[4][sft]; }
+    // PCO > 0 (two waves a SIMD at best): the rows of the NEXT step are requested while this one is folded -- its first row before the first fold, its second
+    // into the registers the first fold has just released (880 against 1 300 us at conv2d_7; the plain form has the occupancy to hide the latency: no gain)
+    const bool more = PCO > 0 && i + 1 < i1;
+    if (more) load_row(2 * i + 3, na, nga);
+    if (PCO == 0) load_row(2 * i + 1, va, ga);
+    fold_row(va, ga, slot, true, cw[3]);
+    if (more) load_row(2 * i + 4, va, ga);
+    if (PCO == 0) {
+      load_row(2 * i + 2, va, ga);
+      fold_row(va, ga, slot, false, cw[4]);
+    } else {
+      fold_row(vb, gb2, slot + 20, i + 1 < i1, cw[4]);                               // (row 2 i1 belongs to the walk of the next segment)
+    }
+    if (live) {
+      const float wr0 = i >= 1 ? 0.5f : 0.f, wr2 = i == H - 1 ? 1.f : 0.5f;
+      float4* dp = reinterpret_cast<float4*>(d) + (((long)n * H + i) * W + j) * 9 * CV + cq;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int sft = 0; sft < 3; ++sft)
+          st_stream(dp + (r * 3 + sft) * CV, f4_fma(wr0, cw[2 - r][sft], f4_fma(wr2, cw[4 - r][sft], cw[3 - r][sft])));
+    }
+    if (PCO > 0) {
+#pragma unroll
+      for (int b5 = 0; b5 < 5; ++b5) { vb[b5] = va[b5]; va[b5] = na[b5]; }
+#pragma unroll
+      for (int tr = 0; tr < GL; ++tr) { gb2[tr] = ga[tr]; ga[tr] = nga[tr]; }
+    }
+  }
+  if (PCO > 0) {
+    // block partial [C][PCO] filter gradient + [PCO] bias gradient: the 256 / CV pixel lanes of a channel quad in a fixed order
+    __shared__ float red[256];
+    const int pl = threadIdx.x / CV, ppb = 256 / CV;
+    float* out = part + (size_t)blockIdx.x * ((size_t)C * PC + PC);
+#pragma unroll
+    for (int k = 0; k < 5 * PC; ++k) {
+      float v;
+      if (k < 4 * PC) {
+        const float4 gv = gw[k >> 2];
+        const int e = k & 3;
+        v = e == 0 ? gv.x : (e == 1 ? gv.y : (e == 2 ? gv.z : gv.w));
+      } else {
+        v = cq == 0 ? gb[k - 4 * PC] : 0.f;
+      }
+      red[threadIdx.x] = v;
+      __syncthreads();
+      if (pl == 0) {
+        float a = 0.f;
+        for (int r = 0; r < ppb; ++r) a += red[r * CV + cq];
+        if (k < 4 * PC) out[(size_t)(4 * cq + (k & 3)) * PC + (k >> 2)] = a;
+        else if (cq == 0) out[(size_t)C * PC + (k - 4 * PC)] = a;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// out[i] = sum over the S block partials, 16 interleaved runs combined in a fixed order (the reduction behind the walk's projection gradients)
+__global__ __launch_bounds__(256) void up2proj_part_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, const int S,
+                                                                  const int n, const int nb) {
+  __shared__ float run[16][17];
+  const int o = threadIdx.x & 15, g = threadIdx.x >> 4, i = blockIdx.x * 16 + o;
+  float a = 0.f;
+  if (i < n + nb)
+    for (int z = g; z < S; z += 16) a += part[(size_t)z * (n + nb) + i];
+  run[g][o] = a;
+  __syncthreads();
+  if (g == 0 && i < n + nb) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += run[k][o];
+    if (i < n) dw[i] = s;
+    else if (db != nullptr) db[i - n] = s;
+  }
+}
+
+
 // ---- round 6: the forward pair in ONE launch -- Z never leaves the CU ------------------------------------------------------------------------------------
 // ladder_up2proj_fwd_combine reads back the nine planes Z [M][9 Cout] that the projection GEMM has just written: 2 x 2.4 GB per forward of conv2d_7 at
 // batch 128, 23.7 GB per iteration over all pairs.  Here a workgroup owns (a group of G = 64 / W images, a slab of 16 output
@@ -1113,11 +1306,77 @@ int ladder_up2proj_fwd_combine(const float* z, const float* bias, float* y, cons
   return LADDER_OK;
 }
 
+// rows a thread of the walking form covers (LADDER_UP2BWD_SEG overrides)
+static int up2bwd_walk_seg(int N, int H, int W, int C) {
+  static const int forced = getenv("LADDER_UP2BWD_SEG") != nullptr ? atoi(getenv("LADDER_UP2BWD_SEG")) : 0;
+  if (forced > 0) return forced < H ? forced : H;
+  // (measured, batch 128, profiles/r06_bwd_walk_probe.txt: long segments win -- the 3-row warm-up is the cost -- as long as every CU has two workgroups;
+  // conv2d_7 under the projection: whole columns 717 us, 16 rows 815, 8 rows 920: r06_bwd_walk_probe_seg.txt)
+  int seg = H;
+  while (seg > 4 && (long)N * ((H + seg - 1) / seg) * W * (C / 4) < 256L * 512) seg = (seg + 1) >> 1;   // two workgroups of 256 threads per CU
+  return seg;
+}
+
+// the walking form of ladder_up2proj_bwd_combine (same arguments; rows_per_thread 0 = chosen here)
+int ladder_up2proj_bwd_combine_walk(const float* dy, float* d, int N, int H, int W, int C, int rows_per_thread, ladder_stream_t stream) {
+  if (N <= 0 || H < 4 || W <= 0 || C <= 0 || (C % 4) != 0 || rows_per_thread < 0 || (long)N * H * W * 4 >= (1L << 30)) return LADDER_E_SHAPE;
+  if (!ladder_aligned16(dy) || !ladder_aligned16(d)) return LADDER_E_ALIGN;
+  const int seg = rows_per_thread > 0 ? (rows_per_thread < H ? rows_per_thread : H) : up2bwd_walk_seg(N, H, W, C);
+  const long total = (long)N * ((H + seg - 1) / seg) * W * (C / 4);
+  hipLaunchKernelGGL(up2proj_bwd_combine_walk_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dy, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, d, (float*)nullptr, N, H, W, C, seg, 0);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
 int ladder_up2proj_bwd_combine(const float* dy, float* d, int N, int H, int W, int C, ladder_stream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4) != 0) return LADDER_E_SHAPE;
   if (!ladder_aligned16(dy) || !ladder_aligned16(d)) return LADDER_E_ALIGN;
+  // the walking form wherever it applies (conv2d_6 173 -> 133 us, conv2d_5 95 -> 74, conv2d_4 27 -> 21 at batch 128); LADDER_UP2BWD_WALK=0: the neighbourhood kernel
+  static const bool walk = getenv("LADDER_UP2BWD_WALK") == nullptr || atoi(getenv("LADDER_UP2BWD_WALK")) != 0;
+  if (walk && H >= 4 && (long)N * H * W * 4 < (1L << 30)) return ladder_up2proj_bwd_combine_walk(dy, d, N, H, W, C, 0, stream);
   const long total = (long)N * H * W * (C / 4);
   hipLaunchKernelGGL(up2proj_bwd_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dy, d, N, H, W, C);
+  LADDER_CHECK_LAUNCH();
+  return LADDER_OK;
+}
+
+// D [N, H, W, 9 C] of a pair whose activated output y [N, 2H, 2W, C] feeds a 1x1 convolution to pco <= 4 channels (pw [C][pco]), straight from the gradient
+// dyp [N, 2H, 2W, pco] of that convolution's output: dy = act'(y) * (dyp . pw^T) is formed inside and never stored; dpw [C][pco] / dpb [pco] (may be NULL)
+// receive the 1x1 convolution's filter / bias gradient (overwritten).  Replaces ladder_conv1x1_smallcout_bwd + ladder_up2proj_bwd_combine.
+int ladder_up2proj_bwd_combine_proj_eligible(int N, int H, int W, int C, int pco) {
+  static const bool off = getenv("LADDER_DISABLE_UP2BWD_PROJ") != nullptr;
+  const int cv = C / 4;
+  return (!off && N > 0 && H >= 4 && W > 0 && C > 0 && (C % 4) == 0 && cv <= 64 && (cv & (cv - 1)) == 0 && pco >= 1 && pco <= 4 && cv >= 5 * pco &&
+          (long)N * H * W * 4 < (1L << 30)) ? 1 : 0;
+}
+
+static long up2bwd_proj_blocks(int N, int H, int W, int C) {
+  const int seg = up2bwd_walk_seg(N, H, W, C);
+  return ((long)N * ((H + seg - 1) / seg) * W * (C / 4) + 255) / 256;
+}
+
+size_t ladder_up2proj_bwd_combine_proj_workspace_bytes(int N, int H, int W, int C, int pco) {
+  if (!ladder_up2proj_bwd_combine_proj_eligible(N, H, W, C, pco)) return 0;
+  return (size_t)up2bwd_proj_blocks(N, H, W, C) * ((size_t)C * pco + pco) * sizeof(float);
+}
+
+int ladder_up2proj_bwd_combine_proj(const float* y, const float* dyp, const float* pw, float* d, float* dpw, float* dpb, int pco, int N, int H, int W, int C,
+                                    int act, void* ws, size_t ws_bytes, ladder_stream_t stream) {
+  if (!ladder_up2proj_bwd_combine_proj_eligible(N, H, W, C, pco) || y == nullptr || dyp == nullptr || pw == nullptr || d == nullptr || dpw == nullptr ||
+      (act != LADDER_ACT_NONE && act != LADDER_ACT_LEAKY && act != LADDER_ACT_RELU))
+    return LADDER_E_SHAPE;
+  if (!ladder_aligned16(y) || !ladder_aligned16(d)) return LADDER_E_ALIGN;
+  if (ws == nullptr || ws_bytes < ladder_up2proj_bwd_combine_proj_workspace_bytes(N, H, W, C, pco)) return LADDER_E_WORKSPACE;
+  const int seg = up2bwd_walk_seg(N, H, W, C);
+  const unsigned blocks = (unsigned)up2bwd_proj_blocks(N, H, W, C);
+  float* part = (float*)ws;
+#define LADDER_UP2BWD_PROJ(P_) hipLaunchKernelGGL(up2proj_bwd_combine_walk_kernel<P_>, dim3(blocks), dim3(256), 0, stream, (const float*)nullptr, y, dyp, pw, d, \
+                                                  part, N, H, W, C, seg, act)
+  switch (pco) { case 1: LADDER_UP2BWD_PROJ(1); break; case 2: LADDER_UP2BWD_PROJ(2); break; case 3: LADDER_UP2BWD_PROJ(3); break; default: LADDER_UP2BWD_PROJ(4); }
+#undef LADDER_UP2BWD_PROJ
+  const int kn = C * pco;
+  hipLaunchKernelGGL(up2proj_part_reduce_kernel, dim3((unsigned)((kn + pco + 15) / 16)), dim3(256), 0, stream, (const float*)part, dpw, dpb, (int)blocks, kn, pco);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }

@@ -231,7 +231,10 @@ class CelebADecoder:
         last_conv, _, last_norm, last_rs = self.blocks[-1]
         fuse_last = (last_norm is None and last_conv.act is not None
                      and (last_rs is None or tuple(last_rs.in_shape[1:3]) == (last_rs.oh, last_rs.ow)))
-        dh = self.conv_out.backward(dxhat, gate_prev=last_conv.act if fuse_last else None)
+        # ... and where that conv ran in the projected form, its backward combination is formed straight from dxhat: neither the 1x1 conv's backward-data
+        # result nor the read of it exist, and conv_out's filter / bias gradient comes out of the same launch (Conv2D.bwd_proj_ok)
+        proj_grad = (dxhat, self.conv_out) if (fuse_last and last_conv.bwd_proj_ok(self.conv_out)) else None
+        dh = None if proj_grad is not None else self.conv_out.backward(dxhat, gate_prev=last_conv.act if fuse_last else None)
         ddlat = None
         lowres = False            # dh is already the gradient of the LOW-resolution tensor behind the next resize (fused into the conv's backward-data)
         pre_gated = False         # ... and already carries this block's activation derivative (gated low-resolution backward-data of the block above)
@@ -239,7 +242,7 @@ class CelebADecoder:
             gated = False
             if lowres:
                 lowres = False                                   # (this block's resize transpose is done)
-            elif rs is not None:
+            elif rs is not None and not (bi == 0 and proj_grad is not None):     # (fuse_last: the last block's resize is the identity)
                 if norm is None and conv.act is not None and not (bi == 0 and fuse_last):
                     dh, gated = rs.backward(dh, gate=(conv.y, conv.act))   # leaky conv -> resize: its activation backward rides on the transpose
                 else:
@@ -260,7 +263,8 @@ class CelebADecoder:
             if (lowres and below is not None and below[2] is None and below[0].act is not None and below[0].y is not None and conv.x is not None
                     and conv.lowres_gate_ok(conv.x.shape[0], below[0].y.shape[1], below[0].y.shape[2])):
                 lgate = (below[0].y, below[0].act)
-            dh = conv.backward(dh, act_done=(bi == 0 and fuse_last) or gated or pre_gated, lowres_dx=lowres, lowres_gate=lgate)
+            dh = conv.backward(dh, act_done=(bi == 0 and fuse_last) or gated or pre_gated, lowres_dx=lowres, lowres_gate=lgate,
+                               proj_grad=proj_grad if bi == 0 else None)
             pre_gated = lgate is not None                      # (the NEXT block's activation backward is done)
         dh = self.conv0.backward(dh if lowres else self.up0.backward(dh))     # (lowres: conv2d_1 returned the gradient of the 1x1 map itself)
         denc = dh.reshape(dh.shape[0], self.nh)
@@ -372,6 +376,7 @@ class LadderEngine:
         # launches and 19.81 with none, same box, profiles/r06_f32_bench_fused_level*.json: a pair that is level in isolation still spares its neighbours 1.2 GB
         # of HBM traffic and an allocation)
         self.ctx.fuse_fwd = int(cfg.get("fused_projected_forward", 2))
+        self.ctx.fuse_bwd_proj = int(cfg.get("fused_projection_backward", 1))
         self.precision = prec
         if self.ctx.comm.rank == 0:
             print("Contraction precision (config key matmul_precision): {} -- {}".format(prec, PRECISION_NOTES[prec]))

@@ -121,6 +121,7 @@ class Ctx:
         self.ns = 0          # LADDER_PREC_* of the split-precision contraction kernels (0 = native f32 MFMA); set by the engine
         self.up2_used = {}   # layer name -> number of upsample-fused launches so far (bench.py's executed-FLOP model)
         self.up2_skipped = {}  # ... and the fraction of the reference's products such a launch never issues (11 / 36 tap-folded, 27 / 36 projected)
+        self.fuse_bwd_proj = 1   # last pair: backward combination straight from the 1x1 output conv's gradient (config `fused_projection_backward`)
         self.fuse_fwd = 2    # projected pairs: forward GEMM + combination in one launch (config `fused_projected_forward`: 2 wherever eligible (default), 1 only where the isolated launch measured faster, 0 off)
         self.up2 = True      # resize -> 3x3 conv pairs of the decoder as ONE upsample-fused convolution in forward-only runs (config `upsample_fused_convs`)
 
@@ -569,9 +570,20 @@ class Conv2D:
         self.x_is_lo = bool(keep_y and upsampled is None)
         return out
 
-    def _backward_proj(self, dy, need_dx, wgrad, gate):
+    def bwd_proj_ok(self, proj):
+        """The backward combination of this (last) pair can be formed straight from the gradient of the 1x1 conv `proj` behind it -- dy of this layer is
+        never materialised and proj's filter / bias gradient comes out of the same launch (ladder_up2proj_bwd_combine_proj)."""
+        if not (self.ctx.fuse_bwd_proj and self.x_is_lo and self.lo_factor == 2 and self.x is not None and self.y is not None
+                and self.act in (None, "leaky_relu", "relu") and proj.k == 1 and proj.stride == 1 and proj.act is None and proj.cin == self.cout):
+            return False
+        N, H, W, _ = self.x.shape
+        return bool(self.proj_ok(N, H, W, 2) and L.query("ladder_up2proj_bwd_combine_proj_eligible", N, H, W, self.cout, proj.cout))
+
+    def _backward_proj(self, dy, need_dx, wgrad, gate, proj_grad=None):
         """Backward of the project-then-upsample form from the low-resolution x: D [M, 9 cout] = (shift o up)^T dy once (elementwise), then
-        dWcat = x^T D (+ the bias gradient as the centre plane's column sums) and dx_lo = D . wcatT -- two dense calls, exact on every pixel."""
+        dWcat = x^T D (+ the bias gradient as the centre plane's column sums) and dx_lo = D . wcatT -- two dense calls, exact on every pixel.
+        `proj_grad` = (dyp, proj): dy is not given -- D comes from this layer's activated output and the gradient dyp of the 1x1 conv `proj`
+        behind it, together with proj's own filter / bias gradient (bwd_proj_ok)."""
         ctx, st = self.ctx, self.ctx.stream
         x = self.x
         N, H, W, _ = x.shape
@@ -579,7 +591,15 @@ class Conv2D:
         flops = 2.0 * N * f * f * H * W * 9 * self.cin * self.cout
         executed = 2.0 * M * self.cin * n9
         d = ctx.empty(M, n9)
-        L.call("ladder_upfproj_bwd_combine", _p(dy), _p(d), f, N, H, W, self.cout, st)
+        if proj_grad is not None:
+            dyp, proj = proj_grad
+            wsp, wsn = ctx.ws(L.query("ladder_up2proj_bwd_combine_proj_workspace_bytes", N, H, W, self.cout, proj.cout))
+            L.call("ladder_up2proj_bwd_combine_proj", _p(self.y), _p(dyp), _p(proj.ps.w[proj.name + "/kernel"]), _p(d), _p(proj.ps.g[proj.name + "/kernel"]),
+                   _p(proj.ps.g[proj.name + "/bias"]) if proj.bias_grad else None, proj.cout, N, H, W, self.cout, L.ACT[self.act] if self.act else 0,
+                   wsp, wsn, st)
+            proj.x = proj.y = None
+        else:
+            L.call("ladder_upfproj_bwd_combine", _p(dy), _p(d), f, N, H, W, self.cout, st)
         if wgrad:
             ctx.up2_used[self.name + ":wgrad"] = ctx.up2_used.get(self.name + ":wgrad", 0) + 1
             ctx.up2_skipped[self.name + ":wgrad"] = 1.0 - 1.0 / (f * f)
@@ -842,8 +862,9 @@ class Conv2D:
         ctx.set_amax(dx, dx_amax)
         return dx
 
-    def backward(self, dy, need_dx=True, wgrad=True, act_done=False, gate_prev=None, lowres_dx=False, lowres_gate=None):
+    def backward(self, dy, need_dx=True, wgrad=True, act_done=False, gate_prev=None, lowres_dx=False, lowres_gate=None, proj_grad=None):
         """`act_done`: dy already carries this layer's activation derivative (fused into the consumer's epilogue).
+        `proj_grad` = (dyp, proj) instead of dy: see _backward_proj / bwd_proj_ok.
         `gate_prev`: activation name of the layer that produced this conv's input x: its derivative act'(x) is fused into
         the backward-data epilogue, so that layer must then be called with act_done=True.
         `lowres_dx`: x is the factor-2 upsample of a tensor the caller wants the gradient of: return d / d (that tensor) (see _dx_lowres)."""
@@ -853,6 +874,10 @@ class Conv2D:
             H, W = self.lo_factor * H, self.lo_factor * W
             if not lowres_dx and need_dx:
                 raise RuntimeError("%s: only the low-resolution gradient exists for a virtual upsample" % self.name)
+        if proj_grad is not None:
+            if not (wgrad and self.bwd_proj_ok(proj_grad[1])):
+                raise RuntimeError("%s: the projection-gradient form of the backward combination does not apply" % self.name)
+            return self._backward_proj(None, need_dx, wgrad, lowres_gate, proj_grad)
         _, Ho, Wo, _ = y.shape
         st = self.ctx.stream
         if self.act is not None and not act_done:

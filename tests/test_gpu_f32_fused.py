@@ -404,7 +404,10 @@ def test_f32_engine_routes_through_the_fused_kernels_and_agrees_with_the_direct_
         # round 6: the forward of conv2d_4 ... conv2d_7 (conv2d_7 with the RGB projection) is ONE launch each -- the nine planes stay in LDS; the 1x1 and 2x2
         # maps (conv2d_1 behind the 1x1 -> 2x2 resize, conv2d_3 behind the factor-4 one) keep the GEMM + combination pair
         assert cs.count("ladder_up2proj_fused_fwd") == 4 and cs.count("ladder_up2proj_fwd_combine") == 0 and cs.count("ladder_upfproj_fwd_combine") == 2
-    assert tc4.count("ladder_upfproj_bwd_combine") == 6 and tc4.count("ladder_up2proj_wgrad_unpack") == 6
+    # ... and the backward combination of the last pair comes straight from the gradient of the 1x1 conv2d_8 behind it, with that conv's filter / bias gradient
+    # (ladder_up2proj_bwd_combine_proj): conv2d_7's dy is never written
+    assert tc4.count("ladder_upfproj_bwd_combine") == 5 and tc4.count("ladder_up2proj_bwd_combine_proj") == 1 and tc4.count("ladder_up2proj_wgrad_unpack") == 6
+    assert "ladder_conv1x1_smallcout_bwd_absmax" not in tc4 and "ladder_conv1x1_smallcout_bwd_absmax" in tc3
     # (backward-data: the K-contiguous 16x16x4 kernel where M >= 8192 -- conv2d_4 ... conv2d_7 -- the implicit-GEMM kernel on the 1x1 and 2x2 maps)
     assert tc4.count("ladder_dense_bwd_weight") == 6 and tc4.count("ladder_dense_bwd_data_nt") == 4 and tc4.count("ladder_dense_bwd_data") == 2
     assert "ladder_dense_bwd_weight" not in tc3
@@ -728,3 +731,43 @@ def test_f32_engine_fused_projected_forward_levels_agree(monkeypatch):
         worst, wname = _worst_grad(g0, g)
         print("fused_projected_forward %d vs 0: worst relative gradient difference %.2e (%s)" % (lvl, worst, wname))
         assert worst < 2e-3, (lvl, worst, wname)
+
+
+def test_f32_engine_fused_projection_backward_agrees(monkeypatch):
+    """`fused_projection_backward` (round 6; reference codes/models.py:572-586, the backward of conv2d_7 -> leaky ReLU -> 1x1 conv2d_8): 1 (default) forms
+    conv2d_7's backward combination straight from the gradient of conv2d_8's output and produces conv2d_8's filter / bias gradient in the same launch; 0 runs
+    conv2d_8's backward (which writes conv2d_7's dy) and then the combination.  Same products, another summation order for conv2d_8's gradients (per-thread
+    column walks instead of grid-stride pixel runs): conv2d_8's gradients within 5e-6 of their scale, every other tensor within the bar of the forward-level test
+    (2e-3: encoder/code_std_dev/kernel, a difference of nearly cancelling terms, carries 2e-4 ... 6e-4 between ANY two fp32 summation orders)."""
+    from ladder_latent_data_distribution_modelling_amd import _lib as L
+    from ladder_latent_data_distribution_modelling_amd.engine import LadderEngine
+    cfg, x, Pm, noise, gm = _celeba_setup(16, 47)
+    calls, real = [], L.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real(name, *a)
+
+    monkeypatch.setattr(L, "call", spy)
+    res = {}
+    for lvl in (0, 1):
+        eng = LadderEngine(dict(cfg, fused_projection_backward=lvl), "cuda:0", values=Pm, seed=1)
+        eng.set_mixture(*gm)
+        del calls[:]
+        eng.run_ae(x, 0.0, noise, False, False)
+        res[lvl] = (eng.fetch(), {k: v.detach().cpu().numpy().copy() for k, v in eng.ps.g.items()}, list(calls))
+        del eng
+        torch.cuda.empty_cache()
+    (f0, g0, c0), (f1, g1, c1) = res[0], res[1]
+    assert c0.count("ladder_up2proj_bwd_combine_proj") == 0 and c0.count("ladder_conv1x1_smallcout_bwd_absmax") == 1
+    assert c1.count("ladder_up2proj_bwd_combine_proj") == 1 and c1.count("ladder_conv1x1_smallcout_bwd_absmax") == 0
+    assert c1.count("ladder_upfproj_bwd_combine") == c0.count("ladder_upfproj_bwd_combine") - 1
+    for k in ("elbo", "l1_reconstruction_error", "loss_ae", "sigma"):
+        assert f0[k] == f1[k], (k, f0[k], f1[k])                     # (the forward pass is the same launches)
+    worst, wname = _worst_grad(g0, g1)
+    print("fused_projection_backward 1 vs 0: worst relative gradient difference %.2e (%s)" % (worst, wname))
+    assert worst < 2e-3, (worst, wname)
+    for k in g0:
+        if "conv2d_8" in k:
+            d = float(np.abs(g1[k] - g0[k]).max() / max(np.abs(g0[k]).max(), 1e-30))
+            assert d < 5e-6, (k, d)

@@ -159,6 +159,85 @@ def test_upproj_combine_is_the_transpose_of_itself(gpu_ctx):
     assert abs(a - b) < 1e-6 * (abs(a) + float(y.double().norm() * dy.double().norm())), (a, b)
 
 
+def _ref_bwd_combine(dy):
+    """D [N H W][9 C] = (shift o up)^T dy in float64: autograd through y = sum_rs shift_rs(up(Z_rs)), the oracle's legacy-bilinear resize and zero-padded shifts."""
+    N, H2, W2, C = dy.shape
+    H, W = H2 // 2, W2 // 2
+    z = torch.zeros(N, H, W, 9, C, dtype=torch.float64, requires_grad=True)
+    y = torch.zeros(N, H2, W2, C, dtype=torch.float64)
+    for r in range(3):
+        for s_ in range(3):
+            up = torch.nn.functional.pad(O.resize_bilinear_legacy(z[:, :, :, 3 * r + s_, :], H2, W2), (0, 0, 1, 1, 1, 1))
+            y = y + up[:, r:r + H2, s_:s_ + W2, :]                      # y[p, q] += up[p + r - 1, q + s - 1]
+    y.backward(torch.as_tensor(dy, dtype=torch.float64))
+    return z.grad.reshape(N * H * W, 9 * C).numpy()
+
+
+WALK_CASES = [(2, 64, 64, 128, 0), (3, 5, 7, 48, 0), (2, 4, 9, 16, 3), (5, 16, 16, 256, 16), (1, 33, 2, 32, 5), (2, 8, 8, 64, 1)]
+
+
+@pytest.mark.parametrize("case", WALK_CASES, ids=lambda c: "n%d_%dx%d_c%d_rows%d" % c)
+def test_upproj_bwd_combine_walk_equals_the_neighbourhood_form(gpu_ctx, case):
+    """The row-walking backward combination (a thread folds each high-resolution row along the columns once and keeps the folded rows of its window in
+    registers; what ladder_up2proj_bwd_combine runs for H >= 4) against float64 autograd through the oracle's resize: 2e-6 of the scale; segment lengths that
+    do and do not divide the map height, rows above / below the map, one-column maps."""
+    L = _lib()
+    N, H, W, C, rows = case
+    st = gpu_ctx.stream
+    g = torch.Generator(device="cuda").manual_seed(H + W + C)
+    dy = torch.randn(N, 2 * H, 2 * W, C, device="cuda", generator=g)
+    d0 = torch.full((N * H * W, 9 * C), float("nan"), device="cuda")
+    d1 = torch.full((N * H * W, 9 * C), float("nan"), device="cuda")
+    L.call("ladder_up2proj_bwd_combine", p(dy), p(d0), N, H, W, C, st)
+    L.call("ladder_up2proj_bwd_combine_walk", p(dy), p(d1), N, H, W, C, rows, st)
+    torch.cuda.synchronize()
+    ref = _ref_bwd_combine(dy.cpu().numpy())
+    close(d1, ref, 2e-6, "D (walk, %d rows a thread)" % rows)
+    close(d0, ref, 2e-6, "D (library's choice)")
+    from ladder_latent_data_distribution_modelling_amd._lib import LadderHipError
+    with pytest.raises(LadderHipError, match="LADDER_E_SHAPE"):
+        L.call("ladder_up2proj_bwd_combine_walk", p(dy), p(d1), N, 3, W, C, 0, st)               # fewer than four rows: the neighbourhood form
+
+
+PROJ_BWD_CASES = [(4, 16, 16, 128, 3, "leaky_relu"), (3, 5, 7, 32, 1, None), (2, 4, 6, 128, 4, "leaky_relu"), (1, 9, 3, 64, 2, "leaky_relu"), (2, 64, 64, 128, 3, "leaky_relu"),
+                  (5, 6, 1, 256, 3, "leaky_relu")]
+
+
+@pytest.mark.parametrize("case", PROJ_BWD_CASES, ids=lambda c: "n%d_%dx%d_c%d_p%d_%s" % c)
+def test_upproj_bwd_combine_from_projection_gradient_vs_oracle(gpu_ctx, case):
+    """ladder_up2proj_bwd_combine_proj (reference codes/models.py:572-586, conv2d_7 -> leaky ReLU -> 1x1 conv2d_8): D from the pair's activated output y and the
+    gradient dyp of the 1x1 convolution, and that convolution's filter / bias gradient, against float64: dy = act'(y) * (dyp . pw^T) through autograd of the
+    oracle's resize + shifts, dpw = y^T dyp, dpb = column sums of dyp.  3e-6 of the scale."""
+    L = _lib()
+    N, H, W, C, pco, act = case
+    st = gpu_ctx.stream
+    rng = np.random.default_rng(H * 7 + C + pco)
+    y = rng.standard_normal((N, 2 * H, 2 * W, C)).astype(np.float32)
+    dyp = rng.standard_normal((N, 2 * H, 2 * W, pco)).astype(np.float32)
+    pw_ = (rng.standard_normal((C, pco)) / np.sqrt(C)).astype(np.float32)
+    assert L.query("ladder_up2proj_bwd_combine_proj_eligible", N, H, W, C, pco) == 1
+    y64, g64 = y.astype(np.float64), dyp.astype(np.float64)
+    dy64 = (g64 @ pw_.astype(np.float64).T) * (np.where(y64 > 0, 1.0, 0.2) if act else 1.0)
+    dref = _ref_bwd_combine(dy64)
+    yd, gd, pwd = dev(y), dev(dyp), dev(pw_)
+    d = torch.full((N * H * W, 9 * C), float("nan"), device="cuda")
+    dpw = torch.full((C, pco), float("nan"), device="cuda")
+    dpb = torch.full((pco,), float("nan"), device="cuda")
+    ws = _ws(L.query("ladder_up2proj_bwd_combine_proj_workspace_bytes", N, H, W, C, pco))
+    L.call("ladder_up2proj_bwd_combine_proj", p(yd), p(gd), p(pwd), p(d), p(dpw), p(dpb), pco, N, H, W, C, 1 if act else 0, p(ws), ws.numel(), st)
+    torch.cuda.synchronize()
+    close(d, dref, TOL32, "D")
+    close(dpw, y64.reshape(-1, C).T @ g64.reshape(-1, pco), TOL32, "projection filter gradient")
+    close(dpb, g64.reshape(-1, pco).sum(0), TOL32, "projection bias gradient")
+    # no bias gradient wanted; workspace too small; not eligible
+    L.call("ladder_up2proj_bwd_combine_proj", p(yd), p(gd), p(pwd), p(d), p(dpw), None, pco, N, H, W, C, 1 if act else 0, p(ws), ws.numel(), st)
+    from ladder_latent_data_distribution_modelling_amd._lib import LadderHipError
+    with pytest.raises(LadderHipError, match="LADDER_E_WORKSPACE"):
+        L.call("ladder_up2proj_bwd_combine_proj", p(yd), p(gd), p(pwd), p(d), p(dpw), None, pco, N, H, W, C, 0, p(ws), 8, st)
+    q = lambda *a: L.query("ladder_up2proj_bwd_combine_proj_eligible", *a)  # noqa: E731
+    assert q(N, H, W, 24, pco) == 0 and q(N, H, W, C, 5) == 0 and q(N, H, W, 16, 1) == 0 and q(N, 3, W, C, pco) == 0 and q(N, H, W, 512, pco) == 0
+
+
 F4_CASES = [(128, 2, 2, 64, 64), (3, 1, 1, 16, 32), (5, 3, 2, 32, 16), (2, 4, 5, 16, 16)]
 
 
