@@ -375,8 +375,11 @@ __global__ __launch_bounds__(256) void up2proj_bwd_combine_walk_kernel(const flo
         const int k = cq + tr * CV;
         if (tr * CV < 5 * PC && k < 5 * PC) sl[k] = gl[tr];
       }
-      // (convergent: without it the compiler sinks the reads into both sides of the branch above, and the lanes that do not write may read first)
+      // (without a convergence point the compiler sinks the reads into both sides of the branch above, and the lanes that do not write may read first; the barrier
+      // is convergent but not a memory operation, so a compiler-level memory clobber on either side keeps the LDS accesses on their side of it)
+      asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int k4 = 0; k4 < (5 * PC + 3) / 4; ++k4) {
         const float4 t4 = *reinterpret_cast<const float4*>(sl + 4 * k4);
@@ -385,7 +388,9 @@ __global__ __launch_bounds__(256) void up2proj_bwd_combine_walk_kernel(const flo
         if (4 * k4 + 2 < 5 * PC) go[4 * k4 + 2] = t4.z;
         if (4 * k4 + 3 < 5 * PC) go[4 * k4 + 3] = t4.w;
       }
+      asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
     }
 #pragma unroll
     for (int b5 = 0; b5 < 5; ++b5) {
