@@ -487,25 +487,21 @@ __global__ __launch_bounds__(256) void up2proj_bwd_combine_walk_kernel(const flo
   }
 }
 
-// out[i] = sum over the S block partials, 16 interleaved runs combined in a fixed order (the reduction behind the walk's projection gradients)
+// out[i] = sum over the S block partials: one wavefront per output, lane l adds partials l, l + 64, ... in order, then a fixed xor tree over the lanes
+// (bit-reproducible; 25 workgroups of 16 serial runs took 24 us for the 1 024 x 387 partials of conv2d_7)
 __global__ __launch_bounds__(256) void up2proj_part_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, const int S,
                                                                   const int n, const int nb) {
-  __shared__ float run[16][17];
-  const int o = threadIdx.x & 15, g = threadIdx.x >> 4, i = blockIdx.x * 16 + o;
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n + nb) return;                                                           // (whole wavefronts leave together)
   float a = 0.f;
-  if (i < n + nb)
-    for (int z = g; z < S; z += 16) a += part[(size_t)z * (n + nb) + i];
-  run[g][o] = a;
-  __syncthreads();
-  if (g == 0 && i < n + nb) {
-    float s = 0.f;
+  for (int z = lane; z < S; z += 64) a += part[(size_t)z * (n + nb) + i];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) s += run[k][o];
-    if (i < n) dw[i] = s;
-    else if (db != nullptr) db[i - n] = s;
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if (lane == 0) {
+    if (i < n) dw[i] = a;
+    else if (db != nullptr) db[i - n] = a;
   }
 }
-
 
 // ---- round 6: the forward pair in ONE launch -- Z never leaves the CU ------------------------------------------------------------------------------------
 // ladder_up2proj_fwd_combine reads back the nine planes Z [M][9 Cout] that the projection GEMM has just written: 2 x 2.4 GB per forward of conv2d_7 at
@@ -1165,6 +1161,34 @@ __global__ __launch_bounds__(256) void up2proj_proj_reduce_kernel(const float* _
   }
 }
 
+// ... four pixels per thread (P is a multiple of 4): every partial plane is read as float4, the 4 x PCO results leave as PCO float4 -- all loads of a thread
+// independent of each other (the scalar form above chains pco x nslab dependent 4-byte loads: 67 us for 0.23 GB at conv2d_7; this one ~45).  Same order of additions.
+template <int PCO>
+__global__ __launch_bounds__(256) void up2proj_proj_reduce4_kernel(const float* __restrict__ ppart, const float* __restrict__ pb, float* __restrict__ pout,
+                                                                   const long P, const int nslab) {
+  const long t4 = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t4 * 4 >= P) return;
+  float4 acc[PCO];
+#pragma unroll
+  for (int o = 0; o < PCO; ++o) {
+    const float b = pb != nullptr ? pb[o] : 0.f;
+    acc[o] = make_float4(b, b, b, b);
+  }
+#pragma unroll 4
+  for (int sl = 0; sl < nslab; ++sl)
+#pragma unroll
+    for (int o = 0; o < PCO; ++o) {
+      const float4 v = *reinterpret_cast<const float4*>(ppart + ((long)sl * PCO + o) * P + t4 * 4);
+      acc[o].x += v.x; acc[o].y += v.y; acc[o].z += v.z; acc[o].w += v.w;
+    }
+  float flat[4 * PCO];                                                                 // [pixel][o]
+#pragma unroll
+  for (int o = 0; o < PCO; ++o) { flat[o] = acc[o].x; flat[PCO + o] = acc[o].y; flat[2 * PCO + o] = acc[o].z; flat[3 * PCO + o] = acc[o].w; }
+  float4* op = reinterpret_cast<float4*>(pout + t4 * 4 * PCO);
+#pragma unroll
+  for (int k = 0; k < PCO; ++k) op[k] = make_float4(flat[4 * k], flat[4 * k + 1], flat[4 * k + 2], flat[4 * k + 3]);
+}
+
 // dw [3][3][Cin][Cout] from dWcat [Cin][9 Cout]; db [Cout] (may be NULL) = the centre tap's column sums of D = sum over all pixels of dy
 __global__ __launch_bounds__(256) void up2proj_wgrad_unpack_kernel(const float* __restrict__ dwcat, const float* __restrict__ db9, float* __restrict__ dw,
                                                                    float* __restrict__ db, const int Cin, const int Cout) {
@@ -1381,7 +1405,7 @@ int ladder_up2proj_bwd_combine_proj(const float* y, const float* dyp, const floa
   switch (pco) { case 1: LADDER_UP2BWD_PROJ(1); break; case 2: LADDER_UP2BWD_PROJ(2); break; case 3: LADDER_UP2BWD_PROJ(3); break; default: LADDER_UP2BWD_PROJ(4); }
 #undef LADDER_UP2BWD_PROJ
   const int kn = C * pco;
-  hipLaunchKernelGGL(up2proj_part_reduce_kernel, dim3((unsigned)((kn + pco + 15) / 16)), dim3(256), 0, stream, (const float*)part, dpw, dpb, (int)blocks, kn, pco);
+  hipLaunchKernelGGL(up2proj_part_reduce_kernel, dim3((unsigned)((kn + pco + 3) / 4)), dim3(256), 0, stream, (const float*)part, dpw, dpb, (int)blocks, kn, pco);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
@@ -1479,8 +1503,15 @@ int ladder_up2proj_fused_fwd(const float* x, const float* wcatT, const float* bi
   if (proj_out != nullptr) {
     if (wres) UF_LAUNCH(true, true); else UF_LAUNCH(true, false);
     const long P = (long)N * 4 * H * W;
-    hipLaunchKernelGGL(up2proj_proj_reduce_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, (const float*)ws, proj_b, proj_out, P, proj_cout,
-                       Cout / UF_CS);
+    if ((P & 3) == 0 && ladder_aligned16(ws) && ladder_aligned16(proj_out)) {
+      const unsigned rb = (unsigned)((P / 4 + 255) / 256);
+#define UF_REDUCE4(C_) hipLaunchKernelGGL(up2proj_proj_reduce4_kernel<C_>, dim3(rb), dim3(256), 0, stream, (const float*)ws, proj_b, proj_out, P, Cout / UF_CS)
+      switch (proj_cout) { case 1: UF_REDUCE4(1); break; case 2: UF_REDUCE4(2); break; case 3: UF_REDUCE4(3); break; default: UF_REDUCE4(4); }
+#undef UF_REDUCE4
+    } else {
+      hipLaunchKernelGGL(up2proj_proj_reduce_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, (const float*)ws, proj_b, proj_out, P, proj_cout,
+                         Cout / UF_CS);
+    }
   } else {
     if (wres) UF_LAUNCH(false, true); else UF_LAUNCH(false, false);
   }
