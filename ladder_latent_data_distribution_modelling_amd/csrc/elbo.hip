@@ -19,6 +19,20 @@ __device__ __forceinline__ double block_sum_256(double v, double* sm /*[4]*/) {
   return (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
+// 1024 threads (16 wavefronts): the same, the wave totals added pairwise in a fixed order.  The single-workgroup latent kernels below sit on the serial
+// chain encoder -> latent -> decoder and are LATENCY-bound (B Z = 8 192 elements: 32 dependent load rounds per thread at 256 threads, 27 us a call, four calls
+// an iteration); four times the threads are four times fewer rounds.
+__device__ __forceinline__ double block_sum_1024(double v, double* sm /*[16]*/) {
+  v = wave_sum_d(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) t[k] = sm[2 * k] + sm[2 * k + 1];
+  return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+}
+
 // ----------------------------------------------------------------------------- pixel terms
 __global__ __launch_bounds__(256) void pixel_partials_stage1(const float* __restrict__ x, const float* __restrict__ xh, size_t n,
                                                              double* __restrict__ ws) {
@@ -75,32 +89,31 @@ __global__ void pixel_grad_kernel(const float* __restrict__ x, const float* __re
 }
 
 // ----------------------------------------------------------------------------- latent blocks (single workgroup: B*Z is tiny)
-__global__ __launch_bounds__(256) void latent_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ sd_raw,
-                                                         const float* __restrict__ eps, float lvp, float* __restrict__ z,
-                                                         float* __restrict__ sd, float* __restrict__ p_log,
-                                                         float* __restrict__ p_mu2sd2, float* __restrict__ p_sdsum, int B, int Z) {
+__global__ __launch_bounds__(1024) void latent_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ sd_raw,
+                                                          const float* __restrict__ eps, float lvp, float* __restrict__ z,
+                                                          float* __restrict__ sd, float* __restrict__ p_log,
+                                                          float* __restrict__ p_mu2sd2, float* __restrict__ p_sdsum, int B, int Z) {
   const int n = B * Z;
   double slog = 0.0, ssq = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) {
+  for (int i = threadIdx.x; i < n; i += 1024) {
     const float s = sd_raw[i] + lvp, m = mu[i];
     sd[i] = s;
     if (z != nullptr) z[i] = m + s * eps[i];
     slog += (double)logf(s);
     ssq += (double)(m * m + s * s);
   }
-  __shared__ double sm[4];
-  const double a = block_sum_256(slog, sm);
-  const double b = block_sum_256(ssq, sm);
+  __shared__ double sm[16];
+  const double a = block_sum_1024(slog, sm);
+  const double b = block_sum_1024(ssq, sm);
   if (threadIdx.x == 0) {
     p_log[0] = (float)a;
     p_mu2sd2[0] = (float)b;
   }
   if (p_sdsum != nullptr) {
-    if (Z <= 256) {
-      // column sums over the batch: G = 256/Z thread groups each take every G-th row (B dependent loads per thread made this tiny
-      // kernel 25 us at B = 256), then a fixed-order combine over the groups
-      __shared__ double col[256];
-      const int G = 256 / Z, j = (int)threadIdx.x % Z, g = (int)threadIdx.x / Z;
+    if (Z <= 1024) {
+      // column sums over the batch: G = 1024 / Z thread groups each take every G-th row, then a fixed-order combine over the groups
+      __shared__ double col[1024];
+      const int G = 1024 / Z, j = (int)threadIdx.x % Z, g = (int)threadIdx.x / Z;
       double s = 0.0;
       if (g < G)
         for (int bb = g; bb < B; bb += G) s += (double)(sd_raw[bb * Z + j] + lvp);
@@ -112,7 +125,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(const float* __restrict
         p_sdsum[j] = (float)t;
       }
     } else {
-      for (int j = threadIdx.x; j < Z; j += 256) {
+      for (int j = threadIdx.x; j < Z; j += 1024) {
         double s = 0.0;
         for (int bb = 0; bb < B; ++bb) s += (double)(sd_raw[bb * Z + j] + lvp);
         p_sdsum[j] = (float)s;
@@ -121,10 +134,10 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(const float* __restrict
   }
 }
 
-__global__ __launch_bounds__(256) void code_partials_kernel(const float* __restrict__ z, const float* __restrict__ zhat,
-                                                            const float* __restrict__ sd_z, int use_mask, float* __restrict__ out, int n) {
+__global__ __launch_bounds__(1024) void code_partials_kernel(const float* __restrict__ z, const float* __restrict__ zhat,
+                                                             const float* __restrict__ sd_z, int use_mask, float* __restrict__ out, int n) {
   double e = 0.0, q = 0.0, a = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) {
+  for (int i = threadIdx.x; i < n; i += 1024) {
     const float d = z[i] - zhat[i];
     float err = d * d;
     if (use_mask && sd_z[i] > 1.f) err = 0.f;
@@ -132,8 +145,8 @@ __global__ __launch_bounds__(256) void code_partials_kernel(const float* __restr
     q += (double)sqrtf(err);
     a += (double)fabsf(d);
   }
-  __shared__ double sm[4];
-  const double te = block_sum_256(e, sm), tq = block_sum_256(q, sm), ta = block_sum_256(a, sm);
+  __shared__ double sm[16];
+  const double te = block_sum_1024(e, sm), tq = block_sum_1024(q, sm), ta = block_sum_1024(a, sm);
   if (threadIdx.x == 0) {
     out[0] = (float)te;
     out[1] = (float)tq;
@@ -904,7 +917,7 @@ int ladder_pixel_grad(const float* x, const float* xhat, const float* coef, floa
 int ladder_latent_fwd(const float* mu, const float* sd_raw, const float* eps, float lvp, float* z, float* sd, float* p_log,
                       float* p_mu2sd2, float* p_sdsum, int B, int Z, ladder_stream_t stream) {
   if (B <= 0 || Z <= 0) return LADDER_E_SHAPE;
-  hipLaunchKernelGGL(latent_fwd_kernel, dim3(1), dim3(256), 0, stream, mu, sd_raw, eps, lvp, z, sd, p_log, p_mu2sd2, p_sdsum, B, Z);
+  hipLaunchKernelGGL(latent_fwd_kernel, dim3(1), dim3(1024), 0, stream, mu, sd_raw, eps, lvp, z, sd, p_log, p_mu2sd2, p_sdsum, B, Z);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
@@ -912,7 +925,7 @@ int ladder_latent_fwd(const float* mu, const float* sd_raw, const float* eps, fl
 int ladder_code_partials(const float* z, const float* zhat, const float* sd_z, int use_mask, float* out, int B, int Z,
                          ladder_stream_t stream) {
   if (B <= 0 || Z <= 0) return LADDER_E_SHAPE;
-  hipLaunchKernelGGL(code_partials_kernel, dim3(1), dim3(256), 0, stream, z, zhat, sd_z, use_mask, out, B * Z);
+  hipLaunchKernelGGL(code_partials_kernel, dim3(1), dim3(1024), 0, stream, z, zhat, sd_z, use_mask, out, B * Z);
   LADDER_CHECK_LAUNCH();
   return LADDER_OK;
 }
