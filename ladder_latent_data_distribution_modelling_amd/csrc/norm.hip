@@ -368,6 +368,44 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   }
   if (yamax != nullptr) amax_commit_block(ymax, yamax);     // max|y| for the split contraction that consumes y
 }
+// ... with the finalisation INSIDE (strict fp32, no absmax record): a thread derives the mean / 1 / sd of its four channels from the fp64 record itself -- the
+// expressions of bn_finalize_kernel, so the values are the same bits -- and workgroup 0 writes mean_rstd for the backward pass.  One launch less per batch
+// norm (a 5 us kernel + its gap on the serial chain, twelve times an iteration).  Host side: only when the stride is a multiple of C.
+__global__ __launch_bounds__(256) void bn_apply_fin_kernel(const float* __restrict__ x, const float* __restrict__ sums, const double count, const float eps,
+                                                           float* __restrict__ mean_rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ y, size_t n, int C, int act) {
+  const double* s64 = reinterpret_cast<const double*>(sums);      // the fp64 record: sum | sum of squares
+  auto coef = [&](const int c, float& mu, float& rs) __attribute__((always_inline)) {
+    const double mean = s64[c] / count;
+    double var = s64[C + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mu = (float)mean;
+    rs = (float)(1.0 / sqrt(var + (double)eps));
+  };
+  if (blockIdx.x == 0)
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float mu, rs;
+      coef(c, mu, rs);
+      mean_rstd[c] = mu;
+      mean_rstd[C + c] = rs;
+    }
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = (int)((i0 * 4) % C);
+  float mu[4], rs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) coef(c + j, mu[j], rs[j]);
+  const float4 g = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+  for (size_t i = i0; i < n / 4; i += stride) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    float4 o;
+    o.x = ladder_act_fn(g.x * ((v.x - mu[0]) * rs[0]) + be.x, act);
+    o.y = ladder_act_fn(g.y * ((v.y - mu[1]) * rs[1]) + be.y, act);
+    o.z = ladder_act_fn(g.z * ((v.z - mu[2]) * rs[2]) + be.z, act);
+    o.w = ladder_act_fn(g.w * ((v.w - mu[3]) * rs[3]) + be.w, act);
+    reinterpret_cast<float4*>(y)[i] = o;
+  }
+}
 __global__ void bn_apply_scalar_kernel(const float* __restrict__ x, const float* __restrict__ mean_rstd,
                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                        float* __restrict__ y, size_t n, int C, int act) {
@@ -462,7 +500,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
                                                               const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ dsums,
                                                               float inv_count, float* __restrict__ dx, size_t n, int C, int act,
-                                                              float* __restrict__ dxamax) {
+                                                              float* __restrict__ dxamax, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  if (dgamma != nullptr && blockIdx.x == 0)                       // (the parameter gradients ARE the reduced sums: no launch of their own)
+    for (int c = threadIdx.x; c < C; c += 256) {
+      dbeta[c] = dsums[c];
+      dgamma[c] = dsums[C + c];
+    }
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool fixed = ((stride * 4) % (size_t)C) == 0;
@@ -1122,9 +1165,16 @@ int ladder_bn_fwd_apply_absmax(const float* x, const float* sums, double count, 
   if (y_absmax != nullptr) {                     // the record is produced by the vectorised kernel only
     if (!(C % 4 == 0 && ladder_aligned16(x) && ladder_aligned16(y))) return LADDER_E_SHAPE;
   }
+  const size_t n = rows * (size_t)C;
+  static const bool fold = getenv("LADDER_DISABLE_BN_FOLD") == nullptr;      // (A / B switch: the finalisation as a launch of its own)
+  if (fold && y_absmax == nullptr && C % 4 == 0 && ladder_aligned16(x) && ladder_aligned16(y) && ladder_aligned16(gamma) && ladder_aligned16(beta) &&
+      ((size_t)ew_grid(n / 4) * 256 * 4) % (size_t)C == 0) {
+    hipLaunchKernelGGL(bn_apply_fin_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, stream, x, sums, count, eps, mean_rstd, gamma, beta, y, n, C, act);
+    LADDER_CHECK_LAUNCH();
+    return LADDER_OK;
+  }
   // (the finalize kernel clears the record: no separate memset launch)
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sums, count, eps, mean_rstd, C, y_absmax);
-  const size_t n = rows * (size_t)C;
   if (C % 4 == 0 && ladder_aligned16(x) && ladder_aligned16(y))
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, stream, x, mean_rstd, gamma, beta, y, n, C, act, y_absmax);
   else
@@ -1204,14 +1254,17 @@ int ladder_bn_bwd_apply_absmax(const float* dy, const float* x, const float* mea
   }
   // the parameter-gradient kernel runs first and clears the record on its way (no memset launch); without parameter gradients: memset
   const bool pgrad = dgamma != nullptr && dbeta != nullptr;
-  if (pgrad)
+  const bool v4 = dx != nullptr && C % 4 == 0 && ladder_aligned16(x) && ladder_aligned16(dy) && ladder_aligned16(dx);
+  static const bool fold = getenv("LADDER_DISABLE_BN_FOLD") == nullptr;
+  const bool pgrad_rides = fold && pgrad && v4 && dx_absmax == nullptr;   // strict fp32: workgroup 0 of the apply kernel copies them
+  if (pgrad && !pgrad_rides)
     hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, dsums, dgamma, dbeta, C, dx_absmax);
-  else if (dx_absmax != nullptr && hipMemsetAsync(dx_absmax, 0, LADDER_ABSMAX_FLOATS * sizeof(float), stream) != hipSuccess)
+  else if (!pgrad && dx_absmax != nullptr && hipMemsetAsync(dx_absmax, 0, LADDER_ABSMAX_FLOATS * sizeof(float), stream) != hipSuccess)
     return LADDER_E_LAUNCH;
   if (dx != nullptr) {
-    if (C % 4 == 0 && ladder_aligned16(x) && ladder_aligned16(dy) && ladder_aligned16(dx))
+    if (v4)
       hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, stream, dy, x, mean_rstd, gamma, beta, dsums,
-                         (float)(1.0 / count), dx, n, C, act, dx_absmax);
+                         (float)(1.0 / count), dx, n, C, act, dx_absmax, pgrad_rides ? dgamma : (float*)nullptr, pgrad_rides ? dbeta : (float*)nullptr);
     else
       hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, dy, x, mean_rstd, gamma, beta, dsums,
                          (float)(1.0 / count), dx, n, C, act);
